@@ -1,0 +1,277 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by running the upstream reference IN THIS CONTAINER ONLY.
+
+Usage:  python tests/golden/make_golden.py [--traj]          (needs /root/reference; CPU; ~1 min, --traj ~10 min)
+
+What this is: test infrastructure.  It imports the reference implementation from
+/root/reference (never copied into this repo, never shipped to the GPU box) and
+records inputs/outputs of its hot path as small .npz fixtures under tests/golden/.
+Those fixtures pin the oracle (oracle/refspec.py) and, through it, the HIP path.
+
+Two harness-level shims are needed to import the reference on this software stack
+(SURVEY.md Appendix C):
+  1. `torchdiffeq` (requirements.txt:7, imported at src/model.py:8) is a third-party
+     dependency that is not installed and not vendored under /root/reference.  A
+     stand-in package is written to a temp dir: fixed grid == requested t, t cast to
+     y0's dtype, euler / midpoint / 3/8-rule rk4.  Because the stepper arithmetic
+     lives in that third-party package, fixtures that depend on it pin everything
+     EXCEPT the stepper definition itself ("parity unpinned" for the stepper; see
+     DESIGN.md §Oracle).
+  2. src/loss.py:69 calls np.sum on a list of grad-requiring tensors, which raises on
+     numpy>=2; the name `np` inside the loaded src.loss module is replaced by an
+     object whose `sum` is Python's builtin sum.  With b == 0 (all shipped PDEs) the
+     term is exactly zero either way.
+
+The sequence of calls inside `one_iteration` follows NODE_WAN_solver.train
+(src/training.py:118-162) for the first outer iteration; sub-steps after the first
+use `.clone()`d sample tensors, which is what `.to(device)` produces on a GPU
+(src/dataset.py:321), i.e. the semantics the HIP engine implements.
+"""
+import argparse
+import builtins
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = '/root/reference'
+
+_TORCHDIFFEQ_STANDIN = '''
+import torch
+def _incr(method, f, t, dt, y):
+    if method == 'euler':
+        return dt * f(t, y)
+    if method == 'midpoint':
+        return dt * f(t + dt / 2, y + f(t, y) * dt / 2)
+    if method == 'rk4':
+        k1 = f(t, y)
+        k2 = f(t + dt / 3, y + dt * k1 / 3)
+        k3 = f(t + 2 * dt / 3, y + dt * (k2 - k1 / 3))
+        k4 = f(t + dt, y + dt * (k1 - k2 + k3))
+        return dt * (k1 + 3 * (k2 + k3) + k4) / 8
+    raise ValueError(method)
+def odeint(func, y0, t, method='midpoint', **unused):
+    t = t.type_as(y0)
+    out = [y0]
+    y = y0
+    for t0, t1 in zip(t[:-1], t[1:]):
+        y = y + _incr(method, func, t0, t1 - t0, y)
+        out.append(y)
+    return torch.stack(out, 0)
+odeint_adjoint = odeint
+'''
+
+
+def load_reference():
+    shim = tempfile.mkdtemp(prefix='tdq_standin_')
+    os.makedirs(os.path.join(shim, 'torchdiffeq'))
+    with open(os.path.join(shim, 'torchdiffeq', '__init__.py'), 'w') as fh:
+        fh.write(_TORCHDIFFEQ_STANDIN)
+    sys.path.insert(0, shim)
+    sys.path.insert(1, REF)
+    import matplotlib
+    matplotlib.use('Agg')
+    import src  # noqa: F401  (runs the reference's src/__init__.py)
+
+    class _NP:
+        sum = staticmethod(builtins.sum)
+    sys.modules['src.loss'].np = _NP
+    import importlib
+    funcs = importlib.import_module('configs.Ex4_1_funcs')
+    return sys.modules['src.training'], sys.modules['src.dataset'], sys.modules['src.loss'], funcs
+
+
+def make_params(d, N_r, N_b, N_t, solver='midpoint', iterations=1, alpha=100000000):
+    # YAML key order (configs/cube_pde.yaml:2-23): 13 config, 7 setup, iterations, domain
+    return {
+        'alpha': alpha, 'u_layers': 8, 'u_hidden_dim': 20, 'u_hidden_hidden_dim': 10,
+        'v_layers': 9, 'v_hidden_dim': 50, 'n1': 2, 'n2': 1, 'u_rate': 0.015, 'v_rate': 0.04,
+        'min_steps': 5, 'adjoint': False, 'solver': solver,
+        'dim': d, 'N_t': N_t, 'N_r': N_r, 'N_b': N_b, 'T0': 0, 'T': 1, 'shape_param': [-1, 1],
+        'iterations': iterations, 'domain': 'Hypercube',
+    }
+
+
+def npy(t):
+    return t.detach().cpu().numpy().copy()
+
+
+def one_iteration(case, d, N_r, N_b, N_t, seed, solver_name, full_tensors):
+    training, dataset, lossmod, F = load_reference()
+    params = make_params(d, N_r, N_b, N_t, solver_name)
+    dev = torch.device('cpu')
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    S = training.NODE_WAN_solver(params, F.func_a, F.func_b, F.func_c, F.func_h, F.func_f, F.func_g, dev, './',
+                                 func_u_sol=F.func_u_sol, p=2)
+    out = {'params_json': np.array(json.dumps(params)), 'seed': np.array(seed)}
+    # initial parameters: unique tensors by canonical name + the full state_dict key list with its aliasing
+    # (tied layers appear under several keys, src/model.py:38,127-131; `module.` prefix from DataParallel)
+    for tag, net in (('u', S.u_net), ('v', S.v_net)):
+        canon = {}
+        for n, p_ in net.named_parameters():
+            out[tag + '_sd/' + n] = npy(p_)
+            canon[p_.data_ptr()] = n
+        sd = net.state_dict()
+        out[tag + '_sd_keys'] = np.array(list(sd.keys()))
+        out[tag + '_sd_alias_of'] = np.array([canon[v.data_ptr()] for v in sd.values()])
+        out[tag + '_param_names'] = np.array([n for n, _ in net.named_parameters()])
+
+    domain = S.domain(S.setup['shape_param'], d, S.setup['T0'], S.setup['T'], N_t)
+    points = dataset.Comb_loader(N_r, N_b, domain, dev)
+    out['times'] = npy(domain.times)
+    out['x_u'] = npy(points.interioru[:, 0, 1:])
+    out['x_v'] = npy(points.interiorv[:, 0, 1:])
+    out['x_b'] = npy(points.boundary[:, 0, 1:])
+    if full_tensors:
+        out['X'] = npy(points.interioru)
+        out['XV'] = npy(points.interiorv)
+        out['BX'] = npy(points.boundary)
+    out['V'] = np.array(float(domain.V()))
+    out['w_v'] = npy(domain.func_w(points.interiorv))
+    out['L2_start'] = np.array(training.L_norm(points.interioru, S.u_net, S.p, S.func_u_sol, domain.V(), N_r).item())
+    out['rel_start'] = np.array(training.rel_err(points.interioru, S.u_net, S.func_u_sol, S.p, domain.V(), N_r).item())
+
+    def net_step(tag, which, datau, datav, bdata, opt):
+        """one optimiser sub-step exactly as in src/training.py:127-138 / :152-162"""
+        opt.zero_grad()
+        pv = S.v_net(datav)
+        pu = S.u_net(datau)
+        h, f, g, a, b, c = training.func_eval(datau.clone().detach(), bdata.clone().detach(), S.setup, pu,
+                                              F.func_a, F.func_b, F.func_c, F.func_h, F.func_f, F.func_g)
+        Lo = lossmod.loss(S.config['alpha'], a, b, c, h, f, g, S.setup, domain, dev)
+        # side-effect-free views of what loss.I reads from X.grad / XV.grad (src/loss.py:55-63)
+        G = torch.autograd.grad(pu.sum(), datau, retain_graph=True)[0]
+        w = domain.func_w(datav).unsqueeze(2)
+        dphi = torch.autograd.grad((pv * w).sum(), datav, retain_graph=True)[0]
+        out[tag + '/u'] = npy(pu.squeeze(2))
+        out[tag + '/v'] = npy(pv.squeeze(2))
+        out[tag + '/h'] = npy(h)
+        out[tag + '/f'] = npy(f)
+        out[tag + '/g'] = npy(g)
+        out[tag + '/Xgrad_l0'] = npy(G[:, 0, :])
+        out[tag + '/Xgrad_rest_absmax_x'] = np.array(float(G[:, 1:, 1:].abs().max()) if N_t > 1 else 0.0)
+        out[tag + '/Xgrad_t_path0'] = npy(G[0, :, 0])
+        out[tag + '/dphi'] = npy(dphi)
+        if which == 'u':
+            ub = S.u_net(bdata)
+            out[tag + '/u_b'] = npy(ub.squeeze(2))
+            out[tag + '/init'] = np.array(Lo.init(pu).item())
+            out[tag + '/bdry'] = np.array(Lo.bdry(S.u_net, bdata).item())
+            L = Lo.u(pu, pv, S.u_net, datau, datav, bdata)
+        else:
+            L = Lo.v(pu, pv, datau, datav)
+        out[tag + '/loss'] = np.array(L.item())
+        # I and int recomputed on a throw-away loss object would disturb .grad; derive from the loss value instead
+        L.backward(retain_graph=True)
+        net = S.u_net if which == 'u' else S.v_net
+        for n, p in net.named_parameters():
+            out[tag + '/grad/' + n] = npy(p.grad)
+        opt.step()
+        for n, p in net.named_parameters():
+            out[tag + '/after/' + n] = npy(p)
+
+    # sub-step 1 of the generator: the loader's own leaves (identical on CPU and GPU semantics)
+    datau, datav, bdata = points[0]
+    net_step('gen1', 'u', datau, datav, bdata, S.optimizer_u)
+    # a separate evaluation of I/int for gen1, on clones so that no .grad state is shared
+    fresh = lambda t: t.detach().clone().requires_grad_(True)  # noqa: E731
+    # sub-step 2 and the discriminator step with GPU loader semantics (fresh differentiable copies per pass)
+    datau2, datav2, bdata2 = fresh(points.interioru), fresh(points.interiorv), fresh(points.boundary)
+    net_step('gen2', 'u', datau2, datav2, bdata2, S.optimizer_u)
+    datau3, datav3, bdata3 = fresh(points.interioru), fresh(points.interiorv), fresh(points.boundary)
+    net_step('disc1', 'v', datau3, datav3, bdata3, S.optimizer_v)
+
+    # stand-alone I / int at the final parameters (pins src/loss.py:46-76,87-90 values)
+    X4, XV4, B4 = fresh(points.interioru), fresh(points.interiorv), fresh(points.boundary)
+    pv = S.v_net(XV4)
+    pu = S.u_net(X4)
+    h, f, g, a, b, c = training.func_eval(X4.clone().detach(), B4.clone().detach(), S.setup, pu,
+                                          F.func_a, F.func_b, F.func_c, F.func_h, F.func_f, F.func_g)
+    Lo = lossmod.loss(S.config['alpha'], a, b, c, h, f, g, S.setup, domain, dev)
+    out['final/I'] = np.array(Lo.I(pu, pv, X4, XV4).item())
+    X5, XV5 = fresh(points.interioru), fresh(points.interiorv)
+    pv = S.v_net(XV5)
+    pu = S.u_net(X5)
+    c = F.func_c(X5.clone().detach(), pu)
+    Lo = lossmod.loss(S.config['alpha'], a, b, c, h, f, g, S.setup, domain, dev)
+    out['final/int'] = np.array(Lo.int(pu, pv, X5, XV5).item())
+    out['final/u'] = npy(pu.squeeze(2))
+    out['final/v'] = npy(pv.squeeze(2))
+
+    # second sample of the iteration + diagnostic (src/training.py:166-167) pins the RNG stream position
+    points2 = dataset.Comb_loader(N_r, N_b, domain, dev)
+    out['x_u_second'] = npy(points2.interioru[:, 0, 1:])
+    out['L2_end'] = np.array(training.L_norm(points2.interioru, S.u_net, S.p, S.func_u_sol, domain.V(), N_r).item())
+    path = os.path.join(HERE, case + '.npz')
+    np.savez_compressed(path, **out)
+    print('wrote', path, '%.1f KB' % (os.path.getsize(path) / 1024))
+
+
+def trajectory(case, d, N_r, N_b, N_t, seed, outer_iters, gpu_loader_semantics):
+    """rel-L2 at every generator sub-step through the reference's own train() loop (stop hook = logging point)."""
+    training, dataset, lossmod, F = load_reference()
+    params = make_params(d, N_r, N_b, N_t, 'midpoint', iterations=outer_iters)
+    if gpu_loader_semantics:
+        orig = dataset.Comb_loader.__getitem__
+
+        def getitem(self, idx):
+            r = orig(self, idx)
+            return tuple(t.clone() for t in r)
+        dataset.Comb_loader.__getitem__ = getitem
+    log, losses = [], []
+
+    def hook(self, pts, domain):
+        with torch.no_grad():
+            log.append(training.rel_err(pts, self.u_net, self.func_u_sol, self.p, domain.V(), self.params['N_r']).item())
+        losses.append(self.av_l)
+        return False
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    cwd = os.getcwd()
+    scratch = tempfile.mkdtemp(prefix='ref_traj_')
+    os.chdir(scratch)
+    try:
+        S = training.NODE_WAN_solver(params, F.func_a, F.func_b, F.func_c, F.func_h, F.func_f, F.func_g,
+                                     torch.device('cpu'), './', func_u_sol=F.func_u_sol, p=2, stop=hook)
+        t0 = time.time()
+        S.train(report=False)
+        wall = time.time() - t0
+        # fixed probe set for the trained u
+        g = torch.Generator().manual_seed(12345)
+        xp = torch.rand(64, 1, d, generator=g) * 2 - 1
+        tp = torch.linspace(0, 1, N_t).view(1, N_t, 1).repeat(64, 1, 1)
+        probe = torch.cat((tp, xp.repeat(1, N_t, 1)), 2)
+        with torch.no_grad():
+            up = S.u_net(probe).squeeze(2)
+    finally:
+        os.chdir(cwd)
+        if gpu_loader_semantics:
+            dataset.Comb_loader.__getitem__ = orig
+    path = os.path.join(HERE, case + '.npz')
+    np.savez_compressed(path, rel_l2=np.array(log), gen_loss=np.array(losses), wall_s=np.array(wall),
+                        params_json=np.array(json.dumps(params)), seed=np.array(seed),
+                        probe_x=npy(xp[:, 0, :]), probe_t=npy(tp[0, :, 0]), probe_u=npy(up))
+    print('wrote', path, 'steps', len(log), 'wall %.1fs' % wall, 'final rel-L2', log[-1])
+
+
+if __name__ == '__main__':
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--traj', action='store_true', help='also produce the 800-step trajectory fixtures (slow)')
+    ap.add_argument('--only-traj', action='store_true')
+    args = ap.parse_args()
+    torch.set_num_threads(4)
+    if not args.only_traj:
+        one_iteration('ref_tiny_midpoint', 3, 8, 12, 6, 7, 'midpoint', True)
+        one_iteration('ref_tiny_euler', 3, 8, 12, 6, 7, 'euler', True)
+        one_iteration('ref_tiny_rk4', 3, 8, 12, 6, 7, 'rk4', True)
+        one_iteration('ref_plumb_midpoint', 5, 256, 64, 16, 0, 'midpoint', False)
+        one_iteration('ref_d20_small_midpoint', 20, 96, 80, 12, 3, 'midpoint', False)
+    if args.traj or args.only_traj:
+        trajectory('ref_traj_plumb_seed0_gpusem', 5, 256, 64, 16, 0, 400, True)
+        trajectory('ref_traj_plumb_seed0_cpusem', 5, 256, 64, 16, 0, 400, False)
