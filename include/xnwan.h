@@ -1,0 +1,107 @@
+/* xnwan.h -- C ABI of libxnwan.so, the MI355X (gfx950) XNODE-WAN hot-path library.
+ *
+ * Every entry point replaces a piece of the reference's Python/ATen hot path (file:line are into
+ * paulvoliva/XNODE-WAN-PDE-solver @ v1).  The reference has no FFI of its own: these are the calls a
+ * maintainer would bind (ctypes stub in INTEGRATION.md) from src/model.py, src/loss.py and src/training.py.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers to contiguous arrays owned by the caller; nothing is allocated inside
+ *   - `stream` is a hipStream_t passed as void*; every call only enqueues work on it (graph-capture safe)
+ *   - return value: 0 = ok, negative = argument/shape error (XW_E_*), positive = hipError_t of the launch
+ *   - per-point arrays are TIME-MAJOR: a[l*N + n] for time index l and path n   ("[L,N]")
+ *   - sample coordinates are passed transposed: xT[i*N + n] = x_n[i] (float32, "[d,N]"); time grid t[L] float32
+ *   - theta / phi are the parameter blobs of u_theta / v_phi in named_parameters() order (float64):
+ *       theta: IL0.w[H,1] IL0.b[H] IL2.w[H,H] IL2.b[H] IL4.w[H,H] IL4.b[H]            (src/model.py:78)
+ *              Win[K,d+1+H] (columns: x(d) | t | y(H)) Win.b[K] Wh[K,K] Wh.b[K] Wo[H,K] Wo.b[H]   (:130-138)
+ *              FL.w[1,H] FL.b[1]                                                      (:85)
+ *       phi:   Vin[W,d+1] (columns: t | x(d)) Vin.b[W] Vh[W,W] Vh.b[W] Vo[1,W] Vo.b[1]    (:34-36)
+ *   - method: 0 = euler, 1 = midpoint, 2 = rk4 (3/8 rule)  -- fixed grid == the sample times (src/model.py:103-106)
+ */
+#ifndef XNWAN_H
+#define XNWAN_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define XW_E_DIMS     (-1) /* (H,K) or W not among the compiled instantiations */
+#define XW_E_ARG      (-2) /* null pointer / non-positive size / bad enum */
+#define XW_E_WORKSPACE (-3) /* workspace too small */
+
+/* library identification; also lets the host check that the .so it loaded is this ABI */
+int xw_abi_version(void);
+/* writes the supported (H,K) pairs and W values as a NUL-terminated string into buf */
+int xw_supported_dims(char* buf, int buflen);
+
+/* sizes of the parameter blobs (doubles) */
+int xw_theta_size(int d, int H, int K);
+int xw_phi_size(int d, int W);
+
+/* ---- u_theta: NeuralODE.forward for a group of N equal-length paths (src/model.py:87-112,140-156) -------------
+ * start[N]: the scalar initial value h(x_n) or g(t_0,x_n) (src/model.py:95-96).
+ * u[L,N] out; Y[L,H,N] out (hidden state at every sample time; needed by xw_ode_bwd), may be NULL. */
+int xw_ode_fwd(const float* xT, const float* t, const double* start, const double* theta,
+               int method, int N, int L, int d, int H, int K, int m,
+               double* u, double* Y, void* stream);
+
+/* number of partial-gradient slabs xw_ode_bwd writes for N paths, and doubles of workspace it needs */
+int xw_ode_bwd_slabs(int N);
+
+/* Reverse sweep through the discrete stepper (autograd replacement for src/loss.py:55 and src/training.py:137).
+ * ubar[L,N]: cotangent on u (NULL = all ones).
+ * mode bit 0: produce gx[d,N] = d<ubar,u>/dx_n  and gs[N] = d<ubar,u>/d start_n     (nabla_x u of src/loss.py:56-58)
+ * mode bit 1: produce parameter-gradient slabs gslab[xw_ode_bwd_slabs(N)][P_u] (to be summed by xw_adam / xw_slab_sum) */
+int xw_ode_bwd(const float* xT, const float* t, const double* start, const double* theta, const double* Y,
+               const double* ubar, int method, int N, int L, int d, int H, int K, int m, int mode,
+               double* gx, double* gs, double* gslab, void* stream);
+
+/* ---- v_phi: discriminator.forward (src/model.py:37-47) + d/dt by forward-mode ------------------------------------
+ * Path mode (tpp == NULL): point (l,n) = (t[l], x_n).  Point mode (tpp != NULL): L must be 1, point n = (tpp[n], x_n).
+ * v[L,N] out; vt[L,N] out = dv/dt (may be NULL); act out (may be NULL) = activation stash [(q+1)][W][L*N]
+ * needed by xw_disc_bwd (post-ReLU hidden activations r_0..r_{q-1}, then tanh output). */
+int xw_disc_fwd(const float* xT, const float* t, const float* tpp, const double* phi,
+                int N, int L, int d, int W, int q, double* v, double* vt, double* act, void* stream);
+
+/* nabla_x v at a set of points (reverse mode, no parameter gradients): gxv[d,N] and gtv[N] (d/dt), for the
+ * N points (t_n, x_n) with t_n = tpp ? tpp[n] : t[0].   (XV.grad of src/loss.py:60-63 restricted to what I reads) */
+int xw_disc_gradx(const float* xT, const float* t, const float* tpp, const double* phi,
+                  int N, int d, int W, int q, double* gxv, double* gtv, void* stream);
+
+int xw_disc_bwd_slabs(int N, int L);
+/* parameter gradient of <vbar, v>: slabs gslab[xw_disc_bwd_slabs][P_v]; optional input gradient is not produced here */
+int xw_disc_bwd(const float* xT, const float* t, const float* tpp, const double* phi, const double* act,
+                const double* vbar, int N, int L, int d, int W, int q, double* gslab, void* stream);
+
+/* ---- weak functional and cotangents (src/loss.py:46-96) -----------------------------------------------------------
+ * scal[16] (device, float64): 0 I   1 S=sum v^2   2 SSE_init   3 SSE_bdry   4 loss_u   5 loss_v   6 int   (rest reserved)
+ * xw_weak_partials ADDS this rank's partial sums into scal[0..2] (zero scal first; all-reduce scal[0..3] across ranks).
+ *   w: distance-to-boundary weight, per path (w_per_point=0, [N]) or per point ([L,N]);  wt: d w/dt [L,N] or NULL (=0)
+ *   s3x[N]: the l=0 gradient-contraction term  sum_ij a_ij d_i phi d_j u + sum_i b_i phi d_i u  (src/loss.py:66-69)
+ *   c, cp: c(u,t,x) and dc/du, [L,N]; both NULL means c = ckappa * u           f[L,N]; h[N]
+ *   Vol = domain volume; Nglob = global number of interior paths (the 1/N, 1/(N L) factors of src/loss.py:64-71) */
+int xw_weak_partials(const double* u, const double* v, const double* vt, const double* w, int w_per_point,
+                     const double* wt, const double* s3x, const double* c, double ckappa, const double* f,
+                     const double* h, int N, int L, double Vol, double Nglob, double* scal, void* stream);
+/* boundary penalty partial: scal[3] += sum (u_b - g)^2 ; ubar_b = alpha * 2 (u_b - g) / (Nbglob * L) */
+int xw_bdry_partials(const double* ub, const double* g, int Nb, int L, double alpha, double Nbglob,
+                     double* ubar_b, double* scal, void* stream);
+/* generator cotangent on u (loss_u of src/loss.py:93 + the pollution of :55), also writes scal[4], scal[6] */
+int xw_gen_cotangent(const double* u, const double* v, const double* w, int w_per_point, const double* c,
+                     const double* cp, double ckappa, const double* h, int N, int L, double Vol, double Nglob,
+                     double Nbglob, double alpha, double pollution, const double* scal_in, double* ubar,
+                     double* scal_out, void* stream);
+/* discriminator cotangent on v (loss_v of src/loss.py:96 + the pollution of :60), also writes scal[5], scal[6] */
+int xw_disc_cotangent(const double* u, const double* v, const double* w, int w_per_point, const double* c,
+                      double ckappa, const double* f, const double* h, int N, int L, double Vol, double Nglob,
+                      double pollution, const double* scal_in, double* vbar, double* scal_out, void* stream);
+
+/* ---- optimiser (torch.optim.Adam defaults, src/training.py:103-104) ------------------------------------------------
+ * grad = sum over nslab slabs of gslab[s][P] (+ gextra[P] if not NULL); state: m[P], v[P], step (device int64, incremented) */
+int xw_adam(double* param, const double* gslab, int nslab, const double* gextra, double* m, double* v,
+            long long* step, int P, double lr, double beta1, double beta2, double eps, double* gsum_out, void* stream);
+/* plain slab reduction: out[P] = (accumulate ? out : 0) + sum_s gslab[s][P] */
+int xw_slab_sum(const double* gslab, int nslab, int P, int accumulate, double* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,210 @@
+"""Parity of every HIP kernel (called through the C ABI) against the oracle on the same seeded inputs.
+
+Run on the GPU box:  python -m pytest tests -m gpu -x -q
+Tolerances: everything is float64 on both sides; the only differences are summation order and tanh()'s last bits,
+so values agree to ~1e-12 relative to their scale and gradients to ~1e-10.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+H, K, W, Q = 20, 10, 50, 9
+
+
+def _cfg(m=8, solver='midpoint'):
+    return {'alpha': 1e8, 'u_layers': m, 'u_hidden_dim': H, 'u_hidden_hidden_dim': K, 'v_layers': Q, 'v_hidden_dim': W,
+            'n1': 2, 'n2': 1, 'u_rate': 0.015, 'v_rate': 0.04, 'min_steps': 5, 'adjoint': False, 'solver': solver}
+
+
+def _setup(d, L):
+    return {'dim': d, 'N_t': L, 'N_r': 1, 'N_b': 1, 'T0': 0, 'T': 1, 'shape_param': [-1, 1]}
+
+
+def _params(d, m, seed):
+    from oracle import refspec as R
+    torch.manual_seed(seed)
+    theta, phi = R.init_parameters(_cfg(m), _setup(d, 2))
+    # non-zero biases so that every bias path is exercised
+    for p in list(theta.values()) + list(phi.values()):
+        if p.dim() == 1:
+            p.copy_(0.3 * torch.randn_like(p))
+    return theta, phi
+
+
+def _blob(p, order):
+    return torch.cat([p[k].reshape(-1) for k in order]).cuda()
+
+
+U_ORDER = ['IL0_w', 'IL0_b', 'IL2_w', 'IL2_b', 'IL4_w', 'IL4_b', 'Win', 'Win_b', 'Wh', 'Wh_b', 'Wo', 'Wo_b', 'FL_w', 'FL_b']
+V_ORDER = ['Vin', 'Vin_b', 'Vh', 'Vh_b', 'Vo', 'Vo_b']
+
+
+def _sample(N, L, d, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = (torch.rand(N, d, generator=g) * 2 - 1).float()
+    t, _ = torch.sort(torch.rand(L, generator=g).float())
+    t[0], t[-1] = 0.0, 1.0
+    X = torch.cat((t.view(1, L, 1).expand(N, L, 1), x.view(N, 1, d).expand(N, L, d)), 2).contiguous()
+    return x, t, X
+
+
+def _close(a, b, tol, what):
+    a = a.detach().cpu().double()
+    b = b.detach().cpu().double()
+    scale = max(float(b.abs().max()), 1e-300)
+    err = float((a - b).abs().max()) / scale
+    assert err < tol, '%s: max rel-to-scale error %.3e (scale %.3e)' % (what, err, scale)
+
+
+CASES = [(37, 7, 5), (64, 6, 20), (16, 2, 3)]
+
+
+@pytest.mark.parametrize('solver', ['euler', 'midpoint', 'rk4'])
+@pytest.mark.parametrize('N,L,d', CASES)
+def test_ode_forward(N, L, d, solver):
+    from oracle import refspec as R
+    from xnode_wan_pde_solver_amd import kernels as KN
+    theta, _ = _params(d, 8, 1)
+    x, t, X = _sample(N, L, d, 2)
+    start = torch.randn(N, dtype=torch.float64, generator=torch.Generator().manual_seed(3))
+    u_ref = R.u_net(theta, _cfg(8, solver), X, start)
+    u, Y = KN.ode_fwd(x.t().contiguous().cuda(), t.cuda(), start.cuda(), _blob(theta, U_ORDER), KN.method_id(solver), H, K, 8)
+    _close(u.t(), u_ref, 1e-12, 'u')
+    assert Y.shape == (L, H, N)
+
+
+@pytest.mark.parametrize('m', [8, 4, 2])
+def test_ode_forward_depths(m):
+    from oracle import refspec as R
+    from xnode_wan_pde_solver_amd import kernels as KN
+    N, L, d = 33, 5, 4
+    theta, _ = _params(d, m, 5)
+    x, t, X = _sample(N, L, d, 6)
+    start = torch.randn(N, dtype=torch.float64, generator=torch.Generator().manual_seed(7))
+    u_ref = R.u_net(theta, _cfg(m), X, start)
+    u, _ = KN.ode_fwd(x.t().contiguous().cuda(), t.cuda(), start.cuda(), _blob(theta, U_ORDER), 1, H, K, m)
+    _close(u.t(), u_ref, 1e-12, 'u')
+
+
+@pytest.mark.parametrize('solver', ['euler', 'midpoint', 'rk4'])
+@pytest.mark.parametrize('N,L,d', CASES)
+@pytest.mark.parametrize('ones', [False, True])
+def test_ode_backward(N, L, d, solver, ones):
+    from oracle import refspec as R
+    from xnode_wan_pde_solver_amd import kernels as KN
+    theta, _ = _params(d, 8, 11)
+    th = {k: v.clone().requires_grad_(True) for k, v in theta.items()}
+    x, t, X = _sample(N, L, d, 12)
+    g = torch.Generator().manual_seed(13)
+    start = torch.randn(N, dtype=torch.float64, generator=g).requires_grad_(True)
+    ubar = torch.ones(N, L, dtype=torch.float64) if ones else torch.randn(N, L, dtype=torch.float64, generator=g)
+    # x enters only through time slice 0 (src/model.py:99): differentiate w.r.t. a float64 copy of that slice
+    x64 = x.double().requires_grad_(True)
+    Xd = torch.cat((t.double().view(1, L, 1).expand(N, L, 1), x64.view(N, 1, d).expand(N, L, d)), 2)
+    u_ref = R.u_net(th, _cfg(8, solver), Xd, start)
+    grads = torch.autograd.grad((u_ref * ubar).sum(), [x64, start] + [th[k] for k in U_ORDER])
+    xT, tc, sc, blob = x.t().contiguous().cuda(), t.cuda(), start.detach().cuda(), _blob(theta, U_ORDER)
+    mid = KN.method_id(solver)
+    u, Y = KN.ode_fwd(xT, tc, sc, blob, mid, H, K, 8)
+    ub = None if ones else ubar.t().contiguous().cuda()
+    gx, gs, _ = KN.ode_bwd(xT, tc, sc, blob, Y, ub, mid, H, K, 8, want_x=True, want_params=False)
+    _close(gx.t(), grads[0], 1e-10, 'gx (x-only sweep)')
+    _close(gs, grads[1], 1e-10, 'gs (x-only sweep)')
+    gx2, gs2, slab = KN.ode_bwd(xT, tc, sc, blob, Y, ub, mid, H, K, 8, want_x=True, want_params=True)
+    _close(gx2.t(), grads[0], 1e-10, 'gx (param sweep)')
+    _close(gs2, grads[1], 1e-10, 'gs (param sweep)')
+    gth = KN.slab_sum(slab).cpu()
+    ref = torch.cat([g_.reshape(-1) for g_ in grads[2:]])
+    off = 0
+    for k, g_ in zip(U_ORDER, grads[2:]):
+        n = g_.numel()
+        _close(gth[off:off + n], g_.reshape(-1), 1e-10 * max(1.0, float(ref.abs().max()) / max(float(g_.abs().max()), 1e-300)), 'grad ' + k)
+        off += n
+    _close(gth, ref, 1e-10, 'theta grad (whole blob)')
+
+
+@pytest.mark.parametrize('N,L,d', CASES + [(50, 3, 70)])
+def test_disc_forward_and_time_tangent(N, L, d):
+    from oracle import refspec as R
+    from xnode_wan_pde_solver_amd import kernels as KN
+    _, phi = _params(d, 8, 21)
+    x, t, X = _sample(N, L, d, 22)
+    Xd = X.double().requires_grad_(True)
+    v_ref = R.v_net(phi, _cfg(), Xd)
+    gX = torch.autograd.grad(v_ref.sum(), Xd)[0]
+    v, vt = KN.disc_fwd(x.t().contiguous().cuda(), t.cuda(), _blob(phi, V_ORDER), W, Q)
+    _close(v.t(), v_ref, 1e-12, 'v')
+    _close(vt.t(), gX[:, :, 0], 1e-11, 'dv/dt')
+    # point mode: arbitrary per-point times
+    tpp = torch.rand(N, generator=torch.Generator().manual_seed(23)).float()
+    Xp = torch.cat((tpp.view(N, 1), x), 1).double()
+    v1, _ = KN.disc_fwd(x.t().contiguous().cuda(), None, _blob(phi, V_ORDER), W, Q, tpp=tpp.cuda())
+    _close(v1[0], R.v_net(phi, _cfg(), Xp), 1e-12, 'v (point mode)')
+
+
+@pytest.mark.parametrize('N,d', [(37, 5), (64, 20), (20, 70)])
+def test_disc_input_gradient(N, d):
+    from oracle import refspec as R
+    from xnode_wan_pde_solver_amd import kernels as KN
+    _, phi = _params(d, 8, 31)
+    x, t, X = _sample(N, 4, d, 32)
+    X0 = X[:, 0, :].double().requires_grad_(True)
+    g = torch.autograd.grad(R.v_net(phi, _cfg(), X0).sum(), X0)[0]
+    gxv, gtv = KN.disc_gradx(x.t().contiguous().cuda(), t.cuda(), _blob(phi, V_ORDER), W, Q)
+    _close(gxv.t(), g[:, 1:], 1e-11, 'nabla_x v')
+    _close(gtv, g[:, 0], 1e-11, 'dv/dt')
+
+
+@pytest.mark.parametrize('N,L,d', CASES + [(50, 3, 70), (300, 5, 6)])
+def test_disc_backward(N, L, d):
+    from oracle import refspec as R
+    from xnode_wan_pde_solver_amd import kernels as KN
+    _, phi = _params(d, 8, 41)
+    ph = {k: v.clone().requires_grad_(True) for k, v in phi.items()}
+    x, t, X = _sample(N, L, d, 42)
+    vbar = torch.randn(N, L, dtype=torch.float64, generator=torch.Generator().manual_seed(43))
+    v_ref = R.v_net(ph, _cfg(), X)
+    grads = torch.autograd.grad((v_ref * vbar).sum(), [ph[k] for k in V_ORDER])
+    slab = KN.disc_bwd(x.t().contiguous().cuda(), t.cuda(), _blob(phi, V_ORDER), vbar.t().contiguous().cuda(), W, Q)
+    got = KN.slab_sum(slab).cpu()
+    ref = torch.cat([g_.reshape(-1) for g_ in grads])
+    off = 0
+    for k, g_ in zip(V_ORDER, grads):
+        n = g_.numel()
+        _close(got[off:off + n], g_.reshape(-1), 1e-10 * max(1.0, float(ref.abs().max()) / max(float(g_.abs().max()), 1e-300)), 'grad ' + k)
+        off += n
+
+
+def test_adam_matches_torch_formula():
+    from oracle import refspec as R
+    from xnode_wan_pde_solver_amd import kernels as KN
+    g = torch.Generator().manual_seed(51)
+    P = 1651
+    p0 = torch.randn(P, dtype=torch.float64, generator=g)
+    p = {'p': p0.clone()}
+    state = {}
+    pc, m, v = p0.clone().cuda(), torch.zeros(P, dtype=torch.float64).cuda(), torch.zeros(P, dtype=torch.float64).cuda()
+    step = torch.zeros(1, dtype=torch.int64).cuda()
+    for it in range(3):
+        slabs = torch.randn(5, P, dtype=torch.float64, generator=g)
+        p = R.adam_update(p, {'p': slabs.sum(0)}, state, 0.015)
+        KN.adam(pc, slabs.cuda(), m, v, step, 0.015)
+    assert int(step.item()) == 3
+    _close(pc, p['p'], 1e-13, 'adam')
+
+
+def test_dims_outside_the_compiled_set_fail_loudly():
+    from xnode_wan_pde_solver_amd import kernels as KN
+    from xnode_wan_pde_solver_amd._lib import XnwanError
+    x = torch.zeros(3, 16, dtype=torch.float32).cuda()
+    t = torch.linspace(0, 1, 4).cuda()
+    with pytest.raises(XnwanError):
+        KN.ode_fwd(x, t, torch.zeros(16, dtype=torch.float64).cuda(),
+                   torch.zeros(KN.theta_size(3, 24, 12), dtype=torch.float64).cuda(), 1, 24, 12, 8)
+    with pytest.raises(XnwanError):
+        KN.ode_fwd(x.cpu(), t, torch.zeros(16, dtype=torch.float64).cuda(),
+                   torch.zeros(KN.theta_size(3, 20, 10), dtype=torch.float64).cuda(), 1, 20, 10, 8)

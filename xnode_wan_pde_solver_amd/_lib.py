@@ -1,0 +1,78 @@
+"""ctypes binding of libxnwan.so (C ABI declared in include/xnwan.h).
+
+The library is the product: there is no CPU or eager-PyTorch fallback.  Importing this module without the built
+library raises, and so does any call when no GPU is present.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libxnwan.so')
+ABI_VERSION = 1
+
+c_f32p = ctypes.c_void_p   # const float*  (device)
+c_f64p = ctypes.c_void_p   # double*       (device)
+c_i64p = ctypes.c_void_p
+c_int, c_dbl, c_vp = ctypes.c_int, ctypes.c_double, ctypes.c_void_p
+
+# name -> argument types (return type is always int); mirrors include/xnwan.h line by line
+SIGNATURES = {
+    'xw_abi_version': [],
+    'xw_supported_dims': [ctypes.c_char_p, c_int],
+    'xw_theta_size': [c_int, c_int, c_int],
+    'xw_phi_size': [c_int, c_int],
+    'xw_ode_fwd': [c_f32p, c_f32p, c_f64p, c_f64p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_f64p, c_f64p, c_vp],
+    'xw_ode_bwd_slabs': [c_int],
+    'xw_ode_bwd': [c_f32p, c_f32p, c_f64p, c_f64p, c_f64p, c_f64p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                   c_f64p, c_f64p, c_f64p, c_vp],
+    'xw_disc_fwd': [c_f32p, c_f32p, c_f32p, c_f64p, c_int, c_int, c_int, c_int, c_int, c_f64p, c_f64p, c_f64p, c_vp],
+    'xw_disc_gradx': [c_f32p, c_f32p, c_f32p, c_f64p, c_int, c_int, c_int, c_int, c_f64p, c_f64p, c_vp],
+    'xw_disc_bwd_slabs': [c_int, c_int],
+    'xw_disc_bwd': [c_f32p, c_f32p, c_f32p, c_f64p, c_f64p, c_f64p, c_int, c_int, c_int, c_int, c_int, c_f64p, c_vp],
+    'xw_weak_partials': [c_f64p, c_f64p, c_f64p, c_f64p, c_int, c_f64p, c_f64p, c_f64p, c_dbl, c_f64p, c_f64p, c_int,
+                         c_int, c_dbl, c_dbl, c_f64p, c_vp],
+    'xw_bdry_partials': [c_f64p, c_f64p, c_int, c_int, c_dbl, c_dbl, c_f64p, c_f64p, c_vp],
+    'xw_gen_cotangent': [c_f64p, c_f64p, c_f64p, c_int, c_f64p, c_f64p, c_dbl, c_f64p, c_int, c_int, c_dbl, c_dbl, c_dbl,
+                         c_dbl, c_dbl, c_f64p, c_f64p, c_f64p, c_vp],
+    'xw_disc_cotangent': [c_f64p, c_f64p, c_f64p, c_int, c_f64p, c_dbl, c_f64p, c_f64p, c_int, c_int, c_dbl, c_dbl, c_dbl,
+                          c_f64p, c_f64p, c_f64p, c_vp],
+    'xw_adam': [c_f64p, c_f64p, c_int, c_f64p, c_f64p, c_f64p, c_i64p, c_int, c_dbl, c_dbl, c_dbl, c_dbl, c_f64p, c_vp],
+    'xw_slab_sum': [c_f64p, c_int, c_int, c_int, c_f64p, c_vp],
+}
+
+ERRORS = {-1: 'XW_E_DIMS: network widths/depths not among the compiled kernel instantiations',
+          -2: 'XW_E_ARG: null pointer, non-positive size or bad enum',
+          -3: 'XW_E_WORKSPACE: workspace too small'}
+
+
+class XnwanError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise XnwanError(
+            'libxnwan.so not found at %s -- build it with `python -c "import __graft_entry__ as g; g.build()"` '
+            'or `make -C xnode_wan_pde_solver_amd/csrc`.  There is no CPU fallback.' % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)           # AttributeError here = the .so does not export the declared ABI
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_int
+    got = lib.xw_abi_version()
+    if got != ABI_VERSION:
+        raise XnwanError('libxnwan.so ABI version %d, host expects %d -- rebuild' % (got, ABI_VERSION))
+    return lib
+
+
+lib = _load()
+
+
+def check(status, what):
+    if status == 0:
+        return
+    if status in ERRORS:
+        buf = ctypes.create_string_buffer(512)
+        lib.xw_supported_dims(buf, 512)
+        raise XnwanError('%s: %s (compiled: %s)' % (what, ERRORS[status], buf.value.decode()))
+    raise XnwanError('%s: HIP launch error %d' % (what, status))

@@ -1,0 +1,147 @@
+// xw_common.h -- shared device helpers for the gfx950 XNODE-WAN kernels.
+//
+// All dense work runs on v_mfma_f64_16x16x4_f64 (measured on MI355X: 64-cycle issue per SIMD = 77.6 TFLOP/s chip-wide,
+// no extra latency on a chained accumulator, +17 cycles when a result feeds the next B operand;
+// profiles/r01_probe_fp64.txt).  Lane maps of that instruction (checked by tools/probe_fp64.hip):
+//     A[i][k]  : lane = i + 16 k          (i = lane & 15, k = lane >> 4),   one f64 per lane
+//     B[k][j]  : lane = j + 16 k
+//     D[i][j]  : lane = j + 16 (i & 3), register r = i >> 2       (row i = (lane >> 4) + 4 r, col j = lane & 15)
+//
+// "Chain layout": a [rows x 16 columns] activation tile kept as a d4 per lane, element (row = g + 4 r, col = n) with
+// g = lane >> 4, n = lane & 15.  It is what an MFMA writes (D) and, register r taken as k-step r, exactly what the next
+// MFMA reads as B (rows 4r + g) -- so a stack of small dense layers runs with no cross-lane data movement at all.
+// The 16 columns are 16 Monte-Carlo paths (stepper) or 16 sample points (test network).
+#pragma once
+#include <hip/hip_runtime.h>
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+#define XW_MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
+
+#define XW_E_DIMS (-1)
+#define XW_E_ARG (-2)
+#define XW_E_WORKSPACE (-3)
+
+// ---- parameter blob layouts (named_parameters() order of the reference modules) ---------------------------------
+struct UOff {  // u_theta, src/model.py:78,85,130-138
+  int IL0w, IL0b, IL2w, IL2b, IL4w, IL4b, Win, Winb, Wh, Whb, Wo, Wob, FLw, FLb, total, ldin;
+};
+__host__ __device__ inline UOff u_offsets(int d, int H, int K) {
+  UOff o;
+  int p = 0;
+  o.IL0w = p; p += H;
+  o.IL0b = p; p += H;
+  o.IL2w = p; p += H * H;
+  o.IL2b = p; p += H;
+  o.IL4w = p; p += H * H;
+  o.IL4b = p; p += H;
+  o.ldin = d + 1 + H;
+  o.Win = p; p += K * o.ldin;
+  o.Winb = p; p += K;
+  o.Wh = p; p += K * K;
+  o.Whb = p; p += K;
+  o.Wo = p; p += H * K;
+  o.Wob = p; p += H;
+  o.FLw = p; p += H;
+  o.FLb = p; p += 1;
+  o.total = p;
+  return o;
+}
+struct VOff {  // v_phi, src/model.py:34-36
+  int Vin, Vinb, Vh, Vhb, Vo, Vob, total, ldin;
+};
+__host__ __device__ inline VOff v_offsets(int d, int W) {
+  VOff o;
+  int p = 0;
+  o.ldin = d + 1;
+  o.Vin = p; p += W * o.ldin;
+  o.Vinb = p; p += W;
+  o.Vh = p; p += W * W;
+  o.Vhb = p; p += W;
+  o.Vo = p; p += W;
+  o.Vob = p; p += 1;
+  o.total = p;
+  return o;
+}
+
+// ---- lane helpers -------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int xw_lane() { return threadIdx.x & 63; }
+
+// A-operand fragment of a row-major matrix Mx[rows x cols] (leading dimension ld): element (r0 + i, c0 + k), 0 outside
+__device__ __forceinline__ double xw_fragA(const double* __restrict__ Mx, int ld, int rows, int cols, int r0, int c0) {
+  const int l = xw_lane();
+  const int r = r0 + (l & 15), c = c0 + (l >> 4);
+  return (r < rows && c < cols) ? Mx[r * ld + c] : 0.0;
+}
+// A-operand fragment of the TRANSPOSE of Mx: element (r0 + i, c0 + k) of Mx^T, i.e. Mx[c0 + k][r0 + i]
+__device__ __forceinline__ double xw_fragAT(const double* __restrict__ Mx, int ld, int rows, int cols, int r0, int c0) {
+  const int l = xw_lane();
+  const int r = r0 + (l & 15), c = c0 + (l >> 4);
+  return (r < cols && c < rows) ? Mx[c * ld + r] : 0.0;
+}
+// chain-layout vector broadcast over the 16 columns: rows r0 + g + 4 r of b[rows]
+__device__ __forceinline__ d4 xw_vecD(const double* __restrict__ b, int rows, int r0) {
+  const int g = xw_lane() >> 4;
+  d4 v;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = r0 + g + 4 * r;
+    v[r] = (i < rows) ? b[i] : 0.0;
+  }
+  return v;
+}
+// same, strided source (column of a row-major matrix)
+__device__ __forceinline__ d4 xw_vecD_strided(const double* __restrict__ b, int stride, int rows, int r0) {
+  const int g = xw_lane() >> 4;
+  d4 v;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = r0 + g + 4 * r;
+    v[r] = (i < rows) ? b[(long)i * stride] : 0.0;
+  }
+  return v;
+}
+__device__ __forceinline__ d4 xw_relu(d4 z) {
+  d4 o;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) o[r] = z[r] > 0.0 ? z[r] : 0.0;
+  return o;
+}
+__device__ __forceinline__ d4 xw_zero4() { d4 z = {0.0, 0.0, 0.0, 0.0}; return z; }
+
+// sum over the 4 lane groups g (lanes n, n+16, n+32, n+48): reduces the ROW index of a chain-layout partial
+__device__ __forceinline__ double xw_sum_over_g(double x) {
+  x += __shfl_xor(x, 16);
+  x += __shfl_xor(x, 32);
+  return x;
+}
+// sum over the 16 columns n (lanes within a 16-lane row)
+__device__ __forceinline__ double xw_sum_over_n(double x) {
+  x += __shfl_xor(x, 1);
+  x += __shfl_xor(x, 2);
+  x += __shfl_xor(x, 4);
+  x += __shfl_xor(x, 8);
+  return x;
+}
+
+// ---- transposition through LDS: chain layout -> operand layout for contractions over the 16 columns ---------------
+// A [16 x 16] tile is stored as tile[row * 17 + col] (row stride 17 doubles keeps both phases nearly conflict-free).
+// After xw_writeT, xw_readT(ks) returns, for lane (i = lane & 15, p = lane >> 4), element (row i, col 4 ks + p):
+// the A operand of  D[i][j] += sum_col Q[i][col] * R[j][col]  and, read from R's tile, its B operand.
+#define XW_TSTRIDE 17
+#define XW_TTILE (16 * XW_TSTRIDE)
+__device__ __forceinline__ void xw_writeT(double* tile, d4 q) {
+  const int l = xw_lane();
+  const int g = l >> 4, n = l & 15;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) tile[(g + 4 * r) * XW_TSTRIDE + n] = q[r];
+}
+__device__ __forceinline__ double xw_readT(const double* tile, int ks) {
+  const int l = xw_lane();
+  return tile[(l & 15) * XW_TSTRIDE + 4 * ks + (l >> 4)];
+}
+
+// launch-error helper for the extern "C" wrappers
+static inline int xw_launch_status() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : (int)e;
+}

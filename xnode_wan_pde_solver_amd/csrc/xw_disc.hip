@@ -1,0 +1,420 @@
+// xw_disc.hip -- adversarial test network v_phi on gfx950.
+//
+// Replaces discriminator.forward (src/model.py:37-47 of the reference), the helper backward that produces
+// nabla phi (src/loss.py:60-63) and the autograd replay that produces phi's gradient (src/training.py:161).
+//
+// v_phi is a W-wide (50) MLP with ONE weight-tied hidden layer applied q (9) times: a real dense contraction
+// [W x W] x [W x points] -- the only part of the hot path where the hidden width makes MFMA tiles pay
+// (4 row tiles x 13 k-steps of v_mfma_f64_16x16x4_f64 per layer per 16 points, 75 % useful after padding 50 -> 64/52).
+//
+//   k_disc_fwd : value and d/dt (forward-mode tangent: the weak form needs d(phi)/dt at every sample point but
+//                nabla_x phi only at the initial time).  Vh lives in registers as 52 A-fragments;
+//                activations never leave the chain layout.  No HBM traffic besides x, t in and v, dv/dt out.
+//   k_disc_bwd : recomputes the forward for a tile of 16 points per wave (activations stay in registers), runs the
+//                reverse chain with Vh^T fragments from LDS, and accumulates  dVh += delta_{j+1} (x) relu(a_j)  as MFMA
+//                outer products over the points (LDS transpose; 4 waves of a block own one 16-row band of dVh each).
+//                Optionally also returns the input gradient (nabla_x v, dv/dt) -- used for nabla phi at t0.
+#include "xw_common.h"
+
+namespace {
+
+template <int W> struct VDim {
+  static constexpr int MT = (W + 15) / 16;
+  static constexpr int KS = (W + 3) / 4;
+  static_assert(MT == 4, "the backward kernel maps the 4 row tiles of dVh onto the 4 waves of a block");
+  static_assert((W % 16) != 0, "a padding row of the last tile carries the bias column of the outer products");
+};
+
+// point -> (time, path) ; path mode: p = l*N + n ; point mode (tpp != null): p = n, L == 1
+struct Pt {
+  int p, n;
+  bool valid;
+  double t;
+};
+__device__ __forceinline__ Pt locate(long tile, long P, int N, const float* __restrict__ tf, const float* __restrict__ tpp) {
+  Pt q;
+  const long p = tile * 16 + (xw_lane() & 15);
+  q.valid = p < P;
+  const long pc = q.valid ? p : P - 1;
+  q.p = (int)pc;
+  if (tpp != nullptr) {
+    q.n = (int)pc;
+    q.t = (double)tpp[pc];
+  } else {
+    const int l = (int)(pc / N);
+    q.n = (int)(pc - (long)l * N);
+    q.t = (double)tf[l];
+  }
+  return q;
+}
+
+// input layer a0 = Vin [t; x] + b  (and its t-tangent = Vin[:, 0])
+template <int W>
+__device__ __forceinline__ void input_layer(const double* __restrict__ ph, const VOff& o, const float* __restrict__ xT,
+                                            int N, int d, const Pt& q, d4 (&a)[VDim<W>::MT], d4 (&ad)[VDim<W>::MT]) {
+  typedef VDim<W> D;
+  const int g = xw_lane() >> 4;
+#pragma unroll
+  for (int mt = 0; mt < D::MT; ++mt) {
+    ad[mt] = xw_vecD_strided(ph + o.Vin, o.ldin, W, 16 * mt);
+    a[mt] = xw_vecD(ph + o.Vinb, W, 16 * mt) + ad[mt] * q.t;
+  }
+  for (int ks = 0; ks < (d + 3) / 4; ++ks) {
+    const int i = 4 * ks + g;
+    const double b = i < d ? (double)xT[(long)i * N + q.n] : 0.0;
+#pragma unroll
+    for (int mt = 0; mt < D::MT; ++mt) a[mt] = XW_MFMA(xw_fragA(ph + o.Vin + 1, o.ldin, W, d, 16 * mt, 4 * ks), b, a[mt]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+template <int W>
+__global__ void __launch_bounds__(256) k_disc_fwd(const float* __restrict__ xT, const float* __restrict__ tf,
+                                                  const float* __restrict__ tpp, const double* __restrict__ ph, int N,
+                                                  int L, int d, int q, double* __restrict__ v, double* __restrict__ vt) {
+  typedef VDim<W> D;
+  const int lane = xw_lane(), g = lane >> 4;
+  const int wave = threadIdx.x >> 6;
+  const VOff o = v_offsets(d, W);
+  const long P = (long)N * L;
+  const long ntiles = (P + 15) / 16;
+  double Vh[D::MT][D::KS];
+  d4 bh[D::MT], vo[D::MT];
+#pragma unroll
+  for (int mt = 0; mt < D::MT; ++mt) {
+#pragma unroll
+    for (int ks = 0; ks < D::KS; ++ks) Vh[mt][ks] = xw_fragA(ph + o.Vh, W, W, W, 16 * mt, 4 * ks);
+    bh[mt] = xw_vecD(ph + o.Vhb, W, 16 * mt);
+    vo[mt] = xw_vecD(ph + o.Vo, W, 16 * mt);
+  }
+  const double vob = ph[o.Vob];
+  for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long)gridDim.x * 4) {
+    const Pt pt = locate(tile, P, N, tf, tpp);
+    d4 a[D::MT], ad[D::MT];
+    input_layer<W>(ph, o, xT, N, d, pt, a, ad);
+    for (int j = 0; j < q; ++j) {
+      d4 nw[D::MT], nd[D::MT];
+#pragma unroll
+      for (int mt = 0; mt < D::MT; ++mt) {
+        nw[mt] = bh[mt];
+        nd[mt] = xw_zero4();
+      }
+#pragma unroll
+      for (int ks = 0; ks < D::KS; ++ks) {
+        const double av = a[ks >> 2][ks & 3];
+        const double b = av > 0.0 ? av : 0.0;
+        const double bd = av > 0.0 ? ad[ks >> 2][ks & 3] : 0.0;
+#pragma unroll
+        for (int mt = 0; mt < D::MT; ++mt) {
+          nw[mt] = XW_MFMA(Vh[mt][ks], b, nw[mt]);
+          nd[mt] = XW_MFMA(Vh[mt][ks], bd, nd[mt]);
+        }
+      }
+#pragma unroll
+      for (int mt = 0; mt < D::MT; ++mt) {
+        a[mt] = nw[mt];
+        ad[mt] = nd[mt];
+      }
+    }
+    double sv = 0.0, sd = 0.0;
+#pragma unroll
+    for (int mt = 0; mt < D::MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (16 * mt + 4 * r < W) {  // rows 16 mt + 4 r + g >= W only carry zero padding
+          const double th = tanh(a[mt][r]);
+          sv += vo[mt][r] * th;
+          sd += vo[mt][r] * (1.0 - th * th) * ad[mt][r];
+        }
+    sv = xw_sum_over_g(sv) + vob;
+    sd = xw_sum_over_g(sd);
+    if (g == 0 && pt.valid) {
+      v[pt.p] = sv;
+      if (vt != nullptr) vt[pt.p] = sd;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// LDS plan of k_disc_bwd (doubles):  Vh frags | Vh^T frags | delta T-tiles [4 waves][MT] | r T-tiles [4][MT] | dVo acc
+template <int W> struct BwdLds {
+  typedef VDim<W> D;
+  static constexpr int nfrag = D::MT * D::KS * 64;
+  static constexpr int ntt = 4 * D::MT * XW_TTILE;
+  static constexpr int oVh = 0, oVhT = nfrag, oD = 2 * nfrag, oR = 2 * nfrag + ntt, oO = 2 * nfrag + 2 * ntt;
+  static constexpr int total = oO + 4 * 64 * 16;
+  static_assert(total * 8 <= 160 * 1024, "LDS budget of one CU");
+};
+
+template <int W, int Q, int CTG, bool PARAMS, bool INGRAD>
+__global__ void __launch_bounds__(256) k_disc_bwd(const float* __restrict__ xT, const float* __restrict__ tf,
+                                                  const float* __restrict__ tpp, const double* __restrict__ ph,
+                                                  const double* __restrict__ vbar, int N, int L, int d,
+                                                  double* __restrict__ gslab, double* __restrict__ gxv,
+                                                  double* __restrict__ gtv) {
+  typedef VDim<W> D;
+  typedef BwdLds<W> S;
+  __shared__ double lds[S::total];
+  double* sVh = lds + S::oVh;
+  double* sVhT = lds + S::oVhT;
+  double* sD = lds + S::oD;
+  double* sR = lds + S::oR;
+  double* sO = lds + S::oO;
+  const int lane = xw_lane(), g = lane >> 4, n = lane & 15;
+  const int wave = threadIdx.x >> 6;
+  const VOff o = v_offsets(d, W);
+  const long P = (long)N * L;
+  const long nsuper = (P + 63) / 64;
+
+  for (int idx = wave; idx < D::MT * D::KS; idx += 4) {
+    const int mt = idx / D::KS, ks = idx - mt * D::KS;
+    sVh[idx * 64 + lane] = xw_fragA(ph + o.Vh, W, W, W, 16 * mt, 4 * ks);
+    sVhT[idx * 64 + lane] = xw_fragAT(ph + o.Vh, W, W, W, 16 * mt, 4 * ks);
+  }
+  if (PARAMS)
+    for (int i = 0; i < 16; ++i) sO[(wave * 64 + lane) * 16 + i] = 0.0;
+  __syncthreads();
+
+  d4 bh[D::MT], vo[D::MT];
+#pragma unroll
+  for (int mt = 0; mt < D::MT; ++mt) {
+    bh[mt] = xw_vecD(ph + o.Vhb, W, 16 * mt);
+    vo[mt] = xw_vecD(ph + o.Vo, W, 16 * mt);
+  }
+  d4 accH[D::MT], accIn[CTG * 4];
+#pragma unroll
+  for (int ct = 0; ct < D::MT; ++ct) accH[ct] = xw_zero4();
+#pragma unroll
+  for (int ct = 0; ct < CTG * 4; ++ct) accIn[ct] = xw_zero4();
+
+  for (long st = blockIdx.x; st < nsuper; st += gridDim.x) {
+    const Pt pt = locate(st * 4 + wave, P, N, tf, tpp);
+    // ---- forward recompute; rs[j] = relu(a_j), j = 0..Q-1 stay in registers
+    d4 rs[Q][D::MT];
+    d4 a[D::MT], ad[D::MT];
+    input_layer<W>(ph, o, xT, N, d, pt, a, ad);
+#pragma unroll
+    for (int j = 0; j < Q; ++j) {
+#pragma unroll
+      for (int mt = 0; mt < D::MT; ++mt) {
+        rs[j][mt] = xw_relu(a[mt]);
+        a[mt] = bh[mt];
+      }
+#pragma unroll
+      for (int ks = 0; ks < D::KS; ++ks) {
+        const double b = rs[j][ks >> 2][ks & 3];
+#pragma unroll
+        for (int mt = 0; mt < D::MT; ++mt) a[mt] = XW_MFMA(sVh[(mt * D::KS + ks) * 64 + lane], b, a[mt]);
+      }
+    }
+    // ---- output layer and its cotangent
+    const double vb = pt.valid ? (vbar != nullptr ? vbar[pt.p] : 1.0) : 0.0;
+    d4 dl[D::MT];
+#pragma unroll
+    for (int mt = 0; mt < D::MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        double th = 0.0;
+        if (16 * mt + 4 * r < W) th = tanh(a[mt][r]);
+        dl[mt][r] = vo[mt][r] * (1.0 - th * th) * vb;
+        if (PARAMS) sO[(wave * 64 + lane) * 16 + mt * 4 + r] += (mt == D::MT - 1 && r == 3) ? (g == 0 ? vb : 0.0) : vb * th;
+      }
+    // ---- reverse chain
+#pragma unroll
+    for (int j = Q - 1; j >= 0; --j) {
+      if (PARAMS) {
+#pragma unroll
+        for (int mt = 0; mt < D::MT; ++mt) {
+          d4 rj = rs[j][mt];
+          if (mt == (W >> 4)) {
+            if (g == ((W & 15) & 3)) rj[(W & 15) >> 2] = 1.0;  // ones row -> column W of dVh collects dVh.b
+          }
+          xw_writeT(sD + (wave * D::MT + mt) * XW_TTILE, dl[mt]);
+          xw_writeT(sR + (wave * D::MT + mt) * XW_TTILE, rj);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int pw = 0; pw < 4; ++pw)
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) {
+            const double av = xw_readT(sD + (pw * D::MT + wave) * XW_TTILE, ks);
+#pragma unroll
+            for (int ct = 0; ct < D::MT; ++ct)
+              accH[ct] = XW_MFMA(av, xw_readT(sR + (pw * D::MT + ct) * XW_TTILE, ks), accH[ct]);
+          }
+        __syncthreads();
+      }
+      d4 nd[D::MT];
+#pragma unroll
+      for (int mt = 0; mt < D::MT; ++mt) nd[mt] = xw_zero4();
+#pragma unroll
+      for (int ks = 0; ks < D::KS; ++ks) {
+        const double b = dl[ks >> 2][ks & 3];
+#pragma unroll
+        for (int mt = 0; mt < D::MT; ++mt) nd[mt] = XW_MFMA(sVhT[(mt * D::KS + ks) * 64 + lane], b, nd[mt]);
+      }
+#pragma unroll
+      for (int mt = 0; mt < D::MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dl[mt][r] = rs[j][mt][r] > 0.0 ? nd[mt][r] : 0.0;
+    }
+    // ---- dl = cotangent of a_0.  Input layer: dVin = dl (x) [t; x; 1]
+    if (PARAMS) {
+#pragma unroll
+      for (int mt = 0; mt < D::MT; ++mt) xw_writeT(sD + (wave * D::MT + mt) * XW_TTILE, dl[mt]);
+#pragma unroll
+      for (int grp = 0; grp < CTG; ++grp) {
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+          const int cl = g + 4 * rr;            // local row 0..63 of this group
+          const int c = 64 * grp + cl;          // input row: 0 = t, 1..d = x, d+1 = ones
+          double val = 0.0;
+          if (pt.valid) {
+            if (c == 0) val = pt.t;
+            else if (c <= d) val = (double)xT[(long)(c - 1) * N + pt.n];
+            else if (c == d + 1) val = 1.0;
+          }
+          sR[(wave * D::MT + (cl >> 4)) * XW_TTILE + (cl & 15) * XW_TSTRIDE + n] = val;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int pw = 0; pw < 4; ++pw)
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) {
+            const double av = xw_readT(sD + (pw * D::MT + wave) * XW_TTILE, ks);
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct)
+              accIn[grp * 4 + ct] = XW_MFMA(av, xw_readT(sR + (pw * D::MT + ct) * XW_TTILE, ks), accIn[grp * 4 + ct]);
+          }
+        __syncthreads();
+      }
+    }
+    if (INGRAD) {
+      for (int rt = 0; rt < (d + 15) / 16; ++rt) {
+        d4 vv = xw_zero4();
+#pragma unroll
+        for (int ks = 0; ks < D::KS; ++ks)
+          vv = XW_MFMA(xw_fragAT(ph + o.Vin + 1, o.ldin, W, d, 16 * rt, 4 * ks), dl[ks >> 2][ks & 3], vv);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = 16 * rt + g + 4 * r;
+          if (i < d && pt.valid) gxv[(long)i * P + pt.p] = vv[r];
+        }
+      }
+      double st_ = 0.0;
+#pragma unroll
+      for (int mt = 0; mt < D::MT; ++mt) {
+        const d4 v0 = xw_vecD_strided(ph + o.Vin, o.ldin, W, 16 * mt);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) st_ += v0[r] * dl[mt][r];
+      }
+      st_ = xw_sum_over_g(st_);
+      if (gtv != nullptr && g == 0 && pt.valid) gtv[pt.p] = st_;
+    }
+  }
+
+  if (PARAMS) {
+    double* slab = gslab + (long)blockIdx.x * o.total;
+    // wave `wave` owns rows [16 wave, 16 wave + 16) of dVh and dVin
+#pragma unroll
+    for (int ct = 0; ct < D::MT; ++ct) {
+      const int c = 16 * ct + n;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * wave + g + 4 * r;
+        if (row < W) {
+          if (c < W) slab[o.Vh + row * W + c] = accH[ct][r];
+          else if (c == W) slab[o.Vhb + row] = accH[ct][r];
+        }
+      }
+    }
+#pragma unroll
+    for (int ct = 0; ct < CTG * 4; ++ct) {
+      const int c = 16 * ct + n;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * wave + g + 4 * r;
+        if (row < W) {
+          if (c <= d) slab[o.Vin + row * o.ldin + c] = accIn[ct][r];
+          else if (c == d + 1) slab[o.Vinb + row] = accIn[ct][r];
+        }
+      }
+    }
+    __syncthreads();
+    const int tid = threadIdx.x;
+    if (tid <= W) {
+      double s = 0.0;
+      if (tid < W) {
+        const int mt = tid >> 4, gg = tid & 3, r = (tid & 15) >> 2;
+        for (int wv = 0; wv < 4; ++wv)
+          for (int nn = 0; nn < 16; ++nn) s += sO[(wv * 64 + gg * 16 + nn) * 16 + mt * 4 + r];
+        slab[o.Vo + tid] = s;
+      } else {
+        for (int wv = 0; wv < 4; ++wv)
+          for (int nn = 0; nn < 16; ++nn) s += sO[(wv * 64 + nn) * 16 + 15];
+        slab[o.Vob] = s;
+      }
+    }
+  }
+}
+
+int bwd_blocks(long P) {
+  long nsuper = (P + 63) / 64;
+  return (int)(nsuper < 256 ? nsuper : 256);
+}
+
+}  // namespace
+
+extern "C" int xw_disc_fwd(const float* xT, const float* t, const float* tpp, const double* phi, int N, int L, int d,
+                           int W, int q, double* v, double* vt, double* act, void* stream) {
+  (void)act;
+  if (!xT || !phi || !v || N <= 0 || L <= 0 || d <= 0 || q < 0) return XW_E_ARG;
+  if (!tpp && !t) return XW_E_ARG;
+  if (tpp && L != 1) return XW_E_ARG;
+  if (W != 50) return XW_E_DIMS;
+  const long ntiles = ((long)N * L + 15) / 16;
+  long blocks = (ntiles + 3) / 4;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL((k_disc_fwd<50>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, xT, t, tpp, phi, N, L, d,
+                     q, v, vt);
+  return xw_launch_status();
+}
+
+extern "C" int xw_disc_bwd_slabs(int N, int L) { return bwd_blocks((long)N * L); }
+
+#define XW_DISC_BWD(PARAMS, INGRAD)                                                                                    \
+  if (d + 2 <= 64)                                                                                                     \
+    hipLaunchKernelGGL((k_disc_bwd<50, 9, 1, PARAMS, INGRAD>), dim3(blocks), dim3(256), 0, s, xT, t, tpp, phi, vbar, N, \
+                       L, d, gslab, gxv, gtv);                                                                         \
+  else                                                                                                                 \
+    hipLaunchKernelGGL((k_disc_bwd<50, 9, 2, PARAMS, INGRAD>), dim3(blocks), dim3(256), 0, s, xT, t, tpp, phi, vbar, N, \
+                       L, d, gslab, gxv, gtv);
+
+extern "C" int xw_disc_bwd(const float* xT, const float* t, const float* tpp, const double* phi, const double* act,
+                           const double* vbar, int N, int L, int d, int W, int q, double* gslab, void* stream) {
+  (void)act;
+  if (!xT || !phi || !gslab || N <= 0 || L <= 0 || d <= 0) return XW_E_ARG;
+  if (!tpp && !t) return XW_E_ARG;
+  if (tpp && L != 1) return XW_E_ARG;
+  if (W != 50 || q != 9 || d + 2 > 128) return XW_E_DIMS;
+  hipStream_t s = (hipStream_t)stream;
+  const int blocks = bwd_blocks((long)N * L);
+  double* gxv = nullptr;
+  double* gtv = nullptr;
+  XW_DISC_BWD(true, false)
+  return xw_launch_status();
+}
+
+extern "C" int xw_disc_gradx(const float* xT, const float* t, const float* tpp, const double* phi, int N, int d, int W,
+                             int q, double* gxv, double* gtv, void* stream) {
+  if (!xT || !phi || !gxv || N <= 0 || d <= 0) return XW_E_ARG;
+  if (!tpp && !t) return XW_E_ARG;
+  if (W != 50 || q != 9 || d + 2 > 128) return XW_E_DIMS;
+  hipStream_t s = (hipStream_t)stream;
+  const int L = 1;
+  const int blocks = bwd_blocks((long)N);
+  const double* vbar = nullptr;
+  double* gslab = nullptr;
+  XW_DISC_BWD(false, true)
+  return xw_launch_status();
+}

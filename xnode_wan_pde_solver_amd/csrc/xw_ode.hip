@@ -1,0 +1,602 @@
+// xw_ode.hip -- XNODE primal network u_theta on gfx950: fused fixed-grid ODE stepper, forward and reverse sweep.
+//
+// Replaces NeuralODE.forward + _F/_ODEField + torchdiffeq's Python stepping loop (src/model.py:87-112,140-156 of the
+// reference) and the autograd replay of that loop (src/loss.py:55, src/training.py:137).
+//
+// One wave = 16 Monte-Carlo paths.  The hidden state y[H], the field's pre-activations z_j[K] and every cotangent live
+// in registers in the "chain layout" of xw_common.h for the whole time loop; all weight matrices are MFMA A-fragments
+// held in registers (13 + 14 f64 per lane at H=20, K=10).  Per field evaluation: 5 + 3(m-1) + 6 MFMAs forward and the
+// same number for the vector-Jacobian product; parameter gradients are contractions over the 16 paths, done as 4-step
+// MFMA outer products after an LDS transpose (xw_writeT / xw_readT), accumulated in registers over all stages, layers
+// and time steps and written once per wave as a deterministic partial "slab".
+//
+// Memory traffic per path: x (d floats) once, the checkpoint y[L,H] written once / read once, u[L] -- everything else
+// stays on chip.  At the headline size this kernel is bound by the FP64 matrix pipe, not by HBM.
+#include "xw_common.h"
+
+namespace {
+
+// ---- explicit Runge-Kutta tableaux of the fixed-grid solvers (torchdiffeq fixed_grid: euler, midpoint, rk4 = 3/8 rule)
+template <int METHOD> struct RK;
+template <> struct RK<0> {
+  static constexpr int S = 1;
+  __device__ static constexpr double c(int) { return 0.0; }
+  __device__ static constexpr double a(int, int) { return 0.0; }
+  __device__ static constexpr double b(int) { return 1.0; }
+};
+template <> struct RK<1> {
+  static constexpr int S = 2;
+  __device__ static constexpr double c(int i) { return i == 1 ? 0.5 : 0.0; }
+  __device__ static constexpr double a(int i, int j) { return (i == 1 && j == 0) ? 0.5 : 0.0; }
+  __device__ static constexpr double b(int i) { return i == 1 ? 1.0 : 0.0; }
+};
+template <> struct RK<2> {
+  static constexpr int S = 4;
+  __device__ static constexpr double c(int i) { return i == 1 ? 1.0 / 3.0 : i == 2 ? 2.0 / 3.0 : i == 3 ? 1.0 : 0.0; }
+  __device__ static constexpr double a(int i, int j) {
+    return (i == 1 && j == 0) ? 1.0 / 3.0
+         : (i == 2 && j == 0) ? -1.0 / 3.0
+         : (i == 2 && j == 1) ? 1.0
+         : (i == 3 && j == 0) ? 1.0
+         : (i == 3 && j == 1) ? -1.0
+         : (i == 3 && j == 2) ? 1.0 : 0.0;
+  }
+  __device__ static constexpr double b(int i) { return (i == 0 || i == 3) ? 0.125 : 0.375; }
+};
+
+template <int H, int K> struct Dim {
+  static constexpr int HT = (H + 15) / 16;   // row tiles of an H-vector
+  static constexpr int KSH = (H + 3) / 4;    // k-steps of a contraction over H
+  static constexpr int KSK = (K + 3) / 4;    // k-steps of a contraction over K
+  static_assert(K <= 15, "one padding row of the K-tile carries the bias column of the outer products");
+  static_assert((H % 16) != 0 && (H % 16) <= 15, "one padding row of the last H-tile carries the time column");
+  static_assert(HT <= 2, "H <= 31");
+};
+
+template <int H, int K> struct FieldW {      // forward operands
+  double Wy[Dim<H, K>::KSH];                 // Win[:, d+1:]  [K x H]
+  double Wh[Dim<H, K>::KSK];                 // Wh            [K x K]
+  double Wo[Dim<H, K>::HT][Dim<H, K>::KSK];  // Wo            [H x K]
+  d4 wt, bh;                                 // Win[:, d] (time column), Wh.b
+  d4 bo[Dim<H, K>::HT];                      // Wo.b
+};
+template <int H, int K> struct FieldWT {     // transposed operands for the vector-Jacobian product
+  double WyT[Dim<H, K>::HT][Dim<H, K>::KSK]; // [H x K]
+  double WhT[Dim<H, K>::KSK];                // [K x K]
+  double WoT[Dim<H, K>::KSH];                // [K x H]
+};
+template <int M> struct Save {               // what the VJP of one field evaluation needs
+  d4 z[M > 1 ? M - 1 : 1];                   // pre-activations z_0 .. z_{m-2} (ReLU layers)
+  d4 a;                                      // tanh(z_{m-1})
+};
+
+template <int H, int K>
+__device__ __forceinline__ void load_field(const double* __restrict__ th, const UOff& o, int d, FieldW<H, K>& w) {
+  typedef Dim<H, K> D;
+  const double* Wy = th + o.Win + d + 1;
+#pragma unroll
+  for (int ks = 0; ks < D::KSH; ++ks) w.Wy[ks] = xw_fragA(Wy, o.ldin, K, H, 0, 4 * ks);
+#pragma unroll
+  for (int ks = 0; ks < D::KSK; ++ks) w.Wh[ks] = xw_fragA(th + o.Wh, K, K, K, 0, 4 * ks);
+#pragma unroll
+  for (int ht = 0; ht < D::HT; ++ht) {
+#pragma unroll
+    for (int ks = 0; ks < D::KSK; ++ks) w.Wo[ht][ks] = xw_fragA(th + o.Wo, K, H, K, 16 * ht, 4 * ks);
+    w.bo[ht] = xw_vecD(th + o.Wob, H, 16 * ht);
+  }
+  w.wt = xw_vecD_strided(th + o.Win + d, o.ldin, K, 0);
+  w.bh = xw_vecD(th + o.Whb, K, 0);
+}
+template <int H, int K>
+__device__ __forceinline__ void load_field_T(const double* __restrict__ th, const UOff& o, int d, FieldWT<H, K>& w) {
+  typedef Dim<H, K> D;
+  const double* Wy = th + o.Win + d + 1;
+#pragma unroll
+  for (int ht = 0; ht < D::HT; ++ht)
+#pragma unroll
+    for (int ks = 0; ks < D::KSK; ++ks) w.WyT[ht][ks] = xw_fragAT(Wy, o.ldin, K, H, 16 * ht, 4 * ks);
+#pragma unroll
+  for (int ks = 0; ks < D::KSK; ++ks) w.WhT[ks] = xw_fragAT(th + o.Wh, K, K, K, 0, 4 * ks);
+#pragma unroll
+  for (int ks = 0; ks < D::KSH; ++ks) w.WoT[ks] = xw_fragAT(th + o.Wo, K, H, K, 0, 4 * ks);
+}
+
+// F([x, t, y]) of src/model.py:153-156: z0 = Win [x;t;y] + b (x part pre-contracted into xp), (m-1) tied ReLU layers,
+// tanh, output layer.  y/out: HT chain tiles.
+template <int H, int K, int M, bool SAVE>
+__device__ __forceinline__ void field_fwd(const FieldW<H, K>& w, double t, d4 xp, const d4 (&y)[Dim<H, K>::HT],
+                                          d4 (&out)[Dim<H, K>::HT], Save<M>& sv) {
+  typedef Dim<H, K> D;
+  d4 z = xp + w.wt * t;
+#pragma unroll
+  for (int ks = 0; ks < D::KSH; ++ks) z = XW_MFMA(w.Wy[ks], y[ks >> 2][ks & 3], z);
+#pragma unroll
+  for (int j = 0; j < M - 1; ++j) {
+    if (SAVE) sv.z[j] = z;
+    d4 r = xw_relu(z);
+    d4 nz = w.bh;
+#pragma unroll
+    for (int ks = 0; ks < D::KSK; ++ks) nz = XW_MFMA(w.Wh[ks], r[ks], nz);
+    z = nz;
+  }
+  d4 a = xw_zero4();
+#pragma unroll
+  for (int ks = 0; ks < D::KSK; ++ks) a[ks] = tanh(z[ks]);
+  if (SAVE) sv.a = a;
+#pragma unroll
+  for (int ht = 0; ht < D::HT; ++ht) {
+    d4 o = w.bo[ht];
+#pragma unroll
+    for (int ks = 0; ks < D::KSK; ++ks) o = XW_MFMA(w.Wo[ht][ks], a[ks], o);
+    out[ht] = o;
+  }
+}
+
+// parameter-gradient accumulators of the field (chain-layout tiles of the gradient matrices)
+template <int H, int K> struct FieldG {
+  d4 Wh;                                          // rows K, cols K (+ column K = bias via a ones row)
+  d4 Wy[(H + 1 + 15) / 16];                       // rows K, cols H (+ column H = time column)
+  d4 Wo[Dim<H, K>::HT];                           // rows H, cols K (+ column K = bias)
+};
+
+// D[i][j] += sum over the 16 paths of Q[i][path] * R[j][path]
+__device__ __forceinline__ void outer_acc(d4& acc, d4 q, d4 r, double* lds) {
+  xw_writeT(lds, q);
+  xw_writeT(lds + XW_TTILE, r);
+  __syncthreads();
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) acc = XW_MFMA(xw_readT(lds, ks), xw_readT(lds + XW_TTILE, ks), acc);
+  __syncthreads();
+}
+// set chain-layout row `row` (0..15) of a tile to the value v in every column
+__device__ __forceinline__ void set_row(d4& q, int row, double v) {
+  if ((xw_lane() >> 4) == (row & 3)) q[row >> 2] = v;
+}
+
+// vector-Jacobian product of one field evaluation.  ob: cotangent of F's output; returns the cotangent of the y input
+// in yb, adds the cotangent of z0 into xpb (= cotangent of the x-projection and of Win.b), and (PARAMS) accumulates the
+// parameter gradients.
+template <int H, int K, int M, bool PARAMS>
+__device__ __forceinline__ void field_vjp(const FieldW<H, K>& w, const FieldWT<H, K>& wT, double t, const Save<M>& sv,
+                                          const d4 (&yin)[Dim<H, K>::HT], const d4 (&ob)[Dim<H, K>::HT],
+                                          d4 (&yb)[Dim<H, K>::HT], d4& xpb, FieldG<H, K>& G, double* lds) {
+  typedef Dim<H, K> D;
+  d4 ab = xw_zero4();
+#pragma unroll
+  for (int ks = 0; ks < D::KSH; ++ks) ab = XW_MFMA(wT.WoT[ks], ob[ks >> 2][ks & 3], ab);
+  if (PARAMS) {
+    d4 a1 = sv.a;
+    set_row(a1, K, 1.0);  // ones row -> column K of the accumulator collects Wo.b's gradient
+#pragma unroll
+    for (int ht = 0; ht < D::HT; ++ht) outer_acc(G.Wo[ht], ob[ht], a1, lds);
+  }
+  d4 zb;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) zb[r] = ab[r] * (1.0 - sv.a[r] * sv.a[r]);
+#pragma unroll
+  for (int j = M - 2; j >= 0; --j) {
+    if (PARAMS) {
+      d4 rj = xw_relu(sv.z[j]);
+      set_row(rj, K, 1.0);
+      outer_acc(G.Wh, zb, rj, lds);
+    }
+    d4 tt = xw_zero4();
+#pragma unroll
+    for (int ks = 0; ks < D::KSK; ++ks) tt = XW_MFMA(wT.WhT[ks], zb[ks], tt);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) zb[r] = sv.z[j][r] > 0.0 ? tt[r] : 0.0;
+  }
+  xpb += zb;
+  if (PARAMS) {
+#pragma unroll
+    for (int ct = 0; ct < (H + 1 + 15) / 16; ++ct) {
+      d4 yy = ct < D::HT ? yin[ct < D::HT ? ct : 0] : xw_zero4();
+      if (ct == (H >> 4)) set_row(yy, H & 15, t);  // time row -> column H collects the time-column gradient
+      outer_acc(G.Wy[ct], zb, yy, lds);
+    }
+  }
+#pragma unroll
+  for (int ht = 0; ht < D::HT; ++ht) {
+    d4 v = xw_zero4();
+#pragma unroll
+    for (int ks = 0; ks < D::KSK; ++ks) v = XW_MFMA(wT.WyT[ht][ks], zb[ks], v);
+    yb[ht] = v;
+  }
+}
+
+// start scalar -> hidden state: initial_layers of src/model.py:78,97
+template <int H, int K>
+__device__ __forceinline__ void lift(const double* __restrict__ th, const UOff& o, double sv, d4 (&a0)[Dim<H, K>::HT],
+                                     d4 (&a1)[Dim<H, K>::HT], d4 (&y)[Dim<H, K>::HT]) {
+  typedef Dim<H, K> D;
+#pragma unroll
+  for (int ht = 0; ht < D::HT; ++ht)
+    a0[ht] = xw_relu(xw_vecD(th + o.IL0w, H, 16 * ht) * sv + xw_vecD(th + o.IL0b, H, 16 * ht));
+#pragma unroll
+  for (int ht = 0; ht < D::HT; ++ht) {
+    d4 v = xw_vecD(th + o.IL2b, H, 16 * ht);
+#pragma unroll
+    for (int ks = 0; ks < D::KSH; ++ks) v = XW_MFMA(xw_fragA(th + o.IL2w, H, H, H, 16 * ht, 4 * ks), a0[ks >> 2][ks & 3], v);
+    a1[ht] = xw_relu(v);
+  }
+#pragma unroll
+  for (int ht = 0; ht < D::HT; ++ht) {
+    d4 v = xw_vecD(th + o.IL4b, H, 16 * ht);
+#pragma unroll
+    for (int ks = 0; ks < D::KSH; ++ks) v = XW_MFMA(xw_fragA(th + o.IL4w, H, H, H, 16 * ht, 4 * ks), a1[ks >> 2][ks & 3], v);
+    y[ht] = v;
+  }
+}
+
+// xp = Win.b + Win[:, :d] x   (time-invariant along a path: src/model.py:99,154)
+template <int H, int K>
+__device__ __forceinline__ d4 project_x(const double* __restrict__ th, const UOff& o, const float* __restrict__ xT,
+                                        int N, int d, int ncl) {
+  const int g = xw_lane() >> 4;
+  d4 xp = xw_vecD(th + o.Winb, K, 0);
+  for (int ks = 0; ks < (d + 3) / 4; ++ks) {
+    const int i = 4 * ks + g;
+    const double b = i < d ? (double)xT[(long)i * N + ncl] : 0.0;
+    xp = XW_MFMA(xw_fragA(th + o.Win, o.ldin, K, d, 0, 4 * ks), b, xp);
+  }
+  return xp;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+template <int H, int K, int M, int METHOD>
+__global__ void __launch_bounds__(64) k_ode_fwd(const float* __restrict__ xT, const float* __restrict__ tf,
+                                                const double* __restrict__ start, const double* __restrict__ th,
+                                                int N, int L, int d, double* __restrict__ u, double* __restrict__ Y) {
+  typedef Dim<H, K> D;
+  typedef RK<METHOD> T;
+  const int lane = xw_lane(), g = lane >> 4, n = lane & 15;
+  const int base = blockIdx.x * 16;
+  const bool valid = base + n < N;
+  const int ncl = valid ? base + n : N - 1;
+  const UOff o = u_offsets(d, H, K);
+  FieldW<H, K> w;
+  load_field<H, K>(th, o, d, w);
+  d4 a0[D::HT], a1[D::HT], y[D::HT], flw[D::HT];
+  lift<H, K>(th, o, start[ncl], a0, a1, y);
+  const d4 xp = project_x<H, K>(th, o, xT, N, d, ncl);
+#pragma unroll
+  for (int ht = 0; ht < D::HT; ++ht) flw[ht] = xw_vecD(th + o.FLw, H, 16 * ht);
+  const double flb = th[o.FLb];
+  Save<M> dummy;
+  for (int l = 0; l < L; ++l) {
+    double part = 0.0;
+#pragma unroll
+    for (int ht = 0; ht < D::HT; ++ht)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * ht + g + 4 * r;
+        part += flw[ht][r] * y[ht][r];
+        if (Y != nullptr && valid && row < H) Y[((long)l * H + row) * N + base + n] = y[ht][r];
+      }
+    const double ul = xw_sum_over_g(part) + flb;           // final_linear, src/model.py:110
+    if (g == 0 && valid) u[(long)l * N + base + n] = ul;
+    if (l == L - 1) break;
+    const double t0 = (double)tf[l], dt = (double)tf[l + 1] - t0;
+    d4 k[T::S][D::HT];
+#pragma unroll
+    for (int i = 0; i < T::S; ++i) {
+      d4 yi[D::HT];
+#pragma unroll
+      for (int ht = 0; ht < D::HT; ++ht) {
+        yi[ht] = y[ht];
+#pragma unroll
+        for (int j = 0; j < i; ++j)
+          if (T::a(i, j) != 0.0) yi[ht] += (dt * T::a(i, j)) * k[j][ht];
+      }
+      field_fwd<H, K, M, false>(w, t0 + T::c(i) * dt, xp, yi, k[i], dummy);
+    }
+#pragma unroll
+    for (int i = 0; i < T::S; ++i)
+      if (T::b(i) != 0.0)
+#pragma unroll
+        for (int ht = 0; ht < D::HT; ++ht) y[ht] += (dt * T::b(i)) * k[i][ht];
+  }
+}
+
+// store a chain-layout accumulator tile (rows r0.., cols c0..) into a row-major matrix
+__device__ __forceinline__ void storeD(double* dst, int ld, int rows, int cols, int r0, int c0, d4 acc) {
+  const int lane = xw_lane(), g = lane >> 4, c = c0 + (lane & 15);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = r0 + g + 4 * r;
+    if (row < rows && c < cols) dst[row * ld + c] = acc[r];
+  }
+}
+// store column `col` of a chain-layout accumulator tile as a (strided) vector
+__device__ __forceinline__ void storeDcol(double* dst, int stride, int rows, int r0, int col, d4 acc) {
+  const int lane = xw_lane(), g = lane >> 4;
+  if ((lane & 15) != col) return;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = r0 + g + 4 * r;
+    if (row < rows) dst[(long)row * stride] = acc[r];
+  }
+}
+// row sums over the 16 paths of a chain tile -> vector
+__device__ __forceinline__ void storeRowSums(double* dst, int rows, int r0, d4 q) {
+  const int lane = xw_lane(), g = lane >> 4;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const double s = xw_sum_over_n(q[r]);
+    const int row = r0 + g + 4 * r;
+    if ((lane & 15) == 0 && row < rows) dst[row] = s;
+  }
+}
+
+template <int H, int K, int M, int METHOD, bool PARAMS>
+__global__ void __launch_bounds__(64) k_ode_bwd(const float* __restrict__ xT, const float* __restrict__ tf,
+                                                const double* __restrict__ start, const double* __restrict__ th,
+                                                const double* __restrict__ Y, const double* __restrict__ ubar,
+                                                int N, int L, int d, double* __restrict__ gx, double* __restrict__ gs,
+                                                double* __restrict__ gslab) {
+  typedef Dim<H, K> D;
+  typedef RK<METHOD> T;
+  __shared__ double lds[2 * XW_TTILE];
+  const int lane = xw_lane(), g = lane >> 4, n = lane & 15;
+  const int base = blockIdx.x * 16;
+  const bool valid = base + n < N;
+  const int ncl = valid ? base + n : N - 1;
+  const UOff o = u_offsets(d, H, K);
+  FieldW<H, K> w;
+  FieldWT<H, K> wT;
+  load_field<H, K>(th, o, d, w);
+  load_field_T<H, K>(th, o, d, wT);
+  const d4 xp = project_x<H, K>(th, o, xT, N, d, ncl);
+  d4 flw[D::HT];
+#pragma unroll
+  for (int ht = 0; ht < D::HT; ++ht) flw[ht] = xw_vecD(th + o.FLw, H, 16 * ht);
+
+  FieldG<H, K> G;
+  G.Wh = xw_zero4();
+#pragma unroll
+  for (int ct = 0; ct < (H + 1 + 15) / 16; ++ct) G.Wy[ct] = xw_zero4();
+#pragma unroll
+  for (int ht = 0; ht < D::HT; ++ht) G.Wo[ht] = xw_zero4();
+  d4 accFL[D::HT];
+#pragma unroll
+  for (int ht = 0; ht < D::HT; ++ht) accFL[ht] = xw_zero4();
+  double accFLb = 0.0;
+  d4 lam[D::HT];
+#pragma unroll
+  for (int ht = 0; ht < D::HT; ++ht) lam[ht] = xw_zero4();
+  d4 xpb = xw_zero4();
+
+  for (int l = L - 1; l >= 0; --l) {
+    d4 y[D::HT];
+#pragma unroll
+    for (int ht = 0; ht < D::HT; ++ht)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * ht + g + 4 * r;
+        y[ht][r] = row < H ? Y[((long)l * H + row) * N + ncl] : 0.0;
+      }
+    if (l < L - 1) {
+      // reverse of the step l -> l+1 : lam currently holds the total cotangent of y_{l+1}
+      const double t0 = (double)tf[l], dt = (double)tf[l + 1] - t0;
+      d4 k[T::S][D::HT], kb[T::S][D::HT], psum[D::HT];
+      Save<M> sv;
+#pragma unroll
+      for (int i = 0; i < T::S - 1; ++i) {      // stage derivatives needed to rebuild the later stage inputs
+        d4 yi[D::HT];
+#pragma unroll
+        for (int ht = 0; ht < D::HT; ++ht) {
+          yi[ht] = y[ht];
+#pragma unroll
+          for (int j = 0; j < i; ++j)
+            if (T::a(i, j) != 0.0) yi[ht] += (dt * T::a(i, j)) * k[j][ht];
+        }
+        field_fwd<H, K, M, false>(w, t0 + T::c(i) * dt, xp, yi, k[i], sv);
+      }
+#pragma unroll
+      for (int i = 0; i < T::S; ++i)
+#pragma unroll
+        for (int ht = 0; ht < D::HT; ++ht) {
+          kb[i][ht] = (dt * T::b(i)) * lam[ht];
+          if (i == 0) psum[ht] = xw_zero4();
+        }
+#pragma unroll
+      for (int i = T::S - 1; i >= 0; --i) {
+        d4 yi[D::HT], ko[D::HT], psi[D::HT];
+#pragma unroll
+        for (int ht = 0; ht < D::HT; ++ht) {
+          yi[ht] = y[ht];
+#pragma unroll
+          for (int j = 0; j < i; ++j)
+            if (T::a(i, j) != 0.0) yi[ht] += (dt * T::a(i, j)) * k[j][ht];
+        }
+        const double ti = t0 + T::c(i) * dt;
+        field_fwd<H, K, M, true>(w, ti, xp, yi, ko, sv);
+        field_vjp<H, K, M, PARAMS>(w, wT, ti, sv, yi, kb[i], psi, xpb, G, lds);
+#pragma unroll
+        for (int ht = 0; ht < D::HT; ++ht) {
+          psum[ht] += psi[ht];
+#pragma unroll
+          for (int j = 0; j < i; ++j)
+            if (T::a(i, j) != 0.0) kb[j][ht] += (dt * T::a(i, j)) * psi[ht];
+        }
+      }
+#pragma unroll
+      for (int ht = 0; ht < D::HT; ++ht) lam[ht] += psum[ht];
+    }
+    // read-out u_l = FL y_l + b
+    const double ub = valid ? (ubar != nullptr ? ubar[(long)l * N + base + n] : 1.0) : 0.0;
+#pragma unroll
+    for (int ht = 0; ht < D::HT; ++ht) {
+      lam[ht] += flw[ht] * ub;
+      if (PARAMS) accFL[ht] += y[ht] * ub;
+    }
+    if (PARAMS) accFLb += ub;
+  }
+
+  // ---- x-projection: cotangent of x, gradients of Win[:, :d] and Win.b -----------------------------------------
+  if (gx != nullptr) {
+    for (int rt = 0; rt < (d + 15) / 16; ++rt) {
+      d4 v = xw_zero4();
+#pragma unroll
+      for (int ks = 0; ks < D::KSK; ++ks) v = XW_MFMA(xw_fragAT(th + o.Win, o.ldin, K, d, 16 * rt, 4 * ks), xpb[ks], v);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 16 * rt + g + 4 * r;
+        if (i < d && valid) gx[(long)i * N + base + n] = v[r];
+      }
+    }
+  }
+  double* slab = PARAMS ? gslab + (long)blockIdx.x * o.total : nullptr;
+  if (PARAMS) {
+    xw_writeT(lds, xpb);
+    __syncthreads();
+    for (int ct = 0; ct < (d + 15) / 16; ++ct) {
+      d4 acc = xw_zero4();
+      const int i = 16 * ct + (lane & 15);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int pn = base + 4 * ks + (lane >> 4);
+        const double b = (i < d && pn < N) ? (double)xT[(long)i * N + pn] : 0.0;
+        acc = XW_MFMA(xw_readT(lds, ks), b, acc);
+      }
+      storeD(slab + o.Win, o.ldin, K, d, 0, 16 * ct, acc);
+    }
+    __syncthreads();
+    storeRowSums(slab + o.Winb, K, 0, xpb);
+    storeD(slab + o.Wh, K, K, K, 0, 0, G.Wh);
+    storeDcol(slab + o.Whb, 1, K, 0, K, G.Wh);
+#pragma unroll
+    for (int ct = 0; ct < (H + 1 + 15) / 16; ++ct) {
+      storeD(slab + o.Win + d + 1, o.ldin, K, H, 0, 16 * ct, G.Wy[ct]);
+      if (ct == (H >> 4)) storeDcol(slab + o.Win + d, o.ldin, K, 0, H & 15, G.Wy[ct]);
+    }
+#pragma unroll
+    for (int ht = 0; ht < D::HT; ++ht) {
+      storeD(slab + o.Wo, K, H, K, 16 * ht, 0, G.Wo[ht]);
+      storeDcol(slab + o.Wob, 1, H, 16 * ht, K, G.Wo[ht]);
+      storeRowSums(slab + o.FLw, H, 16 * ht, accFL[ht]);
+    }
+    const double sb = xw_sum_over_n(accFLb);
+    if (lane == 0) slab[o.FLb] = sb;
+  }
+
+  // ---- initial layers: lam = cotangent of y_0 ----------------------------------------------------------------------
+  {
+    const double sv = start[ncl];
+    d4 a0[D::HT], a1[D::HT], y0[D::HT];
+    lift<H, K>(th, o, sv, a0, a1, y0);
+    d4 d1[D::HT], d0[D::HT];
+    if (PARAMS) {
+#pragma unroll
+      for (int rt = 0; rt < D::HT; ++rt) {
+#pragma unroll
+        for (int ct = 0; ct < D::HT; ++ct) {
+          d4 acc = xw_zero4();
+          outer_acc(acc, lam[rt], a1[ct], lds);
+          storeD(slab + o.IL4w, H, H, H, 16 * rt, 16 * ct, acc);
+        }
+        storeRowSums(slab + o.IL4b, H, 16 * rt, lam[rt]);
+      }
+    }
+#pragma unroll
+    for (int ht = 0; ht < D::HT; ++ht) {
+      d4 v = xw_zero4();
+#pragma unroll
+      for (int ks = 0; ks < D::KSH; ++ks) v = XW_MFMA(xw_fragAT(th + o.IL4w, H, H, H, 16 * ht, 4 * ks), lam[ks >> 2][ks & 3], v);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) d1[ht][r] = a1[ht][r] > 0.0 ? v[r] : 0.0;
+    }
+    if (PARAMS) {
+#pragma unroll
+      for (int rt = 0; rt < D::HT; ++rt) {
+#pragma unroll
+        for (int ct = 0; ct < D::HT; ++ct) {
+          d4 acc = xw_zero4();
+          outer_acc(acc, d1[rt], a0[ct], lds);
+          storeD(slab + o.IL2w, H, H, H, 16 * rt, 16 * ct, acc);
+        }
+        storeRowSums(slab + o.IL2b, H, 16 * rt, d1[rt]);
+      }
+    }
+    double gpart = 0.0;
+#pragma unroll
+    for (int ht = 0; ht < D::HT; ++ht) {
+      d4 v = xw_zero4();
+#pragma unroll
+      for (int ks = 0; ks < D::KSH; ++ks) v = XW_MFMA(xw_fragAT(th + o.IL2w, H, H, H, 16 * ht, 4 * ks), d1[ks >> 2][ks & 3], v);
+      const d4 w0 = xw_vecD(th + o.IL0w, H, 16 * ht);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        d0[ht][r] = a0[ht][r] > 0.0 ? v[r] : 0.0;
+        gpart += w0[r] * d0[ht][r];
+      }
+      if (PARAMS) {
+        storeRowSums(slab + o.IL0w, H, 16 * ht, d0[ht] * sv);
+        storeRowSums(slab + o.IL0b, H, 16 * ht, d0[ht]);
+      }
+    }
+    const double gsn = xw_sum_over_g(gpart);
+    if (gs != nullptr && g == 0 && valid) gs[base + n] = gsn;
+  }
+}
+
+template <int H, int K, int M>
+int launch_fwd(int method, const float* xT, const float* t, const double* start, const double* theta, int N, int L, int d,
+               double* u, double* Y, hipStream_t s) {
+  const dim3 grid((N + 15) / 16), block(64);
+  switch (method) {
+    case 0: hipLaunchKernelGGL((k_ode_fwd<H, K, M, 0>), grid, block, 0, s, xT, t, start, theta, N, L, d, u, Y); break;
+    case 1: hipLaunchKernelGGL((k_ode_fwd<H, K, M, 1>), grid, block, 0, s, xT, t, start, theta, N, L, d, u, Y); break;
+    case 2: hipLaunchKernelGGL((k_ode_fwd<H, K, M, 2>), grid, block, 0, s, xT, t, start, theta, N, L, d, u, Y); break;
+    default: return XW_E_ARG;
+  }
+  return xw_launch_status();
+}
+template <int H, int K, int M, bool PARAMS>
+int launch_bwd(int method, const float* xT, const float* t, const double* start, const double* theta, const double* Y,
+               const double* ubar, int N, int L, int d, double* gx, double* gs, double* gslab, hipStream_t s) {
+  const dim3 grid((N + 15) / 16), block(64);
+  switch (method) {
+    case 0: hipLaunchKernelGGL((k_ode_bwd<H, K, M, 0, PARAMS>), grid, block, 0, s, xT, t, start, theta, Y, ubar, N, L, d, gx, gs, gslab); break;
+    case 1: hipLaunchKernelGGL((k_ode_bwd<H, K, M, 1, PARAMS>), grid, block, 0, s, xT, t, start, theta, Y, ubar, N, L, d, gx, gs, gslab); break;
+    case 2: hipLaunchKernelGGL((k_ode_bwd<H, K, M, 2, PARAMS>), grid, block, 0, s, xT, t, start, theta, Y, ubar, N, L, d, gx, gs, gslab); break;
+    default: return XW_E_ARG;
+  }
+  return xw_launch_status();
+}
+
+}  // namespace
+
+// instantiated (u_hidden_dim, u_hidden_hidden_dim, u_layers) triples; the reference's YAML/notebook use (20, 10, 8)
+#define XW_ODE_DISPATCH(CALL)                     \
+  if (H == 20 && K == 10 && m == 8) { CALL(20, 10, 8) } \
+  else if (H == 20 && K == 10 && m == 4) { CALL(20, 10, 4) } \
+  else if (H == 20 && K == 10 && m == 2) { CALL(20, 10, 2) } \
+  else return XW_E_DIMS;
+
+extern "C" int xw_ode_bwd_slabs(int N) { return (N + 15) / 16; }
+
+extern "C" int xw_ode_fwd(const float* xT, const float* t, const double* start, const double* theta, int method, int N,
+                          int L, int d, int H, int K, int m, double* u, double* Y, void* stream) {
+  if (!xT || !t || !start || !theta || !u || N <= 0 || L <= 0 || d <= 0 || m < 1) return XW_E_ARG;
+  hipStream_t s = (hipStream_t)stream;
+#define CALL(HH, KK, MM) return launch_fwd<HH, KK, MM>(method, xT, t, start, theta, N, L, d, u, Y, s);
+  XW_ODE_DISPATCH(CALL)
+#undef CALL
+}
+
+extern "C" int xw_ode_bwd(const float* xT, const float* t, const double* start, const double* theta, const double* Y,
+                          const double* ubar, int method, int N, int L, int d, int H, int K, int m, int mode, double* gx,
+                          double* gs, double* gslab, void* stream) {
+  if (!xT || !t || !start || !theta || !Y || N <= 0 || L <= 0 || d <= 0 || m < 1 || (mode & 3) == 0) return XW_E_ARG;
+  if ((mode & 2) && !gslab) return XW_E_ARG;
+  if ((mode & 1) && (!gx || !gs)) return XW_E_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  double* gx_ = (mode & 1) ? gx : nullptr;
+  double* gs_ = (mode & 1) ? gs : nullptr;
+#define CALL(HH, KK, MM)                                                                                               \
+  return (mode & 2) ? launch_bwd<HH, KK, MM, true>(method, xT, t, start, theta, Y, ubar, N, L, d, gx_, gs_, gslab, s) \
+                    : launch_bwd<HH, KK, MM, false>(method, xT, t, start, theta, Y, ubar, N, L, d, gx_, gs_, gslab, s);
+  XW_ODE_DISPATCH(CALL)
+#undef CALL
+}

@@ -1,0 +1,207 @@
+"""Tensor-level wrappers around the C ABI: every operand is validated on the host (device, dtype, contiguity,
+shape) BEFORE a kernel is enqueued, then passed as a raw device pointer together with torch's current stream.
+
+Conventions (include/xnwan.h): point arrays are time-major [L, N]; coordinates are transposed xT[d, N] float32.
+"""
+import torch
+
+from ._lib import lib, check, XnwanError
+
+METHODS = {'euler': 0, 'midpoint': 1, 'rk4': 2}
+F32, F64 = torch.float32, torch.float64
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        raise XnwanError('no GPU visible: the XNODE-WAN kernels only run on an MI355X (gfx950); there is no CPU path')
+
+
+def _chk(t, dtype, shape, name):
+    if t is None:
+        return
+    if not (torch.is_tensor(t) and t.is_cuda):
+        raise XnwanError('%s must be a CUDA/HIP tensor' % name)
+    if t.dtype != dtype:
+        raise XnwanError('%s must be %s, got %s' % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise XnwanError('%s must be contiguous' % name)
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise XnwanError('%s must have shape %s, got %s' % (name, tuple(shape), tuple(t.shape)))
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def method_id(name):
+    if name not in METHODS:
+        raise XnwanError("solver %r is not a fixed-grid scheme of this engine (have: %s)" % (name, sorted(METHODS)))
+    return METHODS[name]
+
+
+def theta_size(d, H, K):
+    return lib.xw_theta_size(d, H, K)
+
+
+def phi_size(d, W):
+    return lib.xw_phi_size(d, W)
+
+
+def ode_fwd(xT, t, start, theta, method, H, K, m, want_Y=True, u=None, Y=None):
+    """u_theta on N paths: returns (u[L,N], Y[L,H,N] or None)."""
+    _need_gpu()
+    d, N = xT.shape
+    L = t.shape[0]
+    _chk(xT, F32, (d, N), 'xT'); _chk(t, F32, (L,), 't'); _chk(start, F64, (N,), 'start')
+    _chk(theta, F64, (theta_size(d, H, K),), 'theta')
+    if u is None:
+        u = torch.empty(L, N, dtype=F64, device=xT.device)
+    if Y is None and want_Y:
+        Y = torch.empty(L, H, N, dtype=F64, device=xT.device)
+    _chk(u, F64, (L, N), 'u'); _chk(Y, F64, (L, H, N), 'Y')
+    check(lib.xw_ode_fwd(_p(xT), _p(t), _p(start), _p(theta), method, N, L, d, H, K, m, _p(u), _p(Y), _stream()), 'xw_ode_fwd')
+    return u, Y
+
+
+def ode_bwd_slabs(N):
+    return lib.xw_ode_bwd_slabs(N)
+
+
+def ode_bwd(xT, t, start, theta, Y, ubar, method, H, K, m, want_x=True, want_params=False, gx=None, gs=None, gslab=None):
+    """reverse sweep: returns (gx[d,N], gs[N], gslab[nslab,P_u]) -- entries not requested are None."""
+    _need_gpu()
+    d, N = xT.shape
+    L = t.shape[0]
+    P = theta_size(d, H, K)
+    _chk(xT, F32, (d, N), 'xT'); _chk(t, F32, (L,), 't'); _chk(start, F64, (N,), 'start'); _chk(theta, F64, (P,), 'theta')
+    _chk(Y, F64, (L, H, N), 'Y'); _chk(ubar, F64, (L, N), 'ubar')
+    mode = (1 if want_x else 0) | (2 if want_params else 0)
+    if want_x:
+        gx = torch.empty(d, N, dtype=F64, device=xT.device) if gx is None else gx
+        gs = torch.empty(N, dtype=F64, device=xT.device) if gs is None else gs
+        _chk(gx, F64, (d, N), 'gx'); _chk(gs, F64, (N,), 'gs')
+    if want_params:
+        ns = ode_bwd_slabs(N)
+        gslab = torch.empty(ns, P, dtype=F64, device=xT.device) if gslab is None else gslab
+        _chk(gslab, F64, (ns, P), 'gslab')
+    check(lib.xw_ode_bwd(_p(xT), _p(t), _p(start), _p(theta), _p(Y), _p(ubar), method, N, L, d, H, K, m, mode,
+                         _p(gx if want_x else None), _p(gs if want_x else None), _p(gslab if want_params else None),
+                         _stream()), 'xw_ode_bwd')
+    return (gx if want_x else None), (gs if want_x else None), (gslab if want_params else None)
+
+
+def disc_fwd(xT, t, phi, W, q, tpp=None, want_vt=True, v=None, vt=None):
+    """v_phi and dv/dt.  Path mode: points (t[l], x_n) -> [L,N].  Point mode (tpp[N]): points (tpp[n], x_n) -> [1,N]."""
+    _need_gpu()
+    d, N = xT.shape
+    L = 1 if tpp is not None else t.shape[0]
+    _chk(xT, F32, (d, N), 'xT'); _chk(phi, F64, (phi_size(d, W),), 'phi')
+    _chk(t, F32, None, 't'); _chk(tpp, F32, (N,), 'tpp')
+    v = torch.empty(L, N, dtype=F64, device=xT.device) if v is None else v
+    if want_vt and vt is None:
+        vt = torch.empty(L, N, dtype=F64, device=xT.device)
+    _chk(v, F64, (L, N), 'v'); _chk(vt, F64, (L, N), 'vt')
+    check(lib.xw_disc_fwd(_p(xT), _p(t), _p(tpp), _p(phi), N, L, d, W, q, _p(v), _p(vt if want_vt else None), 0, _stream()),
+          'xw_disc_fwd')
+    return v, (vt if want_vt else None)
+
+
+def disc_gradx(xT, t, phi, W, q, tpp=None, gxv=None, gtv=None):
+    """(nabla_x v)[d,N] and (dv/dt)[N] at the points (tpp[n] or t[0], x_n)."""
+    _need_gpu()
+    d, N = xT.shape
+    _chk(xT, F32, (d, N), 'xT'); _chk(phi, F64, (phi_size(d, W),), 'phi'); _chk(t, F32, None, 't'); _chk(tpp, F32, (N,), 'tpp')
+    gxv = torch.empty(d, N, dtype=F64, device=xT.device) if gxv is None else gxv
+    gtv = torch.empty(N, dtype=F64, device=xT.device) if gtv is None else gtv
+    _chk(gxv, F64, (d, N), 'gxv'); _chk(gtv, F64, (N,), 'gtv')
+    check(lib.xw_disc_gradx(_p(xT), _p(t), _p(tpp), _p(phi), N, d, W, q, _p(gxv), _p(gtv), _stream()), 'xw_disc_gradx')
+    return gxv, gtv
+
+
+def disc_bwd_slabs(N, L):
+    return lib.xw_disc_bwd_slabs(N, L)
+
+
+def disc_bwd(xT, t, phi, vbar, W, q, tpp=None, gslab=None):
+    """parameter gradient of <vbar, v> as partial slabs [nslab, P_v]."""
+    _need_gpu()
+    d, N = xT.shape
+    L = 1 if tpp is not None else t.shape[0]
+    P = phi_size(d, W)
+    _chk(xT, F32, (d, N), 'xT'); _chk(phi, F64, (P,), 'phi'); _chk(vbar, F64, (L, N), 'vbar')
+    _chk(t, F32, None, 't'); _chk(tpp, F32, (N,), 'tpp')
+    ns = disc_bwd_slabs(N, L)
+    gslab = torch.empty(ns, P, dtype=F64, device=xT.device) if gslab is None else gslab
+    _chk(gslab, F64, (ns, P), 'gslab')
+    check(lib.xw_disc_bwd(_p(xT), _p(t), _p(tpp), _p(phi), 0, _p(vbar), N, L, d, W, q, _p(gslab), _stream()), 'xw_disc_bwd')
+    return gslab
+
+
+def weak_partials(u, v, vt, w, s3x, f, h, Vol, Nglob, scal, c=None, ckappa=0.0, wt=None):
+    _need_gpu()
+    L, N = u.shape
+    for name, a in (('u', u), ('v', v), ('vt', vt), ('f', f)):
+        _chk(a, F64, (L, N), name)
+    per_point = 1 if w.dim() == 2 else 0
+    _chk(w, F64, (L, N) if per_point else (N,), 'w'); _chk(wt, F64, (L, N), 'wt'); _chk(c, F64, (L, N), 'c')
+    _chk(s3x, F64, (N,), 's3x'); _chk(h, F64, (N,), 'h'); _chk(scal, F64, (16,), 'scal')
+    check(lib.xw_weak_partials(_p(u), _p(v), _p(vt), _p(w), per_point, _p(wt), _p(s3x), _p(c), float(ckappa), _p(f), _p(h),
+                               N, L, float(Vol), float(Nglob), _p(scal), _stream()), 'xw_weak_partials')
+
+
+def bdry_partials(ub, g, alpha, Nbglob, scal, ubar_b=None):
+    _need_gpu()
+    L, Nb = ub.shape
+    _chk(ub, F64, (L, Nb), 'ub'); _chk(g, F64, (L, Nb), 'g'); _chk(ubar_b, F64, (L, Nb), 'ubar_b'); _chk(scal, F64, (16,), 'scal')
+    check(lib.xw_bdry_partials(_p(ub), _p(g), Nb, L, float(alpha), float(Nbglob), _p(ubar_b), _p(scal), _stream()),
+          'xw_bdry_partials')
+
+
+def gen_cotangent(u, v, w, h, Vol, Nglob, Nbglob, alpha, scal, ubar, c=None, cp=None, ckappa=0.0, pollution=1.0):
+    _need_gpu()
+    L, N = u.shape
+    per_point = 1 if w.dim() == 2 else 0
+    _chk(u, F64, (L, N), 'u'); _chk(v, F64, (L, N), 'v'); _chk(w, F64, (L, N) if per_point else (N,), 'w')
+    _chk(c, F64, (L, N), 'c'); _chk(cp, F64, (L, N), 'cp'); _chk(h, F64, (N,), 'h'); _chk(ubar, F64, (L, N), 'ubar')
+    _chk(scal, F64, (16,), 'scal')
+    check(lib.xw_gen_cotangent(_p(u), _p(v), _p(w), per_point, _p(c), _p(cp), float(ckappa), _p(h), N, L, float(Vol),
+                               float(Nglob), float(Nbglob), float(alpha), float(pollution), _p(scal), _p(ubar), _p(scal),
+                               _stream()), 'xw_gen_cotangent')
+
+
+def disc_cotangent(u, v, w, f, h, Vol, Nglob, scal, vbar, c=None, ckappa=0.0, pollution=1.0):
+    _need_gpu()
+    L, N = u.shape
+    per_point = 1 if w.dim() == 2 else 0
+    _chk(u, F64, (L, N), 'u'); _chk(v, F64, (L, N), 'v'); _chk(w, F64, (L, N) if per_point else (N,), 'w')
+    _chk(c, F64, (L, N), 'c'); _chk(f, F64, (L, N), 'f'); _chk(h, F64, (N,), 'h'); _chk(vbar, F64, (L, N), 'vbar')
+    _chk(scal, F64, (16,), 'scal')
+    check(lib.xw_disc_cotangent(_p(u), _p(v), _p(w), per_point, _p(c), float(ckappa), _p(f), _p(h), N, L, float(Vol),
+                                float(Nglob), float(pollution), _p(scal), _p(vbar), _p(scal), _stream()), 'xw_disc_cotangent')
+
+
+def adam(param, gslab, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, gextra=None, gsum_out=None):
+    _need_gpu()
+    P = param.shape[0]
+    _chk(param, F64, (P,), 'param'); _chk(m, F64, (P,), 'm'); _chk(v, F64, (P,), 'v'); _chk(step, torch.int64, (1,), 'step')
+    ns = 0
+    if gslab is not None:
+        ns = gslab.shape[0]
+        _chk(gslab, F64, (ns, P), 'gslab')
+    _chk(gextra, F64, (P,), 'gextra'); _chk(gsum_out, F64, (P,), 'gsum_out')
+    check(lib.xw_adam(_p(param), _p(gslab), ns, _p(gextra), _p(m), _p(v), _p(step), P, float(lr), float(beta1), float(beta2),
+                      float(eps), _p(gsum_out), _stream()), 'xw_adam')
+
+
+def slab_sum(gslab, out=None, accumulate=False):
+    _need_gpu()
+    ns, P = gslab.shape
+    _chk(gslab, F64, (ns, P), 'gslab')
+    out = torch.empty(P, dtype=F64, device=gslab.device) if out is None else out
+    _chk(out, F64, (P,), 'out')
+    check(lib.xw_slab_sum(_p(gslab), ns, P, 1 if accumulate else 0, _p(out), _stream()), 'xw_slab_sum')
+    return out

@@ -1,0 +1,243 @@
+"""Network shells: nn.Modules with the reference's attribute names / state_dict keys whose parameters are VIEWS into
+one flat float64 blob per network -- the blob is what the HIP kernels read and what the fused Adam kernel updates.
+
+Call surface mirrored (file:line into the reference):
+    XNODE            <- NeuralODE        src/model.py:54-112      u_theta: lift h/g -> hidden state, fixed-grid ODE, read-out
+    HiddenField      <- _ODEField        src/model.py:115-141     the field MLP (one weight-tied hidden Linear)
+    TestNet          <- discriminator    src/model.py:18-51       v_phi (one weight-tied hidden Linear)
+    PathParallel     <- nn.DataParallel  src/training.py:93-97    only the `.module` wrapper / `module.` key prefix; the
+                                                                  actual multi-GPU strategy is in dist.py
+    init_weights                          src/model.py:12-15
+Module construction order and `apply(init_weights)` order are the reference's, so seeded runs draw identical weights
+(pinned by tests/golden).
+
+The modules' forward()/backward run on the HIP kernels through two autograd Functions, so `u_net(X)`, `v_net(XV)`,
+`.backward()` and torch optimisers keep working for user code; the training loop itself does not use autograd at all
+(engine.py).
+"""
+import torch
+from torch import nn
+
+from . import kernels as KN
+from ._lib import XnwanError
+
+F64 = torch.float64
+
+
+def init_weights(layer):
+    """Xavier-uniform weights, zero bias on every Linear (reference src/model.py:12-15)."""
+    if type(layer) == nn.Linear:
+        nn.init.xavier_uniform_(layer.weight)
+        layer.bias.data.fill_(0)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# flat parameter storage
+# ----------------------------------------------------------------------------------------------------------------------
+class Blob:
+    """One contiguous float64 vector holding all parameters of a network in named_parameters() order."""
+
+    def __init__(self, module, device):
+        params = [p for _, p in module.named_parameters()]      # de-duplicated: tied layers appear once
+        self.names = [n for n, _ in module.named_parameters()]
+        self.shapes = [tuple(p.shape) for p in params]
+        self.sizes = [p.numel() for p in params]
+        self.data = torch.empty(sum(self.sizes), dtype=F64, device=device)
+        self.grad = torch.zeros_like(self.data)
+        off = 0
+        self.offsets = []
+        for p, n in zip(params, self.sizes):
+            if p.dtype != F64:
+                raise XnwanError('network parameters must be float64 (the reference computes in float64 throughout)')
+            self.data[off:off + n].copy_(p.data.reshape(-1))
+            p.data = self.data[off:off + n].view(p.shape)       # parameter now aliases the blob
+            self.offsets.append(off)
+            off += n
+        self.params = params
+
+    def split(self, flat):
+        return [flat[o:o + n].view(s) for o, n, s in zip(self.offsets, self.sizes, self.shapes)]
+
+    def check_alias(self):
+        """The kernels read the blob, user code sees the Parameters: make sure they are still the same memory."""
+        for p, o in zip(self.params, self.offsets):
+            if p.data.data_ptr() != self.data.data_ptr() + 8 * o:
+                raise XnwanError('a parameter no longer aliases its blob (module moved/cast after construction?) -- '
+                                 'call solver.rebind() after .to()/.double()')
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# autograd bridges (compat path for user code; the training loop calls the kernels directly)
+# ----------------------------------------------------------------------------------------------------------------------
+class _OdeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, X, start, net, *params):
+        xT = X[:, 0, 1:].detach().to(torch.float32).t().contiguous()
+        t = X[0, :, 0].detach().to(torch.float32).contiguous()
+        s = start.detach().to(F64).reshape(-1).contiguous()
+        blob = net.blob
+        blob.check_alias()
+        need = any(ctx.needs_input_grad)
+        u, Y = KN.ode_fwd(xT, t, s, blob.data, net.method, net.hidden_dim, net.hidden_hidden_dim, net.num_layers, want_Y=need)
+        ctx.net, ctx.x_dtype, ctx.x_shape, ctx.s_shape, ctx.s_dtype = net, X.dtype, X.shape, start.shape, start.dtype
+        ctx.save_for_backward(xT, t, s, Y if need else None)
+        return u.t().unsqueeze(2)
+
+    @staticmethod
+    def backward(ctx, gu):
+        net = ctx.net
+        xT, t, s, Y = ctx.saved_tensors
+        ubar = gu.squeeze(2).t().contiguous().to(F64)
+        want_p = any(ctx.needs_input_grad[3:])
+        gx, gs, slab = KN.ode_bwd(xT, t, s, net.blob.data, Y, ubar, net.method, net.hidden_dim, net.hidden_hidden_dim,
+                                  net.num_layers, want_x=True, want_params=want_p)
+        gX = None
+        if ctx.needs_input_grad[0]:
+            # nabla_x u is deposited at time index 0 (the model reads x from slice 0 only, src/model.py:99); the time
+            # channel's gradient (non-zero only on path 0 in the reference, never read by the loss) is returned as 0
+            gX = torch.zeros(ctx.x_shape, dtype=ctx.x_dtype, device=gu.device)
+            gX[:, 0, 1:] = gx.t().to(ctx.x_dtype)
+        gS = gs.view(ctx.s_shape).to(ctx.s_dtype) if ctx.needs_input_grad[1] else None
+        gp = [None] * len(net.blob.params)
+        if want_p:
+            gp = net.blob.split(KN.slab_sum(slab))
+        return (gX, gS, None) + tuple(gp)
+
+
+class _DiscFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, XV, net, *params):
+        pts = XV.detach().reshape(-1, XV.shape[-1])
+        xT = pts[:, 1:].to(torch.float32).t().contiguous()
+        tpp = pts[:, 0].to(torch.float32).contiguous()
+        net.blob.check_alias()
+        v, _ = KN.disc_fwd(xT, None, net.blob.data, net.hidden_dim, net.num_layers, tpp=tpp, want_vt=False)
+        ctx.net, ctx.shape, ctx.dtype = net, XV.shape, XV.dtype
+        ctx.save_for_backward(xT, tpp)
+        return v.view(XV.shape[:-1]).unsqueeze(-1)
+
+    @staticmethod
+    def backward(ctx, gv):
+        net = ctx.net
+        xT, tpp = ctx.saved_tensors
+        vbar = gv.reshape(1, -1).contiguous().to(F64)
+        gX = None
+        if ctx.needs_input_grad[0]:
+            gxv, gtv = KN.disc_gradx(xT, None, net.blob.data, net.hidden_dim, net.num_layers, tpp=tpp, vbar=vbar)
+            gX = torch.cat((gtv.view(-1, 1), gxv.t()), 1).view(ctx.shape).to(ctx.dtype)
+        gp = [None] * len(net.blob.params)
+        if any(ctx.needs_input_grad[2:]):
+            gp = net.blob.split(KN.slab_sum(KN.disc_bwd(xT, None, net.blob.data, vbar, net.hidden_dim, net.num_layers, tpp=tpp)))
+        return (gX, None) + tuple(gp)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# modules
+# ----------------------------------------------------------------------------------------------------------------------
+class HiddenField(nn.Module):
+    """dh/dt = F([x, t, h]): Linear(H+d+1, K) -> (ReLU -> tied Linear(K, K)) x (layers-1) -> Tanh -> Linear(K, H)."""
+
+    def __init__(self, input_dim, setup, num_layers, hidden_dim):
+        super().__init__()
+        self.input_dim, self.hidden_dim, self.num_layers = input_dim, hidden_dim, num_layers
+        if num_layers < 1:
+            raise XnwanError('u_layers must be >= 1')
+        tied = [nn.ReLU(), nn.Linear(hidden_dim, hidden_dim)] * (num_layers - 1) if num_layers > 1 else []
+        self.net = nn.Sequential(nn.Linear(input_dim + setup['dim'] + 1, hidden_dim), *tied, nn.Tanh(),
+                                 nn.Linear(hidden_dim, input_dim)).double()
+
+    def forward(self, h):
+        raise XnwanError('the field is only evaluated inside the fused HIP stepper (XNODE.forward)')
+
+
+class XNODE(nn.Module):
+    """u_theta.  forward(inputs[N, L, d+1]) -> [N, L, 1] for a group of equal-length paths (time in channel 0)."""
+
+    def __init__(self, hidden_dim, output_dim, func_h, func_g, setup, hidden_hidden_dim, num_layers, domain,
+                 solver='midpoint', min_steps=5, adjoint=False):
+        super().__init__()
+        if output_dim != 1:
+            raise XnwanError('the PDE solution is scalar: output_dim must be 1')
+        if adjoint:
+            raise XnwanError("adjoint=True (continuous adjoint) is not built; gradients are the exact reverse of the "
+                             "discrete stepper, i.e. the reference's default adjoint=False")
+        self.hidden_dim, self.output_dim, self.hidden_hidden_dim = hidden_dim, output_dim, hidden_hidden_dim
+        self.h, self.g, self.setup, self.num_layers, self.domain = func_h, func_g, setup, num_layers, domain
+        self.solver, self.min_steps, self.adjoint = solver, min_steps, adjoint
+        self.method = KN.method_id(solver)
+        self.initial_layers = nn.Sequential(nn.Linear(1, hidden_dim), nn.ReLU(), nn.Linear(hidden_dim, hidden_dim),
+                                            nn.ReLU(), nn.Linear(hidden_dim, hidden_dim)).double()
+        self.ODE_rhs = HiddenField(hidden_dim, setup, num_layers, hidden_hidden_dim)
+        self.ODE_rhs.apply(init_weights)
+        self.final_linear = nn.Linear(hidden_dim, output_dim).double()
+        self.blob = None
+
+    def bind(self, device):
+        self.to(device)
+        self.blob = Blob(self, device)
+        return self.blob
+
+    def start_values(self, inputs):
+        """h(x) for groups that start at T0, g(t0, x) for groups that start on the boundary (src/model.py:95-96)."""
+        first = inputs[:, 0, :]
+        if float(inputs[0, 0, 0]) == self.setup['T0']:
+            return self.h(first).reshape(-1).double()
+        return self.g(first.unsqueeze(1)).reshape(-1).double()
+
+    def forward(self, inputs):
+        if self.blob is None:
+            raise XnwanError('XNODE.bind(device) has not been called')
+        inputs = inputs.to(self.blob.data.device)
+        starts_at_T0 = float(inputs[0, 0, 0]) == self.setup['T0']
+        if not starts_at_T0:
+            on_boundary = float(torch.max(self.domain.func_w(inputs[:, 0, :].unsqueeze(1)))) < 1e-5
+            if not on_boundary:
+                raise XnwanError('paths that start neither at T0 nor on the boundary need the bound_pad/fillt evaluation '
+                                 'path (SURVEY.md section 8(f) row 3), which is not built yet')
+        out = _OdeFn.apply(inputs, self.start_values(inputs), self, *self.blob.params)
+        if inputs.shape[1] == 1 and starts_at_T0:
+            return out[:, 0, :]                                   # reference returns [N, 1] here (src/model.py:89-91)
+        return out
+
+
+class TestNet(nn.Module):
+    """v_phi: Linear(d+1, W) -> (ReLU -> tied Linear(W, W)) x v_layers -> Tanh -> Linear(W, 1), pointwise on [..., d+1]."""
+    __test__ = False
+
+    def __init__(self, config, setup):
+        super().__init__()
+        self.num_layers, self.hidden_dim = config['v_layers'], config['v_hidden_dim']
+        self.input = nn.Linear(setup['dim'] + 1, self.hidden_dim)
+        self.hidden = nn.Linear(self.hidden_dim, self.hidden_dim)
+        self.output = nn.Linear(self.hidden_dim, 1)
+        self.net = nn.Sequential(self.input, *[nn.ReLU(), self.hidden] * self.num_layers, nn.Tanh(), self.output)
+        self.net.double()
+        self.blob = None
+
+    def bind(self, device):
+        self.to(device)
+        self.blob = Blob(self, device)
+        return self.blob
+
+    def forward(self, XV):
+        if self.blob is None:
+            raise XnwanError('TestNet.bind(device) has not been called')
+        return _DiscFn.apply(XV.to(self.blob.data.device), self, *self.blob.params)
+
+
+class PathParallel(nn.Module):
+    """Stands where the reference has nn.DataParallel: same `.module` attribute and `module.` state_dict prefix.
+    Monte-Carlo paths are sharded across GPUs by one process per GPU (dist.py), not by this wrapper."""
+
+    def __init__(self, module):
+        super().__init__()
+        self.module = module
+
+    def forward(self, *a, **kw):
+        return self.module(*a, **kw)
+
+
+# names under which the reference exports these classes (src/model.py)
+NeuralODE = XNODE
+discriminator = TestNet
+_ODEField = HiddenField
