@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""bench.py -- WAN training-steps/sec on the BASELINE.json headline workload:
+d=20 time-independent cube (Ex4_1 functions), N_r = N_b = 4096 paths, N_t = 32, YAML hyper-parameters, float64.
+
+    python bench.py [--gpus N --steps K --warmup W]          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" is one optimiser sub-step of the adversarial loop (src/training.py:125-138 generator, :151-162 discriminator)
+on synthetic sampled paths already resident in HBM; the timed region cycles generator, generator, discriminator
+(n1 = 2, n2 = 1) and contains every kernel of the sub-step including the fused Adam update.  Resampling, diagnostics
+and file I/O of the outer loop are outside the timed region (reported separately in `extras`).
+
+Scaling is WEAK: every rank holds its own N_r = 4096 interior + 4096 boundary paths (global batch 4096 x n_gpus), the
+loss couples them through two small all-reduces per sub-step (dist.py); `value` = sub-steps/s x n_gpus, i.e. 4096-path
+sub-steps per second over the whole job.
+
+Prints ONE JSON line (rank 0).  Extra objects: `roofline` for the dominant kernel (HIP-event timed on the launch
+stream), `cpu_baseline` (the oracle = CPU restatement of the reference, timed on this host, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP64_MATRIX_TFLOPS = 78.6   # MI355X dense FP64 matrix peak (spec); v_mfma_f64_16x16x4 measured 77.6 (profiles/r01_probe_fp64.txt)
+
+
+def workload_params(d, n_r, n_b, n_t):
+    return {'alpha': 100000000, 'u_layers': 8, 'u_hidden_dim': 20, 'u_hidden_hidden_dim': 10, 'v_layers': 9,
+            'v_hidden_dim': 50, 'n1': 2, 'n2': 1, 'u_rate': 0.015, 'v_rate': 0.04, 'min_steps': 5, 'adjoint': False,
+            'solver': 'midpoint', 'dim': d, 'N_t': n_t, 'N_r': n_r, 'N_b': n_b, 'T0': 0, 'T': 1, 'shape_param': [-1, 1],
+            'iterations': 1, 'domain': 'Hypercube'}
+
+
+def algorithmic_macs(p):
+    """per-unit multiply-accumulates of the two nets."""
+    d, H, K, m, W, q, L = p['dim'], p['u_hidden_dim'], p['u_hidden_hidden_dim'], p['u_layers'], p['v_hidden_dim'], p['v_layers'], p['N_t']
+    macs_F = (d + 1 + H) * K + (m - 1) * K * K + K * H
+    path_u = 2 * (L - 1) * macs_F + (H + 2 * H * H) + L * H
+    macs_v = (d + 1) * W + q * W * W + W
+    return macs_F, path_u, macs_v
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=60)
+    ap.add_argument('--warmup', type=int, default=6)
+    ap.add_argument('--dim', type=int, default=20)
+    ap.add_argument('--n_r', type=int, default=4096)
+    ap.add_argument('--n_b', type=int, default=4096)
+    ap.add_argument('--n_t', type=int, default=32)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--train-iters', type=int, default=100, help='outer iterations of real training (with resampling) for '
+                    'the rel-L2 figure, outside the timed region; 0 disables')
+    args = ap.parse_args()
+
+    import configs.Ex4_1_funcs as P
+    from xnode_wan_pde_solver_amd import dist as xdist, kernels as KN
+    from src.training import NODE_WAN_solver
+    from src.dataset import Comb_loader
+    from utils.auxillary_funcs import rel_err
+
+    world, local = xdist.init_from_env()
+    size = world.size if world is not None else 1
+    rank = world.rank if world is not None else 0
+    if size != args.gpus:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d' % (args.gpus, size, args.gpus))
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    params = workload_params(args.dim, args.n_r, args.n_b, args.n_t)
+
+    torch.manual_seed(0)                                  # identical initial parameters and time grid on every rank
+    S = NODE_WAN_solver(params, P.func_a, P.func_b, P.func_c, P.func_h, P.func_f, P.func_g, dev, './',
+                        func_u_sol=P.func_u_sol, p=2, world=world)
+    eng, s = S.engine, S.setup
+    domain = S.domain(s['shape_param'], s['dim'], s['T0'], s['T'], s['N_t'])
+    torch.manual_seed(1000 + rank)                        # every rank draws its own shard of the global Monte-Carlo batch
+    t_s0 = time.time()
+    pts = Comb_loader(s['N_r'], s['N_b'], domain, dev)
+    du, dv, bd = pts[0]
+    G = eng.load_group(du, dv, bd, domain, n_glob=s['N_r'] * size, nb_glob=s['N_b'] * size)
+    torch.cuda.synchronize()
+    t_sample = time.time() - t_s0
+
+    schedule = ['g', 'g', 'd']
+
+    def run(n, offset=0):
+        for i in range(n):
+            if schedule[(offset + i) % 3] == 'g':
+                eng.generator_step(G)
+            else:
+                eng.discriminator_step(G)
+
+    def barrier():
+        if world is not None:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    run(args.warmup)
+    barrier()
+    t0 = time.perf_counter()
+    run(args.steps, args.warmup)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world is not None:
+        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(te, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(te.item())
+    steps_per_s = args.steps / elapsed
+    finite = bool(torch.isfinite(eng.scal[4]).item() and torch.isfinite(eng.theta.data).all().item())
+
+    # ---- per-kernel timing with events on the launch stream (instrumented pass, outside the timed region) ------------
+    names = ['disc_fwd', 'disc_gradx', 'ode_fwd', 'ode_bwd', 'weak_partials', 'bdry_partials', 'gen_cotangent',
+             'disc_cotangent', 'disc_bwd', 'adam', 'slab_sum']
+    records, originals = {}, {}
+
+    def wrap(name, fn):
+        def inner(*a, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = fn(*a, **kw)
+            e1.record()
+            key = name
+            if name == 'ode_bwd':
+                key = 'ode_bwd_params' if kw.get('want_params') else 'ode_bwd_x'
+            records.setdefault(key, []).append((e0, e1))
+            return r
+        return inner
+    for n_ in names:
+        originals[n_] = getattr(KN, n_)
+        setattr(KN, n_, wrap(n_, originals[n_]))
+    prof_steps = 9
+    run(prof_steps)
+    torch.cuda.synchronize()
+    for n_ in names:
+        setattr(KN, n_, originals[n_])
+    kern = {k: {'launches_per_step': len(v) / prof_steps, 'avg_ms': sum(a.elapsed_time(b) for a, b in v) / len(v)}
+            for k, v in records.items()}
+    for k in kern:
+        kern[k]['ms_per_step'] = kern[k]['avg_ms'] * kern[k]['launches_per_step']
+    macs_F, path_u, macs_v = algorithmic_macs(params)
+    Pn, N, Nb = s['N_r'] * s['N_t'], s['N_r'], s['N_b']
+    alg_flops = {                                          # algorithmic FLOP (2 x MAC) per launch, SURVEY section 8(d)
+        'disc_fwd': 2.0 * 2 * Pn * macs_v,                 # value + d/dt tangent
+        'disc_bwd': 2.0 * 2 * Pn * macs_v,                 # reverse chain + weight-gradient contraction (recompute not counted)
+        'ode_fwd': 2.0 * N * path_u,
+        'ode_bwd_x': 2.0 * N * path_u,                     # adjoint chain (recompute not counted)
+        'ode_bwd_params': 2.0 * 2 * N * path_u,            # adjoint chain + weight-gradient contraction
+    }
+    dominant = max((k for k in kern if k in alg_flops), key=lambda k: kern[k]['ms_per_step'])
+    ach = alg_flops[dominant] / (kern[dominant]['avg_ms'] * 1e-3) / 1e12
+    roofline = {'bound': 'mfma', 'kernel': dominant, 'achieved': round(ach, 3), 'peak': PEAK_FP64_MATRIX_TFLOPS,
+                'unit': 'TFLOP/s', 'frac': round(ach / PEAK_FP64_MATRIX_TFLOPS, 4), 'traffic': None,
+                'avg_launch_ms': round(kern[dominant]['avg_ms'], 4)}
+    gen_flops = 2.0 * (2 * Pn * macs_v + 4 * N * path_u + 3 * Nb * path_u)
+    dis_flops = 2.0 * (3 * Pn * macs_v + 2 * N * path_u)
+    step_flops = (2 * gen_flops + dis_flops) / 3.0
+    whole = {'alg_gflop_per_step_avg': round(step_flops / 1e9, 2),
+             'achieved_tflops': round(step_flops * steps_per_s / 1e12, 3),
+             'frac_fp64_matrix_peak': round(step_flops * steps_per_s / 1e12 / PEAK_FP64_MATRIX_TFLOPS, 4)}
+
+    # ---- real training (resampling every outer iteration) for the rel-L2 figure ----------------------------------------
+    extras = {'sample_and_tabulate_s': round(t_sample, 4), 'finite': finite, 'structure': eng.structure.describe()}
+    if args.train_iters > 0 and world is None:
+        torch.manual_seed(0)
+        S2 = NODE_WAN_solver(dict(params, iterations=args.train_iters), P.func_a, P.func_b, P.func_c, P.func_h, P.func_f,
+                             P.func_g, dev, './', func_u_sol=P.func_u_sol, p=2)
+        tt0 = time.time()
+        cwd = os.getcwd()
+        os.makedirs('/tmp/xnwan_bench', exist_ok=True)
+        os.chdir('/tmp/xnwan_bench')
+        try:
+            S2.train(report=False)
+        finally:
+            os.chdir(cwd)
+        torch.manual_seed(12345)
+        hold = S2.domain(s['shape_param'], s['dim'], s['T0'], s['T'], s['N_t'])
+        Xh = hold.interior(16384)
+        extras['train'] = {'outer_iterations': args.train_iters, 'wall_s': round(time.time() - tt0, 2),
+                           'rel_l2_heldout_16384': float(rel_err(Xh, S2.u_net, P.func_u_sol, 2, hold.V(), 16384))}
+
+    # ---- CPU baseline: the oracle (port of the reference's CPU/PyTorch path), bounded sample ---------------------------
+    cpu = None
+    if rank == 0 and size == 1 and not args.no_cpu_baseline:
+        from oracle import refspec as R
+        funcs = dict(h=P.func_h, f=P.func_f, g=P.func_g, a=P.func_a, b=P.func_b, c=P.func_c)
+        torch.manual_seed(0)
+        O = R.Solver(params, funcs, u_sol=P.func_u_sol, p=2)
+        O.new_sample()
+        c0 = time.perf_counter()
+        O.generator_step()
+        O.discriminator_step()
+        c_el = time.perf_counter() - c0
+        cpu = {'value': round(2 / c_el, 5), 'unit': 'steps/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+               'sample': '1 generator + 1 discriminator sub-step at the full workload size (%.1f s)' % c_el}
+
+    if rank == 0:
+        out = {
+            'metric': 'WAN training-steps/sec (optimiser sub-steps, d=20 cube, N_r=4096 paths per GPU)',
+            'value': round(steps_per_s * size, 3), 'unit': 'steps/s', 'n_gpus': size, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(1e3 * elapsed / args.steps, 4), 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': 'Ex4_1 cube d=%d N_r=%d N_b=%d N_t=%d per GPU, midpoint, n1=2 n2=1 (configs[1])'
+                       % (s['dim'], s['N_r'], s['N_b'], s['N_t']), 'global_paths': s['N_r'] * size,
+                       'parallelism': 'paths sharded x%d, 2 small all-reduces per sub-step' % size},
+            'roofline': roofline, 'cpu_baseline': cpu, 'whole_step': whole,
+            'kernels': {k: {'ms': round(v['avg_ms'], 4), 'per_step': round(v['launches_per_step'], 2)} for k, v in sorted(kern.items())},
+            'extras': extras,
+        }
+        print(json.dumps(out))
+    if world is not None:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

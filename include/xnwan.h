@@ -61,9 +61,10 @@ int xw_ode_bwd(const float* xT, const float* t, const double* start, const doubl
 int xw_disc_fwd(const float* xT, const float* t, const float* tpp, const double* phi,
                 int N, int L, int d, int W, int q, double* v, double* vt, double* act, void* stream);
 
-/* nabla_x v at a set of points (reverse mode, no parameter gradients): gxv[d,N] and gtv[N] (d/dt), for the
- * N points (t_n, x_n) with t_n = tpp ? tpp[n] : t[0].   (XV.grad of src/loss.py:60-63 restricted to what I reads) */
-int xw_disc_gradx(const float* xT, const float* t, const float* tpp, const double* phi,
+/* input gradient of <vbar, v> at a set of points (reverse mode, no parameter gradients): gxv[d,N] (nabla_x) and
+ * gtv[N] (d/dt), for the N points (t_n, x_n) with t_n = tpp ? tpp[n] : t[0]; vbar[N] or NULL (= ones).
+ * (XV.grad of src/loss.py:60-63; the fused step only needs it at the first time index) */
+int xw_disc_gradx(const float* xT, const float* t, const float* tpp, const double* phi, const double* vbar,
                   int N, int d, int W, int q, double* gxv, double* gtv, void* stream);
 
 int xw_disc_bwd_slabs(int N, int L);

@@ -258,11 +258,14 @@ def tabulate(funcs, setup, X, BX, u):
 # --------------------------------------------------------------------------------------
 # weak functional and losses (src/loss.py:46-96)
 # --------------------------------------------------------------------------------------
-def weak_I(setup, V, u, v, w, du, dphi, h, f, a, b, c):
+def weak_I(setup, V, u, v, w, du, dphi, h, f, a, b, c, n_glob=None):
     """I = <A[u], phi> as the reference evaluates it.  du/dphi are CONSTANTS ([N,L,d+1], from the helper
-    backward passes); the u factor of s2 and the phi factor of s32 carry no gradient (Q2)."""
+    backward passes); the u factor of s2 and the phi factor of s32 carry no gradient (Q2).
+    n_glob: number of paths the 1/N factors refer to when u, v, ... are only one shard of the batch (multi-GPU tests)."""
     d = setup['dim']
     N, L = u.shape
+    if n_glob is not None:
+        N = n_glob
     phi = v * w                                                               # :52
     s1 = V * (u[:, -1] * v[:, -1] - h * v[:, 0]) / N                          # :64  (v, not phi)
     s2 = V * (u.detach() * dphi[:, :, 0]) / N / L                             # :65  (grad wrt u killed by :75)

@@ -260,6 +260,23 @@ def trajectory(case, d, N_r, N_b, N_t, seed, outer_iters, gpu_loader_semantics):
     print('wrote', path, 'steps', len(log), 'wall %.1fs' % wall, 'final rel-L2', log[-1])
 
 
+def fillt_vectors():
+    """src/dataset.py:13-32 on a few hand-picked time vectors (the helper has surprising edge behaviour that the
+    product reproduces verbatim: it can drop a sample and return indices past the filled vector)."""
+    training, dataset, lossmod, F = load_reference()
+    probes = [[0.0, 0.05, 0.6, 1.0], [0.0, 0.3, 0.35, 0.9, 1.0], [0.2, 0.25, 0.8], [0.0, 1.0], [0.0, 0.1, 0.2, 0.3]]
+    out = {}
+    k = 0
+    for t in probes:
+        for ms in (5, 20):
+            i, f = dataset.fillt(torch.tensor(t), 1.0, 0.0, ms)
+            out['%d/t' % k], out['%d/ms' % k], out['%d/idx' % k], out['%d/filled' % k] = np.array(t, dtype=np.float32), np.array(ms), npy(i), npy(f)
+            k += 1
+    out['n'] = np.array(k)
+    np.savez_compressed(os.path.join(HERE, 'ref_fillt.npz'), **out)
+    print('wrote ref_fillt.npz', k, 'cases')
+
+
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('--traj', action='store_true', help='also produce the 800-step trajectory fixtures (slow)')
@@ -267,6 +284,7 @@ if __name__ == '__main__':
     args = ap.parse_args()
     torch.set_num_threads(4)
     if not args.only_traj:
+        fillt_vectors()
         one_iteration('ref_tiny_midpoint', 3, 8, 12, 6, 7, 'midpoint', True)
         one_iteration('ref_tiny_euler', 3, 8, 12, 6, 7, 'euler', True)
         one_iteration('ref_tiny_rk4', 3, 8, 12, 6, 7, 'rk4', True)

@@ -1,0 +1,110 @@
+"""world_size-2 `gloo` test (CPU) of the multi-GPU exchange: path sharding (dist.World.shard_group / bounds), the
+32-byte partial-sum all-reduce and the packed-gradient all-reduce.  The per-shard arithmetic is done with the oracle
+(the HIP kernels need a GPU); what is under test is that shard-local partials with GLOBAL 1/N factors, combined by
+dist.World exactly the way engine.Engine combines them, reproduce the unsharded loss and gradient."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+import configs.Ex4_1_funcs as P
+
+FUNCS = dict(h=P.func_h, f=P.func_f, g=P.func_g, a=P.func_a, b=P.func_b, c=P.func_c)
+PARAMS = {'alpha': 1e8, 'u_layers': 8, 'u_hidden_dim': 20, 'u_hidden_hidden_dim': 10, 'v_layers': 9, 'v_hidden_dim': 50,
+          'n1': 2, 'n2': 1, 'u_rate': 0.015, 'v_rate': 0.04, 'min_steps': 5, 'adjoint': False, 'solver': 'midpoint',
+          'dim': 4, 'N_t': 6, 'N_r': 37, 'N_b': 21, 'T0': 0, 'T': 1, 'shape_param': [-1, 1], 'iterations': 1,
+          'domain': 'Hypercube'}
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _sharded_substep(which, O, world):
+    """what one rank of the engine does in a sub-step, with oracle arithmetic on its shard"""
+    from oracle import refspec as R
+    X, XV, BX, n, nb = world.shard_group(O.X, O.XV, O.BX)
+    theta = {k: v.clone().requires_grad_(which == 'u') for k, v in O.theta.items()}
+    phi = {k: v.clone().requires_grad_(which == 'v') for k, v in O.phi.items()}
+    o = R.forward_all(theta, phi, O.config, O.setup, O.cube, FUNCS, X, XV, BX, which == 'u')
+    L = X.shape[1]
+    I_part = R.weak_I(O.setup, o['V'], o['u'], o['v'], o['w'], o['du'], o['dphi'], o['h'], o['f'],
+                      *R.tabulate(FUNCS, O.setup, X, BX, o['u'])[3:5], R.tabulate(FUNCS, O.setup, X, BX, o['u'])[5], n_glob=n)
+    S_part = torch.sum(o['v'] ** 2)
+    sse_i = torch.sum((o['u'][:, 0] - o['h']) ** 2)
+    sse_b = torch.sum((o['u_b'] - o['g']) ** 2) if which == 'u' else torch.zeros((), dtype=torch.float64)
+    scal = torch.stack([I_part, S_part, sse_i, sse_b]).detach().clone()
+    world.all_reduce(scal)                                                   # exchange 1: 32 bytes
+    I, S = scal[0], scal[1]
+    alpha = O.config['alpha']
+    if which == 'u':
+        # d loss_u / d theta on this shard with the GLOBAL I:  (2/I) dI_part + alpha (d sse_i / n + d sse_b / (nb L)) + pollution
+        surrogate = (2.0 / I) * I_part + alpha * (sse_i / n + sse_b / (nb * L))
+        keys = list(theta)
+        g = torch.autograd.grad(surrogate, [theta[k] for k in keys], allow_unused=True)
+        flat = torch.cat([(o['pol_theta'][k] + (gi if gi is not None else 0)).reshape(-1) for k, gi in zip(keys, g)])
+        loss = torch.log(I ** 2) - torch.log(o['V'] * S / (n * L)) + alpha * (scal[2] / n + scal[3] / (nb * L))
+    else:
+        surrogate = -(2.0 / I) * I_part + S_part / S
+        keys = list(phi)
+        g = torch.autograd.grad(surrogate, [phi[k] for k in keys], allow_unused=True)
+        flat = torch.cat([(o['pol_phi'][k] + (gi if gi is not None else 0)).reshape(-1) for k, gi in zip(keys, g)])
+        loss = -(torch.log(I ** 2) - torch.log(o['V'] * S / (n * L)))
+    flat = flat.detach().clone()
+    world.all_reduce(flat)                                                   # exchange 2: packed gradient
+    return loss.item(), flat, keys
+
+
+def _worker(rank, size, port, out_dir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(size), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from oracle import refspec as R
+    from xnode_wan_pde_solver_amd import dist as xdist
+    world, _ = xdist.init_from_env('gloo')
+    assert world.size == size and world.rank == rank
+    torch.manual_seed(3)
+    O = R.Solver(PARAMS, FUNCS, u_sol=P.func_u_sol, p=2)
+    O.new_sample()                                       # same seed on every rank -> same global sample
+    res = {}
+    for which in ('u', 'v'):
+        loss, flat, keys = _sharded_substep(which, O, world)
+        ref = (R.generator_grad if which == 'u' else R.discriminator_grad)(O.theta, O.phi, O.config, O.setup, O.cube, FUNCS, O.X, O.XV, O.BX)
+        ref_flat = torch.cat([ref['grad'][k].reshape(-1) for k in keys])
+        res[which] = (loss, ref['loss'].item(), float((flat - ref_flat).abs().max()), float(ref_flat.abs().max()))
+    lo, hi = world.bounds(37)
+    res['bounds'] = (lo, hi)
+    torch.save(res, os.path.join(out_dir, 'rank%d.pt' % rank))
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_gloo_exchange_reproduces_unsharded_step(tmp_path):
+    size = 2
+    mp.spawn(_worker, args=(size, _free_port(), str(tmp_path)), nprocs=size, join=True)
+    res = [torch.load(tmp_path / ('rank%d.pt' % r)) for r in range(size)]
+    assert res[0]['bounds'] == (0, 19) and res[1]['bounds'] == (19, 37)
+    for r in res:
+        for which in ('u', 'v'):
+            loss, ref_loss, err, scale = r[which]
+            np.testing.assert_allclose(loss, ref_loss, rtol=1e-6 if which == 'v' else 1e-9)
+            assert err <= 2e-5 * scale, (which, err, scale)
+    assert res[0]['u'][0] == res[1]['u'][0]               # every rank sees the same global loss
+
+
+def test_bounds_cover_everything_once():
+    from xnode_wan_pde_solver_amd.dist import World
+
+    class W(World):
+        def __init__(self, rank, size):
+            self.rank, self.size, self.group = rank, size, None
+    for n in (1, 7, 8, 4096, 4097):
+        for size in (1, 2, 3, 8):
+            spans = [W(r, size).bounds(n) for r in range(size)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans[:-1], spans[1:]))
+            assert max(hi - lo for lo, hi in spans) - min(hi - lo for lo, hi in spans) <= 1

@@ -405,15 +405,14 @@ extern "C" int xw_disc_bwd(const float* xT, const float* t, const float* tpp, co
   return xw_launch_status();
 }
 
-extern "C" int xw_disc_gradx(const float* xT, const float* t, const float* tpp, const double* phi, int N, int d, int W,
-                             int q, double* gxv, double* gtv, void* stream) {
+extern "C" int xw_disc_gradx(const float* xT, const float* t, const float* tpp, const double* phi, const double* vbar,
+                             int N, int d, int W, int q, double* gxv, double* gtv, void* stream) {
   if (!xT || !phi || !gxv || N <= 0 || d <= 0) return XW_E_ARG;
   if (!tpp && !t) return XW_E_ARG;
   if (W != 50 || q != 9 || d + 2 > 128) return XW_E_DIMS;
   hipStream_t s = (hipStream_t)stream;
   const int L = 1;
   const int blocks = bwd_blocks((long)N);
-  const double* vbar = nullptr;
   double* gslab = nullptr;
   XW_DISC_BWD(false, true)
   return xw_launch_status();

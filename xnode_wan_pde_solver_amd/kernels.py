@@ -110,15 +110,18 @@ def disc_fwd(xT, t, phi, W, q, tpp=None, want_vt=True, v=None, vt=None):
     return v, (vt if want_vt else None)
 
 
-def disc_gradx(xT, t, phi, W, q, tpp=None, gxv=None, gtv=None):
-    """(nabla_x v)[d,N] and (dv/dt)[N] at the points (tpp[n] or t[0], x_n)."""
+def disc_gradx(xT, t, phi, W, q, tpp=None, vbar=None, gxv=None, gtv=None):
+    """input gradient of <vbar, v>: (nabla_x)[d,N] and (d/dt)[N] at the points (tpp[n] or t[0], x_n); vbar None = ones."""
     _need_gpu()
     d, N = xT.shape
     _chk(xT, F32, (d, N), 'xT'); _chk(phi, F64, (phi_size(d, W),), 'phi'); _chk(t, F32, None, 't'); _chk(tpp, F32, (N,), 'tpp')
     gxv = torch.empty(d, N, dtype=F64, device=xT.device) if gxv is None else gxv
     gtv = torch.empty(N, dtype=F64, device=xT.device) if gtv is None else gtv
     _chk(gxv, F64, (d, N), 'gxv'); _chk(gtv, F64, (N,), 'gtv')
-    check(lib.xw_disc_gradx(_p(xT), _p(t), _p(tpp), _p(phi), N, d, W, q, _p(gxv), _p(gtv), _stream()), 'xw_disc_gradx')
+    if vbar is not None:
+        vbar = vbar.reshape(-1)
+        _chk(vbar, F64, (N,), 'vbar')
+    check(lib.xw_disc_gradx(_p(xT), _p(t), _p(tpp), _p(phi), _p(vbar), N, d, W, q, _p(gxv), _p(gtv), _stream()), 'xw_disc_gradx')
     return gxv, gtv
 
 

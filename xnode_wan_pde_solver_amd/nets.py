@@ -178,23 +178,24 @@ class XNODE(nn.Module):
         return self.blob
 
     def start_values(self, inputs):
-        """h(x) for groups that start at T0, g(t0, x) for groups that start on the boundary (src/model.py:95-96)."""
+        """h(x) for groups that start at T0, g(t0, x) for groups that start on the boundary (src/model.py:95-96);
+        evaluated on the device `inputs` lives on (host tensors -> bitwise the reference's CPU values)."""
         first = inputs[:, 0, :]
-        if float(inputs[0, 0, 0]) == self.setup['T0']:
+        if float(inputs[0, 0, 0].detach()) == self.setup['T0']:
             return self.h(first).reshape(-1).double()
         return self.g(first.unsqueeze(1)).reshape(-1).double()
 
     def forward(self, inputs):
         if self.blob is None:
             raise XnwanError('XNODE.bind(device) has not been called')
-        inputs = inputs.to(self.blob.data.device)
-        starts_at_T0 = float(inputs[0, 0, 0]) == self.setup['T0']
+        dev = self.blob.data.device
+        starts_at_T0 = float(inputs[0, 0, 0].detach()) == self.setup['T0']
         if not starts_at_T0:
-            on_boundary = float(torch.max(self.domain.func_w(inputs[:, 0, :].unsqueeze(1)))) < 1e-5
+            on_boundary = float(torch.max(self.domain.func_w(inputs[:, 0, :].detach().unsqueeze(1)))) < 1e-5
             if not on_boundary:
                 raise XnwanError('paths that start neither at T0 nor on the boundary need the bound_pad/fillt evaluation '
                                  'path (SURVEY.md section 8(f) row 3), which is not built yet')
-        out = _OdeFn.apply(inputs, self.start_values(inputs), self, *self.blob.params)
+        out = _OdeFn.apply(inputs.to(dev), self.start_values(inputs).to(dev), self, *self.blob.params)
         if inputs.shape[1] == 1 and starts_at_T0:
             return out[:, 0, :]                                   # reference returns [N, 1] here (src/model.py:89-91)
         return out

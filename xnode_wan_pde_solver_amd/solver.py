@@ -1,0 +1,221 @@
+"""NODE_WAN_solver with the reference's constructor / attributes / train() behaviour (src/training.py:54-187), driving
+the HIP engine instead of eager PyTorch + autograd.
+
+What is kept (callers: main.py, example.ipynb, user `stop` hooks -- SURVEY.md section 8(b)):
+  * NODE_WAN_solver(params, func_a, func_b, func_c, func_h, func_f, func_g, device, path, stop=None, func_u_sol=None, p=1)
+  * attributes  u_net v_net config setup iterations domain n1 n2 optimizer_u optimizer_v best_l av_l params p func_*
+  * train(report=False, report_it=10, show_plt=False): resample -> n1 generator sub-steps -> n2 discriminator sub-steps
+    -> diagnostics, with the same side-effect files (losses_NODE_{d}.json, L2_NODE_{d}.json, Time_NODE_{d}.json,
+    best_model_weights_NODE.pth) and the same `stop` hook protocol
+  * state_dict keys of u_net / v_net (`module.` prefix, tied-layer aliases)
+Differences, all deliberate:
+  * `params` is read BY KEY (the reference slices the dict positionally, src/training.py:80-83, which breaks for the
+    notebook's dict); `shape_param` defaults to [-1, 1] when absent; `domain` is looked up in a registry, not eval()'d
+  * a CPU `device` is refused: there is no CPU path in this engine
+  * `exit()` on the stop criterion can be turned into a normal return with `solver.exit_on_stop = False`
+"""
+import json
+import time
+from itertools import product
+
+import torch
+
+from . import nets, sampling
+from ._lib import XnwanError
+from .engine import Engine
+from .kernels import adam as _adam_kernel
+
+CONFIG_KEYS = ['alpha', 'u_layers', 'u_hidden_dim', 'u_hidden_hidden_dim', 'v_layers', 'v_hidden_dim', 'n1', 'n2',
+               'u_rate', 'v_rate', 'min_steps', 'adjoint', 'solver']
+SETUP_KEYS = ['dim', 'N_t', 'N_r', 'N_b', 'T0', 'T', 'shape_param']
+
+
+def split_params(params):
+    missing = [k for k in CONFIG_KEYS + SETUP_KEYS[:-1] + ['iterations', 'domain'] if k not in params]
+    if missing:
+        raise KeyError('params is missing %s' % missing)
+    config = {k: params[k] for k in CONFIG_KEYS}
+    setup = {k: params[k] for k in SETUP_KEYS if k in params}
+    setup.setdefault('shape_param', [-1, 1])     # the notebook's dict has none; Hypercube default (documented)
+    return config, setup, int(params['iterations'])
+
+
+def func_eval(X, BX, setup, y_output_u, func_a, func_b, func_c, func_h, func_f, func_g):
+    """Tabulate the PDE data on a group (reference src/training.py:13-43): h[N], f[N,L], g[N_b,L], a[d,d,N,L],
+    b[d,N,L], c[N,L,1] (attached to y_output_u).  Kept for user code; the engine itself never builds a[d,d,N,L]."""
+    d = setup['dim']
+    h, f, g = func_h(X[:, 0, :]), func_f(X), func_g(BX)
+    c = func_c(X, y_output_u)
+    a = torch.empty(d, d, X.shape[0], X.shape[1])
+    for i, j in product(range(d), repeat=2):
+        a[i, j] = func_a(X, i, j)
+    b = torch.empty(d, X.shape[0], X.shape[1])
+    for i in range(d):
+        b[i] = func_b(X, i)
+    dev = X.device
+    return h.to(dev), f.to(dev), g.to(dev), a.to(dev), b.to(dev), c.to(dev)
+
+
+def build_networks(config, setup, func_h, func_g, domain_cls):
+    """Construct (u_net, v_net) on the host in the reference's order (src/training.py:88-100): a domain instance first
+    (its time grid consumes N_t uniforms), then the XNODE, the test network, and the two Xavier passes."""
+    s = setup
+    domain = domain_cls(s['shape_param'], s['dim'], s['T0'], s['T'], s['N_t'])
+    xnode = nets.XNODE(config['u_hidden_dim'], 1, func_h, func_g, s, config['u_hidden_hidden_dim'], config['u_layers'],
+                       domain, config['solver'], config['min_steps'], config['adjoint'])
+    u_net = nets.PathParallel(xnode)
+    v_net = nets.PathParallel(nets.TestNet(config, s))
+    u_net.apply(nets.init_weights)
+    v_net.apply(nets.init_weights)
+    return u_net, v_net
+
+
+class FusedAdam:
+    """Stands where the reference has torch.optim.Adam (attributes optimizer_u / optimizer_v).  step() applies the
+    fused HIP Adam kernel to the blob using the .grad of the parameters (for user code that went through autograd);
+    the engine's own sub-steps call the same kernel with the slab gradients."""
+
+    def __init__(self, blob, state, lr):
+        self.blob, self.state, self.lr = blob, state, lr
+        self.param_groups = [{'params': blob.params, 'lr': lr, 'betas': (0.9, 0.999), 'eps': 1e-8}]
+
+    def zero_grad(self, set_to_none=True):
+        for p in self.blob.params:
+            p.grad = None
+
+    def step(self):
+        g = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self.blob.params])
+        _adam_kernel(self.blob.data, None, self.state['m'], self.state['v'], self.state['step'],
+                     self.param_groups[0]['lr'], gextra=g.contiguous())
+
+    def state_dict(self):
+        return {'m': self.state['m'].clone(), 'v': self.state['v'].clone(), 'step': int(self.state['step'].item()),
+                'lr': self.lr}
+
+    def load_state_dict(self, sd):
+        self.state['m'].copy_(sd['m'])
+        self.state['v'].copy_(sd['v'])
+        self.state['step'].fill_(sd['step'])
+
+
+class NODE_WAN_solver:
+    def __init__(self, params, func_a, func_b, func_c, func_h, func_f, func_g, device, path, stop=None,
+                 func_u_sol=None, p=1, world=None):
+        self.params = params
+        self.func_a, self.func_b, self.func_c = func_a, func_b, func_c
+        self.func_h, self.func_f, self.func_g = func_h, func_f, func_g
+        self.device = torch.device(device) if not isinstance(device, torch.device) else device
+        if self.device.type != 'cuda':
+            raise XnwanError("device %r: this engine only runs on an MI355X ('cuda' device of PyTorch-ROCm)" % (device,))
+        if self.device.index is None:
+            self.device = torch.device('cuda', torch.cuda.current_device())
+        self.path, self.stop, self.func_u_sol, self.p = path, stop, func_u_sol, p
+        self.world = world
+        self.exit_on_stop = True
+        self.tabulate_on_host = True
+        self.config, self.setup, self.iterations = split_params(params)
+        self.domain = sampling.resolve_domain(params['domain'])
+        self.n1, self.n2 = self.config['n1'], self.config['n2']
+
+        s = self.setup
+        self.u_net, self.v_net = build_networks(self.config, s, func_h, func_g, self.domain)
+        with torch.cuda.device(self.device):
+            self.u_net.module.bind(self.device)
+            self.v_net.module.bind(self.device)
+            funcs = dict(a=func_a, b=func_b, c=func_c, h=func_h, f=func_f, g=func_g)
+            self.engine = Engine(self.config, s, self.u_net.module, self.v_net.module, funcs, self.device, world=world)
+        self.optimizer_u = FusedAdam(self.u_net.module.blob, self.engine.adam_u, self.config['u_rate'])
+        self.optimizer_v = FusedAdam(self.v_net.module.blob, self.engine.adam_v, self.config['v_rate'])
+        self.best_l = float('inf')
+        self.av_l = 0
+        self.last_loss_u = self.last_loss_v = float('nan')
+
+    def rebind(self):
+        """re-alias the parameters to fresh blobs after the modules were moved or cast"""
+        self.u_net.module.bind(self.device)
+        self.v_net.module.bind(self.device)
+        self.engine.theta, self.engine.phi = self.u_net.module.blob, self.v_net.module.blob
+        self.optimizer_u.blob, self.optimizer_v.blob = self.engine.theta, self.engine.phi
+
+    # --------------------------------------------------------------------------------------------------------------
+    def _new_domain(self):
+        s = self.setup
+        return self.domain(s['shape_param'], s['dim'], s['T0'], s['T'], s['N_t'])
+
+    def _groups(self, points):
+        """(u, v, boundary) groups of a loader.  `tabulate_on_host` (default True) hands the engine the loader's HOST
+        tensors, so that h, f, g, w are tabulated exactly like the reference's CPU path; False tabulates on the GPU."""
+        if not self.tabulate_on_host:
+            return list(points)
+        if isinstance(points.interioru, list):
+            n = min(len(points.interioru), len(points.boundary))      # same truncation as iterating the loader
+            return [(points.interioru[i], points.interiorv[i], points.boundary[i]) for i in range(n)]
+        return [(points.interioru, points.interiorv, points.boundary)]
+
+    def _shard(self, points):
+        """this rank's contiguous share of every group (dist.py); identity on one GPU"""
+        if self.world is None:
+            return [(du, dv, bd, None, None) for (du, dv, bd) in points]
+        return [self.world.shard_group(du, dv, bd) for (du, dv, bd) in points]
+
+    def _l_norm(self, interior, volume):
+        from utils.auxillary_funcs import L_norm
+        if self.func_u_sol is None:
+            return float('nan')
+        return L_norm(interior, self.u_net, self.p, self.func_u_sol, volume, self.setup['N_r']).item()
+
+    def train(self, report=False, report_it=10, show_plt=False):
+        past_losses = []
+        times = [time.time()]
+        d = self.setup['dim']
+        eng = self.engine
+        with torch.cuda.device(self.device):
+            for k in range(self.iterations):
+                domain = self._new_domain()
+                points = sampling.Comb_loader(self.setup['N_r'], self.setup['N_b'], domain, self.device)
+                L2 = self._l_norm(points.interioru, domain.V())
+                groups = [eng.load_group(du, dv, bd, domain, ng, nbg) for (du, dv, bd, ng, nbg) in self._shard(self._groups(points))]
+                for _ in range(self.n1):
+                    self.av_l = 0
+                    for G in groups:
+                        eng.generator_step(G)
+                        self.last_loss_u = eng.loss_u().item()
+                        self.av_l += self.last_loss_u
+                    past_losses.append(self.av_l)
+                    if self._is_main():
+                        with open('losses_NODE_' + str(d) + '.json', 'w') as fh:
+                            json.dump(past_losses, fh)
+                    if self.stop is not None and self.stop(self, points.interioru, domain):
+                        if self._is_main():
+                            torch.save(self.u_net.state_dict(), self.path + 'best_model_weights_NODE.pth')
+                        print('Stopping Criterion Reached')
+                        if self.exit_on_stop:
+                            exit()
+                        return past_losses
+                    if self.av_l < self.best_l:
+                        if self._is_main():
+                            torch.save(self.u_net.state_dict(), 'best_model_weights_NODE.pth')
+                        self.best_l = self.av_l
+                for _ in range(self.n2):
+                    for G in groups:
+                        eng.discriminator_step(G)
+                        self.last_loss_v = eng.loss_v().item()
+                points = sampling.Comb_loader(self.setup['N_r'], self.setup['N_b'], domain, self.device)
+                L2 = self._l_norm(points.interioru, domain.V())
+                times.append(time.time())
+                if self._is_main():
+                    with open('L2_NODE_' + str(d) + '.json', 'w') as fh:
+                        json.dump([L2], fh)
+                    with open('Time_NODE_' + str(d) + '.json', 'w') as fh:
+                        json.dump(times, fh)
+                if report and k % report_it == 0 and self._is_main():
+                    print('iteration: ' + str(k), 'Loss u: ' + str(self.last_loss_u), 'Loss v: ' + str(self.last_loss_v))
+                    if self.func_u_sol is not None:
+                        print('L^2 norm error: ' + str(L2))
+                        from utils.auxillary_funcs import proj
+                        proj(self.u_net, self.setup, k, self.device, axes=[0, 1], resolution=200, colours=20, save=True,
+                             show=show_plt, func_u_sol=self.func_u_sol)
+        return past_losses
+
+    def _is_main(self):
+        return self.world is None or self.world.rank == 0
