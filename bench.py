@@ -117,8 +117,10 @@ def main():
     finite = bool(torch.isfinite(eng.scal[4]).item() and torch.isfinite(eng.theta.data).all().item())
 
     # ---- per-kernel timing with events on the launch stream (instrumented pass, outside the timed region) ------------
-    names = ['disc_fwd', 'disc_gradx', 'ode_fwd', 'ode_bwd', 'weak_partials', 'bdry_partials', 'gen_cotangent',
-             'disc_cotangent', 'disc_bwd', 'adam', 'slab_sum']
+    names = ['disc_fwd', 'disc_gradx', 'ode_fwd_multi', 'ode_bwd_multi', 'weak_partials', 'bdry_partials', 'gen_cotangents',
+             'disc_cotangent', 'disc_bwd', 'adam', 'slab_sum', 'losses']
+    graphs_on, streams_on = eng.use_graphs, eng.use_streams
+    eng.use_graphs = eng.use_streams = False             # serial, eager: one event pair per kernel launch
     records, originals = {}, {}
 
     def wrap(name, fn):
@@ -128,8 +130,10 @@ def main():
             r = fn(*a, **kw)
             e1.record()
             key = name
-            if name == 'ode_bwd':
-                key = 'ode_bwd_params' if kw.get('want_params') else 'ode_bwd_x'
+            if name == 'ode_bwd_multi':
+                key = ('ode_bwd_params' if kw.get('want_params') else 'ode_bwd_x') + '_%djob' % len(a[0])
+            if name == 'ode_fwd_multi':
+                key = 'ode_fwd_%djob' % len(a[0])
             records.setdefault(key, []).append((e0, e1))
             return r
         return inner
@@ -141,6 +145,7 @@ def main():
     torch.cuda.synchronize()
     for n_ in names:
         setattr(KN, n_, originals[n_])
+    eng.use_graphs, eng.use_streams = graphs_on, streams_on
     kern = {k: {'launches_per_step': len(v) / prof_steps, 'avg_ms': sum(a.elapsed_time(b) for a, b in v) / len(v)}
             for k, v in records.items()}
     for k in kern:
@@ -150,9 +155,11 @@ def main():
     alg_flops = {                                          # algorithmic FLOP (2 x MAC) per launch, SURVEY section 8(d)
         'disc_fwd': 2.0 * 2 * Pn * macs_v,                 # value + d/dt tangent
         'disc_bwd': 2.0 * 2 * Pn * macs_v,                 # reverse chain + weight-gradient contraction (recompute not counted)
-        'ode_fwd': 2.0 * N * path_u,
-        'ode_bwd_x': 2.0 * N * path_u,                     # adjoint chain (recompute not counted)
-        'ode_bwd_params': 2.0 * 2 * N * path_u,            # adjoint chain + weight-gradient contraction
+        'ode_fwd_1job': 2.0 * N * path_u,
+        'ode_fwd_2job': 2.0 * (N + Nb) * path_u,
+        'ode_bwd_x_1job': 2.0 * N * path_u,                # adjoint chain (recompute not counted)
+        'ode_bwd_params_1job': 2.0 * 2 * N * path_u,       # adjoint chain + weight-gradient contraction
+        'ode_bwd_params_2job': 2.0 * 2 * (N + Nb) * path_u,
     }
     dominant = max((k for k in kern if k in alg_flops), key=lambda k: kern[k]['ms_per_step'])
     ach = alg_flops[dominant] / (kern[dominant]['avg_ms'] * 1e-3) / 1e12
@@ -167,7 +174,9 @@ def main():
              'frac_fp64_matrix_peak': round(step_flops * steps_per_s / 1e12 / PEAK_FP64_MATRIX_TFLOPS, 4)}
 
     # ---- real training (resampling every outer iteration) for the rel-L2 figure ----------------------------------------
-    extras = {'sample_and_tabulate_s': round(t_sample, 4), 'finite': finite, 'structure': eng.structure.describe()}
+    extras = {'sample_and_tabulate_s': round(t_sample, 4), 'finite': finite, 'structure': eng.structure.describe(),
+              'hip_graphs': graphs_on, 'side_streams': streams_on,
+              'serial_kernel_ms_per_step': round(sum(v['ms_per_step'] for v in kern.values()), 4)}
     if args.train_iters > 0 and world is None:
         torch.manual_seed(0)
         S2 = NODE_WAN_solver(dict(params, iterations=args.train_iters), P.func_a, P.func_b, P.func_c, P.func_h, P.func_f,

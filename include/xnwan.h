@@ -43,6 +43,12 @@ int xw_ode_fwd(const float* xT, const float* t, const double* start, const doubl
                int method, int N, int L, int d, int H, int K, int m,
                double* u, double* Y, void* stream);
 
+/* The same for up to 4 independent groups of paths in ONE launch (interior + boundary sample, ...): one wave per 16
+ * paths fills only a quarter of an MI355X at N = 4096, so independent groups are co-scheduled explicitly. */
+typedef struct { const float* xT; const double* start; double* u; double* Y; int N; } XwOdeFwdJob;
+int xw_ode_fwd_multi(const XwOdeFwdJob* jobs, int njobs, const float* t, const double* theta,
+                     int method, int L, int d, int H, int K, int m, void* stream);
+
 /* number of partial-gradient slabs xw_ode_bwd writes for N paths, and doubles of workspace it needs */
 int xw_ode_bwd_slabs(int N);
 
@@ -53,6 +59,12 @@ int xw_ode_bwd_slabs(int N);
 int xw_ode_bwd(const float* xT, const float* t, const double* start, const double* theta, const double* Y,
                const double* ubar, int method, int N, int L, int d, int H, int K, int m, int mode,
                double* gx, double* gs, double* gslab, void* stream);
+
+/* multi-group form: every job has its own sample, checkpoints, cotangent and outputs; `mode` is common to all jobs */
+typedef struct { const float* xT; const double* start; const double* Y; const double* ubar;
+                 double* gx; double* gs; double* gslab; int N; } XwOdeBwdJob;
+int xw_ode_bwd_multi(const XwOdeBwdJob* jobs, int njobs, const float* t, const double* theta,
+                     int method, int L, int d, int H, int K, int m, int mode, void* stream);
 
 /* ---- v_phi: discriminator.forward (src/model.py:37-47) + d/dt by forward-mode ------------------------------------
  * Path mode (tpp == NULL): point (l,n) = (t[l], x_n).  Point mode (tpp != NULL): L must be 1, point n = (tpp[n], x_n).
@@ -76,29 +88,41 @@ int xw_disc_bwd(const float* xT, const float* t, const float* tpp, const double*
  * scal[16] (device, float64): 0 I   1 S=sum v^2   2 SSE_init   3 SSE_bdry   4 loss_u   5 loss_v   6 int   (rest reserved)
  * xw_weak_partials ADDS this rank's partial sums into scal[0..2] (zero scal first; all-reduce scal[0..3] across ranks).
  *   w: distance-to-boundary weight, per path (w_per_point=0, [N]) or per point ([L,N]);  wt: d w/dt [L,N] or NULL (=0)
- *   s3x[N]: the l=0 gradient-contraction term  sum_ij a_ij d_i phi d_j u + sum_i b_i phi d_i u  (src/loss.py:66-69)
+ *   s3x[N]: the l=0 gradient-contraction term  sum_ij a_ij d_i phi d_j u + sum_i b_i phi d_i u  (src/loss.py:66-69);
+ *           NULL for a = identity, b = 0: then it is contracted in-kernel from gx[d,N], gs[N] (xw_ode_bwd), ghT[d,N]
+ *           (nabla_x of the start value), gxv[d,N] (xw_disc_gradx), w0[N], gwx0T[d,N] (w and nabla_x w at t_0)
  *   c, cp: c(u,t,x) and dc/du, [L,N]; both NULL means c = ckappa * u           f[L,N]; h[N]
  *   Vol = domain volume; Nglob = global number of interior paths (the 1/N, 1/(N L) factors of src/loss.py:64-71) */
 int xw_weak_partials(const double* u, const double* v, const double* vt, const double* w, int w_per_point,
-                     const double* wt, const double* s3x, const double* c, double ckappa, const double* f,
-                     const double* h, int N, int L, double Vol, double Nglob, double* scal, void* stream);
+                     const double* wt, const double* s3x, const double* gx, const double* gs, const double* ghT,
+                     const double* gxv, const double* w0, const double* gwx0T, int d, const double* c, double ckappa,
+                     const double* f, const double* h, int N, int L, double Vol, double Nglob, double* scal, void* stream);
 /* boundary penalty partial: scal[3] += sum (u_b - g)^2 ; ubar_b = alpha * 2 (u_b - g) / (Nbglob * L) */
 int xw_bdry_partials(const double* ub, const double* g, int Nb, int L, double alpha, double Nbglob,
                      double* ubar_b, double* scal, void* stream);
-/* generator cotangent on u (loss_u of src/loss.py:93 + the pollution of :55), also writes scal[4], scal[6] */
-int xw_gen_cotangent(const double* u, const double* v, const double* w, int w_per_point, const double* c,
-                     const double* cp, double ckappa, const double* h, int N, int L, double Vol, double Nglob,
-                     double Nbglob, double alpha, double pollution, const double* scal_in, double* ubar,
-                     double* scal_out, void* stream);
-/* discriminator cotangent on v (loss_v of src/loss.py:96 + the pollution of :60), also writes scal[5], scal[6] */
+/* generator cotangent bases on u (loss_u of src/loss.py:93 + the pollution of :55).  Both are available right after
+ * the forward passes (neither needs the global I), so the parameter sweeps need not wait for the x-sweep:
+ *   ubarA = pollution + alpha * 2 (u[0,n] - h_n) / Nglob at l = 0
+ *   ubarB = dI/du = (V/N) v[L-1,n] at l = L-1  +  (V/(N L)) (c + u dc/du) v w
+ *   d loss_u / d theta = J^T ubarA + (2 / I) J^T ubarB + (boundary sweep);  the 2/I is applied by xw_adam.
+ * Either output may be NULL; basis A does not read v (it can be formed before the test network has run). */
+int xw_gen_cotangents(const double* u, const double* v, const double* w, int w_per_point, const double* c,
+                      const double* cp, double ckappa, const double* h, int N, int L, double Vol, double Nglob,
+                      double alpha, double pollution, double* ubarA, double* ubarB, void* stream);
+/* discriminator cotangent on v (loss_v of src/loss.py:96 + the pollution of :60); reads I = scal_in[0], S = scal_in[1] */
 int xw_disc_cotangent(const double* u, const double* v, const double* w, int w_per_point, const double* c,
                       double ckappa, const double* f, const double* h, int N, int L, double Vol, double Nglob,
-                      double pollution, const double* scal_in, double* vbar, double* scal_out, void* stream);
+                      double pollution, const double* scal_in, double* vbar, void* stream);
+/* scal[4] = loss_u, scal[5] = loss_v, scal[6] = int from the (all-reduced) partial sums scal[0..3] (src/loss.py:87-96) */
+int xw_losses(double* scal, int L, double Vol, double Nglob, double Nbglob, double alpha, void* stream);
 
 /* ---- optimiser (torch.optim.Adam defaults, src/training.py:103-104) ------------------------------------------------
- * grad = sum over nslab slabs of gslab[s][P] (+ gextra[P] if not NULL); state: m[P], v[P], step (device int64, incremented) */
-int xw_adam(double* param, const double* gslab, int nslab, const double* gextra, double* m, double* v,
-            long long* step, int P, double lr, double beta1, double beta2, double eps, double* gsum_out, void* stream);
+ * grad = gextraA + sum_s gslabA[s] + coefB * (gextraB + sum_s gslabB[s]),  coefB = scal ? 2 / scal[0] : 1
+ * (slab sets [n][P]; gextra*[P] pre-reduced gradients, e.g. after an all-reduce; any of them may be NULL / 0)
+ * state: m[P], v[P], step (device int64, incremented by one) */
+int xw_adam(double* param, const double* gslabA, int nA, const double* gextraA, const double* gslabB, int nB,
+            const double* gextraB, const double* scal, double* m, double* v, long long* step, int P, double lr,
+            double beta1, double beta2, double eps, double* gsum_out, void* stream);
 /* plain slab reduction: out[P] = (accumulate ? out : 0) + sum_s gslab[s][P] */
 int xw_slab_sum(const double* gslab, int nslab, int P, int accumulate, double* out, void* stream);
 

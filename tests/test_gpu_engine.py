@@ -92,7 +92,7 @@ def test_first_iteration_against_reference_vectors(golden_dir, case):
         scal = eng.scal.cpu().numpy()
         if which == 'u':
             close(G.g.t(), z[tag + '/g'], F32TOL, 1e-7)
-            close(G.ub.t(), z[tag + '/u_b'], F32TOL, F32TOL, tag + ' u_b')
+            close(G.ub.t(), z[tag + '/u_b'], F32TOL, F32TOL, tag + ' u_b')  # (boundary forward of this sub-step)
             close(scal[2] / G.N, float(z[tag + '/init']), 1e-5)
             close(scal[3] / (G.Nb * G.L), float(z[tag + '/bdry']), 1e-5)
             close(scal[4], float(z[tag + '/loss']), 1e-5, what=tag + ' loss_u')
@@ -113,7 +113,8 @@ def test_first_iteration_against_reference_vectors(golden_dir, case):
     check('disc1', 'v')
     assert int(eng.adam_u['step'].item()) == 2 and int(eng.adam_v['step'].item()) == 1
     # value of I / int at the final parameters
-    eng._forward(G, boundary=False)
+    eng.use_graphs = False
+    eng._disc_front(G)
     scal = eng.scal.cpu().numpy()
     close(scal[0], float(z['final/I']), 1e-5)
     close(np.log(scal[0] ** 2) - np.log(G.Vol * scal[1] / (G.N * G.L)), float(z['final/int']), 1e-5, 1e-6)

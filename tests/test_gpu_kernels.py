@@ -189,10 +189,14 @@ def test_adam_matches_torch_formula():
     state = {}
     pc, m, v = p0.clone().cuda(), torch.zeros(P, dtype=torch.float64).cuda(), torch.zeros(P, dtype=torch.float64).cuda()
     step = torch.zeros(1, dtype=torch.int64).cuda()
+    scal = torch.zeros(16, dtype=torch.float64)
     for it in range(3):
-        slabs = torch.randn(5, P, dtype=torch.float64, generator=g)
-        p = R.adam_update(p, {'p': slabs.sum(0)}, state, 0.015)
-        KN.adam(pc, slabs.cuda(), m, v, step, 0.015)
+        slabs = torch.randn(37, P, dtype=torch.float64, generator=g)
+        slabsB = torch.randn(5, P, dtype=torch.float64, generator=g)
+        extra = torch.randn(P, dtype=torch.float64, generator=g)
+        scal[0] = 0.7 + it
+        p = R.adam_update(p, {'p': slabs.sum(0) + extra + (2.0 / scal[0]) * slabsB.sum(0)}, state, 0.015)
+        KN.adam(pc, slabs.cuda(), m, v, step, 0.015, gextraA=extra.cuda(), gslabB=slabsB.cuda(), scal=scal.cuda())
     assert int(step.item()) == 3
     _close(pc, p['p'], 1e-13, 'adam')
 

@@ -8,12 +8,22 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libxnwan.so')
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 c_f32p = ctypes.c_void_p   # const float*  (device)
 c_f64p = ctypes.c_void_p   # double*       (device)
 c_i64p = ctypes.c_void_p
 c_int, c_dbl, c_vp = ctypes.c_int, ctypes.c_double, ctypes.c_void_p
+
+
+class XwOdeFwdJob(ctypes.Structure):      # include/xnwan.h
+    _fields_ = [('xT', c_vp), ('start', c_vp), ('u', c_vp), ('Y', c_vp), ('N', c_int)]
+
+
+class XwOdeBwdJob(ctypes.Structure):
+    _fields_ = [('xT', c_vp), ('start', c_vp), ('Y', c_vp), ('ubar', c_vp), ('gx', c_vp), ('gs', c_vp), ('gslab', c_vp),
+                ('N', c_int)]
+
 
 # name -> argument types (return type is always int); mirrors include/xnwan.h line by line
 SIGNATURES = {
@@ -22,21 +32,25 @@ SIGNATURES = {
     'xw_theta_size': [c_int, c_int, c_int],
     'xw_phi_size': [c_int, c_int],
     'xw_ode_fwd': [c_f32p, c_f32p, c_f64p, c_f64p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_f64p, c_f64p, c_vp],
+    'xw_ode_fwd_multi': [ctypes.POINTER(XwOdeFwdJob), c_int, c_f32p, c_f64p, c_int, c_int, c_int, c_int, c_int, c_int, c_vp],
     'xw_ode_bwd_slabs': [c_int],
+    'xw_ode_bwd_multi': [ctypes.POINTER(XwOdeBwdJob), c_int, c_f32p, c_f64p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp],
     'xw_ode_bwd': [c_f32p, c_f32p, c_f64p, c_f64p, c_f64p, c_f64p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                    c_f64p, c_f64p, c_f64p, c_vp],
     'xw_disc_fwd': [c_f32p, c_f32p, c_f32p, c_f64p, c_int, c_int, c_int, c_int, c_int, c_f64p, c_f64p, c_f64p, c_vp],
     'xw_disc_gradx': [c_f32p, c_f32p, c_f32p, c_f64p, c_f64p, c_int, c_int, c_int, c_int, c_f64p, c_f64p, c_vp],
     'xw_disc_bwd_slabs': [c_int, c_int],
     'xw_disc_bwd': [c_f32p, c_f32p, c_f32p, c_f64p, c_f64p, c_f64p, c_int, c_int, c_int, c_int, c_int, c_f64p, c_vp],
-    'xw_weak_partials': [c_f64p, c_f64p, c_f64p, c_f64p, c_int, c_f64p, c_f64p, c_f64p, c_dbl, c_f64p, c_f64p, c_int,
-                         c_int, c_dbl, c_dbl, c_f64p, c_vp],
+    'xw_weak_partials': [c_f64p, c_f64p, c_f64p, c_f64p, c_int, c_f64p, c_f64p, c_f64p, c_f64p, c_f64p, c_f64p, c_f64p,
+                         c_f64p, c_int, c_f64p, c_dbl, c_f64p, c_f64p, c_int, c_int, c_dbl, c_dbl, c_f64p, c_vp],
     'xw_bdry_partials': [c_f64p, c_f64p, c_int, c_int, c_dbl, c_dbl, c_f64p, c_f64p, c_vp],
-    'xw_gen_cotangent': [c_f64p, c_f64p, c_f64p, c_int, c_f64p, c_f64p, c_dbl, c_f64p, c_int, c_int, c_dbl, c_dbl, c_dbl,
-                         c_dbl, c_dbl, c_f64p, c_f64p, c_f64p, c_vp],
+    'xw_gen_cotangents': [c_f64p, c_f64p, c_f64p, c_int, c_f64p, c_f64p, c_dbl, c_f64p, c_int, c_int, c_dbl, c_dbl, c_dbl,
+                          c_dbl, c_f64p, c_f64p, c_vp],
     'xw_disc_cotangent': [c_f64p, c_f64p, c_f64p, c_int, c_f64p, c_dbl, c_f64p, c_f64p, c_int, c_int, c_dbl, c_dbl, c_dbl,
-                          c_f64p, c_f64p, c_f64p, c_vp],
-    'xw_adam': [c_f64p, c_f64p, c_int, c_f64p, c_f64p, c_f64p, c_i64p, c_int, c_dbl, c_dbl, c_dbl, c_dbl, c_f64p, c_vp],
+                          c_f64p, c_f64p, c_vp],
+    'xw_losses': [c_f64p, c_int, c_dbl, c_dbl, c_dbl, c_dbl, c_vp],
+    'xw_adam': [c_f64p, c_f64p, c_int, c_f64p, c_f64p, c_int, c_f64p, c_f64p, c_f64p, c_f64p, c_i64p, c_int, c_dbl, c_dbl,
+                c_dbl, c_dbl, c_f64p, c_vp],
     'xw_slab_sum': [c_f64p, c_int, c_int, c_int, c_f64p, c_vp],
 }
 

@@ -122,7 +122,7 @@ __global__ void __launch_bounds__(256) k_disc_fwd(const float* __restrict__ xT, 
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         if (16 * mt + 4 * r < W) {  // rows 16 mt + 4 r + g >= W only carry zero padding
-          const double th = tanh(a[mt][r]);
+          const double th = xw_tanh(a[mt][r]);
           sv += vo[mt][r] * th;
           sd += vo[mt][r] * (1.0 - th * th) * ad[mt][r];
         }
@@ -215,7 +215,7 @@ __global__ void __launch_bounds__(256) k_disc_bwd(const float* __restrict__ xT, 
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         double th = 0.0;
-        if (16 * mt + 4 * r < W) th = tanh(a[mt][r]);
+        if (16 * mt + 4 * r < W) th = xw_tanh(a[mt][r]);
         dl[mt][r] = vo[mt][r] * (1.0 - th * th) * vb;
         if (PARAMS) sO[(wave * 64 + lane) * 16 + mt * 4 + r] += (mt == D::MT - 1 && r == 3) ? (g == 0 ? vb : 0.0) : vb * th;
       }

@@ -13,6 +13,7 @@
 // Memory traffic per path: x (d floats) once, the checkpoint y[L,H] written once / read once, u[L] -- everything else
 // stays on chip.  At the headline size this kernel is bound by the FP64 matrix pipe, not by HBM.
 #include "xw_common.h"
+#include "xnwan.h"
 
 namespace {
 
@@ -121,7 +122,7 @@ __device__ __forceinline__ void field_fwd(const FieldW<H, K>& w, double t, d4 xp
   }
   d4 a = xw_zero4();
 #pragma unroll
-  for (int ks = 0; ks < D::KSK; ++ks) a[ks] = tanh(z[ks]);
+  for (int ks = 0; ks < D::KSK; ++ks) a[ks] = xw_tanh(z[ks]);
   if (SAVE) sv.a = a;
 #pragma unroll
   for (int ht = 0; ht < D::HT; ++ht) {
@@ -242,15 +243,53 @@ __device__ __forceinline__ d4 project_x(const double* __restrict__ th, const UOf
   return xp;
 }
 
+// Up to XW_MAXJOBS independent groups of paths (e.g. interior + boundary sample, or two cotangents of the same sample)
+// run in ONE launch: one wave per 16 paths only fills a quarter of the chip at N = 4096, and separate launches on
+// separate streams do not reliably overlap (they can land on the same hardware queue).
+#define XW_MAXJOBS 4
+struct FwdJobs {
+  const float* xT[XW_MAXJOBS];
+  const double* start[XW_MAXJOBS];
+  double* u[XW_MAXJOBS];
+  double* Y[XW_MAXJOBS];
+  int N[XW_MAXJOBS];
+  int tile0[XW_MAXJOBS + 1];   // first block of each job
+  int n;
+};
+struct BwdJobs {
+  const float* xT[XW_MAXJOBS];
+  const double* start[XW_MAXJOBS];
+  const double* Y[XW_MAXJOBS];
+  const double* ubar[XW_MAXJOBS];
+  double* gx[XW_MAXJOBS];
+  double* gs[XW_MAXJOBS];
+  double* gslab[XW_MAXJOBS];
+  int N[XW_MAXJOBS];
+  int tile0[XW_MAXJOBS + 1];
+  int n;
+};
+template <typename J> __device__ __forceinline__ int find_job(const J& jobs) {
+  int j = 0;
+#pragma unroll
+  for (int k = 1; k < XW_MAXJOBS; ++k)
+    if (k < jobs.n && (int)blockIdx.x >= jobs.tile0[k]) j = k;
+  return j;
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 template <int H, int K, int M, int METHOD>
-__global__ void __launch_bounds__(64) k_ode_fwd(const float* __restrict__ xT, const float* __restrict__ tf,
-                                                const double* __restrict__ start, const double* __restrict__ th,
-                                                int N, int L, int d, double* __restrict__ u, double* __restrict__ Y) {
+__global__ void __launch_bounds__(64) k_ode_fwd(const FwdJobs jobs, const float* __restrict__ tf,
+                                                const double* __restrict__ th, int L, int d) {
   typedef Dim<H, K> D;
   typedef RK<METHOD> T;
+  const int job = find_job(jobs);
+  const float* __restrict__ xT = jobs.xT[job];
+  const double* __restrict__ start = jobs.start[job];
+  double* __restrict__ u = jobs.u[job];
+  double* __restrict__ Y = jobs.Y[job];
+  const int N = jobs.N[job];
   const int lane = xw_lane(), g = lane >> 4, n = lane & 15;
-  const int base = blockIdx.x * 16;
+  const int base = ((int)blockIdx.x - jobs.tile0[job]) * 16;
   const bool valid = base + n < N;
   const int ncl = valid ? base + n : N - 1;
   const UOff o = u_offsets(d, H, K);
@@ -329,16 +368,23 @@ __device__ __forceinline__ void storeRowSums(double* dst, int rows, int r0, d4 q
 }
 
 template <int H, int K, int M, int METHOD, bool PARAMS>
-__global__ void __launch_bounds__(64) k_ode_bwd(const float* __restrict__ xT, const float* __restrict__ tf,
-                                                const double* __restrict__ start, const double* __restrict__ th,
-                                                const double* __restrict__ Y, const double* __restrict__ ubar,
-                                                int N, int L, int d, double* __restrict__ gx, double* __restrict__ gs,
-                                                double* __restrict__ gslab) {
+__global__ void __launch_bounds__(64) k_ode_bwd(const BwdJobs jobs, const float* __restrict__ tf,
+                                                const double* __restrict__ th, int L, int d) {
   typedef Dim<H, K> D;
   typedef RK<METHOD> T;
   __shared__ double lds[2 * XW_TTILE];
+  const int job = find_job(jobs);
+  const float* __restrict__ xT = jobs.xT[job];
+  const double* __restrict__ start = jobs.start[job];
+  const double* __restrict__ Y = jobs.Y[job];
+  const double* __restrict__ ubar = jobs.ubar[job];
+  double* __restrict__ gx = jobs.gx[job];
+  double* __restrict__ gs = jobs.gs[job];
+  double* __restrict__ gslab = jobs.gslab[job];
+  const int N = jobs.N[job];
+  const int tile = (int)blockIdx.x - jobs.tile0[job];
   const int lane = xw_lane(), g = lane >> 4, n = lane & 15;
-  const int base = blockIdx.x * 16;
+  const int base = tile * 16;
   const bool valid = base + n < N;
   const int ncl = valid ? base + n : N - 1;
   const UOff o = u_offsets(d, H, K);
@@ -446,7 +492,7 @@ __global__ void __launch_bounds__(64) k_ode_bwd(const float* __restrict__ xT, co
       }
     }
   }
-  double* slab = PARAMS ? gslab + (long)blockIdx.x * o.total : nullptr;
+  double* slab = PARAMS ? gslab + (long)tile * o.total : nullptr;
   if (PARAMS) {
     xw_writeT(lds, xpb);
     __syncthreads();
@@ -541,25 +587,23 @@ __global__ void __launch_bounds__(64) k_ode_bwd(const float* __restrict__ xT, co
 }
 
 template <int H, int K, int M>
-int launch_fwd(int method, const float* xT, const float* t, const double* start, const double* theta, int N, int L, int d,
-               double* u, double* Y, hipStream_t s) {
-  const dim3 grid((N + 15) / 16), block(64);
+int launch_fwd(int method, const FwdJobs& jobs, const float* t, const double* theta, int L, int d, hipStream_t s) {
+  const dim3 grid(jobs.tile0[jobs.n]), block(64);
   switch (method) {
-    case 0: hipLaunchKernelGGL((k_ode_fwd<H, K, M, 0>), grid, block, 0, s, xT, t, start, theta, N, L, d, u, Y); break;
-    case 1: hipLaunchKernelGGL((k_ode_fwd<H, K, M, 1>), grid, block, 0, s, xT, t, start, theta, N, L, d, u, Y); break;
-    case 2: hipLaunchKernelGGL((k_ode_fwd<H, K, M, 2>), grid, block, 0, s, xT, t, start, theta, N, L, d, u, Y); break;
+    case 0: hipLaunchKernelGGL((k_ode_fwd<H, K, M, 0>), grid, block, 0, s, jobs, t, theta, L, d); break;
+    case 1: hipLaunchKernelGGL((k_ode_fwd<H, K, M, 1>), grid, block, 0, s, jobs, t, theta, L, d); break;
+    case 2: hipLaunchKernelGGL((k_ode_fwd<H, K, M, 2>), grid, block, 0, s, jobs, t, theta, L, d); break;
     default: return XW_E_ARG;
   }
   return xw_launch_status();
 }
 template <int H, int K, int M, bool PARAMS>
-int launch_bwd(int method, const float* xT, const float* t, const double* start, const double* theta, const double* Y,
-               const double* ubar, int N, int L, int d, double* gx, double* gs, double* gslab, hipStream_t s) {
-  const dim3 grid((N + 15) / 16), block(64);
+int launch_bwd(int method, const BwdJobs& jobs, const float* t, const double* theta, int L, int d, hipStream_t s) {
+  const dim3 grid(jobs.tile0[jobs.n]), block(64);
   switch (method) {
-    case 0: hipLaunchKernelGGL((k_ode_bwd<H, K, M, 0, PARAMS>), grid, block, 0, s, xT, t, start, theta, Y, ubar, N, L, d, gx, gs, gslab); break;
-    case 1: hipLaunchKernelGGL((k_ode_bwd<H, K, M, 1, PARAMS>), grid, block, 0, s, xT, t, start, theta, Y, ubar, N, L, d, gx, gs, gslab); break;
-    case 2: hipLaunchKernelGGL((k_ode_bwd<H, K, M, 2, PARAMS>), grid, block, 0, s, xT, t, start, theta, Y, ubar, N, L, d, gx, gs, gslab); break;
+    case 0: hipLaunchKernelGGL((k_ode_bwd<H, K, M, 0, PARAMS>), grid, block, 0, s, jobs, t, theta, L, d); break;
+    case 1: hipLaunchKernelGGL((k_ode_bwd<H, K, M, 1, PARAMS>), grid, block, 0, s, jobs, t, theta, L, d); break;
+    case 2: hipLaunchKernelGGL((k_ode_bwd<H, K, M, 2, PARAMS>), grid, block, 0, s, jobs, t, theta, L, d); break;
     default: return XW_E_ARG;
   }
   return xw_launch_status();
@@ -576,11 +620,61 @@ int launch_bwd(int method, const float* xT, const float* t, const double* start,
 
 extern "C" int xw_ode_bwd_slabs(int N) { return (N + 15) / 16; }
 
+extern "C" int xw_ode_fwd_multi(const XwOdeFwdJob* jobs, int njobs, const float* t, const double* theta, int method, int L,
+                                int d, int H, int K, int m, void* stream) {
+  if (!jobs || njobs < 1 || njobs > XW_MAXJOBS || !t || !theta || L <= 0 || d <= 0 || m < 1) return XW_E_ARG;
+  FwdJobs J;
+  J.n = njobs;
+  J.tile0[0] = 0;
+  for (int i = 0; i < XW_MAXJOBS; ++i) {
+    const bool on = i < njobs;
+    if (on && (!jobs[i].xT || !jobs[i].start || !jobs[i].u || jobs[i].N <= 0)) return XW_E_ARG;
+    J.xT[i] = on ? jobs[i].xT : nullptr;
+    J.start[i] = on ? jobs[i].start : nullptr;
+    J.u[i] = on ? jobs[i].u : nullptr;
+    J.Y[i] = on ? jobs[i].Y : nullptr;
+    J.N[i] = on ? jobs[i].N : 0;
+    J.tile0[i + 1] = J.tile0[i] + (on ? (jobs[i].N + 15) / 16 : 0);
+  }
+  hipStream_t s = (hipStream_t)stream;
+#define CALL(HH, KK, MM) return launch_fwd<HH, KK, MM>(method, J, t, theta, L, d, s);
+  XW_ODE_DISPATCH(CALL)
+#undef CALL
+}
+
 extern "C" int xw_ode_fwd(const float* xT, const float* t, const double* start, const double* theta, int method, int N,
                           int L, int d, int H, int K, int m, double* u, double* Y, void* stream) {
-  if (!xT || !t || !start || !theta || !u || N <= 0 || L <= 0 || d <= 0 || m < 1) return XW_E_ARG;
+  XwOdeFwdJob j = {xT, start, u, Y, N};
+  return xw_ode_fwd_multi(&j, 1, t, theta, method, L, d, H, K, m, stream);
+}
+
+extern "C" int xw_ode_bwd_multi(const XwOdeBwdJob* jobs, int njobs, const float* t, const double* theta, int method, int L,
+                                int d, int H, int K, int m, int mode, void* stream) {
+  if (!jobs || njobs < 1 || njobs > XW_MAXJOBS || !t || !theta || L <= 0 || d <= 0 || m < 1 || (mode & 3) == 0) return XW_E_ARG;
+  BwdJobs J;
+  J.n = njobs;
+  J.tile0[0] = 0;
+  for (int i = 0; i < XW_MAXJOBS; ++i) {
+    const bool on = i < njobs;
+    if (on) {
+      if (!jobs[i].xT || !jobs[i].start || !jobs[i].Y || jobs[i].N <= 0) return XW_E_ARG;
+      if ((mode & 2) && !jobs[i].gslab) return XW_E_ARG;
+      if ((mode & 1) && (!jobs[i].gx || !jobs[i].gs)) return XW_E_ARG;
+    }
+    J.xT[i] = on ? jobs[i].xT : nullptr;
+    J.start[i] = on ? jobs[i].start : nullptr;
+    J.Y[i] = on ? jobs[i].Y : nullptr;
+    J.ubar[i] = on ? jobs[i].ubar : nullptr;
+    J.gx[i] = (on && (mode & 1)) ? jobs[i].gx : nullptr;
+    J.gs[i] = (on && (mode & 1)) ? jobs[i].gs : nullptr;
+    J.gslab[i] = (on && (mode & 2)) ? jobs[i].gslab : nullptr;
+    J.N[i] = on ? jobs[i].N : 0;
+    J.tile0[i + 1] = J.tile0[i] + (on ? (jobs[i].N + 15) / 16 : 0);
+  }
   hipStream_t s = (hipStream_t)stream;
-#define CALL(HH, KK, MM) return launch_fwd<HH, KK, MM>(method, xT, t, start, theta, N, L, d, u, Y, s);
+#define CALL(HH, KK, MM)                                                             \
+  return (mode & 2) ? launch_bwd<HH, KK, MM, true>(method, J, t, theta, L, d, s)     \
+                    : launch_bwd<HH, KK, MM, false>(method, J, t, theta, L, d, s);
   XW_ODE_DISPATCH(CALL)
 #undef CALL
 }
@@ -588,15 +682,6 @@ extern "C" int xw_ode_fwd(const float* xT, const float* t, const double* start, 
 extern "C" int xw_ode_bwd(const float* xT, const float* t, const double* start, const double* theta, const double* Y,
                           const double* ubar, int method, int N, int L, int d, int H, int K, int m, int mode, double* gx,
                           double* gs, double* gslab, void* stream) {
-  if (!xT || !t || !start || !theta || !Y || N <= 0 || L <= 0 || d <= 0 || m < 1 || (mode & 3) == 0) return XW_E_ARG;
-  if ((mode & 2) && !gslab) return XW_E_ARG;
-  if ((mode & 1) && (!gx || !gs)) return XW_E_ARG;
-  hipStream_t s = (hipStream_t)stream;
-  double* gx_ = (mode & 1) ? gx : nullptr;
-  double* gs_ = (mode & 1) ? gs : nullptr;
-#define CALL(HH, KK, MM)                                                                                               \
-  return (mode & 2) ? launch_bwd<HH, KK, MM, true>(method, xT, t, start, theta, Y, ubar, N, L, d, gx_, gs_, gslab, s) \
-                    : launch_bwd<HH, KK, MM, false>(method, xT, t, start, theta, Y, ubar, N, L, d, gx_, gs_, gslab, s);
-  XW_ODE_DISPATCH(CALL)
-#undef CALL
+  XwOdeBwdJob j = {xT, start, Y, ubar, gx, gs, gslab, N};
+  return xw_ode_bwd_multi(&j, 1, t, theta, method, L, d, H, K, m, mode, stream);
 }

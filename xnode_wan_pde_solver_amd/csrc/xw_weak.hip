@@ -35,13 +35,16 @@ __device__ __forceinline__ void block_atomic_add(double (&val)[NV], double* dst)
   }
 }
 
-__global__ void __launch_bounds__(256) k_weak_partials(const double* __restrict__ u, const double* __restrict__ v,
+__global__ void __launch_bounds__(64) k_weak_partials(const double* __restrict__ u, const double* __restrict__ v,
                                                        const double* __restrict__ vt, const double* __restrict__ w,
                                                        int w_per_point, const double* __restrict__ wt,
-                                                       const double* __restrict__ s3x, const double* __restrict__ c,
-                                                       double ckappa, const double* __restrict__ f,
-                                                       const double* __restrict__ h, int N, int L, double Vol,
-                                                       double Nglob, double* __restrict__ scal) {
+                                                       const double* __restrict__ s3x, const double* __restrict__ gx,
+                                                       const double* __restrict__ gs, const double* __restrict__ ghT,
+                                                       const double* __restrict__ gxv, const double* __restrict__ w0,
+                                                       const double* __restrict__ gwx0T, int d,
+                                                       const double* __restrict__ c, double ckappa,
+                                                       const double* __restrict__ f, const double* __restrict__ h, int N,
+                                                       int L, double Vol, double Nglob, double* __restrict__ scal) {
   double acc[3] = {0.0, 0.0, 0.0};  // I, sum v^2, SSE_init
   const double cN = Vol / Nglob, cNL = Vol / Nglob / (double)L;
   for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
@@ -58,7 +61,20 @@ __global__ void __launch_bounds__(256) k_weak_partials(const double* __restrict_
       const double cl = c != nullptr ? c[p] : ckappa * ul;
       double s3 = cl * ul * phi + f[p] * phi;         // src/loss.py:70
       if (l == 0) {
-        s3 += s3x[n];                                 // src/loss.py:66-69 (only non-zero at l = 0)
+        double s31;
+        if (s3x != nullptr) {
+          s31 = s3x[n];
+        } else {
+          // a = identity, b = 0:  sum_i d_i phi d_i u  with  nabla phi = w nabla v + v nabla w  (at t_0, on the v-sample)
+          // and  nabla u = G_n = d(sum_l u)/dx_n + d(sum_l u)/d(start) nabla h   
+          s31 = 0.0;
+          const double w0n = w0[n], gsn = gs[n];
+          for (int i = 0; i < d; ++i) {
+            const long q = (long)i * N + n;
+            s31 += (w0n * gxv[q] + vl * gwx0T[q]) * (gx[q] + gsn * ghT[q]);
+          }
+        }
+        s3 += s31;                                    // src/loss.py:66-69 (only non-zero at l = 0)
         u0 = ul;
         I -= cN * hn * vl;                            // s1, src/loss.py:64
       }
@@ -89,31 +105,42 @@ __device__ __forceinline__ double interior_loss(const double* scal, double Vol, 
   return log(I * I) - log(Vol * S / (Nglob * (double)L));  // src/loss.py:89-90
 }
 
-__global__ void __launch_bounds__(256) k_gen_cot(const double* __restrict__ u, const double* __restrict__ v,
-                                                 const double* __restrict__ w, int w_per_point,
-                                                 const double* __restrict__ c, const double* __restrict__ cp,
-                                                 double ckappa, const double* __restrict__ h, int N, int L, double Vol,
-                                                 double Nglob, double Nbglob, double alpha, double pollution,
-                                                 const double* __restrict__ scal_in, double* __restrict__ ubar,
-                                                 double* __restrict__ scal_out) {
-  const double I = scal_in[0];
-  const double cI = 2.0 / I;                          // d log(I^2) / dI
+// Generator cotangent bases (both available right after the forward passes -- neither needs the global I):
+//   ubarA = pollution + alpha * d(init)/du        ubarB = dI/du
+// d loss_u/d theta = J^T ubarA + (2/I) J^T ubarB (+ the boundary sweep); the 2/I is applied inside the Adam kernel.
+__global__ void __launch_bounds__(256) k_gen_cots(const double* __restrict__ u, const double* __restrict__ v,
+                                                  const double* __restrict__ w, int w_per_point,
+                                                  const double* __restrict__ c, const double* __restrict__ cp,
+                                                  double ckappa, const double* __restrict__ h, int N, int L, double Vol,
+                                                  double Nglob, double alpha, double pollution,
+                                                  double* __restrict__ ubarA, double* __restrict__ ubarB) {
   const double cN = Vol / Nglob, cNL = Vol / Nglob / (double)L;
   const long P = (long)N * L;
   for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (long)gridDim.x * blockDim.x) {
     const int l = (int)(p / N), n = (int)(p - (long)l * N);
-    const double ul = u[p], vl = v[p];
+    const double ul = u[p];
+    const double vl = ubarB != nullptr ? v[p] : 0.0;   // basis A does not read the test network at all
     const double wl = w_per_point ? w[p] : w[n];
     const double dcu = c != nullptr ? c[p] + ul * cp[p] : 2.0 * ckappa * ul;   // d(c(u) u)/du
-    double g = pollution + cI * cNL * dcu * vl * wl;
-    if (l == L - 1) g += cI * cN * vl;
-    if (l == 0) g += alpha * 2.0 * (ul - h[n]) / Nglob;
-    ubar[p] = g;
+    if (ubarB != nullptr) {
+      double gB = cNL * dcu * vl * wl;                 // through c u phi  (src/loss.py:70)
+      if (l == L - 1) gB += cN * vl;                   // through s1       (src/loss.py:64)
+      ubarB[p] = gB;
+    }
+    if (ubarA != nullptr) {
+      double gA = pollution;                           // helper backward  (src/loss.py:55)
+      if (l == 0) gA += alpha * 2.0 * (ul - h[n]) / Nglob;   // initial penalty  (src/loss.py:79,93)
+      ubarA[p] = gA;
+    }
   }
+}
+
+__global__ void k_losses(double* __restrict__ scal, int L, double Vol, double Nglob, double Nbglob, double alpha) {
   if (blockIdx.x == 0 && threadIdx.x == 0) {
-    const double in_ = interior_loss(scal_in, Vol, Nglob, L);
-    scal_out[6] = in_;
-    scal_out[4] = in_ + alpha * (scal_in[2] / Nglob + scal_in[3] / (Nbglob * (double)L));  // src/loss.py:93
+    const double in_ = interior_loss(scal, Vol, Nglob, L);
+    scal[6] = in_;
+    scal[4] = in_ + alpha * (scal[2] / Nglob + scal[3] / (Nbglob * (double)L));  // src/loss.py:93
+    scal[5] = -in_;                                                                // src/loss.py:96
   }
 }
 
@@ -122,8 +149,7 @@ __global__ void __launch_bounds__(256) k_disc_cot(const double* __restrict__ u, 
                                                   const double* __restrict__ c, double ckappa,
                                                   const double* __restrict__ f, const double* __restrict__ h, int N,
                                                   int L, double Vol, double Nglob, double pollution,
-                                                  const double* __restrict__ scal_in, double* __restrict__ vbar,
-                                                  double* __restrict__ scal_out) {
+                                                  const double* __restrict__ scal_in, double* __restrict__ vbar) {
   const double I = scal_in[0], S = scal_in[1];
   const double cI = 2.0 / I;
   const double cN = Vol / Nglob, cNL = Vol / Nglob / (double)L;
@@ -138,34 +164,49 @@ __global__ void __launch_bounds__(256) k_disc_cot(const double* __restrict__ u, 
     if (l == 0) dI -= cN * h[n];
     vbar[p] = pollution * wl - cI * dI + 2.0 * vl / S;  // loss_v = -(log I^2 - log(V S / P))
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    const double in_ = interior_loss(scal_in, Vol, Nglob, L);
-    scal_out[6] = in_;
-    scal_out[5] = -in_;                               // src/loss.py:96
-  }
 }
 
-// torch.optim.Adam (betas, eps defaults; no weight decay, no amsgrad).  One block: P is a few thousand.
-__global__ void __launch_bounds__(1024) k_adam(double* __restrict__ param, const double* __restrict__ gslab, int nslab,
-                                               const double* __restrict__ gextra, double* __restrict__ m,
-                                               double* __restrict__ v, long long* __restrict__ step, int P, double lr,
-                                               double beta1, double beta2, double eps, double* __restrict__ gsum_out) {
+// torch.optim.Adam (betas, eps defaults; no weight decay, no amsgrad) fused with the reduction of the per-wave gradient
+// slabs:   g = eA + sum_s A[s] + coefB * (eB + sum_s B[s]),   coefB = scal ? 2 / scal[0] : 1
+// (A: cotangent basis that needs no global scalar, B: the dI/du basis scaled by d log(I^2)/dI).
+// Block = 64 parameters x 16 slab groups; grid = P / 64.
+__global__ void __launch_bounds__(1024) k_adam(double* __restrict__ param, const double* __restrict__ gA, int nA,
+                                               const double* __restrict__ eA, const double* __restrict__ gB, int nB,
+                                               const double* __restrict__ eB, const double* __restrict__ scal,
+                                               double* __restrict__ m, double* __restrict__ v,
+                                               const long long* __restrict__ step, int P, double lr, double beta1,
+                                               double beta2, double eps, double* __restrict__ gsum_out) {
+  __shared__ double red[2][16][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + tx;
+  double a = 0.0, b = 0.0;
+  if (i < P) {
+    for (int s = ty; s < nA; s += 16) a += gA[(long)s * P + i];
+    for (int s = ty; s < nB; s += 16) b += gB[(long)s * P + i];
+  }
+  red[0][ty][tx] = a;
+  red[1][ty][tx] = b;
+  __syncthreads();
+  if (ty != 0 || i >= P) return;
+  a = eA != nullptr ? eA[i] : 0.0;
+  b = eB != nullptr ? eB[i] : 0.0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    a += red[0][k][tx];
+    b += red[1][k][tx];
+  }
+  const double coefB = scal != nullptr ? 2.0 / scal[0] : 1.0;
+  const double g = a + coefB * b;
+  if (gsum_out != nullptr) gsum_out[i] = g;
   const long long t = *step + 1;
   const double bc1 = 1.0 - pow(beta1, (double)t), bc2 = 1.0 - pow(beta2, (double)t);
-  const double step_size = lr / bc1, rs2 = sqrt(bc2);
-  for (int i = threadIdx.x; i < P; i += blockDim.x) {
-    double g = gextra != nullptr ? gextra[i] : 0.0;
-    for (int s = 0; s < nslab; ++s) g += gslab[(long)s * P + i];
-    if (gsum_out != nullptr) gsum_out[i] = g;
-    const double mi = beta1 * m[i] + (1.0 - beta1) * g;
-    const double vi = beta2 * v[i] + (1.0 - beta2) * g * g;
-    m[i] = mi;
-    v[i] = vi;
-    param[i] -= step_size * (mi / (sqrt(vi) / rs2 + eps));
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) *step = t;
+  const double mi = beta1 * m[i] + (1.0 - beta1) * g;
+  const double vi = beta2 * v[i] + (1.0 - beta2) * g * g;
+  m[i] = mi;
+  v[i] = vi;
+  param[i] -= (lr / bc1) * (mi / (sqrt(vi) / sqrt(bc2) + eps));
 }
+__global__ void k_step_inc(long long* step) { *step += 1; }
 
 __global__ void __launch_bounds__(256) k_slab_sum(const double* __restrict__ gslab, int nslab, int P, int accumulate,
                                                   double* __restrict__ out) {
@@ -185,11 +226,14 @@ inline int blocks_for(long n, int per, int cap) {
 }  // namespace
 
 extern "C" int xw_weak_partials(const double* u, const double* v, const double* vt, const double* w, int w_per_point,
-                                const double* wt, const double* s3x, const double* c, double ckappa, const double* f,
-                                const double* h, int N, int L, double Vol, double Nglob, double* scal, void* stream) {
-  if (!u || !v || !vt || !w || !s3x || !f || !h || !scal || N <= 0 || L <= 0) return XW_E_ARG;
-  hipLaunchKernelGGL(k_weak_partials, dim3(blocks_for(N, 256, 1024)), dim3(256), 0, (hipStream_t)stream, u, v, vt, w,
-                     w_per_point, wt, s3x, c, ckappa, f, h, N, L, Vol, Nglob, scal);
+                                const double* wt, const double* s3x, const double* gx, const double* gs, const double* ghT,
+                                const double* gxv, const double* w0, const double* gwx0T, int d, const double* c,
+                                double ckappa, const double* f, const double* h, int N, int L, double Vol, double Nglob,
+                                double* scal, void* stream) {
+  if (!u || !v || !vt || !w || !f || !h || !scal || N <= 0 || L <= 0) return XW_E_ARG;
+  if (!s3x && (!gx || !gs || !ghT || !gxv || !w0 || !gwx0T || d <= 0)) return XW_E_ARG;
+  hipLaunchKernelGGL(k_weak_partials, dim3(blocks_for(N, 64, 1024)), dim3(64), 0, (hipStream_t)stream, u, v, vt, w,
+                     w_per_point, wt, s3x, gx, gs, ghT, gxv, w0, gwx0T, d, c, ckappa, f, h, N, L, Vol, Nglob, scal);
   return xw_launch_status();
 }
 
@@ -202,32 +246,38 @@ extern "C" int xw_bdry_partials(const double* ub, const double* g, int Nb, int L
   return xw_launch_status();
 }
 
-extern "C" int xw_gen_cotangent(const double* u, const double* v, const double* w, int w_per_point, const double* c,
-                                const double* cp, double ckappa, const double* h, int N, int L, double Vol, double Nglob,
-                                double Nbglob, double alpha, double pollution, const double* scal_in, double* ubar,
-                                double* scal_out, void* stream) {
-  if (!u || !v || !w || !h || !scal_in || !ubar || !scal_out || N <= 0 || L <= 0) return XW_E_ARG;
+extern "C" int xw_gen_cotangents(const double* u, const double* v, const double* w, int w_per_point, const double* c,
+                                 const double* cp, double ckappa, const double* h, int N, int L, double Vol, double Nglob,
+                                 double alpha, double pollution, double* ubarA, double* ubarB, void* stream) {
+  if (!u || !w || !h || (!ubarA && !ubarB) || (ubarB && !v) || N <= 0 || L <= 0) return XW_E_ARG;
   if ((c == nullptr) != (cp == nullptr)) return XW_E_ARG;
-  hipLaunchKernelGGL(k_gen_cot, dim3(blocks_for((long)N * L, 256, 2048)), dim3(256), 0, (hipStream_t)stream, u, v, w,
-                     w_per_point, c, cp, ckappa, h, N, L, Vol, Nglob, Nbglob, alpha, pollution, scal_in, ubar, scal_out);
+  hipLaunchKernelGGL(k_gen_cots, dim3(blocks_for((long)N * L, 256, 2048)), dim3(256), 0, (hipStream_t)stream, u, v, w,
+                     w_per_point, c, cp, ckappa, h, N, L, Vol, Nglob, alpha, pollution, ubarA, ubarB);
+  return xw_launch_status();
+}
+
+extern "C" int xw_losses(double* scal, int L, double Vol, double Nglob, double Nbglob, double alpha, void* stream) {
+  if (!scal || L <= 0) return XW_E_ARG;
+  hipLaunchKernelGGL(k_losses, dim3(1), dim3(64), 0, (hipStream_t)stream, scal, L, Vol, Nglob, Nbglob, alpha);
   return xw_launch_status();
 }
 
 extern "C" int xw_disc_cotangent(const double* u, const double* v, const double* w, int w_per_point, const double* c,
                                  double ckappa, const double* f, const double* h, int N, int L, double Vol, double Nglob,
-                                 double pollution, const double* scal_in, double* vbar, double* scal_out, void* stream) {
-  if (!u || !v || !w || !f || !h || !scal_in || !vbar || !scal_out || N <= 0 || L <= 0) return XW_E_ARG;
+                                 double pollution, const double* scal_in, double* vbar, void* stream) {
+  if (!u || !v || !w || !f || !h || !scal_in || !vbar || N <= 0 || L <= 0) return XW_E_ARG;
   hipLaunchKernelGGL(k_disc_cot, dim3(blocks_for((long)N * L, 256, 2048)), dim3(256), 0, (hipStream_t)stream, u, v, w,
-                     w_per_point, c, ckappa, f, h, N, L, Vol, Nglob, pollution, scal_in, vbar, scal_out);
+                     w_per_point, c, ckappa, f, h, N, L, Vol, Nglob, pollution, scal_in, vbar);
   return xw_launch_status();
 }
 
-extern "C" int xw_adam(double* param, const double* gslab, int nslab, const double* gextra, double* m, double* v,
-                       long long* step, int P, double lr, double beta1, double beta2, double eps, double* gsum_out,
-                       void* stream) {
-  if (!param || !m || !v || !step || P <= 0 || nslab < 0 || (nslab > 0 && !gslab)) return XW_E_ARG;
-  hipLaunchKernelGGL(k_adam, dim3(1), dim3(1024), 0, (hipStream_t)stream, param, gslab, nslab, gextra, m, v, step, P, lr,
-                     beta1, beta2, eps, gsum_out);
+extern "C" int xw_adam(double* param, const double* gslabA, int nA, const double* gextraA, const double* gslabB, int nB,
+                       const double* gextraB, const double* scal, double* m, double* v, long long* step, int P, double lr,
+                       double beta1, double beta2, double eps, double* gsum_out, void* stream) {
+  if (!param || !m || !v || !step || P <= 0 || nA < 0 || nB < 0 || (nA > 0 && !gslabA) || (nB > 0 && !gslabB)) return XW_E_ARG;
+  hipLaunchKernelGGL(k_adam, dim3((P + 63) / 64), dim3(1024), 0, (hipStream_t)stream, param, gslabA, nA, gextraA, gslabB,
+                     nB, gextraB, scal, m, v, step, P, lr, beta1, beta2, eps, gsum_out);
+  hipLaunchKernelGGL(k_step_inc, dim3(1), dim3(1), 0, (hipStream_t)stream, step);
   return xw_launch_status();
 }
 
@@ -237,7 +287,7 @@ extern "C" int xw_slab_sum(const double* gslab, int nslab, int P, int accumulate
   return xw_launch_status();
 }
 
-extern "C" int xw_abi_version(void) { return 1; }
+extern "C" int xw_abi_version(void) { return 2; }
 
 extern "C" int xw_supported_dims(char* buf, int buflen) {
   static const char s[] = "ode(H,K,m)=(20,10,8),(20,10,4),(20,10,2); disc_fwd W=50 any q; disc_bwd (W,q)=(50,9), d<=126";

@@ -4,16 +4,16 @@ The reference's only parallelism is nn.DataParallel around both nets (src/traini
 broadcasts the parameters, scatters the [N, L, d+1] batch along dim 0 and gathers the outputs; per backward it
 reduce-adds the gradients.  Here nothing but two small buffers ever crosses xGMI per optimiser sub-step:
 
-  1. scal[0:4] = (I, sum v^2, SSE_init, SSE_bdry) partial sums          32 bytes     all-reduce(sum)
-     -- the loss is log(I^2) - log(V S / P) + alpha (...): NOT a sum over paths, so the global I and S must be known
-        before the cotangents 2/I * dI/du, 2 v / S can be formed (engine._forward)
-  2. the packed parameter gradient (P_u = 1451 + 10 d or P_v = 2701 + 50 d doubles; 13 / 30 KB at d = 20)   all-reduce(sum)
-     -- every rank then applies the identical fused Adam update, so parameters stay bit-identical without broadcasts.
-
-Both messages are latency-bound (RCCL's LL protocol on the fully connected xGMI mesh).  The north star asks for a
-single all-reduce per step; folding (1) into (2) would need three separate parameter sweeps (gradient bases for
-1, dI/du and the penalties) instead of one -- about 2x the backward work -- so the 32-byte pre-reduce is kept
-(multi-GPU).  The 1/N, 1/(N L), 1/(N_b L) factors use GLOBAL counts on every rank.
+  generator sub-step: ONE all-reduce of [ J^T ubarA (P_u) | J^T ubarB (P_u) | I, sum v^2, SSE_init, SSE_bdry ]
+     (2 P_u + 16 doubles = 26 KB at d = 20).  The loss is log(I^2) - log(V S / P) + alpha (...), NOT a sum over paths,
+     but its theta-gradient is  J^T ubarA + (2/I) J^T ubarB  with two cotangent bases that need no global scalar
+     (xw_gen_cotangents); the 2/I factor is applied after the exchange, inside the fused Adam kernel.
+  discriminator sub-step: TWO all-reduces -- (I, sum v^2) (32 bytes) before the cotangent
+     vbar = w - (2/I) dI/dv + 2 v / S can be formed, then the packed gradient (P_v doubles, 30 KB at d = 20).  Folding
+     them into one would need three backward passes through the test network (the dominant kernel) instead of one.
+Every rank applies the identical fused Adam update, so parameters stay bit-identical without broadcasts.  All
+messages are latency-bound (RCCL LL protocol on the fully connected xGMI mesh).  The 1/N, 1/(N L), 1/(N_b L) factors
+use GLOBAL counts on every rank.
 """
 import os
 

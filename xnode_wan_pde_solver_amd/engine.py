@@ -66,8 +66,13 @@ class Structure:
 
 
 class Group:
-    """Device-resident data of one group of equal-length paths + every buffer its sub-steps need (allocated once)."""
-    pass
+    """Device-resident data of one group of equal-length paths + every buffer its sub-steps need.  Buffers are allocated
+    once and refilled in place by Engine.load_group(..., into=G), so captured HIP graphs stay valid across resampling."""
+    SAMPLE_FIELDS = ('t', 'xT', 'xvT', 'xbT', 'start', 'ghT', 'h', 'f', 'w', 'wt', 'w0', 'gwx0T', 'start_b', 'g', 'X',
+                     'A0', 'B0')
+
+    def signature(self):
+        return tuple((k, tuple(getattr(self, k).shape)) for k in self.SAMPLE_FIELDS if getattr(self, k, None) is not None)
 
 
 class Engine:
@@ -90,156 +95,299 @@ class Engine:
         self.adam_u = dict(m=z(self.Pu), v=z(self.Pu), step=torch.zeros(1, dtype=torch.int64, device=device))
         self.adam_v = dict(m=z(self.Pv), v=z(self.Pv), step=torch.zeros(1, dtype=torch.int64, device=device))
         self.grad_u, self.grad_v = z(self.Pu), z(self.Pv)   # the gradient Adam saw in the last sub-step
-        self.scal = z(16)
+        # generator exchange buffer [sum of A slabs | sum of B slabs | scal]: ONE all-reduce per generator sub-step
+        self.pack_u = z(2 * self.Pu + 16)
+        self.scal = self.pack_u[2 * self.Pu:]
+        self.use_streams = True          # independent kernel chains on side streams (test net, boundary, the two sweeps)
+        self.use_graphs = True           # capture each sub-step of a group into a HIP graph and replay it
+        self.streams = [torch.cuda.Stream(device=device) for _ in range(4)]
 
     # ------------------------------------------------------------------------------------------------------------
     # per-sample preparation (once per outer iteration; everything here is parameter-independent)
     # ------------------------------------------------------------------------------------------------------------
-    def load_group(self, X, XV, BX, domain, n_glob=None, nb_glob=None):
+    def load_group(self, X, XV, BX, domain, n_glob=None, nb_glob=None, into=None):
         """Prepare one group.  The user's callables (h, f, g, func_w, a, b) are evaluated on the device the given
         tensors live on and only their results are uploaded: pass the loader's host tensors to tabulate exactly like
         the reference's CPU path, or device tensors to tabulate on the GPU (float32 transcendental functions then
-        differ from the host's in the last bit)."""
+        differ from the host's in the last bit).  `into`: a Group of the same shapes to refill in place."""
         dev, d = self.dev, self.d
-        G = Group()
         X, XV = X.detach(), XV.detach()
         BX = BX.detach() if BX is not None else None
-        G.domain = domain
-        G.N, G.L = X.shape[0], X.shape[1]
-        G.Nb = BX.shape[0] if BX is not None else 0
-        G.Nglob = float(n_glob if n_glob is not None else G.N)
-        G.Nbglob = float(nb_glob if nb_glob is not None else max(G.Nb, 1))
-        G.Vol = float(domain.V())
-        G.t = X[0, :, 0].to(dev).to(F32).contiguous()
-        G.xT = X[:, 0, 1:].to(dev).to(F32).t().contiguous()
-        G.xvT = XV[:, 0, 1:].to(dev).to(F32).t().contiguous()
-        if XV.shape[1] != G.L:
-            raise XnwanError('u- and v-samples of a group must share the time grid')
+        N, L = X.shape[0], X.shape[1]
+        Nb = BX.shape[0] if BX is not None else 0
+        if XV.shape[1] != L or XV.shape[0] != N:
+            raise XnwanError('u- and v-samples of a group must have the same shape')
+        S = {}
+        S['t'] = X[0, :, 0].to(dev).to(F32).contiguous()
+        S['xT'] = X[:, 0, 1:].to(dev).to(F32).t().contiguous()
+        S['xvT'] = XV[:, 0, 1:].to(dev).to(F32).t().contiguous()
         # start values and their x-gradient (the h -> y0 path of nabla_x u, src/model.py:95)
         X0 = X[:, 0, :].clone().requires_grad_(True)
         starts_T0 = float(X[0, 0, 0]) == self.setup['T0']
         s = self.funcs['h'](X0) if starts_T0 else self.funcs['g'](X0.unsqueeze(1)).reshape(-1)
-        G.start = s.detach().to(dev).to(F64).reshape(-1).contiguous()
+        S['start'] = s.detach().to(dev).to(F64).reshape(-1).contiguous()
         if s.requires_grad:
-            G.ghT = torch.autograd.grad(s.sum(), X0)[0][:, 1:].to(dev).to(F64).t().contiguous()
+            S['ghT'] = torch.autograd.grad(s.sum(), X0)[0][:, 1:].to(dev).to(F64).t().contiguous()
         else:
-            G.ghT = torch.zeros(d, G.N, dtype=F64, device=dev)
-        G.h = self.funcs['h'](X[:, 0, :]).detach().to(dev).to(F64).reshape(-1).contiguous()
-        G.f = _to_LN(self.funcs['f'](X), dev)
+            S['ghT'] = torch.zeros(d, N, dtype=F64, device=dev)
+        S['h'] = self.funcs['h'](X[:, 0, :]).detach().to(dev).to(F64).reshape(-1).contiguous()
+        S['f'] = _to_LN(self.funcs['f'](X), dev)
         # distance weight on the v-sample and its gradient (nabla phi = w nabla v + v nabla w, src/loss.py:51-63)
         XVl = XV.clone().requires_grad_(True)
         w = domain.func_w(XVl)
         gw = torch.autograd.grad(w.sum(), XVl)[0] if w.requires_grad else torch.zeros_like(XVl)
         if getattr(domain, 'time_independent', False):
-            G.w = w[:, 0].detach().to(dev).to(F64).contiguous()
-            G.wt = None
+            S['w'] = w[:, 0].detach().to(dev).to(F64).contiguous()
+            S['wt'] = None
         else:
-            G.w = _to_LN(w, dev)
-            G.wt = _to_LN(gw[:, :, 0], dev)
-        G.w0 = w[:, 0].detach().to(dev).to(F64).contiguous()
-        G.gwx0T = gw[:, 0, 1:].to(dev).to(F64).t().contiguous()
+            S['w'] = _to_LN(w, dev)
+            S['wt'] = _to_LN(gw[:, :, 0], dev)
+        S['w0'] = w[:, 0].detach().to(dev).to(F64).contiguous()
+        S['gwx0T'] = gw[:, 0, 1:].to(dev).to(F64).t().contiguous()
+        S['xbT'] = S['start_b'] = S['g'] = None
         if BX is not None:
-            G.xbT = BX[:, 0, 1:].to(dev).to(F32).t().contiguous()
+            S['xbT'] = BX[:, 0, 1:].to(dev).to(F32).t().contiguous()
             b_T0 = float(BX[0, 0, 0]) == self.setup['T0']
             sb = self.funcs['h'](BX[:, 0, :]) if b_T0 else self.funcs['g'](BX[:, 0, :].unsqueeze(1)).reshape(-1)
-            G.start_b = sb.detach().to(dev).to(F64).reshape(-1).contiguous()
-            G.g = _to_LN(self.funcs['g'](BX), dev)
-            if not torch.equal(BX[0, :, 0].to(dev).to(F32), G.t):
-                raise XnwanError('boundary and interior groups of the cube share one time grid')
-        G.X = X.to(dev)                          # only read by a general (non-linear) reaction callable c(u, t, x)
+            S['start_b'] = sb.detach().to(dev).to(F64).reshape(-1).contiguous()
+            S['g'] = _to_LN(self.funcs['g'](BX), dev)
+            if not torch.equal(BX[0, :, 0].to(dev).to(F32), S['t']):
+                raise XnwanError('boundary and interior paths of a group share one time grid')
         st = self.structure
-        G.A0 = G.B0 = None
+        S['X'] = X.to(dev) if st.c_kappa is None else None      # only read by a general reaction callable c(u, t, x)
+        S['A0'] = S['B0'] = None
         if not st.a_identity:
             X1 = X[:, :1, :]
-            G.A0 = torch.stack([torch.stack([self.funcs['a'](X1, i, j).to(dev).to(F64)[:, 0] for j in range(d)], 0)
-                                for i in range(d)], 0)                       # [d, d, N] at time index 0
+            S['A0'] = torch.stack([torch.stack([self.funcs['a'](X1, i, j).to(dev).to(F64)[:, 0] for j in range(d)], 0)
+                                   for i in range(d)], 0).contiguous()     # [d, d, N] at time index 0
         if not st.b_zero:
             X1 = X[:, :1, :]
-            G.B0 = torch.stack([self.funcs['b'](X1, i).to(dev).to(F64)[:, 0] for i in range(d)], 0)   # [d, N]
+            S['B0'] = torch.stack([self.funcs['b'](X1, i).to(dev).to(F64)[:, 0] for i in range(d)], 0).contiguous()
+        vol = float(domain.V())
+        nglob = float(n_glob if n_glob is not None else N)
+        nbglob = float(nb_glob if nb_glob is not None else max(Nb, 1))
+        if into is not None:
+            G = into
+            same = (G.N, G.L, G.Nb, G.Vol, G.Nglob, G.Nbglob) == (N, L, Nb, vol, nglob, nbglob) and all(
+                (getattr(G, k) is None) == (S[k] is None) and (S[k] is None or getattr(G, k).shape == S[k].shape)
+                for k in Group.SAMPLE_FIELDS)
+            if same:
+                for k in Group.SAMPLE_FIELDS:
+                    if S[k] is not None:
+                        getattr(G, k).copy_(S[k])
+                G.domain = domain
+                return G
+        G = Group()
+        for k in Group.SAMPLE_FIELDS:
+            setattr(G, k, S[k])
+        G.domain, G.N, G.L, G.Nb, G.Vol, G.Nglob, G.Nbglob = domain, N, L, Nb, vol, nglob, nbglob
         # work buffers
         e = lambda *s_: torch.empty(*s_, dtype=F64, device=dev)  # noqa: E731
-        L, N, Nb, H = G.L, G.N, G.Nb, self.H
+        H = self.H
         G.u, G.Y, G.v, G.vt = e(L, N), e(L, H, N), e(L, N), e(L, N)
         G.gxv, G.gtv, G.gx, G.gs = e(d, N), e(N), e(d, N), e(N)
-        G.ubar, G.vbar, G.s3x = e(L, N), e(L, N), e(N)
+        G.ubarA, G.ubarB, G.vbar, G.s3x = e(L, N), e(L, N), e(L, N), e(N)
+        G.c = G.cp = None
         G.ns_u = KN.ode_bwd_slabs(N)
         G.ns_b = KN.ode_bwd_slabs(Nb) if Nb else 0
-        G.slab_u = e(G.ns_u + G.ns_b, self.Pu)
+        G.slabA = e(G.ns_u + G.ns_b, self.Pu)          # sweep with cotangent A (interior) + the boundary sweep
+        G.slabB = e(G.ns_u, self.Pu)                   # sweep with cotangent B = dI/du
         G.slab_v = e(KN.disc_bwd_slabs(N, L), self.Pv)
         if Nb:
             G.ub, G.Yb, G.ubar_b = e(L, Nb), e(L, H, Nb), e(L, Nb)
+        G.graphs = {}
         return G
 
     # ------------------------------------------------------------------------------------------------------------
-    # shared front half of both sub-steps
+    # building blocks
     # ------------------------------------------------------------------------------------------------------------
-    def _forward(self, G, boundary):
-        th, ph = self.theta.data, self.phi.data
+    def _side(self, i, *events):
+        """context: run on side stream i after `events` (falls back to the current stream when streams are off)"""
+        if not self.use_streams:
+            return torch.cuda.stream(torch.cuda.current_stream())
+        st = self.streams[i]
+        for ev in events:
+            st.wait_event(ev)
+        return torch.cuda.stream(st)
+
+    def _mark(self):
+        return torch.cuda.current_stream().record_event()
+
+    def _join(self, *events):
+        if self.use_streams:
+            cur = torch.cuda.current_stream()
+            for ev in events:
+                cur.wait_event(ev)
+
+    def _test_net(self, G):
+        ph = self.phi.data
         KN.disc_fwd(G.xvT, G.t, ph, self.W, self.q, v=G.v, vt=G.vt)                       # v, dv/dt at all points
         KN.disc_gradx(G.xvT, G.t, ph, self.W, self.q, gxv=G.gxv, gtv=G.gtv)               # nabla_x v at t_0
-        KN.ode_fwd(G.xT, G.t, G.start, th, self.method, self.H, self.K, self.m, u=G.u, Y=G.Y)
-        if boundary:
-            KN.ode_fwd(G.xbT, G.t, G.start_b, th, self.method, self.H, self.K, self.m, u=G.ub, Y=G.Yb)
-        # helper backward #1 (src/loss.py:55): G_n = d(sum_l u)/dx_n, including the path through the start value
-        KN.ode_bwd(G.xT, G.t, G.start, th, G.Y, None, self.method, self.H, self.K, self.m, want_x=True, want_params=False,
-                   gx=G.gx, gs=G.gs)
-        Gx = G.gx + G.gs.unsqueeze(0) * G.ghT                                              # [d, N]
-        dphi0 = G.w0.unsqueeze(0) * G.gxv + G.v[0].unsqueeze(0) * G.gwx0T                  # nabla_x phi at t_0, [d, N]
-        if G.A0 is None:
-            s3x = (dphi0 * Gx).sum(0)
-        else:
-            s3x = torch.einsum('ijn,in,jn->n', G.A0, dphi0, Gx)
-        if G.B0 is not None:
-            s3x = s3x + G.v[0] * G.w0 * (G.B0 * Gx).sum(0)
-        G.s3x.copy_(s3x)
-        # reaction term c(u, t, x): linear fast path or the user's callable differentiated by autograd
-        G.c = G.cp = None
+
+    def _reaction(self, G):
+        """c(u, t, x): linear fast path, or the user's callable differentiated by autograd (not graph-capturable)"""
         ck = self.structure.c_kappa
         if ck is None:
             ul = G.u.t().unsqueeze(2).detach().requires_grad_(True)
-            c = self.funcs['c'](G.X, ul)
-            cp = torch.autograd.grad(c.sum(), ul)[0] if c.requires_grad else torch.zeros_like(ul)
+            with torch.enable_grad():
+                c = self.funcs['c'](G.X, ul)
+                cp = torch.autograd.grad(c.sum(), ul)[0] if c.requires_grad else torch.zeros_like(ul)
             G.c, G.cp = _to_LN(c.squeeze(2), self.dev), _to_LN(cp.squeeze(2), self.dev)
             ck = 0.0
         G.ck = ck
-        self.scal.zero_()
-        KN.weak_partials(G.u, G.v, G.vt, G.w, G.s3x, G.f, G.h, G.Vol, G.Nglob, self.scal, c=G.c, ckappa=ck, wt=G.wt)
-        if boundary:
-            KN.bdry_partials(G.ub, G.g, self.alpha, G.Nbglob, self.scal, ubar_b=G.ubar_b)
-        if self.world is not None:
-            self.world.all_reduce(self.scal[0:4])
 
-    def _apply_adam(self, blob, slabs, state, lr, gsum):
-        if self.world is None:
-            KN.adam(blob.data, slabs, state['m'], state['v'], state['step'], lr, gsum_out=gsum)
+    def _job(self, G, which, ubar=None, gslab=None, want_x=False):
+        if which == 'i':
+            j = dict(xT=G.xT, start=G.start, u=G.u, Y=G.Y, ubar=ubar, gslab=gslab)
+            if want_x:
+                j.update(gx=G.gx, gs=G.gs)
         else:
-            KN.slab_sum(slabs, out=gsum)
-            self.world.all_reduce(gsum)
-            KN.adam(blob.data, None, state['m'], state['v'], state['step'], lr, gextra=gsum)
+            j = dict(xT=G.xbT, start=G.start_b, u=G.ub, Y=G.Yb, ubar=ubar, gslab=gslab)
+        return j
+
+    def _contract(self, G):
+        """I, sum v^2, SSE_init from u, v, dv/dt and the two helper-backward gradients (src/loss.py:46-76)"""
+        if G.A0 is None and G.B0 is None:
+            KN.weak_partials(G.u, G.v, G.vt, G.w, G.f, G.h, G.Vol, G.Nglob, self.scal, c=G.c, ckappa=G.ck, wt=G.wt,
+                             contract=dict(gx=G.gx, gs=G.gs, ghT=G.ghT, gxv=G.gxv, w0=G.w0, gwx0T=G.gwx0T))
+            return
+        Gx = G.gx + G.gs.unsqueeze(0) * G.ghT                                              # [d, N]
+        dphi0 = G.w0.unsqueeze(0) * G.gxv + G.v[0].unsqueeze(0) * G.gwx0T                  # nabla_x phi at t_0, [d, N]
+        s3x = (dphi0 * Gx).sum(0) if G.A0 is None else torch.einsum('ijn,in,jn->n', G.A0, dphi0, Gx)
+        if G.B0 is not None:
+            s3x = s3x + G.v[0] * G.w0 * (G.B0 * Gx).sum(0)
+        G.s3x.copy_(s3x)
+        KN.weak_partials(G.u, G.v, G.vt, G.w, G.f, G.h, G.Vol, G.Nglob, self.scal, s3x=G.s3x, c=G.c, ckappa=G.ck, wt=G.wt)
 
     # ------------------------------------------------------------------------------------------------------------
-    def generator_step(self, G):
-        """one pass of the generator sub-step body (src/training.py:127-138); returns nothing -- loss in scal[4]"""
-        self._forward(G, boundary=G.Nb > 0)
-        KN.gen_cotangent(G.u, G.v, G.w, G.h, G.Vol, G.Nglob, G.Nbglob, self.alpha, self.scal, G.ubar, c=G.c, cp=G.cp,
-                         ckappa=G.ck, pollution=self.pollution)
+    # generator sub-step (src/training.py:127-138)
+    # ------------------------------------------------------------------------------------------------------------
+    def _gen_front(self, G):
+        """everything up to (not including) the exchange: leaves slabA, slabB and scal[0..3] complete.
+        Kernel chains:  main   u-forward (interior + boundary, one launch) -> cotangent A, boundary residual
+                               -> parameter sweeps {interior/A, boundary} (one launch)
+                        side 0 test network v, dv/dt, nabla_x v(t_0)             (independent of theta)
+                        side 1 x-sweep (nabla_x u)                               (after the forward)
+                        side 2 cotangent B = dI/du -> parameter sweep B          (after the forward and v)"""
         th = self.theta.data
-        KN.ode_bwd(G.xT, G.t, G.start, th, G.Y, G.ubar, self.method, self.H, self.K, self.m, want_x=False,
-                   want_params=True, gslab=G.slab_u[:G.ns_u])
+        M = (self.method, self.H, self.K, self.m)
+        self.scal.zero_()
+        e0 = self._mark()
+        with self._side(0, e0):
+            self._test_net(G)
+            e_v = self._mark()
+        fwd = [self._job(G, 'i')] + ([self._job(G, 'b')] if G.Nb else [])
+        KN.ode_fwd_multi(fwd, G.t, th, *M)
+        self._reaction(G)
+        e_f = self._mark()
+        with self._side(1, e_f):
+            KN.ode_bwd_multi([self._job(G, 'i', want_x=True)], G.t, th, *M, want_x=True, want_params=False)
+            e_x = self._mark()
+        with self._side(2, e_f, e_v):
+            KN.gen_cotangents(G.u, G.v, G.w, G.h, G.Vol, G.Nglob, self.alpha, None, G.ubarB, c=G.c, cp=G.cp, ckappa=G.ck,
+                              pollution=self.pollution)
+            KN.ode_bwd_multi([self._job(G, 'i', G.ubarB, G.slabB)], G.t, th, *M, want_x=False, want_params=True)
+            e_B = self._mark()
+        KN.gen_cotangents(G.u, None, G.w, G.h, G.Vol, G.Nglob, self.alpha, G.ubarA, None, c=G.c, cp=G.cp, ckappa=G.ck,
+                          pollution=self.pollution)
+        sweeps = [self._job(G, 'i', G.ubarA, G.slabA[:G.ns_u])]
         if G.Nb:
-            KN.ode_bwd(G.xbT, G.t, G.start_b, th, G.Yb, G.ubar_b, self.method, self.H, self.K, self.m, want_x=False,
-                       want_params=True, gslab=G.slab_u[G.ns_u:])
-        self._apply_adam(self.theta, G.slab_u, self.adam_u, self.config['u_rate'], self.grad_u)
+            KN.bdry_partials(G.ub, G.g, self.alpha, G.Nbglob, self.scal, ubar_b=G.ubar_b)
+            sweeps.append(self._job(G, 'b', G.ubar_b, G.slabA[G.ns_u:]))
+        KN.ode_bwd_multi(sweeps, G.t, th, *M, want_x=False, want_params=True)
+        self._join(e_x, e_v)
+        self._contract(G)                                        # -> scal[0..2]
+        self._join(e_B)
 
-    def discriminator_step(self, G):
-        """one pass of the discriminator sub-step body (src/training.py:152-162); loss in scal[5]"""
-        self._forward(G, boundary=False)
+    def _gen_back(self, G):
+        lr, st = self.config['u_rate'], self.adam_u
+        if self.world is None:
+            KN.adam(self.theta.data, G.slabA, st['m'], st['v'], st['step'], lr, gslabB=G.slabB, scal=self.scal,
+                    gsum_out=self.grad_u)
+        else:
+            P = self.Pu
+            KN.adam(self.theta.data, None, st['m'], st['v'], st['step'], lr, gextraA=self.pack_u[:P],
+                    gextraB=self.pack_u[P:2 * P], scal=self.scal, gsum_out=self.grad_u)
+        KN.losses(self.scal, G.L, G.Vol, G.Nglob, G.Nbglob, self.alpha)
+
+    def generator_step(self, G):
+        """one pass of the generator sub-step body; loss_u is left in scal[4] (device)"""
+        self._run(G, 'gen_front', self._gen_front)
+        if self.world is not None:
+            P = self.Pu
+            KN.slab_sum(G.slabA, out=self.pack_u[:P])
+            KN.slab_sum(G.slabB, out=self.pack_u[P:2 * P])
+            self.world.all_reduce(self.pack_u)                    # the ONE exchange of the generator sub-step
+        self._run(G, 'gen_back', self._gen_back)
+
+    # ------------------------------------------------------------------------------------------------------------
+    # discriminator sub-step (src/training.py:152-162)
+    # ------------------------------------------------------------------------------------------------------------
+    def _disc_front(self, G):
+        th = self.theta.data
+        M = (self.method, self.H, self.K, self.m)
+        self.scal.zero_()
+        e0 = self._mark()
+        with self._side(0, e0):
+            self._test_net(G)
+            e_v = self._mark()
+        KN.ode_fwd_multi([self._job(G, 'i')], G.t, th, *M)
+        self._reaction(G)
+        KN.ode_bwd_multi([self._job(G, 'i', want_x=True)], G.t, th, *M, want_x=True, want_params=False)
+        self._join(e_v)
+        self._contract(G)
+
+    def _disc_mid(self, G):
         KN.disc_cotangent(G.u, G.v, G.w, G.f, G.h, G.Vol, G.Nglob, self.scal, G.vbar, c=G.c, ckappa=G.ck,
                           pollution=self.pollution)
         KN.disc_bwd(G.xvT, G.t, self.phi.data, G.vbar, self.W, self.q, gslab=G.slab_v)
-        self._apply_adam(self.phi, G.slab_v, self.adam_v, self.config['v_rate'], self.grad_v)
+
+    def _disc_back(self, G):
+        lr, st = self.config['v_rate'], self.adam_v
+        if self.world is None:
+            KN.adam(self.phi.data, G.slab_v, st['m'], st['v'], st['step'], lr, gsum_out=self.grad_v)
+        else:
+            KN.adam(self.phi.data, None, st['m'], st['v'], st['step'], lr, gextraA=self.grad_v)
+        KN.losses(self.scal, G.L, G.Vol, G.Nglob, G.Nbglob, self.alpha)
+
+    def _disc_all(self, G):
+        self._disc_front(G)
+        self._disc_mid(G)
+        self._disc_back(G)
+
+    def discriminator_step(self, G):
+        """one pass of the discriminator sub-step body; loss_v is left in scal[5] (device)"""
+        if self.world is None:
+            self._run(G, 'disc', self._disc_all)
+            return
+        self._run(G, 'disc_front', self._disc_front)
+        self.world.all_reduce(self.scal[0:4])                     # I and sum v^2 must be global before the cotangent
+        self._run(G, 'disc_mid', self._disc_mid)
+        KN.slab_sum(G.slab_v, out=self.grad_v)
+        self.world.all_reduce(self.grad_v)
+        self._run(G, 'disc_back', self._disc_back)
 
     # ------------------------------------------------------------------------------------------------------------
+    def _run(self, G, key, fn):
+        """execute fn(G) eagerly, or capture it once into a HIP graph (per group and segment) and replay it"""
+        capturable = self.use_graphs and self.structure.c_kappa is not None
+        if not capturable:
+            fn(G)
+            return
+        g = G.graphs.get(key)
+        if g is None:
+            g = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g, stream=self._capture_stream()):
+                fn(G)
+            G.graphs[key] = g
+        g.replay()
+
+    def _capture_stream(self):
+        if not hasattr(self, '_cap'):
+            self._cap = torch.cuda.Stream(device=self.dev)
+        return self._cap
+
     def loss_u(self):
         return self.scal[4]
 
@@ -248,10 +396,10 @@ class Engine:
 
     def predict(self, X):
         """u_theta on a group [N, L, d+1] -> [L, N] (diagnostics; no checkpoints kept)"""
-        X = X.detach().to(self.dev)
-        starts_T0 = float(X[0, 0, 0]) == self.setup['T0']
-        s = self.funcs['h'](X[:, 0, :]) if starts_T0 else self.funcs['g'](X[:, 0, :].unsqueeze(1)).reshape(-1)
-        u, _ = KN.ode_fwd(X[:, 0, 1:].to(F32).t().contiguous(), X[0, :, 0].to(F32).contiguous(),
+        Xd = X.detach()
+        starts_T0 = float(Xd[0, 0, 0]) == self.setup['T0']
+        s = self.funcs['h'](Xd[:, 0, :]) if starts_T0 else self.funcs['g'](Xd[:, 0, :].unsqueeze(1)).reshape(-1)
+        u, _ = KN.ode_fwd(Xd[:, 0, 1:].to(self.dev).to(F32).t().contiguous(), Xd[0, :, 0].to(self.dev).to(F32).contiguous(),
                           s.detach().to(self.dev).to(F64).reshape(-1).contiguous(), self.theta.data, self.method,
                           self.H, self.K, self.m, want_Y=False)
         return u

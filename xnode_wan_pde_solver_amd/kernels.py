@@ -5,7 +5,7 @@ Conventions (include/xnwan.h): point arrays are time-major [L, N]; coordinates a
 """
 import torch
 
-from ._lib import lib, check, XnwanError
+from ._lib import lib, check, XnwanError, XwOdeFwdJob, XwOdeBwdJob
 
 METHODS = {'euler': 0, 'midpoint': 1, 'rk4': 2}
 F32, F64 = torch.float32, torch.float64
@@ -65,6 +65,43 @@ def ode_fwd(xT, t, start, theta, method, H, K, m, want_Y=True, u=None, Y=None):
     _chk(u, F64, (L, N), 'u'); _chk(Y, F64, (L, H, N), 'Y')
     check(lib.xw_ode_fwd(_p(xT), _p(t), _p(start), _p(theta), method, N, L, d, H, K, m, _p(u), _p(Y), _stream()), 'xw_ode_fwd')
     return u, Y
+
+
+def ode_fwd_multi(jobs, t, theta, method, H, K, m):
+    """jobs: list of dicts(xT[d,N], start[N], u[L,N], Y[L,H,N] or None) -- all groups share t, theta; ONE launch"""
+    _need_gpu()
+    L = t.shape[0]
+    d = jobs[0]['xT'].shape[0]
+    _chk(t, F32, (L,), 't'); _chk(theta, F64, (theta_size(d, H, K),), 'theta')
+    arr = (XwOdeFwdJob * len(jobs))()
+    for a, j in zip(arr, jobs):
+        N = j['xT'].shape[1]
+        _chk(j['xT'], F32, (d, N), 'xT'); _chk(j['start'], F64, (N,), 'start'); _chk(j['u'], F64, (L, N), 'u')
+        _chk(j.get('Y'), F64, (L, H, N), 'Y')
+        a.xT, a.start, a.u, a.Y, a.N = _p(j['xT']), _p(j['start']), _p(j['u']), _p(j.get('Y')), N
+    check(lib.xw_ode_fwd_multi(arr, len(jobs), _p(t), _p(theta), method, L, d, H, K, m, _stream()), 'xw_ode_fwd_multi')
+
+
+def ode_bwd_multi(jobs, t, theta, method, H, K, m, want_x, want_params):
+    """jobs: list of dicts(xT, start, Y, ubar or None, gx, gs, gslab); ONE launch for all groups"""
+    _need_gpu()
+    L = t.shape[0]
+    d = jobs[0]['xT'].shape[0]
+    P = theta_size(d, H, K)
+    _chk(t, F32, (L,), 't'); _chk(theta, F64, (P,), 'theta')
+    arr = (XwOdeBwdJob * len(jobs))()
+    for a, j in zip(arr, jobs):
+        N = j['xT'].shape[1]
+        _chk(j['xT'], F32, (d, N), 'xT'); _chk(j['start'], F64, (N,), 'start'); _chk(j['Y'], F64, (L, H, N), 'Y')
+        _chk(j.get('ubar'), F64, (L, N), 'ubar')
+        if want_x:
+            _chk(j['gx'], F64, (d, N), 'gx'); _chk(j['gs'], F64, (N,), 'gs')
+        if want_params:
+            _chk(j['gslab'], F64, (ode_bwd_slabs(N), P), 'gslab')
+        a.xT, a.start, a.Y, a.ubar, a.N = _p(j['xT']), _p(j['start']), _p(j['Y']), _p(j.get('ubar')), N
+        a.gx, a.gs, a.gslab = _p(j.get('gx')), _p(j.get('gs')), _p(j.get('gslab'))
+    mode = (1 if want_x else 0) | (2 if want_params else 0)
+    check(lib.xw_ode_bwd_multi(arr, len(jobs), _p(t), _p(theta), method, L, d, H, K, m, mode, _stream()), 'xw_ode_bwd_multi')
 
 
 def ode_bwd_slabs(N):
@@ -144,7 +181,9 @@ def disc_bwd(xT, t, phi, vbar, W, q, tpp=None, gslab=None):
     return gslab
 
 
-def weak_partials(u, v, vt, w, s3x, f, h, Vol, Nglob, scal, c=None, ckappa=0.0, wt=None):
+def weak_partials(u, v, vt, w, f, h, Vol, Nglob, scal, s3x=None, contract=None, c=None, ckappa=0.0, wt=None):
+    """partial sums of I, sum v^2, SSE_init.  Either s3x[N] (pre-contracted gradient term) or contract = dict(gx, gs, ghT,
+    gxv, w0, gwx0T) for the in-kernel contraction with a = identity, b = 0."""
     _need_gpu()
     L, N = u.shape
     for name, a in (('u', u), ('v', v), ('vt', vt), ('f', f)):
@@ -152,8 +191,17 @@ def weak_partials(u, v, vt, w, s3x, f, h, Vol, Nglob, scal, c=None, ckappa=0.0, 
     per_point = 1 if w.dim() == 2 else 0
     _chk(w, F64, (L, N) if per_point else (N,), 'w'); _chk(wt, F64, (L, N), 'wt'); _chk(c, F64, (L, N), 'c')
     _chk(s3x, F64, (N,), 's3x'); _chk(h, F64, (N,), 'h'); _chk(scal, F64, (16,), 'scal')
-    check(lib.xw_weak_partials(_p(u), _p(v), _p(vt), _p(w), per_point, _p(wt), _p(s3x), _p(c), float(ckappa), _p(f), _p(h),
-                               N, L, float(Vol), float(Nglob), _p(scal), _stream()), 'xw_weak_partials')
+    k, d = {}, 0
+    if s3x is None:
+        k = contract
+        d = k['gx'].shape[0]
+        for name in ('gx', 'ghT', 'gxv', 'gwx0T'):
+            _chk(k[name], F64, (d, N), name)
+        _chk(k['gs'], F64, (N,), 'gs'); _chk(k['w0'], F64, (N,), 'w0')
+    check(lib.xw_weak_partials(_p(u), _p(v), _p(vt), _p(w), per_point, _p(wt), _p(s3x), _p(k.get('gx')), _p(k.get('gs')),
+                               _p(k.get('ghT')), _p(k.get('gxv')), _p(k.get('w0')), _p(k.get('gwx0T')), d, _p(c),
+                               float(ckappa), _p(f), _p(h), N, L, float(Vol), float(Nglob), _p(scal), _stream()),
+          'xw_weak_partials')
 
 
 def bdry_partials(ub, g, alpha, Nbglob, scal, ubar_b=None):
@@ -164,16 +212,19 @@ def bdry_partials(ub, g, alpha, Nbglob, scal, ubar_b=None):
           'xw_bdry_partials')
 
 
-def gen_cotangent(u, v, w, h, Vol, Nglob, Nbglob, alpha, scal, ubar, c=None, cp=None, ckappa=0.0, pollution=1.0):
+def gen_cotangents(u, v, w, h, Vol, Nglob, alpha, ubarA, ubarB, c=None, cp=None, ckappa=0.0, pollution=1.0):
+    """cotangent bases of the generator loss; pass ubarA=None or ubarB=None to form only one of them"""
     _need_gpu()
+    if ubarA is None and ubarB is None:
+        raise XnwanError('gen_cotangents: nothing to compute')
     L, N = u.shape
     per_point = 1 if w.dim() == 2 else 0
     _chk(u, F64, (L, N), 'u'); _chk(v, F64, (L, N), 'v'); _chk(w, F64, (L, N) if per_point else (N,), 'w')
-    _chk(c, F64, (L, N), 'c'); _chk(cp, F64, (L, N), 'cp'); _chk(h, F64, (N,), 'h'); _chk(ubar, F64, (L, N), 'ubar')
-    _chk(scal, F64, (16,), 'scal')
-    check(lib.xw_gen_cotangent(_p(u), _p(v), _p(w), per_point, _p(c), _p(cp), float(ckappa), _p(h), N, L, float(Vol),
-                               float(Nglob), float(Nbglob), float(alpha), float(pollution), _p(scal), _p(ubar), _p(scal),
-                               _stream()), 'xw_gen_cotangent')
+    _chk(c, F64, (L, N), 'c'); _chk(cp, F64, (L, N), 'cp'); _chk(h, F64, (N,), 'h')
+    _chk(ubarA, F64, (L, N), 'ubarA'); _chk(ubarB, F64, (L, N), 'ubarB')
+    check(lib.xw_gen_cotangents(_p(u), _p(v), _p(w), per_point, _p(c), _p(cp), float(ckappa), _p(h), N, L, float(Vol),
+                                float(Nglob), float(alpha), float(pollution), _p(ubarA), _p(ubarB), _stream()),
+          'xw_gen_cotangents')
 
 
 def disc_cotangent(u, v, w, f, h, Vol, Nglob, scal, vbar, c=None, ckappa=0.0, pollution=1.0):
@@ -184,20 +235,32 @@ def disc_cotangent(u, v, w, f, h, Vol, Nglob, scal, vbar, c=None, ckappa=0.0, po
     _chk(c, F64, (L, N), 'c'); _chk(f, F64, (L, N), 'f'); _chk(h, F64, (N,), 'h'); _chk(vbar, F64, (L, N), 'vbar')
     _chk(scal, F64, (16,), 'scal')
     check(lib.xw_disc_cotangent(_p(u), _p(v), _p(w), per_point, _p(c), float(ckappa), _p(f), _p(h), N, L, float(Vol),
-                                float(Nglob), float(pollution), _p(scal), _p(vbar), _p(scal), _stream()), 'xw_disc_cotangent')
+                                float(Nglob), float(pollution), _p(scal), _p(vbar), _stream()), 'xw_disc_cotangent')
 
 
-def adam(param, gslab, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, gextra=None, gsum_out=None):
+def losses(scal, L, Vol, Nglob, Nbglob, alpha):
+    _need_gpu()
+    _chk(scal, F64, (16,), 'scal')
+    check(lib.xw_losses(_p(scal), L, float(Vol), float(Nglob), float(Nbglob), float(alpha), _stream()), 'xw_losses')
+
+
+def adam(param, gslabA, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, gextraA=None, gslabB=None, gextraB=None,
+         scal=None, gsum_out=None):
+    """param -= Adam(g),  g = gextraA + sum(gslabA) + coefB (gextraB + sum(gslabB)),  coefB = 2 / scal[0] if scal else 1"""
     _need_gpu()
     P = param.shape[0]
     _chk(param, F64, (P,), 'param'); _chk(m, F64, (P,), 'm'); _chk(v, F64, (P,), 'v'); _chk(step, torch.int64, (1,), 'step')
-    ns = 0
-    if gslab is not None:
-        ns = gslab.shape[0]
-        _chk(gslab, F64, (ns, P), 'gslab')
-    _chk(gextra, F64, (P,), 'gextra'); _chk(gsum_out, F64, (P,), 'gsum_out')
-    check(lib.xw_adam(_p(param), _p(gslab), ns, _p(gextra), _p(m), _p(v), _p(step), P, float(lr), float(beta1), float(beta2),
-                      float(eps), _p(gsum_out), _stream()), 'xw_adam')
+    nA = nB = 0
+    if gslabA is not None:
+        nA = gslabA.shape[0]
+        _chk(gslabA, F64, (nA, P), 'gslabA')
+    if gslabB is not None:
+        nB = gslabB.shape[0]
+        _chk(gslabB, F64, (nB, P), 'gslabB')
+    _chk(gextraA, F64, (P,), 'gextraA'); _chk(gextraB, F64, (P,), 'gextraB'); _chk(gsum_out, F64, (P,), 'gsum_out')
+    _chk(scal, F64, (16,), 'scal')
+    check(lib.xw_adam(_p(param), _p(gslabA), nA, _p(gextraA), _p(gslabB), nB, _p(gextraB), _p(scal), _p(m), _p(v), _p(step), P,
+                      float(lr), float(beta1), float(beta2), float(eps), _p(gsum_out), _stream()), 'xw_adam')
 
 
 def slab_sum(gslab, out=None, accumulate=False):

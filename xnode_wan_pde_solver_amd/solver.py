@@ -86,7 +86,7 @@ class FusedAdam:
     def step(self):
         g = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self.blob.params])
         _adam_kernel(self.blob.data, None, self.state['m'], self.state['v'], self.state['step'],
-                     self.param_groups[0]['lr'], gextra=g.contiguous())
+                     self.param_groups[0]['lr'], gextraA=g.contiguous())
 
     def state_dict(self):
         return {'m': self.state['m'].clone(), 'v': self.state['v'].clone(), 'step': int(self.state['step'].item()),
@@ -113,6 +113,7 @@ class NODE_WAN_solver:
         self.world = world
         self.exit_on_stop = True
         self.tabulate_on_host = True
+        self._group_cache = []
         self.config, self.setup, self.iterations = split_params(params)
         self.domain = sampling.resolve_domain(params['domain'])
         self.n1, self.n2 = self.config['n1'], self.config['n2']
@@ -174,7 +175,12 @@ class NODE_WAN_solver:
                 domain = self._new_domain()
                 points = sampling.Comb_loader(self.setup['N_r'], self.setup['N_b'], domain, self.device)
                 L2 = self._l_norm(points.interioru, domain.V())
-                groups = [eng.load_group(du, dv, bd, domain, ng, nbg) for (du, dv, bd, ng, nbg) in self._shard(self._groups(points))]
+                shards = self._shard(self._groups(points))
+                if len(self._group_cache) != len(shards):
+                    self._group_cache = [None] * len(shards)
+                groups = [eng.load_group(du, dv, bd, domain, ng, nbg, into=old)
+                          for (du, dv, bd, ng, nbg), old in zip(shards, self._group_cache)]
+                self._group_cache = groups
                 for _ in range(self.n1):
                     self.av_l = 0
                     for G in groups:
