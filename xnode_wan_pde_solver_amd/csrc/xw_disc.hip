@@ -69,24 +69,29 @@ __device__ __forceinline__ void input_layer(const double* __restrict__ ph, const
 
 // ------------------------------------------------------------------------------------------------------------------
 template <int W>
-__global__ void __launch_bounds__(256) k_disc_fwd(const float* __restrict__ xT, const float* __restrict__ tf,
-                                                  const float* __restrict__ tpp, const double* __restrict__ ph, int N,
-                                                  int L, int d, int q, double* __restrict__ v, double* __restrict__ vt) {
+__global__ void __launch_bounds__(256, 2) k_disc_fwd(const float* __restrict__ xT, const float* __restrict__ tf,
+                                                     const float* __restrict__ tpp, const double* __restrict__ ph, int N,
+                                                     int L, int d, int q, double* __restrict__ v, double* __restrict__ vt) {
   typedef VDim<W> D;
+  // Vh as MFMA A-fragments in LDS (26.6 KB), shared by the 4 waves of the block: one ds_read_b64 feeds two 64-cycle MFMAs
+  // (value and d/dt tangent), and keeping them out of the register file lets two waves share a SIMD so that one wave's
+  // relu / tanh VALU work overlaps the other's matrix work.
+  __shared__ double sVh[D::MT * D::KS * 64];
+  __shared__ double sB[2 * 16 * D::MT];
   const int lane = xw_lane(), g = lane >> 4;
   const int wave = threadIdx.x >> 6;
   const VOff o = v_offsets(d, W);
   const long P = (long)N * L;
   const long ntiles = (P + 15) / 16;
-  double Vh[D::MT][D::KS];
-  d4 bh[D::MT], vo[D::MT];
-#pragma unroll
-  for (int mt = 0; mt < D::MT; ++mt) {
-#pragma unroll
-    for (int ks = 0; ks < D::KS; ++ks) Vh[mt][ks] = xw_fragA(ph + o.Vh, W, W, W, 16 * mt, 4 * ks);
-    bh[mt] = xw_vecD(ph + o.Vhb, W, 16 * mt);
-    vo[mt] = xw_vecD(ph + o.Vo, W, 16 * mt);
+  for (int idx = wave; idx < D::MT * D::KS; idx += 4) {
+    const int mt = idx / D::KS, ks = idx - mt * D::KS;
+    sVh[idx * 64 + lane] = xw_fragA(ph + o.Vh, W, W, W, 16 * mt, 4 * ks);
   }
+  if (threadIdx.x < 16 * D::MT) {
+    sB[threadIdx.x] = (int)threadIdx.x < W ? ph[o.Vhb + threadIdx.x] : 0.0;
+    sB[16 * D::MT + threadIdx.x] = (int)threadIdx.x < W ? ph[o.Vo + threadIdx.x] : 0.0;
+  }
+  __syncthreads();
   const double vob = ph[o.Vob];
   for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long)gridDim.x * 4) {
     const Pt pt = locate(tile, P, N, tf, tpp);
@@ -96,7 +101,8 @@ __global__ void __launch_bounds__(256) k_disc_fwd(const float* __restrict__ xT, 
       d4 nw[D::MT], nd[D::MT];
 #pragma unroll
       for (int mt = 0; mt < D::MT; ++mt) {
-        nw[mt] = bh[mt];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) nw[mt][r] = sB[16 * mt + g + 4 * r];
         nd[mt] = xw_zero4();
       }
 #pragma unroll
@@ -104,10 +110,12 @@ __global__ void __launch_bounds__(256) k_disc_fwd(const float* __restrict__ xT, 
         const double av = a[ks >> 2][ks & 3];
         const double b = av > 0.0 ? av : 0.0;
         const double bd = av > 0.0 ? ad[ks >> 2][ks & 3] : 0.0;
+        if ((ks & 1) == 0) asm volatile("" ::: "memory");   // bound the LDS loads in flight (else all 52 are hoisted -> spills)
 #pragma unroll
         for (int mt = 0; mt < D::MT; ++mt) {
-          nw[mt] = XW_MFMA(Vh[mt][ks], b, nw[mt]);
-          nd[mt] = XW_MFMA(Vh[mt][ks], bd, nd[mt]);
+          const double w = sVh[(mt * D::KS + ks) * 64 + lane];
+          nw[mt] = XW_MFMA(w, b, nw[mt]);
+          nd[mt] = XW_MFMA(w, bd, nd[mt]);
         }
       }
 #pragma unroll
@@ -123,8 +131,9 @@ __global__ void __launch_bounds__(256) k_disc_fwd(const float* __restrict__ xT, 
       for (int r = 0; r < 4; ++r)
         if (16 * mt + 4 * r < W) {  // rows 16 mt + 4 r + g >= W only carry zero padding
           const double th = xw_tanh(a[mt][r]);
-          sv += vo[mt][r] * th;
-          sd += vo[mt][r] * (1.0 - th * th) * ad[mt][r];
+          const double vo = sB[16 * D::MT + 16 * mt + g + 4 * r];
+          sv += vo * th;
+          sd += vo * (1.0 - th * th) * ad[mt][r];
         }
     sv = xw_sum_over_g(sv) + vob;
     sd = xw_sum_over_g(sd);
@@ -142,7 +151,8 @@ template <int W> struct BwdLds {
   static constexpr int nfrag = D::MT * D::KS * 64;
   static constexpr int ntt = 4 * D::MT * XW_TTILE;
   static constexpr int oVh = 0, oVhT = nfrag, oD = 2 * nfrag, oR = 2 * nfrag + ntt, oO = 2 * nfrag + 2 * ntt;
-  static constexpr int total = oO + 4 * 64 * 16;
+  static constexpr int oB = oO + 4 * 64 * 16;     // Vh.b and Vo, zero-padded to 16 MT rows each
+  static constexpr int total = oB + 2 * 16 * D::MT;
   static_assert(total * 8 <= 160 * 1024, "LDS budget of one CU");
 };
 
@@ -166,46 +176,60 @@ __global__ void __launch_bounds__(256) k_disc_bwd(const float* __restrict__ xT, 
   const long P = (long)N * L;
   const long nsuper = (P + 63) / 64;
 
+  double* sB = lds + S::oB;
   for (int idx = wave; idx < D::MT * D::KS; idx += 4) {
     const int mt = idx / D::KS, ks = idx - mt * D::KS;
     sVh[idx * 64 + lane] = xw_fragA(ph + o.Vh, W, W, W, 16 * mt, 4 * ks);
     sVhT[idx * 64 + lane] = xw_fragAT(ph + o.Vh, W, W, W, 16 * mt, 4 * ks);
   }
+  if (threadIdx.x < 16 * D::MT) {
+    sB[threadIdx.x] = (int)threadIdx.x < W ? ph[o.Vhb + threadIdx.x] : 0.0;
+    sB[16 * D::MT + threadIdx.x] = (int)threadIdx.x < W ? ph[o.Vo + threadIdx.x] : 0.0;
+  }
   if (PARAMS)
     for (int i = 0; i < 16; ++i) sO[(wave * 64 + lane) * 16 + i] = 0.0;
   __syncthreads();
 
-  d4 bh[D::MT], vo[D::MT];
-#pragma unroll
-  for (int mt = 0; mt < D::MT; ++mt) {
-    bh[mt] = xw_vecD(ph + o.Vhb, W, 16 * mt);
-    vo[mt] = xw_vecD(ph + o.Vo, W, 16 * mt);
-  }
   d4 accH[D::MT], accIn[CTG * 4];
 #pragma unroll
   for (int ct = 0; ct < D::MT; ++ct) accH[ct] = xw_zero4();
 #pragma unroll
   for (int ct = 0; ct < CTG * 4; ++ct) accIn[ct] = xw_zero4();
 
+  // one tied hidden layer  a_out = Vh.b + Vh r  with A-fragments and the bias read from LDS
+  auto layer = [&](const d4 (&r)[D::MT], d4 (&out)[D::MT]) {
+    asm volatile("" ::: "memory");   // keep the A-fragments in LDS: without this the compiler hoists all 52 loads of
+                                     // every unrolled layer into registers and spills the activations instead
+#pragma unroll
+    for (int mt = 0; mt < D::MT; ++mt)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) out[mt][rr] = sB[16 * mt + g + 4 * rr];
+#pragma unroll
+    for (int ks = 0; ks < D::KS; ++ks) {
+      const double b = r[ks >> 2][ks & 3];
+#pragma unroll
+      for (int mt = 0; mt < D::MT; ++mt) out[mt] = XW_MFMA(sVh[(mt * D::KS + ks) * 64 + lane], b, out[mt]);
+    }
+  };
+
+  constexpr int SEG = 3;                              // layers per checkpoint segment
+  constexpr int NSEG = (Q + SEG - 1) / SEG;
   for (long st = blockIdx.x; st < nsuper; st += gridDim.x) {
     const Pt pt = locate(st * 4 + wave, P, N, tf, tpp);
-    // ---- forward recompute; rs[j] = relu(a_j), j = 0..Q-1 stay in registers
-    d4 rs[Q][D::MT];
+    // ---- forward: only r_0, r_3, r_6 (= relu(a_j)) are kept; the layers in between are recomputed per segment, so the
+    //      live activations are 2 x SEG tiles instead of Q (which did not fit the 512-register file and spilled)
+    d4 ck[NSEG][D::MT];
     d4 a[D::MT], ad[D::MT];
     input_layer<W>(ph, o, xT, N, d, pt, a, ad);
 #pragma unroll
     for (int j = 0; j < Q; ++j) {
+      d4 r[D::MT];
 #pragma unroll
       for (int mt = 0; mt < D::MT; ++mt) {
-        rs[j][mt] = xw_relu(a[mt]);
-        a[mt] = bh[mt];
+        r[mt] = xw_relu(a[mt]);
+        if (j % SEG == 0) ck[j / SEG][mt] = r[mt];
       }
-#pragma unroll
-      for (int ks = 0; ks < D::KS; ++ks) {
-        const double b = rs[j][ks >> 2][ks & 3];
-#pragma unroll
-        for (int mt = 0; mt < D::MT; ++mt) a[mt] = XW_MFMA(sVh[(mt * D::KS + ks) * 64 + lane], b, a[mt]);
-      }
+      layer(r, a);
     }
     // ---- output layer and its cotangent
     const double vb = pt.valid ? (vbar != nullptr ? vbar[pt.p] : 1.0) : 0.0;
@@ -216,47 +240,63 @@ __global__ void __launch_bounds__(256) k_disc_bwd(const float* __restrict__ xT, 
       for (int r = 0; r < 4; ++r) {
         double th = 0.0;
         if (16 * mt + 4 * r < W) th = xw_tanh(a[mt][r]);
-        dl[mt][r] = vo[mt][r] * (1.0 - th * th) * vb;
+        dl[mt][r] = sB[16 * D::MT + 16 * mt + g + 4 * r] * (1.0 - th * th) * vb;
         if (PARAMS) sO[(wave * 64 + lane) * 16 + mt * 4 + r] += (mt == D::MT - 1 && r == 3) ? (g == 0 ? vb : 0.0) : vb * th;
       }
-    // ---- reverse chain
+    // ---- reverse chain, segment by segment
 #pragma unroll
-    for (int j = Q - 1; j >= 0; --j) {
-      if (PARAMS) {
+    for (int sg = NSEG - 1; sg >= 0; --sg) {
+      d4 seg[SEG][D::MT];
 #pragma unroll
-        for (int mt = 0; mt < D::MT; ++mt) {
-          d4 rj = rs[j][mt];
-          if (mt == (W >> 4)) {
-            if (g == ((W & 15) & 3)) rj[(W & 15) >> 2] = 1.0;  // ones row -> column W of dVh collects dVh.b
-          }
-          xw_writeT(sD + (wave * D::MT + mt) * XW_TTILE, dl[mt]);
-          xw_writeT(sR + (wave * D::MT + mt) * XW_TTILE, rj);
+      for (int mt = 0; mt < D::MT; ++mt) seg[0][mt] = ck[sg][mt];
+#pragma unroll
+      for (int k = 1; k < SEG; ++k)
+        if (sg * SEG + k < Q) {
+          d4 tmp[D::MT];
+          layer(seg[k - 1], tmp);
+#pragma unroll
+          for (int mt = 0; mt < D::MT; ++mt) seg[k][mt] = xw_relu(tmp[mt]);
         }
-        __syncthreads();
 #pragma unroll
-        for (int pw = 0; pw < 4; ++pw)
+      for (int k = SEG - 1; k >= 0; --k) {
+        if (sg * SEG + k >= Q) continue;
+        if (PARAMS) {
 #pragma unroll
-          for (int ks = 0; ks < 4; ++ks) {
-            const double av = xw_readT(sD + (pw * D::MT + wave) * XW_TTILE, ks);
-#pragma unroll
-            for (int ct = 0; ct < D::MT; ++ct)
-              accH[ct] = XW_MFMA(av, xw_readT(sR + (pw * D::MT + ct) * XW_TTILE, ks), accH[ct]);
+          for (int mt = 0; mt < D::MT; ++mt) {
+            d4 rj = seg[k][mt];
+            if (mt == (W >> 4)) {
+              if (g == ((W & 15) & 3)) rj[(W & 15) >> 2] = 1.0;  // ones row -> column W of dVh collects dVh.b
+            }
+            xw_writeT(sD + (wave * D::MT + mt) * XW_TTILE, dl[mt]);
+            xw_writeT(sR + (wave * D::MT + mt) * XW_TTILE, rj);
           }
-        __syncthreads();
+          __syncthreads();
+#pragma unroll
+          for (int pw = 0; pw < 4; ++pw)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+              const double av = xw_readT(sD + (pw * D::MT + wave) * XW_TTILE, ks);
+#pragma unroll
+              for (int ct = 0; ct < D::MT; ++ct)
+                accH[ct] = XW_MFMA(av, xw_readT(sR + (pw * D::MT + ct) * XW_TTILE, ks), accH[ct]);
+            }
+          __syncthreads();
+        }
+        d4 nd[D::MT];
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int mt = 0; mt < D::MT; ++mt) nd[mt] = xw_zero4();
+#pragma unroll
+        for (int ks = 0; ks < D::KS; ++ks) {
+          const double b = dl[ks >> 2][ks & 3];
+#pragma unroll
+          for (int mt = 0; mt < D::MT; ++mt) nd[mt] = XW_MFMA(sVhT[(mt * D::KS + ks) * 64 + lane], b, nd[mt]);
+        }
+#pragma unroll
+        for (int mt = 0; mt < D::MT; ++mt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dl[mt][r] = seg[k][mt][r] > 0.0 ? nd[mt][r] : 0.0;
       }
-      d4 nd[D::MT];
-#pragma unroll
-      for (int mt = 0; mt < D::MT; ++mt) nd[mt] = xw_zero4();
-#pragma unroll
-      for (int ks = 0; ks < D::KS; ++ks) {
-        const double b = dl[ks >> 2][ks & 3];
-#pragma unroll
-        for (int mt = 0; mt < D::MT; ++mt) nd[mt] = XW_MFMA(sVhT[(mt * D::KS + ks) * 64 + lane], b, nd[mt]);
-      }
-#pragma unroll
-      for (int mt = 0; mt < D::MT; ++mt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) dl[mt][r] = rs[j][mt][r] > 0.0 ? nd[mt][r] : 0.0;
     }
     // ---- dl = cotangent of a_0.  Input layer: dVin = dl (x) [t; x; 1]
     if (PARAMS) {
@@ -374,7 +414,7 @@ extern "C" int xw_disc_fwd(const float* xT, const float* t, const float* tpp, co
   if (W != 50) return XW_E_DIMS;
   const long ntiles = ((long)N * L + 15) / 16;
   long blocks = (ntiles + 3) / 4;
-  if (blocks > 1024) blocks = 1024;
+  if (blocks > 512) blocks = 512;   // 2 blocks per CU resident (launch bounds), grid-stride over the tiles
   hipLaunchKernelGGL((k_disc_fwd<50>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, xT, t, tpp, phi, N, L, d,
                      q, v, vt);
   return xw_launch_status();
