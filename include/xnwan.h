@@ -113,16 +113,17 @@ int xw_gen_cotangents(const double* u, const double* v, const double* w, int w_p
 int xw_disc_cotangent(const double* u, const double* v, const double* w, int w_per_point, const double* c,
                       double ckappa, const double* f, const double* h, int N, int L, double Vol, double Nglob,
                       double pollution, const double* scal_in, double* vbar, void* stream);
-/* scal[4] = loss_u, scal[5] = loss_v, scal[6] = int from the (all-reduced) partial sums scal[0..3] (src/loss.py:87-96) */
-int xw_losses(double* scal, int L, double Vol, double Nglob, double Nbglob, double alpha, void* stream);
+/* scal[4] = loss_u, scal[5] = loss_v, scal[6] = int from the (all-reduced) partial sums scal[0..3] (src/loss.py:87-96);
+ * step (may be NULL): optimiser step counter to increment here when xw_adam was called with bump_step = 0 */
+int xw_losses(double* scal, int L, double Vol, double Nglob, double Nbglob, double alpha, long long* step, void* stream);
 
 /* ---- optimiser (torch.optim.Adam defaults, src/training.py:103-104) ------------------------------------------------
  * grad = gextraA + sum_s gslabA[s] + coefB * (gextraB + sum_s gslabB[s]),  coefB = scal ? 2 / scal[0] : 1
  * (slab sets [n][P]; gextra*[P] pre-reduced gradients, e.g. after an all-reduce; any of them may be NULL / 0)
- * state: m[P], v[P], step (device int64, incremented by one) */
+ * state: m[P], v[P], step (device int64; incremented by one after the update iff bump_step, else by xw_losses) */
 int xw_adam(double* param, const double* gslabA, int nA, const double* gextraA, const double* gslabB, int nB,
-            const double* gextraB, const double* scal, double* m, double* v, long long* step, int P, double lr,
-            double beta1, double beta2, double eps, double* gsum_out, void* stream);
+            const double* gextraB, const double* scal, double* m, double* v, long long* step, int bump_step, int P,
+            double lr, double beta1, double beta2, double eps, double* gsum_out, void* stream);
 /* plain slab reduction: out[P] = (accumulate ? out : 0) + sum_s gslab[s][P] */
 int xw_slab_sum(const double* gslab, int nslab, int P, int accumulate, double* out, void* stream);
 

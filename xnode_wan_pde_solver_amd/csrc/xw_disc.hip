@@ -15,6 +15,7 @@
 //                outer products over the points (LDS transpose; 4 waves of a block own one 16-row band of dVh each).
 //                Optionally also returns the input gradient (nabla_x v, dv/dt) -- used for nabla phi at t0.
 #include "xw_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -414,7 +415,9 @@ extern "C" int xw_disc_fwd(const float* xT, const float* t, const float* tpp, co
   if (W != 50) return XW_E_DIMS;
   const long ntiles = ((long)N * L + 15) / 16;
   long blocks = (ntiles + 3) / 4;
-  if (blocks > 512) blocks = 512;   // 2 blocks per CU resident (launch bounds), grid-stride over the tiles
+  long cap = 512;                   // 2 blocks per CU resident (launch bounds), grid-stride over the tiles
+  if (const char* e = getenv("XW_DISC_FWD_BLOCKS")) cap = atol(e);
+  if (blocks > cap) blocks = cap;
   hipLaunchKernelGGL((k_disc_fwd<50>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, xT, t, tpp, phi, N, L, d,
                      q, v, vt);
   return xw_launch_status();

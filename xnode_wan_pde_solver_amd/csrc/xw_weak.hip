@@ -135,8 +135,10 @@ __global__ void __launch_bounds__(256) k_gen_cots(const double* __restrict__ u, 
   }
 }
 
-__global__ void k_losses(double* __restrict__ scal, int L, double Vol, double Nglob, double Nbglob, double alpha) {
+__global__ void k_losses(double* __restrict__ scal, int L, double Vol, double Nglob, double Nbglob, double alpha,
+                         long long* __restrict__ step) {
   if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (step != nullptr) *step += 1;                  // optimiser step counter (after xw_adam has read it)
     const double in_ = interior_loss(scal, Vol, Nglob, L);
     scal[6] = in_;
     scal[4] = in_ + alpha * (scal[2] / Nglob + scal[3] / (Nbglob * (double)L));  // src/loss.py:93
@@ -256,9 +258,10 @@ extern "C" int xw_gen_cotangents(const double* u, const double* v, const double*
   return xw_launch_status();
 }
 
-extern "C" int xw_losses(double* scal, int L, double Vol, double Nglob, double Nbglob, double alpha, void* stream) {
+extern "C" int xw_losses(double* scal, int L, double Vol, double Nglob, double Nbglob, double alpha, long long* step,
+                         void* stream) {
   if (!scal || L <= 0) return XW_E_ARG;
-  hipLaunchKernelGGL(k_losses, dim3(1), dim3(64), 0, (hipStream_t)stream, scal, L, Vol, Nglob, Nbglob, alpha);
+  hipLaunchKernelGGL(k_losses, dim3(1), dim3(64), 0, (hipStream_t)stream, scal, L, Vol, Nglob, Nbglob, alpha, step);
   return xw_launch_status();
 }
 
@@ -272,12 +275,12 @@ extern "C" int xw_disc_cotangent(const double* u, const double* v, const double*
 }
 
 extern "C" int xw_adam(double* param, const double* gslabA, int nA, const double* gextraA, const double* gslabB, int nB,
-                       const double* gextraB, const double* scal, double* m, double* v, long long* step, int P, double lr,
-                       double beta1, double beta2, double eps, double* gsum_out, void* stream) {
+                       const double* gextraB, const double* scal, double* m, double* v, long long* step, int bump_step,
+                       int P, double lr, double beta1, double beta2, double eps, double* gsum_out, void* stream) {
   if (!param || !m || !v || !step || P <= 0 || nA < 0 || nB < 0 || (nA > 0 && !gslabA) || (nB > 0 && !gslabB)) return XW_E_ARG;
   hipLaunchKernelGGL(k_adam, dim3((P + 63) / 64), dim3(1024), 0, (hipStream_t)stream, param, gslabA, nA, gextraA, gslabB,
                      nB, gextraB, scal, m, v, step, P, lr, beta1, beta2, eps, gsum_out);
-  hipLaunchKernelGGL(k_step_inc, dim3(1), dim3(1), 0, (hipStream_t)stream, step);
+  if (bump_step) hipLaunchKernelGGL(k_step_inc, dim3(1), dim3(1), 0, (hipStream_t)stream, step);
   return xw_launch_status();
 }
 
@@ -287,7 +290,7 @@ extern "C" int xw_slab_sum(const double* gslab, int nslab, int P, int accumulate
   return xw_launch_status();
 }
 
-extern "C" int xw_abi_version(void) { return 2; }
+extern "C" int xw_abi_version(void) { return 3; }
 
 extern "C" int xw_supported_dims(char* buf, int buflen) {
   static const char s[] = "ode(H,K,m)=(20,10,8),(20,10,4),(20,10,2); disc_fwd W=50 any q; disc_bwd (W,q)=(50,9), d<=126";

@@ -98,9 +98,12 @@ class Engine:
         # generator exchange buffer [sum of A slabs | sum of B slabs | scal]: ONE all-reduce per generator sub-step
         self.pack_u = z(2 * self.Pu + 16)
         self.scal = self.pack_u[2 * self.Pu:]
-        self.use_streams = True          # independent kernel chains on side streams (test net, boundary, the two sweeps)
-        self.use_graphs = True           # capture each sub-step of a group into a HIP graph and replay it
-        self.streams = [torch.cuda.Stream(device=device) for _ in range(4)]
+        import os
+        self.use_streams = os.environ.get('XW_STREAMS', '1') == '1'   # independent kernel chains on side streams
+        self.use_graphs = os.environ.get('XW_GRAPHS', '1') == '1'     # capture each sub-step into a HIP graph and replay it
+        self.par_gradx = os.environ.get('XW_PAR_GRADX', '1') == '1'
+        self.side_contract = os.environ.get('XW_SIDE_CONTRACT', '0') == '1'   # measured slower (queue mapping)
+        self.streams = [torch.cuda.Stream(device=device) for _ in range(5)]
 
     # ------------------------------------------------------------------------------------------------------------
     # per-sample preparation (once per outer iteration; everything here is parameter-independent)
@@ -213,16 +216,32 @@ class Engine:
     def _mark(self):
         return torch.cuda.current_stream().record_event()
 
+    def _join_side(self, i, *events):
+        if self.use_streams:
+            for ev in events:
+                self.streams[i].wait_event(ev)
+
     def _join(self, *events):
         if self.use_streams:
             cur = torch.cuda.current_stream()
             for ev in events:
                 cur.wait_event(ev)
 
-    def _test_net(self, G):
+    def _test_net(self, G, e0):
+        """test network on side streams 0 (v, dv/dt at all points) and 4 (nabla_x v at t_0); returns (e_v, e_g)"""
         ph = self.phi.data
-        KN.disc_fwd(G.xvT, G.t, ph, self.W, self.q, v=G.v, vt=G.vt)                       # v, dv/dt at all points
-        KN.disc_gradx(G.xvT, G.t, ph, self.W, self.q, gxv=G.gxv, gtv=G.gtv)               # nabla_x v at t_0
+        if self.par_gradx:
+            with self._side(4, e0):
+                KN.disc_gradx(G.xvT, G.t, ph, self.W, self.q, gxv=G.gxv, gtv=G.gtv)
+                e_g = self._mark()
+        with self._side(0, e0):
+            KN.disc_fwd(G.xvT, G.t, ph, self.W, self.q, v=G.v, vt=G.vt)
+            if not self.par_gradx:
+                KN.disc_gradx(G.xvT, G.t, ph, self.W, self.q, gxv=G.gxv, gtv=G.gtv)
+            e_v = self._mark()
+        if not self.par_gradx:
+            e_g = e_v
+        return e_v, e_g
 
     def _reaction(self, G):
         """c(u, t, x): linear fast path, or the user's callable differentiated by autograd (not graph-capturable)"""
@@ -273,15 +292,19 @@ class Engine:
         M = (self.method, self.H, self.K, self.m)
         self.scal.zero_()
         e0 = self._mark()
-        with self._side(0, e0):
-            self._test_net(G)
-            e_v = self._mark()
+        e_v, e_g = self._test_net(G, e0)
         fwd = [self._job(G, 'i')] + ([self._job(G, 'b')] if G.Nb else [])
         KN.ode_fwd_multi(fwd, G.t, th, *M)
         self._reaction(G)
         e_f = self._mark()
+        if G.Nb:
+            KN.bdry_partials(G.ub, G.g, self.alpha, G.Nbglob, self.scal, ubar_b=G.ubar_b)
+            e_f = self._mark()
         with self._side(1, e_f):
             KN.ode_bwd_multi([self._job(G, 'i', want_x=True)], G.t, th, *M, want_x=True, want_params=False)
+            if self.side_contract:
+                self._join_side(1, e_v, e_g)
+                self._contract(G)                                # -> scal[0..2]
             e_x = self._mark()
         with self._side(2, e_f, e_v):
             KN.gen_cotangents(G.u, G.v, G.w, G.h, G.Vol, G.Nglob, self.alpha, None, G.ubarB, c=G.c, cp=G.cp, ckappa=G.ck,
@@ -292,23 +315,23 @@ class Engine:
                           pollution=self.pollution)
         sweeps = [self._job(G, 'i', G.ubarA, G.slabA[:G.ns_u])]
         if G.Nb:
-            KN.bdry_partials(G.ub, G.g, self.alpha, G.Nbglob, self.scal, ubar_b=G.ubar_b)
             sweeps.append(self._job(G, 'b', G.ubar_b, G.slabA[G.ns_u:]))
         KN.ode_bwd_multi(sweeps, G.t, th, *M, want_x=False, want_params=True)
-        self._join(e_x, e_v)
-        self._contract(G)                                        # -> scal[0..2]
+        self._join(e_x, e_v, e_g)
+        if not self.side_contract:
+            self._contract(G)
         self._join(e_B)
 
     def _gen_back(self, G):
         lr, st = self.config['u_rate'], self.adam_u
         if self.world is None:
             KN.adam(self.theta.data, G.slabA, st['m'], st['v'], st['step'], lr, gslabB=G.slabB, scal=self.scal,
-                    gsum_out=self.grad_u)
+                    gsum_out=self.grad_u, bump_step=False)
         else:
             P = self.Pu
             KN.adam(self.theta.data, None, st['m'], st['v'], st['step'], lr, gextraA=self.pack_u[:P],
-                    gextraB=self.pack_u[P:2 * P], scal=self.scal, gsum_out=self.grad_u)
-        KN.losses(self.scal, G.L, G.Vol, G.Nglob, G.Nbglob, self.alpha)
+                    gextraB=self.pack_u[P:2 * P], scal=self.scal, gsum_out=self.grad_u, bump_step=False)
+        KN.losses(self.scal, G.L, G.Vol, G.Nglob, G.Nbglob, self.alpha, step=st['step'])
 
     def generator_step(self, G):
         """one pass of the generator sub-step body; loss_u is left in scal[4] (device)"""
@@ -328,13 +351,11 @@ class Engine:
         M = (self.method, self.H, self.K, self.m)
         self.scal.zero_()
         e0 = self._mark()
-        with self._side(0, e0):
-            self._test_net(G)
-            e_v = self._mark()
+        e_v, e_g = self._test_net(G, e0)
         KN.ode_fwd_multi([self._job(G, 'i')], G.t, th, *M)
         self._reaction(G)
         KN.ode_bwd_multi([self._job(G, 'i', want_x=True)], G.t, th, *M, want_x=True, want_params=False)
-        self._join(e_v)
+        self._join(e_v, e_g)
         self._contract(G)
 
     def _disc_mid(self, G):
@@ -345,10 +366,10 @@ class Engine:
     def _disc_back(self, G):
         lr, st = self.config['v_rate'], self.adam_v
         if self.world is None:
-            KN.adam(self.phi.data, G.slab_v, st['m'], st['v'], st['step'], lr, gsum_out=self.grad_v)
+            KN.adam(self.phi.data, G.slab_v, st['m'], st['v'], st['step'], lr, gsum_out=self.grad_v, bump_step=False)
         else:
-            KN.adam(self.phi.data, None, st['m'], st['v'], st['step'], lr, gextraA=self.grad_v)
-        KN.losses(self.scal, G.L, G.Vol, G.Nglob, G.Nbglob, self.alpha)
+            KN.adam(self.phi.data, None, st['m'], st['v'], st['step'], lr, gextraA=self.grad_v, bump_step=False)
+        KN.losses(self.scal, G.L, G.Vol, G.Nglob, G.Nbglob, self.alpha, step=st['step'])
 
     def _disc_all(self, G):
         self._disc_front(G)

@@ -238,14 +238,15 @@ def disc_cotangent(u, v, w, f, h, Vol, Nglob, scal, vbar, c=None, ckappa=0.0, po
                                 float(Nglob), float(pollution), _p(scal), _p(vbar), _stream()), 'xw_disc_cotangent')
 
 
-def losses(scal, L, Vol, Nglob, Nbglob, alpha):
+def losses(scal, L, Vol, Nglob, Nbglob, alpha, step=None):
+    """loss values from the partial sums; also increments `step` when given (pair with adam(..., bump_step=False))"""
     _need_gpu()
-    _chk(scal, F64, (16,), 'scal')
-    check(lib.xw_losses(_p(scal), L, float(Vol), float(Nglob), float(Nbglob), float(alpha), _stream()), 'xw_losses')
+    _chk(scal, F64, (16,), 'scal'); _chk(step, torch.int64, (1,), 'step')
+    check(lib.xw_losses(_p(scal), L, float(Vol), float(Nglob), float(Nbglob), float(alpha), _p(step), _stream()), 'xw_losses')
 
 
 def adam(param, gslabA, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, gextraA=None, gslabB=None, gextraB=None,
-         scal=None, gsum_out=None):
+         scal=None, gsum_out=None, bump_step=True):
     """param -= Adam(g),  g = gextraA + sum(gslabA) + coefB (gextraB + sum(gslabB)),  coefB = 2 / scal[0] if scal else 1"""
     _need_gpu()
     P = param.shape[0]
@@ -259,7 +260,8 @@ def adam(param, gslabA, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, gextra
         _chk(gslabB, F64, (nB, P), 'gslabB')
     _chk(gextraA, F64, (P,), 'gextraA'); _chk(gextraB, F64, (P,), 'gextraB'); _chk(gsum_out, F64, (P,), 'gsum_out')
     _chk(scal, F64, (16,), 'scal')
-    check(lib.xw_adam(_p(param), _p(gslabA), nA, _p(gextraA), _p(gslabB), nB, _p(gextraB), _p(scal), _p(m), _p(v), _p(step), P,
+    check(lib.xw_adam(_p(param), _p(gslabA), nA, _p(gextraA), _p(gslabB), nB, _p(gextraB), _p(scal), _p(m), _p(v), _p(step),
+                      1 if bump_step else 0, P,
                       float(lr), float(beta1), float(beta2), float(eps), _p(gsum_out), _stream()), 'xw_adam')
 
 
