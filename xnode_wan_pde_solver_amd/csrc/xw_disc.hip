@@ -271,6 +271,19 @@ __global__ void __launch_bounds__(256) k_disc_bwd(const float* __restrict__ xT, 
             xw_writeT(sD + (wave * D::MT + mt) * XW_TTILE, dl[mt]);
             xw_writeT(sR + (wave * D::MT + mt) * XW_TTILE, rj);
           }
+        }
+        // reverse chain first: its 52 MFMAs only need dl and Vh^T and cover the latency of the LDS transposes above
+        d4 nd[D::MT];
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int mt = 0; mt < D::MT; ++mt) nd[mt] = xw_zero4();
+#pragma unroll
+        for (int ks = 0; ks < D::KS; ++ks) {
+          const double b = dl[ks >> 2][ks & 3];
+#pragma unroll
+          for (int mt = 0; mt < D::MT; ++mt) nd[mt] = XW_MFMA(sVhT[(mt * D::KS + ks) * 64 + lane], b, nd[mt]);
+        }
+        if (PARAMS) {
           __syncthreads();
 #pragma unroll
           for (int pw = 0; pw < 4; ++pw)
@@ -282,16 +295,6 @@ __global__ void __launch_bounds__(256) k_disc_bwd(const float* __restrict__ xT, 
                 accH[ct] = XW_MFMA(av, xw_readT(sR + (pw * D::MT + ct) * XW_TTILE, ks), accH[ct]);
             }
           __syncthreads();
-        }
-        d4 nd[D::MT];
-        asm volatile("" ::: "memory");
-#pragma unroll
-        for (int mt = 0; mt < D::MT; ++mt) nd[mt] = xw_zero4();
-#pragma unroll
-        for (int ks = 0; ks < D::KS; ++ks) {
-          const double b = dl[ks >> 2][ks & 3];
-#pragma unroll
-          for (int mt = 0; mt < D::MT; ++mt) nd[mt] = XW_MFMA(sVhT[(mt * D::KS + ks) * 64 + lane], b, nd[mt]);
         }
 #pragma unroll
         for (int mt = 0; mt < D::MT; ++mt)

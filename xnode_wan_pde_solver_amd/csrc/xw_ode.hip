@@ -141,13 +141,17 @@ template <int H, int K> struct FieldG {
 };
 
 // D[i][j] += sum over the 16 paths of Q[i][path] * R[j][path]
+// The block is exactly ONE wave and the LDS executes a wave's DS instructions in issue order, so the transposing
+// write -> read round trip needs no s_barrier: a compiler-level fence keeps the program order of the accesses.
 __device__ __forceinline__ void outer_acc(d4& acc, d4 q, d4 r, double* lds) {
   xw_writeT(lds, q);
   xw_writeT(lds + XW_TTILE, r);
-  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) acc = XW_MFMA(xw_readT(lds, ks), xw_readT(lds + XW_TTILE, ks), acc);
-  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
 }
 // set chain-layout row `row` (0..15) of a tile to the value v in every column
 __device__ __forceinline__ void set_row(d4& q, int row, double v) {
@@ -495,7 +499,8 @@ __global__ void __launch_bounds__(64) k_ode_bwd(const BwdJobs jobs, const float*
   double* slab = PARAMS ? gslab + (long)tile * o.total : nullptr;
   if (PARAMS) {
     xw_writeT(lds, xpb);
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     for (int ct = 0; ct < (d + 15) / 16; ++ct) {
       d4 acc = xw_zero4();
       const int i = 16 * ct + (lane & 15);
@@ -507,7 +512,8 @@ __global__ void __launch_bounds__(64) k_ode_bwd(const BwdJobs jobs, const float*
       }
       storeD(slab + o.Win, o.ldin, K, d, 0, 16 * ct, acc);
     }
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     storeRowSums(slab + o.Winb, K, 0, xpb);
     storeD(slab + o.Wh, K, K, K, 0, 0, G.Wh);
     storeDcol(slab + o.Whb, 1, K, 0, K, G.Wh);
