@@ -110,7 +110,8 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world is not None:
-        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        on_host = torch.distributed.get_backend() == 'gloo'
+        te = torch.tensor([elapsed], dtype=torch.float64, device='cpu' if on_host else dev)
         torch.distributed.all_reduce(te, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(te.item())
     steps_per_s = args.steps / elapsed

@@ -1,0 +1,74 @@
+"""Two ranks sharing the one GPU of the test box (gloo rendezvous, host-staged all-reduce): the engine's sharded
+sub-steps -- path sharding, the single packed all-reduce of the generator sub-step, the two exchanges of the
+discriminator sub-step, graph segments around the collectives -- must reproduce the single-process result."""
+import json
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+PARAMS = {'alpha': 1e8, 'u_layers': 8, 'u_hidden_dim': 20, 'u_hidden_hidden_dim': 10, 'v_layers': 9, 'v_hidden_dim': 50,
+          'n1': 2, 'n2': 1, 'u_rate': 0.015, 'v_rate': 0.04, 'min_steps': 5, 'adjoint': False, 'solver': 'midpoint',
+          'dim': 6, 'N_t': 9, 'N_r': 150, 'N_b': 70, 'T0': 0, 'T': 1, 'shape_param': [-1, 1], 'iterations': 1,
+          'domain': 'Hypercube'}
+
+
+def _run(world, out_path):
+    import configs.Ex4_1_funcs as P
+    from src.training import NODE_WAN_solver
+    from src.dataset import Comb_loader
+    torch.manual_seed(11)
+    S = NODE_WAN_solver(PARAMS, P.func_a, P.func_b, P.func_c, P.func_h, P.func_f, P.func_g, torch.device('cuda', 0), './',
+                        func_u_sol=P.func_u_sol, p=2, world=world)
+    s = S.setup
+    domain = S.domain(s['shape_param'], s['dim'], s['T0'], s['T'], s['N_t'])
+    pts = Comb_loader(s['N_r'], s['N_b'], domain, S.device)          # same seed -> same global sample on every rank
+    shard = S._shard(S._groups(pts))[0]
+    G = S.engine.load_group(*shard[:3], domain, shard[3], shard[4])
+    losses = []
+    for kind in ('g', 'g', 'd', 'g'):
+        if kind == 'g':
+            S.engine.generator_step(G)
+            losses.append(float(S.engine.scal[4]))
+        else:
+            S.engine.discriminator_step(G)
+            losses.append(float(S.engine.scal[5]))
+    torch.cuda.synchronize()
+    torch.save({'theta': S.engine.theta.data.cpu(), 'phi': S.engine.phi.data.cpu(), 'losses': losses, 'N': G.N,
+                'grad_u': S.engine.grad_u.cpu()}, out_path)
+
+
+def _worker(rank, size, port, out_dir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(size), LOCAL_RANK='0')
+    from xnode_wan_pde_solver_amd import dist as xdist
+    world, _ = xdist.init_from_env('gloo')
+    torch.cuda.set_device(0)
+    _run(world, os.path.join(out_dir, 'rank%d.pt' % rank))
+    torch.distributed.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.timeout(900)
+def test_two_ranks_on_one_gpu_match_single_process(tmp_path):
+    size = 2
+    mp.spawn(_worker, args=(size, _free_port(), str(tmp_path)), nprocs=size, join=True)
+    _run(None, str(tmp_path / 'single.pt'))
+    one = torch.load(tmp_path / 'single.pt')
+    ranks = [torch.load(tmp_path / ('rank%d.pt' % r)) for r in range(size)]
+    assert sum(r['N'] for r in ranks) == one['N'] == PARAMS['N_r']
+    for r in ranks:
+        np.testing.assert_allclose(r['losses'], one['losses'], rtol=1e-9)
+        np.testing.assert_allclose(r['grad_u'].numpy(), one['grad_u'].numpy(), rtol=1e-7, atol=1e-9 * float(one['grad_u'].abs().max()))
+        np.testing.assert_allclose(r['theta'].numpy(), one['theta'].numpy(), rtol=1e-8, atol=1e-10)
+        np.testing.assert_allclose(r['phi'].numpy(), one['phi'].numpy(), rtol=1e-8, atol=1e-10)
+    assert torch.equal(ranks[0]['theta'], ranks[1]['theta'])      # replicas stay bit-identical without broadcasts

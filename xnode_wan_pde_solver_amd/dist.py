@@ -30,6 +30,12 @@ class World:
         self.size = dist.get_world_size(group)
 
     def all_reduce(self, t):
+        if t.is_cuda and dist.get_backend(self.group) == 'gloo':
+            # rehearsal mode (several ranks sharing one GPU, or no RCCL): stage through the host
+            h = t.detach().cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+            t.copy_(h)
+            return t
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
 
@@ -58,7 +64,9 @@ def init_from_env(backend=None):
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     if backend is None:
-        backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        backend = os.environ.get('XW_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
+    if torch.cuda.is_available():
+        local = local % torch.cuda.device_count()      # rehearsal: more ranks than GPUs share devices (gloo only)
     if backend == 'nccl':
         torch.cuda.set_device(local)
         dist.init_process_group(backend, device_id=torch.device('cuda', local))
