@@ -164,9 +164,17 @@ def main():
     }
     dominant = max((k for k in kern if k in alg_flops), key=lambda k: kern[k]['ms_per_step'])
     ach = alg_flops[dominant] / (kern[dominant]['avg_ms'] * 1e-3) / 1e12
+    traffic = None                                         # HBM bytes per launch from the committed PMC passes (profiles/)
+    pmc_path = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
+    default_workload = (args.dim, args.n_r, args.n_b, args.n_t) == (20, 4096, 4096, 32)
+    if os.path.exists(pmc_path) and default_workload:
+        pmc = json.load(open(pmc_path))['kernels']
+        key = {'disc_fwd': 'k_disc_fwd<50>', 'disc_bwd': 'k_disc_bwd<50,9,1,true,false>'}.get(dominant)
+        if key in pmc:
+            traffic = pmc[key]['hbm_bytes_per_launch_corrected']
     roofline = {'bound': 'mfma', 'kernel': dominant, 'achieved': round(ach, 3), 'peak': PEAK_FP64_MATRIX_TFLOPS,
-                'unit': 'TFLOP/s', 'frac': round(ach / PEAK_FP64_MATRIX_TFLOPS, 4), 'traffic': None,
-                'avg_launch_ms': round(kern[dominant]['avg_ms'], 4)}
+                'unit': 'TFLOP/s', 'frac': round(ach / PEAK_FP64_MATRIX_TFLOPS, 4), 'traffic': traffic,
+                'alg_flop_per_launch': alg_flops[dominant], 'avg_launch_ms': round(kern[dominant]['avg_ms'], 4)}
     gen_flops = 2.0 * (2 * Pn * macs_v + 4 * N * path_u + 3 * Nb * path_u)
     dis_flops = 2.0 * (3 * Pn * macs_v + 2 * N * path_u)
     step_flops = (2 * gen_flops + dis_flops) / 3.0
@@ -219,7 +227,7 @@ def main():
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': 'Ex4_1 cube d=%d N_r=%d N_b=%d N_t=%d per GPU, midpoint, n1=2 n2=1 (configs[1])'
                        % (s['dim'], s['N_r'], s['N_b'], s['N_t']), 'global_paths': s['N_r'] * size,
-                       'parallelism': 'paths sharded x%d, 2 small all-reduces per sub-step' % size},
+                       'parallelism': 'paths sharded x%d; 1 all-reduce per generator, 2 per discriminator sub-step' % size},
             'roofline': roofline, 'cpu_baseline': cpu, 'whole_step': whole,
             'kernels': {k: {'ms': round(v['avg_ms'], 4), 'per_step': round(v['launches_per_step'], 2)} for k, v in sorted(kern.items())},
             'extras': extras,
