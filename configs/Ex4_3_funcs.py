@@ -1,0 +1,59 @@
+"""PDE data for the time-varying-domain example of Section 4.3 of the XNODE-WAN paper:
+
+    u_t - laplace(u) - u^2 = f  on  D subset [0,1] x R^d,   u = g on the boundary,   u(0,.) = h
+
+with  u(t,x) = (pi/2)^d * 2 * prod_i sin(pi x_i / 2 + pi (i-1) / 2) * exp(-t)  -- every coordinate enters.
+Same callable protocol as the upstream configs/Ex4_3_funcs.py:6-49.  The upstream file reads the dimension from a
+`params` dict of a module that does not exist (`NODE_GAN.main`); here it is taken from the last axis of the input.
+"""
+import math
+
+import torch
+
+from utils.auxillary_funcs import rel_err
+
+
+def _sines(X, first):
+    d = X.shape[-1] - 1
+    out = 1
+    for i in range(d):
+        out = out * torch.sin(math.pi / 2 * X[..., first + i] + math.pi / 2 * i)
+    return out, (2 / math.pi) ** (-d)
+
+
+def func_u_sol(X):
+    s, scale = _sines(X, 1)
+    return scale * 2 * s * torch.exp(-X[..., 0])
+
+
+def func_f(X):
+    s, scale = _sines(X, 1)
+    t = X[..., 0]
+    return scale * (math.pi ** 2 - 2) * s * torch.exp(-t) - 4 * s ** 2 * torch.exp(-2 * t)
+
+
+def func_g(BX):
+    return func_u_sol(BX)
+
+
+def func_h(X0):
+    s, scale = _sines(X0, 1)
+    return scale * 2 * s
+
+
+def func_a(X, i, j):
+    shape = X.shape[:-1]
+    return torch.ones(shape) if i == j else torch.zeros(shape)
+
+
+def func_b(X, i):
+    return torch.zeros(X.shape[:-1])
+
+
+def func_c(X, y_output_u):
+    return -y_output_u
+
+
+def stop(solver, points, domain):
+    err = rel_err(points, solver.u_net, solver.func_u_sol, solver.p, domain.V(), solver.params['N_r'])
+    return bool(err < 0.01)

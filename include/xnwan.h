@@ -9,7 +9,9 @@
  *   - `stream` is a hipStream_t passed as void*; every call only enqueues work on it (graph-capture safe)
  *   - return value: 0 = ok, negative = argument/shape error (XW_E_*), positive = hipError_t of the launch
  *   - per-point arrays are TIME-MAJOR: a[l*N + n] for time index l and path n   ("[L,N]")
- *   - sample coordinates are passed transposed: xT[i*N + n] = x_n[i] (float32, "[d,N]"); time grid t[L] float32
+ *   - sample coordinates are passed transposed: xT[i*N + n] = x_n[i] ("[d,N]"), time grid t[L]; both float64 (the
+ *     reference's cube samples are float32 and up-cast exactly at the first layer, src/model.py:46,154; its sphere
+ *     samples are float64, src/dataset.py:65-96)
  *   - theta / phi are the parameter blobs of u_theta / v_phi in named_parameters() order (float64):
  *       theta: IL0.w[H,1] IL0.b[H] IL2.w[H,H] IL2.b[H] IL4.w[H,H] IL4.b[H]            (src/model.py:78)
  *              Win[K,d+1+H] (columns: x(d) | t | y(H)) Win.b[K] Wh[K,K] Wh.b[K] Wo[H,K] Wo.b[H]   (:130-138)
@@ -39,14 +41,14 @@ int xw_phi_size(int d, int W);
 /* ---- u_theta: NeuralODE.forward for a group of N equal-length paths (src/model.py:87-112,140-156) -------------
  * start[N]: the scalar initial value h(x_n) or g(t_0,x_n) (src/model.py:95-96).
  * u[L,N] out; Y[L,H,N] out (hidden state at every sample time; needed by xw_ode_bwd), may be NULL. */
-int xw_ode_fwd(const float* xT, const float* t, const double* start, const double* theta,
+int xw_ode_fwd(const double* xT, const double* t, const double* start, const double* theta,
                int method, int N, int L, int d, int H, int K, int m,
                double* u, double* Y, void* stream);
 
 /* The same for up to 4 independent groups of paths in ONE launch (interior + boundary sample, ...): one wave per 16
  * paths fills only a quarter of an MI355X at N = 4096, so independent groups are co-scheduled explicitly. */
-typedef struct { const float* xT; const double* start; double* u; double* Y; int N; } XwOdeFwdJob;
-int xw_ode_fwd_multi(const XwOdeFwdJob* jobs, int njobs, const float* t, const double* theta,
+typedef struct { const double* xT; const double* start; double* u; double* Y; int N; } XwOdeFwdJob;
+int xw_ode_fwd_multi(const XwOdeFwdJob* jobs, int njobs, const double* t, const double* theta,
                      int method, int L, int d, int H, int K, int m, void* stream);
 
 /* number of partial-gradient slabs xw_ode_bwd writes for N paths, and doubles of workspace it needs */
@@ -56,32 +58,32 @@ int xw_ode_bwd_slabs(int N);
  * ubar[L,N]: cotangent on u (NULL = all ones).
  * mode bit 0: produce gx[d,N] = d<ubar,u>/dx_n  and gs[N] = d<ubar,u>/d start_n     (nabla_x u of src/loss.py:56-58)
  * mode bit 1: produce parameter-gradient slabs gslab[xw_ode_bwd_slabs(N)][P_u] (to be summed by xw_adam / xw_slab_sum) */
-int xw_ode_bwd(const float* xT, const float* t, const double* start, const double* theta, const double* Y,
+int xw_ode_bwd(const double* xT, const double* t, const double* start, const double* theta, const double* Y,
                const double* ubar, int method, int N, int L, int d, int H, int K, int m, int mode,
                double* gx, double* gs, double* gslab, void* stream);
 
 /* multi-group form: every job has its own sample, checkpoints, cotangent and outputs; `mode` is common to all jobs */
-typedef struct { const float* xT; const double* start; const double* Y; const double* ubar;
+typedef struct { const double* xT; const double* start; const double* Y; const double* ubar;
                  double* gx; double* gs; double* gslab; int N; } XwOdeBwdJob;
-int xw_ode_bwd_multi(const XwOdeBwdJob* jobs, int njobs, const float* t, const double* theta,
+int xw_ode_bwd_multi(const XwOdeBwdJob* jobs, int njobs, const double* t, const double* theta,
                      int method, int L, int d, int H, int K, int m, int mode, void* stream);
 
 /* ---- v_phi: discriminator.forward (src/model.py:37-47) + d/dt by forward-mode ------------------------------------
  * Path mode (tpp == NULL): point (l,n) = (t[l], x_n).  Point mode (tpp != NULL): L must be 1, point n = (tpp[n], x_n).
  * v[L,N] out; vt[L,N] out = dv/dt (may be NULL); act out (may be NULL) = activation stash [(q+1)][W][L*N]
  * needed by xw_disc_bwd (post-ReLU hidden activations r_0..r_{q-1}, then tanh output). */
-int xw_disc_fwd(const float* xT, const float* t, const float* tpp, const double* phi,
+int xw_disc_fwd(const double* xT, const double* t, const double* tpp, const double* phi,
                 int N, int L, int d, int W, int q, double* v, double* vt, double* act, void* stream);
 
 /* input gradient of <vbar, v> at a set of points (reverse mode, no parameter gradients): gxv[d,N] (nabla_x) and
  * gtv[N] (d/dt), for the N points (t_n, x_n) with t_n = tpp ? tpp[n] : t[0]; vbar[N] or NULL (= ones).
  * (XV.grad of src/loss.py:60-63; the fused step only needs it at the first time index) */
-int xw_disc_gradx(const float* xT, const float* t, const float* tpp, const double* phi, const double* vbar,
+int xw_disc_gradx(const double* xT, const double* t, const double* tpp, const double* phi, const double* vbar,
                   int N, int d, int W, int q, double* gxv, double* gtv, void* stream);
 
 int xw_disc_bwd_slabs(int N, int L);
 /* parameter gradient of <vbar, v>: slabs gslab[xw_disc_bwd_slabs][P_v]; optional input gradient is not produced here */
-int xw_disc_bwd(const float* xT, const float* t, const float* tpp, const double* phi, const double* act,
+int xw_disc_bwd(const double* xT, const double* t, const double* tpp, const double* phi, const double* act,
                 const double* vbar, int N, int L, int d, int W, int q, double* gslab, void* stream);
 
 /* ---- weak functional and cotangents (src/loss.py:46-96) -----------------------------------------------------------
@@ -114,8 +116,10 @@ int xw_disc_cotangent(const double* u, const double* v, const double* w, int w_p
                       double ckappa, const double* f, const double* h, int N, int L, double Vol, double Nglob,
                       double pollution, const double* scal_in, double* vbar, void* stream);
 /* scal[4] = loss_u, scal[5] = loss_v, scal[6] = int from the (all-reduced) partial sums scal[0..3] (src/loss.py:87-96);
+ * L / Lb: sample times of the interior / boundary paths of the group;
  * step (may be NULL): optimiser step counter to increment here when xw_adam was called with bump_step = 0 */
-int xw_losses(double* scal, int L, double Vol, double Nglob, double Nbglob, double alpha, long long* step, void* stream);
+int xw_losses(double* scal, int L, int Lb, double Vol, double Nglob, double Nbglob, double alpha, long long* step,
+              void* stream);
 
 /* ---- optimiser (torch.optim.Adam defaults, src/training.py:103-104) ------------------------------------------------
  * grad = gextraA + sum_s gslabA[s] + coefB * (gextraB + sum_s gslabB[s]),  coefB = scal ? 2 / scal[0] : 1

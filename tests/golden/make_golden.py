@@ -260,6 +260,65 @@ def trajectory(case, d, N_r, N_b, N_t, seed, outer_iters, gpu_loader_semantics):
     print('wrote', path, 'steps', len(log), 'wall %.1fs' % wall, 'final rel-L2', log[-1])
 
 
+def sphere_groups(case, domain_name, d, N_r, N_b, N_t, seed):
+    """Time-varying ball domains (src/dataset.py:48-229): the sampled groups themselves, and one generator sub-iteration,
+    one more, and one discriminator sub-iteration over hand-paired (interior, boundary) groups with the reference's own
+    modules -- zero_grad() once per sub-iteration, optimizer.step() after every group (src/training.py:127-138,152-162),
+    GPU loader semantics (fresh copies per pass).  Only groups with >= 2 samples and boundary times != T0 are used:
+    for single-slice groups the reference returns [N,1] instead of [N,1,1] (src/model.py:89-91) and its loss broadcasts
+    to [N,N] pairwise terms (src/loss.py:65,79,84); the engine implements the elementwise intent there."""
+    training, dataset, lossmod, F = load_reference()
+    params = make_params(d, N_r, N_b, N_t, 'midpoint')
+    params['domain'] = domain_name
+    params['shape_param'] = 1.0
+    dev = torch.device('cpu')
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    S = training.NODE_WAN_solver(params, F.func_a, F.func_b, F.func_c, F.func_h, F.func_f, F.func_g, dev, './',
+                                 func_u_sol=F.func_u_sol, p=2)
+    out = {'params_json': np.array(json.dumps(params)), 'seed': np.array(seed)}
+    domain = S.domain(S.setup['shape_param'], d, S.setup['T0'], S.setup['T'], N_t)
+    points = dataset.Comb_loader(N_r, N_b, domain, dev)
+    out['times'] = npy(domain.times)
+    out['V'] = np.array(float(domain.V()))
+    out['n_interior'], out['n_boundary'] = np.array(len(points.interioru)), np.array(len(points.boundary))
+    for k, g in enumerate(points.interioru):
+        out['interior/%d' % k] = npy(g)
+        out['w/%d' % k] = npy(domain.func_w(g))
+    for k, g in enumerate(points.boundary):
+        out['boundary/%d' % k] = npy(g)
+    out['L2_start'] = np.array(training.L_norm(points.interioru, S.u_net, S.p, S.func_u_sol, domain.V(), N_r).item())
+    inner = [k for k, g in enumerate(points.interioru) if g.shape[1] >= 2]
+    edge = [k for k, g in enumerate(points.boundary) if float(g[0, 0, 0]) != S.setup['T0']]
+    pairs = list(zip(inner, edge))
+    out['pairs'] = np.array(pairs)
+    fresh = lambda t: t.detach().clone().requires_grad_(True)  # noqa: E731
+    step = 0
+    for which, opt, net in (('u', S.optimizer_u, S.u_net), ('u', S.optimizer_u, S.u_net), ('v', S.optimizer_v, S.v_net)):
+        opt.zero_grad()
+        for (ki, kb) in pairs:
+            datau, datav, bdata = fresh(points.interioru[ki]), fresh(points.interioru[ki]), fresh(points.boundary[kb])
+            pv, pu = S.v_net(datav), S.u_net(datau)
+            h, f, g, a, b, c = training.func_eval(datau.clone().detach(), bdata.clone().detach(), S.setup, pu,
+                                                  F.func_a, F.func_b, F.func_c, F.func_h, F.func_f, F.func_g)
+            Lo = lossmod.loss(S.config['alpha'], a, b, c, h, f, g, S.setup, domain, dev)
+            L = Lo.u(pu, pv, S.u_net, datau, datav, bdata) if which == 'u' else Lo.v(pu, pv, datau, datav)
+            L.backward(retain_graph=True)
+            tag = 'step%d' % step
+            out[tag + '/which'] = np.array(which)
+            out[tag + '/loss'] = np.array(L.item())
+            out[tag + '/u'] = npy(pu.squeeze(2))
+            out[tag + '/v'] = npy(pv.squeeze(2))
+            out[tag + '/grad'] = np.concatenate([npy(p.grad).reshape(-1) for p in net.parameters()])
+            opt.step()
+            out[tag + '/after'] = np.concatenate([npy(p).reshape(-1) for p in net.parameters()])
+            step += 1
+    out['n_steps'] = np.array(step)
+    path = os.path.join(HERE, case + '.npz')
+    np.savez_compressed(path, **out)
+    print('wrote', path, '%.1f KB' % (os.path.getsize(path) / 1024), 'groups', len(points.interioru), 'pairs', pairs)
+
+
 def fillt_vectors():
     """src/dataset.py:13-32 on a few hand-picked time vectors (the helper has surprising edge behaviour that the
     product reproduces verbatim: it can drop a sample and return indices past the filled vector)."""
@@ -285,6 +344,8 @@ if __name__ == '__main__':
     torch.set_num_threads(4)
     if not args.only_traj:
         fillt_vectors()
+        sphere_groups('ref_cone_groups', 'NSphere_TCone', 3, 64, 40, 8, 1)
+        sphere_groups('ref_hourglass_groups', 'NSphere_THourglass', 3, 64, 40, 8, 1)
         one_iteration('ref_tiny_midpoint', 3, 8, 12, 6, 7, 'midpoint', True)
         one_iteration('ref_tiny_euler', 3, 8, 12, 6, 7, 'euler', True)
         one_iteration('ref_tiny_rk4', 3, 8, 12, 6, 7, 'rk4', True)

@@ -72,7 +72,7 @@ def test_ode_forward(N, L, d, solver):
     x, t, X = _sample(N, L, d, 2)
     start = torch.randn(N, dtype=torch.float64, generator=torch.Generator().manual_seed(3))
     u_ref = R.u_net(theta, _cfg(8, solver), X, start)
-    u, Y = KN.ode_fwd(x.t().contiguous().cuda(), t.cuda(), start.cuda(), _blob(theta, U_ORDER), KN.method_id(solver), H, K, 8)
+    u, Y = KN.ode_fwd(x.double().t().contiguous().cuda(), t.double().cuda(), start.double().cuda(), _blob(theta, U_ORDER), KN.method_id(solver), H, K, 8)
     _close(u.t(), u_ref, 1e-12, 'u')
     assert Y.shape == (L, H, N)
 
@@ -86,7 +86,7 @@ def test_ode_forward_depths(m):
     x, t, X = _sample(N, L, d, 6)
     start = torch.randn(N, dtype=torch.float64, generator=torch.Generator().manual_seed(7))
     u_ref = R.u_net(theta, _cfg(m), X, start)
-    u, _ = KN.ode_fwd(x.t().contiguous().cuda(), t.cuda(), start.cuda(), _blob(theta, U_ORDER), 1, H, K, m)
+    u, _ = KN.ode_fwd(x.double().t().contiguous().cuda(), t.double().cuda(), start.double().cuda(), _blob(theta, U_ORDER), 1, H, K, m)
     _close(u.t(), u_ref, 1e-12, 'u')
 
 
@@ -107,7 +107,7 @@ def test_ode_backward(N, L, d, solver, ones):
     Xd = torch.cat((t.double().view(1, L, 1).expand(N, L, 1), x64.view(N, 1, d).expand(N, L, d)), 2)
     u_ref = R.u_net(th, _cfg(8, solver), Xd, start)
     grads = torch.autograd.grad((u_ref * ubar).sum(), [x64, start] + [th[k] for k in U_ORDER])
-    xT, tc, sc, blob = x.t().contiguous().cuda(), t.cuda(), start.detach().cuda(), _blob(theta, U_ORDER)
+    xT, tc, sc, blob = x.double().t().contiguous().cuda(), t.double().cuda(), start.detach().cuda(), _blob(theta, U_ORDER)
     mid = KN.method_id(solver)
     u, Y = KN.ode_fwd(xT, tc, sc, blob, mid, H, K, 8)
     ub = None if ones else ubar.t().contiguous().cuda()
@@ -136,13 +136,13 @@ def test_disc_forward_and_time_tangent(N, L, d):
     Xd = X.double().requires_grad_(True)
     v_ref = R.v_net(phi, _cfg(), Xd)
     gX = torch.autograd.grad(v_ref.sum(), Xd)[0]
-    v, vt = KN.disc_fwd(x.t().contiguous().cuda(), t.cuda(), _blob(phi, V_ORDER), W, Q)
+    v, vt = KN.disc_fwd(x.double().t().contiguous().cuda(), t.double().cuda(), _blob(phi, V_ORDER), W, Q)
     _close(v.t(), v_ref, 1e-12, 'v')
     _close(vt.t(), gX[:, :, 0], 1e-11, 'dv/dt')
     # point mode: arbitrary per-point times
     tpp = torch.rand(N, generator=torch.Generator().manual_seed(23)).float()
     Xp = torch.cat((tpp.view(N, 1), x), 1).double()
-    v1, _ = KN.disc_fwd(x.t().contiguous().cuda(), None, _blob(phi, V_ORDER), W, Q, tpp=tpp.cuda())
+    v1, _ = KN.disc_fwd(x.double().t().contiguous().cuda(), None, _blob(phi, V_ORDER), W, Q, tpp=tpp.double().cuda())
     _close(v1[0], R.v_net(phi, _cfg(), Xp), 1e-12, 'v (point mode)')
 
 
@@ -154,7 +154,7 @@ def test_disc_input_gradient(N, d):
     x, t, X = _sample(N, 4, d, 32)
     X0 = X[:, 0, :].double().requires_grad_(True)
     g = torch.autograd.grad(R.v_net(phi, _cfg(), X0).sum(), X0)[0]
-    gxv, gtv = KN.disc_gradx(x.t().contiguous().cuda(), t.cuda(), _blob(phi, V_ORDER), W, Q)
+    gxv, gtv = KN.disc_gradx(x.double().t().contiguous().cuda(), t.double().cuda(), _blob(phi, V_ORDER), W, Q)
     _close(gxv.t(), g[:, 1:], 1e-11, 'nabla_x v')
     _close(gtv, g[:, 0], 1e-11, 'dv/dt')
 
@@ -169,7 +169,7 @@ def test_disc_backward(N, L, d):
     vbar = torch.randn(N, L, dtype=torch.float64, generator=torch.Generator().manual_seed(43))
     v_ref = R.v_net(ph, _cfg(), X)
     grads = torch.autograd.grad((v_ref * vbar).sum(), [ph[k] for k in V_ORDER])
-    slab = KN.disc_bwd(x.t().contiguous().cuda(), t.cuda(), _blob(phi, V_ORDER), vbar.t().contiguous().cuda(), W, Q)
+    slab = KN.disc_bwd(x.double().t().contiguous().cuda(), t.double().cuda(), _blob(phi, V_ORDER), vbar.t().contiguous().cuda(), W, Q)
     got = KN.slab_sum(slab).cpu()
     ref = torch.cat([g_.reshape(-1) for g_ in grads])
     off = 0
@@ -204,8 +204,8 @@ def test_adam_matches_torch_formula():
 def test_dims_outside_the_compiled_set_fail_loudly():
     from xnode_wan_pde_solver_amd import kernels as KN
     from xnode_wan_pde_solver_amd._lib import XnwanError
-    x = torch.zeros(3, 16, dtype=torch.float32).cuda()
-    t = torch.linspace(0, 1, 4).cuda()
+    x = torch.zeros(3, 16, dtype=torch.float64).cuda()
+    t = torch.linspace(0, 1, 4, dtype=torch.float64).cuda()
     with pytest.raises(XnwanError):
         KN.ode_fwd(x, t, torch.zeros(16, dtype=torch.float64).cuda(),
                    torch.zeros(KN.theta_size(3, 24, 12), dtype=torch.float64).cuda(), 1, 24, 12, 8)

@@ -140,3 +140,26 @@ def test_product_never_imports_the_oracle():
     assert not bad, bad
     main_txt = open(os.path.join(ROOT, 'main.py')).read()
     assert 'oracle' not in main_txt
+
+
+@pytest.mark.parametrize('case,name', [('ref_cone_groups', 'NSphere_TCone'), ('ref_hourglass_groups', 'NSphere_THourglass')])
+def test_sphere_domains_sample_like_the_reference(golden_dir, case, name):
+    z, params = load(golden_dir, case)
+    config, setup, _ = S.split_params(params)
+    torch.manual_seed(int(z['seed']))
+    np.random.seed(int(z['seed']))
+    dom_cls = sampling.resolve_domain(name)
+    S.build_networks(config, setup, P.func_h, P.func_g, dom_cls)          # consumes the RNG like the constructor
+    domain = dom_cls(setup['shape_param'], setup['dim'], setup['T0'], setup['T'], setup['N_t'])
+    pts = sampling.Comb_loader(setup['N_r'], setup['N_b'], domain, torch.device('cpu'))
+    assert np.array_equal(domain.times.numpy(), z['times']) and domain.V() == float(z['V'])
+    assert len(pts.interioru) == int(z['n_interior']) and len(pts.boundary) == int(z['n_boundary'])
+    for k, g in enumerate(pts.interioru):
+        assert g.dtype == torch.float64 and g.requires_grad
+        assert np.array_equal(g.detach().numpy(), z['interior/%d' % k])
+        assert np.array_equal(pts.interiorv[k].detach().numpy(), z['interior/%d' % k])       # v sample = copy of the u sample
+        assert np.array_equal(domain.func_w(g).detach().numpy(), z['w/%d' % k])
+    for k, g in enumerate(pts.boundary):
+        assert np.array_equal(g.detach().numpy(), z['boundary/%d' % k])
+        assert float(domain.func_w(g.detach()).abs().max()) < 1e-12                          # boundary points sit on the boundary
+    assert len(list(pts)) == min(len(pts.interioru), len(pts.boundary))                      # silent truncation (Q7)

@@ -8,9 +8,9 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libxnwan.so')
-ABI_VERSION = 3
+ABI_VERSION = 4
 
-c_f32p = ctypes.c_void_p   # const float*  (device)
+c_f32p = ctypes.c_void_p   # coordinates / time grid: const double* (device)
 c_f64p = ctypes.c_void_p   # double*       (device)
 c_i64p = ctypes.c_void_p
 c_int, c_dbl, c_vp = ctypes.c_int, ctypes.c_double, ctypes.c_void_p
@@ -48,7 +48,7 @@ SIGNATURES = {
                           c_dbl, c_f64p, c_f64p, c_vp],
     'xw_disc_cotangent': [c_f64p, c_f64p, c_f64p, c_int, c_f64p, c_dbl, c_f64p, c_f64p, c_int, c_int, c_dbl, c_dbl, c_dbl,
                           c_f64p, c_f64p, c_vp],
-    'xw_losses': [c_f64p, c_int, c_dbl, c_dbl, c_dbl, c_dbl, c_i64p, c_vp],
+    'xw_losses': [c_f64p, c_int, c_int, c_dbl, c_dbl, c_dbl, c_dbl, c_i64p, c_vp],
     'xw_adam': [c_f64p, c_f64p, c_int, c_f64p, c_f64p, c_int, c_f64p, c_f64p, c_f64p, c_f64p, c_i64p, c_int, c_int, c_dbl,
                 c_dbl, c_dbl, c_dbl, c_f64p, c_vp],
     'xw_slab_sum': [c_f64p, c_int, c_int, c_int, c_f64p, c_vp],

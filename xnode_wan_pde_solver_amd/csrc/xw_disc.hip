@@ -32,7 +32,7 @@ struct Pt {
   bool valid;
   double t;
 };
-__device__ __forceinline__ Pt locate(long tile, long P, int N, const float* __restrict__ tf, const float* __restrict__ tpp) {
+__device__ __forceinline__ Pt locate(long tile, long P, int N, const double* __restrict__ tf, const double* __restrict__ tpp) {
   Pt q;
   const long p = tile * 16 + (xw_lane() & 15);
   q.valid = p < P;
@@ -40,18 +40,18 @@ __device__ __forceinline__ Pt locate(long tile, long P, int N, const float* __re
   q.p = (int)pc;
   if (tpp != nullptr) {
     q.n = (int)pc;
-    q.t = (double)tpp[pc];
+    q.t = tpp[pc];
   } else {
     const int l = (int)(pc / N);
     q.n = (int)(pc - (long)l * N);
-    q.t = (double)tf[l];
+    q.t = tf[l];
   }
   return q;
 }
 
 // input layer a0 = Vin [t; x] + b  (and its t-tangent = Vin[:, 0])
 template <int W>
-__device__ __forceinline__ void input_layer(const double* __restrict__ ph, const VOff& o, const float* __restrict__ xT,
+__device__ __forceinline__ void input_layer(const double* __restrict__ ph, const VOff& o, const double* __restrict__ xT,
                                             int N, int d, const Pt& q, d4 (&a)[VDim<W>::MT], d4 (&ad)[VDim<W>::MT]) {
   typedef VDim<W> D;
   const int g = xw_lane() >> 4;
@@ -62,7 +62,7 @@ __device__ __forceinline__ void input_layer(const double* __restrict__ ph, const
   }
   for (int ks = 0; ks < (d + 3) / 4; ++ks) {
     const int i = 4 * ks + g;
-    const double b = i < d ? (double)xT[(long)i * N + q.n] : 0.0;
+    const double b = i < d ? xT[(long)i * N + q.n] : 0.0;
 #pragma unroll
     for (int mt = 0; mt < D::MT; ++mt) a[mt] = XW_MFMA(xw_fragA(ph + o.Vin + 1, o.ldin, W, d, 16 * mt, 4 * ks), b, a[mt]);
   }
@@ -70,8 +70,8 @@ __device__ __forceinline__ void input_layer(const double* __restrict__ ph, const
 
 // ------------------------------------------------------------------------------------------------------------------
 template <int W>
-__global__ void __launch_bounds__(256, 2) k_disc_fwd(const float* __restrict__ xT, const float* __restrict__ tf,
-                                                     const float* __restrict__ tpp, const double* __restrict__ ph, int N,
+__global__ void __launch_bounds__(256, 2) k_disc_fwd(const double* __restrict__ xT, const double* __restrict__ tf,
+                                                     const double* __restrict__ tpp, const double* __restrict__ ph, int N,
                                                      int L, int d, int q, double* __restrict__ v, double* __restrict__ vt) {
   typedef VDim<W> D;
   // Vh as MFMA A-fragments in LDS (26.6 KB), shared by the 4 waves of the block: one ds_read_b64 feeds two 64-cycle MFMAs
@@ -158,8 +158,8 @@ template <int W> struct BwdLds {
 };
 
 template <int W, int Q, int CTG, bool PARAMS, bool INGRAD>
-__global__ void __launch_bounds__(256) k_disc_bwd(const float* __restrict__ xT, const float* __restrict__ tf,
-                                                  const float* __restrict__ tpp, const double* __restrict__ ph,
+__global__ void __launch_bounds__(256) k_disc_bwd(const double* __restrict__ xT, const double* __restrict__ tf,
+                                                  const double* __restrict__ tpp, const double* __restrict__ ph,
                                                   const double* __restrict__ vbar, int N, int L, int d,
                                                   double* __restrict__ gslab, double* __restrict__ gxv,
                                                   double* __restrict__ gtv) {
@@ -315,7 +315,7 @@ __global__ void __launch_bounds__(256) k_disc_bwd(const float* __restrict__ xT, 
           double val = 0.0;
           if (pt.valid) {
             if (c == 0) val = pt.t;
-            else if (c <= d) val = (double)xT[(long)(c - 1) * N + pt.n];
+            else if (c <= d) val = xT[(long)(c - 1) * N + pt.n];
             else if (c == d + 1) val = 1.0;
           }
           sR[(wave * D::MT + (cl >> 4)) * XW_TTILE + (cl & 15) * XW_TSTRIDE + n] = val;
@@ -409,7 +409,7 @@ int bwd_blocks(long P) {
 
 }  // namespace
 
-extern "C" int xw_disc_fwd(const float* xT, const float* t, const float* tpp, const double* phi, int N, int L, int d,
+extern "C" int xw_disc_fwd(const double* xT, const double* t, const double* tpp, const double* phi, int N, int L, int d,
                            int W, int q, double* v, double* vt, double* act, void* stream) {
   (void)act;
   if (!xT || !phi || !v || N <= 0 || L <= 0 || d <= 0 || q < 0) return XW_E_ARG;
@@ -436,7 +436,7 @@ extern "C" int xw_disc_bwd_slabs(int N, int L) { return bwd_blocks((long)N * L);
     hipLaunchKernelGGL((k_disc_bwd<50, 9, 2, PARAMS, INGRAD>), dim3(blocks), dim3(256), 0, s, xT, t, tpp, phi, vbar, N, \
                        L, d, gslab, gxv, gtv);
 
-extern "C" int xw_disc_bwd(const float* xT, const float* t, const float* tpp, const double* phi, const double* act,
+extern "C" int xw_disc_bwd(const double* xT, const double* t, const double* tpp, const double* phi, const double* act,
                            const double* vbar, int N, int L, int d, int W, int q, double* gslab, void* stream) {
   (void)act;
   if (!xT || !phi || !gslab || N <= 0 || L <= 0 || d <= 0) return XW_E_ARG;
@@ -451,7 +451,7 @@ extern "C" int xw_disc_bwd(const float* xT, const float* t, const float* tpp, co
   return xw_launch_status();
 }
 
-extern "C" int xw_disc_gradx(const float* xT, const float* t, const float* tpp, const double* phi, const double* vbar,
+extern "C" int xw_disc_gradx(const double* xT, const double* t, const double* tpp, const double* phi, const double* vbar,
                              int N, int d, int W, int q, double* gxv, double* gtv, void* stream) {
   if (!xT || !phi || !gxv || N <= 0 || d <= 0) return XW_E_ARG;
   if (!tpp && !t) return XW_E_ARG;

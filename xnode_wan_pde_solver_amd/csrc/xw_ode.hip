@@ -235,13 +235,13 @@ __device__ __forceinline__ void lift(const double* __restrict__ th, const UOff& 
 
 // xp = Win.b + Win[:, :d] x   (time-invariant along a path: src/model.py:99,154)
 template <int H, int K>
-__device__ __forceinline__ d4 project_x(const double* __restrict__ th, const UOff& o, const float* __restrict__ xT,
+__device__ __forceinline__ d4 project_x(const double* __restrict__ th, const UOff& o, const double* __restrict__ xT,
                                         int N, int d, int ncl) {
   const int g = xw_lane() >> 4;
   d4 xp = xw_vecD(th + o.Winb, K, 0);
   for (int ks = 0; ks < (d + 3) / 4; ++ks) {
     const int i = 4 * ks + g;
-    const double b = i < d ? (double)xT[(long)i * N + ncl] : 0.0;
+    const double b = i < d ? xT[(long)i * N + ncl] : 0.0;
     xp = XW_MFMA(xw_fragA(th + o.Win, o.ldin, K, d, 0, 4 * ks), b, xp);
   }
   return xp;
@@ -252,7 +252,7 @@ __device__ __forceinline__ d4 project_x(const double* __restrict__ th, const UOf
 // separate streams do not reliably overlap (they can land on the same hardware queue).
 #define XW_MAXJOBS 4
 struct FwdJobs {
-  const float* xT[XW_MAXJOBS];
+  const double* xT[XW_MAXJOBS];
   const double* start[XW_MAXJOBS];
   double* u[XW_MAXJOBS];
   double* Y[XW_MAXJOBS];
@@ -261,7 +261,7 @@ struct FwdJobs {
   int n;
 };
 struct BwdJobs {
-  const float* xT[XW_MAXJOBS];
+  const double* xT[XW_MAXJOBS];
   const double* start[XW_MAXJOBS];
   const double* Y[XW_MAXJOBS];
   const double* ubar[XW_MAXJOBS];
@@ -282,12 +282,12 @@ template <typename J> __device__ __forceinline__ int find_job(const J& jobs) {
 
 // ------------------------------------------------------------------------------------------------------------------
 template <int H, int K, int M, int METHOD>
-__global__ void __launch_bounds__(64) k_ode_fwd(const FwdJobs jobs, const float* __restrict__ tf,
+__global__ void __launch_bounds__(64) k_ode_fwd(const FwdJobs jobs, const double* __restrict__ tf,
                                                 const double* __restrict__ th, int L, int d) {
   typedef Dim<H, K> D;
   typedef RK<METHOD> T;
   const int job = find_job(jobs);
-  const float* __restrict__ xT = jobs.xT[job];
+  const double* __restrict__ xT = jobs.xT[job];
   const double* __restrict__ start = jobs.start[job];
   double* __restrict__ u = jobs.u[job];
   double* __restrict__ Y = jobs.Y[job];
@@ -319,7 +319,7 @@ __global__ void __launch_bounds__(64) k_ode_fwd(const FwdJobs jobs, const float*
     const double ul = xw_sum_over_g(part) + flb;           // final_linear, src/model.py:110
     if (g == 0 && valid) u[(long)l * N + base + n] = ul;
     if (l == L - 1) break;
-    const double t0 = (double)tf[l], dt = (double)tf[l + 1] - t0;
+    const double t0 = tf[l], dt = tf[l + 1] - t0;
     d4 k[T::S][D::HT];
 #pragma unroll
     for (int i = 0; i < T::S; ++i) {
@@ -372,13 +372,13 @@ __device__ __forceinline__ void storeRowSums(double* dst, int rows, int r0, d4 q
 }
 
 template <int H, int K, int M, int METHOD, bool PARAMS>
-__global__ void __launch_bounds__(64) k_ode_bwd(const BwdJobs jobs, const float* __restrict__ tf,
+__global__ void __launch_bounds__(64) k_ode_bwd(const BwdJobs jobs, const double* __restrict__ tf,
                                                 const double* __restrict__ th, int L, int d) {
   typedef Dim<H, K> D;
   typedef RK<METHOD> T;
   __shared__ double lds[2 * XW_TTILE];
   const int job = find_job(jobs);
-  const float* __restrict__ xT = jobs.xT[job];
+  const double* __restrict__ xT = jobs.xT[job];
   const double* __restrict__ start = jobs.start[job];
   const double* __restrict__ Y = jobs.Y[job];
   const double* __restrict__ ubar = jobs.ubar[job];
@@ -427,7 +427,7 @@ __global__ void __launch_bounds__(64) k_ode_bwd(const BwdJobs jobs, const float*
       }
     if (l < L - 1) {
       // reverse of the step l -> l+1 : lam currently holds the total cotangent of y_{l+1}
-      const double t0 = (double)tf[l], dt = (double)tf[l + 1] - t0;
+      const double t0 = tf[l], dt = tf[l + 1] - t0;
       d4 k[T::S][D::HT], kb[T::S][D::HT], psum[D::HT];
       Save<M> sv;
 #pragma unroll
@@ -507,7 +507,7 @@ __global__ void __launch_bounds__(64) k_ode_bwd(const BwdJobs jobs, const float*
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         const int pn = base + 4 * ks + (lane >> 4);
-        const double b = (i < d && pn < N) ? (double)xT[(long)i * N + pn] : 0.0;
+        const double b = (i < d && pn < N) ? xT[(long)i * N + pn] : 0.0;
         acc = XW_MFMA(xw_readT(lds, ks), b, acc);
       }
       storeD(slab + o.Win, o.ldin, K, d, 0, 16 * ct, acc);
@@ -593,7 +593,7 @@ __global__ void __launch_bounds__(64) k_ode_bwd(const BwdJobs jobs, const float*
 }
 
 template <int H, int K, int M>
-int launch_fwd(int method, const FwdJobs& jobs, const float* t, const double* theta, int L, int d, hipStream_t s) {
+int launch_fwd(int method, const FwdJobs& jobs, const double* t, const double* theta, int L, int d, hipStream_t s) {
   const dim3 grid(jobs.tile0[jobs.n]), block(64);
   switch (method) {
     case 0: hipLaunchKernelGGL((k_ode_fwd<H, K, M, 0>), grid, block, 0, s, jobs, t, theta, L, d); break;
@@ -604,7 +604,7 @@ int launch_fwd(int method, const FwdJobs& jobs, const float* t, const double* th
   return xw_launch_status();
 }
 template <int H, int K, int M, bool PARAMS>
-int launch_bwd(int method, const BwdJobs& jobs, const float* t, const double* theta, int L, int d, hipStream_t s) {
+int launch_bwd(int method, const BwdJobs& jobs, const double* t, const double* theta, int L, int d, hipStream_t s) {
   const dim3 grid(jobs.tile0[jobs.n]), block(64);
   switch (method) {
     case 0: hipLaunchKernelGGL((k_ode_bwd<H, K, M, 0, PARAMS>), grid, block, 0, s, jobs, t, theta, L, d); break;
@@ -626,7 +626,7 @@ int launch_bwd(int method, const BwdJobs& jobs, const float* t, const double* th
 
 extern "C" int xw_ode_bwd_slabs(int N) { return (N + 15) / 16; }
 
-extern "C" int xw_ode_fwd_multi(const XwOdeFwdJob* jobs, int njobs, const float* t, const double* theta, int method, int L,
+extern "C" int xw_ode_fwd_multi(const XwOdeFwdJob* jobs, int njobs, const double* t, const double* theta, int method, int L,
                                 int d, int H, int K, int m, void* stream) {
   if (!jobs || njobs < 1 || njobs > XW_MAXJOBS || !t || !theta || L <= 0 || d <= 0 || m < 1) return XW_E_ARG;
   FwdJobs J;
@@ -648,13 +648,13 @@ extern "C" int xw_ode_fwd_multi(const XwOdeFwdJob* jobs, int njobs, const float*
 #undef CALL
 }
 
-extern "C" int xw_ode_fwd(const float* xT, const float* t, const double* start, const double* theta, int method, int N,
+extern "C" int xw_ode_fwd(const double* xT, const double* t, const double* start, const double* theta, int method, int N,
                           int L, int d, int H, int K, int m, double* u, double* Y, void* stream) {
   XwOdeFwdJob j = {xT, start, u, Y, N};
   return xw_ode_fwd_multi(&j, 1, t, theta, method, L, d, H, K, m, stream);
 }
 
-extern "C" int xw_ode_bwd_multi(const XwOdeBwdJob* jobs, int njobs, const float* t, const double* theta, int method, int L,
+extern "C" int xw_ode_bwd_multi(const XwOdeBwdJob* jobs, int njobs, const double* t, const double* theta, int method, int L,
                                 int d, int H, int K, int m, int mode, void* stream) {
   if (!jobs || njobs < 1 || njobs > XW_MAXJOBS || !t || !theta || L <= 0 || d <= 0 || m < 1 || (mode & 3) == 0) return XW_E_ARG;
   BwdJobs J;
@@ -685,7 +685,7 @@ extern "C" int xw_ode_bwd_multi(const XwOdeBwdJob* jobs, int njobs, const float*
 #undef CALL
 }
 
-extern "C" int xw_ode_bwd(const float* xT, const float* t, const double* start, const double* theta, const double* Y,
+extern "C" int xw_ode_bwd(const double* xT, const double* t, const double* start, const double* theta, const double* Y,
                           const double* ubar, int method, int N, int L, int d, int H, int K, int m, int mode, double* gx,
                           double* gs, double* gslab, void* stream) {
   XwOdeBwdJob j = {xT, start, Y, ubar, gx, gs, gslab, N};

@@ -135,13 +135,13 @@ __global__ void __launch_bounds__(256) k_gen_cots(const double* __restrict__ u, 
   }
 }
 
-__global__ void k_losses(double* __restrict__ scal, int L, double Vol, double Nglob, double Nbglob, double alpha,
+__global__ void k_losses(double* __restrict__ scal, int L, int Lb, double Vol, double Nglob, double Nbglob, double alpha,
                          long long* __restrict__ step) {
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     if (step != nullptr) *step += 1;                  // optimiser step counter (after xw_adam has read it)
     const double in_ = interior_loss(scal, Vol, Nglob, L);
     scal[6] = in_;
-    scal[4] = in_ + alpha * (scal[2] / Nglob + scal[3] / (Nbglob * (double)L));  // src/loss.py:93
+    scal[4] = in_ + alpha * (scal[2] / Nglob + scal[3] / (Nbglob * (double)Lb));  // src/loss.py:93
     scal[5] = -in_;                                                                // src/loss.py:96
   }
 }
@@ -258,10 +258,10 @@ extern "C" int xw_gen_cotangents(const double* u, const double* v, const double*
   return xw_launch_status();
 }
 
-extern "C" int xw_losses(double* scal, int L, double Vol, double Nglob, double Nbglob, double alpha, long long* step,
-                         void* stream) {
-  if (!scal || L <= 0) return XW_E_ARG;
-  hipLaunchKernelGGL(k_losses, dim3(1), dim3(64), 0, (hipStream_t)stream, scal, L, Vol, Nglob, Nbglob, alpha, step);
+extern "C" int xw_losses(double* scal, int L, int Lb, double Vol, double Nglob, double Nbglob, double alpha,
+                         long long* step, void* stream) {
+  if (!scal || L <= 0 || Lb <= 0) return XW_E_ARG;
+  hipLaunchKernelGGL(k_losses, dim3(1), dim3(64), 0, (hipStream_t)stream, scal, L, Lb, Vol, Nglob, Nbglob, alpha, step);
   return xw_launch_status();
 }
 
@@ -290,7 +290,7 @@ extern "C" int xw_slab_sum(const double* gslab, int nslab, int P, int accumulate
   return xw_launch_status();
 }
 
-extern "C" int xw_abi_version(void) { return 3; }
+extern "C" int xw_abi_version(void) { return 4; }
 
 extern "C" int xw_supported_dims(char* buf, int buflen) {
   static const char s[] = "ode(H,K,m)=(20,10,8),(20,10,4),(20,10,2); disc_fwd W=50 any q; disc_bwd (W,q)=(50,9), d<=126";

@@ -14,9 +14,9 @@ Semantics are the reference's ON A GPU, stated once here 
   Q5  no stale .grad carry-over between sub-steps (that is a CPU-only artefact of the reference).
 
 Data layout in HBM (per group of N equal-length paths, L sample times, d dimensions):
-  xT, xvT, xbT  float32 [d, N]   transposed coordinates of the u-, v- and boundary samples (the [N, L, d+1] path tensor
+  xT, xvT, xbT  float64 [d, N]   transposed coordinates of the u-, v- and boundary samples (the [N, L, d+1] path tensor
                                  of the reference is never materialised on the device: on vertical paths it is x (x) t)
-  t             float32 [L]      shared time grid
+  t             float64 [L]      shared time grid
   u, v, vt, f, ubar, vbar ...    float64 [L, N]   time-major point arrays (coalesced for one-lane-per-path kernels)
   Y             float64 [L, H, N]  hidden-state checkpoints of the stepper (written by the forward, read by the sweeps)
   slabs         float64 [n_slab, P]  per-wave partial parameter gradients, summed inside the Adam kernel
@@ -68,7 +68,7 @@ class Structure:
 class Group:
     """Device-resident data of one group of equal-length paths + every buffer its sub-steps need.  Buffers are allocated
     once and refilled in place by Engine.load_group(..., into=G), so captured HIP graphs stay valid across resampling."""
-    SAMPLE_FIELDS = ('t', 'xT', 'xvT', 'xbT', 'start', 'ghT', 'h', 'f', 'w', 'wt', 'w0', 'gwx0T', 'start_b', 'g', 'X',
+    SAMPLE_FIELDS = ('t', 'tb', 'tpp', 'tpp0', 'xvT_pts', 'xT', 'xvT', 'xbT', 'start', 'ghT', 'h', 'f', 'w', 'wt', 'w0', 'gwx0T', 'start_b', 'g', 'X',
                      'A0', 'B0')
 
     def signature(self):
@@ -98,6 +98,9 @@ class Engine:
         # generator exchange buffer [sum of A slabs | sum of B slabs | scal]: ONE all-reduce per generator sub-step
         self.pack_u = z(2 * self.Pu + 16)
         self.scal = self.pack_u[2 * self.Pu:]
+        # gradient carried from the previous groups of the same sub-iteration (list domains: the reference calls zero_grad()
+        # once per sub-iteration but optimizer.step() after every group, src/training.py:127-138); None = off (one group)
+        self.accum_u = self.accum_v = None
         import os
         self.use_streams = os.environ.get('XW_STREAMS', '1') == '1'   # independent kernel chains on side streams
         self.use_graphs = os.environ.get('XW_GRAPHS', '1') == '1'     # capture each sub-step into a HIP graph and replay it
@@ -121,9 +124,16 @@ class Engine:
         if XV.shape[1] != L or XV.shape[0] != N:
             raise XnwanError('u- and v-samples of a group must have the same shape')
         S = {}
-        S['t'] = X[0, :, 0].to(dev).to(F32).contiguous()
-        S['xT'] = X[:, 0, 1:].to(dev).to(F32).t().contiguous()
-        S['xvT'] = XV[:, 0, 1:].to(dev).to(F32).t().contiguous()
+        S['t'] = X[0, :, 0].to(dev).to(F64).contiguous()
+        S['xT'] = X[:, 0, 1:].to(dev).to(F64).t().contiguous()
+        S['xvT'] = XV[:, 0, 1:].to(dev).to(F64).t().contiguous()
+        # the test network is pointwise on XV: when the paths of a group do not share one time column (late-entry groups
+        # of the hourglass: every path has its own entry time at l = 0) it runs in point mode on all L*N points
+        S['tpp'] = S['tpp0'] = S['xvT_pts'] = None
+        if not bool(torch.all(XV[:, :, 0] == XV[:1, :, 0])):
+            S['tpp'] = XV[:, :, 0].to(dev).to(F64).t().contiguous().reshape(-1)              # time-major: p = l*N + n
+            S['tpp0'] = XV[:, 0, 0].to(dev).to(F64).contiguous()
+            S['xvT_pts'] = S['xvT'].unsqueeze(1).expand(d, L, N).reshape(d, L * N).contiguous()
         # start values and their x-gradient (the h -> y0 path of nabla_x u, src/model.py:95)
         X0 = X[:, 0, :].clone().requires_grad_(True)
         starts_T0 = float(X[0, 0, 0]) == self.setup['T0']
@@ -147,15 +157,17 @@ class Engine:
             S['wt'] = _to_LN(gw[:, :, 0], dev)
         S['w0'] = w[:, 0].detach().to(dev).to(F64).contiguous()
         S['gwx0T'] = gw[:, 0, 1:].to(dev).to(F64).t().contiguous()
-        S['xbT'] = S['start_b'] = S['g'] = None
+        S['xbT'] = S['start_b'] = S['g'] = S['tb'] = None
+        Lb, same_grid = 0, True
         if BX is not None:
-            S['xbT'] = BX[:, 0, 1:].to(dev).to(F32).t().contiguous()
+            Lb = BX.shape[1]
+            S['tb'] = BX[0, :, 0].to(dev).to(F64).contiguous()
+            same_grid = Lb == L and bool(torch.equal(S['tb'], S['t']))
+            S['xbT'] = BX[:, 0, 1:].to(dev).to(F64).t().contiguous()
             b_T0 = float(BX[0, 0, 0]) == self.setup['T0']
             sb = self.funcs['h'](BX[:, 0, :]) if b_T0 else self.funcs['g'](BX[:, 0, :].unsqueeze(1)).reshape(-1)
             S['start_b'] = sb.detach().to(dev).to(F64).reshape(-1).contiguous()
             S['g'] = _to_LN(self.funcs['g'](BX), dev)
-            if not torch.equal(BX[0, :, 0].to(dev).to(F32), S['t']):
-                raise XnwanError('boundary and interior paths of a group share one time grid')
         st = self.structure
         S['X'] = X.to(dev) if st.c_kappa is None else None      # only read by a general reaction callable c(u, t, x)
         S['A0'] = S['B0'] = None
@@ -171,7 +183,7 @@ class Engine:
         nbglob = float(nb_glob if nb_glob is not None else max(Nb, 1))
         if into is not None:
             G = into
-            same = (G.N, G.L, G.Nb, G.Vol, G.Nglob, G.Nbglob) == (N, L, Nb, vol, nglob, nbglob) and all(
+            same = (G.N, G.L, G.Nb, G.Lb, G.same_grid, G.Vol, G.Nglob, G.Nbglob) == (N, L, Nb, Lb, same_grid, vol, nglob, nbglob) and all(
                 (getattr(G, k) is None) == (S[k] is None) and (S[k] is None or getattr(G, k).shape == S[k].shape)
                 for k in Group.SAMPLE_FIELDS)
             if same:
@@ -184,6 +196,7 @@ class Engine:
         for k in Group.SAMPLE_FIELDS:
             setattr(G, k, S[k])
         G.domain, G.N, G.L, G.Nb, G.Vol, G.Nglob, G.Nbglob = domain, N, L, Nb, vol, nglob, nbglob
+        G.Lb, G.same_grid = Lb, same_grid
         # work buffers
         e = lambda *s_: torch.empty(*s_, dtype=F64, device=dev)  # noqa: E731
         H = self.H
@@ -197,7 +210,7 @@ class Engine:
         G.slabB = e(G.ns_u, self.Pu)                   # sweep with cotangent B = dI/du
         G.slab_v = e(KN.disc_bwd_slabs(N, L), self.Pv)
         if Nb:
-            G.ub, G.Yb, G.ubar_b = e(L, Nb), e(L, H, Nb), e(L, Nb)
+            G.ub, G.Yb, G.ubar_b = e(Lb, Nb), e(Lb, H, Nb), e(Lb, Nb)
         G.graphs = {}
         return G
 
@@ -230,14 +243,23 @@ class Engine:
     def _test_net(self, G, e0):
         """test network on side streams 0 (v, dv/dt at all points) and 4 (nabla_x v at t_0); returns (e_v, e_g)"""
         ph = self.phi.data
+
+        def gradx():
+            KN.disc_gradx(G.xvT, G.t, ph, self.W, self.q, tpp=G.tpp0, gxv=G.gxv, gtv=G.gtv)
+
+        def fwd():
+            if G.tpp is None:
+                KN.disc_fwd(G.xvT, G.t, ph, self.W, self.q, v=G.v, vt=G.vt)
+            else:
+                KN.disc_fwd(G.xvT_pts, None, ph, self.W, self.q, tpp=G.tpp, v=G.v.view(1, -1), vt=G.vt.view(1, -1))
         if self.par_gradx:
             with self._side(4, e0):
-                KN.disc_gradx(G.xvT, G.t, ph, self.W, self.q, gxv=G.gxv, gtv=G.gtv)
+                gradx()
                 e_g = self._mark()
         with self._side(0, e0):
-            KN.disc_fwd(G.xvT, G.t, ph, self.W, self.q, v=G.v, vt=G.vt)
+            fwd()
             if not self.par_gradx:
-                KN.disc_gradx(G.xvT, G.t, ph, self.W, self.q, gxv=G.gxv, gtv=G.gtv)
+                gradx()
             e_v = self._mark()
         if not self.par_gradx:
             e_g = e_v
@@ -293,8 +315,10 @@ class Engine:
         self.scal.zero_()
         e0 = self._mark()
         e_v, e_g = self._test_net(G, e0)
-        fwd = [self._job(G, 'i')] + ([self._job(G, 'b')] if G.Nb else [])
-        KN.ode_fwd_multi(fwd, G.t, th, *M)
+        joint = G.Nb and G.same_grid           # boundary paths on the interior's time grid: one launch for both
+        KN.ode_fwd_multi([self._job(G, 'i')] + ([self._job(G, 'b')] if joint else []), G.t, th, *M)
+        if G.Nb and not joint:
+            KN.ode_fwd_multi([self._job(G, 'b')], G.tb, th, *M)
         self._reaction(G)
         e_f = self._mark()
         if G.Nb:
@@ -314,24 +338,41 @@ class Engine:
         KN.gen_cotangents(G.u, None, G.w, G.h, G.Vol, G.Nglob, self.alpha, G.ubarA, None, c=G.c, cp=G.cp, ckappa=G.ck,
                           pollution=self.pollution)
         sweeps = [self._job(G, 'i', G.ubarA, G.slabA[:G.ns_u])]
-        if G.Nb:
+        if joint:
             sweeps.append(self._job(G, 'b', G.ubar_b, G.slabA[G.ns_u:]))
         KN.ode_bwd_multi(sweeps, G.t, th, *M, want_x=False, want_params=True)
+        if G.Nb and not joint:
+            KN.ode_bwd_multi([self._job(G, 'b', G.ubar_b, G.slabA[G.ns_u:])], G.tb, th, *M, want_x=False, want_params=True)
         self._join(e_x, e_v, e_g)
         if not self.side_contract:
             self._contract(G)
         self._join(e_B)
 
+    def begin_substep(self, which, accumulate):
+        """start of a generator ('u') / discriminator ('v') sub-iteration over several groups: zero the carried gradient"""
+        name, P = ('accum_u', self.Pu) if which == 'u' else ('accum_v', self.Pv)
+        if not accumulate:
+            setattr(self, name, None)
+        elif getattr(self, name) is None:
+            setattr(self, name, torch.zeros(P, dtype=F64, device=self.dev))
+        else:
+            getattr(self, name).zero_()
+
     def _gen_back(self, G):
         lr, st = self.config['u_rate'], self.adam_u
+        acc = self.accum_u
         if self.world is None:
             KN.adam(self.theta.data, G.slabA, st['m'], st['v'], st['step'], lr, gslabB=G.slabB, scal=self.scal,
-                    gsum_out=self.grad_u, bump_step=False)
+                    gextraA=acc, gsum_out=self.grad_u, bump_step=False)
         else:
             P = self.Pu
+            if acc is not None:
+                self.pack_u[:P].add_(acc)
             KN.adam(self.theta.data, None, st['m'], st['v'], st['step'], lr, gextraA=self.pack_u[:P],
                     gextraB=self.pack_u[P:2 * P], scal=self.scal, gsum_out=self.grad_u, bump_step=False)
-        KN.losses(self.scal, G.L, G.Vol, G.Nglob, G.Nbglob, self.alpha, step=st['step'])
+        if acc is not None:
+            acc.copy_(self.grad_u)
+        KN.losses(self.scal, G.L, G.Lb, G.Vol, G.Nglob, G.Nbglob, self.alpha, step=st['step'])
 
     def generator_step(self, G):
         """one pass of the generator sub-step body; loss_u is left in scal[4] (device)"""
@@ -361,15 +402,24 @@ class Engine:
     def _disc_mid(self, G):
         KN.disc_cotangent(G.u, G.v, G.w, G.f, G.h, G.Vol, G.Nglob, self.scal, G.vbar, c=G.c, ckappa=G.ck,
                           pollution=self.pollution)
-        KN.disc_bwd(G.xvT, G.t, self.phi.data, G.vbar, self.W, self.q, gslab=G.slab_v)
+        if G.tpp is None:
+            KN.disc_bwd(G.xvT, G.t, self.phi.data, G.vbar, self.W, self.q, gslab=G.slab_v)
+        else:
+            KN.disc_bwd(G.xvT_pts, None, self.phi.data, G.vbar.view(1, -1), self.W, self.q, tpp=G.tpp, gslab=G.slab_v)
 
     def _disc_back(self, G):
         lr, st = self.config['v_rate'], self.adam_v
+        acc = self.accum_v
         if self.world is None:
-            KN.adam(self.phi.data, G.slab_v, st['m'], st['v'], st['step'], lr, gsum_out=self.grad_v, bump_step=False)
+            KN.adam(self.phi.data, G.slab_v, st['m'], st['v'], st['step'], lr, gextraA=acc, gsum_out=self.grad_v,
+                    bump_step=False)
         else:
+            if acc is not None:
+                self.grad_v.add_(acc)
             KN.adam(self.phi.data, None, st['m'], st['v'], st['step'], lr, gextraA=self.grad_v, bump_step=False)
-        KN.losses(self.scal, G.L, G.Vol, G.Nglob, G.Nbglob, self.alpha, step=st['step'])
+        if acc is not None:
+            acc.copy_(self.grad_v)
+        KN.losses(self.scal, G.L, G.Lb, G.Vol, G.Nglob, G.Nbglob, self.alpha, step=st['step'])
 
     def _disc_all(self, G):
         self._disc_front(G)
@@ -391,7 +441,8 @@ class Engine:
     # ------------------------------------------------------------------------------------------------------------
     def _run(self, G, key, fn):
         """execute fn(G) eagerly, or capture it once into a HIP graph (per group and segment) and replay it"""
-        capturable = self.use_graphs and self.structure.c_kappa is not None
+        capturable = (self.use_graphs and self.structure.c_kappa is not None and self.accum_u is None
+                      and self.accum_v is None and getattr(G, 'persistent', True))
         if not capturable:
             fn(G)
             return
@@ -420,7 +471,7 @@ class Engine:
         Xd = X.detach()
         starts_T0 = float(Xd[0, 0, 0]) == self.setup['T0']
         s = self.funcs['h'](Xd[:, 0, :]) if starts_T0 else self.funcs['g'](Xd[:, 0, :].unsqueeze(1)).reshape(-1)
-        u, _ = KN.ode_fwd(Xd[:, 0, 1:].to(self.dev).to(F32).t().contiguous(), Xd[0, :, 0].to(self.dev).to(F32).contiguous(),
+        u, _ = KN.ode_fwd(Xd[:, 0, 1:].to(self.dev).to(F64).t().contiguous(), Xd[0, :, 0].to(self.dev).to(F64).contiguous(),
                           s.detach().to(self.dev).to(F64).reshape(-1).contiguous(), self.theta.data, self.method,
                           self.H, self.K, self.m, want_Y=False)
         return u

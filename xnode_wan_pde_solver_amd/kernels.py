@@ -1,7 +1,7 @@
 """Tensor-level wrappers around the C ABI: every operand is validated on the host (device, dtype, contiguity,
 shape) BEFORE a kernel is enqueued, then passed as a raw device pointer together with torch's current stream.
 
-Conventions (include/xnwan.h): point arrays are time-major [L, N]; coordinates are transposed xT[d, N] float32.
+Conventions (include/xnwan.h): point arrays are time-major [L, N]; coordinates are transposed xT[d, N]; all float64.
 """
 import torch
 
@@ -56,7 +56,7 @@ def ode_fwd(xT, t, start, theta, method, H, K, m, want_Y=True, u=None, Y=None):
     _need_gpu()
     d, N = xT.shape
     L = t.shape[0]
-    _chk(xT, F32, (d, N), 'xT'); _chk(t, F32, (L,), 't'); _chk(start, F64, (N,), 'start')
+    _chk(xT, F64, (d, N), 'xT'); _chk(t, F64, (L,), 't'); _chk(start, F64, (N,), 'start')
     _chk(theta, F64, (theta_size(d, H, K),), 'theta')
     if u is None:
         u = torch.empty(L, N, dtype=F64, device=xT.device)
@@ -72,11 +72,11 @@ def ode_fwd_multi(jobs, t, theta, method, H, K, m):
     _need_gpu()
     L = t.shape[0]
     d = jobs[0]['xT'].shape[0]
-    _chk(t, F32, (L,), 't'); _chk(theta, F64, (theta_size(d, H, K),), 'theta')
+    _chk(t, F64, (L,), 't'); _chk(theta, F64, (theta_size(d, H, K),), 'theta')
     arr = (XwOdeFwdJob * len(jobs))()
     for a, j in zip(arr, jobs):
         N = j['xT'].shape[1]
-        _chk(j['xT'], F32, (d, N), 'xT'); _chk(j['start'], F64, (N,), 'start'); _chk(j['u'], F64, (L, N), 'u')
+        _chk(j['xT'], F64, (d, N), 'xT'); _chk(j['start'], F64, (N,), 'start'); _chk(j['u'], F64, (L, N), 'u')
         _chk(j.get('Y'), F64, (L, H, N), 'Y')
         a.xT, a.start, a.u, a.Y, a.N = _p(j['xT']), _p(j['start']), _p(j['u']), _p(j.get('Y')), N
     check(lib.xw_ode_fwd_multi(arr, len(jobs), _p(t), _p(theta), method, L, d, H, K, m, _stream()), 'xw_ode_fwd_multi')
@@ -88,11 +88,11 @@ def ode_bwd_multi(jobs, t, theta, method, H, K, m, want_x, want_params):
     L = t.shape[0]
     d = jobs[0]['xT'].shape[0]
     P = theta_size(d, H, K)
-    _chk(t, F32, (L,), 't'); _chk(theta, F64, (P,), 'theta')
+    _chk(t, F64, (L,), 't'); _chk(theta, F64, (P,), 'theta')
     arr = (XwOdeBwdJob * len(jobs))()
     for a, j in zip(arr, jobs):
         N = j['xT'].shape[1]
-        _chk(j['xT'], F32, (d, N), 'xT'); _chk(j['start'], F64, (N,), 'start'); _chk(j['Y'], F64, (L, H, N), 'Y')
+        _chk(j['xT'], F64, (d, N), 'xT'); _chk(j['start'], F64, (N,), 'start'); _chk(j['Y'], F64, (L, H, N), 'Y')
         _chk(j.get('ubar'), F64, (L, N), 'ubar')
         if want_x:
             _chk(j['gx'], F64, (d, N), 'gx'); _chk(j['gs'], F64, (N,), 'gs')
@@ -114,7 +114,7 @@ def ode_bwd(xT, t, start, theta, Y, ubar, method, H, K, m, want_x=True, want_par
     d, N = xT.shape
     L = t.shape[0]
     P = theta_size(d, H, K)
-    _chk(xT, F32, (d, N), 'xT'); _chk(t, F32, (L,), 't'); _chk(start, F64, (N,), 'start'); _chk(theta, F64, (P,), 'theta')
+    _chk(xT, F64, (d, N), 'xT'); _chk(t, F64, (L,), 't'); _chk(start, F64, (N,), 'start'); _chk(theta, F64, (P,), 'theta')
     _chk(Y, F64, (L, H, N), 'Y'); _chk(ubar, F64, (L, N), 'ubar')
     mode = (1 if want_x else 0) | (2 if want_params else 0)
     if want_x:
@@ -136,8 +136,8 @@ def disc_fwd(xT, t, phi, W, q, tpp=None, want_vt=True, v=None, vt=None):
     _need_gpu()
     d, N = xT.shape
     L = 1 if tpp is not None else t.shape[0]
-    _chk(xT, F32, (d, N), 'xT'); _chk(phi, F64, (phi_size(d, W),), 'phi')
-    _chk(t, F32, None, 't'); _chk(tpp, F32, (N,), 'tpp')
+    _chk(xT, F64, (d, N), 'xT'); _chk(phi, F64, (phi_size(d, W),), 'phi')
+    _chk(t, F64, None, 't'); _chk(tpp, F64, (N,), 'tpp')
     v = torch.empty(L, N, dtype=F64, device=xT.device) if v is None else v
     if want_vt and vt is None:
         vt = torch.empty(L, N, dtype=F64, device=xT.device)
@@ -151,7 +151,7 @@ def disc_gradx(xT, t, phi, W, q, tpp=None, vbar=None, gxv=None, gtv=None):
     """input gradient of <vbar, v>: (nabla_x)[d,N] and (d/dt)[N] at the points (tpp[n] or t[0], x_n); vbar None = ones."""
     _need_gpu()
     d, N = xT.shape
-    _chk(xT, F32, (d, N), 'xT'); _chk(phi, F64, (phi_size(d, W),), 'phi'); _chk(t, F32, None, 't'); _chk(tpp, F32, (N,), 'tpp')
+    _chk(xT, F64, (d, N), 'xT'); _chk(phi, F64, (phi_size(d, W),), 'phi'); _chk(t, F64, None, 't'); _chk(tpp, F64, (N,), 'tpp')
     gxv = torch.empty(d, N, dtype=F64, device=xT.device) if gxv is None else gxv
     gtv = torch.empty(N, dtype=F64, device=xT.device) if gtv is None else gtv
     _chk(gxv, F64, (d, N), 'gxv'); _chk(gtv, F64, (N,), 'gtv')
@@ -172,8 +172,8 @@ def disc_bwd(xT, t, phi, vbar, W, q, tpp=None, gslab=None):
     d, N = xT.shape
     L = 1 if tpp is not None else t.shape[0]
     P = phi_size(d, W)
-    _chk(xT, F32, (d, N), 'xT'); _chk(phi, F64, (P,), 'phi'); _chk(vbar, F64, (L, N), 'vbar')
-    _chk(t, F32, None, 't'); _chk(tpp, F32, (N,), 'tpp')
+    _chk(xT, F64, (d, N), 'xT'); _chk(phi, F64, (P,), 'phi'); _chk(vbar, F64, (L, N), 'vbar')
+    _chk(t, F64, None, 't'); _chk(tpp, F64, (N,), 'tpp')
     ns = disc_bwd_slabs(N, L)
     gslab = torch.empty(ns, P, dtype=F64, device=xT.device) if gslab is None else gslab
     _chk(gslab, F64, (ns, P), 'gslab')
@@ -238,11 +238,12 @@ def disc_cotangent(u, v, w, f, h, Vol, Nglob, scal, vbar, c=None, ckappa=0.0, po
                                 float(Nglob), float(pollution), _p(scal), _p(vbar), _stream()), 'xw_disc_cotangent')
 
 
-def losses(scal, L, Vol, Nglob, Nbglob, alpha, step=None):
+def losses(scal, L, Lb, Vol, Nglob, Nbglob, alpha, step=None):
     """loss values from the partial sums; also increments `step` when given (pair with adam(..., bump_step=False))"""
     _need_gpu()
     _chk(scal, F64, (16,), 'scal'); _chk(step, torch.int64, (1,), 'step')
-    check(lib.xw_losses(_p(scal), L, float(Vol), float(Nglob), float(Nbglob), float(alpha), _p(step), _stream()), 'xw_losses')
+    check(lib.xw_losses(_p(scal), L, max(int(Lb), 1), float(Vol), float(Nglob), float(Nbglob), float(alpha), _p(step), _stream()),
+          'xw_losses')
 
 
 def adam(param, gslabA, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, gextraA=None, gslabB=None, gextraB=None,

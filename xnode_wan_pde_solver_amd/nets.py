@@ -72,8 +72,8 @@ class Blob:
 class _OdeFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, X, start, net, *params):
-        xT = X[:, 0, 1:].detach().to(torch.float32).t().contiguous()
-        t = X[0, :, 0].detach().to(torch.float32).contiguous()
+        xT = X[:, 0, 1:].detach().to(F64).t().contiguous()
+        t = X[0, :, 0].detach().to(F64).contiguous()
         s = start.detach().to(F64).reshape(-1).contiguous()
         blob = net.blob
         blob.check_alias()
@@ -108,8 +108,8 @@ class _DiscFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, XV, net, *params):
         pts = XV.detach().reshape(-1, XV.shape[-1])
-        xT = pts[:, 1:].to(torch.float32).t().contiguous()
-        tpp = pts[:, 0].to(torch.float32).contiguous()
+        xT = pts[:, 1:].to(F64).t().contiguous()
+        tpp = pts[:, 0].to(F64).contiguous()
         net.blob.check_alias()
         v, _ = KN.disc_fwd(xT, None, net.blob.data, net.hidden_dim, net.num_layers, tpp=tpp, want_vt=False)
         ctx.net, ctx.shape, ctx.dtype = net, XV.shape, XV.dtype

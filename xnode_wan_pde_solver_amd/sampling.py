@@ -2,9 +2,11 @@
 exact RNG consumption (so that a seeded run draws the same points; pinned by tests/golden).
 
 Mirrors (file:line into the reference):
-    Hypercube      src/dataset.py:232-290
-    Comb_loader    src/dataset.py:293-322
-    fillt          src/dataset.py:13-32
+    Hypercube            src/dataset.py:232-290
+    NSphere_TCone        src/dataset.py:162-229     ball of radius r (1 - t): paths leave the domain, groups by life time
+    NSphere_THourglass   src/dataset.py:48-159      ball of radius r (1 - t) then r t: paths may leave and re-enter
+    Comb_loader          src/dataset.py:293-322
+    fillt                src/dataset.py:13-32
 Domain protocol (src/dataset.py:34-45): interior(N_r), boundary(N_b), func_w(x), bound_pad(x), V().
 Data layout: [N, L, 1+d], time in channel 0; on the cube every path is one spatial point repeated over the shared,
 sorted random time grid.
@@ -12,6 +14,10 @@ sorted random time grid.
 Sampling stays on the host RNG (torch CPU generator) -- it is O(N d) work per outer iteration and must be
 draw-for-draw identical to the reference for "same seeds" parity; the engine uploads only what the kernels need.
 """
+import math
+from itertools import groupby
+
+import numpy as np
 import torch
 from torch.utils.data import Dataset
 
@@ -95,6 +101,139 @@ class Hypercube:
     time_independent = True
 
 
+def _ball_volume_factor(dim, r):
+    from scipy.special import gamma
+    return math.pi ** (dim / 2) / gamma(dim / 2 + 1) * r ** dim
+
+
+class _NSphereBase:
+    """Shared pieces of the two time-varying ball domains.  Spatial points come from numpy's GLOBAL generator (like the
+    reference: seed with np.random.seed), the time grid from torch's.  Paths are float64; a group is a tensor
+    [n, L_k, 1+d] of paths with the same number of samples; boundary groups hold one time each, [n_t, 1, 1+d]."""
+    time_independent = False
+
+    def __init__(self, r, dim, T0, T, N_t):
+        self.r, self.dim, self.T0, self.T, self.N_t = r, dim, T0, T, N_t
+        self.times = _time_grid(T0, T, N_t)
+
+    def surf(self, N):
+        """N points uniform on the sphere of radius r, as a [dim, N] array"""
+        z = np.random.normal(size=(self.dim, N))
+        return self.r * z / np.sqrt((z ** 2).sum(axis=0))
+
+    def _ball(self, N):
+        pts = self.surf(N)
+        pts *= np.random.rand(N) ** (1 / self.dim)
+        return pts
+
+    def _shell_groups(self, N_b, radius_factor):
+        """one boundary group per sample time: int(N_b * factor(t)^dim) points on the sphere of radius factor(t)
+        (the reference scales the unit-r surface by factor(t) only, src/dataset.py:103,196)"""
+        out = []
+        for t in self.times.numpy():
+            fac = radius_factor(t)
+            n = int(N_b * fac ** self.dim)
+            pts = torch.from_numpy(self.surf(n) * fac).t().unsqueeze(1)
+            if n != 0:
+                out.append(torch.cat((t * torch.ones(n, 1, 1), pts), 2).requires_grad_(True))
+        return out
+
+
+class NSphere_TCone(_NSphereBase):
+    """{ |x| < r (1 - t) }: the ball shrinks linearly to a point at t = 1."""
+
+    def interior(self, N_r):
+        pts = self._ball(N_r)
+        tcol = self.times.repeat(N_r, 1).unsqueeze(2)
+        groups, k = [], self.N_t
+        for t in self.times.numpy()[::-1]:
+            # walking back from T: a point first found inside at this time lives for the k samples t_0 .. t_{k-1}
+            alive = np.sqrt(np.sum(pts ** 2, 0)) < self.r * (1 - t)
+            chosen = torch.from_numpy(pts[:, alive]).t().unsqueeze(1).repeat(1, k, 1)
+            pts = np.delete(pts, alive, 1)
+            if chosen.shape[0] != 0:
+                groups.append(torch.cat((tcol[:chosen.shape[0], :k], chosen), 2).requires_grad_(True))
+            k -= 1
+        return groups[::-1]
+
+    def boundary(self, N_b):
+        return self._shell_groups(N_b, lambda t: 1 - t)
+
+    def func_w(self, x):
+        return self.r * (1 - x[:, :, 0]) - torch.sqrt(torch.sum(x[:, :, 1:] ** 2, 2))
+
+    def bound_pad(self, x):
+        t = torch.cat((torch.tensor(self.T0).view(1), x[0, :, 0]), 0)
+        idx, data = fillt(t, self.T, self.T0, self.N_t)
+        return None, idx[1:], data
+
+    def V(self):
+        d1 = self.dim + 1
+        return _ball_volume_factor(self.dim, self.r) * ((1 - self.T0) ** d1 / d1 - (1 - self.T) ** d1 / d1)
+
+
+class NSphere_THourglass(_NSphereBase):
+    """{ |x| < r ((T - T0) - t) } for t <= (T - T0)/2, { |x| < r t } after: paths can leave the domain and re-enter; a
+    re-entering piece is prepended its entry point on the moving boundary (time |x| / r)."""
+
+    def _half(self):
+        return (self.T - self.T0) / 2
+
+    def _entry_padded(self, piece):
+        x0 = piece[0, 1:]
+        t_in = (torch.sqrt(torch.sum(x0 ** 2, 0)) / self.r).view(1, 1)
+        return torch.cat((torch.cat((t_in, x0.unsqueeze(0)), 1), piece), 0)
+
+    @staticmethod
+    def _by_length(pieces):
+        pieces = sorted((p.unsqueeze(0) for p in pieces), key=lambda p: p.shape[1])
+        return [torch.cat(tuple(grp), 0) for _, grp in groupby(pieces, key=lambda p: p.shape[1])]
+
+    def interior(self, N_r):
+        pts = self._ball(N_r)
+        L = self.N_t
+        tcol = self.times.repeat(N_r, 1).unsqueeze(2)
+        P = torch.from_numpy(pts).t().unsqueeze(1).repeat(1, L, 1)
+        early = torch.le(tcol, self._half())
+        bound = torch.zeros_like(P[:, :, 0]).unsqueeze(2)
+        bound[early] = self.r * ((self.T - self.T0) - tcol)[early].double()
+        bound[~early] = self.r * tcol[~early].double()
+        inside = (torch.sqrt(torch.sum(P ** 2, 2)).unsqueeze(2) < bound).squeeze()
+        paths = torch.cat((tcol, P), 2)
+        first, late = [], []
+        for k in range(N_r):
+            rows = paths[k, inside[k]]
+            gone = torch.nonzero(inside[k] == False)  # noqa: E712
+            if gone.shape[0] != 0:
+                a, b = rows.split([int(gone[0]), L - int(gone[-1]) - 1], dim=0)
+                first.append(a)
+                late.append(self._entry_padded(b))
+            else:
+                first.append(rows)
+        return sorted([*self._by_length(first), *self._by_length(late)], key=lambda g: g.shape[1])
+
+    def boundary(self, N_b):
+        span, half = self.T - self.T0, self._half()
+        return self._shell_groups(N_b, lambda t: (span - t) if t < half else t)
+
+    def func_w(self, x):
+        t = x[:, :, 0]
+        dist = torch.sqrt(torch.sum(x[:, :, 1:] ** 2, 2))
+        res = torch.ones_like(t)
+        early = torch.le(t, self._half())
+        res[early] = self.r * ((self.T - self.T0) - t[early]) - dist[early]
+        res[~early] = self.r * t[~early] - dist[~early]
+        return res
+
+    def bound_pad(self, x):
+        raise NotImplementedError('hourglass bound_pad (off-boundary evaluation, reference src/dataset.py:127-152) is '
+                                  'not built yet -- SURVEY.md section 8(f) row 3')
+
+    def V(self):
+        d1 = self.dim + 1
+        return _ball_volume_factor(self.dim, self.r) * 2 * ((1 - self.T0) ** d1 / d1 - (1 - self._half()) ** d1 / d1)
+
+
 class Comb_loader(Dataset):
     """Groups of equal-length paths: (interior for u, interior for v, boundary).  For a single-tensor domain (cube) the
     v sample is a second, independent interior draw; for list domains it is a copy of the u sample."""
@@ -126,7 +265,7 @@ class Comb_loader(Dataset):
         return tuple(g.to(self.device) for g in group)
 
 
-DOMAINS = {'Hypercube': Hypercube}
+DOMAINS = {'Hypercube': Hypercube, 'NSphere_TCone': NSphere_TCone, 'NSphere_THourglass': NSphere_THourglass}
 
 
 def resolve_domain(name):

@@ -181,8 +181,12 @@ class NODE_WAN_solver:
                 groups = [eng.load_group(du, dv, bd, domain, ng, nbg, into=old)
                           for (du, dv, bd, ng, nbg), old in zip(shards, self._group_cache)]
                 self._group_cache = groups
+                several = len(groups) > 1
+                for G in groups:
+                    G.persistent = not several        # list domains: group shapes change every sample -> no graph capture
                 for _ in range(self.n1):
                     self.av_l = 0
+                    eng.begin_substep('u', several)
                     for G in groups:
                         eng.generator_step(G)
                         self.last_loss_u = eng.loss_u().item()
@@ -203,6 +207,7 @@ class NODE_WAN_solver:
                             torch.save(self.u_net.state_dict(), 'best_model_weights_NODE.pth')
                         self.best_l = self.av_l
                 for _ in range(self.n2):
+                    eng.begin_substep('v', several)
                     for G in groups:
                         eng.discriminator_step(G)
                         self.last_loss_v = eng.loss_v().item()
