@@ -29,13 +29,11 @@ def _time_grid(T0, T, N_t):
 
 
 def _paths(times, x):
-    """[n, d] spatial points -> [n, L, 1+d] vertical paths over the time grid."""
+    """[n, d] spatial points -> [n, L, 1+d] vertical paths over the time grid (same device / dtype as x)."""
     n, d = x.shape
     L = times.shape[0]
-    out = torch.empty(n, L, d + 1)
-    out[:, :, 0] = times.view(1, L)
-    out[:, :, 1:] = x.view(n, 1, d)
-    return out
+    t = times.to(device=x.device, dtype=x.dtype)
+    return torch.cat((t.view(1, L, 1).expand(n, L, 1), x.view(n, 1, d).expand(n, L, d)), 2)
 
 
 def fillt(inputs, T, T0, min_steps=5):
@@ -69,10 +67,17 @@ class Hypercube:
     def _uniform_points(self, n):
         return torch.Tensor(n, 1, self.dim).uniform_(self.bot, self.top).view(n, self.dim)
 
+    def interior_x(self, N_r):
+        """the N_r spatial points of an interior sample, [N_r, d] (compact form of interior())"""
+        return self._uniform_points(N_r)
+
     def interior(self, N_r):
-        return _paths(self.times, self._uniform_points(N_r))
+        return _paths(self.times, self.interior_x(N_r))
 
     def boundary(self, N_b):
+        return _paths(self.times, self.boundary_x(N_b))
+
+    def boundary_x(self, N_b):
         x = self._uniform_points(N_b)
         self._uniform_points(N_b)          # the reference draws a second, unused batch here (src/dataset.py:263)
         block = int(N_b / self.dim / 2)    # rows per face; the last face takes the remainder
@@ -80,7 +85,21 @@ class Hypercube:
         for axis in range(self.dim):
             x[cuts[2 * axis]:cuts[2 * axis + 1], axis] = self.top
             x[cuts[2 * axis + 1]:cuts[2 * axis + 2], axis] = self.bot
-        return _paths(self.times, x[torch.randperm(N_b)])
+        return x[torch.randperm(N_b)]
+
+    def device_sample(self, N_r, N_b, device):
+        """(x_u, x_v, x_b) drawn with the DEVICE generator: same distribution as interior/interior/boundary, no seed
+        parity with the reference's host draws (NODE_WAN_solver.device_sampling)"""
+        span = self.top - self.bot
+        xu = torch.rand(N_r, self.dim, device=device) * span + self.bot
+        xv = torch.rand(N_r, self.dim, device=device) * span + self.bot
+        xb = torch.rand(N_b, self.dim, device=device) * span + self.bot
+        block = int(N_b / self.dim / 2)
+        cuts = [block * i for i in range(2 * self.dim)] + [N_b]
+        for axis in range(self.dim):
+            xb[cuts[2 * axis]:cuts[2 * axis + 1], axis] = self.top
+            xb[cuts[2 * axis + 1]:cuts[2 * axis + 2], axis] = self.bot
+        return xu, xv, xb[torch.randperm(N_b, device=device)]
 
     def func_w(self, x):
         """distance to the nearest face: min_i min(|top - x_i|, |bot - x_i|); x is [N, L, 1+d]"""
@@ -236,19 +255,42 @@ class NSphere_THourglass(_NSphereBase):
 
 class Comb_loader(Dataset):
     """Groups of equal-length paths: (interior for u, interior for v, boundary).  For a single-tensor domain (cube) the
-    v sample is a second, independent interior draw; for list domains it is a copy of the u sample."""
+    v sample is a second, independent interior draw; for list domains it is a copy of the u sample.
+
+    For domains that offer compact draws (`interior_x` / `boundary_x`: vertical paths over one shared grid) only the
+    [N, d] points are drawn here -- same RNG consumption -- and the [N, L, 1+d] tensors `interioru`, `interiorv`,
+    `boundary` are materialised on first access; the engine works from the compact form (`compact()`)."""
 
     def __init__(self, N_r, N_b, shape, device):
         self.N_r, self.N_b, self.shape, self.device = N_r, N_b, shape, device
+        self._lazy, self._cache = None, {}
+        if hasattr(shape, 'interior_x') and hasattr(shape, 'boundary_x'):
+            self._lazy = {'interioru': shape.interior_x(N_r), 'interiorv': shape.interior_x(N_r), 'boundary': shape.boundary_x(N_b)}
+            return
         inner = shape.interior(N_r)
         if isinstance(inner, list):
-            self.interioru = [g.requires_grad_(True) for g in inner]
-            self.interiorv = [g.clone().detach().requires_grad_(True) for g in self.interioru]
+            self._cache['interioru'] = [g.requires_grad_(True) for g in inner]
+            self._cache['interiorv'] = [g.clone().detach().requires_grad_(True) for g in self._cache['interioru']]
         else:
-            self.interioru = inner.requires_grad_(True)
-            self.interiorv = shape.interior(N_r).clone().detach().requires_grad_(True)
+            self._cache['interioru'] = inner.requires_grad_(True)
+            self._cache['interiorv'] = shape.interior(N_r).clone().detach().requires_grad_(True)
         edge = shape.boundary(N_b)
-        self.boundary = [g.requires_grad_(True) for g in edge] if isinstance(edge, list) else edge.requires_grad_(True)
+        self._cache['boundary'] = [g.requires_grad_(True) for g in edge] if isinstance(edge, list) else edge.requires_grad_(True)
+
+    def _get(self, name):
+        if name not in self._cache:
+            self._cache[name] = _paths(self.shape.times, self._lazy[name]).requires_grad_(True)
+        return self._cache[name]
+
+    interioru = property(lambda self: self._get('interioru'))
+    interiorv = property(lambda self: self._get('interiorv'))
+    boundary = property(lambda self: self._get('boundary'))
+
+    def compact(self):
+        """(times[L], x_u[N,d], x_v[N,d], x_b[N_b,d]) or None when the domain has no compact form"""
+        if self._lazy is None:
+            return None
+        return self.shape.times, self._lazy['interioru'], self._lazy['interiorv'], self._lazy['boundary']
 
     def __len__(self):
         return len(self.interioru) if isinstance(self.interioru, list) else 1
@@ -263,6 +305,35 @@ class Comb_loader(Dataset):
                 raise IndexError
             group = (self.interioru, self.interiorv, self.boundary)
         return tuple(g.to(self.device) for g in group)
+
+
+class DeviceCubeLoader:
+    """Comb_loader's attributes for a sample drawn on the device (Hypercube.device_sample); no host tensors at all."""
+
+    def __init__(self, N_r, N_b, shape, device):
+        self.N_r, self.N_b, self.shape, self.device = N_r, N_b, shape, device
+        self._x = shape.device_sample(N_r, N_b, device)
+        self._cache = {}
+
+    def _get(self, i, name):
+        if name not in self._cache:
+            self._cache[name] = _paths(self.shape.times, self._x[i]).requires_grad_(True)
+        return self._cache[name]
+
+    interioru = property(lambda self: self._get(0, 'interioru'))
+    interiorv = property(lambda self: self._get(1, 'interiorv'))
+    boundary = property(lambda self: self._get(2, 'boundary'))
+
+    def compact(self):
+        return (self.shape.times,) + tuple(self._x)
+
+    def __len__(self):
+        return 1
+
+    def __getitem__(self, idx):
+        if idx != 0:
+            raise IndexError
+        return self.interioru, self.interiorv, self.boundary
 
 
 DOMAINS = {'Hypercube': Hypercube, 'NSphere_TCone': NSphere_TCone, 'NSphere_THourglass': NSphere_THourglass}

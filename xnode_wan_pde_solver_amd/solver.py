@@ -112,7 +112,8 @@ class NODE_WAN_solver:
         self.path, self.stop, self.func_u_sol, self.p = path, stop, func_u_sol, p
         self.world = world
         self.exit_on_stop = True
-        self.tabulate_on_host = True
+        self.tabulate_on_host = True      # False: h, f, g, w are tabulated on the GPU from the compact sample (fast)
+        self.device_sampling = False      # True: draw the cube samples with the device RNG (no seed parity, fastest)
         self._group_cache = []
         self.config, self.setup, self.iterations = split_params(params)
         self.domain = sampling.resolve_domain(params['domain'])
@@ -143,10 +144,21 @@ class NODE_WAN_solver:
         s = self.setup
         return self.domain(s['shape_param'], s['dim'], s['T0'], s['T'], s['N_t'])
 
+    def _loader(self, domain):
+        if self.device_sampling and hasattr(domain, 'device_sample'):
+            return sampling.DeviceCubeLoader(self.setup['N_r'], self.setup['N_b'], domain, self.device)
+        return sampling.Comb_loader(self.setup['N_r'], self.setup['N_b'], domain, self.device)
+
     def _groups(self, points):
         """(u, v, boundary) groups of a loader.  `tabulate_on_host` (default True) hands the engine the loader's HOST
-        tensors, so that h, f, g, w are tabulated exactly like the reference's CPU path; False tabulates on the GPU."""
-        if not self.tabulate_on_host:
+        tensors, so that h, f, g, w are tabulated exactly like the reference's CPU path; False builds the path tensors
+        on the GPU from the compact sample and tabulates there."""
+        if not self.tabulate_on_host or self.device_sampling:
+            comp = points.compact() if hasattr(points, 'compact') else None
+            if comp is not None:
+                times, xu, xv, xb = comp
+                mk = lambda x: sampling._paths(times.to(self.device), x.to(self.device))  # noqa: E731
+                return [(mk(xu), mk(xv), mk(xb))]
             return list(points)
         if isinstance(points.interioru, list):
             n = min(len(points.interioru), len(points.boundary))      # same truncation as iterating the loader
@@ -159,11 +171,16 @@ class NODE_WAN_solver:
             return [(du, dv, bd, None, None) for (du, dv, bd) in points]
         return [self.world.shard_group(du, dv, bd) for (du, dv, bd) in points]
 
-    def _l_norm(self, interior, volume):
+    def _l_norm(self, points, volume):
         from utils.auxillary_funcs import L_norm
         if self.func_u_sol is None:
             return float('nan')
-        return L_norm(interior, self.u_net, self.p, self.func_u_sol, volume, self.setup['N_r']).item()
+        if not self.tabulate_on_host or self.device_sampling:
+            comp = points.compact() if hasattr(points, 'compact') else None
+            if comp is not None:          # diagnostic entirely on the device
+                X = sampling._paths(comp[0].to(self.device), comp[1].to(self.device))
+                return L_norm(X, self.u_net, self.p, self.func_u_sol, volume, self.setup['N_r']).item()
+        return L_norm(points.interioru, self.u_net, self.p, self.func_u_sol, volume, self.setup['N_r']).item()
 
     def train(self, report=False, report_it=10, show_plt=False):
         past_losses = []
@@ -173,8 +190,8 @@ class NODE_WAN_solver:
         with torch.cuda.device(self.device):
             for k in range(self.iterations):
                 domain = self._new_domain()
-                points = sampling.Comb_loader(self.setup['N_r'], self.setup['N_b'], domain, self.device)
-                L2 = self._l_norm(points.interioru, domain.V())
+                points = self._loader(domain)
+                L2 = self._l_norm(points, domain.V())
                 shards = self._shard(self._groups(points))
                 if len(self._group_cache) != len(shards):
                     self._group_cache = [None] * len(shards)
@@ -211,8 +228,8 @@ class NODE_WAN_solver:
                     for G in groups:
                         eng.discriminator_step(G)
                         self.last_loss_v = eng.loss_v().item()
-                points = sampling.Comb_loader(self.setup['N_r'], self.setup['N_b'], domain, self.device)
-                L2 = self._l_norm(points.interioru, domain.V())
+                points = self._loader(domain)
+                L2 = self._l_norm(points, domain.V())
                 times.append(time.time())
                 if self._is_main():
                     with open('L2_NODE_' + str(d) + '.json', 'w') as fh:
