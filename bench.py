@@ -202,6 +202,7 @@ def main():
         hold = S2.domain(s['shape_param'], s['dim'], s['T0'], s['T'], s['N_t'])
         Xh = hold.interior(16384)
         extras['train'] = {'outer_iterations': args.train_iters, 'wall_s': round(time.time() - tt0, 2),
+                           'ms_per_outer_iteration_incl_resampling_diagnostics_io': round(1e3 * (time.time() - tt0) / args.train_iters, 2),
                            'rel_l2_heldout_16384': float(rel_err(Xh, S2.u_net, P.func_u_sol, 2, hold.V(), 16384))}
 
     # ---- CPU baseline: the oracle (port of the reference's CPU/PyTorch path), bounded sample ---------------------------

@@ -219,6 +219,7 @@ def test_trained_error_trajectory_matches_reference(golden_dir, tmp_path):
         log.append(float(rel_err(pts, self.u_net, self.func_u_sol, self.p, domain.V(), self.params['N_r'])))
         return False
     S = make_solver(params, int(z['seed']), stop=hook)
+    S.tabulate_on_host = True          # tabulate h, f, g like the reference's CPU run (tight early-step comparison)
     cwd = os.getcwd()
     os.chdir(tmp_path)
     try:

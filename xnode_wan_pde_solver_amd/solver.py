@@ -112,7 +112,9 @@ class NODE_WAN_solver:
         self.path, self.stop, self.func_u_sol, self.p = path, stop, func_u_sol, p
         self.world = world
         self.exit_on_stop = True
-        self.tabulate_on_host = True      # False: h, f, g, w are tabulated on the GPU from the compact sample (fast)
+        self.tabulate_on_host = False     # False: h, f, g, w are tabulated on the GPU from the compact sample (fast; the
+                                          # sample itself is still drawn with the host RNG, draw-for-draw like the reference);
+                                          # True: tabulate on the host exactly like the reference's CPU path (bitwise h, f, g)
         self.device_sampling = False      # True: draw the cube samples with the device RNG (no seed parity, fastest)
         self._group_cache = []
         self.config, self.setup, self.iterations = split_params(params)
@@ -150,8 +152,8 @@ class NODE_WAN_solver:
         return sampling.Comb_loader(self.setup['N_r'], self.setup['N_b'], domain, self.device)
 
     def _groups(self, points):
-        """(u, v, boundary) groups of a loader.  `tabulate_on_host` (default True) hands the engine the loader's HOST
-        tensors, so that h, f, g, w are tabulated exactly like the reference's CPU path; False builds the path tensors
+        """(u, v, boundary) groups of a loader.  `tabulate_on_host=True` hands the engine the loader's HOST
+        tensors, so that h, f, g, w are tabulated exactly like the reference's CPU path; False (default) builds the path tensors
         on the GPU from the compact sample and tabulates there."""
         if not self.tabulate_on_host or self.device_sampling:
             comp = points.compact() if hasattr(points, 'compact') else None
