@@ -182,9 +182,23 @@ def main():
              'achieved_tflops': round(step_flops * steps_per_s / 1e12, 3),
              'frac_fp64_matrix_peak': round(step_flops * steps_per_s / 1e12 / PEAK_FP64_MATRIX_TFLOPS, 4)}
 
+    # ---- opt-in exact optimisation, reported separately: reuse v, dv/dt, nabla_x v(t_0) while phi is unchanged ----------
+    if world is None:
+        eng.reuse_test_net = True
+        run(6)
+        torch.cuda.synchronize()
+        r0 = time.perf_counter()
+        run(args.steps)
+        torch.cuda.synchronize()
+        reuse_rate = args.steps / (time.perf_counter() - r0)
+        eng.reuse_test_net = False
+    else:
+        reuse_rate = None
+
     # ---- real training (resampling every outer iteration) for the rel-L2 figure ----------------------------------------
     extras = {'sample_and_tabulate_s': round(t_sample, 4), 'finite': finite, 'structure': eng.structure.describe(),
               'hip_graphs': graphs_on, 'side_streams': streams_on,
+              'steps_per_s_with_test_net_reuse_optin': None if reuse_rate is None else round(reuse_rate, 1),
               'serial_kernel_ms_per_step': round(sum(v['ms_per_step'] for v in kern.values()), 4)}
     if args.train_iters > 0 and world is None:
         torch.manual_seed(0)

@@ -300,3 +300,21 @@ def test_sphere_domain_trains_end_to_end(tmp_path):
     assert len(losses) == 6 and all(np.isfinite(losses))
     assert torch.isfinite(S.engine.theta.data).all() and torch.isfinite(S.engine.phi.data).all()
     assert int(S.engine.adam_u['step'].item()) > 6            # one optimiser step per group, not per sub-iteration
+
+
+def test_test_net_reuse_is_exact(golden_dir):
+    """opt-in reuse of v, dv/dt, nabla_x v(t_0) while phi and the sample are unchanged gives bit-identical parameters"""
+    z, params = load(golden_dir, 'ref_plumb_midpoint')
+    outs = []
+    for reuse in (False, True):
+        S = make_solver(params, 0)
+        domain, pts = first_sample(S)
+        S.engine.reuse_test_net = reuse
+        G = S.engine.load_group(pts.interioru, pts.interiorv, pts.boundary, domain)
+        for k in range(2):
+            S.engine.generator_step(G)
+            S.engine.generator_step(G)
+            S.engine.discriminator_step(G)
+            G = S.engine.load_group(pts.interiorv, pts.interioru, pts.boundary, domain, into=G)      # "resample" in place
+        outs.append((S.engine.theta.data.clone(), S.engine.phi.data.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
