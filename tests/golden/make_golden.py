@@ -319,6 +319,31 @@ def sphere_groups(case, domain_name, d, N_r, N_b, N_t, seed):
     print('wrote', path, '%.1f KB' % (os.path.getsize(path) / 1024), 'groups', len(points.interioru), 'pairs', pairs)
 
 
+def bound_pad_vectors():
+    """NeuralODE.forward on paths that start neither at T0 nor on the boundary (src/model.py:92-106 with
+    Hypercube.bound_pad / fillt): pins the evaluation path (proj plots with a fixed time use it)."""
+    training, dataset, lossmod, F = load_reference()
+    d = 3
+    params = make_params(d, 8, 12, 6, 'midpoint')
+    torch.manual_seed(7)
+    np.random.seed(7)
+    S = training.NODE_WAN_solver(params, F.func_a, F.func_b, F.func_c, F.func_h, F.func_f, F.func_g, torch.device('cpu'), './',
+                                 func_u_sol=F.func_u_sol, p=2)
+    g = torch.Generator().manual_seed(5)
+    out = {'params_json': np.array(json.dumps(params)), 'seed': np.array(7)}
+    k = 0
+    for times in ([0.3, 0.5, 0.9], [0.25, 0.26, 0.8, 1.0], [1.0, 1.0, 1.0]):
+        x = torch.rand(5, 1, d, generator=g) - 0.5
+        X = torch.cat((torch.tensor(times).view(1, -1, 1).repeat(5, 1, 1), x.repeat(1, len(times), 1)), 2)
+        with torch.no_grad():
+            u = S.u_net(X)
+        out['%d/X' % k], out['%d/u' % k] = npy(X), npy(u)
+        k += 1
+    out['n'] = np.array(k)
+    np.savez_compressed(os.path.join(HERE, 'ref_boundpad.npz'), **out)
+    print('wrote ref_boundpad.npz', k, 'cases', [tuple(out['%d/u' % i].shape) for i in range(k)])
+
+
 def fillt_vectors():
     """src/dataset.py:13-32 on a few hand-picked time vectors (the helper has surprising edge behaviour that the
     product reproduces verbatim: it can drop a sample and return indices past the filled vector)."""
@@ -344,6 +369,7 @@ if __name__ == '__main__':
     torch.set_num_threads(4)
     if not args.only_traj:
         fillt_vectors()
+        bound_pad_vectors()
         sphere_groups('ref_cone_groups', 'NSphere_TCone', 3, 64, 40, 8, 1)
         sphere_groups('ref_hourglass_groups', 'NSphere_THourglass', 3, 64, 40, 8, 1)
         one_iteration('ref_tiny_midpoint', 3, 8, 12, 6, 7, 'midpoint', True)

@@ -318,3 +318,15 @@ def test_test_net_reuse_is_exact(golden_dir):
             G = S.engine.load_group(pts.interiorv, pts.interioru, pts.boundary, domain, into=G)      # "resample" in place
         outs.append((S.engine.theta.data.clone(), S.engine.phi.data.clone()))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+def test_evaluation_off_the_boundary_matches_reference(golden_dir):
+    """u_net on paths that start neither at T0 nor on the boundary: bound_pad / fillt densified grid (src/model.py:92-106)"""
+    z, params = load(golden_dir, 'ref_boundpad')
+    S = make_solver(params, int(z['seed']))
+    for k in range(int(z['n'])):
+        X = torch.from_numpy(z['%d/X' % k])
+        with torch.no_grad():
+            u = S.u_net(X)
+        assert tuple(u.shape) == z['%d/u' % k].shape
+        close(u, z['%d/u' % k], F32TOL, F32TOL, 'case %d' % k)

@@ -190,11 +190,21 @@ class XNODE(nn.Module):
             raise XnwanError('XNODE.bind(device) has not been called')
         dev = self.blob.data.device
         starts_at_T0 = float(inputs[0, 0, 0].detach()) == self.setup['T0']
+        gather = None
         if not starts_at_T0:
             on_boundary = float(torch.max(self.domain.func_w(inputs[:, 0, :].detach().unsqueeze(1)))) < 1e-5
             if not on_boundary:
-                raise XnwanError('paths that start neither at T0 nor on the boundary need the bound_pad/fillt evaluation '
-                                 'path (SURVEY.md section 8(f) row 3), which is not built yet')
+                # evaluation of points that are neither at T0 nor on the boundary (src/model.py:92-106): integrate from T0
+                # over the densified grid of domain.bound_pad / fillt and keep the states at the requested times
+                path_i, gather, filled = self.domain.bound_pad(inputs.detach())
+                if path_i is not None:
+                    raise XnwanError('per-path padded grids (hourglass bound_pad) are not built yet')
+                grid = filled.to(inputs.device).to(inputs.dtype)
+                padded = inputs[:, :1, :].repeat(1, grid.shape[0], 1)
+                padded[:, :, 0] = grid.view(1, -1)
+                start = self.start_values(inputs)
+                out = _OdeFn.apply(padded.to(dev), start.to(dev), self, *self.blob.params)
+                return out[:, gather.long().to(dev), :]
         out = _OdeFn.apply(inputs.to(dev), self.start_values(inputs).to(dev), self, *self.blob.params)
         if inputs.shape[1] == 1 and starts_at_T0:
             return out[:, 0, :]                                   # reference returns [N, 1] here (src/model.py:89-91)
