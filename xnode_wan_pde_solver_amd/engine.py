@@ -110,6 +110,9 @@ class Engine:
         self.reuse_test_net = os.environ.get('XW_REUSE_V', '0') == '1'
         self._phi_version = 0
         self.side_contract = os.environ.get('XW_SIDE_CONTRACT', '0') == '1'   # measured slower (queue mapping)
+        # let the short, latency-critical u-forward finish before the chip-filling test-network forward starts
+        self.fwd_first_gen = os.environ.get('XW_FWD_FIRST_GEN', '0') == '1'
+        self.fwd_first_disc = os.environ.get('XW_FWD_FIRST_DISC', '0') == '1'
         self.streams = [torch.cuda.Stream(device=device) for _ in range(5)]
 
     # ------------------------------------------------------------------------------------------------------------
@@ -246,8 +249,9 @@ class Engine:
             for ev in events:
                 cur.wait_event(ev)
 
-    def _test_net(self, G, e0):
-        """test network on side streams 0 (v, dv/dt at all points) and 4 (nabla_x v at t_0); returns (e_v, e_g)"""
+    def _test_net(self, G, e0, e_fwd=None):
+        """test network on side streams 0 (v, dv/dt at all points) and 4 (nabla_x v at t_0); returns (e_v, e_g).
+        e_fwd: event the big forward additionally waits for (scheduling knob fwd_first_*)"""
         ph = self.phi.data
         if getattr(G, 'skip_v', False):          # reuse_test_net: v, dv/dt, nabla_x v(t_0) are still valid (see _v_fresh)
             return e0, e0
@@ -264,7 +268,7 @@ class Engine:
             with self._side(4, e0):
                 gradx()
                 e_g = self._mark()
-        with self._side(0, e0):
+        with self._side(0, e0, *([e_fwd] if e_fwd is not None else [])):
             fwd()
             if not self.par_gradx:
                 gradx()
@@ -322,13 +326,16 @@ class Engine:
         M = (self.method, self.H, self.K, self.m)
         self.scal.zero_()
         e0 = self._mark()
-        e_v, e_g = self._test_net(G, e0)
+        if not self.fwd_first_gen:
+            e_v, e_g = self._test_net(G, e0)
         joint = G.Nb and G.same_grid           # boundary paths on the interior's time grid: one launch for both
         KN.ode_fwd_multi([self._job(G, 'i')] + ([self._job(G, 'b')] if joint else []), G.t, th, *M)
         if G.Nb and not joint:
             KN.ode_fwd_multi([self._job(G, 'b')], G.tb, th, *M)
         self._reaction(G)
         e_f = self._mark()
+        if self.fwd_first_gen:
+            e_v, e_g = self._test_net(G, e0, e_f)
         if G.Nb:
             KN.bdry_partials(G.ub, G.g, self.alpha, G.Nbglob, self.scal, ubar_b=G.ubar_b)
             e_f = self._mark()
@@ -408,9 +415,12 @@ class Engine:
         M = (self.method, self.H, self.K, self.m)
         self.scal.zero_()
         e0 = self._mark()
-        e_v, e_g = self._test_net(G, e0)
+        if not self.fwd_first_disc:
+            e_v, e_g = self._test_net(G, e0)
         KN.ode_fwd_multi([self._job(G, 'i')], G.t, th, *M)
         self._reaction(G)
+        if self.fwd_first_disc:
+            e_v, e_g = self._test_net(G, e0, self._mark())
         KN.ode_bwd_multi([self._job(G, 'i', want_x=True)], G.t, th, *M, want_x=True, want_params=False)
         self._join(e_v, e_g)
         self._contract(G)
@@ -468,8 +478,17 @@ class Engine:
         if g is None:
             g = torch.cuda.CUDAGraph()
             torch.cuda.synchronize()
-            with torch.cuda.graph(g, stream=self._capture_stream()):
+            try:
+                # thread_local: other threads (the RCCL watchdog polls events) must not invalidate the capture
+                with torch.cuda.graph(g, stream=self._capture_stream(), capture_error_mode='thread_local'):
+                    fn(G)
+            except Exception as exc:  # capture refused by the runtime: run this and all later segments eagerly
+                import warnings
+                warnings.warn('HIP graph capture of %r failed (%s); falling back to eager launches' % (key, exc))
+                self.use_graphs = False
+                torch.cuda.synchronize()
                 fn(G)
+                return
             G.graphs[key] = g
         g.replay()
 
