@@ -70,10 +70,10 @@ int xw_ode_bwd_multi(const XwOdeBwdJob* jobs, int njobs, const double* t, const 
 
 /* ---- v_phi: discriminator.forward (src/model.py:37-47) + d/dt by forward-mode ------------------------------------
  * Path mode (tpp == NULL): point (l,n) = (t[l], x_n).  Point mode (tpp != NULL): L must be 1, point n = (tpp[n], x_n).
- * v[L,N] out; vt[L,N] out = dv/dt (may be NULL); act out (may be NULL) = activation stash [(q+1)][W][L*N]
- * needed by xw_disc_bwd (post-ReLU hidden activations r_0..r_{q-1}, then tanh output). */
+ * v[L,N] out; vt[L,N] out = dv/dt (may be NULL).  Nothing is stashed for the backward: xw_disc_bwd recomputes the
+ * forward of its 16-point tiles in registers (cheaper than an HBM round trip of the activations). */
 int xw_disc_fwd(const double* xT, const double* t, const double* tpp, const double* phi,
-                int N, int L, int d, int W, int q, double* v, double* vt, double* act, void* stream);
+                int N, int L, int d, int W, int q, double* v, double* vt, void* stream);
 
 /* input gradient of <vbar, v> at a set of points (reverse mode, no parameter gradients): gxv[d,N] (nabla_x) and
  * gtv[N] (d/dt), for the N points (t_n, x_n) with t_n = tpp ? tpp[n] : t[0]; vbar[N] or NULL (= ones).
@@ -82,9 +82,9 @@ int xw_disc_gradx(const double* xT, const double* t, const double* tpp, const do
                   int N, int d, int W, int q, double* gxv, double* gtv, void* stream);
 
 int xw_disc_bwd_slabs(int N, int L);
-/* parameter gradient of <vbar, v>: slabs gslab[xw_disc_bwd_slabs][P_v]; optional input gradient is not produced here */
-int xw_disc_bwd(const double* xT, const double* t, const double* tpp, const double* phi, const double* act,
-                const double* vbar, int N, int L, int d, int W, int q, double* gslab, void* stream);
+/* parameter gradient of <vbar, v>: slabs gslab[xw_disc_bwd_slabs][P_v] (input gradient: xw_disc_gradx) */
+int xw_disc_bwd(const double* xT, const double* t, const double* tpp, const double* phi, const double* vbar,
+                int N, int L, int d, int W, int q, double* gslab, void* stream);
 
 /* ---- weak functional and cotangents (src/loss.py:46-96) -----------------------------------------------------------
  * scal[16] (device, float64): 0 I   1 S=sum v^2   2 SSE_init   3 SSE_bdry   4 loss_u   5 loss_v   6 int   (rest reserved)

@@ -4,7 +4,7 @@ import re, subprocess, sys
 srcs = sys.argv[1:] or ['xw_ode.hip', 'xw_disc.hip', 'xw_weak.hip']
 for f in srcs:
     out = subprocess.run(['/opt/rocm/bin/hipcc', '-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950', '-I../../include',
-                          '-Rpass-analysis=kernel-resource-usage', '-c', f, '-o', '/dev/null'], capture_output=True, text=True).stderr
+                          *(['-mllvm', '-amdgpu-mfma-vgpr-form=1'] if f == 'xw_ode.hip' else []), '-Rpass-analysis=kernel-resource-usage', '-c', f, '-o', '/dev/null'], capture_output=True, text=True).stderr
     cur = {}
     for line in out.splitlines():
         m = re.search(r'remark:\s+(.*?): (.*?) \[-Rpass', line)

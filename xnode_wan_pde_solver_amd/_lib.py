@@ -8,9 +8,9 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libxnwan.so')
-ABI_VERSION = 4
+ABI_VERSION = 5
 
-c_f32p = ctypes.c_void_p   # coordinates / time grid: const double* (device)
+c_f32p = ctypes.c_void_p   # coordinates / time grid: const double* (device)   [name kept from the float32 era]
 c_f64p = ctypes.c_void_p   # double*       (device)
 c_i64p = ctypes.c_void_p
 c_int, c_dbl, c_vp = ctypes.c_int, ctypes.c_double, ctypes.c_void_p
@@ -37,10 +37,10 @@ SIGNATURES = {
     'xw_ode_bwd_multi': [ctypes.POINTER(XwOdeBwdJob), c_int, c_f32p, c_f64p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp],
     'xw_ode_bwd': [c_f32p, c_f32p, c_f64p, c_f64p, c_f64p, c_f64p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                    c_f64p, c_f64p, c_f64p, c_vp],
-    'xw_disc_fwd': [c_f32p, c_f32p, c_f32p, c_f64p, c_int, c_int, c_int, c_int, c_int, c_f64p, c_f64p, c_f64p, c_vp],
+    'xw_disc_fwd': [c_f32p, c_f32p, c_f32p, c_f64p, c_int, c_int, c_int, c_int, c_int, c_f64p, c_f64p, c_vp],
     'xw_disc_gradx': [c_f32p, c_f32p, c_f32p, c_f64p, c_f64p, c_int, c_int, c_int, c_int, c_f64p, c_f64p, c_vp],
     'xw_disc_bwd_slabs': [c_int, c_int],
-    'xw_disc_bwd': [c_f32p, c_f32p, c_f32p, c_f64p, c_f64p, c_f64p, c_int, c_int, c_int, c_int, c_int, c_f64p, c_vp],
+    'xw_disc_bwd': [c_f32p, c_f32p, c_f32p, c_f64p, c_f64p, c_int, c_int, c_int, c_int, c_int, c_f64p, c_vp],
     'xw_weak_partials': [c_f64p, c_f64p, c_f64p, c_f64p, c_int, c_f64p, c_f64p, c_f64p, c_f64p, c_f64p, c_f64p, c_f64p,
                          c_f64p, c_int, c_f64p, c_dbl, c_f64p, c_f64p, c_int, c_int, c_dbl, c_dbl, c_f64p, c_vp],
     'xw_bdry_partials': [c_f64p, c_f64p, c_int, c_int, c_dbl, c_dbl, c_f64p, c_f64p, c_vp],

@@ -410,8 +410,7 @@ int bwd_blocks(long P) {
 }  // namespace
 
 extern "C" int xw_disc_fwd(const double* xT, const double* t, const double* tpp, const double* phi, int N, int L, int d,
-                           int W, int q, double* v, double* vt, double* act, void* stream) {
-  (void)act;
+                           int W, int q, double* v, double* vt, void* stream) {
   if (!xT || !phi || !v || N <= 0 || L <= 0 || d <= 0 || q < 0) return XW_E_ARG;
   if (!tpp && !t) return XW_E_ARG;
   if (tpp && L != 1) return XW_E_ARG;
@@ -436,9 +435,8 @@ extern "C" int xw_disc_bwd_slabs(int N, int L) { return bwd_blocks((long)N * L);
     hipLaunchKernelGGL((k_disc_bwd<50, 9, 2, PARAMS, INGRAD>), dim3(blocks), dim3(256), 0, s, xT, t, tpp, phi, vbar, N, \
                        L, d, gslab, gxv, gtv);
 
-extern "C" int xw_disc_bwd(const double* xT, const double* t, const double* tpp, const double* phi, const double* act,
-                           const double* vbar, int N, int L, int d, int W, int q, double* gslab, void* stream) {
-  (void)act;
+extern "C" int xw_disc_bwd(const double* xT, const double* t, const double* tpp, const double* phi, const double* vbar,
+                           int N, int L, int d, int W, int q, double* gslab, void* stream) {
   if (!xT || !phi || !gslab || N <= 0 || L <= 0 || d <= 0) return XW_E_ARG;
   if (!tpp && !t) return XW_E_ARG;
   if (tpp && L != 1) return XW_E_ARG;

@@ -142,7 +142,7 @@ def disc_fwd(xT, t, phi, W, q, tpp=None, want_vt=True, v=None, vt=None):
     if want_vt and vt is None:
         vt = torch.empty(L, N, dtype=F64, device=xT.device)
     _chk(v, F64, (L, N), 'v'); _chk(vt, F64, (L, N), 'vt')
-    check(lib.xw_disc_fwd(_p(xT), _p(t), _p(tpp), _p(phi), N, L, d, W, q, _p(v), _p(vt if want_vt else None), 0, _stream()),
+    check(lib.xw_disc_fwd(_p(xT), _p(t), _p(tpp), _p(phi), N, L, d, W, q, _p(v), _p(vt if want_vt else None), _stream()),
           'xw_disc_fwd')
     return v, (vt if want_vt else None)
 
@@ -177,7 +177,7 @@ def disc_bwd(xT, t, phi, vbar, W, q, tpp=None, gslab=None):
     ns = disc_bwd_slabs(N, L)
     gslab = torch.empty(ns, P, dtype=F64, device=xT.device) if gslab is None else gslab
     _chk(gslab, F64, (ns, P), 'gslab')
-    check(lib.xw_disc_bwd(_p(xT), _p(t), _p(tpp), _p(phi), 0, _p(vbar), N, L, d, W, q, _p(gslab), _stream()), 'xw_disc_bwd')
+    check(lib.xw_disc_bwd(_p(xT), _p(t), _p(tpp), _p(phi), _p(vbar), N, L, d, W, q, _p(gslab), _stream()), 'xw_disc_bwd')
     return gslab
 
 
