@@ -21,6 +21,8 @@ Data layout in HBM (per group of N equal-length paths, L sample times, d dimensi
   Y             float64 [L, H, N]  hidden-state checkpoints of the stepper (written by the forward, read by the sweeps)
   slabs         float64 [n_slab, P]  per-wave partial parameter gradients, summed inside the Adam kernel
 """
+import os
+
 import torch
 
 from . import kernels as KN
@@ -101,7 +103,6 @@ class Engine:
         # gradient carried from the previous groups of the same sub-iteration (list domains: the reference calls zero_grad()
         # once per sub-iteration but optimizer.step() after every group, src/training.py:127-138); None = off (one group)
         self.accum_u = self.accum_v = None
-        import os
         self.use_streams = os.environ.get('XW_STREAMS', '1') == '1'   # independent kernel chains on side streams
         self.use_graphs = os.environ.get('XW_GRAPHS', '1') == '1'     # capture each sub-step into a HIP graph and replay it
         self.par_gradx = os.environ.get('XW_PAR_GRADX', '1') == '1'
@@ -113,6 +114,8 @@ class Engine:
         # let the short, latency-critical u-forward finish before the chip-filling test-network forward starts
         self.fwd_first_gen = os.environ.get('XW_FWD_FIRST_GEN', '0') == '1'
         self.fwd_first_disc = os.environ.get('XW_FWD_FIRST_DISC', '0') == '1'
+        # hold the sweeps that are NOT on the critical path (x-sweep, A / boundary sweeps) until the test network is done
+        self.sweeps_after_v = os.environ.get('XW_SWEEPS_AFTER_V', '0') == '1'
         self.streams = [torch.cuda.Stream(device=device) for _ in range(5)]
 
     # ------------------------------------------------------------------------------------------------------------
@@ -339,7 +342,7 @@ class Engine:
         if G.Nb:
             KN.bdry_partials(G.ub, G.g, self.alpha, G.Nbglob, self.scal, ubar_b=G.ubar_b)
             e_f = self._mark()
-        with self._side(1, e_f):
+        with self._side(1, e_f, *([e_v] if self.sweeps_after_v else [])):
             KN.ode_bwd_multi([self._job(G, 'i', want_x=True)], G.t, th, *M, want_x=True, want_params=False)
             if self.side_contract:
                 self._join_side(1, e_v, e_g)
@@ -352,6 +355,8 @@ class Engine:
             e_B = self._mark()
         KN.gen_cotangents(G.u, None, G.w, G.h, G.Vol, G.Nglob, self.alpha, G.ubarA, None, c=G.c, cp=G.cp, ckappa=G.ck,
                           pollution=self.pollution)
+        if self.sweeps_after_v:
+            self._join(e_v)
         sweeps = [self._job(G, 'i', G.ubarA, G.slabA[:G.ns_u])]
         if joint:
             sweeps.append(self._job(G, 'b', G.ubar_b, G.slabA[G.ns_u:]))
