@@ -77,7 +77,7 @@ def test_ode_forward(N, L, d, solver):
     assert Y.shape == (L, H, N)
 
 
-@pytest.mark.parametrize('m', [8, 4, 2])
+@pytest.mark.parametrize('m', [8, 7, 6, 5, 4, 3, 2, 1])
 def test_ode_forward_depths(m):
     from oracle import refspec as R
     from xnode_wan_pde_solver_amd import kernels as KN

@@ -617,12 +617,23 @@ int launch_bwd(int method, const BwdJobs& jobs, const double* t, const double* t
 
 }  // namespace
 
-// instantiated (u_hidden_dim, u_hidden_hidden_dim, u_layers) triples; the reference's YAML/notebook use (20, 10, 8)
-#define XW_ODE_DISPATCH(CALL)                     \
-  if (H == 20 && K == 10 && m == 8) { CALL(20, 10, 8) } \
-  else if (H == 20 && K == 10 && m == 4) { CALL(20, 10, 4) } \
-  else if (H == 20 && K == 10 && m == 2) { CALL(20, 10, 2) } \
-  else return XW_E_DIMS;
+// instantiated (u_hidden_dim, u_hidden_hidden_dim, u_layers) triples: the reference's YAML / notebook widths (20, 10) at
+// every depth 1..8.  Other widths are template parameters (H <= 31 and not a multiple of 16, K <= 15).
+#define XW_ODE_DISPATCH(CALL)                                    \
+  if (H == 20 && K == 10) {                                      \
+    switch (m) {                                                 \
+      case 1: { CALL(20, 10, 1) }                                \
+      case 2: { CALL(20, 10, 2) }                                \
+      case 3: { CALL(20, 10, 3) }                                \
+      case 4: { CALL(20, 10, 4) }                                \
+      case 5: { CALL(20, 10, 5) }                                \
+      case 6: { CALL(20, 10, 6) }                                \
+      case 7: { CALL(20, 10, 7) }                                \
+      case 8: { CALL(20, 10, 8) }                                \
+      default: return XW_E_DIMS;                                 \
+    }                                                            \
+  }                                                              \
+  return XW_E_DIMS;
 
 extern "C" int xw_ode_bwd_slabs(int N) { return (N + 15) / 16; }
 

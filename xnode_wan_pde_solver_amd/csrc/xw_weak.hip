@@ -293,7 +293,7 @@ extern "C" int xw_slab_sum(const double* gslab, int nslab, int P, int accumulate
 extern "C" int xw_abi_version(void) { return 5; }
 
 extern "C" int xw_supported_dims(char* buf, int buflen) {
-  static const char s[] = "ode(H,K,m)=(20,10,8),(20,10,4),(20,10,2); disc_fwd W=50 any q; disc_bwd (W,q)=(50,9), d<=126";
+  static const char s[] = "ode (H,K)=(20,10), m=1..8; disc_fwd W=50 any q; disc_bwd (W,q)=(50,9), d<=126";
   int i = 0;
   for (; s[i] && i < buflen - 1; ++i) buf[i] = s[i];
   if (buflen > 0) buf[i] = 0;

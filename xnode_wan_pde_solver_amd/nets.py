@@ -140,8 +140,9 @@ class HiddenField(nn.Module):
     def __init__(self, input_dim, setup, num_layers, hidden_dim):
         super().__init__()
         self.input_dim, self.hidden_dim, self.num_layers = input_dim, hidden_dim, num_layers
-        if num_layers < 1:
-            raise XnwanError('u_layers must be >= 1')
+        if num_layers < 2:
+            raise XnwanError('u_layers must be >= 2: the kernels\' parameter blob always carries the tied hidden layer '
+                             '(with u_layers = 1 the reference builds a field without it, src/model.py:127)')
         tied = [nn.ReLU(), nn.Linear(hidden_dim, hidden_dim)] * (num_layers - 1) if num_layers > 1 else []
         self.net = nn.Sequential(nn.Linear(input_dim + setup['dim'] + 1, hidden_dim), *tied, nn.Tanh(),
                                  nn.Linear(hidden_dim, input_dim)).double()
