@@ -330,3 +330,23 @@ def test_evaluation_off_the_boundary_matches_reference(golden_dir):
             u = S.u_net(X)
         assert tuple(u.shape) == z['%d/u' % k].shape
         close(u, z['%d/u' % k], F32TOL, F32TOL, 'case %d' % k)
+
+
+def test_checkpoint_resume_is_bit_exact(golden_dir, tmp_path):
+    """train 2+2 outer iterations with a save/load in the middle == train 4 outer iterations in one go"""
+    z, params = load(golden_dir, 'ref_tiny_midpoint')
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        A = make_solver(dict(params, iterations=4), 5)
+        A.train()
+        B = make_solver(dict(params, iterations=2), 5)
+        B.train()
+        B.save_checkpoint('mid.pt')
+        C = make_solver(dict(params, iterations=2), 99)          # different init: everything must come from the file
+        C.load_checkpoint('mid.pt')
+        C.train()
+    finally:
+        os.chdir(cwd)
+    assert torch.equal(A.engine.theta.data, C.engine.theta.data) and torch.equal(A.engine.phi.data, C.engine.phi.data)
+    assert int(C.engine.adam_u['step'].item()) == 8 and int(C.engine.adam_v['step'].item()) == 4

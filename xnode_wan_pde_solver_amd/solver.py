@@ -247,5 +247,29 @@ class NODE_WAN_solver:
                              show=show_plt, func_u_sol=self.func_u_sol)
         return past_losses
 
+    # --------------------------------------------------------------------------------------------------------------
+    def save_checkpoint(self, path):
+        """Everything needed to resume: both networks (reference key layout), both Adam states, RNG positions.
+        (The reference only ever saves u_net's state_dict, src/training.py:143,148.)"""
+        import numpy as np
+        torch.save({'u_net': self.u_net.state_dict(), 'v_net': self.v_net.state_dict(),
+                    'optimizer_u': self.optimizer_u.state_dict(), 'optimizer_v': self.optimizer_v.state_dict(),
+                    'best_l': self.best_l, 'torch_rng': torch.get_rng_state(), 'numpy_rng': np.random.get_state(),
+                    'params': dict(self.params)}, path)
+
+    def load_checkpoint(self, path):
+        import numpy as np
+        ck = torch.load(path, map_location=self.device, weights_only=False)
+        self.u_net.load_state_dict(ck['u_net'])          # copies into the parameter views, i.e. into the blobs
+        self.v_net.load_state_dict(ck['v_net'])
+        self.u_net.module.blob.check_alias()
+        self.v_net.module.blob.check_alias()
+        self.optimizer_u.load_state_dict(ck['optimizer_u'])
+        self.optimizer_v.load_state_dict(ck['optimizer_v'])
+        self.best_l = ck['best_l']
+        torch.set_rng_state(ck['torch_rng'].cpu())
+        np.random.set_state(ck['numpy_rng'])
+        self.engine._phi_version += 1                    # cached test-network outputs (reuse_test_net) are stale now
+
     def _is_main(self):
         return self.world is None or self.world.rank == 0
