@@ -89,6 +89,9 @@ int xw_disc_bwd(const double* xT, const double* t, const double* tpp, const doub
 /* ---- weak functional and cotangents (src/loss.py:46-96) -----------------------------------------------------------
  * scal[16] (device, float64): 0 I   1 S=sum v^2   2 SSE_init   3 SSE_bdry   4 loss_u   5 loss_v   6 int   (rest reserved)
  * xw_weak_partials ADDS this rank's partial sums into scal[0..2] (zero scal first; all-reduce scal[0..3] across ranks).
+ *   The grid-wide sums are deterministic (per-block partials + last-block final sum, no float atomics): `work` is a
+ *   caller-provided scratch of xw_reduce_work_size() doubles, zero-initialised ONCE (the kernels leave it clean), not
+ *   shared between launches that may run concurrently.
  *   w: distance-to-boundary weight, per path (w_per_point=0, [N]) or per point ([L,N]);  wt: d w/dt [L,N] or NULL (=0)
  *   s3x[N]: the l=0 gradient-contraction term  sum_ij a_ij d_i phi d_j u + sum_i b_i phi d_i u  (src/loss.py:66-69);
  *           NULL for a = identity, b = 0: then it is contracted in-kernel from gx[d,N], gs[N] (xw_ode_bwd), ghT[d,N]
@@ -98,10 +101,12 @@ int xw_disc_bwd(const double* xT, const double* t, const double* tpp, const doub
 int xw_weak_partials(const double* u, const double* v, const double* vt, const double* w, int w_per_point,
                      const double* wt, const double* s3x, const double* gx, const double* gs, const double* ghT,
                      const double* gxv, const double* w0, const double* gwx0T, int d, const double* c, double ckappa,
-                     const double* f, const double* h, int N, int L, double Vol, double Nglob, double* scal, void* stream);
+                     const double* f, const double* h, int N, int L, double Vol, double Nglob, double* work, double* scal,
+                     void* stream);
+int xw_reduce_work_size(void);
 /* boundary penalty partial: scal[3] += sum (u_b - g)^2 ; ubar_b = alpha * 2 (u_b - g) / (Nbglob * L) */
 int xw_bdry_partials(const double* ub, const double* g, int Nb, int L, double alpha, double Nbglob,
-                     double* ubar_b, double* scal, void* stream);
+                     double* ubar_b, double* work, double* scal, void* stream);
 /* generator cotangent bases on u (loss_u of src/loss.py:93 + the pollution of :55).  Both are available right after
  * the forward passes (neither needs the global I), so the parameter sweeps need not wait for the x-sweep:
  *   ubarA = pollution + alpha * 2 (u[0,n] - h_n) / Nglob at l = 0

@@ -2,7 +2,7 @@
 //
 // Replaces loss.I / init / bdry / int / u / v (src/loss.py:46-96 of the reference) and torch.optim.Adam.step
 // (src/training.py:103-104,138,162).  These are HBM-streaming kernels over the time-major [L, N] point arrays:
-// one thread per Monte-Carlo path walks its L sample times (coalesced across the wave), partial sums are reduced
+// one lane per sample point (consecutive lanes = consecutive paths of one time index), partial sums are reduced
 // wave -> block with shuffles and leave the block as one atomic per scalar.
 //
 // Reference semantics kept on purpose: s1 uses v, not phi; +f*phi; the u-factor of the
@@ -18,9 +18,16 @@ __device__ __forceinline__ double wave_sum(double x) {
   for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
   return x;
 }
+// Deterministic grid-wide sum of NV per-thread partials: every block stores its partial sums to `work`, the block that
+// arrives last (agent-scope ticket) adds them up in block order and accumulates into dst[0..NV).  Float atomics would
+// be shorter but make two runs of the same step differ in the last bits; training must be bit-reproducible
+// (checkpoint/resume, test_test_net_reuse_is_exact).  work: NV * gridDim.x doubles + 1 ticket word (kept at zero
+// between launches: the last block resets it).  Hand-off follows cdna_hip_programming.md Guideline 16: stores ->
+// s_waitcnt vmcnt(0) -> barrier -> lane-0 release fence -> ticket; consumer: ticket -> acquire fence -> barrier -> loads.
 template <int NV>
-__device__ __forceinline__ void block_atomic_add(double (&val)[NV], double* dst) {
+__device__ __forceinline__ void grid_sum(double (&val)[NV], double* __restrict__ work, double* __restrict__ dst) {
   __shared__ double red[NV][4];
+  __shared__ int is_last;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
@@ -31,11 +38,41 @@ __device__ __forceinline__ void block_atomic_add(double (&val)[NV], double* dst)
   if (threadIdx.x < NV) {
     double s = 0.0;
     for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += red[threadIdx.x][w];
-    atomicAdd(dst + threadIdx.x, s);
+    work[(long)blockIdx.x * NV + threadIdx.x] = s;
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  unsigned int* ticket = reinterpret_cast<unsigned int*>(work + (long)gridDim.x * NV);
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    is_last = (t == gridDim.x - 1);
+    if (is_last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  }
+  __syncthreads();
+  if (!is_last) return;
+  // final sum by the whole last block in a fixed order: strided per-thread partials, then the same shuffle / LDS tree
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    double part = 0.0;
+    for (unsigned int b = threadIdx.x; b < gridDim.x; b += blockDim.x) part += work[(long)b * NV + i];
+    const double s = wave_sum(part);
+    if (lane == 0) red[i][wave] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < NV) {
+    double tot = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) tot += red[threadIdx.x][w];
+    dst[threadIdx.x] += tot;
+  }
+  if (threadIdx.x == 0) *ticket = 0u;
 }
 
-__global__ void __launch_bounds__(64) k_weak_partials(const double* __restrict__ u, const double* __restrict__ v,
+__global__ void __launch_bounds__(256) k_weak_partials(const double* __restrict__ u, const double* __restrict__ v,
                                                        const double* __restrict__ vt, const double* __restrict__ w,
                                                        int w_per_point, const double* __restrict__ wt,
                                                        const double* __restrict__ s3x, const double* __restrict__ gx,
@@ -44,60 +81,59 @@ __global__ void __launch_bounds__(64) k_weak_partials(const double* __restrict__
                                                        const double* __restrict__ gwx0T, int d,
                                                        const double* __restrict__ c, double ckappa,
                                                        const double* __restrict__ f, const double* __restrict__ h, int N,
-                                                       int L, double Vol, double Nglob, double* __restrict__ scal) {
+                                                       int L, double Vol, double Nglob, double* __restrict__ work,
+                                                       double* __restrict__ scal) {
+  // one lane per sample point (time-major: consecutive lanes = consecutive paths of one time index, coalesced)
   double acc[3] = {0.0, 0.0, 0.0};  // I, sum v^2, SSE_init
   const double cN = Vol / Nglob, cNL = Vol / Nglob / (double)L;
-  for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
-    const double hn = h[n];
-    double I = 0.0, S = 0.0;
-    double u0 = 0.0;
-    for (int l = 0; l < L; ++l) {
-      const long p = (long)l * N + n;
-      const double ul = u[p], vl = v[p];
-      const double wl = w_per_point ? w[p] : w[n];
-      const double phi = vl * wl;
-      double phit = wl * vt[p];                       // d(phi)/dt = w dv/dt + v dw/dt
-      if (wt != nullptr) phit += vl * wt[p];
-      const double cl = c != nullptr ? c[p] : ckappa * ul;
-      double s3 = cl * ul * phi + f[p] * phi;         // src/loss.py:70
-      if (l == 0) {
-        double s31;
-        if (s3x != nullptr) {
-          s31 = s3x[n];
-        } else {
-          // a = identity, b = 0:  sum_i d_i phi d_i u  with  nabla phi = w nabla v + v nabla w  (at t_0, on the v-sample)
-          // and  nabla u = G_n = d(sum_l u)/dx_n + d(sum_l u)/d(start) nabla h   
-          s31 = 0.0;
-          const double w0n = w0[n], gsn = gs[n];
-          for (int i = 0; i < d; ++i) {
-            const long q = (long)i * N + n;
-            s31 += (w0n * gxv[q] + vl * gwx0T[q]) * (gx[q] + gsn * ghT[q]);
-          }
+  const long P = (long)N * L;
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (long)gridDim.x * blockDim.x) {
+    const int l = (int)(p / N), n = (int)(p - (long)l * N);
+    const double ul = u[p], vl = v[p];
+    const double wl = w_per_point ? w[p] : w[n];
+    const double phi = vl * wl;
+    double phit = wl * vt[p];                         // d(phi)/dt = w dv/dt + v dw/dt
+    if (wt != nullptr) phit += vl * wt[p];
+    const double cl = c != nullptr ? c[p] : ckappa * ul;
+    double s3 = cl * ul * phi + f[p] * phi;           // src/loss.py:70
+    double I = 0.0;
+    if (l == 0) {
+      const double hn = h[n];
+      double s31;
+      if (s3x != nullptr) {
+        s31 = s3x[n];
+      } else {
+        // a = identity, b = 0:  sum_i d_i phi d_i u  with  nabla phi = w nabla v + v nabla w  (at t_0, on the v-sample)
+        // and  nabla u = G_n = d(sum_l u)/dx_n + d(sum_l u)/d(start) nabla h   
+        s31 = 0.0;
+        const double w0n = w0[n], gsn = gs[n];
+        for (int i = 0; i < d; ++i) {
+          const long q = (long)i * N + n;
+          s31 += (w0n * gxv[q] + vl * gwx0T[q]) * (gx[q] + gsn * ghT[q]);
         }
-        s3 += s31;                                    // src/loss.py:66-69 (only non-zero at l = 0)
-        u0 = ul;
-        I -= cN * hn * vl;                            // s1, src/loss.py:64
       }
-      if (l == L - 1) I += cN * ul * vl;
-      I -= cNL * (ul * phit - s3);                    // -(s2 - s3), src/loss.py:65,71-73
-      S += vl * vl;
+      s3 += s31;                                      // src/loss.py:66-69 (only non-zero at l = 0)
+      I -= cN * hn * vl;                              // s1, src/loss.py:64
+      acc[2] += (ul - hn) * (ul - hn);                // src/loss.py:79
     }
+    if (l == L - 1) I += cN * ul * vl;
+    I -= cNL * (ul * phit - s3);                      // -(s2 - s3), src/loss.py:65,71-73
     acc[0] += I;
-    acc[1] += S;
-    acc[2] += (u0 - hn) * (u0 - hn);                  // src/loss.py:79
+    acc[1] += vl * vl;
   }
-  block_atomic_add<3>(acc, scal);
+  grid_sum<3>(acc, work, scal);
 }
 
 __global__ void __launch_bounds__(256) k_bdry(const double* __restrict__ ub, const double* __restrict__ gb, long P,
-                                              double coef, double* __restrict__ ubar_b, double* __restrict__ scal) {
+                                              double coef, double* __restrict__ ubar_b, double* __restrict__ work,
+                                              double* __restrict__ scal) {
   double acc[1] = {0.0};
   for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (long)gridDim.x * blockDim.x) {
     const double r = ub[p] - gb[p];
     acc[0] += r * r;                                  // src/loss.py:84
     if (ubar_b != nullptr) ubar_b[p] = coef * r;
   }
-  block_atomic_add<1>(acc, scal + 3);
+  grid_sum<1>(acc, work, scal + 3);
 }
 
 __device__ __forceinline__ double interior_loss(const double* scal, double Vol, double Nglob, int L) {
@@ -231,20 +267,20 @@ extern "C" int xw_weak_partials(const double* u, const double* v, const double* 
                                 const double* wt, const double* s3x, const double* gx, const double* gs, const double* ghT,
                                 const double* gxv, const double* w0, const double* gwx0T, int d, const double* c,
                                 double ckappa, const double* f, const double* h, int N, int L, double Vol, double Nglob,
-                                double* scal, void* stream) {
-  if (!u || !v || !vt || !w || !f || !h || !scal || N <= 0 || L <= 0) return XW_E_ARG;
+                                double* work, double* scal, void* stream) {
+  if (!u || !v || !vt || !w || !f || !h || !work || !scal || N <= 0 || L <= 0) return XW_E_ARG;
   if (!s3x && (!gx || !gs || !ghT || !gxv || !w0 || !gwx0T || d <= 0)) return XW_E_ARG;
-  hipLaunchKernelGGL(k_weak_partials, dim3(blocks_for(N, 64, 1024)), dim3(64), 0, (hipStream_t)stream, u, v, vt, w,
-                     w_per_point, wt, s3x, gx, gs, ghT, gxv, w0, gwx0T, d, c, ckappa, f, h, N, L, Vol, Nglob, scal);
+  hipLaunchKernelGGL(k_weak_partials, dim3(blocks_for((long)N * L, 256, 1024)), dim3(256), 0, (hipStream_t)stream, u, v, vt, w,
+                     w_per_point, wt, s3x, gx, gs, ghT, gxv, w0, gwx0T, d, c, ckappa, f, h, N, L, Vol, Nglob, work, scal);
   return xw_launch_status();
 }
 
 extern "C" int xw_bdry_partials(const double* ub, const double* g, int Nb, int L, double alpha, double Nbglob,
-                                double* ubar_b, double* scal, void* stream) {
-  if (!ub || !g || !scal || Nb <= 0 || L <= 0) return XW_E_ARG;
+                                double* ubar_b, double* work, double* scal, void* stream) {
+  if (!ub || !g || !work || !scal || Nb <= 0 || L <= 0) return XW_E_ARG;
   const long P = (long)Nb * L;
   const double coef = alpha * 2.0 / (Nbglob * (double)L);
-  hipLaunchKernelGGL(k_bdry, dim3(blocks_for(P, 256, 1024)), dim3(256), 0, (hipStream_t)stream, ub, g, P, coef, ubar_b, scal);
+  hipLaunchKernelGGL(k_bdry, dim3(blocks_for(P, 256, 1024)), dim3(256), 0, (hipStream_t)stream, ub, g, P, coef, ubar_b, work, scal);
   return xw_launch_status();
 }
 
@@ -290,7 +326,8 @@ extern "C" int xw_slab_sum(const double* gslab, int nslab, int P, int accumulate
   return xw_launch_status();
 }
 
-extern "C" int xw_abi_version(void) { return 5; }
+extern "C" int xw_abi_version(void) { return 6; }
+extern "C" int xw_reduce_work_size(void) { return 3 * 1024 + 8; }
 
 extern "C" int xw_supported_dims(char* buf, int buflen) {
   static const char s[] = "ode (H,K)=(20,10), m=1..8; disc_fwd W=50 any q; disc_bwd (W,q)=(50,9), d<=126";

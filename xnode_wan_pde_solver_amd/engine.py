@@ -222,6 +222,8 @@ class Engine:
         G.slab_v = e(KN.disc_bwd_slabs(N, L), self.Pv)
         if Nb:
             G.ub, G.Yb, G.ubar_b = e(Lb, Nb), e(Lb, H, Nb), e(Lb, Nb)
+        G.work_i = torch.zeros(KN.reduce_work_size(), dtype=F64, device=dev)   # scratch of the deterministic grid sums
+        G.work_b = torch.zeros(KN.reduce_work_size(), dtype=F64, device=dev)   # (interior / boundary run concurrently)
         G.graphs = {}
         G.sample_version = 0
         return G
@@ -304,7 +306,7 @@ class Engine:
     def _contract(self, G):
         """I, sum v^2, SSE_init from u, v, dv/dt and the two helper-backward gradients (src/loss.py:46-76)"""
         if G.A0 is None and G.B0 is None:
-            KN.weak_partials(G.u, G.v, G.vt, G.w, G.f, G.h, G.Vol, G.Nglob, self.scal, c=G.c, ckappa=G.ck, wt=G.wt,
+            KN.weak_partials(G.u, G.v, G.vt, G.w, G.f, G.h, G.Vol, G.Nglob, self.scal, G.work_i, c=G.c, ckappa=G.ck, wt=G.wt,
                              contract=dict(gx=G.gx, gs=G.gs, ghT=G.ghT, gxv=G.gxv, w0=G.w0, gwx0T=G.gwx0T))
             return
         Gx = G.gx + G.gs.unsqueeze(0) * G.ghT                                              # [d, N]
@@ -313,7 +315,8 @@ class Engine:
         if G.B0 is not None:
             s3x = s3x + G.v[0] * G.w0 * (G.B0 * Gx).sum(0)
         G.s3x.copy_(s3x)
-        KN.weak_partials(G.u, G.v, G.vt, G.w, G.f, G.h, G.Vol, G.Nglob, self.scal, s3x=G.s3x, c=G.c, ckappa=G.ck, wt=G.wt)
+        KN.weak_partials(G.u, G.v, G.vt, G.w, G.f, G.h, G.Vol, G.Nglob, self.scal, G.work_i, s3x=G.s3x, c=G.c, ckappa=G.ck,
+                         wt=G.wt)
 
     # ------------------------------------------------------------------------------------------------------------
     # generator sub-step (src/training.py:127-138)
@@ -340,7 +343,7 @@ class Engine:
         if self.fwd_first_gen:
             e_v, e_g = self._test_net(G, e0, e_f)
         if G.Nb:
-            KN.bdry_partials(G.ub, G.g, self.alpha, G.Nbglob, self.scal, ubar_b=G.ubar_b)
+            KN.bdry_partials(G.ub, G.g, self.alpha, G.Nbglob, self.scal, G.work_b, ubar_b=G.ubar_b)
             e_f = self._mark()
         with self._side(1, e_f, *([e_v] if self.sweeps_after_v else [])):
             KN.ode_bwd_multi([self._job(G, 'i', want_x=True)], G.t, th, *M, want_x=True, want_params=False)

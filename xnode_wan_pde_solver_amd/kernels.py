@@ -181,7 +181,11 @@ def disc_bwd(xT, t, phi, vbar, W, q, tpp=None, gslab=None):
     return gslab
 
 
-def weak_partials(u, v, vt, w, f, h, Vol, Nglob, scal, s3x=None, contract=None, c=None, ckappa=0.0, wt=None):
+def reduce_work_size():
+    return lib.xw_reduce_work_size()
+
+
+def weak_partials(u, v, vt, w, f, h, Vol, Nglob, scal, work, s3x=None, contract=None, c=None, ckappa=0.0, wt=None):
     """partial sums of I, sum v^2, SSE_init.  Either s3x[N] (pre-contracted gradient term) or contract = dict(gx, gs, ghT,
     gxv, w0, gwx0T) for the in-kernel contraction with a = identity, b = 0."""
     _need_gpu()
@@ -191,6 +195,7 @@ def weak_partials(u, v, vt, w, f, h, Vol, Nglob, scal, s3x=None, contract=None, 
     per_point = 1 if w.dim() == 2 else 0
     _chk(w, F64, (L, N) if per_point else (N,), 'w'); _chk(wt, F64, (L, N), 'wt'); _chk(c, F64, (L, N), 'c')
     _chk(s3x, F64, (N,), 's3x'); _chk(h, F64, (N,), 'h'); _chk(scal, F64, (16,), 'scal')
+    _chk(work, F64, (reduce_work_size(),), 'work')
     k, d = {}, 0
     if s3x is None:
         k = contract
@@ -200,15 +205,16 @@ def weak_partials(u, v, vt, w, f, h, Vol, Nglob, scal, s3x=None, contract=None, 
         _chk(k['gs'], F64, (N,), 'gs'); _chk(k['w0'], F64, (N,), 'w0')
     check(lib.xw_weak_partials(_p(u), _p(v), _p(vt), _p(w), per_point, _p(wt), _p(s3x), _p(k.get('gx')), _p(k.get('gs')),
                                _p(k.get('ghT')), _p(k.get('gxv')), _p(k.get('w0')), _p(k.get('gwx0T')), d, _p(c),
-                               float(ckappa), _p(f), _p(h), N, L, float(Vol), float(Nglob), _p(scal), _stream()),
+                               float(ckappa), _p(f), _p(h), N, L, float(Vol), float(Nglob), _p(work), _p(scal), _stream()),
           'xw_weak_partials')
 
 
-def bdry_partials(ub, g, alpha, Nbglob, scal, ubar_b=None):
+def bdry_partials(ub, g, alpha, Nbglob, scal, work, ubar_b=None):
     _need_gpu()
     L, Nb = ub.shape
     _chk(ub, F64, (L, Nb), 'ub'); _chk(g, F64, (L, Nb), 'g'); _chk(ubar_b, F64, (L, Nb), 'ubar_b'); _chk(scal, F64, (16,), 'scal')
-    check(lib.xw_bdry_partials(_p(ub), _p(g), Nb, L, float(alpha), float(Nbglob), _p(ubar_b), _p(scal), _stream()),
+    _chk(work, F64, (reduce_work_size(),), 'work')
+    check(lib.xw_bdry_partials(_p(ub), _p(g), Nb, L, float(alpha), float(Nbglob), _p(ubar_b), _p(work), _p(scal), _stream()),
           'xw_bdry_partials')
 
 
