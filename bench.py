@@ -154,7 +154,7 @@ def main():
     macs_F, path_u, macs_v = algorithmic_macs(params)
     Pn, N, Nb = s['N_r'] * s['N_t'], s['N_r'], s['N_b']
     alg_flops = {                                          # algorithmic FLOP (2 x MAC) per launch, SURVEY section 8(d)
-        'disc_fwd': 2.0 * 2 * Pn * macs_v,                 # value + d/dt tangent
+        'disc_fwd': 2.0 * (2 * Pn + N) * macs_v,           # value + d/dt tangent at all points, reverse pass at the N points of t_0
         'disc_bwd': 2.0 * 2 * Pn * macs_v,                 # reverse chain + weight-gradient contraction (recompute not counted)
         'ode_fwd_1job': 2.0 * N * path_u,
         'ode_fwd_2job': 2.0 * (N + Nb) * path_u,

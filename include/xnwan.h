@@ -71,9 +71,15 @@ int xw_ode_bwd_multi(const XwOdeBwdJob* jobs, int njobs, const double* t, const 
 /* ---- v_phi: discriminator.forward (src/model.py:37-47) + d/dt by forward-mode ------------------------------------
  * Path mode (tpp == NULL): point (l,n) = (t[l], x_n).  Point mode (tpp != NULL): L must be 1, point n = (tpp[n], x_n).
  * v[L,N] out; vt[L,N] out = dv/dt (may be NULL).  Nothing is stashed for the backward: xw_disc_bwd recomputes the
- * forward of its 16-point tiles in registers (cheaper than an HBM round trip of the activations). */
+ * forward of its 16-point tiles in registers (cheaper than an HBM round trip of the activations).
+ * gxv[d,ngrad], gtv[ngrad] (may be NULL): input gradient of v (nabla_x v, dv/dt by reverse mode) for the LEADING ngrad
+ * points in time-major order -- the weak form reads nabla phi only at the first time index (pass ngrad = N), so this
+ * fuses what would otherwise be a separate xw_disc_gradx launch; needs q <= 16.
+ * max_blocks: cap on the grid (0 = default, two resident blocks per CU); a smaller grid leaves SIMD slots to kernels
+ * that run concurrently. */
 int xw_disc_fwd(const double* xT, const double* t, const double* tpp, const double* phi,
-                int N, int L, int d, int W, int q, double* v, double* vt, void* stream);
+                int N, int L, int d, int W, int q, double* v, double* vt, double* gxv, double* gtv, int ngrad,
+                int max_blocks, void* stream);
 
 /* input gradient of <vbar, v> at a set of points (reverse mode, no parameter gradients): gxv[d,N] (nabla_x) and
  * gtv[N] (d/dt), for the N points (t_n, x_n) with t_n = tpp ? tpp[n] : t[0]; vbar[N] or NULL (= ones).

@@ -144,6 +144,14 @@ def test_disc_forward_and_time_tangent(N, L, d):
     Xp = torch.cat((tpp.view(N, 1), x), 1).double()
     v1, _ = KN.disc_fwd(x.double().t().contiguous().cuda(), None, _blob(phi, V_ORDER), W, Q, tpp=tpp.double().cuda())
     _close(v1[0], R.v_net(phi, _cfg(), Xp), 1e-12, 'v (point mode)')
+    # fused input gradient at the leading points (first time index), with a reduced grid
+    gxv = torch.empty(d, N, dtype=torch.float64).cuda()
+    gtv = torch.empty(N, dtype=torch.float64).cuda()
+    v2, vt2 = KN.disc_fwd(x.double().t().contiguous().cuda(), t.double().cuda(), _blob(phi, V_ORDER), W, Q, gxv=gxv, gtv=gtv,
+                          ngrad=N, max_blocks=3)
+    _close(v2.t(), v_ref, 1e-12, 'v (with fused gradient)')
+    _close(gxv.t(), gX[:, 0, 1:], 1e-11, 'fused nabla_x v at t0')
+    _close(gtv, gX[:, 0, 0], 1e-11, 'fused dv/dt at t0')
 
 
 @pytest.mark.parametrize('N,d', [(37, 5), (64, 20), (20, 70)])

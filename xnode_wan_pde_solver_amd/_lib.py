@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libxnwan.so')
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 c_f32p = ctypes.c_void_p   # coordinates / time grid: const double* (device)   [name kept from the float32 era]
 c_f64p = ctypes.c_void_p   # double*       (device)
@@ -37,7 +37,8 @@ SIGNATURES = {
     'xw_ode_bwd_multi': [ctypes.POINTER(XwOdeBwdJob), c_int, c_f32p, c_f64p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp],
     'xw_ode_bwd': [c_f32p, c_f32p, c_f64p, c_f64p, c_f64p, c_f64p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                    c_f64p, c_f64p, c_f64p, c_vp],
-    'xw_disc_fwd': [c_f32p, c_f32p, c_f32p, c_f64p, c_int, c_int, c_int, c_int, c_int, c_f64p, c_f64p, c_vp],
+    'xw_disc_fwd': [c_f32p, c_f32p, c_f32p, c_f64p, c_int, c_int, c_int, c_int, c_int, c_f64p, c_f64p, c_f64p, c_f64p, c_int,
+                    c_int, c_vp],
     'xw_disc_gradx': [c_f32p, c_f32p, c_f32p, c_f64p, c_f64p, c_int, c_int, c_int, c_int, c_f64p, c_f64p, c_vp],
     'xw_disc_bwd_slabs': [c_int, c_int],
     'xw_disc_bwd': [c_f32p, c_f32p, c_f32p, c_f64p, c_f64p, c_int, c_int, c_int, c_int, c_int, c_f64p, c_vp],

@@ -15,7 +15,6 @@
 //                outer products over the points (LDS transpose; 4 waves of a block own one 16-row band of dVh each).
 //                Optionally also returns the input gradient (nabla_x v, dv/dt) -- used for nabla phi at t0.
 #include "xw_common.h"
-#include <cstdlib>
 
 namespace {
 
@@ -69,16 +68,20 @@ __device__ __forceinline__ void input_layer(const double* __restrict__ ph, const
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+#define XW_QMAX 16   // deepest test network whose ReLU masks fit the LDS stash of k_disc_fwd's fused input gradient
+
 template <int W>
 __global__ void __launch_bounds__(256, 2) k_disc_fwd(const double* __restrict__ xT, const double* __restrict__ tf,
                                                      const double* __restrict__ tpp, const double* __restrict__ ph, int N,
-                                                     int L, int d, int q, double* __restrict__ v, double* __restrict__ vt) {
+                                                     int L, int d, int q, double* __restrict__ v, double* __restrict__ vt,
+                                                     double* __restrict__ gxv, double* __restrict__ gtv, int ngrad) {
   typedef VDim<W> D;
   // Vh as MFMA A-fragments in LDS (26.6 KB), shared by the 4 waves of the block: one ds_read_b64 feeds two 64-cycle MFMAs
   // (value and d/dt tangent), and keeping them out of the register file lets two waves share a SIMD so that one wave's
   // relu / tanh VALU work overlaps the other's matrix work.
   __shared__ double sVh[D::MT * D::KS * 64];
   __shared__ double sB[2 * 16 * D::MT];
+  __shared__ unsigned short sMask[XW_QMAX][256];   // ReLU masks (16 rows per lane) of the layers, for the fused reverse chain
   const int lane = xw_lane(), g = lane >> 4;
   const int wave = threadIdx.x >> 6;
   const VOff o = v_offsets(d, W);
@@ -96,16 +99,24 @@ __global__ void __launch_bounds__(256, 2) k_disc_fwd(const double* __restrict__ 
   const double vob = ph[o.Vob];
   for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long)gridDim.x * 4) {
     const Pt pt = locate(tile, P, N, tf, tpp);
+    // nabla phi is only read at the first time index: the leading `ngrad` points (time-major
+    // order) also get the input gradient of v, by a reverse chain through the masks stashed below
+    const bool want_grad = gxv != nullptr && tile * 16 < ngrad;         // wave-uniform
     d4 a[D::MT], ad[D::MT];
     input_layer<W>(ph, o, xT, N, d, pt, a, ad);
     for (int j = 0; j < q; ++j) {
       d4 nw[D::MT], nd[D::MT];
+      unsigned int mask = 0;
 #pragma unroll
       for (int mt = 0; mt < D::MT; ++mt) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) nw[mt][r] = sB[16 * mt + g + 4 * r];
+        for (int r = 0; r < 4; ++r) {
+          nw[mt][r] = sB[16 * mt + g + 4 * r];
+          mask |= (a[mt][r] > 0.0 ? 1u : 0u) << (4 * mt + r);
+        }
         nd[mt] = xw_zero4();
       }
+      if (want_grad) sMask[j][threadIdx.x] = (unsigned short)mask;
 #pragma unroll
       for (int ks = 0; ks < D::KS; ++ks) {
         const double av = a[ks >> 2][ks & 3];
@@ -135,12 +146,59 @@ __global__ void __launch_bounds__(256, 2) k_disc_fwd(const double* __restrict__ 
           const double vo = sB[16 * D::MT + 16 * mt + g + 4 * r];
           sv += vo * th;
           sd += vo * (1.0 - th * th) * ad[mt][r];
+          a[mt][r] = vo * (1.0 - th * th);       // reused below as the cotangent of a_q for d(sum v)/d(input)
+        } else {
+          a[mt][r] = 0.0;
         }
     sv = xw_sum_over_g(sv) + vob;
     sd = xw_sum_over_g(sd);
     if (g == 0 && pt.valid) {
       v[pt.p] = sv;
       if (vt != nullptr) vt[pt.p] = sd;
+    }
+    if (want_grad) {
+      // reverse chain: delta_j = relu'(a_j) .* (Vh^T delta_{j+1}); Vh^T fragments come from L2 (1 tile in L is affected)
+      d4 (&dl)[D::MT] = a;
+      for (int j = q - 1; j >= 0; --j) {
+        d4 nd[D::MT];
+#pragma unroll
+        for (int mt = 0; mt < D::MT; ++mt) nd[mt] = xw_zero4();
+#pragma unroll
+        for (int ks = 0; ks < D::KS; ++ks) {
+          const double b = dl[ks >> 2][ks & 3];
+          asm volatile("" ::: "memory");   // a few loads in flight, not all 52 (register pressure)
+#pragma unroll
+          for (int mt = 0; mt < D::MT; ++mt) nd[mt] = XW_MFMA(xw_fragAT(ph + o.Vh, W, W, W, 16 * mt, 4 * ks), b, nd[mt]);
+        }
+        const unsigned int mask = sMask[j][threadIdx.x];
+#pragma unroll
+        for (int mt = 0; mt < D::MT; ++mt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dl[mt][r] = ((mask >> (4 * mt + r)) & 1u) ? nd[mt][r] : 0.0;
+      }
+      const bool gl = pt.valid && pt.p < ngrad;
+      for (int rt = 0; rt < (d + 15) / 16; ++rt) {
+        d4 vv = xw_zero4();
+#pragma unroll
+        for (int ks = 0; ks < D::KS; ++ks) {
+          if ((ks & 3) == 0) asm volatile("" ::: "memory");
+          vv = XW_MFMA(xw_fragAT(ph + o.Vin + 1, o.ldin, W, d, 16 * rt, 4 * ks), dl[ks >> 2][ks & 3], vv);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = 16 * rt + g + 4 * r;
+          if (i < d && gl) gxv[(long)i * ngrad + pt.p] = vv[r];
+        }
+      }
+      double st_ = 0.0;
+#pragma unroll
+      for (int mt = 0; mt < D::MT; ++mt) {
+        const d4 v0 = xw_vecD_strided(ph + o.Vin, o.ldin, W, 16 * mt);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) st_ += v0[r] * dl[mt][r];
+      }
+      st_ = xw_sum_over_g(st_);
+      if (gtv != nullptr && g == 0 && gl) gtv[pt.p] = st_;
     }
   }
 }
@@ -410,18 +468,19 @@ int bwd_blocks(long P) {
 }  // namespace
 
 extern "C" int xw_disc_fwd(const double* xT, const double* t, const double* tpp, const double* phi, int N, int L, int d,
-                           int W, int q, double* v, double* vt, void* stream) {
+                           int W, int q, double* v, double* vt, double* gxv, double* gtv, int ngrad, int max_blocks,
+                           void* stream) {
   if (!xT || !phi || !v || N <= 0 || L <= 0 || d <= 0 || q < 0) return XW_E_ARG;
   if (!tpp && !t) return XW_E_ARG;
   if (tpp && L != 1) return XW_E_ARG;
+  if (gxv && (ngrad <= 0 || (long)ngrad > (long)N * L || q > XW_QMAX)) return XW_E_ARG;
   if (W != 50) return XW_E_DIMS;
   const long ntiles = ((long)N * L + 15) / 16;
   long blocks = (ntiles + 3) / 4;
-  long cap = 512;                   // 2 blocks per CU resident (launch bounds), grid-stride over the tiles
-  if (const char* e = getenv("XW_DISC_FWD_BLOCKS")) cap = atol(e);
+  long cap = max_blocks > 0 ? max_blocks : 512;   // default: 2 blocks per CU resident (launch bounds), grid-stride over tiles
   if (blocks > cap) blocks = cap;
   hipLaunchKernelGGL((k_disc_fwd<50>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, xT, t, tpp, phi, N, L, d,
-                     q, v, vt);
+                     q, v, vt, gxv, gtv, ngrad);
   return xw_launch_status();
 }
 

@@ -105,18 +105,12 @@ class Engine:
         self.accum_u = self.accum_v = None
         self.use_streams = os.environ.get('XW_STREAMS', '1') == '1'   # independent kernel chains on side streams
         self.use_graphs = os.environ.get('XW_GRAPHS', '1') == '1'     # capture each sub-step into a HIP graph and replay it
-        self.par_gradx = os.environ.get('XW_PAR_GRADX', '1') == '1'
         # opt-in: v, dv/dt, nabla_x v(t_0) of a group are reused while phi and the sample are unchanged (exact: the
         # reference recomputes identical values in every sub-step of an outer iteration).  Off by default.
         self.reuse_test_net = os.environ.get('XW_REUSE_V', '0') == '1'
         self._phi_version = 0
         self.side_contract = os.environ.get('XW_SIDE_CONTRACT', '0') == '1'   # measured slower (queue mapping)
-        # let the short, latency-critical u-forward finish before the chip-filling test-network forward starts
-        self.fwd_first_gen = os.environ.get('XW_FWD_FIRST_GEN', '0') == '1'
-        self.fwd_first_disc = os.environ.get('XW_FWD_FIRST_DISC', '0') == '1'
-        # hold the sweeps that are NOT on the critical path (x-sweep, A / boundary sweeps) until the test network is done
-        self.sweeps_after_v = os.environ.get('XW_SWEEPS_AFTER_V', '0') == '1'
-        self.streams = [torch.cuda.Stream(device=device) for _ in range(5)]
+        self.streams = [torch.cuda.Stream(device=device) for _ in range(4)]
 
     # ------------------------------------------------------------------------------------------------------------
     # per-sample preparation (once per outer iteration; everything here is parameter-independent)
@@ -254,33 +248,19 @@ class Engine:
             for ev in events:
                 cur.wait_event(ev)
 
-    def _test_net(self, G, e0, e_fwd=None):
-        """test network on side streams 0 (v, dv/dt at all points) and 4 (nabla_x v at t_0); returns (e_v, e_g).
-        e_fwd: event the big forward additionally waits for (scheduling knob fwd_first_*)"""
+    def _test_net(self, G, e0):
+        """test network on side stream 0: v, dv/dt at all points; nabla_x v at the first time index rides along in the
+        same launch (fused reverse chain).  Returns the completion event."""
         ph = self.phi.data
         if getattr(G, 'skip_v', False):          # reuse_test_net: v, dv/dt, nabla_x v(t_0) are still valid (see _v_fresh)
-            return e0, e0
-
-        def gradx():
-            KN.disc_gradx(G.xvT, G.t, ph, self.W, self.q, tpp=G.tpp0, gxv=G.gxv, gtv=G.gtv)
-
-        def fwd():
-            if G.tpp is None:
-                KN.disc_fwd(G.xvT, G.t, ph, self.W, self.q, v=G.v, vt=G.vt)
+            return e0
+        with self._side(0, e0):
+            if G.tpp is not None:
+                KN.disc_fwd(G.xvT_pts, None, ph, self.W, self.q, tpp=G.tpp, v=G.v.view(1, -1), vt=G.vt.view(1, -1),
+                            gxv=G.gxv, gtv=G.gtv, ngrad=G.N)
             else:
-                KN.disc_fwd(G.xvT_pts, None, ph, self.W, self.q, tpp=G.tpp, v=G.v.view(1, -1), vt=G.vt.view(1, -1))
-        if self.par_gradx:
-            with self._side(4, e0):
-                gradx()
-                e_g = self._mark()
-        with self._side(0, e0, *([e_fwd] if e_fwd is not None else [])):
-            fwd()
-            if not self.par_gradx:
-                gradx()
-            e_v = self._mark()
-        if not self.par_gradx:
-            e_g = e_v
-        return e_v, e_g
+                KN.disc_fwd(G.xvT, G.t, ph, self.W, self.q, v=G.v, vt=G.vt, gxv=G.gxv, gtv=G.gtv, ngrad=G.N)
+            return self._mark()
 
     def _reaction(self, G):
         """c(u, t, x): linear fast path, or the user's callable differentiated by autograd (not graph-capturable)"""
@@ -325,30 +305,27 @@ class Engine:
         """everything up to (not including) the exchange: leaves slabA, slabB and scal[0..3] complete.
         Kernel chains:  main   u-forward (interior + boundary, one launch) -> cotangent A, boundary residual
                                -> parameter sweeps {interior/A, boundary} (one launch)
-                        side 0 test network v, dv/dt, nabla_x v(t_0)             (independent of theta)
+                        side 0 test network v, dv/dt and (fused) nabla_x v(t_0)  (independent of theta)
                         side 1 x-sweep (nabla_x u)                               (after the forward)
                         side 2 cotangent B = dI/du -> parameter sweep B          (after the forward and v)"""
         th = self.theta.data
         M = (self.method, self.H, self.K, self.m)
         self.scal.zero_()
         e0 = self._mark()
-        if not self.fwd_first_gen:
-            e_v, e_g = self._test_net(G, e0)
+        e_v = self._test_net(G, e0)
         joint = G.Nb and G.same_grid           # boundary paths on the interior's time grid: one launch for both
         KN.ode_fwd_multi([self._job(G, 'i')] + ([self._job(G, 'b')] if joint else []), G.t, th, *M)
         if G.Nb and not joint:
             KN.ode_fwd_multi([self._job(G, 'b')], G.tb, th, *M)
         self._reaction(G)
         e_f = self._mark()
-        if self.fwd_first_gen:
-            e_v, e_g = self._test_net(G, e0, e_f)
         if G.Nb:
             KN.bdry_partials(G.ub, G.g, self.alpha, G.Nbglob, self.scal, G.work_b, ubar_b=G.ubar_b)
             e_f = self._mark()
-        with self._side(1, e_f, *([e_v] if self.sweeps_after_v else [])):
+        with self._side(1, e_f):
             KN.ode_bwd_multi([self._job(G, 'i', want_x=True)], G.t, th, *M, want_x=True, want_params=False)
             if self.side_contract:
-                self._join_side(1, e_v, e_g)
+                self._join_side(1, e_v)
                 self._contract(G)                                # -> scal[0..2]
             e_x = self._mark()
         with self._side(2, e_f, e_v):
@@ -358,15 +335,13 @@ class Engine:
             e_B = self._mark()
         KN.gen_cotangents(G.u, None, G.w, G.h, G.Vol, G.Nglob, self.alpha, G.ubarA, None, c=G.c, cp=G.cp, ckappa=G.ck,
                           pollution=self.pollution)
-        if self.sweeps_after_v:
-            self._join(e_v)
         sweeps = [self._job(G, 'i', G.ubarA, G.slabA[:G.ns_u])]
         if joint:
             sweeps.append(self._job(G, 'b', G.ubar_b, G.slabA[G.ns_u:]))
         KN.ode_bwd_multi(sweeps, G.t, th, *M, want_x=False, want_params=True)
         if G.Nb and not joint:
             KN.ode_bwd_multi([self._job(G, 'b', G.ubar_b, G.slabA[G.ns_u:])], G.tb, th, *M, want_x=False, want_params=True)
-        self._join(e_x, e_v, e_g)
+        self._join(e_x, e_v)
         if not self.side_contract:
             self._contract(G)
         self._join(e_B)
@@ -423,14 +398,11 @@ class Engine:
         M = (self.method, self.H, self.K, self.m)
         self.scal.zero_()
         e0 = self._mark()
-        if not self.fwd_first_disc:
-            e_v, e_g = self._test_net(G, e0)
+        e_v = self._test_net(G, e0)
         KN.ode_fwd_multi([self._job(G, 'i')], G.t, th, *M)
         self._reaction(G)
-        if self.fwd_first_disc:
-            e_v, e_g = self._test_net(G, e0, self._mark())
         KN.ode_bwd_multi([self._job(G, 'i', want_x=True)], G.t, th, *M, want_x=True, want_params=False)
-        self._join(e_v, e_g)
+        self._join(e_v)
         self._contract(G)
 
     def _disc_mid(self, G):

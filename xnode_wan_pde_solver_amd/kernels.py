@@ -131,8 +131,9 @@ def ode_bwd(xT, t, start, theta, Y, ubar, method, H, K, m, want_x=True, want_par
     return (gx if want_x else None), (gs if want_x else None), (gslab if want_params else None)
 
 
-def disc_fwd(xT, t, phi, W, q, tpp=None, want_vt=True, v=None, vt=None):
-    """v_phi and dv/dt.  Path mode: points (t[l], x_n) -> [L,N].  Point mode (tpp[N]): points (tpp[n], x_n) -> [1,N]."""
+def disc_fwd(xT, t, phi, W, q, tpp=None, want_vt=True, v=None, vt=None, gxv=None, gtv=None, ngrad=0, max_blocks=0):
+    """v_phi and dv/dt.  Path mode: points (t[l], x_n) -> [L,N].  Point mode (tpp[N]): points (tpp[n], x_n) -> [1,N].
+    gxv[d,ngrad] / gtv[ngrad]: also return the input gradient of v at the leading ngrad points (time-major order)."""
     _need_gpu()
     d, N = xT.shape
     L = 1 if tpp is not None else t.shape[0]
@@ -142,8 +143,10 @@ def disc_fwd(xT, t, phi, W, q, tpp=None, want_vt=True, v=None, vt=None):
     if want_vt and vt is None:
         vt = torch.empty(L, N, dtype=F64, device=xT.device)
     _chk(v, F64, (L, N), 'v'); _chk(vt, F64, (L, N), 'vt')
-    check(lib.xw_disc_fwd(_p(xT), _p(t), _p(tpp), _p(phi), N, L, d, W, q, _p(v), _p(vt if want_vt else None), _stream()),
-          'xw_disc_fwd')
+    if gxv is not None:
+        _chk(gxv, F64, (d, ngrad), 'gxv'); _chk(gtv, F64, (ngrad,), 'gtv')
+    check(lib.xw_disc_fwd(_p(xT), _p(t), _p(tpp), _p(phi), N, L, d, W, q, _p(v), _p(vt if want_vt else None), _p(gxv), _p(gtv),
+                          int(ngrad), int(max_blocks), _stream()), 'xw_disc_fwd')
     return v, (vt if want_vt else None)
 
 
