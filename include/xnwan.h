@@ -48,8 +48,10 @@ int xw_ode_fwd(const double* xT, const double* t, const double* start, const dou
 /* The same for up to 4 independent groups of paths in ONE launch (interior + boundary sample, ...): one wave per 16
  * paths fills only a quarter of an MI355X at N = 4096, so independent groups are co-scheduled explicitly. */
 typedef struct { const double* xT; const double* start; double* u; double* Y; int N; } XwOdeFwdJob;
+/* zero16 (may be NULL): 16 doubles cleared by the launch -- the sub-step's partial-sum slots scal[], so that no separate
+ * memset sits at the head of the critical path */
 int xw_ode_fwd_multi(const XwOdeFwdJob* jobs, int njobs, const double* t, const double* theta,
-                     int method, int L, int d, int H, int K, int m, void* stream);
+                     int method, int L, int d, int H, int K, int m, double* zero16, void* stream);
 
 /* number of partial-gradient slabs xw_ode_bwd writes for N paths, and doubles of workspace it needs */
 int xw_ode_bwd_slabs(int N);
@@ -135,7 +137,8 @@ int xw_losses(double* scal, int L, int Lb, double Vol, double Nglob, double Nbgl
 /* ---- optimiser (torch.optim.Adam defaults, src/training.py:103-104) ------------------------------------------------
  * grad = gextraA + sum_s gslabA[s] + coefB * (gextraB + sum_s gslabB[s]),  coefB = scal ? 2 / scal[0] : 1
  * (slab sets [n][P]; gextra*[P] pre-reduced gradients, e.g. after an all-reduce; any of them may be NULL / 0)
- * state: m[P], v[P], step (device int64; incremented by one after the update iff bump_step, else by xw_losses) */
+ * state: m[P], v[P], step (device int64).  bump_step = 1: incremented here after the update; 0: left alone (a later
+ * xw_losses does it); -1: xw_losses already advanced it for this update (lets Adam be the last kernel of a sub-step) */
 int xw_adam(double* param, const double* gslabA, int nA, const double* gextraA, const double* gslabB, int nB,
             const double* gextraB, const double* scal, double* m, double* v, long long* step, int bump_step, int P,
             double lr, double beta1, double beta2, double eps, double* gsum_out, void* stream);

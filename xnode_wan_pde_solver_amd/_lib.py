@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libxnwan.so')
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 c_f32p = ctypes.c_void_p   # coordinates / time grid: const double* (device)   [name kept from the float32 era]
 c_f64p = ctypes.c_void_p   # double*       (device)
@@ -32,7 +32,8 @@ SIGNATURES = {
     'xw_theta_size': [c_int, c_int, c_int],
     'xw_phi_size': [c_int, c_int],
     'xw_ode_fwd': [c_f32p, c_f32p, c_f64p, c_f64p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_f64p, c_f64p, c_vp],
-    'xw_ode_fwd_multi': [ctypes.POINTER(XwOdeFwdJob), c_int, c_f32p, c_f64p, c_int, c_int, c_int, c_int, c_int, c_int, c_vp],
+    'xw_ode_fwd_multi': [ctypes.POINTER(XwOdeFwdJob), c_int, c_f32p, c_f64p, c_int, c_int, c_int, c_int, c_int, c_int, c_f64p,
+                         c_vp],
     'xw_ode_bwd_slabs': [c_int],
     'xw_ode_bwd_multi': [ctypes.POINTER(XwOdeBwdJob), c_int, c_f32p, c_f64p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp],
     'xw_ode_bwd': [c_f32p, c_f32p, c_f64p, c_f64p, c_f64p, c_f64p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,

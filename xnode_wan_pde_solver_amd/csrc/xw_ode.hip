@@ -259,6 +259,7 @@ struct FwdJobs {
   int N[XW_MAXJOBS];
   int tile0[XW_MAXJOBS + 1];   // first block of each job
   int n;
+  double* zero16;              // optional: 16 doubles cleared by block 0 (the sub-step's partial-sum slots)
 };
 struct BwdJobs {
   const double* xT[XW_MAXJOBS];
@@ -294,6 +295,7 @@ __global__ void __launch_bounds__(64) k_ode_fwd(const FwdJobs jobs, const double
   const int N = jobs.N[job];
   const int lane = xw_lane(), g = lane >> 4, n = lane & 15;
   const int base = ((int)blockIdx.x - jobs.tile0[job]) * 16;
+  if (blockIdx.x == 0 && jobs.zero16 != nullptr && lane < 16) jobs.zero16[lane] = 0.0;
   const bool valid = base + n < N;
   const int ncl = valid ? base + n : N - 1;
   const UOff o = u_offsets(d, H, K);
@@ -638,10 +640,11 @@ int launch_bwd(int method, const BwdJobs& jobs, const double* t, const double* t
 extern "C" int xw_ode_bwd_slabs(int N) { return (N + 15) / 16; }
 
 extern "C" int xw_ode_fwd_multi(const XwOdeFwdJob* jobs, int njobs, const double* t, const double* theta, int method, int L,
-                                int d, int H, int K, int m, void* stream) {
+                                int d, int H, int K, int m, double* zero16, void* stream) {
   if (!jobs || njobs < 1 || njobs > XW_MAXJOBS || !t || !theta || L <= 0 || d <= 0 || m < 1) return XW_E_ARG;
   FwdJobs J;
   J.n = njobs;
+  J.zero16 = zero16;
   J.tile0[0] = 0;
   for (int i = 0; i < XW_MAXJOBS; ++i) {
     const bool on = i < njobs;
@@ -662,7 +665,7 @@ extern "C" int xw_ode_fwd_multi(const XwOdeFwdJob* jobs, int njobs, const double
 extern "C" int xw_ode_fwd(const double* xT, const double* t, const double* start, const double* theta, int method, int N,
                           int L, int d, int H, int K, int m, double* u, double* Y, void* stream) {
   XwOdeFwdJob j = {xT, start, u, Y, N};
-  return xw_ode_fwd_multi(&j, 1, t, theta, method, L, d, H, K, m, stream);
+  return xw_ode_fwd_multi(&j, 1, t, theta, method, L, d, H, K, m, nullptr, stream);
 }
 
 extern "C" int xw_ode_bwd_multi(const XwOdeBwdJob* jobs, int njobs, const double* t, const double* theta, int method, int L,

@@ -212,8 +212,8 @@ __global__ void __launch_bounds__(1024) k_adam(double* __restrict__ param, const
                                                const double* __restrict__ eA, const double* __restrict__ gB, int nB,
                                                const double* __restrict__ eB, const double* __restrict__ scal,
                                                double* __restrict__ m, double* __restrict__ v,
-                                               const long long* __restrict__ step, int P, double lr, double beta1,
-                                               double beta2, double eps, double* __restrict__ gsum_out) {
+                                               const long long* __restrict__ step, int step_is_current, int P, double lr,
+                                               double beta1, double beta2, double eps, double* __restrict__ gsum_out) {
   __shared__ double red[2][16][64];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int i = blockIdx.x * 64 + tx;
@@ -236,7 +236,7 @@ __global__ void __launch_bounds__(1024) k_adam(double* __restrict__ param, const
   const double coefB = scal != nullptr ? 2.0 / scal[0] : 1.0;
   const double g = a + coefB * b;
   if (gsum_out != nullptr) gsum_out[i] = g;
-  const long long t = *step + 1;
+  const long long t = *step + (step_is_current ? 0 : 1);
   const double bc1 = 1.0 - pow(beta1, (double)t), bc2 = 1.0 - pow(beta2, (double)t);
   const double mi = beta1 * m[i] + (1.0 - beta1) * g;
   const double vi = beta2 * v[i] + (1.0 - beta2) * g * g;
@@ -313,10 +313,12 @@ extern "C" int xw_disc_cotangent(const double* u, const double* v, const double*
 extern "C" int xw_adam(double* param, const double* gslabA, int nA, const double* gextraA, const double* gslabB, int nB,
                        const double* gextraB, const double* scal, double* m, double* v, long long* step, int bump_step,
                        int P, double lr, double beta1, double beta2, double eps, double* gsum_out, void* stream) {
+  // bump_step: 1 = this call advances the counter after the update; 0 = the counter was left alone (caller advances it
+  // later);  -1 = the counter was ALREADY advanced for this update (xw_losses ran first), use it as is
   if (!param || !m || !v || !step || P <= 0 || nA < 0 || nB < 0 || (nA > 0 && !gslabA) || (nB > 0 && !gslabB)) return XW_E_ARG;
   hipLaunchKernelGGL(k_adam, dim3((P + 63) / 64), dim3(1024), 0, (hipStream_t)stream, param, gslabA, nA, gextraA, gslabB,
-                     nB, gextraB, scal, m, v, step, P, lr, beta1, beta2, eps, gsum_out);
-  if (bump_step) hipLaunchKernelGGL(k_step_inc, dim3(1), dim3(1), 0, (hipStream_t)stream, step);
+                     nB, gextraB, scal, m, v, step, bump_step < 0 ? 1 : 0, P, lr, beta1, beta2, eps, gsum_out);
+  if (bump_step > 0) hipLaunchKernelGGL(k_step_inc, dim3(1), dim3(1), 0, (hipStream_t)stream, step);
   return xw_launch_status();
 }
 
@@ -326,7 +328,7 @@ extern "C" int xw_slab_sum(const double* gslab, int nslab, int P, int accumulate
   return xw_launch_status();
 }
 
-extern "C" int xw_abi_version(void) { return 7; }
+extern "C" int xw_abi_version(void) { return 8; }
 extern "C" int xw_reduce_work_size(void) { return 3 * 1024 + 8; }
 
 extern "C" int xw_supported_dims(char* buf, int buflen) {

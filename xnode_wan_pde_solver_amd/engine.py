@@ -310,11 +310,10 @@ class Engine:
                         side 2 cotangent B = dI/du -> parameter sweep B          (after the forward and v)"""
         th = self.theta.data
         M = (self.method, self.H, self.K, self.m)
-        self.scal.zero_()
         e0 = self._mark()
         e_v = self._test_net(G, e0)
         joint = G.Nb and G.same_grid           # boundary paths on the interior's time grid: one launch for both
-        KN.ode_fwd_multi([self._job(G, 'i')] + ([self._job(G, 'b')] if joint else []), G.t, th, *M)
+        KN.ode_fwd_multi([self._job(G, 'i')] + ([self._job(G, 'b')] if joint else []), G.t, th, *M, zero16=self.scal)
         if G.Nb and not joint:
             KN.ode_fwd_multi([self._job(G, 'b')], G.tb, th, *M)
         self._reaction(G)
@@ -359,18 +358,18 @@ class Engine:
     def _gen_back(self, G):
         lr, st = self.config['u_rate'], self.adam_u
         acc = self.accum_u
+        KN.losses(self.scal, G.L, G.Lb, G.Vol, G.Nglob, G.Nbglob, self.alpha, step=st['step'])   # also advances the counter
         if self.world is None:
             KN.adam(self.theta.data, G.slabA, st['m'], st['v'], st['step'], lr, gslabB=G.slabB, scal=self.scal,
-                    gextraA=acc, gsum_out=self.grad_u, bump_step=False)
+                    gextraA=acc, gsum_out=self.grad_u, bump_step=-1)
         else:
             P = self.Pu
             if acc is not None:
                 self.pack_u[:P].add_(acc)
             KN.adam(self.theta.data, None, st['m'], st['v'], st['step'], lr, gextraA=self.pack_u[:P],
-                    gextraB=self.pack_u[P:2 * P], scal=self.scal, gsum_out=self.grad_u, bump_step=False)
+                    gextraB=self.pack_u[P:2 * P], scal=self.scal, gsum_out=self.grad_u, bump_step=-1)
         if acc is not None:
             acc.copy_(self.grad_u)
-        KN.losses(self.scal, G.L, G.Lb, G.Vol, G.Nglob, G.Nbglob, self.alpha, step=st['step'])
 
     def _v_fresh(self, G):
         """python-side bookkeeping (outside the captured graphs): are the test-network outputs of this group still those
@@ -396,10 +395,9 @@ class Engine:
     def _disc_front(self, G):
         th = self.theta.data
         M = (self.method, self.H, self.K, self.m)
-        self.scal.zero_()
         e0 = self._mark()
         e_v = self._test_net(G, e0)
-        KN.ode_fwd_multi([self._job(G, 'i')], G.t, th, *M)
+        KN.ode_fwd_multi([self._job(G, 'i')], G.t, th, *M, zero16=self.scal)
         self._reaction(G)
         KN.ode_bwd_multi([self._job(G, 'i', want_x=True)], G.t, th, *M, want_x=True, want_params=False)
         self._join(e_v)
@@ -416,16 +414,16 @@ class Engine:
     def _disc_back(self, G):
         lr, st = self.config['v_rate'], self.adam_v
         acc = self.accum_v
+        KN.losses(self.scal, G.L, G.Lb, G.Vol, G.Nglob, G.Nbglob, self.alpha, step=st['step'])
         if self.world is None:
             KN.adam(self.phi.data, G.slab_v, st['m'], st['v'], st['step'], lr, gextraA=acc, gsum_out=self.grad_v,
-                    bump_step=False)
+                    bump_step=-1)
         else:
             if acc is not None:
                 self.grad_v.add_(acc)
-            KN.adam(self.phi.data, None, st['m'], st['v'], st['step'], lr, gextraA=self.grad_v, bump_step=False)
+            KN.adam(self.phi.data, None, st['m'], st['v'], st['step'], lr, gextraA=self.grad_v, bump_step=-1)
         if acc is not None:
             acc.copy_(self.grad_v)
-        KN.losses(self.scal, G.L, G.Lb, G.Vol, G.Nglob, G.Nbglob, self.alpha, step=st['step'])
 
     def _disc_all(self, G):
         self._disc_front(G)

@@ -67,7 +67,7 @@ def ode_fwd(xT, t, start, theta, method, H, K, m, want_Y=True, u=None, Y=None):
     return u, Y
 
 
-def ode_fwd_multi(jobs, t, theta, method, H, K, m):
+def ode_fwd_multi(jobs, t, theta, method, H, K, m, zero16=None):
     """jobs: list of dicts(xT[d,N], start[N], u[L,N], Y[L,H,N] or None) -- all groups share t, theta; ONE launch"""
     _need_gpu()
     L = t.shape[0]
@@ -79,7 +79,8 @@ def ode_fwd_multi(jobs, t, theta, method, H, K, m):
         _chk(j['xT'], F64, (d, N), 'xT'); _chk(j['start'], F64, (N,), 'start'); _chk(j['u'], F64, (L, N), 'u')
         _chk(j.get('Y'), F64, (L, H, N), 'Y')
         a.xT, a.start, a.u, a.Y, a.N = _p(j['xT']), _p(j['start']), _p(j['u']), _p(j.get('Y')), N
-    check(lib.xw_ode_fwd_multi(arr, len(jobs), _p(t), _p(theta), method, L, d, H, K, m, _stream()), 'xw_ode_fwd_multi')
+    _chk(zero16, F64, (16,), 'zero16')
+    check(lib.xw_ode_fwd_multi(arr, len(jobs), _p(t), _p(theta), method, L, d, H, K, m, _p(zero16), _stream()), 'xw_ode_fwd_multi')
 
 
 def ode_bwd_multi(jobs, t, theta, method, H, K, m, want_x, want_params):
@@ -271,7 +272,7 @@ def adam(param, gslabA, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, gextra
     _chk(gextraA, F64, (P,), 'gextraA'); _chk(gextraB, F64, (P,), 'gextraB'); _chk(gsum_out, F64, (P,), 'gsum_out')
     _chk(scal, F64, (16,), 'scal')
     check(lib.xw_adam(_p(param), _p(gslabA), nA, _p(gextraA), _p(gslabB), nB, _p(gextraB), _p(scal), _p(m), _p(v), _p(step),
-                      1 if bump_step else 0, P,
+                      (1 if bump_step is True else 0 if bump_step is False else int(bump_step)), P,
                       float(lr), float(beta1), float(beta2), float(eps), _p(gsum_out), _stream()), 'xw_adam')
 
 
