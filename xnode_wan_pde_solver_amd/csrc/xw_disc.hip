@@ -103,7 +103,9 @@ __global__ void __launch_bounds__(256, 2) k_disc_fwd(const double* __restrict__ 
     // order) also get the input gradient of v, by a reverse chain through the masks stashed below
     const bool want_grad = gxv != nullptr && tile * 16 < ngrad;         // wave-uniform
     d4 a[D::MT], ad[D::MT];
-    input_layer<W>(ph, o, xT, N, d, pt, a, ad);
+    const double* pht = ph;                                             // laundered: keeps the input-layer fragment
+    asm volatile("" : "+s"(pht));                                       // addresses out of the loop-invariant (spilled) set
+    input_layer<W>(pht, o, xT, N, d, pt, a, ad);
     for (int j = 0; j < q; ++j) {
       d4 nw[D::MT], nd[D::MT];
       unsigned int mask = 0;
@@ -157,7 +159,11 @@ __global__ void __launch_bounds__(256, 2) k_disc_fwd(const double* __restrict__ 
       if (vt != nullptr) vt[pt.p] = sd;
     }
     if (want_grad) {
-      // reverse chain: delta_j = relu'(a_j) .* (Vh^T delta_{j+1}); Vh^T fragments come from L2 (1 tile in L is affected)
+      // reverse chain: delta_j = relu'(a_j) .* (Vh^T delta_{j+1}); Vh^T fragments come from L2 (1 tile in L is affected).
+      // The base pointer is laundered so that the per-lane fragment addresses are formed HERE: hoisted out of the tile
+      // loop they spilled to scratch in every wave's prologue (17 MB of scratch writes per launch in the PMC pass).
+      const double* phg = ph;
+      asm volatile("" : "+s"(phg));
       d4 (&dl)[D::MT] = a;
       for (int j = q - 1; j >= 0; --j) {
         d4 nd[D::MT];
@@ -168,7 +174,7 @@ __global__ void __launch_bounds__(256, 2) k_disc_fwd(const double* __restrict__ 
           const double b = dl[ks >> 2][ks & 3];
           asm volatile("" ::: "memory");   // a few loads in flight, not all 52 (register pressure)
 #pragma unroll
-          for (int mt = 0; mt < D::MT; ++mt) nd[mt] = XW_MFMA(xw_fragAT(ph + o.Vh, W, W, W, 16 * mt, 4 * ks), b, nd[mt]);
+          for (int mt = 0; mt < D::MT; ++mt) nd[mt] = XW_MFMA(xw_fragAT(phg + o.Vh, W, W, W, 16 * mt, 4 * ks), b, nd[mt]);
         }
         const unsigned int mask = sMask[j][threadIdx.x];
 #pragma unroll
@@ -182,7 +188,7 @@ __global__ void __launch_bounds__(256, 2) k_disc_fwd(const double* __restrict__ 
 #pragma unroll
         for (int ks = 0; ks < D::KS; ++ks) {
           if ((ks & 3) == 0) asm volatile("" ::: "memory");
-          vv = XW_MFMA(xw_fragAT(ph + o.Vin + 1, o.ldin, W, d, 16 * rt, 4 * ks), dl[ks >> 2][ks & 3], vv);
+          vv = XW_MFMA(xw_fragAT(phg + o.Vin + 1, o.ldin, W, d, 16 * rt, 4 * ks), dl[ks >> 2][ks & 3], vv);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -193,7 +199,7 @@ __global__ void __launch_bounds__(256, 2) k_disc_fwd(const double* __restrict__ 
       double st_ = 0.0;
 #pragma unroll
       for (int mt = 0; mt < D::MT; ++mt) {
-        const d4 v0 = xw_vecD_strided(ph + o.Vin, o.ldin, W, 16 * mt);
+        const d4 v0 = xw_vecD_strided(phg + o.Vin, o.ldin, W, 16 * mt);
 #pragma unroll
         for (int r = 0; r < 4; ++r) st_ += v0[r] * dl[mt][r];
       }
