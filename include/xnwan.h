@@ -120,10 +120,12 @@ int xw_bdry_partials(const double* ub, const double* g, int Nb, int L, double al
  *   ubarA = pollution + alpha * 2 (u[0,n] - h_n) / Nglob at l = 0
  *   ubarB = dI/du = (V/N) v[L-1,n] at l = L-1  +  (V/(N L)) (c + u dc/du) v w
  *   d loss_u / d theta = J^T ubarA + (2 / I) J^T ubarB + (boundary sweep);  the 2/I is applied by xw_adam.
- * Either output may be NULL; basis A does not read v (it can be formed before the test network has run). */
+ * Either output may be NULL; basis A does not read v (it can be formed before the test network has run).
+ * scal != NULL (merged form, ubarB must be NULL): the global I = scal[0] is already known, ubarA := A + (2/I) B --
+ * one interior sweep instead of two (single-GPU path; the split form buys the single all-reduce on several GPUs). */
 int xw_gen_cotangents(const double* u, const double* v, const double* w, int w_per_point, const double* c,
                       const double* cp, double ckappa, const double* h, int N, int L, double Vol, double Nglob,
-                      double alpha, double pollution, double* ubarA, double* ubarB, void* stream);
+                      double alpha, double pollution, const double* scal, double* ubarA, double* ubarB, void* stream);
 /* discriminator cotangent on v (loss_v of src/loss.py:96 + the pollution of :60); reads I = scal_in[0], S = scal_in[1] */
 int xw_disc_cotangent(const double* u, const double* v, const double* w, int w_per_point, const double* c,
                       double ckappa, const double* f, const double* h, int N, int L, double Vol, double Nglob,

@@ -320,6 +320,27 @@ def test_test_net_reuse_is_exact(golden_dir):
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
+def test_split_and_merged_generator_cotangents_agree(golden_dir):
+    """the two generator schedules -- split bases A/B combined with 2/I inside Adam (one all-reduce on several GPUs) and
+    the single-GPU merged cotangent A + (2/I) B -- are the same gradient up to summation order"""
+    z, params = load(golden_dir, 'ref_plumb_midpoint')
+    outs = []
+    for split in (False, True):
+        S = make_solver(params, 0)
+        domain, pts = first_sample(S)
+        S.engine.split_cotangents = split
+        G = S.engine.load_group(pts.interioru, pts.interiorv, pts.boundary, domain)
+        S.engine.generator_step(G)
+        g1 = S.engine.grad_u.clone()
+        S.engine.generator_step(G)
+        S.engine.discriminator_step(G)
+        outs.append((g1, S.engine.theta.data.clone(), S.engine.phi.data.clone(), S.engine.scal.clone()))
+    a, b = outs
+    close(a[0], b[0], 1e-11, 1e-13 * float(b[0].abs().max()), 'gradient')
+    close(a[1], b[1], 1e-9, 1e-12, 'theta after two steps')
+    close(a[2], b[2], 1e-9, 1e-12, 'phi')
+
+
 def test_evaluation_off_the_boundary_matches_reference(golden_dir):
     """u_net on paths that start neither at T0 nor on the boundary: bound_pad / fillt densified grid (src/model.py:92-106)"""
     z, params = load(golden_dir, 'ref_boundpad')

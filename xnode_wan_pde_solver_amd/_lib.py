@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libxnwan.so')
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 c_f32p = ctypes.c_void_p   # coordinates / time grid: const double* (device)   [name kept from the float32 era]
 c_f64p = ctypes.c_void_p   # double*       (device)
@@ -48,7 +48,7 @@ SIGNATURES = {
     'xw_bdry_partials': [c_f64p, c_f64p, c_int, c_int, c_dbl, c_dbl, c_f64p, c_f64p, c_f64p, c_vp],
     'xw_reduce_work_size': [],
     'xw_gen_cotangents': [c_f64p, c_f64p, c_f64p, c_int, c_f64p, c_f64p, c_dbl, c_f64p, c_int, c_int, c_dbl, c_dbl, c_dbl,
-                          c_dbl, c_f64p, c_f64p, c_vp],
+                          c_dbl, c_f64p, c_f64p, c_f64p, c_vp],
     'xw_disc_cotangent': [c_f64p, c_f64p, c_f64p, c_int, c_f64p, c_dbl, c_f64p, c_f64p, c_int, c_int, c_dbl, c_dbl, c_dbl,
                           c_f64p, c_f64p, c_vp],
     'xw_losses': [c_f64p, c_int, c_int, c_dbl, c_dbl, c_dbl, c_dbl, c_i64p, c_vp],

@@ -149,24 +149,29 @@ __global__ void __launch_bounds__(256) k_gen_cots(const double* __restrict__ u, 
                                                   const double* __restrict__ c, const double* __restrict__ cp,
                                                   double ckappa, const double* __restrict__ h, int N, int L, double Vol,
                                                   double Nglob, double alpha, double pollution,
-                                                  double* __restrict__ ubarA, double* __restrict__ ubarB) {
+                                                  const double* __restrict__ scal, double* __restrict__ ubarA,
+                                                  double* __restrict__ ubarB) {
+  // scal != NULL: merged form -- the global I = scal[0] is known, write ubarA := A + (2/I) B (ubarB is not written)
+  const double cI = scal != nullptr ? 2.0 / scal[0] : 0.0;
   const double cN = Vol / Nglob, cNL = Vol / Nglob / (double)L;
   const long P = (long)N * L;
   for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (long)gridDim.x * blockDim.x) {
     const int l = (int)(p / N), n = (int)(p - (long)l * N);
     const double ul = u[p];
-    const double vl = ubarB != nullptr ? v[p] : 0.0;   // basis A does not read the test network at all
+    const bool needB = ubarB != nullptr || scal != nullptr;
+    const double vl = needB ? v[p] : 0.0;              // basis A does not read the test network at all
     const double wl = w_per_point ? w[p] : w[n];
     const double dcu = c != nullptr ? c[p] + ul * cp[p] : 2.0 * ckappa * ul;   // d(c(u) u)/du
-    if (ubarB != nullptr) {
-      double gB = cNL * dcu * vl * wl;                 // through c u phi  (src/loss.py:70)
+    double gB = 0.0;
+    if (needB) {
+      gB = cNL * dcu * vl * wl;                        // through c u phi  (src/loss.py:70)
       if (l == L - 1) gB += cN * vl;                   // through s1       (src/loss.py:64)
-      ubarB[p] = gB;
+      if (ubarB != nullptr) ubarB[p] = gB;
     }
     if (ubarA != nullptr) {
       double gA = pollution;                           // helper backward  (src/loss.py:55)
       if (l == 0) gA += alpha * 2.0 * (ul - h[n]) / Nglob;   // initial penalty  (src/loss.py:79,93)
-      ubarA[p] = gA;
+      ubarA[p] = gA + cI * gB;
     }
   }
 }
@@ -286,11 +291,13 @@ extern "C" int xw_bdry_partials(const double* ub, const double* g, int Nb, int L
 
 extern "C" int xw_gen_cotangents(const double* u, const double* v, const double* w, int w_per_point, const double* c,
                                  const double* cp, double ckappa, const double* h, int N, int L, double Vol, double Nglob,
-                                 double alpha, double pollution, double* ubarA, double* ubarB, void* stream) {
-  if (!u || !w || !h || (!ubarA && !ubarB) || (ubarB && !v) || N <= 0 || L <= 0) return XW_E_ARG;
+                                 double alpha, double pollution, const double* scal, double* ubarA, double* ubarB,
+                                 void* stream) {
+  if (!u || !w || !h || (!ubarA && !ubarB) || ((ubarB || scal) && !v) || (scal && (!ubarA || ubarB)) || N <= 0 || L <= 0)
+    return XW_E_ARG;
   if ((c == nullptr) != (cp == nullptr)) return XW_E_ARG;
   hipLaunchKernelGGL(k_gen_cots, dim3(blocks_for((long)N * L, 256, 2048)), dim3(256), 0, (hipStream_t)stream, u, v, w,
-                     w_per_point, c, cp, ckappa, h, N, L, Vol, Nglob, alpha, pollution, ubarA, ubarB);
+                     w_per_point, c, cp, ckappa, h, N, L, Vol, Nglob, alpha, pollution, scal, ubarA, ubarB);
   return xw_launch_status();
 }
 
@@ -328,7 +335,7 @@ extern "C" int xw_slab_sum(const double* gslab, int nslab, int P, int accumulate
   return xw_launch_status();
 }
 
-extern "C" int xw_abi_version(void) { return 8; }
+extern "C" int xw_abi_version(void) { return 9; }
 extern "C" int xw_reduce_work_size(void) { return 3 * 1024 + 8; }
 
 extern "C" int xw_supported_dims(char* buf, int buflen) {

@@ -108,6 +108,10 @@ class Engine:
         # opt-in: v, dv/dt, nabla_x v(t_0) of a group are reused while phi and the sample are unchanged (exact: the
         # reference recomputes identical values in every sub-step of an outer iteration).  Off by default.
         self.reuse_test_net = os.environ.get('XW_REUSE_V', '0') == '1'
+        # generator gradient: split cotangent bases (two interior sweeps that need no global scalar -> ONE all-reduce on
+        # several GPUs; sweep A overlaps the test network) or merged (wait for I, then one interior sweep: a quarter less
+        # sweep work but a longer critical path -- measured 1000 vs 1086 steps/s on the headline workload, so opt-in)
+        self.split_cotangents = world is not None or os.environ.get('XW_SPLIT_COT', '1') == '1'
         self._phi_version = 0
         self.side_contract = os.environ.get('XW_SIDE_CONTRACT', '0') == '1'   # measured slower (queue mapping)
         self.streams = [torch.cuda.Stream(device=device) for _ in range(4)]
@@ -302,6 +306,49 @@ class Engine:
     # generator sub-step (src/training.py:127-138)
     # ------------------------------------------------------------------------------------------------------------
     def _gen_front(self, G):
+        if self.split_cotangents:
+            self._gen_front_split(G)
+        else:
+            self._gen_front_merged(G)
+
+    def _gen_front_merged(self, G):
+        """opt-in single-GPU form (XW_SPLIT_COT=0): the interior parameter sweep waits for I and runs ONCE with
+        ubarA + (2/I) ubarB.
+        Kernel chains:  main   u-forward (interior + boundary, one launch) -> boundary residual -> [join] -> I ->
+                               merged cotangent -> interior parameter sweep
+                        side 0 test network v, dv/dt and (fused) nabla_x v(t_0)  (independent of theta)
+                        side 1 x-sweep (nabla_x u)                               (after the forward)
+                        side 2 boundary parameter sweep                          (after the boundary residual)"""
+        th = self.theta.data
+        M = (self.method, self.H, self.K, self.m)
+        e0 = self._mark()
+        e_v = self._test_net(G, e0)
+        joint = G.Nb and G.same_grid
+        KN.ode_fwd_multi([self._job(G, 'i')] + ([self._job(G, 'b')] if joint else []), G.t, th, *M, zero16=self.scal)
+        if G.Nb and not joint:
+            KN.ode_fwd_multi([self._job(G, 'b')], G.tb, th, *M)
+        self._reaction(G)
+        e_f = self._mark()
+        with self._side(1, e_f):
+            KN.ode_bwd_multi([self._job(G, 'i', want_x=True)], G.t, th, *M, want_x=True, want_params=False)
+            e_x = self._mark()
+        e_b = None
+        if G.Nb:
+            KN.bdry_partials(G.ub, G.g, self.alpha, G.Nbglob, self.scal, G.work_b, ubar_b=G.ubar_b)
+            e_r = self._mark()
+            with self._side(2, e_r):
+                KN.ode_bwd_multi([self._job(G, 'b', G.ubar_b, G.slabA[G.ns_u:])], G.t if joint else G.tb, th, *M,
+                                 want_x=False, want_params=True)
+                e_b = self._mark()
+        self._join(e_x, e_v)
+        self._contract(G)                                        # -> scal[0..2]
+        KN.gen_cotangents(G.u, G.v, G.w, G.h, G.Vol, G.Nglob, self.alpha, G.ubarA, None, c=G.c, cp=G.cp, ckappa=G.ck,
+                          pollution=self.pollution, scal=self.scal)
+        KN.ode_bwd_multi([self._job(G, 'i', G.ubarA, G.slabA[:G.ns_u])], G.t, th, *M, want_x=False, want_params=True)
+        if e_b is not None:
+            self._join(e_b)
+
+    def _gen_front_split(self, G):
         """everything up to (not including) the exchange: leaves slabA, slabB and scal[0..3] complete.
         Kernel chains:  main   u-forward (interior + boundary, one launch) -> cotangent A, boundary residual
                                -> parameter sweeps {interior/A, boundary} (one launch)
@@ -359,7 +406,10 @@ class Engine:
         lr, st = self.config['u_rate'], self.adam_u
         acc = self.accum_u
         KN.losses(self.scal, G.L, G.Lb, G.Vol, G.Nglob, G.Nbglob, self.alpha, step=st['step'])   # also advances the counter
-        if self.world is None:
+        if self.world is None and not self.split_cotangents:
+            KN.adam(self.theta.data, G.slabA, st['m'], st['v'], st['step'], lr, gextraA=acc, gsum_out=self.grad_u,
+                    bump_step=-1)
+        elif self.world is None:
             KN.adam(self.theta.data, G.slabA, st['m'], st['v'], st['step'], lr, gslabB=G.slabB, scal=self.scal,
                     gextraA=acc, gsum_out=self.grad_u, bump_step=-1)
         else:

@@ -222,7 +222,7 @@ def bdry_partials(ub, g, alpha, Nbglob, scal, work, ubar_b=None):
           'xw_bdry_partials')
 
 
-def gen_cotangents(u, v, w, h, Vol, Nglob, alpha, ubarA, ubarB, c=None, cp=None, ckappa=0.0, pollution=1.0):
+def gen_cotangents(u, v, w, h, Vol, Nglob, alpha, ubarA, ubarB, c=None, cp=None, ckappa=0.0, pollution=1.0, scal=None):
     """cotangent bases of the generator loss; pass ubarA=None or ubarB=None to form only one of them"""
     _need_gpu()
     if ubarA is None and ubarB is None:
@@ -231,9 +231,9 @@ def gen_cotangents(u, v, w, h, Vol, Nglob, alpha, ubarA, ubarB, c=None, cp=None,
     per_point = 1 if w.dim() == 2 else 0
     _chk(u, F64, (L, N), 'u'); _chk(v, F64, (L, N), 'v'); _chk(w, F64, (L, N) if per_point else (N,), 'w')
     _chk(c, F64, (L, N), 'c'); _chk(cp, F64, (L, N), 'cp'); _chk(h, F64, (N,), 'h')
-    _chk(ubarA, F64, (L, N), 'ubarA'); _chk(ubarB, F64, (L, N), 'ubarB')
+    _chk(ubarA, F64, (L, N), 'ubarA'); _chk(ubarB, F64, (L, N), 'ubarB'); _chk(scal, F64, (16,), 'scal')
     check(lib.xw_gen_cotangents(_p(u), _p(v), _p(w), per_point, _p(c), _p(cp), float(ckappa), _p(h), N, L, float(Vol),
-                                float(Nglob), float(alpha), float(pollution), _p(ubarA), _p(ubarB), _stream()),
+                                float(Nglob), float(alpha), float(pollution), _p(scal), _p(ubarA), _p(ubarB), _stream()),
           'xw_gen_cotangents')
 
 
