@@ -114,6 +114,7 @@ def test_first_iteration_against_reference_vectors(golden_dir, case):
     assert int(eng.adam_u['step'].item()) == 2 and int(eng.adam_v['step'].item()) == 1
     # value of I / int at the final parameters
     eng.use_graphs = False
+    G.skip_v = False
     eng._disc_front(G)
     scal = eng.scal.cpu().numpy()
     close(scal[0], float(z['final/I']), 1e-5)
@@ -302,14 +303,15 @@ def test_sphere_domain_trains_end_to_end(tmp_path):
     assert int(S.engine.adam_u['step'].item()) > 6            # one optimiser step per group, not per sub-iteration
 
 
-def test_test_net_reuse_is_exact(golden_dir):
-    """opt-in reuse of v, dv/dt, nabla_x v(t_0) while phi and the sample are unchanged gives bit-identical parameters"""
+def test_test_net_prefetch_and_reuse_are_exact(golden_dir):
+    """test network evaluated at the start of every sub-step (plain) == evaluated one sub-step ahead while phi and the
+    sample are unchanged (prefetch, the default) == opt-in reuse of one evaluation: bit-identical parameters"""
     z, params = load(golden_dir, 'ref_plumb_midpoint')
     outs = []
-    for reuse in (False, True):
+    for prefetch, reuse in ((False, False), (True, False), (False, True)):
         S = make_solver(params, 0)
         domain, pts = first_sample(S)
-        S.engine.reuse_test_net = reuse
+        S.engine.prefetch_test_net, S.engine.reuse_test_net = prefetch, reuse
         G = S.engine.load_group(pts.interioru, pts.interiorv, pts.boundary, domain)
         for k in range(2):
             S.engine.generator_step(G)
@@ -317,7 +319,33 @@ def test_test_net_reuse_is_exact(golden_dir):
             S.engine.discriminator_step(G)
             G = S.engine.load_group(pts.interiorv, pts.interioru, pts.boundary, domain, into=G)      # "resample" in place
         outs.append((S.engine.theta.data.clone(), S.engine.phi.data.clone()))
-    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    for o in outs[1:]:
+        assert torch.equal(outs[0][0], o[0]) and torch.equal(outs[0][1], o[1])
+
+
+def test_prefetched_test_net_is_dropped_when_phi_moves_outside_the_engine(golden_dir):
+    """a prefetched v must not survive optimizer_v.step() / load_state_dict / in-place edits of the parameters"""
+    z, params = load(golden_dir, 'ref_tiny_midpoint')
+    S = make_solver(params, 7)
+    domain, pts = first_sample(S)
+    eng = S.engine
+    eng.prefetch_test_net = True
+    G = eng.load_group(pts.interioru, pts.interiorv, pts.boundary, domain)
+    eng.generator_step(G)                                    # leaves a prefetched v for the current phi
+    with torch.no_grad():
+        for p_ in S.v_net.parameters():
+            p_.mul_(1.25)                                    # torch-side write: bumps the blob's version counter
+    eng.generator_step(G)
+    th1 = eng.theta.data.clone()
+    S2 = make_solver(params, 7)
+    G2 = S2.engine.load_group(pts.interioru, pts.interiorv, pts.boundary, domain)
+    S2.engine.prefetch_test_net = False
+    S2.engine.generator_step(G2)
+    with torch.no_grad():
+        for p_ in S2.v_net.parameters():
+            p_.mul_(1.25)
+    S2.engine.generator_step(G2)
+    assert torch.equal(th1, S2.engine.theta.data)
 
 
 def test_split_and_merged_generator_cotangents_agree(golden_dir):

@@ -104,7 +104,7 @@ __device__ __forceinline__ void load_field_T(const double* __restrict__ th, cons
 
 // F([x, t, y]) of src/model.py:153-156: z0 = Win [x;t;y] + b (x part pre-contracted into xp), (m-1) tied ReLU layers,
 // tanh, output layer.  y/out: HT chain tiles.
-template <int H, int K, int M, bool SAVE>
+template <int H, int K, int M, bool SAVE, bool OUT = true>
 __device__ __forceinline__ void field_fwd(const FieldW<H, K>& w, double t, d4 xp, const d4 (&y)[Dim<H, K>::HT],
                                           d4 (&out)[Dim<H, K>::HT], Save<M>& sv) {
   typedef Dim<H, K> D;
@@ -124,6 +124,7 @@ __device__ __forceinline__ void field_fwd(const FieldW<H, K>& w, double t, d4 xp
 #pragma unroll
   for (int ks = 0; ks < D::KSK; ++ks) a[ks] = xw_tanh(z[ks]);
   if (SAVE) sv.a = a;
+  if (!OUT) return;
 #pragma unroll
   for (int ht = 0; ht < D::HT; ++ht) {
     d4 o = w.bo[ht];
@@ -373,6 +374,50 @@ __device__ __forceinline__ void storeRowSums(double* dst, int rows, int r0, d4 q
   }
 }
 
+// what the reverse of one step l -> l+1 needs from the forward pass: the stage inputs and the stage activations
+template <int H, int K, int M, int S> struct Rec {
+  d4 yi[S][Dim<H, K>::HT];
+  Save<M> sv[S];
+};
+template <int H, int K>
+__device__ __forceinline__ void load_ckpt(const double* __restrict__ Y, int l, int N, int ncl, d4 (&y)[Dim<H, K>::HT]) {
+  const int g = xw_lane() >> 4;
+#pragma unroll
+  for (int ht = 0; ht < Dim<H, K>::HT; ++ht)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * ht + g + 4 * r;
+      y[ht][r] = row < H ? Y[((long)l * H + row) * N + ncl] : 0.0;
+    }
+}
+// rebuild the stages of step l -> l+1 from the checkpoint y_l (no dependence on any cotangent)
+template <int H, int K, int M, int METHOD>
+__device__ __forceinline__ void recompute(const FieldW<H, K>& w, d4 xp, const double* __restrict__ Y,
+                                          const double* __restrict__ tf, int l, int N, int ncl,
+                                          Rec<H, K, M, RK<METHOD>::S>& R) {
+  typedef Dim<H, K> D;
+  typedef RK<METHOD> T;
+  const double t0 = tf[l], dt = tf[l + 1] - t0;
+  d4 k[T::S][D::HT];
+  load_ckpt<H, K>(Y, l, N, ncl, R.yi[0]);
+#pragma unroll
+  for (int i = 0; i < T::S; ++i) {
+    if (i > 0) {
+#pragma unroll
+      for (int ht = 0; ht < D::HT; ++ht) {
+        R.yi[i][ht] = R.yi[0][ht];
+#pragma unroll
+        for (int j = 0; j < i; ++j)
+          if (T::a(i, j) != 0.0) R.yi[i][ht] += (dt * T::a(i, j)) * k[j][ht];
+      }
+    }
+    if (i < T::S - 1)
+      field_fwd<H, K, M, true, true>(w, t0 + T::c(i) * dt, xp, R.yi[i], k[i], R.sv[i]);
+    else
+      field_fwd<H, K, M, true, false>(w, t0 + T::c(i) * dt, xp, R.yi[i], k[i], R.sv[i]);   // last stage: activations only
+  }
+}
+
 template <int H, int K, int M, int METHOD, bool PARAMS>
 __global__ void __launch_bounds__(64) k_ode_bwd(const BwdJobs jobs, const double* __restrict__ tf,
                                                 const double* __restrict__ th, int L, int d) {
@@ -418,71 +463,118 @@ __global__ void __launch_bounds__(64) k_ode_bwd(const BwdJobs jobs, const double
   for (int ht = 0; ht < D::HT; ++ht) lam[ht] = xw_zero4();
   d4 xpb = xw_zero4();
 
-  for (int l = L - 1; l >= 0; --l) {
-    d4 y[D::HT];
+  if constexpr (T::S <= 2) {
+    Rec<H, K, M, T::S> cur;
+    for (int l = L - 1; l >= 0; --l) {
+      d4 yl[D::HT];
+      if (l < L - 1) {
+        // reverse of the step l -> l+1 : lam holds the total cotangent of y_{l+1}.  Every stage is evaluated ONCE, its
+        // activations kept for the vector-Jacobian product (one wave per SIMD: the register file is ours).
+        recompute<H, K, M, METHOD>(w, xp, Y, tf, l, N, ncl, cur);
+        const double t0 = tf[l], dt = tf[l + 1] - t0;
+        d4 kb[T::S][D::HT], psum[D::HT];
 #pragma unroll
-    for (int ht = 0; ht < D::HT; ++ht)
+        for (int i = 0; i < T::S; ++i)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = 16 * ht + g + 4 * r;
-        y[ht][r] = row < H ? Y[((long)l * H + row) * N + ncl] : 0.0;
+          for (int ht = 0; ht < D::HT; ++ht) {
+            kb[i][ht] = (dt * T::b(i)) * lam[ht];
+            if (i == 0) psum[ht] = xw_zero4();
+          }
+#pragma unroll
+        for (int i = T::S - 1; i >= 0; --i) {
+          d4 psi[D::HT];
+          field_vjp<H, K, M, PARAMS>(w, wT, t0 + T::c(i) * dt, cur.sv[i], cur.yi[i], kb[i], psi, xpb, G, lds);
+#pragma unroll
+          for (int ht = 0; ht < D::HT; ++ht) {
+            psum[ht] += psi[ht];
+#pragma unroll
+            for (int j = 0; j < i; ++j)
+              if (T::a(i, j) != 0.0) kb[j][ht] += (dt * T::a(i, j)) * psi[ht];
+          }
+        }
+#pragma unroll
+        for (int ht = 0; ht < D::HT; ++ht) {
+          lam[ht] += psum[ht];
+          yl[ht] = cur.yi[0][ht];                        // stage 0's input is y_l itself
+        }
+      } else {
+        load_ckpt<H, K>(Y, l, N, ncl, yl);
       }
-    if (l < L - 1) {
-      // reverse of the step l -> l+1 : lam currently holds the total cotangent of y_{l+1}
-      const double t0 = tf[l], dt = tf[l + 1] - t0;
-      d4 k[T::S][D::HT], kb[T::S][D::HT], psum[D::HT];
-      Save<M> sv;
+      const double ub = valid ? (ubar != nullptr ? ubar[(long)l * N + base + n] : 1.0) : 0.0;
 #pragma unroll
-      for (int i = 0; i < T::S - 1; ++i) {      // stage derivatives needed to rebuild the later stage inputs
-        d4 yi[D::HT];
-#pragma unroll
-        for (int ht = 0; ht < D::HT; ++ht) {
-          yi[ht] = y[ht];
-#pragma unroll
-          for (int j = 0; j < i; ++j)
-            if (T::a(i, j) != 0.0) yi[ht] += (dt * T::a(i, j)) * k[j][ht];
-        }
-        field_fwd<H, K, M, false>(w, t0 + T::c(i) * dt, xp, yi, k[i], sv);
+      for (int ht = 0; ht < D::HT; ++ht) {
+        lam[ht] += flw[ht] * ub;
+        if (PARAMS) accFL[ht] += yl[ht] * ub;
       }
-#pragma unroll
-      for (int i = 0; i < T::S; ++i)
-#pragma unroll
-        for (int ht = 0; ht < D::HT; ++ht) {
-          kb[i][ht] = (dt * T::b(i)) * lam[ht];
-          if (i == 0) psum[ht] = xw_zero4();
-        }
-#pragma unroll
-      for (int i = T::S - 1; i >= 0; --i) {
-        d4 yi[D::HT], ko[D::HT], psi[D::HT];
-#pragma unroll
-        for (int ht = 0; ht < D::HT; ++ht) {
-          yi[ht] = y[ht];
-#pragma unroll
-          for (int j = 0; j < i; ++j)
-            if (T::a(i, j) != 0.0) yi[ht] += (dt * T::a(i, j)) * k[j][ht];
-        }
-        const double ti = t0 + T::c(i) * dt;
-        field_fwd<H, K, M, true>(w, ti, xp, yi, ko, sv);
-        field_vjp<H, K, M, PARAMS>(w, wT, ti, sv, yi, kb[i], psi, xpb, G, lds);
-#pragma unroll
-        for (int ht = 0; ht < D::HT; ++ht) {
-          psum[ht] += psi[ht];
-#pragma unroll
-          for (int j = 0; j < i; ++j)
-            if (T::a(i, j) != 0.0) kb[j][ht] += (dt * T::a(i, j)) * psi[ht];
-        }
-      }
-#pragma unroll
-      for (int ht = 0; ht < D::HT; ++ht) lam[ht] += psum[ht];
+      if (PARAMS) accFLb += ub;
     }
-    // read-out u_l = FL y_l + b
-    const double ub = valid ? (ubar != nullptr ? ubar[(long)l * N + base + n] : 1.0) : 0.0;
-#pragma unroll
-    for (int ht = 0; ht < D::HT; ++ht) {
-      lam[ht] += flw[ht] * ub;
-      if (PARAMS) accFL[ht] += y[ht] * ub;
+  } else {
+    for (int l = L - 1; l >= 0; --l) {
+      d4 y[D::HT];
+  #pragma unroll
+      for (int ht = 0; ht < D::HT; ++ht)
+  #pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * ht + g + 4 * r;
+          y[ht][r] = row < H ? Y[((long)l * H + row) * N + ncl] : 0.0;
+        }
+      if (l < L - 1) {
+        // reverse of the step l -> l+1 : lam currently holds the total cotangent of y_{l+1}
+        const double t0 = tf[l], dt = tf[l + 1] - t0;
+        d4 k[T::S][D::HT], kb[T::S][D::HT], psum[D::HT];
+        Save<M> sv;
+  #pragma unroll
+        for (int i = 0; i < T::S - 1; ++i) {      // stage derivatives needed to rebuild the later stage inputs
+          d4 yi[D::HT];
+  #pragma unroll
+          for (int ht = 0; ht < D::HT; ++ht) {
+            yi[ht] = y[ht];
+  #pragma unroll
+            for (int j = 0; j < i; ++j)
+              if (T::a(i, j) != 0.0) yi[ht] += (dt * T::a(i, j)) * k[j][ht];
+          }
+          field_fwd<H, K, M, false>(w, t0 + T::c(i) * dt, xp, yi, k[i], sv);
+        }
+  #pragma unroll
+        for (int i = 0; i < T::S; ++i)
+  #pragma unroll
+          for (int ht = 0; ht < D::HT; ++ht) {
+            kb[i][ht] = (dt * T::b(i)) * lam[ht];
+            if (i == 0) psum[ht] = xw_zero4();
+          }
+  #pragma unroll
+        for (int i = T::S - 1; i >= 0; --i) {
+          d4 yi[D::HT], ko[D::HT], psi[D::HT];
+  #pragma unroll
+          for (int ht = 0; ht < D::HT; ++ht) {
+            yi[ht] = y[ht];
+  #pragma unroll
+            for (int j = 0; j < i; ++j)
+              if (T::a(i, j) != 0.0) yi[ht] += (dt * T::a(i, j)) * k[j][ht];
+          }
+          const double ti = t0 + T::c(i) * dt;
+          field_fwd<H, K, M, true>(w, ti, xp, yi, ko, sv);
+          field_vjp<H, K, M, PARAMS>(w, wT, ti, sv, yi, kb[i], psi, xpb, G, lds);
+  #pragma unroll
+          for (int ht = 0; ht < D::HT; ++ht) {
+            psum[ht] += psi[ht];
+  #pragma unroll
+            for (int j = 0; j < i; ++j)
+              if (T::a(i, j) != 0.0) kb[j][ht] += (dt * T::a(i, j)) * psi[ht];
+          }
+        }
+  #pragma unroll
+        for (int ht = 0; ht < D::HT; ++ht) lam[ht] += psum[ht];
+      }
+      // read-out u_l = FL y_l + b
+      const double ub = valid ? (ubar != nullptr ? ubar[(long)l * N + base + n] : 1.0) : 0.0;
+  #pragma unroll
+      for (int ht = 0; ht < D::HT; ++ht) {
+        lam[ht] += flw[ht] * ub;
+        if (PARAMS) accFL[ht] += y[ht] * ub;
+      }
+      if (PARAMS) accFLb += ub;
     }
-    if (PARAMS) accFLb += ub;
   }
 
   // ---- x-projection: cotangent of x, gradients of Win[:, :d] and Win.b -----------------------------------------

@@ -108,6 +108,12 @@ class Engine:
         # opt-in: v, dv/dt, nabla_x v(t_0) of a group are reused while phi and the sample are unchanged (exact: the
         # reference recomputes identical values in every sub-step of an outer iteration).  Off by default.
         self.reuse_test_net = os.environ.get('XW_REUSE_V', '0') == '1'
+        # opt-in (measured neutral: 1084 vs 1106 steps/s, the sweeps fill the register files): software pipelining of the test network.  A generator sub-step leaves phi untouched, so once the
+        # consumers of v in it are done it evaluates v AGAIN for the sub-step that follows (same phi, same sample), next
+        # to its own parameter sweep B -- which occupies a quarter of the SIMDs.  Every sub-step still pays for one
+        # evaluation, none is skipped, values are bit-identical; a prefetch is wasted only when a resample follows.
+        self.prefetch_test_net = os.environ.get('XW_PREFETCH_V', '0') == '1'
+        self.v_blocks = int(os.environ.get('XW_V_BLOCKS', '0'))           # resident blocks of the test-network launch (0: all)
         # generator gradient: split cotangent bases (two interior sweeps that need no global scalar -> ONE all-reduce on
         # several GPUs; sweep A overlaps the test network) or merged (wait for I, then one interior sweep: a quarter less
         # sweep work but a longer critical path -- measured 1000 vs 1086 steps/s on the headline workload, so opt-in)
@@ -255,15 +261,19 @@ class Engine:
     def _test_net(self, G, e0):
         """test network on side stream 0: v, dv/dt at all points; nabla_x v at the first time index rides along in the
         same launch (fused reverse chain).  Returns the completion event."""
-        ph = self.phi.data
-        if getattr(G, 'skip_v', False):          # reuse_test_net: v, dv/dt, nabla_x v(t_0) are still valid (see _v_fresh)
+        if getattr(G, 'skip_v', False):          # v, dv/dt, nabla_x v(t_0) in the buffers are still valid (see _v_fresh)
             return e0
-        with self._side(0, e0):
+        return self._launch_test_net(G, e0)
+
+    def _launch_test_net(self, G, *events, side=0):
+        ph = self.phi.data
+        with self._side(side, *events):
             if G.tpp is not None:
                 KN.disc_fwd(G.xvT_pts, None, ph, self.W, self.q, tpp=G.tpp, v=G.v.view(1, -1), vt=G.vt.view(1, -1),
-                            gxv=G.gxv, gtv=G.gtv, ngrad=G.N)
+                            gxv=G.gxv, gtv=G.gtv, ngrad=G.N, max_blocks=self.v_blocks)
             else:
-                KN.disc_fwd(G.xvT, G.t, ph, self.W, self.q, v=G.v, vt=G.vt, gxv=G.gxv, gtv=G.gtv, ngrad=G.N)
+                KN.disc_fwd(G.xvT, G.t, ph, self.W, self.q, v=G.v, vt=G.vt, gxv=G.gxv, gtv=G.gtv, ngrad=G.N,
+                            max_blocks=self.v_blocks)
             return self._mark()
 
     def _reaction(self, G):
@@ -305,11 +315,21 @@ class Engine:
     # ------------------------------------------------------------------------------------------------------------
     # generator sub-step (src/training.py:127-138)
     # ------------------------------------------------------------------------------------------------------------
-    def _gen_front(self, G):
+    def _gen_front(self, G, join_prefetch=True):
         if self.split_cotangents:
-            self._gen_front_split(G)
+            e_p = self._gen_front_split(G)
         else:
-            self._gen_front_merged(G)
+            e_p = self._gen_front_merged(G)
+        if e_p is not None and join_prefetch:
+            self._join(e_p)
+        return e_p
+
+    def _gen_all(self, G):
+        """single GPU: the whole generator sub-step is one graph, and Adam does not wait for the prefetch"""
+        e_p = self._gen_front(G, join_prefetch=False)
+        self._gen_back(G)
+        if e_p is not None:
+            self._join(e_p)
 
     def _gen_front_merged(self, G):
         """opt-in single-GPU form (XW_SPLIT_COT=0): the interior parameter sweep waits for I and runs ONCE with
@@ -344,9 +364,12 @@ class Engine:
         self._contract(G)                                        # -> scal[0..2]
         KN.gen_cotangents(G.u, G.v, G.w, G.h, G.Vol, G.Nglob, self.alpha, G.ubarA, None, c=G.c, cp=G.cp, ckappa=G.ck,
                           pollution=self.pollution, scal=self.scal)
+        e_c = self._mark()
         KN.ode_bwd_multi([self._job(G, 'i', G.ubarA, G.slabA[:G.ns_u])], G.t, th, *M, want_x=False, want_params=True)
+        e_p = self._launch_test_net(G, e_c, side=3) if getattr(G, 'prefetch_v', False) else None
         if e_b is not None:
             self._join(e_b)
+        return e_p
 
     def _gen_front_split(self, G):
         """everything up to (not including) the exchange: leaves slabA, slabB and scal[0..3] complete.
@@ -377,6 +400,7 @@ class Engine:
         with self._side(2, e_f, e_v):
             KN.gen_cotangents(G.u, G.v, G.w, G.h, G.Vol, G.Nglob, self.alpha, None, G.ubarB, c=G.c, cp=G.cp, ckappa=G.ck,
                               pollution=self.pollution)
+            e_cB = self._mark()
             KN.ode_bwd_multi([self._job(G, 'i', G.ubarB, G.slabB)], G.t, th, *M, want_x=False, want_params=True)
             e_B = self._mark()
         KN.gen_cotangents(G.u, None, G.w, G.h, G.Vol, G.Nglob, self.alpha, G.ubarA, None, c=G.c, cp=G.cp, ckappa=G.ck,
@@ -390,7 +414,11 @@ class Engine:
         self._join(e_x, e_v)
         if not self.side_contract:
             self._contract(G)
+        e_p = None
+        if getattr(G, 'prefetch_v', False):      # all readers of v, dv/dt, nabla_x v are done: evaluate it for the next sub-step
+            e_p = self._launch_test_net(G, self._mark(), e_cB, e_x, side=3)   # (a second fork of side 0 in one capture crashes hipStreamEndCapture)
         self._join(e_B)
+        return e_p
 
     def begin_substep(self, which, accumulate):
         """start of a generator ('u') / discriminator ('v') sub-iteration over several groups: zero the carried gradient"""
@@ -424,14 +452,26 @@ class Engine:
     def _v_fresh(self, G):
         """python-side bookkeeping (outside the captured graphs): are the test-network outputs of this group still those
         of the current phi and sample?  Sets G.skip_v for the front segment and returns the graph-key suffix."""
-        G.skip_v = self.reuse_test_net and getattr(G, 'v_version', None) == (self._phi_version, G.sample_version)
-        if not G.skip_v:
-            G.v_version = (self._phi_version, G.sample_version)
+        now = (self._phi_version, self.phi.data._version, G.sample_version)   # (engine steps, torch-side writes, resamples)
+        G.skip_v = (self.reuse_test_net or self.prefetch_test_net) and getattr(G, 'v_version', None) == now
+        G.v_version = now if (G.skip_v or self.reuse_test_net) else None     # without reuse only a prefetch validates
         return '_vcached' if G.skip_v else ''
+
+    def invalidate_test_net(self):
+        """phi was changed from outside the engine (optimizer_v.step(), load_state_dict, ...)"""
+        self._phi_version += 1
 
     def generator_step(self, G):
         """one pass of the generator sub-step body; loss_u is left in scal[4] (device)"""
-        self._run(G, 'gen_front' + self._v_fresh(G), self._gen_front)
+        sfx = self._v_fresh(G)
+        G.prefetch_v = self.prefetch_test_net and not self.reuse_test_net
+        if G.prefetch_v:
+            sfx += '_pf'
+            G.v_version = (self._phi_version, self.phi.data._version, G.sample_version)   # valid until phi / the sample move
+        if self.world is None:
+            self._run(G, 'gen' + sfx, self._gen_all)
+            return
+        self._run(G, 'gen_front' + sfx, self._gen_front)
         if self.world is not None:
             P = self.Pu
             KN.slab_sum(G.slabA, out=self.pack_u[:P])

@@ -75,8 +75,8 @@ class FusedAdam:
     fused HIP Adam kernel to the blob using the .grad of the parameters (for user code that went through autograd);
     the engine's own sub-steps call the same kernel with the slab gradients."""
 
-    def __init__(self, blob, state, lr):
-        self.blob, self.state, self.lr = blob, state, lr
+    def __init__(self, blob, state, lr, on_step=None):
+        self.blob, self.state, self.lr, self.on_step = blob, state, lr, on_step
         self.param_groups = [{'params': blob.params, 'lr': lr, 'betas': (0.9, 0.999), 'eps': 1e-8}]
 
     def zero_grad(self, set_to_none=True):
@@ -87,6 +87,8 @@ class FusedAdam:
         g = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self.blob.params])
         _adam_kernel(self.blob.data, None, self.state['m'], self.state['v'], self.state['step'],
                      self.param_groups[0]['lr'], gextraA=g.contiguous())
+        if self.on_step is not None:
+            self.on_step()
 
     def state_dict(self):
         return {'m': self.state['m'].clone(), 'v': self.state['v'].clone(), 'step': int(self.state['step'].item()),
@@ -129,7 +131,8 @@ class NODE_WAN_solver:
             funcs = dict(a=func_a, b=func_b, c=func_c, h=func_h, f=func_f, g=func_g)
             self.engine = Engine(self.config, s, self.u_net.module, self.v_net.module, funcs, self.device, world=world)
         self.optimizer_u = FusedAdam(self.u_net.module.blob, self.engine.adam_u, self.config['u_rate'])
-        self.optimizer_v = FusedAdam(self.v_net.module.blob, self.engine.adam_v, self.config['v_rate'])
+        self.optimizer_v = FusedAdam(self.v_net.module.blob, self.engine.adam_v, self.config['v_rate'],
+                                     on_step=self.engine.invalidate_test_net)
         self.best_l = float('inf')
         self.av_l = 0
         self.last_loss_u = self.last_loss_v = float('nan')
@@ -269,7 +272,7 @@ class NODE_WAN_solver:
         self.best_l = ck['best_l']
         torch.set_rng_state(ck['torch_rng'].cpu())
         np.random.set_state(ck['numpy_rng'])
-        self.engine._phi_version += 1                    # cached test-network outputs (reuse_test_net) are stale now
+        self.engine.invalidate_test_net()                # cached / prefetched test-network outputs are stale now
 
     def _is_main(self):
         return self.world is None or self.world.rank == 0
