@@ -145,10 +145,19 @@ __device__ __forceinline__ double xw_tanh(double x) {
 }
 
 // sum over the 4 lane groups g (lanes n, n+16, n+32, n+48): reduces the ROW index of a chain-layout partial
+// gfx950 lane-swap instructions (VALU, no LDS round trip): v_permlane16_swap exchanges the odd 16-lane rows of one
+// register with the even rows of the other, v_permlane32_swap the upper half with the lower half; fed the same value
+// twice they return (x[row ^ 1] pairs) resp. (x[half ^ 1] pairs), so two swaps + two adds leave the total in every lane.
 __device__ __forceinline__ double xw_sum_over_g(double x) {
-  x += __shfl_xor(x, 16);
-  x += __shfl_xor(x, 32);
-  return x;
+  typedef unsigned xw_u2 __attribute__((ext_vector_type(2)));
+  unsigned lo = __double2loint(x), hi = __double2hiint(x);
+  xw_u2 a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  xw_u2 b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  x = __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+  lo = __double2loint(x), hi = __double2hiint(x);
+  a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
 }
 // sum over the 16 columns n (lanes within a 16-lane row)
 __device__ __forceinline__ double xw_sum_over_n(double x) {

@@ -21,6 +21,11 @@ namespace {
 template <int W> struct VDim {
   static constexpr int MT = (W + 15) / 16;
   static constexpr int KS = (W + 3) / 4;
+  // rows of the last (partial) row tile.  A 16-row MFMA tile for 2 live rows (W = 50) is 13 x 2 wasted 64-cycle matrix
+  // instructions per layer: when the tail is short the forward kernel contracts those rows on the vector ALU instead.
+  static constexpr int TR = W - 16 * (MT - 1);
+  static constexpr bool VTAIL = TR <= 3;
+  static constexpr int MTF = VTAIL ? MT - 1 : MT;     // row tiles that go through the matrix pipe in k_disc_fwd
   static_assert(MT == 4, "the backward kernel maps the 4 row tiles of dVh onto the 4 waves of a block");
   static_assert((W % 16) != 0, "a padding row of the last tile carries the bias column of the outer products");
 };
@@ -81,13 +86,14 @@ __global__ void __launch_bounds__(256, 2) k_disc_fwd(const double* __restrict__ 
   // relu / tanh VALU work overlaps the other's matrix work.
   __shared__ double sVh[D::MT * D::KS * 64];
   __shared__ double sB[2 * 16 * D::MT];
+  __shared__ double sT[D::KS * 4 * (D::VTAIL ? D::TR : 1)];   // Vh[16 (MT-1) + r][4 ks + g]: the tail rows, per lane group
   __shared__ unsigned short sMask[XW_QMAX][256];   // ReLU masks (16 rows per lane) of the layers, for the fused reverse chain
   const int lane = xw_lane(), g = lane >> 4;
   const int wave = threadIdx.x >> 6;
   const VOff o = v_offsets(d, W);
   const long P = (long)N * L;
   const long ntiles = (P + 15) / 16;
-  for (int idx = wave; idx < D::MT * D::KS; idx += 4) {
+  for (int idx = wave; idx < D::MTF * D::KS; idx += 4) {
     const int mt = idx / D::KS, ks = idx - mt * D::KS;
     sVh[idx * 64 + lane] = xw_fragA(ph + o.Vh, W, W, W, 16 * mt, 4 * ks);
   }
@@ -95,6 +101,11 @@ __global__ void __launch_bounds__(256, 2) k_disc_fwd(const double* __restrict__ 
     sB[threadIdx.x] = (int)threadIdx.x < W ? ph[o.Vhb + threadIdx.x] : 0.0;
     sB[16 * D::MT + threadIdx.x] = (int)threadIdx.x < W ? ph[o.Vo + threadIdx.x] : 0.0;
   }
+  if (D::VTAIL)
+    for (int idx = threadIdx.x; idx < D::KS * 4 * D::TR; idx += blockDim.x) {
+      const int r = idx % D::TR, k = idx / D::TR;                        // k = 4 ks + g
+      sT[idx] = k < W ? ph[o.Vh + (long)(16 * (D::MT - 1) + r) * W + k] : 0.0;
+    }
   __syncthreads();
   const double vob = ph[o.Vob];
   for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long)gridDim.x * 4) {
@@ -119,6 +130,9 @@ __global__ void __launch_bounds__(256, 2) k_disc_fwd(const double* __restrict__ 
         nd[mt] = xw_zero4();
       }
       if (want_grad) sMask[j][threadIdx.x] = (unsigned short)mask;
+      double tv[D::TR], td[D::TR];                          // partial dot products of the tail rows (this lane's k = 4 ks + g)
+#pragma unroll
+      for (int r = 0; r < D::TR; ++r) tv[r] = td[r] = 0.0;
 #pragma unroll
       for (int ks = 0; ks < D::KS; ++ks) {
         const double av = a[ks >> 2][ks & 3];
@@ -126,11 +140,32 @@ __global__ void __launch_bounds__(256, 2) k_disc_fwd(const double* __restrict__ 
         const double bd = av > 0.0 ? ad[ks >> 2][ks & 3] : 0.0;
         if ((ks & 1) == 0) asm volatile("" ::: "memory");   // bound the LDS loads in flight (else all 52 are hoisted -> spills)
 #pragma unroll
-        for (int mt = 0; mt < D::MT; ++mt) {
+        for (int mt = 0; mt < D::MTF; ++mt) {
           const double w = sVh[(mt * D::KS + ks) * 64 + lane];
           nw[mt] = XW_MFMA(w, b, nw[mt]);
           nd[mt] = XW_MFMA(w, bd, nd[mt]);
         }
+        if (D::VTAIL) {
+#pragma unroll
+          for (int r = 0; r < D::TR; ++r) {
+            const double w = sT[(4 * ks + g) * D::TR + r];
+            tv[r] = fma(w, b, tv[r]);
+            td[r] = fma(w, bd, td[r]);
+          }
+        }
+      }
+      if (D::VTAIL) {   // row 16 (MT-1) + r of the chain layout lives in lane group g = r, register 0
+        d4 tw = xw_zero4(), tdd = xw_zero4();
+#pragma unroll
+        for (int r = 0; r < D::TR; ++r) {
+          const double sv_ = xw_sum_over_g(tv[r]) + nw[D::MT - 1][0], sd_ = xw_sum_over_g(td[r]);
+          if (g == r) {
+            tw[0] = sv_;
+            tdd[0] = sd_;
+          }
+        }
+        nw[D::MT - 1] = tw;
+        nd[D::MT - 1] = tdd;
       }
 #pragma unroll
       for (int mt = 0; mt < D::MT; ++mt) {
