@@ -13,6 +13,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 H, K, W, Q = 20, 10, 50, 9
+F64 = torch.float64
 
 
 def _cfg(m=8, solver='midpoint'):
@@ -185,6 +186,30 @@ def test_disc_backward(N, L, d):
         n = g_.numel()
         _close(got[off:off + n], g_.reshape(-1), 1e-10 * max(1.0, float(ref.abs().max()) / max(float(g_.abs().max()), 1e-300)), 'grad ' + k)
         off += n
+
+
+def test_generator_cotangents_split_and_merged_forms():
+    """ubarA (pollution + initial penalty), ubarB (= dI/du) and the merged form A + (2/I) B against the closed formulas
+    (src/loss.py:55,64,70,79,93)"""
+    from xnode_wan_pde_solver_amd import kernels as KN
+    torch.manual_seed(5)
+    L, N, Vol, Nglob, alpha, kappa = 6, 37, 2.5, 74.0, 1e3, -0.7
+    u, v = torch.randn(L, N, dtype=F64), torch.randn(L, N, dtype=F64)
+    w, h = torch.rand(N, dtype=F64), torch.randn(N, dtype=F64)
+    cN, cNL = Vol / Nglob, Vol / Nglob / L
+    refB = cNL * (2 * kappa * u) * v * w
+    refB[L - 1] += cN * v[L - 1]
+    refA = torch.ones(L, N, dtype=F64)
+    refA[0] += alpha * 2 * (u[0] - h) / Nglob
+    dev = lambda x: x.cuda()   # noqa: E731
+    A, B, Mg = (torch.empty(L, N, dtype=F64, device='cuda') for _ in range(3))
+    KN.gen_cotangents(dev(u), dev(v), dev(w), dev(h), Vol, Nglob, alpha, A, B, ckappa=kappa)
+    scal = torch.zeros(16, dtype=F64, device='cuda')
+    scal[0] = -1.7
+    KN.gen_cotangents(dev(u), dev(v), dev(w), dev(h), Vol, Nglob, alpha, Mg, None, ckappa=kappa, scal=scal)
+    np.testing.assert_allclose(A.cpu().numpy(), refA.numpy(), rtol=1e-13, atol=1e-13)
+    np.testing.assert_allclose(B.cpu().numpy(), refB.numpy(), rtol=1e-13, atol=1e-15)
+    np.testing.assert_allclose(Mg.cpu().numpy(), (refA + (2 / -1.7) * refB).numpy(), rtol=1e-13, atol=1e-13)
 
 
 def test_adam_matches_torch_formula():

@@ -24,5 +24,12 @@ for name, fn in (('gen', eng.generator_step), ('disc', eng.discriminator_step)):
     for _ in range(n):
         fn(G)
     torch.cuda.synchronize(); out[name] = 1e3 * (time.perf_counter() - t0) / n
+for _ in range(6):
+    eng.generator_step(G); eng.generator_step(G); eng.discriminator_step(G)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(n // 3):
+    eng.generator_step(G); eng.generator_step(G); eng.discriminator_step(G)
+torch.cuda.synchronize(); cycle_real = 1e3 * (time.perf_counter() - t0) / (n // 3)
+print('real cycle %.4f ms -> %.1f steps/s' % (cycle_real, 3e3 / cycle_real))
 print('v_blocks %s  gen %.4f ms  disc %.4f ms  cycle(g,g,d) %.4f ms -> %.1f steps/s' % (
     os.environ.get('XW_V_BLOCKS', '0'), out['gen'], out['disc'], 2 * out['gen'] + out['disc'], 3e3 / (2 * out['gen'] + out['disc'])))

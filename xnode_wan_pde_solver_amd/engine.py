@@ -108,20 +108,11 @@ class Engine:
         # opt-in: v, dv/dt, nabla_x v(t_0) of a group are reused while phi and the sample are unchanged (exact: the
         # reference recomputes identical values in every sub-step of an outer iteration).  Off by default.
         self.reuse_test_net = os.environ.get('XW_REUSE_V', '0') == '1'
-        # opt-in (measured neutral: 1084 vs 1106 steps/s, the sweeps fill the register files): software pipelining of the test network.  A generator sub-step leaves phi untouched, so once the
-        # consumers of v in it are done it evaluates v AGAIN for the sub-step that follows (same phi, same sample), next
-        # to its own parameter sweep B -- which occupies a quarter of the SIMDs.  Every sub-step still pays for one
-        # evaluation, none is skipped, values are bit-identical; a prefetch is wasted only when a resample follows.
-        self.prefetch_test_net = os.environ.get('XW_PREFETCH_V', '0') == '1'
         # The test network's launch is persistent (grid-stride over point tiles) and at 2 blocks per CU it owns every SIMD's
         # register file: the stepper's waves, launched next to it, then wait until it drains.  Capping it at 3/4 of the
         # resident slots leaves a quarter of the SIMDs to the stepper chains (measured: 1221 vs 1159 steps/s).
         cus = torch.cuda.get_device_properties(device).multi_processor_count
         self.v_blocks = int(os.environ.get('XW_V_BLOCKS', '0')) or (3 * 2 * cus) // 4
-        # generator gradient: split cotangent bases (two interior sweeps that need no global scalar -> ONE all-reduce on
-        # several GPUs; sweep A overlaps the test network) or merged (wait for I, then one interior sweep: a quarter less
-        # sweep work but a longer critical path -- measured 1000 vs 1086 steps/s on the headline workload, so opt-in)
-        self.split_cotangents = world is not None or os.environ.get('XW_SPLIT_COT', '1') == '1'
         self._phi_version = 0
         self.side_contract = os.environ.get('XW_SIDE_CONTRACT', '0') == '1'   # measured slower (queue mapping)
         self.streams = [torch.cuda.Stream(device=device) for _ in range(4)]
@@ -269,9 +260,9 @@ class Engine:
             return e0
         return self._launch_test_net(G, e0)
 
-    def _launch_test_net(self, G, *events, side=0):
+    def _launch_test_net(self, G, *events):
         ph = self.phi.data
-        with self._side(side, *events):
+        with self._side(0, *events):
             if G.tpp is not None:
                 KN.disc_fwd(G.xvT_pts, None, ph, self.W, self.q, tpp=G.tpp, v=G.v.view(1, -1), vt=G.vt.view(1, -1),
                             gxv=G.gxv, gtv=G.gtv, ngrad=G.N, max_blocks=self.v_blocks)
@@ -319,63 +310,12 @@ class Engine:
     # ------------------------------------------------------------------------------------------------------------
     # generator sub-step (src/training.py:127-138)
     # ------------------------------------------------------------------------------------------------------------
-    def _gen_front(self, G, join_prefetch=True):
-        if self.split_cotangents:
-            e_p = self._gen_front_split(G)
-        else:
-            e_p = self._gen_front_merged(G)
-        if e_p is not None and join_prefetch:
-            self._join(e_p)
-        return e_p
-
     def _gen_all(self, G):
-        """single GPU: the whole generator sub-step is one graph, and Adam does not wait for the prefetch"""
-        e_p = self._gen_front(G, join_prefetch=False)
+        """single GPU: the whole generator sub-step is one captured graph"""
+        self._gen_front(G)
         self._gen_back(G)
-        if e_p is not None:
-            self._join(e_p)
 
-    def _gen_front_merged(self, G):
-        """opt-in single-GPU form (XW_SPLIT_COT=0): the interior parameter sweep waits for I and runs ONCE with
-        ubarA + (2/I) ubarB.
-        Kernel chains:  main   u-forward (interior + boundary, one launch) -> boundary residual -> [join] -> I ->
-                               merged cotangent -> interior parameter sweep
-                        side 0 test network v, dv/dt and (fused) nabla_x v(t_0)  (independent of theta)
-                        side 1 x-sweep (nabla_x u)                               (after the forward)
-                        side 2 boundary parameter sweep                          (after the boundary residual)"""
-        th = self.theta.data
-        M = (self.method, self.H, self.K, self.m)
-        e0 = self._mark()
-        e_v = self._test_net(G, e0)
-        joint = G.Nb and G.same_grid
-        KN.ode_fwd_multi([self._job(G, 'i')] + ([self._job(G, 'b')] if joint else []), G.t, th, *M, zero16=self.scal)
-        if G.Nb and not joint:
-            KN.ode_fwd_multi([self._job(G, 'b')], G.tb, th, *M)
-        self._reaction(G)
-        e_f = self._mark()
-        with self._side(1, e_f):
-            KN.ode_bwd_multi([self._job(G, 'i', want_x=True)], G.t, th, *M, want_x=True, want_params=False)
-            e_x = self._mark()
-        e_b = None
-        if G.Nb:
-            KN.bdry_partials(G.ub, G.g, self.alpha, G.Nbglob, self.scal, G.work_b, ubar_b=G.ubar_b)
-            e_r = self._mark()
-            with self._side(2, e_r):
-                KN.ode_bwd_multi([self._job(G, 'b', G.ubar_b, G.slabA[G.ns_u:])], G.t if joint else G.tb, th, *M,
-                                 want_x=False, want_params=True)
-                e_b = self._mark()
-        self._join(e_x, e_v)
-        self._contract(G)                                        # -> scal[0..2]
-        KN.gen_cotangents(G.u, G.v, G.w, G.h, G.Vol, G.Nglob, self.alpha, G.ubarA, None, c=G.c, cp=G.cp, ckappa=G.ck,
-                          pollution=self.pollution, scal=self.scal)
-        e_c = self._mark()
-        KN.ode_bwd_multi([self._job(G, 'i', G.ubarA, G.slabA[:G.ns_u])], G.t, th, *M, want_x=False, want_params=True)
-        e_p = self._launch_test_net(G, e_c, side=3) if getattr(G, 'prefetch_v', False) else None
-        if e_b is not None:
-            self._join(e_b)
-        return e_p
-
-    def _gen_front_split(self, G):
+    def _gen_front(self, G):
         """everything up to (not including) the exchange: leaves slabA, slabB and scal[0..3] complete.
         Kernel chains:  main   u-forward (interior + boundary, one launch) -> cotangent A, boundary residual
                                -> parameter sweeps {interior/A, boundary} (one launch)
@@ -404,7 +344,6 @@ class Engine:
         with self._side(2, e_f, e_v):
             KN.gen_cotangents(G.u, G.v, G.w, G.h, G.Vol, G.Nglob, self.alpha, None, G.ubarB, c=G.c, cp=G.cp, ckappa=G.ck,
                               pollution=self.pollution)
-            e_cB = self._mark()
             KN.ode_bwd_multi([self._job(G, 'i', G.ubarB, G.slabB)], G.t, th, *M, want_x=False, want_params=True)
             e_B = self._mark()
         KN.gen_cotangents(G.u, None, G.w, G.h, G.Vol, G.Nglob, self.alpha, G.ubarA, None, c=G.c, cp=G.cp, ckappa=G.ck,
@@ -418,11 +357,7 @@ class Engine:
         self._join(e_x, e_v)
         if not self.side_contract:
             self._contract(G)
-        e_p = None
-        if getattr(G, 'prefetch_v', False):      # all readers of v, dv/dt, nabla_x v are done: evaluate it for the next sub-step
-            e_p = self._launch_test_net(G, self._mark(), e_cB, e_x, side=3)   # (a second fork of side 0 in one capture crashes hipStreamEndCapture)
         self._join(e_B)
-        return e_p
 
     def begin_substep(self, which, accumulate):
         """start of a generator ('u') / discriminator ('v') sub-iteration over several groups: zero the carried gradient"""
@@ -438,10 +373,7 @@ class Engine:
         lr, st = self.config['u_rate'], self.adam_u
         acc = self.accum_u
         KN.losses(self.scal, G.L, G.Lb, G.Vol, G.Nglob, G.Nbglob, self.alpha, step=st['step'])   # also advances the counter
-        if self.world is None and not self.split_cotangents:
-            KN.adam(self.theta.data, G.slabA, st['m'], st['v'], st['step'], lr, gextraA=acc, gsum_out=self.grad_u,
-                    bump_step=-1)
-        elif self.world is None:
+        if self.world is None:
             KN.adam(self.theta.data, G.slabA, st['m'], st['v'], st['step'], lr, gslabB=G.slabB, scal=self.scal,
                     gextraA=acc, gsum_out=self.grad_u, bump_step=-1)
         else:
@@ -457,8 +389,8 @@ class Engine:
         """python-side bookkeeping (outside the captured graphs): are the test-network outputs of this group still those
         of the current phi and sample?  Sets G.skip_v for the front segment and returns the graph-key suffix."""
         now = self._v_key(G)
-        G.skip_v = (self.reuse_test_net or self.prefetch_test_net) and getattr(G, 'v_version', None) == now
-        G.v_version = now if (G.skip_v or self.reuse_test_net) else None     # without reuse only a prefetch validates
+        G.skip_v = self.reuse_test_net and getattr(G, 'v_version', None) == now
+        G.v_version = now
         return '_vcached' if G.skip_v else ''
 
     def _v_key(self, G):
@@ -472,10 +404,6 @@ class Engine:
     def generator_step(self, G):
         """one pass of the generator sub-step body; loss_u is left in scal[4] (device)"""
         sfx = self._v_fresh(G)
-        G.prefetch_v = self.prefetch_test_net and not self.reuse_test_net
-        if G.prefetch_v:
-            sfx += '_pf'
-            G.v_version = self._v_key(G)                             # valid until phi or the sample move
         if self.world is None:
             self._run(G, 'gen' + sfx, self._gen_all)
             return
