@@ -58,6 +58,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--train-iters', type=int, default=100, help='outer iterations of real training (with resampling) for '
                     'the rel-L2 figure, outside the timed region; 0 disables')
+    ap.add_argument('--no-solo', action='store_true', help='skip the extra full-grid launches of the dominant kernel '
+                    '(roofline.solo_full_grid), so that a profiler run only sees production launches')
     args = ap.parse_args()
 
     import configs.Ex4_1_funcs as P
@@ -175,7 +177,7 @@ def main():
     roofline = {'bound': 'mfma', 'kernel': dominant, 'achieved': round(ach, 3), 'peak': PEAK_FP64_MATRIX_TFLOPS,
                 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_FP64_MATRIX_TFLOPS, 4), 'traffic': traffic,
                 'alg_flop_per_launch': alg_flops[dominant], 'avg_launch_ms': round(kern[dominant]['avg_ms'], 4)}
-    if dominant == 'disc_fwd':
+    if dominant == 'disc_fwd' and not args.no_solo:
         # The production launch above is capped at 3/4 of the resident block slots (Engine.v_blocks) so that the stepper's
         # waves find room next to it; the same kernel given the whole chip, for reference:
         roofline['launch_blocks'] = eng.v_blocks
