@@ -198,9 +198,16 @@ def main():
     gen_flops = 2.0 * (2 * Pn * macs_v + 4 * N * path_u + 3 * Nb * path_u)
     dis_flops = 2.0 * (3 * Pn * macs_v + 2 * N * path_u)
     step_flops = (2 * gen_flops + dis_flops) / 3.0
+    # SURVEY 8(d) asks for both fractions of the whole sub-step: FP64 (the binding one) and HBM (the reference layout's
+    # bytes X, XV, BX [*, L, d+1] f32 + ~48 B/point of [N, L] f64 side streams -- a few per cent at most by construction)
+    d_ = s['dim']
+    bytes_step = 4.0 * (d_ + 1) * (2 * Pn + Nb * s['N_t']) + 48.0 * Pn
+    per_gpu_rate = steps_per_s                             # weak scaling: every rank steps through its own shard
     whole = {'alg_gflop_per_step_avg': round(step_flops / 1e9, 2),
-             'achieved_tflops': round(step_flops * steps_per_s / 1e12, 3),
-             'frac_fp64_matrix_peak': round(step_flops * steps_per_s / 1e12 / PEAK_FP64_MATRIX_TFLOPS, 4)}
+             'achieved_tflops': round(step_flops * per_gpu_rate / 1e12, 3),
+             'frac_fp64_matrix_peak': round(step_flops * per_gpu_rate / 1e12 / PEAK_FP64_MATRIX_TFLOPS, 4),
+             'ref_layout_mbytes_per_step': round(bytes_step / 1e6, 1),
+             'frac_hbm_peak': round(bytes_step * per_gpu_rate / 8.0e12, 5)}
 
     # ---- opt-in exact optimisation, reported separately: reuse v, dv/dt, nabla_x v(t_0) while phi is unchanged ----------
     if world is None:
