@@ -59,7 +59,11 @@ int xw_ode_bwd_slabs(int N);
 /* Reverse sweep through the discrete stepper (autograd replacement for src/loss.py:55 and src/training.py:137).
  * ubar[L,N]: cotangent on u (NULL = all ones).
  * mode bit 0: produce gx[d,N] = d<ubar,u>/dx_n  and gs[N] = d<ubar,u>/d start_n     (nabla_x u of src/loss.py:56-58)
- * mode bit 1: produce parameter-gradient slabs gslab[xw_ode_bwd_slabs(N)][P_u] (to be summed by xw_adam / xw_slab_sum) */
+ * mode bit 1: produce parameter-gradient slabs gslab[xw_ode_bwd_slabs(N)][P_u] (to be summed by xw_adam / xw_slab_sum)
+ * mode bit 2 (only with bits 0 and 1): the caller guarantees ubar == 1 at every time index >= 1; gx, gs are then
+ *   returned for the ALL-ONES cotangent (the helper backward of src/loss.py:55) while the parameter gradients use ubar
+ *   itself -- the pollution sweep and the nabla_x u sweep of a generator sub-step are the same adjoint, run once.
+ *   In the multi-group form jobs with gx == gs == NULL simply produce no x outputs. */
 int xw_ode_bwd(const double* xT, const double* t, const double* start, const double* theta, const double* Y,
                const double* ubar, int method, int N, int L, int d, int H, int K, int m, int mode,
                double* gx, double* gs, double* gslab, void* stream);

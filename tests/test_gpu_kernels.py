@@ -128,6 +128,36 @@ def test_ode_backward(N, L, d, solver, ones):
     _close(gth, ref, 1e-10, 'theta grad (whole blob)')
 
 
+@pytest.mark.parametrize('solver', ['euler', 'midpoint', 'rk4'])
+def test_ode_backward_pollution_and_x_sweep_in_one(solver):
+    """mode 7: cotangent = ones + (initial-value term at time index 0).  One sweep must return the parameter gradient of
+    that cotangent AND the x / start gradients of the all-ones cotangent (the helper backward of src/loss.py:55),
+    for two groups in one launch, the second without x outputs."""
+    from xnode_wan_pde_solver_amd import kernels as KN
+    N, L, d = 37, 6, 20
+    theta, _ = _params(d, 8, 31)
+    x, t, _ = _sample(N, L, d, 32)
+    g = torch.Generator().manual_seed(33)
+    start = torch.randn(N, dtype=F64, generator=g)
+    ubar = torch.ones(L, N, dtype=F64)
+    ubar[0] += 50.0 * torch.randn(N, dtype=F64, generator=g)
+    xT, tc, sc, blob = x.double().t().contiguous().cuda(), t.double().cuda(), start.cuda(), _blob(theta, U_ORDER)
+    mid = KN.method_id(solver)
+    u, Y = KN.ode_fwd(xT, tc, sc, blob, mid, H, K, 8)
+    ub = ubar.cuda()
+    gx1, gs1, _ = KN.ode_bwd(xT, tc, sc, blob, Y, None, mid, H, K, 8, want_x=True, want_params=False)
+    _, _, slab1 = KN.ode_bwd(xT, tc, sc, blob, Y, ub, mid, H, K, 8, want_x=False, want_params=True)
+    gx, gs = torch.empty_like(gx1), torch.empty_like(gs1)
+    slab, slab_b = torch.empty_like(slab1), torch.empty_like(slab1)
+    u2 = torch.empty_like(u)
+    jobs = [dict(xT=xT, start=sc, u=u2, Y=Y, ubar=ub, gx=gx, gs=gs, gslab=slab),
+            dict(xT=xT, start=sc, u=u2, Y=Y, ubar=ub, gslab=slab_b)]
+    KN.ode_bwd_multi(jobs, tc, blob, mid, H, K, 8, want_x=True, want_params=True, x_cot_ones=True)
+    _close(gx, gx1, 1e-12, 'gx of the ones cotangent')
+    _close(gs, gs1, 1e-11, 'gs of the ones cotangent')
+    assert torch.equal(slab, slab1) and torch.equal(slab_b, slab1)
+
+
 @pytest.mark.parametrize('N,L,d', CASES + [(50, 3, 70)])
 def test_disc_forward_and_time_tangent(N, L, d):
     from oracle import refspec as R

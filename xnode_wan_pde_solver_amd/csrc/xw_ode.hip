@@ -273,6 +273,7 @@ struct BwdJobs {
   int N[XW_MAXJOBS];
   int tile0[XW_MAXJOBS + 1];
   int n;
+  int x_ones;                  // gx, gs are those of the all-ones cotangent (ubar == 1 at every time index >= 1)
 };
 template <typename J> __device__ __forceinline__ int find_job(const J& jobs) {
   int j = 0;
@@ -462,6 +463,7 @@ __global__ void __launch_bounds__(64) k_ode_bwd(const BwdJobs jobs, const double
 #pragma unroll
   for (int ht = 0; ht < D::HT; ++ht) lam[ht] = xw_zero4();
   d4 xpb = xw_zero4();
+  double ub0 = 0.0;            // cotangent of u at the first time index (the last one visited)
 
   if constexpr (T::S <= 2) {
     Rec<H, K, M, T::S> cur;
@@ -501,6 +503,7 @@ __global__ void __launch_bounds__(64) k_ode_bwd(const BwdJobs jobs, const double
         load_ckpt<H, K>(Y, l, N, ncl, yl);
       }
       const double ub = valid ? (ubar != nullptr ? ubar[(long)l * N + base + n] : 1.0) : 0.0;
+      ub0 = ub;
 #pragma unroll
       for (int ht = 0; ht < D::HT; ++ht) {
         lam[ht] += flw[ht] * ub;
@@ -568,6 +571,7 @@ __global__ void __launch_bounds__(64) k_ode_bwd(const BwdJobs jobs, const double
       }
       // read-out u_l = FL y_l + b
       const double ub = valid ? (ubar != nullptr ? ubar[(long)l * N + base + n] : 1.0) : 0.0;
+      ub0 = ub;
   #pragma unroll
       for (int ht = 0; ht < D::HT; ++ht) {
         lam[ht] += flw[ht] * ub;
@@ -681,7 +685,34 @@ __global__ void __launch_bounds__(64) k_ode_bwd(const BwdJobs jobs, const double
         storeRowSums(slab + o.IL0b, H, 16 * ht, d0[ht]);
       }
     }
-    const double gsn = xw_sum_over_g(gpart);
+    double gsn = xw_sum_over_g(gpart);
+    if (PARAMS && gs != nullptr && jobs.x_ones) {
+      // The x outputs of this launch stand for the helper backward u.backward(ones) (src/loss.py:55) while the
+      // parameter gradients use ubar, which differs from ones at the first time index only (the initial-value penalty).
+      // gx never sees that entry (no step is reversed after it), d/d start does, linearly through the lift:
+      // subtract the lift's response to flw * (ubar_0 - 1).
+      const double dub = ub0 - (valid ? 1.0 : 0.0);
+      d4 e1[D::HT];
+#pragma unroll
+      for (int ht = 0; ht < D::HT; ++ht) {
+        d4 v = xw_zero4();
+#pragma unroll
+        for (int ks = 0; ks < D::KSH; ++ks) v = XW_MFMA(xw_fragAT(th + o.IL4w, H, H, H, 16 * ht, 4 * ks), flw[ks >> 2][ks & 3], v);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) e1[ht][r] = a1[ht][r] > 0.0 ? v[r] : 0.0;
+      }
+      double cpart = 0.0;
+#pragma unroll
+      for (int ht = 0; ht < D::HT; ++ht) {
+        d4 v = xw_zero4();
+#pragma unroll
+        for (int ks = 0; ks < D::KSH; ++ks) v = XW_MFMA(xw_fragAT(th + o.IL2w, H, H, H, 16 * ht, 4 * ks), e1[ks >> 2][ks & 3], v);
+        const d4 w0 = xw_vecD(th + o.IL0w, H, 16 * ht);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cpart += a0[ht][r] > 0.0 ? w0[r] * v[r] : 0.0;
+      }
+      gsn -= dub * xw_sum_over_g(cpart);
+    }
     if (gs != nullptr && g == 0 && valid) gs[base + n] = gsn;
   }
 }
@@ -762,16 +793,18 @@ extern "C" int xw_ode_fwd(const double* xT, const double* t, const double* start
 
 extern "C" int xw_ode_bwd_multi(const XwOdeBwdJob* jobs, int njobs, const double* t, const double* theta, int method, int L,
                                 int d, int H, int K, int m, int mode, void* stream) {
-  if (!jobs || njobs < 1 || njobs > XW_MAXJOBS || !t || !theta || L <= 0 || d <= 0 || m < 1 || (mode & 3) == 0) return XW_E_ARG;
+  if (!jobs || njobs < 1 || njobs > XW_MAXJOBS || !t || !theta || L <= 0 || d <= 0 || m < 1 || (mode & 3) == 0 || ((mode & 4) && (mode & 3) != 3)) return XW_E_ARG;
   BwdJobs J;
   J.n = njobs;
+  J.x_ones = (mode & 4) ? 1 : 0;
   J.tile0[0] = 0;
   for (int i = 0; i < XW_MAXJOBS; ++i) {
     const bool on = i < njobs;
     if (on) {
       if (!jobs[i].xT || !jobs[i].start || !jobs[i].Y || jobs[i].N <= 0) return XW_E_ARG;
       if ((mode & 2) && !jobs[i].gslab) return XW_E_ARG;
-      if ((mode & 1) && (!jobs[i].gx || !jobs[i].gs)) return XW_E_ARG;
+      if ((mode & 1) && !(mode & 4) && (!jobs[i].gx || !jobs[i].gs)) return XW_E_ARG;
+      if ((mode & 1) && (!jobs[i].gx != !jobs[i].gs)) return XW_E_ARG;
     }
     J.xT[i] = on ? jobs[i].xT : nullptr;
     J.start[i] = on ? jobs[i].start : nullptr;

@@ -320,7 +320,7 @@ class Engine:
         Kernel chains:  main   u-forward (interior + boundary, one launch) -> cotangent A, boundary residual
                                -> parameter sweeps {interior/A, boundary} (one launch)
                         side 0 test network v, dv/dt and (fused) nabla_x v(t_0)  (independent of theta)
-                        side 1 x-sweep (nabla_x u)                               (after the forward)
+                               (sweep A also returns nabla_x u: same adjoint as the helper backward)
                         side 2 cotangent B = dI/du -> parameter sweep B          (after the forward and v)"""
         th = self.theta.data
         M = (self.method, self.H, self.K, self.m)
@@ -335,12 +335,17 @@ class Engine:
         if G.Nb:
             KN.bdry_partials(G.ub, G.g, self.alpha, G.Nbglob, self.scal, G.work_b, ubar_b=G.ubar_b)
             e_f = self._mark()
-        with self._side(1, e_f):
-            KN.ode_bwd_multi([self._job(G, 'i', want_x=True)], G.t, th, *M, want_x=True, want_params=False)
-            if self.side_contract:
-                self._join_side(1, e_v)
-                self._contract(G)                                # -> scal[0..2]
-            e_x = self._mark()
+        # With the reference's pollution (cotangent A = ones + the initial-value term at t_0) sweep A and the helper
+        # backward u.backward(ones) are the same adjoint: one launch returns the parameter gradient of A and nabla_x u.
+        fused_x = self.pollution == 1.0 and not self.side_contract
+        e_x = None
+        if not fused_x:
+            with self._side(1, e_f):
+                KN.ode_bwd_multi([self._job(G, 'i', want_x=True)], G.t, th, *M, want_x=True, want_params=False)
+                if self.side_contract:
+                    self._join_side(1, e_v)
+                    self._contract(G)                            # -> scal[0..2]
+                e_x = self._mark()
         with self._side(2, e_f, e_v):
             KN.gen_cotangents(G.u, G.v, G.w, G.h, G.Vol, G.Nglob, self.alpha, None, G.ubarB, c=G.c, cp=G.cp, ckappa=G.ck,
                               pollution=self.pollution)
@@ -348,13 +353,13 @@ class Engine:
             e_B = self._mark()
         KN.gen_cotangents(G.u, None, G.w, G.h, G.Vol, G.Nglob, self.alpha, G.ubarA, None, c=G.c, cp=G.cp, ckappa=G.ck,
                           pollution=self.pollution)
-        sweeps = [self._job(G, 'i', G.ubarA, G.slabA[:G.ns_u])]
+        sweeps = [self._job(G, 'i', G.ubarA, G.slabA[:G.ns_u], want_x=fused_x)]
         if joint:
             sweeps.append(self._job(G, 'b', G.ubar_b, G.slabA[G.ns_u:]))
-        KN.ode_bwd_multi(sweeps, G.t, th, *M, want_x=False, want_params=True)
+        KN.ode_bwd_multi(sweeps, G.t, th, *M, want_x=fused_x, want_params=True, x_cot_ones=fused_x)
         if G.Nb and not joint:
             KN.ode_bwd_multi([self._job(G, 'b', G.ubar_b, G.slabA[G.ns_u:])], G.tb, th, *M, want_x=False, want_params=True)
-        self._join(e_x, e_v)
+        self._join(e_v) if fused_x else self._join(e_x, e_v)
         if not self.side_contract:
             self._contract(G)
         self._join(e_B)

@@ -83,8 +83,10 @@ def ode_fwd_multi(jobs, t, theta, method, H, K, m, zero16=None):
     check(lib.xw_ode_fwd_multi(arr, len(jobs), _p(t), _p(theta), method, L, d, H, K, m, _p(zero16), _stream()), 'xw_ode_fwd_multi')
 
 
-def ode_bwd_multi(jobs, t, theta, method, H, K, m, want_x, want_params):
-    """jobs: list of dicts(xT, start, Y, ubar or None, gx, gs, gslab); ONE launch for all groups"""
+def ode_bwd_multi(jobs, t, theta, method, H, K, m, want_x, want_params, x_cot_ones=False):
+    """jobs: list of dicts(xT, start, Y, ubar or None, gx, gs, gslab); ONE launch for all groups.
+    x_cot_ones (with want_x and want_params): gx, gs for the all-ones cotangent, parameter gradients for ubar, which must
+    equal 1 at every time index >= 1; jobs without gx / gs produce no x outputs."""
     _need_gpu()
     L = t.shape[0]
     d = jobs[0]['xT'].shape[0]
@@ -95,13 +97,15 @@ def ode_bwd_multi(jobs, t, theta, method, H, K, m, want_x, want_params):
         N = j['xT'].shape[1]
         _chk(j['xT'], F64, (d, N), 'xT'); _chk(j['start'], F64, (N,), 'start'); _chk(j['Y'], F64, (L, H, N), 'Y')
         _chk(j.get('ubar'), F64, (L, N), 'ubar')
-        if want_x:
+        if want_x and not (x_cot_ones and j.get('gx') is None):
             _chk(j['gx'], F64, (d, N), 'gx'); _chk(j['gs'], F64, (N,), 'gs')
         if want_params:
             _chk(j['gslab'], F64, (ode_bwd_slabs(N), P), 'gslab')
         a.xT, a.start, a.Y, a.ubar, a.N = _p(j['xT']), _p(j['start']), _p(j['Y']), _p(j.get('ubar')), N
         a.gx, a.gs, a.gslab = _p(j.get('gx')), _p(j.get('gs')), _p(j.get('gslab'))
-    mode = (1 if want_x else 0) | (2 if want_params else 0)
+    if x_cot_ones and not (want_x and want_params):
+        raise XnwanError('x_cot_ones needs want_x and want_params')
+    mode = (1 if want_x else 0) | (2 if want_params else 0) | (4 if x_cot_ones else 0)
     check(lib.xw_ode_bwd_multi(arr, len(jobs), _p(t), _p(theta), method, L, d, H, K, m, mode, _stream()), 'xw_ode_bwd_multi')
 
 
