@@ -109,12 +109,15 @@ int xw_disc_bwd(const double* xT, const double* t, const double* tpp, const doub
  *           NULL for a = identity, b = 0: then it is contracted in-kernel from gx[d,N], gs[N] (xw_ode_bwd), ghT[d,N]
  *           (nabla_x of the start value), gxv[d,N] (xw_disc_gradx), w0[N], gwx0T[d,N] (w and nabla_x w at t_0)
  *   c, cp: c(u,t,x) and dc/du, [L,N]; both NULL means c = ckappa * u           f[L,N]; h[N]
- *   Vol = domain volume; Nglob = global number of interior paths (the 1/N, 1/(N L) factors of src/loss.py:64-71) */
+ *   Vol = domain volume; Nglob = global number of interior paths (the 1/N, 1/(N L) factors of src/loss.py:64-71)
+ *   finalize != 0 (single-GPU path): the sums of this launch are the global ones, so the block that completes them also
+ *   does what xw_losses does (loss values into scal[4..6] from scal[0..3], optimiser counter *step += 1 if step != NULL);
+ *   Lb, Nbglob, alpha as in xw_losses.  With several GPUs call xw_losses after the all-reduce instead. */
 int xw_weak_partials(const double* u, const double* v, const double* vt, const double* w, int w_per_point,
                      const double* wt, const double* s3x, const double* gx, const double* gs, const double* ghT,
                      const double* gxv, const double* w0, const double* gwx0T, int d, const double* c, double ckappa,
                      const double* f, const double* h, int N, int L, double Vol, double Nglob, double* work, double* scal,
-                     void* stream);
+                     int finalize, int Lb, double Nbglob, double alpha, long long* step, void* stream);
 int xw_reduce_work_size(void);
 /* boundary penalty partial: scal[3] += sum (u_b - g)^2 ; ubar_b = alpha * 2 (u_b - g) / (Nbglob * L) */
 int xw_bdry_partials(const double* ub, const double* g, int Nb, int L, double alpha, double Nbglob,

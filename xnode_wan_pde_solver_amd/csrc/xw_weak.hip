@@ -25,7 +25,7 @@ __device__ __forceinline__ double wave_sum(double x) {
 // between launches: the last block resets it).  Hand-off follows cdna_hip_programming.md Guideline 16: stores ->
 // s_waitcnt vmcnt(0) -> barrier -> lane-0 release fence -> ticket; consumer: ticket -> acquire fence -> barrier -> loads.
 template <int NV>
-__device__ __forceinline__ void grid_sum(double (&val)[NV], double* __restrict__ work, double* __restrict__ dst) {
+__device__ __forceinline__ bool grid_sum(double (&val)[NV], double* __restrict__ work, double* __restrict__ dst) {
   __shared__ double red[NV][4];
   __shared__ int is_last;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -54,7 +54,7 @@ __device__ __forceinline__ void grid_sum(double (&val)[NV], double* __restrict__
     }
   }
   __syncthreads();
-  if (!is_last) return;
+  if (!is_last) return false;
   // final sum by the whole last block in a fixed order: strided per-thread partials, then the same shuffle / LDS tree
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
@@ -70,6 +70,12 @@ __device__ __forceinline__ void grid_sum(double (&val)[NV], double* __restrict__
     dst[threadIdx.x] += tot;
   }
   if (threadIdx.x == 0) *ticket = 0u;
+  return true;                                          // this block completed the sum
+}
+
+__device__ __forceinline__ double interior_loss(const double* scal, double Vol, double Nglob, int L) {
+  const double I = scal[0], S = scal[1];
+  return log(I * I) - log(Vol * S / (Nglob * (double)L));  // src/loss.py:89-90
 }
 
 __global__ void __launch_bounds__(256) k_weak_partials(const double* __restrict__ u, const double* __restrict__ v,
@@ -82,7 +88,8 @@ __global__ void __launch_bounds__(256) k_weak_partials(const double* __restrict_
                                                        const double* __restrict__ c, double ckappa,
                                                        const double* __restrict__ f, const double* __restrict__ h, int N,
                                                        int L, double Vol, double Nglob, double* __restrict__ work,
-                                                       double* __restrict__ scal) {
+                                                       double* __restrict__ scal, int finalize, int Lb, double Nbglob,
+                                                       double alpha, long long* __restrict__ step) {
   // one lane per sample point (time-major: consecutive lanes = consecutive paths of one time index, coalesced)
   double acc[3] = {0.0, 0.0, 0.0};  // I, sum v^2, SSE_init
   const double cN = Vol / Nglob, cNL = Vol / Nglob / (double)L;
@@ -121,7 +128,19 @@ __global__ void __launch_bounds__(256) k_weak_partials(const double* __restrict_
     acc[0] += I;
     acc[1] += vl * vl;
   }
-  grid_sum<3>(acc, work, scal);
+  const bool last = grid_sum<3>(acc, work, scal);
+  if (finalize && last) {
+    // the block that completed the sums also turns them into the loss values (what xw_losses does) -- one launch and
+    // one dependency edge less per sub-step; scal[3] (boundary SSE) was completed by an earlier launch on this stream
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      if (step != nullptr) *step += 1;
+      const double in_ = interior_loss(scal, Vol, Nglob, L);
+      scal[6] = in_;
+      scal[4] = in_ + alpha * (scal[2] / Nglob + scal[3] / (Nbglob * (double)Lb));  // src/loss.py:93
+      scal[5] = -in_;                                                                // src/loss.py:96
+    }
+  }
 }
 
 __global__ void __launch_bounds__(256) k_bdry(const double* __restrict__ ub, const double* __restrict__ gb, long P,
@@ -136,10 +155,6 @@ __global__ void __launch_bounds__(256) k_bdry(const double* __restrict__ ub, con
   grid_sum<1>(acc, work, scal + 3);
 }
 
-__device__ __forceinline__ double interior_loss(const double* scal, double Vol, double Nglob, int L) {
-  const double I = scal[0], S = scal[1];
-  return log(I * I) - log(Vol * S / (Nglob * (double)L));  // src/loss.py:89-90
-}
 
 // Generator cotangent bases (both available right after the forward passes -- neither needs the global I):
 //   ubarA = pollution + alpha * d(init)/du        ubarB = dI/du
@@ -272,11 +287,13 @@ extern "C" int xw_weak_partials(const double* u, const double* v, const double* 
                                 const double* wt, const double* s3x, const double* gx, const double* gs, const double* ghT,
                                 const double* gxv, const double* w0, const double* gwx0T, int d, const double* c,
                                 double ckappa, const double* f, const double* h, int N, int L, double Vol, double Nglob,
-                                double* work, double* scal, void* stream) {
-  if (!u || !v || !vt || !w || !f || !h || !work || !scal || N <= 0 || L <= 0) return XW_E_ARG;
+                                double* work, double* scal, int finalize, int Lb, double Nbglob, double alpha,
+                                long long* step, void* stream) {
+  if (!u || !v || !vt || !w || !f || !h || !work || !scal || N <= 0 || L <= 0 || (finalize && Lb <= 0)) return XW_E_ARG;
   if (!s3x && (!gx || !gs || !ghT || !gxv || !w0 || !gwx0T || d <= 0)) return XW_E_ARG;
   hipLaunchKernelGGL(k_weak_partials, dim3(blocks_for((long)N * L, 256, 1024)), dim3(256), 0, (hipStream_t)stream, u, v, vt, w,
-                     w_per_point, wt, s3x, gx, gs, ghT, gxv, w0, gwx0T, d, c, ckappa, f, h, N, L, Vol, Nglob, work, scal);
+                     w_per_point, wt, s3x, gx, gs, ghT, gxv, w0, gwx0T, d, c, ckappa, f, h, N, L, Vol, Nglob, work, scal, finalize,
+                     Lb, Nbglob, alpha, step);
   return xw_launch_status();
 }
 
@@ -335,7 +352,7 @@ extern "C" int xw_slab_sum(const double* gslab, int nslab, int P, int accumulate
   return xw_launch_status();
 }
 
-extern "C" int xw_abi_version(void) { return 10; }
+extern "C" int xw_abi_version(void) { return 11; }
 extern "C" int xw_reduce_work_size(void) { return 3 * 1024 + 8; }
 
 extern "C" int xw_supported_dims(char* buf, int buflen) {

@@ -114,7 +114,6 @@ class Engine:
         cus = torch.cuda.get_device_properties(device).multi_processor_count
         self.v_blocks = int(os.environ.get('XW_V_BLOCKS', '0')) or (3 * 2 * cus) // 4
         self._phi_version = 0
-        self.side_contract = os.environ.get('XW_SIDE_CONTRACT', '0') == '1'   # measured slower (queue mapping)
         self.streams = [torch.cuda.Stream(device=device) for _ in range(4)]
 
     # ------------------------------------------------------------------------------------------------------------
@@ -292,11 +291,16 @@ class Engine:
             j = dict(xT=G.xbT, start=G.start_b, u=G.ub, Y=G.Yb, ubar=ubar, gslab=gslab)
         return j
 
-    def _contract(self, G):
-        """I, sum v^2, SSE_init from u, v, dv/dt and the two helper-backward gradients (src/loss.py:46-76)"""
+    def _contract(self, G, adam_state=None):
+        """I, sum v^2, SSE_init from u, v, dv/dt and the two helper-backward gradients (src/loss.py:46-76).
+        Single GPU: the sums are global, so the same launch also forms the loss values and advances the optimiser's
+        counter (`adam_state`); with several GPUs that is done by KN.losses after the all-reduce."""
+        fin = None
+        if self.world is None and adam_state is not None:
+            fin = dict(Lb=G.Lb, Nbglob=G.Nbglob, alpha=self.alpha, step=adam_state['step'])
         if G.A0 is None and G.B0 is None:
             KN.weak_partials(G.u, G.v, G.vt, G.w, G.f, G.h, G.Vol, G.Nglob, self.scal, G.work_i, c=G.c, ckappa=G.ck, wt=G.wt,
-                             contract=dict(gx=G.gx, gs=G.gs, ghT=G.ghT, gxv=G.gxv, w0=G.w0, gwx0T=G.gwx0T))
+                             contract=dict(gx=G.gx, gs=G.gs, ghT=G.ghT, gxv=G.gxv, w0=G.w0, gwx0T=G.gwx0T), finalize=fin)
             return
         Gx = G.gx + G.gs.unsqueeze(0) * G.ghT                                              # [d, N]
         dphi0 = G.w0.unsqueeze(0) * G.gxv + G.v[0].unsqueeze(0) * G.gwx0T                  # nabla_x phi at t_0, [d, N]
@@ -305,7 +309,7 @@ class Engine:
             s3x = s3x + G.v[0] * G.w0 * (G.B0 * Gx).sum(0)
         G.s3x.copy_(s3x)
         KN.weak_partials(G.u, G.v, G.vt, G.w, G.f, G.h, G.Vol, G.Nglob, self.scal, G.work_i, s3x=G.s3x, c=G.c, ckappa=G.ck,
-                         wt=G.wt)
+                         wt=G.wt, finalize=fin)
 
     # ------------------------------------------------------------------------------------------------------------
     # generator sub-step (src/training.py:127-138)
@@ -337,14 +341,11 @@ class Engine:
             e_f = self._mark()
         # With the reference's pollution (cotangent A = ones + the initial-value term at t_0) sweep A and the helper
         # backward u.backward(ones) are the same adjoint: one launch returns the parameter gradient of A and nabla_x u.
-        fused_x = self.pollution == 1.0 and not self.side_contract
+        fused_x = self.pollution == 1.0
         e_x = None
         if not fused_x:
             with self._side(1, e_f):
                 KN.ode_bwd_multi([self._job(G, 'i', want_x=True)], G.t, th, *M, want_x=True, want_params=False)
-                if self.side_contract:
-                    self._join_side(1, e_v)
-                    self._contract(G)                            # -> scal[0..2]
                 e_x = self._mark()
         with self._side(2, e_f, e_v):
             KN.gen_cotangents(G.u, G.v, G.w, G.h, G.Vol, G.Nglob, self.alpha, None, G.ubarB, c=G.c, cp=G.cp, ckappa=G.ck,
@@ -360,8 +361,7 @@ class Engine:
         if G.Nb and not joint:
             KN.ode_bwd_multi([self._job(G, 'b', G.ubar_b, G.slabA[G.ns_u:])], G.tb, th, *M, want_x=False, want_params=True)
         self._join(e_v) if fused_x else self._join(e_x, e_v)
-        if not self.side_contract:
-            self._contract(G)
+        self._contract(G, self.adam_u)                           # -> scal[0..2], loss values
         self._join(e_B)
 
     def begin_substep(self, which, accumulate):
@@ -377,7 +377,8 @@ class Engine:
     def _gen_back(self, G):
         lr, st = self.config['u_rate'], self.adam_u
         acc = self.accum_u
-        KN.losses(self.scal, G.L, G.Lb, G.Vol, G.Nglob, G.Nbglob, self.alpha, step=st['step'])   # also advances the counter
+        if self.world is not None:     # (single GPU: loss values and counter were done by the reduction launch, _contract)
+            KN.losses(self.scal, G.L, G.Lb, G.Vol, G.Nglob, G.Nbglob, self.alpha, step=st['step'])
         if self.world is None:
             KN.adam(self.theta.data, G.slabA, st['m'], st['v'], st['step'], lr, gslabB=G.slabB, scal=self.scal,
                     gextraA=acc, gsum_out=self.grad_u, bump_step=-1)
@@ -432,7 +433,7 @@ class Engine:
         self._reaction(G)
         KN.ode_bwd_multi([self._job(G, 'i', want_x=True)], G.t, th, *M, want_x=True, want_params=False)
         self._join(e_v)
-        self._contract(G)
+        self._contract(G, self.adam_v)
 
     def _disc_mid(self, G):
         KN.disc_cotangent(G.u, G.v, G.w, G.f, G.h, G.Vol, G.Nglob, self.scal, G.vbar, c=G.c, ckappa=G.ck,
@@ -445,7 +446,8 @@ class Engine:
     def _disc_back(self, G):
         lr, st = self.config['v_rate'], self.adam_v
         acc = self.accum_v
-        KN.losses(self.scal, G.L, G.Lb, G.Vol, G.Nglob, G.Nbglob, self.alpha, step=st['step'])
+        if self.world is not None:
+            KN.losses(self.scal, G.L, G.Lb, G.Vol, G.Nglob, G.Nbglob, self.alpha, step=st['step'])
         if self.world is None:
             KN.adam(self.phi.data, G.slab_v, st['m'], st['v'], st['step'], lr, gextraA=acc, gsum_out=self.grad_v,
                     bump_step=-1)

@@ -193,9 +193,12 @@ def reduce_work_size():
     return lib.xw_reduce_work_size()
 
 
-def weak_partials(u, v, vt, w, f, h, Vol, Nglob, scal, work, s3x=None, contract=None, c=None, ckappa=0.0, wt=None):
+def weak_partials(u, v, vt, w, f, h, Vol, Nglob, scal, work, s3x=None, contract=None, c=None, ckappa=0.0, wt=None,
+                  finalize=None):
     """partial sums of I, sum v^2, SSE_init.  Either s3x[N] (pre-contracted gradient term) or contract = dict(gx, gs, ghT,
-    gxv, w0, gwx0T) for the in-kernel contraction with a = identity, b = 0."""
+    gxv, w0, gwx0T) for the in-kernel contraction with a = identity, b = 0.
+    finalize = dict(Lb, Nbglob, alpha, step) (single GPU): also turn the sums into the loss values and advance `step`,
+    exactly what losses() does."""
     _need_gpu()
     L, N = u.shape
     for name, a in (('u', u), ('v', v), ('vt', vt), ('f', f)):
@@ -204,6 +207,8 @@ def weak_partials(u, v, vt, w, f, h, Vol, Nglob, scal, work, s3x=None, contract=
     _chk(w, F64, (L, N) if per_point else (N,), 'w'); _chk(wt, F64, (L, N), 'wt'); _chk(c, F64, (L, N), 'c')
     _chk(s3x, F64, (N,), 's3x'); _chk(h, F64, (N,), 'h'); _chk(scal, F64, (16,), 'scal')
     _chk(work, F64, (reduce_work_size(),), 'work')
+    fz = finalize or {}
+    _chk(fz.get('step'), torch.int64, (1,), 'step')
     k, d = {}, 0
     if s3x is None:
         k = contract
@@ -213,7 +218,9 @@ def weak_partials(u, v, vt, w, f, h, Vol, Nglob, scal, work, s3x=None, contract=
         _chk(k['gs'], F64, (N,), 'gs'); _chk(k['w0'], F64, (N,), 'w0')
     check(lib.xw_weak_partials(_p(u), _p(v), _p(vt), _p(w), per_point, _p(wt), _p(s3x), _p(k.get('gx')), _p(k.get('gs')),
                                _p(k.get('ghT')), _p(k.get('gxv')), _p(k.get('w0')), _p(k.get('gwx0T')), d, _p(c),
-                               float(ckappa), _p(f), _p(h), N, L, float(Vol), float(Nglob), _p(work), _p(scal), _stream()),
+                               float(ckappa), _p(f), _p(h), N, L, float(Vol), float(Nglob), _p(work), _p(scal),
+                               0 if finalize is None else 1, max(int(fz.get('Lb', 1)), 1), float(fz.get('Nbglob', 1.0)),
+                               float(fz.get('alpha', 0.0)), _p(fz.get('step')), _stream()),
           'xw_weak_partials')
 
 
