@@ -119,17 +119,20 @@ __global__ void __launch_bounds__(256, 2) k_disc_fwd(const double* __restrict__ 
     input_layer<W>(pht, o, xT, N, d, pt, a, ad);
     for (int j = 0; j < q; ++j) {
       d4 nw[D::MT], nd[D::MT];
-      unsigned int mask = 0;
 #pragma unroll
       for (int mt = 0; mt < D::MT; ++mt) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          nw[mt][r] = sB[16 * mt + g + 4 * r];
-          mask |= (a[mt][r] > 0.0 ? 1u : 0u) << (4 * mt + r);
-        }
+        for (int r = 0; r < 4; ++r) nw[mt][r] = sB[16 * mt + g + 4 * r];
         nd[mt] = xw_zero4();
       }
-      if (want_grad) sMask[j][threadIdx.x] = (unsigned short)mask;
+      if (want_grad) {                                      // (wave-uniform; 1 tile in L needs the masks)
+        unsigned int mask = 0;
+#pragma unroll
+        for (int mt = 0; mt < D::MT; ++mt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) mask |= (a[mt][r] > 0.0 ? 1u : 0u) << (4 * mt + r);
+        sMask[j][threadIdx.x] = (unsigned short)mask;
+      }
       double tv[D::TR], td[D::TR];                          // partial dot products of the tail rows (this lane's k = 4 ks + g)
 #pragma unroll
       for (int r = 0; r < D::TR; ++r) tv[r] = td[r] = 0.0;
