@@ -180,6 +180,14 @@ __device__ __forceinline__ void xw_writeT(double* tile, d4 q) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) tile[(g + 4 * r) * XW_TSTRIDE + n] = q[r];
 }
+// the first NR registers only (rows g + 4 r, r < NR): tiles with fewer than 16 live rows.  The rows left alone keep
+// stale LDS contents; as operand rows of an outer product they only reach accumulator rows / columns that are never stored.
+template <int NR> __device__ __forceinline__ void xw_writeT_n(double* tile, d4 q) {
+  const int l = xw_lane();
+  const int g = l >> 4, n = l & 15;
+#pragma unroll
+  for (int r = 0; r < NR; ++r) tile[(g + 4 * r) * XW_TSTRIDE + n] = q[r];
+}
 __device__ __forceinline__ double xw_readT(const double* tile, int ks) {
   const int l = xw_lane();
   return tile[(l & 15) * XW_TSTRIDE + 4 * ks + (l >> 4)];

@@ -49,6 +49,9 @@ template <int H, int K> struct Dim {
   static constexpr int HT = (H + 15) / 16;   // row tiles of an H-vector
   static constexpr int KSH = (H + 3) / 4;    // k-steps of a contraction over H
   static constexpr int KSK = (K + 3) / 4;    // k-steps of a contraction over K
+  static constexpr int KR = (K + 1 + 3) / 4;   // live registers of a K-tile incl. the ones row (rows 0 .. K)
+  __device__ static constexpr int HR(int ht) { return (H - 16 * ht) >= 16 ? 4 : (H - 16 * ht + 3) / 4; }        // rows of y
+  __device__ static constexpr int HR1(int ht) { return (H + 1 - 16 * ht) >= 16 ? 4 : (H + 1 - 16 * ht + 3) / 4; }  // + time row
   static_assert(K <= 15, "one padding row of the K-tile carries the bias column of the outer products");
   static_assert((H % 16) != 0 && (H % 16) <= 15, "one padding row of the last H-tile carries the time column");
   static_assert(HT <= 2, "H <= 31");
@@ -108,13 +111,17 @@ template <int H, int K, int M, bool SAVE, bool OUT = true>
 __device__ __forceinline__ void field_fwd(const FieldW<H, K>& w, double t, d4 xp, const d4 (&y)[Dim<H, K>::HT],
                                           d4 (&out)[Dim<H, K>::HT], Save<M>& sv) {
   typedef Dim<H, K> D;
-  d4 z = xp + w.wt * t;
+  d4 z = xw_zero4();
+#pragma unroll
+  for (int r = 0; r < D::KSK; ++r) z[r] = fma(w.wt[r], t, xp[r]);
 #pragma unroll
   for (int ks = 0; ks < D::KSH; ++ks) z = XW_MFMA(w.Wy[ks], y[ks >> 2][ks & 3], z);
 #pragma unroll
   for (int j = 0; j < M - 1; ++j) {
     if (SAVE) sv.z[j] = z;
-    d4 r = xw_relu(z);
+    d4 r = xw_zero4();
+#pragma unroll
+    for (int ks = 0; ks < D::KSK; ++ks) r[ks] = z[ks] > 0.0 ? z[ks] : 0.0;
     d4 nz = w.bh;
 #pragma unroll
     for (int ks = 0; ks < D::KSK; ++ks) nz = XW_MFMA(w.Wh[ks], r[ks], nz);
@@ -144,15 +151,34 @@ template <int H, int K> struct FieldG {
 // D[i][j] += sum over the 16 paths of Q[i][path] * R[j][path]
 // The block is exactly ONE wave and the LDS executes a wave's DS instructions in issue order, so the transposing
 // write -> read round trip needs no s_barrier: a compiler-level fence keeps the program order of the accesses.
+// QR / RR: live registers (4-row groups) of the two tiles
+template <int QR = 4, int RR = 4>
 __device__ __forceinline__ void outer_acc(d4& acc, d4 q, d4 r, double* lds) {
-  xw_writeT(lds, q);
-  xw_writeT(lds + XW_TTILE, r);
+  xw_writeT_n<QR>(lds, q);
+  xw_writeT_n<RR>(lds + XW_TTILE, r);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) acc = XW_MFMA(xw_readT(lds, ks), xw_readT(lds + XW_TTILE, ks), acc);
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   __builtin_amdgcn_wave_barrier();
+}
+// elementwise helpers on the first nr registers of a tile (nr is a compile-time constant after unrolling): an H-vector's
+// last tile has H - 16 live rows, the rest is padding that no MFMA ever reads -- on this chip every FP64 VALU
+// instruction of the lone sweep wave is time the matrix pipe stands still.
+__device__ __forceinline__ void t_axpy(d4& y, double a, const d4& x, int nr) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    if (r < nr) y[r] += a * x[r];
+}
+__device__ __forceinline__ void t_scale(d4& y, double a, const d4& x, int nr) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) y[r] = r < nr ? a * x[r] : 0.0;
+}
+__device__ __forceinline__ void t_add(d4& y, const d4& x, int nr) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    if (r < nr) y[r] += x[r];
 }
 // set chain-layout row `row` (0..15) of a tile to the value v in every column
 __device__ __forceinline__ void set_row(d4& q, int row, double v) {
@@ -174,31 +200,38 @@ __device__ __forceinline__ void field_vjp(const FieldW<H, K>& w, const FieldWT<H
     d4 a1 = sv.a;
     set_row(a1, K, 1.0);  // ones row -> column K of the accumulator collects Wo.b's gradient
 #pragma unroll
-    for (int ht = 0; ht < D::HT; ++ht) outer_acc(G.Wo[ht], ob[ht], a1, lds);
+    for (int ht = 0; ht < D::HT; ++ht) {
+      if (ht == 0) outer_acc<D::HR(0), D::KR>(G.Wo[ht], ob[ht], a1, lds);
+      else outer_acc<D::HR(1), D::KR>(G.Wo[ht], ob[ht], a1, lds);
+    }
   }
-  d4 zb;
+  d4 zb = xw_zero4();
 #pragma unroll
-  for (int r = 0; r < 4; ++r) zb[r] = ab[r] * (1.0 - sv.a[r] * sv.a[r]);
+  for (int r = 0; r < D::KSK; ++r) zb[r] = ab[r] * (1.0 - sv.a[r] * sv.a[r]);
 #pragma unroll
   for (int j = M - 2; j >= 0; --j) {
     if (PARAMS) {
-      d4 rj = xw_relu(sv.z[j]);
+      d4 rj = xw_zero4();
+#pragma unroll
+      for (int r = 0; r < D::KSK; ++r) rj[r] = sv.z[j][r] > 0.0 ? sv.z[j][r] : 0.0;
       set_row(rj, K, 1.0);
-      outer_acc(G.Wh, zb, rj, lds);
+      outer_acc<D::KSK, D::KR>(G.Wh, zb, rj, lds);
     }
     d4 tt = xw_zero4();
 #pragma unroll
     for (int ks = 0; ks < D::KSK; ++ks) tt = XW_MFMA(wT.WhT[ks], zb[ks], tt);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) zb[r] = sv.z[j][r] > 0.0 ? tt[r] : 0.0;
+    for (int r = 0; r < D::KSK; ++r) zb[r] = sv.z[j][r] > 0.0 ? tt[r] : 0.0;
   }
-  xpb += zb;
+#pragma unroll
+  for (int r = 0; r < D::KSK; ++r) xpb[r] += zb[r];
   if (PARAMS) {
 #pragma unroll
     for (int ct = 0; ct < (H + 1 + 15) / 16; ++ct) {
       d4 yy = ct < D::HT ? yin[ct < D::HT ? ct : 0] : xw_zero4();
       if (ct == (H >> 4)) set_row(yy, H & 15, t);  // time row -> column H collects the time-column gradient
-      outer_acc(G.Wy[ct], zb, yy, lds);
+      if (ct == 0) outer_acc<D::KSK, D::HR1(0)>(G.Wy[ct], zb, yy, lds);
+      else outer_acc<D::KSK, D::HR1(1)>(G.Wy[ct], zb, yy, lds);
     }
   }
 #pragma unroll
@@ -409,7 +442,7 @@ __device__ __forceinline__ void recompute(const FieldW<H, K>& w, d4 xp, const do
         R.yi[i][ht] = R.yi[0][ht];
 #pragma unroll
         for (int j = 0; j < i; ++j)
-          if (T::a(i, j) != 0.0) R.yi[i][ht] += (dt * T::a(i, j)) * k[j][ht];
+          if (T::a(i, j) != 0.0) t_axpy(R.yi[i][ht], dt * T::a(i, j), k[j][ht], D::HR(ht));
       }
     }
     if (i < T::S - 1)
@@ -479,7 +512,7 @@ __global__ void __launch_bounds__(64) k_ode_bwd(const BwdJobs jobs, const double
         for (int i = 0; i < T::S; ++i)
 #pragma unroll
           for (int ht = 0; ht < D::HT; ++ht) {
-            kb[i][ht] = (dt * T::b(i)) * lam[ht];
+            t_scale(kb[i][ht], dt * T::b(i), lam[ht], D::HR(ht));
             if (i == 0) psum[ht] = xw_zero4();
           }
 #pragma unroll
@@ -488,15 +521,15 @@ __global__ void __launch_bounds__(64) k_ode_bwd(const BwdJobs jobs, const double
           field_vjp<H, K, M, PARAMS>(w, wT, t0 + T::c(i) * dt, cur.sv[i], cur.yi[i], kb[i], psi, xpb, G, lds);
 #pragma unroll
           for (int ht = 0; ht < D::HT; ++ht) {
-            psum[ht] += psi[ht];
+            t_add(psum[ht], psi[ht], D::HR(ht));
 #pragma unroll
             for (int j = 0; j < i; ++j)
-              if (T::a(i, j) != 0.0) kb[j][ht] += (dt * T::a(i, j)) * psi[ht];
+              if (T::a(i, j) != 0.0) t_axpy(kb[j][ht], dt * T::a(i, j), psi[ht], D::HR(ht));
           }
         }
 #pragma unroll
         for (int ht = 0; ht < D::HT; ++ht) {
-          lam[ht] += psum[ht];
+          t_add(lam[ht], psum[ht], D::HR(ht));
           yl[ht] = cur.yi[0][ht];                        // stage 0's input is y_l itself
         }
       } else {
@@ -506,8 +539,8 @@ __global__ void __launch_bounds__(64) k_ode_bwd(const BwdJobs jobs, const double
       ub0 = ub;
 #pragma unroll
       for (int ht = 0; ht < D::HT; ++ht) {
-        lam[ht] += flw[ht] * ub;
-        if (PARAMS) accFL[ht] += yl[ht] * ub;
+        t_axpy(lam[ht], ub, flw[ht], D::HR(ht));
+        if (PARAMS) t_axpy(accFL[ht], ub, yl[ht], D::HR(ht));
       }
       if (PARAMS) accFLb += ub;
     }
