@@ -70,7 +70,7 @@ template <int H, int K> struct FieldWT {     // transposed operands for the vect
   double WoT[Dim<H, K>::KSH];                // [K x H]
 };
 template <int M> struct Save {               // what the VJP of one field evaluation needs
-  d4 z[M > 1 ? M - 1 : 1];                   // pre-activations z_0 .. z_{m-2} (ReLU layers)
+  d4 z[M > 1 ? M - 1 : 1];                   // relu(z_0) .. relu(z_{m-2}): layer inputs; their sign pattern is the ReLU mask
   d4 a;                                      // tanh(z_{m-1})
 };
 
@@ -118,10 +118,10 @@ __device__ __forceinline__ void field_fwd(const FieldW<H, K>& w, double t, d4 xp
   for (int ks = 0; ks < D::KSH; ++ks) z = XW_MFMA(w.Wy[ks], y[ks >> 2][ks & 3], z);
 #pragma unroll
   for (int j = 0; j < M - 1; ++j) {
-    if (SAVE) sv.z[j] = z;
     d4 r = xw_zero4();
 #pragma unroll
     for (int ks = 0; ks < D::KSK; ++ks) r[ks] = z[ks] > 0.0 ? z[ks] : 0.0;
+    if (SAVE) sv.z[j] = r;
     d4 nz = w.bh;
 #pragma unroll
     for (int ks = 0; ks < D::KSK; ++ks) nz = XW_MFMA(w.Wh[ks], r[ks], nz);
@@ -180,6 +180,27 @@ __device__ __forceinline__ void t_add(d4& y, const d4& x, int nr) {
   for (int r = 0; r < 4; ++r)
     if (r < nr) y[r] += x[r];
 }
+// Outer product whose R operand is a K-row activation followed by a row of ones (the bias gradient rides along as column
+// K of the accumulator).  The ones row lives permanently in a dedicated LDS tile (written once per kernel): only the K
+// real rows are stored, nothing is patched into registers.
+template <int QR, int K>
+__device__ __forceinline__ void outer_acc_ones(d4& acc, d4 q, d4 r, double* lds) {
+  double* rt = lds + 2 * XW_TTILE;
+  xw_writeT_n<QR>(lds, q);
+  {
+    const int l = xw_lane();
+    const int g = l >> 4, n = l & 15;
+#pragma unroll
+    for (int rr = 0; rr < (K + 3) / 4; ++rr)
+      if (4 * rr + 3 < K || g + 4 * rr < K) rt[(g + 4 * rr) * XW_TSTRIDE + n] = r[rr];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) acc = XW_MFMA(xw_readT(lds, ks), xw_readT(rt, ks), acc);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
 // set chain-layout row `row` (0..15) of a tile to the value v in every column
 __device__ __forceinline__ void set_row(d4& q, int row, double v) {
   if ((xw_lane() >> 4) == (row & 3)) q[row >> 2] = v;
@@ -188,21 +209,57 @@ __device__ __forceinline__ void set_row(d4& q, int row, double v) {
 // vector-Jacobian product of one field evaluation.  ob: cotangent of F's output; returns the cotangent of the y input
 // in yb, adds the cotangent of z0 into xpb (= cotangent of the x-projection and of Win.b), and (PARAMS) accumulates the
 // parameter gradients.
+// The two halves of an outer product, so that the chain's next matrix instructions can be issued between the LDS
+// stores and the loads that read them back transposed: the lone wave has nothing else to cover that round trip with.
+template <int QR, int RR>
+__device__ __forceinline__ void outer_post(d4 q, d4 r, double* lds) {                 // general R tile
+  xw_writeT_n<QR>(lds, q);
+  xw_writeT_n<RR>(lds + XW_TTILE, r);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+}
+template <int QR, int K>
+__device__ __forceinline__ void outer_post_ones(d4 q, d4 r, double* lds) {            // K rows + the permanent ones row
+  double* rt = lds + 2 * XW_TTILE;
+  xw_writeT_n<QR>(lds, q);
+  const int l = xw_lane();
+  const int g = l >> 4, n = l & 15;
+#pragma unroll
+  for (int rr = 0; rr < (K + 3) / 4; ++rr)
+    if (4 * rr + 3 < K || g + 4 * rr < K) rt[(g + 4 * rr) * XW_TSTRIDE + n] = r[rr];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ void outer_take(d4& acc, const double* qt, const double* rt) {
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) acc = XW_MFMA(xw_readT(qt, ks), xw_readT(rt, ks), acc);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// vector-Jacobian product of one field evaluation.  ob: cotangent of F's output; returns the cotangent of the y input
+// in yb, adds the cotangent of z0 into xpb (= cotangent of the x-projection and of Win.b), and (PARAMS) accumulates the
+// parameter gradients (outer products over the 16 paths; a row of ones / the time row in the R tile makes the bias and
+// time-column gradients ride along as an extra accumulator column).
 template <int H, int K, int M, bool PARAMS>
 __device__ __forceinline__ void field_vjp(const FieldW<H, K>& w, const FieldWT<H, K>& wT, double t, const Save<M>& sv,
                                           const d4 (&yin)[Dim<H, K>::HT], const d4 (&ob)[Dim<H, K>::HT],
                                           d4 (&yb)[Dim<H, K>::HT], d4& xpb, FieldG<H, K>& G, double* lds) {
   typedef Dim<H, K> D;
+  const double* rt1 = lds + 2 * XW_TTILE;
+  if (PARAMS) outer_post_ones<D::HR(0), K>(ob[0], sv.a, lds);
   d4 ab = xw_zero4();
 #pragma unroll
   for (int ks = 0; ks < D::KSH; ++ks) ab = XW_MFMA(wT.WoT[ks], ob[ks >> 2][ks & 3], ab);
   if (PARAMS) {
-    d4 a1 = sv.a;
-    set_row(a1, K, 1.0);  // ones row -> column K of the accumulator collects Wo.b's gradient
+    outer_take(G.Wo[0], lds, rt1);
 #pragma unroll
-    for (int ht = 0; ht < D::HT; ++ht) {
-      if (ht == 0) outer_acc<D::HR(0), D::KR>(G.Wo[ht], ob[ht], a1, lds);
-      else outer_acc<D::HR(1), D::KR>(G.Wo[ht], ob[ht], a1, lds);
+    for (int ht = 1; ht < D::HT; ++ht) {
+      outer_post_ones<D::HR(1), K>(ob[ht], sv.a, lds);
+      outer_take(G.Wo[ht], lds, rt1);
     }
   }
   d4 zb = xw_zero4();
@@ -210,37 +267,31 @@ __device__ __forceinline__ void field_vjp(const FieldW<H, K>& w, const FieldWT<H
   for (int r = 0; r < D::KSK; ++r) zb[r] = ab[r] * (1.0 - sv.a[r] * sv.a[r]);
 #pragma unroll
   for (int j = M - 2; j >= 0; --j) {
-    if (PARAMS) {
-      d4 rj = xw_zero4();
-#pragma unroll
-      for (int r = 0; r < D::KSK; ++r) rj[r] = sv.z[j][r] > 0.0 ? sv.z[j][r] : 0.0;
-      set_row(rj, K, 1.0);
-      outer_acc<D::KSK, D::KR>(G.Wh, zb, rj, lds);
-    }
+    if (PARAMS) outer_post_ones<D::KSK, K>(zb, sv.z[j], lds);
     d4 tt = xw_zero4();
 #pragma unroll
     for (int ks = 0; ks < D::KSK; ++ks) tt = XW_MFMA(wT.WhT[ks], zb[ks], tt);
+    if (PARAMS) outer_take(G.Wh, lds, rt1);
 #pragma unroll
     for (int r = 0; r < D::KSK; ++r) zb[r] = sv.z[j][r] > 0.0 ? tt[r] : 0.0;
   }
 #pragma unroll
   for (int r = 0; r < D::KSK; ++r) xpb[r] += zb[r];
-  if (PARAMS) {
-#pragma unroll
-    for (int ct = 0; ct < (H + 1 + 15) / 16; ++ct) {
-      d4 yy = ct < D::HT ? yin[ct < D::HT ? ct : 0] : xw_zero4();
-      if (ct == (H >> 4)) set_row(yy, H & 15, t);  // time row -> column H collects the time-column gradient
-      if (ct == 0) outer_acc<D::KSK, D::HR1(0)>(G.Wy[ct], zb, yy, lds);
-      else outer_acc<D::KSK, D::HR1(1)>(G.Wy[ct], zb, yy, lds);
-    }
-  }
 #pragma unroll
   for (int ht = 0; ht < D::HT; ++ht) {
+    if (PARAMS) {
+      d4 yy = yin[ht];
+      if (ht == (H >> 4)) set_row(yy, H & 15, t);  // time row -> column H collects the time-column gradient
+      if (ht == 0) outer_post<D::KSK, D::HR1(0)>(zb, yy, lds);
+      else outer_post<D::KSK, D::HR1(1)>(zb, yy, lds);
+    }
     d4 v = xw_zero4();
 #pragma unroll
     for (int ks = 0; ks < D::KSK; ++ks) v = XW_MFMA(wT.WyT[ht][ks], zb[ks], v);
     yb[ht] = v;
+    if (PARAMS) outer_take(G.Wy[ht], lds, lds + XW_TTILE);
   }
+  static_assert((H + 1 + 15) / 16 == Dim<H, K>::HT, "the time column lives in the last H-tile");
 }
 
 // start scalar -> hidden state: initial_layers of src/model.py:78,97
@@ -457,7 +508,12 @@ __global__ void __launch_bounds__(64) k_ode_bwd(const BwdJobs jobs, const double
                                                 const double* __restrict__ th, int L, int d) {
   typedef Dim<H, K> D;
   typedef RK<METHOD> T;
-  __shared__ double lds[2 * XW_TTILE];
+  __shared__ double lds[3 * XW_TTILE];          // Q tile | R tile | R tile of K rows + a permanent row of ones
+  if (PARAMS) {
+    if (xw_lane() < 16) lds[2 * XW_TTILE + K * XW_TSTRIDE + xw_lane()] = 1.0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
   const int job = find_job(jobs);
   const double* __restrict__ xT = jobs.xT[job];
   const double* __restrict__ start = jobs.start[job];
