@@ -26,6 +26,9 @@ template <int W> struct VDim {
   static constexpr int TR = W - 16 * (MT - 1);
   static constexpr bool VTAIL = TR <= 3;
   static constexpr int MTF = VTAIL ? MT - 1 : MT;     // row tiles that go through the matrix pipe in k_disc_fwd
+  // live registers (4-row groups) of row tile mt, counting the ones row W of the outer products: elementwise work,
+  // checkpoints and transposes skip the padding rows (a lone wave pays ~9 clocks per FP64 VALU instruction)
+  __device__ static constexpr int LR(int mt) { return (W + 1 - 16 * mt) >= 16 ? 4 : (W + 1 - 16 * mt + 3) / 4; }
   static_assert(MT == 4, "the backward kernel maps the 4 row tiles of dVh onto the 4 waves of a block");
   static_assert((W % 16) != 0, "a padding row of the last tile carries the bias column of the outer products");
 };
@@ -315,7 +318,10 @@ __global__ void __launch_bounds__(256) k_disc_bwd(const double* __restrict__ xT,
     }
   };
 
-  constexpr int SEG = 3;                              // layers per checkpoint segment
+  // layers per checkpoint segment.  1: every layer input r_j stays in registers (13 live f64 per layer at W = 50) and
+  // nothing is recomputed -- 497 vs 558 us at SEG = 3 even with 48 spilled registers.  The wide-input variant (CTG = 2,
+  // d > 62) carries 32 more accumulator registers and keeps the 3-layer segments.
+  constexpr int SEG = CTG == 1 ? 1 : 3;
   constexpr int NSEG = (Q + SEG - 1) / SEG;
   for (long st = blockIdx.x; st < nsuper; st += gridDim.x) {
     const Pt pt = locate(st * 4 + wave, P, N, tf, tpp);
@@ -329,8 +335,12 @@ __global__ void __launch_bounds__(256) k_disc_bwd(const double* __restrict__ xT,
       d4 r[D::MT];
 #pragma unroll
       for (int mt = 0; mt < D::MT; ++mt) {
-        r[mt] = xw_relu(a[mt]);
-        if (j % SEG == 0) ck[j / SEG][mt] = r[mt];
+#pragma unroll
+        for (int q_ = 0; q_ < 4; ++q_)
+          if (q_ < D::LR(mt)) {
+            r[mt][q_] = a[mt][q_] > 0.0 ? a[mt][q_] : 0.0;
+            if (j % SEG == 0) ck[j / SEG][mt][q_] = r[mt][q_];
+          }
       }
       layer(r, a);
     }
@@ -351,14 +361,20 @@ __global__ void __launch_bounds__(256) k_disc_bwd(const double* __restrict__ xT,
     for (int sg = NSEG - 1; sg >= 0; --sg) {
       d4 seg[SEG][D::MT];
 #pragma unroll
-      for (int mt = 0; mt < D::MT; ++mt) seg[0][mt] = ck[sg][mt];
+      for (int mt = 0; mt < D::MT; ++mt)
+#pragma unroll
+        for (int q_ = 0; q_ < 4; ++q_)
+          if (q_ < D::LR(mt)) seg[0][mt][q_] = ck[sg][mt][q_];
 #pragma unroll
       for (int k = 1; k < SEG; ++k)
         if (sg * SEG + k < Q) {
           d4 tmp[D::MT];
           layer(seg[k - 1], tmp);
 #pragma unroll
-          for (int mt = 0; mt < D::MT; ++mt) seg[k][mt] = xw_relu(tmp[mt]);
+          for (int mt = 0; mt < D::MT; ++mt)
+#pragma unroll
+            for (int q_ = 0; q_ < 4; ++q_)
+              if (q_ < D::LR(mt)) seg[k][mt][q_] = tmp[mt][q_] > 0.0 ? tmp[mt][q_] : 0.0;
         }
 #pragma unroll
       for (int k = SEG - 1; k >= 0; --k) {
@@ -370,8 +386,13 @@ __global__ void __launch_bounds__(256) k_disc_bwd(const double* __restrict__ xT,
             if (mt == (W >> 4)) {
               if (g == ((W & 15) & 3)) rj[(W & 15) >> 2] = 1.0;  // ones row -> column W of dVh collects dVh.b
             }
-            xw_writeT(sD + (wave * D::MT + mt) * XW_TTILE, dl[mt]);
-            xw_writeT(sR + (wave * D::MT + mt) * XW_TTILE, rj);
+            if (mt < D::MT - 1) {
+              xw_writeT(sD + (wave * D::MT + mt) * XW_TTILE, dl[mt]);
+              xw_writeT(sR + (wave * D::MT + mt) * XW_TTILE, rj);
+            } else {
+              xw_writeT_n<D::LR(D::MT - 1)>(sD + (wave * D::MT + mt) * XW_TTILE, dl[mt]);
+              xw_writeT_n<D::LR(D::MT - 1)>(sR + (wave * D::MT + mt) * XW_TTILE, rj);
+            }
           }
         }
         // reverse chain first: its 52 MFMAs only need dl and Vh^T and cover the latency of the LDS transposes above
@@ -401,7 +422,8 @@ __global__ void __launch_bounds__(256) k_disc_bwd(const double* __restrict__ xT,
 #pragma unroll
         for (int mt = 0; mt < D::MT; ++mt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) dl[mt][r] = seg[k][mt][r] > 0.0 ? nd[mt][r] : 0.0;
+          for (int r = 0; r < 4; ++r)
+            if (r < D::LR(mt)) dl[mt][r] = seg[k][mt][r] > 0.0 ? nd[mt][r] : 0.0;
       }
     }
     // ---- dl = cotangent of a_0.  Input layer: dVin = dl (x) [t; x; 1]
