@@ -47,7 +47,13 @@ int xw_ode_fwd(const double* xT, const double* t, const double* start, const dou
 
 /* The same for up to 4 independent groups of paths in ONE launch (interior + boundary sample, ...): one wave per 16
  * paths fills only a quarter of an MI355X at N = 4096, so independent groups are co-scheduled explicitly. */
-typedef struct { const double* xT; const double* start; double* u; double* Y; int N; } XwOdeFwdJob;
+/* act (may be NULL): activation store [L-1][xw_ode_act_rows()][N] -- the forward pass keeps the layer inputs of every
+ * stage of every step so that the sweeps (XwOdeBwdJob.act) read them back instead of re-evaluating the field: the
+ * record is 180 doubles per path and step at (H, K, m) = (20, 10, 8) with midpoint, HBM capacity and bandwidth are idle
+ * on this path, and the lone sweep wave saves 58 MFMAs + two tanh blocks per step.  Ignored by rk4. */
+typedef struct { const double* xT; const double* start; double* u; double* Y; double* act; int N; } XwOdeFwdJob;
+/* rows of the activation record per step (0: this method's sweeps recompute; negative: XW_E_*) */
+int xw_ode_act_rows(int method, int H, int K, int m);
 /* zero16 (may be NULL): 16 doubles cleared by the launch -- the sub-step's partial-sum slots scal[], so that no separate
  * memset sits at the head of the critical path */
 int xw_ode_fwd_multi(const XwOdeFwdJob* jobs, int njobs, const double* t, const double* theta,
@@ -69,7 +75,7 @@ int xw_ode_bwd(const double* xT, const double* t, const double* start, const dou
                double* gx, double* gs, double* gslab, void* stream);
 
 /* multi-group form: every job has its own sample, checkpoints, cotangent and outputs; `mode` is common to all jobs */
-typedef struct { const double* xT; const double* start; const double* Y; const double* ubar;
+typedef struct { const double* xT; const double* start; const double* Y; const double* act; const double* ubar;
                  double* gx; double* gs; double* gslab; int N; } XwOdeBwdJob;
 int xw_ode_bwd_multi(const XwOdeBwdJob* jobs, int njobs, const double* t, const double* theta,
                      int method, int L, int d, int H, int K, int m, int mode, void* stream);

@@ -158,6 +158,36 @@ def test_ode_backward_pollution_and_x_sweep_in_one(solver):
     assert torch.equal(slab, slab1) and torch.equal(slab_b, slab1)
 
 
+@pytest.mark.parametrize('solver', ['euler', 'midpoint', 'rk4'])
+def test_ode_backward_from_stored_activations(solver):
+    """the sweeps read the stage activations the forward stored (XwOdeFwdJob.act) instead of re-evaluating the field:
+    same gradients as the recomputing sweeps (rk4 ignores the store)"""
+    from xnode_wan_pde_solver_amd import kernels as KN
+    N, L, d = 37, 6, 20
+    theta, _ = _params(d, 8, 41)
+    x, t, _ = _sample(N, L, d, 42)
+    g = torch.Generator().manual_seed(43)
+    start = torch.randn(N, dtype=F64, generator=g)
+    ub = torch.randn(L, N, dtype=F64, generator=g).cuda()
+    xT, tc, sc, blob = x.double().t().contiguous().cuda(), t.double().cuda(), start.cuda(), _blob(theta, U_ORDER)
+    mid = KN.method_id(solver)
+    rows = KN.ode_act_rows(mid, H, K, 8)
+    assert rows == {'euler': 80, 'midpoint': 180, 'rk4': 0}[solver]
+    u0, Y0 = KN.ode_fwd(xT, tc, sc, blob, mid, H, K, 8)
+    gx0, gs0, slab0 = KN.ode_bwd(xT, tc, sc, blob, Y0, ub, mid, H, K, 8, want_x=True, want_params=True)
+    u, Y = torch.empty_like(u0), torch.empty_like(Y0)
+    act = torch.full((L - 1, max(rows, 1), N), float('nan'), dtype=F64, device='cuda')
+    job = dict(xT=xT, start=sc, u=u, Y=Y, act=act if rows else None)
+    KN.ode_fwd_multi([job], tc, blob, mid, H, K, 8)
+    assert torch.equal(u, u0) and torch.equal(Y, Y0)
+    if rows:
+        assert torch.isfinite(act).all()                     # every row of every step was written
+    gx, gs, slab = torch.empty_like(gx0), torch.empty_like(gs0), torch.empty_like(slab0)
+    KN.ode_bwd_multi([dict(job, ubar=ub, gx=gx, gs=gs, gslab=slab)], tc, blob, mid, H, K, 8, want_x=True, want_params=True)
+    _close(gx, gx0, 1e-12, 'gx'); _close(gs, gs0, 1e-12, 'gs')
+    _close(KN.slab_sum(slab), KN.slab_sum(slab0), 1e-12, 'theta gradient')
+
+
 @pytest.mark.parametrize('N,L,d', CASES + [(50, 3, 70)])
 def test_disc_forward_and_time_tangent(N, L, d):
     from oracle import refspec as R

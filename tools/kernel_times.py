@@ -30,6 +30,14 @@ print('fwd      %.1f us' % timeit(lambda: KN.ode_fwd_multi([job], t, th, *M)))
 print('bwd x    %.1f us' % timeit(lambda: KN.ode_bwd_multi([dict(job, ubar=None, gx=gx, gs=gs)], t, th, *M, want_x=True, want_params=False)))
 print('bwd par  %.1f us' % timeit(lambda: KN.ode_bwd_multi([dict(job, ubar=ubar, gslab=slab)], t, th, *M, want_x=False, want_params=True)))
 print('checksum %.12e %.12e' % (float(slab.sum(0).abs().sum()), float(gx.abs().sum())))
+ar = KN.ode_act_rows(M[0], H, K, m)
+if ar:
+    act = torch.empty(L - 1, ar, N, dtype=torch.float64, device=dev)
+    joba = dict(job, act=act)
+    print('fwd+act  %.1f us' % timeit(lambda: KN.ode_fwd_multi([joba], t, th, *M)))
+    print('bwd x  (act) %.1f us' % timeit(lambda: KN.ode_bwd_multi([dict(joba, ubar=None, gx=gx, gs=gs)], t, th, *M, want_x=True, want_params=False)))
+    print('bwd par(act) %.1f us' % timeit(lambda: KN.ode_bwd_multi([dict(joba, ubar=ubar, gslab=slab)], t, th, *M, want_x=False, want_params=True)))
+    print('checksum %.12e %.12e' % (float(slab.sum(0).abs().sum()), float(gx.abs().sum())))
 # ---- test network at the headline size (131072 points)
 W, q = 50, 9
 Pv = _lib.lib.xw_phi_size(d, W)

@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('XW_LIBRARY') or os.path.join(_HERE, 'libxnwan.so')   # (override: kernel experiments only)
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 c_f32p = ctypes.c_void_p   # coordinates / time grid: const double* (device)   [name kept from the float32 era]
 c_f64p = ctypes.c_void_p   # double*       (device)
@@ -17,12 +17,12 @@ c_int, c_dbl, c_vp = ctypes.c_int, ctypes.c_double, ctypes.c_void_p
 
 
 class XwOdeFwdJob(ctypes.Structure):      # include/xnwan.h
-    _fields_ = [('xT', c_vp), ('start', c_vp), ('u', c_vp), ('Y', c_vp), ('N', c_int)]
+    _fields_ = [('xT', c_vp), ('start', c_vp), ('u', c_vp), ('Y', c_vp), ('act', c_vp), ('N', c_int)]
 
 
 class XwOdeBwdJob(ctypes.Structure):
-    _fields_ = [('xT', c_vp), ('start', c_vp), ('Y', c_vp), ('ubar', c_vp), ('gx', c_vp), ('gs', c_vp), ('gslab', c_vp),
-                ('N', c_int)]
+    _fields_ = [('xT', c_vp), ('start', c_vp), ('Y', c_vp), ('act', c_vp), ('ubar', c_vp), ('gx', c_vp), ('gs', c_vp),
+                ('gslab', c_vp), ('N', c_int)]
 
 
 # name -> argument types (return type is always int); mirrors include/xnwan.h line by line
@@ -35,6 +35,7 @@ SIGNATURES = {
     'xw_ode_fwd_multi': [ctypes.POINTER(XwOdeFwdJob), c_int, c_f32p, c_f64p, c_int, c_int, c_int, c_int, c_int, c_int, c_f64p,
                          c_vp],
     'xw_ode_bwd_slabs': [c_int],
+    'xw_ode_act_rows': [c_int, c_int, c_int, c_int],
     'xw_ode_bwd_multi': [ctypes.POINTER(XwOdeBwdJob), c_int, c_f32p, c_f64p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp],
     'xw_ode_bwd': [c_f32p, c_f32p, c_f64p, c_f64p, c_f64p, c_f64p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                    c_f64p, c_f64p, c_f64p, c_vp],

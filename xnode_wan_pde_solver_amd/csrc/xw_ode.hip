@@ -107,9 +107,19 @@ __device__ __forceinline__ void load_field_T(const double* __restrict__ th, cons
 
 // F([x, t, y]) of src/model.py:153-156: z0 = Win [x;t;y] + b (x part pre-contracted into xp), (m-1) tied ReLU layers,
 // tanh, output layer.  y/out: HT chain tiles.
-template <int H, int K, int M, bool SAVE, bool OUT = true>
+// Where the layer inputs of an evaluation go: nowhere, into registers (Save), or straight to the activation store.
+struct SinkNone {
+  __device__ __forceinline__ void z(int, d4) const {}
+  __device__ __forceinline__ void a(d4) const {}
+};
+template <int M> struct SinkSave {
+  Save<M>& sv;
+  __device__ __forceinline__ void z(int j, d4 r) const { sv.z[j] = r; }
+  __device__ __forceinline__ void a(d4 v) const { sv.a = v; }
+};
+template <int H, int K, int M, bool OUT = true, class Sink>
 __device__ __forceinline__ void field_fwd(const FieldW<H, K>& w, double t, d4 xp, const d4 (&y)[Dim<H, K>::HT],
-                                          d4 (&out)[Dim<H, K>::HT], Save<M>& sv) {
+                                          d4 (&out)[Dim<H, K>::HT], const Sink& sink) {
   typedef Dim<H, K> D;
   d4 z = xw_zero4();
 #pragma unroll
@@ -121,7 +131,7 @@ __device__ __forceinline__ void field_fwd(const FieldW<H, K>& w, double t, d4 xp
     d4 r = xw_zero4();
 #pragma unroll
     for (int ks = 0; ks < D::KSK; ++ks) r[ks] = z[ks] > 0.0 ? z[ks] : 0.0;
-    if (SAVE) sv.z[j] = r;
+    sink.z(j, r);
     d4 nz = w.bh;
 #pragma unroll
     for (int ks = 0; ks < D::KSK; ++ks) nz = XW_MFMA(w.Wh[ks], r[ks], nz);
@@ -130,7 +140,7 @@ __device__ __forceinline__ void field_fwd(const FieldW<H, K>& w, double t, d4 xp
   d4 a = xw_zero4();
 #pragma unroll
   for (int ks = 0; ks < D::KSK; ++ks) a[ks] = xw_tanh(z[ks]);
-  if (SAVE) sv.a = a;
+  sink.a(a);
   if (!OUT) return;
 #pragma unroll
   for (int ht = 0; ht < D::HT; ++ht) {
@@ -341,6 +351,7 @@ struct FwdJobs {
   const double* start[XW_MAXJOBS];
   double* u[XW_MAXJOBS];
   double* Y[XW_MAXJOBS];
+  double* act[XW_MAXJOBS];     // optional: stage activations of every step (ActLayout), read back by the sweeps
   int N[XW_MAXJOBS];
   int tile0[XW_MAXJOBS + 1];   // first block of each job
   int n;
@@ -350,6 +361,7 @@ struct BwdJobs {
   const double* xT[XW_MAXJOBS];
   const double* start[XW_MAXJOBS];
   const double* Y[XW_MAXJOBS];
+  const double* act[XW_MAXJOBS];
   const double* ubar[XW_MAXJOBS];
   double* gx[XW_MAXJOBS];
   double* gs[XW_MAXJOBS];
@@ -367,9 +379,61 @@ template <typename J> __device__ __forceinline__ int find_job(const J& jobs) {
   return j;
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-template <int H, int K, int M, int METHOD>
-__global__ void __launch_bounds__(64) k_ode_fwd(const FwdJobs jobs, const double* __restrict__ tf,
+// ---- stage activations kept from the forward pass ---------------------------------------------------------------------
+// The sweeps need, for every stage of every step, the layer inputs relu(z_j), the tanh output and the stage input.
+// Recomputing them from the checkpoint y_l costs the lone sweep wave 58 MFMAs and ~280 FP64 VALU instructions per step
+// (two tanh blocks); HBM has 288 GB and is idle on this path, so the forward can simply store them:
+//   act[l][row][n],  l = 0 .. L-2,  rows: stage i -> i * M K + j K + k  (j < M-1: relu(z_j), j = M-1: tanh(z_{M-1})),
+//                                         then the inputs of the stages i >= 1: S M K + (i-1) H + h.
+// 180 doubles per path and step at (H, K, m) = (20, 10, 8), midpoint: 183 MB for 4096 paths x 32 times.
+template <int H, int K, int M, int S> struct ActLayout {
+  static constexpr int STAGE = M * K;
+  static constexpr int YI = S * STAGE;
+  static constexpr int ROWS = S * STAGE + (S - 1) * H;
+};
+// rows [row0, row0 + nrows) of the record <-> the first registers of a chain tile (row g + 4 r).  Addresses are
+// formed as  (uniform row pointer) + (32-bit lane offset)  so that they cost SGPRs, not a VGPR pair per stored row.
+struct ActLane {
+  int off;        // g * N + column (clamped column for loads)
+  int off_part;   // the same with g clamped into a partially filled register of a K-row tile
+  bool valid;
+};
+__device__ __forceinline__ ActLane act_lane(int N, int col, bool valid, int krows) {
+  const int g = xw_lane() >> 4;
+  const int gp = (krows & 3) ? (g < (krows & 3) ? g : (krows & 3) - 1) : g;
+  return ActLane{g * N + col, gp * N + col, valid};
+}
+__device__ __forceinline__ void act_store(double* __restrict__ A, int row0, int nrows, int N, const ActLane& q, d4 v) {
+  const int g = xw_lane() >> 4;
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    if (4 * r < nrows) {
+      double* __restrict__ rowp = A + (long)(row0 + 4 * r) * N;             // uniform
+      if (g + 4 * r < nrows && q.valid) rowp[q.off] = v[r];
+    }
+}
+__device__ __forceinline__ d4 act_load(const double* __restrict__ A, int row0, int nrows, int N, const ActLane& q) {
+  d4 v = xw_zero4();
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    if (4 * r < nrows) {
+      const double* __restrict__ rowp = A + (long)(row0 + 4 * r) * N;       // uniform
+      v[r] = rowp[4 * r + 4 <= nrows ? q.off : q.off_part];                  // padding rows: any finite value
+    }
+  return v;
+}
+
+// streams the layer inputs of one stage into the activation store as they are produced (no register copy kept)
+template <int K, int M> struct SinkAct {
+  double* __restrict__ A;      // record of this step
+  int row0, N;
+  const ActLane& q;
+  __device__ __forceinline__ void z(int j, d4 r) const { act_store(A, row0 + j * K, K, N, q, r); }
+  __device__ __forceinline__ void a(d4 v) const { act_store(A, row0 + (M - 1) * K, K, N, q, v); }
+};
+
+template <int H, int K, int M, int METHOD, bool ACT>
+__global__ void __launch_bounds__(64, 2) k_ode_fwd(const FwdJobs jobs, const double* __restrict__ tf,
                                                 const double* __restrict__ th, int L, int d) {
   typedef Dim<H, K> D;
   typedef RK<METHOD> T;
@@ -378,6 +442,8 @@ __global__ void __launch_bounds__(64) k_ode_fwd(const FwdJobs jobs, const double
   const double* __restrict__ start = jobs.start[job];
   double* __restrict__ u = jobs.u[job];
   double* __restrict__ Y = jobs.Y[job];
+  double* __restrict__ act = jobs.act[job];
+  typedef ActLayout<H, K, M, T::S> AL;
   const int N = jobs.N[job];
   const int lane = xw_lane(), g = lane >> 4, n = lane & 15;
   const int base = ((int)blockIdx.x - jobs.tile0[job]) * 16;
@@ -393,7 +459,7 @@ __global__ void __launch_bounds__(64) k_ode_fwd(const FwdJobs jobs, const double
 #pragma unroll
   for (int ht = 0; ht < D::HT; ++ht) flw[ht] = xw_vecD(th + o.FLw, H, 16 * ht);
   const double flb = th[o.FLb];
-  Save<M> dummy;
+  const ActLane aq = act_lane(N, base + n, valid, K);
   for (int l = 0; l < L; ++l) {
     double part = 0.0;
 #pragma unroll
@@ -419,7 +485,17 @@ __global__ void __launch_bounds__(64) k_ode_fwd(const FwdJobs jobs, const double
         for (int j = 0; j < i; ++j)
           if (T::a(i, j) != 0.0) yi[ht] += (dt * T::a(i, j)) * k[j][ht];
       }
-      field_fwd<H, K, M, false>(w, t0 + T::c(i) * dt, xp, yi, k[i], dummy);
+      if (!ACT) {
+        field_fwd<H, K, M, true>(w, t0 + T::c(i) * dt, xp, yi, k[i], SinkNone{});
+      } else {
+        double* __restrict__ A = act + (long)l * AL::ROWS * N;
+        if (i > 0) {
+#pragma unroll
+          for (int ht = 0; ht < D::HT; ++ht)
+            act_store(A, AL::YI + (i - 1) * H + 16 * ht, H - 16 * ht < 16 ? H - 16 * ht : 16, N, aq, yi[ht]);
+        }
+        field_fwd<H, K, M, true>(w, t0 + T::c(i) * dt, xp, yi, k[i], SinkAct<K, M>{A, i * AL::STAGE, N, aq});
+      }
     }
 #pragma unroll
     for (int i = 0; i < T::S; ++i)
@@ -497,15 +573,43 @@ __device__ __forceinline__ void recompute(const FieldW<H, K>& w, d4 xp, const do
       }
     }
     if (i < T::S - 1)
-      field_fwd<H, K, M, true, true>(w, t0 + T::c(i) * dt, xp, R.yi[i], k[i], R.sv[i]);
+      field_fwd<H, K, M, true>(w, t0 + T::c(i) * dt, xp, R.yi[i], k[i], SinkSave<M>{R.sv[i]});
     else
-      field_fwd<H, K, M, true, false>(w, t0 + T::c(i) * dt, xp, R.yi[i], k[i], R.sv[i]);   // last stage: activations only
+      field_fwd<H, K, M, false>(w, t0 + T::c(i) * dt, xp, R.yi[i], k[i], SinkSave<M>{R.sv[i]});   // last stage: activations only
   }
 }
 
-template <int H, int K, int M, int METHOD, bool PARAMS>
+// one stage of that record read back from the forward pass's activation store (k_ode_fwd<ACT>): loads only.
+// Stage granularity: while one stage is reversed the loads of the next one are in flight -- a whole step ahead would
+// keep twice as many registers occupied.
+template <int H, int K, int M> struct StageRec {
+  d4 yi[Dim<H, K>::HT];
+  Save<M> sv;
+};
+template <int H, int K, int M, int METHOD>
+__device__ __forceinline__ void load_stage(const double* __restrict__ Y, const double* __restrict__ act, int l, int i,
+                                           int N, int ncl, StageRec<H, K, M>& R) {
+  typedef Dim<H, K> D;
+  typedef ActLayout<H, K, M, RK<METHOD>::S> AL;
+  const double* __restrict__ A = act + (long)l * AL::ROWS * N;
+  const ActLane q = act_lane(N, ncl, true, K);
+  if (i == 0) {
+    load_ckpt<H, K>(Y, l, N, ncl, R.yi);
+  } else {
+#pragma unroll
+    for (int ht = 0; ht < D::HT; ++ht)
+      R.yi[ht] = act_load(A, AL::YI + (i - 1) * H + 16 * ht, H - 16 * ht < 16 ? H - 16 * ht : 16, N, q);
+  }
+#pragma unroll
+  for (int j = 0; j < M - 1; ++j) R.sv.z[j] = act_load(A, i * AL::STAGE + j * K, K, N, q);
+  R.sv.a = act_load(A, i * AL::STAGE + (M - 1) * K, K, N, q);
+}
+
+// SAVED: the stage activations come from the forward pass's store (euler, midpoint); otherwise they are recomputed
+template <int H, int K, int M, int METHOD, bool PARAMS, bool SAVED>
 __global__ void __launch_bounds__(64) k_ode_bwd(const BwdJobs jobs, const double* __restrict__ tf,
                                                 const double* __restrict__ th, int L, int d) {
+  static_assert(!SAVED || RK<METHOD>::S <= 2, "the activation store is used by euler and midpoint");
   typedef Dim<H, K> D;
   typedef RK<METHOD> T;
   __shared__ double lds[3 * XW_TTILE];          // Q tile | R tile | R tile of K rows + a permanent row of ones
@@ -518,6 +622,7 @@ __global__ void __launch_bounds__(64) k_ode_bwd(const BwdJobs jobs, const double
   const double* __restrict__ xT = jobs.xT[job];
   const double* __restrict__ start = jobs.start[job];
   const double* __restrict__ Y = jobs.Y[job];
+  const double* __restrict__ act = jobs.act[job];
   const double* __restrict__ ubar = jobs.ubar[job];
   double* __restrict__ gx = jobs.gx[job];
   double* __restrict__ gs = jobs.gs[job];
@@ -529,11 +634,9 @@ __global__ void __launch_bounds__(64) k_ode_bwd(const BwdJobs jobs, const double
   const bool valid = base + n < N;
   const int ncl = valid ? base + n : N - 1;
   const UOff o = u_offsets(d, H, K);
-  FieldW<H, K> w;
+  FieldW<H, K> w;                               // (only the recomputing paths load it)
   FieldWT<H, K> wT;
-  load_field<H, K>(th, o, d, w);
   load_field_T<H, K>(th, o, d, wT);
-  const d4 xp = project_x<H, K>(th, o, xT, N, d, ncl);
   d4 flw[D::HT];
 #pragma unroll
   for (int ht = 0; ht < D::HT; ++ht) flw[ht] = xw_vecD(th + o.FLw, H, 16 * ht);
@@ -554,53 +657,95 @@ __global__ void __launch_bounds__(64) k_ode_bwd(const BwdJobs jobs, const double
   d4 xpb = xw_zero4();
   double ub0 = 0.0;            // cotangent of u at the first time index (the last one visited)
 
-  if constexpr (T::S <= 2) {
-    Rec<H, K, M, T::S> cur;
-    for (int l = L - 1; l >= 0; --l) {
-      d4 yl[D::HT];
-      if (l < L - 1) {
-        // reverse of the step l -> l+1 : lam holds the total cotangent of y_{l+1}.  Every stage is evaluated ONCE, its
-        // activations kept for the vector-Jacobian product (one wave per SIMD: the register file is ours).
-        recompute<H, K, M, METHOD>(w, xp, Y, tf, l, N, ncl, cur);
-        const double t0 = tf[l], dt = tf[l + 1] - t0;
-        d4 kb[T::S][D::HT], psum[D::HT];
+  // read-out u_l = FL y_l + b at time index l: cotangent into lam, gradients of the read-out layer
+  auto readout = [&](int l, const d4 (&yl)[D::HT]) {
+    const double ub = valid ? (ubar != nullptr ? ubar[(long)l * N + base + n] : 1.0) : 0.0;
+    ub0 = ub;
 #pragma unroll
-        for (int i = 0; i < T::S; ++i)
+    for (int ht = 0; ht < D::HT; ++ht) {
+      t_axpy(lam[ht], ub, flw[ht], D::HR(ht));
+      if (PARAMS) t_axpy(accFL[ht], ub, yl[ht], D::HR(ht));
+    }
+    if (PARAMS) accFLb += ub;
+  };
+  // reverse of ONE stage i of the step l -> l+1: kb[i] is the cotangent of the stage derivative k_i
+  d4 kb[T::S][D::HT], psum[D::HT];
+  auto begin_step = [&](int l) {
+    const double dt = tf[l + 1] - tf[l];
 #pragma unroll
-          for (int ht = 0; ht < D::HT; ++ht) {
-            t_scale(kb[i][ht], dt * T::b(i), lam[ht], D::HR(ht));
-            if (i == 0) psum[ht] = xw_zero4();
-          }
-#pragma unroll
-        for (int i = T::S - 1; i >= 0; --i) {
-          d4 psi[D::HT];
-          field_vjp<H, K, M, PARAMS>(w, wT, t0 + T::c(i) * dt, cur.sv[i], cur.yi[i], kb[i], psi, xpb, G, lds);
-#pragma unroll
-          for (int ht = 0; ht < D::HT; ++ht) {
-            t_add(psum[ht], psi[ht], D::HR(ht));
-#pragma unroll
-            for (int j = 0; j < i; ++j)
-              if (T::a(i, j) != 0.0) t_axpy(kb[j][ht], dt * T::a(i, j), psi[ht], D::HR(ht));
-          }
-        }
-#pragma unroll
-        for (int ht = 0; ht < D::HT; ++ht) {
-          t_add(lam[ht], psum[ht], D::HR(ht));
-          yl[ht] = cur.yi[0][ht];                        // stage 0's input is y_l itself
-        }
-      } else {
-        load_ckpt<H, K>(Y, l, N, ncl, yl);
-      }
-      const double ub = valid ? (ubar != nullptr ? ubar[(long)l * N + base + n] : 1.0) : 0.0;
-      ub0 = ub;
+    for (int i = 0; i < T::S; ++i)
 #pragma unroll
       for (int ht = 0; ht < D::HT; ++ht) {
-        t_axpy(lam[ht], ub, flw[ht], D::HR(ht));
-        if (PARAMS) t_axpy(accFL[ht], ub, yl[ht], D::HR(ht));
+        t_scale(kb[i][ht], dt * T::b(i), lam[ht], D::HR(ht));
+        if (i == 0) psum[ht] = xw_zero4();
       }
-      if (PARAMS) accFLb += ub;
+  };
+  auto reverse_stage = [&](int l, int i, const d4 (&yin)[D::HT], const Save<M>& sv) {
+    const double t0 = tf[l], dt = tf[l + 1] - t0;
+    d4 psi[D::HT];
+    field_vjp<H, K, M, PARAMS>(w, wT, t0 + T::c(i) * dt, sv, yin, kb[i], psi, xpb, G, lds);
+#pragma unroll
+    for (int ht = 0; ht < D::HT; ++ht) {
+      t_add(psum[ht], psi[ht], D::HR(ht));
+#pragma unroll
+      for (int j = 0; j < T::S; ++j)
+        if (j < i && T::a(i, j) != 0.0) t_axpy(kb[j][ht], dt * T::a(i, j), psi[ht], D::HR(ht));
+    }
+  };
+  auto end_step = [&](int l, const d4 (&y_l)[D::HT]) {
+#pragma unroll
+    for (int ht = 0; ht < D::HT; ++ht) t_add(lam[ht], psum[ht], D::HR(ht));
+    readout(l, y_l);
+  };
+
+  if constexpr (SAVED) {
+    {
+      d4 yl[D::HT];
+      load_ckpt<H, K>(Y, L - 1, N, ncl, yl);
+      readout(L - 1, yl);
+    }
+    StageRec<H, K, M> sa, sb;
+    if constexpr (T::S == 2) {
+      // stage 1 always lives in sa, stage 0 in sb: each is loaded while the other one is reversed
+      if (L > 1) load_stage<H, K, M, METHOD>(Y, act, L - 2, 1, N, ncl, sa);
+      for (int l = L - 2; l >= 0; --l) {
+        load_stage<H, K, M, METHOD>(Y, act, l, 0, N, ncl, sb);
+        begin_step(l);
+        reverse_stage(l, 1, sa.yi, sa.sv);
+        load_stage<H, K, M, METHOD>(Y, act, l > 0 ? l - 1 : 0, 1, N, ncl, sa);
+        reverse_stage(l, 0, sb.yi, sb.sv);
+        end_step(l, sb.yi);                               // stage 0's input is y_l itself
+      }
+    } else {
+      if (L > 1) load_stage<H, K, M, METHOD>(Y, act, L - 2, 0, N, ncl, sa);
+      int l = L - 2;
+      for (; l >= 1; l -= 2) {
+        load_stage<H, K, M, METHOD>(Y, act, l - 1, 0, N, ncl, sb);
+        begin_step(l); reverse_stage(l, 0, sa.yi, sa.sv); end_step(l, sa.yi);
+        load_stage<H, K, M, METHOD>(Y, act, l >= 2 ? l - 2 : 0, 0, N, ncl, sa);
+        begin_step(l - 1); reverse_stage(l - 1, 0, sb.yi, sb.sv); end_step(l - 1, sb.yi);
+      }
+      if (l == 0) { begin_step(0); reverse_stage(0, 0, sa.yi, sa.sv); end_step(0, sa.yi); }
+    }
+  } else if constexpr (T::S <= 2) {
+    load_field<H, K>(th, o, d, w);
+    const d4 xp = project_x<H, K>(th, o, xT, N, d, ncl);
+    Rec<H, K, M, T::S> cur;
+    {
+      d4 yl[D::HT];
+      load_ckpt<H, K>(Y, L - 1, N, ncl, yl);
+      readout(L - 1, yl);
+    }
+    for (int l = L - 2; l >= 0; --l) {
+      recompute<H, K, M, METHOD>(w, xp, Y, tf, l, N, ncl, cur);
+      begin_step(l);
+#pragma unroll
+      for (int i = T::S - 1; i >= 0; --i) reverse_stage(l, i, cur.yi[i], cur.sv[i]);
+      end_step(l, cur.yi[0]);
     }
   } else {
+    load_field<H, K>(th, o, d, w);
+    const d4 xp = project_x<H, K>(th, o, xT, N, d, ncl);
     for (int l = L - 1; l >= 0; --l) {
       d4 y[D::HT];
   #pragma unroll
@@ -625,7 +770,7 @@ __global__ void __launch_bounds__(64) k_ode_bwd(const BwdJobs jobs, const double
             for (int j = 0; j < i; ++j)
               if (T::a(i, j) != 0.0) yi[ht] += (dt * T::a(i, j)) * k[j][ht];
           }
-          field_fwd<H, K, M, false>(w, t0 + T::c(i) * dt, xp, yi, k[i], sv);
+          field_fwd<H, K, M, true>(w, t0 + T::c(i) * dt, xp, yi, k[i], SinkNone{});
         }
   #pragma unroll
         for (int i = 0; i < T::S; ++i)
@@ -645,7 +790,7 @@ __global__ void __launch_bounds__(64) k_ode_bwd(const BwdJobs jobs, const double
               if (T::a(i, j) != 0.0) yi[ht] += (dt * T::a(i, j)) * k[j][ht];
           }
           const double ti = t0 + T::c(i) * dt;
-          field_fwd<H, K, M, true>(w, ti, xp, yi, ko, sv);
+          field_fwd<H, K, M, true>(w, ti, xp, yi, ko, SinkSave<M>{sv});
           field_vjp<H, K, M, PARAMS>(w, wT, ti, sv, yi, kb[i], psi, xpb, G, lds);
   #pragma unroll
           for (int ht = 0; ht < D::HT; ++ht) {
@@ -809,10 +954,14 @@ __global__ void __launch_bounds__(64) k_ode_bwd(const BwdJobs jobs, const double
 template <int H, int K, int M>
 int launch_fwd(int method, const FwdJobs& jobs, const double* t, const double* theta, int L, int d, hipStream_t s) {
   const dim3 grid(jobs.tile0[jobs.n]), block(64);
-  switch (method) {
-    case 0: hipLaunchKernelGGL((k_ode_fwd<H, K, M, 0>), grid, block, 0, s, jobs, t, theta, L, d); break;
-    case 1: hipLaunchKernelGGL((k_ode_fwd<H, K, M, 1>), grid, block, 0, s, jobs, t, theta, L, d); break;
-    case 2: hipLaunchKernelGGL((k_ode_fwd<H, K, M, 2>), grid, block, 0, s, jobs, t, theta, L, d); break;
+  bool act = true;                                     // all jobs or none (checked by the caller)
+  for (int i = 0; i < jobs.n; ++i) act = act && jobs.act[i] != nullptr;
+  switch (method * 2 + (act ? 1 : 0)) {
+    case 0: hipLaunchKernelGGL((k_ode_fwd<H, K, M, 0, false>), grid, block, 0, s, jobs, t, theta, L, d); break;
+    case 1: hipLaunchKernelGGL((k_ode_fwd<H, K, M, 0, true>), grid, block, 0, s, jobs, t, theta, L, d); break;
+    case 2: hipLaunchKernelGGL((k_ode_fwd<H, K, M, 1, false>), grid, block, 0, s, jobs, t, theta, L, d); break;
+    case 3: hipLaunchKernelGGL((k_ode_fwd<H, K, M, 1, true>), grid, block, 0, s, jobs, t, theta, L, d); break;
+    case 4: hipLaunchKernelGGL((k_ode_fwd<H, K, M, 2, false>), grid, block, 0, s, jobs, t, theta, L, d); break;
     default: return XW_E_ARG;
   }
   return xw_launch_status();
@@ -820,10 +969,14 @@ int launch_fwd(int method, const FwdJobs& jobs, const double* t, const double* t
 template <int H, int K, int M, bool PARAMS>
 int launch_bwd(int method, const BwdJobs& jobs, const double* t, const double* theta, int L, int d, hipStream_t s) {
   const dim3 grid(jobs.tile0[jobs.n]), block(64);
-  switch (method) {
-    case 0: hipLaunchKernelGGL((k_ode_bwd<H, K, M, 0, PARAMS>), grid, block, 0, s, jobs, t, theta, L, d); break;
-    case 1: hipLaunchKernelGGL((k_ode_bwd<H, K, M, 1, PARAMS>), grid, block, 0, s, jobs, t, theta, L, d); break;
-    case 2: hipLaunchKernelGGL((k_ode_bwd<H, K, M, 2, PARAMS>), grid, block, 0, s, jobs, t, theta, L, d); break;
+  bool act = true;                                     // all jobs or none (checked by the caller)
+  for (int i = 0; i < jobs.n; ++i) act = act && jobs.act[i] != nullptr;
+  switch (method * 2 + (act ? 1 : 0)) {
+    case 0: hipLaunchKernelGGL((k_ode_bwd<H, K, M, 0, PARAMS, false>), grid, block, 0, s, jobs, t, theta, L, d); break;
+    case 1: hipLaunchKernelGGL((k_ode_bwd<H, K, M, 0, PARAMS, true>), grid, block, 0, s, jobs, t, theta, L, d); break;
+    case 2: hipLaunchKernelGGL((k_ode_bwd<H, K, M, 1, PARAMS, false>), grid, block, 0, s, jobs, t, theta, L, d); break;
+    case 3: hipLaunchKernelGGL((k_ode_bwd<H, K, M, 1, PARAMS, true>), grid, block, 0, s, jobs, t, theta, L, d); break;
+    case 4: hipLaunchKernelGGL((k_ode_bwd<H, K, M, 2, PARAMS, false>), grid, block, 0, s, jobs, t, theta, L, d); break;
     default: return XW_E_ARG;
   }
   return xw_launch_status();
@@ -851,6 +1004,12 @@ int launch_bwd(int method, const BwdJobs& jobs, const double* t, const double* t
 
 extern "C" int xw_ode_bwd_slabs(int N) { return (N + 15) / 16; }
 
+extern "C" int xw_ode_act_rows(int method, int H, int K, int m) {
+  if (H != 20 || K != 10 || m < 1 || m > 8) return XW_E_DIMS;
+  const int S = method == 0 ? 1 : method == 1 ? 2 : 0;           // rk4: the sweeps recompute
+  return S == 0 ? 0 : S * m * K + (S - 1) * H;
+}
+
 extern "C" int xw_ode_fwd_multi(const XwOdeFwdJob* jobs, int njobs, const double* t, const double* theta, int method, int L,
                                 int d, int H, int K, int m, double* zero16, void* stream) {
   if (!jobs || njobs < 1 || njobs > XW_MAXJOBS || !t || !theta || L <= 0 || d <= 0 || m < 1) return XW_E_ARG;
@@ -865,6 +1024,8 @@ extern "C" int xw_ode_fwd_multi(const XwOdeFwdJob* jobs, int njobs, const double
     J.start[i] = on ? jobs[i].start : nullptr;
     J.u[i] = on ? jobs[i].u : nullptr;
     J.Y[i] = on ? jobs[i].Y : nullptr;
+    J.act[i] = (on && method != 2) ? jobs[i].act : nullptr;     // (rk4 sweeps recompute: nothing to store)
+    if (on && (J.act[i] != nullptr) != (J.act[0] != nullptr)) return XW_E_ARG;   // all groups of a launch, or none
     J.N[i] = on ? jobs[i].N : 0;
     J.tile0[i + 1] = J.tile0[i] + (on ? (jobs[i].N + 15) / 16 : 0);
   }
@@ -876,7 +1037,7 @@ extern "C" int xw_ode_fwd_multi(const XwOdeFwdJob* jobs, int njobs, const double
 
 extern "C" int xw_ode_fwd(const double* xT, const double* t, const double* start, const double* theta, int method, int N,
                           int L, int d, int H, int K, int m, double* u, double* Y, void* stream) {
-  XwOdeFwdJob j = {xT, start, u, Y, N};
+  XwOdeFwdJob j = {xT, start, u, Y, nullptr, N};
   return xw_ode_fwd_multi(&j, 1, t, theta, method, L, d, H, K, m, nullptr, stream);
 }
 
@@ -898,6 +1059,8 @@ extern "C" int xw_ode_bwd_multi(const XwOdeBwdJob* jobs, int njobs, const double
     J.xT[i] = on ? jobs[i].xT : nullptr;
     J.start[i] = on ? jobs[i].start : nullptr;
     J.Y[i] = on ? jobs[i].Y : nullptr;
+    J.act[i] = (on && method != 2) ? jobs[i].act : nullptr;
+    if (on && (J.act[i] != nullptr) != (J.act[0] != nullptr)) return XW_E_ARG;   // all groups of a launch, or none
     J.ubar[i] = on ? jobs[i].ubar : nullptr;
     J.gx[i] = (on && (mode & 1)) ? jobs[i].gx : nullptr;
     J.gs[i] = (on && (mode & 1)) ? jobs[i].gs : nullptr;
@@ -916,6 +1079,6 @@ extern "C" int xw_ode_bwd_multi(const XwOdeBwdJob* jobs, int njobs, const double
 extern "C" int xw_ode_bwd(const double* xT, const double* t, const double* start, const double* theta, const double* Y,
                           const double* ubar, int method, int N, int L, int d, int H, int K, int m, int mode, double* gx,
                           double* gs, double* gslab, void* stream) {
-  XwOdeBwdJob j = {xT, start, Y, ubar, gx, gs, gslab, N};
+  XwOdeBwdJob j = {xT, start, Y, nullptr, ubar, gx, gs, gslab, N};
   return xw_ode_bwd_multi(&j, 1, t, theta, method, L, d, H, K, m, mode, stream);
 }

@@ -108,6 +108,8 @@ class Engine:
         # opt-in: v, dv/dt, nabla_x v(t_0) of a group are reused while phi and the sample are unchanged (exact: the
         # reference recomputes identical values in every sub-step of an outer iteration).  Off by default.
         self.reuse_test_net = os.environ.get('XW_REUSE_V', '0') == '1'
+        # the forward pass stores the stage activations of every step for the sweeps (see include/xnwan.h, XwOdeFwdJob.act)
+        self.keep_activations = os.environ.get('XW_KEEP_ACT', '1') == '1'
         # The test network's launch is persistent (grid-stride over point tiles) and at 2 blocks per CU it owns every SIMD's
         # register file: the stepper's waves, launched next to it, then wait until it drains.  Capping it at 3/4 of the
         # resident slots leaves a quarter of the SIMDs to the stepper chains (measured: 1221 vs 1159 steps/s).
@@ -215,6 +217,10 @@ class Engine:
         G.gxv, G.gtv, G.gx, G.gs = e(d, N), e(N), e(d, N), e(N)
         G.ubarA, G.ubarB, G.vbar, G.s3x = e(L, N), e(L, N), e(L, N), e(N)
         G.c = G.cp = None
+        # stage activations of every step, written by the forward, read back by the sweeps (183 MB at N = 4096, L = 32)
+        ar = KN.ode_act_rows(self.method, H, self.K, self.m) if self.keep_activations else 0
+        G.act = e(max(L - 1, 1), ar, N) if ar else None
+        G.act_b = e(max(Lb - 1, 1), ar, Nb) if (ar and Nb) else None
         G.ns_u = KN.ode_bwd_slabs(N)
         G.ns_b = KN.ode_bwd_slabs(Nb) if Nb else 0
         G.slabA = e(G.ns_u + G.ns_b, self.Pu)          # sweep with cotangent A (interior) + the boundary sweep
@@ -287,11 +293,11 @@ class Engine:
 
     def _job(self, G, which, ubar=None, gslab=None, want_x=False):
         if which == 'i':
-            j = dict(xT=G.xT, start=G.start, u=G.u, Y=G.Y, ubar=ubar, gslab=gslab)
+            j = dict(xT=G.xT, start=G.start, u=G.u, Y=G.Y, act=G.act, ubar=ubar, gslab=gslab)
             if want_x:
                 j.update(gx=G.gx, gs=G.gs)
         else:
-            j = dict(xT=G.xbT, start=G.start_b, u=G.ub, Y=G.Yb, ubar=ubar, gslab=gslab)
+            j = dict(xT=G.xbT, start=G.start_b, u=G.ub, Y=G.Yb, act=G.act_b, ubar=ubar, gslab=gslab)
         return j
 
     def _contract(self, G, adam_state=None):

@@ -78,7 +78,9 @@ def ode_fwd_multi(jobs, t, theta, method, H, K, m, zero16=None):
         N = j['xT'].shape[1]
         _chk(j['xT'], F64, (d, N), 'xT'); _chk(j['start'], F64, (N,), 'start'); _chk(j['u'], F64, (L, N), 'u')
         _chk(j.get('Y'), F64, (L, H, N), 'Y')
-        a.xT, a.start, a.u, a.Y, a.N = _p(j['xT']), _p(j['start']), _p(j['u']), _p(j.get('Y')), N
+        if j.get('act') is not None:
+            _chk(j['act'], F64, (max(L - 1, 1), ode_act_rows(method, H, K, m), N), 'act')
+        a.xT, a.start, a.u, a.Y, a.act, a.N = _p(j['xT']), _p(j['start']), _p(j['u']), _p(j.get('Y')), _p(j.get('act')), N
     _chk(zero16, F64, (16,), 'zero16')
     check(lib.xw_ode_fwd_multi(arr, len(jobs), _p(t), _p(theta), method, L, d, H, K, m, _p(zero16), _stream()), 'xw_ode_fwd_multi')
 
@@ -101,7 +103,10 @@ def ode_bwd_multi(jobs, t, theta, method, H, K, m, want_x, want_params, x_cot_on
             _chk(j['gx'], F64, (d, N), 'gx'); _chk(j['gs'], F64, (N,), 'gs')
         if want_params:
             _chk(j['gslab'], F64, (ode_bwd_slabs(N), P), 'gslab')
+        if j.get('act') is not None:
+            _chk(j['act'], F64, (max(L - 1, 1), ode_act_rows(method, H, K, m), N), 'act')
         a.xT, a.start, a.Y, a.ubar, a.N = _p(j['xT']), _p(j['start']), _p(j['Y']), _p(j.get('ubar')), N
+        a.act = _p(j.get('act'))
         a.gx, a.gs, a.gslab = _p(j.get('gx')), _p(j.get('gs')), _p(j.get('gslab'))
     if x_cot_ones and not (want_x and want_params):
         raise XnwanError('x_cot_ones needs want_x and want_params')
@@ -111,6 +116,13 @@ def ode_bwd_multi(jobs, t, theta, method, H, K, m, want_x, want_params, x_cot_on
 
 def ode_bwd_slabs(N):
     return lib.xw_ode_bwd_slabs(N)
+
+
+def ode_act_rows(method, H, K, m):
+    """rows per step of the activation store that ode_fwd_multi fills and ode_bwd_multi reads (0: not used by `method`)"""
+    r = lib.xw_ode_act_rows(int(method), H, K, m)
+    check(min(r, 0), 'xw_ode_act_rows')
+    return r
 
 
 def ode_bwd(xT, t, start, theta, Y, ubar, method, H, K, m, want_x=True, want_params=False, gx=None, gs=None, gslab=None):
