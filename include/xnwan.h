@@ -82,8 +82,7 @@ int xw_ode_bwd_multi(const XwOdeBwdJob* jobs, int njobs, const double* t, const 
 
 /* ---- v_phi: discriminator.forward (src/model.py:37-47) + d/dt by forward-mode ------------------------------------
  * Path mode (tpp == NULL): point (l,n) = (t[l], x_n).  Point mode (tpp != NULL): L must be 1, point n = (tpp[n], x_n).
- * v[L,N] out; vt[L,N] out = dv/dt (may be NULL).  Nothing is stashed for the backward: xw_disc_bwd recomputes the
- * forward of its 16-point tiles in registers (cheaper than an HBM round trip of the activations).
+ * v[L,N] out; vt[L,N] out = dv/dt (may be NULL).
  * gxv[d,ngrad], gtv[ngrad] (may be NULL): input gradient of v (nabla_x v, dv/dt by reverse mode) for the LEADING ngrad
  * points in time-major order -- the weak form reads nabla phi only at the first time index (pass ngrad = N), so this
  * fuses what would otherwise be a separate xw_disc_gradx launch; needs q <= 16.
@@ -91,7 +90,11 @@ int xw_ode_bwd_multi(const XwOdeBwdJob* jobs, int njobs, const double* t, const 
  * that run concurrently. */
 int xw_disc_fwd(const double* xT, const double* t, const double* tpp, const double* phi,
                 int N, int L, int d, int W, int q, double* v, double* vt, double* gxv, double* gtv, int ngrad,
-                int max_blocks, void* stream);
+                int max_blocks, double* act, void* stream);
+/* act (may be NULL): activation record [xw_disc_act_rows(W, q)][N L] = the inputs relu(a_j) of the q tied layers and
+ * tanh(a_q), point-major.  Given to xw_disc_bwd it replaces that kernel's forward recompute (500 doubles per point =
+ * 524 MB at the headline size; written at ~2 TB/s next to a matrix-bound kernel, read once by the backward). */
+int xw_disc_act_rows(int W, int q);
 
 /* input gradient of <vbar, v> at a set of points (reverse mode, no parameter gradients): gxv[d,N] (nabla_x) and
  * gtv[N] (d/dt), for the N points (t_n, x_n) with t_n = tpp ? tpp[n] : t[0]; vbar[N] or NULL (= ones).
@@ -100,9 +103,10 @@ int xw_disc_gradx(const double* xT, const double* t, const double* tpp, const do
                   int N, int d, int W, int q, double* gxv, double* gtv, void* stream);
 
 int xw_disc_bwd_slabs(int N, int L);
-/* parameter gradient of <vbar, v>: slabs gslab[xw_disc_bwd_slabs][P_v] (input gradient: xw_disc_gradx) */
+/* parameter gradient of <vbar, v>: slabs gslab[xw_disc_bwd_slabs][P_v] (input gradient: xw_disc_gradx).
+ * act: the record xw_disc_fwd stored for the same phi and points, or NULL (the forward is then recomputed per tile) */
 int xw_disc_bwd(const double* xT, const double* t, const double* tpp, const double* phi, const double* vbar,
-                int N, int L, int d, int W, int q, double* gslab, void* stream);
+                int N, int L, int d, int W, int q, const double* act, double* gslab, void* stream);
 
 /* ---- weak functional and cotangents (src/loss.py:46-96) -----------------------------------------------------------
  * scal[16] (device, float64): 0 I   1 S=sum v^2   2 SSE_init   3 SSE_bdry   4 loss_u   5 loss_v   6 int   (rest reserved)

@@ -248,6 +248,28 @@ def test_disc_backward(N, L, d):
         off += n
 
 
+@pytest.mark.parametrize('N,L,d', [(37, 4, 5), (64, 3, 20), (50, 3, 70)])
+def test_disc_backward_from_stored_activations(N, L, d):
+    """xw_disc_fwd can leave the layer inputs of every point behind; xw_disc_bwd given that record skips its forward
+    recompute and must return the same parameter gradient"""
+    from xnode_wan_pde_solver_amd import kernels as KN
+    _, phi = _params(d, 8, 51)
+    x, t, _ = _sample(N, L, d, 52)
+    g = torch.Generator().manual_seed(53)
+    vbar = torch.randn(L, N, dtype=F64, generator=g).cuda()
+    xT, tc, blob = x.double().t().contiguous().cuda(), t.double().cuda(), _blob(phi, V_ORDER)
+    rows = KN.disc_act_rows(W, Q)
+    assert rows == (Q + 1) * W
+    act = torch.full((rows, L * N), float('nan'), dtype=F64, device='cuda')
+    v0, vt0 = KN.disc_fwd(xT, tc, blob, W, Q)
+    v1, vt1 = KN.disc_fwd(xT, tc, blob, W, Q, act=act)
+    assert torch.equal(v0, v1) and torch.equal(vt0, vt1)
+    assert torch.isfinite(act).all() and bool((act[:Q * W] >= 0).all())          # relu outputs, every row written
+    s0 = KN.slab_sum(KN.disc_bwd(xT, tc, blob, vbar, W, Q))
+    s1 = KN.slab_sum(KN.disc_bwd(xT, tc, blob, vbar, W, Q, act=act))
+    _close(s1, s0, 1e-12, 'phi gradient from the stored record')
+
+
 def test_generator_cotangents_split_and_merged_forms():
     """ubarA (pollution + initial penalty), ubarB (= dI/du) and the merged form A + (2/I) B against the closed formulas
     (src/loss.py:55,64,70,79,93)"""

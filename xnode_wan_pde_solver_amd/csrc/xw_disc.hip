@@ -78,11 +78,12 @@ __device__ __forceinline__ void input_layer(const double* __restrict__ ph, const
 // ------------------------------------------------------------------------------------------------------------------
 #define XW_QMAX 16   // deepest test network whose ReLU masks fit the LDS stash of k_disc_fwd's fused input gradient
 
-template <int W>
+template <int W, bool ACT>
 __global__ void __launch_bounds__(256, 2) k_disc_fwd(const double* __restrict__ xT, const double* __restrict__ tf,
                                                      const double* __restrict__ tpp, const double* __restrict__ ph, int N,
                                                      int L, int d, int q, double* __restrict__ v, double* __restrict__ vt,
-                                                     double* __restrict__ gxv, double* __restrict__ gtv, int ngrad) {
+                                                     double* __restrict__ gxv, double* __restrict__ gtv, int ngrad,
+                                                     double* __restrict__ act) {
   typedef VDim<W> D;
   // Vh as MFMA A-fragments in LDS (26.6 KB), shared by the 4 waves of the block: one ds_read_b64 feeds two 64-cycle MFMAs
   // (value and d/dt tangent), and keeping them out of the register file lets two waves share a SIMD so that one wave's
@@ -117,6 +118,9 @@ __global__ void __launch_bounds__(256, 2) k_disc_fwd(const double* __restrict__ 
     // order) also get the input gradient of v, by a reverse chain through the masks stashed below
     const bool want_grad = gxv != nullptr && tile * 16 < ngrad;         // wave-uniform
     d4 a[D::MT], ad[D::MT];
+    double* actl = act;                                                 // laundered like pht below: the record's row
+    asm volatile("" : "+s"(actl));                                      // addresses are formed per tile, not hoisted
+    const int aoff = g * (int)P + pt.p;
     const double* pht = ph;                                             // laundered: keeps the input-layer fragment
     asm volatile("" : "+s"(pht));                                       // addresses out of the loop-invariant (spilled) set
     input_layer<W>(pht, o, xT, N, d, pt, a, ad);
@@ -144,6 +148,10 @@ __global__ void __launch_bounds__(256, 2) k_disc_fwd(const double* __restrict__ 
         const double av = a[ks >> 2][ks & 3];
         const double b = av > 0.0 ? av : 0.0;
         const double bd = av > 0.0 ? ad[ks >> 2][ks & 3] : 0.0;
+        if (ACT) {   // activation store: row j W + k of the record is the layer input relu(a_j)[k], point-major
+          double* __restrict__ rowp = actl + ((long)j * W + 4 * ks) * P;        // uniform pointer + 32-bit lane offset
+          if (4 * ks + g < W && pt.valid) rowp[aoff] = b;
+        }
         if ((ks & 1) == 0) asm volatile("" ::: "memory");   // bound the LDS loads in flight (else all 52 are hoisted -> spills)
 #pragma unroll
         for (int mt = 0; mt < D::MTF; ++mt) {
@@ -186,6 +194,8 @@ __global__ void __launch_bounds__(256, 2) k_disc_fwd(const double* __restrict__ 
       for (int r = 0; r < 4; ++r)
         if (16 * mt + 4 * r < W) {  // rows 16 mt + 4 r + g >= W only carry zero padding
           const double th = xw_tanh(a[mt][r]);
+          if (ACT && 16 * mt + 4 * r + g < W && pt.valid)
+            (actl + ((long)q * W + 16 * mt + 4 * r) * P)[aoff] = th;           // last rows of the record: tanh(a_q)
           const double vo = sB[16 * D::MT + 16 * mt + g + 4 * r];
           sv += vo * th;
           sd += vo * (1.0 - th * th) * ad[mt][r];
@@ -262,12 +272,14 @@ template <int W> struct BwdLds {
   static_assert(total * 8 <= 160 * 1024, "LDS budget of one CU");
 };
 
-template <int W, int Q, int CTG, bool PARAMS, bool INGRAD>
+// SAVED: the layer inputs relu(a_j) and tanh(a_q) come from the record k_disc_fwd stored (xw_disc_fwd `act`): no forward
+// recompute at all -- the kernel is the reverse chain + the weight-gradient outer products.
+template <int W, int Q, int CTG, bool PARAMS, bool INGRAD, bool SAVED = false>
 __global__ void __launch_bounds__(256) k_disc_bwd(const double* __restrict__ xT, const double* __restrict__ tf,
                                                   const double* __restrict__ tpp, const double* __restrict__ ph,
                                                   const double* __restrict__ vbar, int N, int L, int d,
                                                   double* __restrict__ gslab, double* __restrict__ gxv,
-                                                  double* __restrict__ gtv) {
+                                                  double* __restrict__ gtv, const double* __restrict__ act) {
   typedef VDim<W> D;
   typedef BwdLds<W> S;
   __shared__ double lds[S::total];
@@ -321,7 +333,7 @@ __global__ void __launch_bounds__(256) k_disc_bwd(const double* __restrict__ xT,
   // layers per checkpoint segment.  1: every layer input r_j stays in registers (13 live f64 per layer at W = 50) and
   // nothing is recomputed -- 497 vs 558 us at SEG = 3 even with 48 spilled registers.  The wide-input variant (CTG = 2,
   // d > 62) carries 32 more accumulator registers and keeps the 3-layer segments.
-  constexpr int SEG = CTG == 1 ? 1 : 3;
+  constexpr int SEG = (CTG == 1 || SAVED) ? 1 : 3;
   constexpr int NSEG = (Q + SEG - 1) / SEG;
   for (long st = blockIdx.x; st < nsuper; st += gridDim.x) {
     const Pt pt = locate(st * 4 + wave, P, N, tf, tpp);
@@ -329,20 +341,40 @@ __global__ void __launch_bounds__(256) k_disc_bwd(const double* __restrict__ xT,
     //      live activations are 2 x SEG tiles instead of Q (which did not fit the 512-register file and spilled)
     d4 ck[NSEG][D::MT];
     d4 a[D::MT], ad[D::MT];
-    input_layer<W>(ph, o, xT, N, d, pt, a, ad);
+    // one layer's inputs from the activation store (rows >= W of the last tile: zero)
+    const int aoff = g * (int)P + pt.p;                // 32-bit lane offset; row pointers below are uniform
+    auto load_layer = [&](int j, d4 (&r)[D::MT]) {
+      const double* base = act + (long)j * W * P;
+      asm volatile("" : "+s"(base));                   // form the row addresses here, not hoisted out of the tile loop
 #pragma unroll
-    for (int j = 0; j < Q; ++j) {
-      d4 r[D::MT];
-#pragma unroll
-      for (int mt = 0; mt < D::MT; ++mt) {
+      for (int mt = 0; mt < D::MT; ++mt)
 #pragma unroll
         for (int q_ = 0; q_ < 4; ++q_)
           if (q_ < D::LR(mt)) {
-            r[mt][q_] = a[mt][q_] > 0.0 ? a[mt][q_] : 0.0;
-            if (j % SEG == 0) ck[j / SEG][mt][q_] = r[mt][q_];
+            const int row = 16 * mt + 4 * q_ + g;
+            r[mt][q_] = (16 * mt + 4 * q_ + 3 < W || row < W) ? (base + (long)(16 * mt + 4 * q_) * P)[aoff] : 0.0;
           }
+    };
+    d4 rnext[D::MT];                                   // SAVED: inputs of the layer that is reversed next (prefetch)
+    if constexpr (SAVED) {
+      load_layer(Q, a);                                // tanh(a_q)
+      load_layer(Q - 1, rnext);
+    } else {
+      input_layer<W>(ph, o, xT, N, d, pt, a, ad);
+#pragma unroll
+      for (int j = 0; j < Q; ++j) {
+        d4 r[D::MT];
+#pragma unroll
+        for (int mt = 0; mt < D::MT; ++mt) {
+#pragma unroll
+          for (int q_ = 0; q_ < 4; ++q_)
+            if (q_ < D::LR(mt)) {
+              r[mt][q_] = a[mt][q_] > 0.0 ? a[mt][q_] : 0.0;
+              if (j % SEG == 0) ck[j / SEG][mt][q_] = r[mt][q_];
+            }
+        }
+        layer(r, a);
       }
-      layer(r, a);
     }
     // ---- output layer and its cotangent
     const double vb = pt.valid ? (vbar != nullptr ? vbar[pt.p] : 1.0) : 0.0;
@@ -352,7 +384,7 @@ __global__ void __launch_bounds__(256) k_disc_bwd(const double* __restrict__ xT,
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         double th = 0.0;
-        if (16 * mt + 4 * r < W) th = xw_tanh(a[mt][r]);
+        if (16 * mt + 4 * r < W) th = SAVED ? (r < D::LR(mt) ? a[mt][r] : 0.0) : xw_tanh(a[mt][r]);
         dl[mt][r] = sB[16 * D::MT + 16 * mt + g + 4 * r] * (1.0 - th * th) * vb;
         if (PARAMS) sO[(wave * 64 + lane) * 16 + mt * 4 + r] += (mt == D::MT - 1 && r == 3) ? (g == 0 ? vb : 0.0) : vb * th;
       }
@@ -364,7 +396,10 @@ __global__ void __launch_bounds__(256) k_disc_bwd(const double* __restrict__ xT,
       for (int mt = 0; mt < D::MT; ++mt)
 #pragma unroll
         for (int q_ = 0; q_ < 4; ++q_)
-          if (q_ < D::LR(mt)) seg[0][mt][q_] = ck[sg][mt][q_];
+          if (q_ < D::LR(mt)) seg[0][mt][q_] = SAVED ? rnext[mt][q_] : ck[sg][mt][q_];
+      if constexpr (SAVED) {
+        if (sg > 0) load_layer(sg - 1, rnext);         // in flight while this layer is reversed
+      }
 #pragma unroll
       for (int k = 1; k < SEG; ++k)
         if (sg * SEG + k < Q) {
@@ -533,9 +568,11 @@ int bwd_blocks(long P) {
 
 }  // namespace
 
+extern "C" int xw_disc_act_rows(int W, int q) { return (W == 50 && q >= 0) ? (q + 1) * W : XW_E_DIMS; }
+
 extern "C" int xw_disc_fwd(const double* xT, const double* t, const double* tpp, const double* phi, int N, int L, int d,
                            int W, int q, double* v, double* vt, double* gxv, double* gtv, int ngrad, int max_blocks,
-                           void* stream) {
+                           double* act, void* stream) {
   if (!xT || !phi || !v || N <= 0 || L <= 0 || d <= 0 || q < 0) return XW_E_ARG;
   if (!tpp && !t) return XW_E_ARG;
   if (tpp && L != 1) return XW_E_ARG;
@@ -545,23 +582,28 @@ extern "C" int xw_disc_fwd(const double* xT, const double* t, const double* tpp,
   long blocks = (ntiles + 3) / 4;
   long cap = max_blocks > 0 ? max_blocks : 512;   // default: 2 blocks per CU resident (launch bounds), grid-stride over tiles
   if (blocks > cap) blocks = cap;
-  hipLaunchKernelGGL((k_disc_fwd<50>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, xT, t, tpp, phi, N, L, d,
-                     q, v, vt, gxv, gtv, ngrad);
+  if ((long)N * L * 4 >= (1L << 31)) return XW_E_ARG;                  // 32-bit lane offsets into the activation record
+  if (act != nullptr)
+    hipLaunchKernelGGL((k_disc_fwd<50, true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, xT, t, tpp, phi, N,
+                       L, d, q, v, vt, gxv, gtv, ngrad, act);
+  else
+    hipLaunchKernelGGL((k_disc_fwd<50, false>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, xT, t, tpp, phi, N,
+                       L, d, q, v, vt, gxv, gtv, ngrad, act);
   return xw_launch_status();
 }
 
 extern "C" int xw_disc_bwd_slabs(int N, int L) { return bwd_blocks((long)N * L); }
 
-#define XW_DISC_BWD(PARAMS, INGRAD)                                                                                    \
-  if (d + 2 <= 64)                                                                                                     \
-    hipLaunchKernelGGL((k_disc_bwd<50, 9, 1, PARAMS, INGRAD>), dim3(blocks), dim3(256), 0, s, xT, t, tpp, phi, vbar, N, \
-                       L, d, gslab, gxv, gtv);                                                                         \
-  else                                                                                                                 \
-    hipLaunchKernelGGL((k_disc_bwd<50, 9, 2, PARAMS, INGRAD>), dim3(blocks), dim3(256), 0, s, xT, t, tpp, phi, vbar, N, \
-                       L, d, gslab, gxv, gtv);
+#define XW_DISC_BWD(PARAMS, INGRAD, SAVED)                                                                               \
+  if (d + 2 <= 64)                                                                                                       \
+    hipLaunchKernelGGL((k_disc_bwd<50, 9, 1, PARAMS, INGRAD, SAVED>), dim3(blocks), dim3(256), 0, s, xT, t, tpp, phi, vbar, \
+                       N, L, d, gslab, gxv, gtv, act);                                                                   \
+  else                                                                                                                   \
+    hipLaunchKernelGGL((k_disc_bwd<50, 9, 2, PARAMS, INGRAD, SAVED>), dim3(blocks), dim3(256), 0, s, xT, t, tpp, phi, vbar, \
+                       N, L, d, gslab, gxv, gtv, act);
 
 extern "C" int xw_disc_bwd(const double* xT, const double* t, const double* tpp, const double* phi, const double* vbar,
-                           int N, int L, int d, int W, int q, double* gslab, void* stream) {
+                           int N, int L, int d, int W, int q, const double* act, double* gslab, void* stream) {
   if (!xT || !phi || !gslab || N <= 0 || L <= 0 || d <= 0) return XW_E_ARG;
   if (!tpp && !t) return XW_E_ARG;
   if (tpp && L != 1) return XW_E_ARG;
@@ -570,7 +612,11 @@ extern "C" int xw_disc_bwd(const double* xT, const double* t, const double* tpp,
   const int blocks = bwd_blocks((long)N * L);
   double* gxv = nullptr;
   double* gtv = nullptr;
-  XW_DISC_BWD(true, false)
+  if (act != nullptr) {
+    XW_DISC_BWD(true, false, true)
+  } else {
+    XW_DISC_BWD(true, false, false)
+  }
   return xw_launch_status();
 }
 
@@ -583,6 +629,7 @@ extern "C" int xw_disc_gradx(const double* xT, const double* t, const double* tp
   const int L = 1;
   const int blocks = bwd_blocks((long)N);
   double* gslab = nullptr;
-  XW_DISC_BWD(false, true)
+  const double* act = nullptr;
+  XW_DISC_BWD(false, true, false)
   return xw_launch_status();
 }

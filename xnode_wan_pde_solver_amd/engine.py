@@ -221,6 +221,9 @@ class Engine:
         ar = KN.ode_act_rows(self.method, H, self.K, self.m) if self.keep_activations else 0
         G.act = e(max(L - 1, 1), ar, N) if ar else None
         G.act_b = e(max(Lb - 1, 1), ar, Nb) if (ar and Nb) else None
+        # layer inputs of the test network at every point, stored by its forward in the discriminator sub-step and read
+        # back by its backward (524 MB at 131072 points)
+        G.vact = e(KN.disc_act_rows(self.W, self.q), L * N) if self.keep_activations else None
         G.ns_u = KN.ode_bwd_slabs(N)
         G.ns_b = KN.ode_bwd_slabs(Nb) if Nb else 0
         G.slabA = e(G.ns_u + G.ns_b, self.Pu)          # sweep with cotangent A (interior) + the boundary sweep
@@ -260,23 +263,26 @@ class Engine:
             for ev in events:
                 cur.wait_event(ev)
 
-    def _test_net(self, G, e0, blocks=None):
+    def _test_net(self, G, e0, blocks=None, store=False):
         """test network on side stream 0: v, dv/dt at all points; nabla_x v at the first time index rides along in the
         same launch (fused reverse chain).  Returns the completion event."""
         if getattr(G, 'skip_v', False):          # v, dv/dt, nabla_x v(t_0) in the buffers are still valid (see _v_fresh)
             return e0
-        return self._launch_test_net(G, e0, blocks=blocks)
+        return self._launch_test_net(G, e0, blocks=blocks, store=store)
 
-    def _launch_test_net(self, G, *events, blocks=None):
+    def _launch_test_net(self, G, *events, blocks=None, store=False):
         ph = self.phi.data
         blocks = blocks or self.v_blocks
+        # the record of layer inputs is wanted by the discriminator sub-step's backward; when evaluations are shared
+        # (reuse_test_net) the one that runs must leave it behind for that later sub-step
+        act = G.vact if getattr(G, 'vact_valid', False) else None      # (decided in _v_fresh, outside the captured code)
         with self._side(0, *events):
             if G.tpp is not None:
                 KN.disc_fwd(G.xvT_pts, None, ph, self.W, self.q, tpp=G.tpp, v=G.v.view(1, -1), vt=G.vt.view(1, -1),
-                            gxv=G.gxv, gtv=G.gtv, ngrad=G.N, max_blocks=blocks)
+                            gxv=G.gxv, gtv=G.gtv, ngrad=G.N, max_blocks=blocks, act=act)
             else:
                 KN.disc_fwd(G.xvT, G.t, ph, self.W, self.q, v=G.v, vt=G.vt, gxv=G.gxv, gtv=G.gtv, ngrad=G.N,
-                            max_blocks=blocks)
+                            max_blocks=blocks, act=act)
             return self._mark()
 
     def _reaction(self, G):
@@ -400,13 +406,15 @@ class Engine:
         if acc is not None:
             acc.copy_(self.grad_u)
 
-    def _v_fresh(self, G):
+    def _v_fresh(self, G, store=False):
         """python-side bookkeeping (outside the captured graphs): are the test-network outputs of this group still those
         of the current phi and sample?  Sets G.skip_v for the front segment and returns the graph-key suffix."""
         now = self._v_key(G)
         G.skip_v = self.reuse_test_net and getattr(G, 'v_version', None) == now
         G.v_version = now
-        return '_vcached' if G.skip_v else ''
+        if not G.skip_v:                 # this sub-step evaluates the test network: does it leave the layer inputs behind?
+            G.vact_valid = G.vact is not None and (store or self.reuse_test_net)
+        return ('_vcached' if G.skip_v else '') + ('_act' if getattr(G, 'vact_valid', False) else '')
 
     def _v_key(self, G):
         """(engine-side updates of phi, torch-side in-place writes to its parameters, resamples of the group)"""
@@ -437,7 +445,7 @@ class Engine:
         th = self.theta.data
         M = (self.method, self.H, self.K, self.m)
         e0 = self._mark()
-        e_v = self._test_net(G, e0, blocks=self.v_blocks_disc)
+        e_v = self._test_net(G, e0, blocks=self.v_blocks_disc, store=True)
         KN.ode_fwd_multi([self._job(G, 'i')], G.t, th, *M, zero16=self.scal)
         self._reaction(G)
         KN.ode_bwd_multi([self._job(G, 'i', want_x=True)], G.t, th, *M, want_x=True, want_params=False)
@@ -447,10 +455,11 @@ class Engine:
     def _disc_mid(self, G):
         KN.disc_cotangent(G.u, G.v, G.w, G.f, G.h, G.Vol, G.Nglob, self.scal, G.vbar, c=G.c, ckappa=G.ck,
                           pollution=self.pollution)
+        act = G.vact if getattr(G, 'vact_valid', False) else None
         if G.tpp is None:
-            KN.disc_bwd(G.xvT, G.t, self.phi.data, G.vbar, self.W, self.q, gslab=G.slab_v)
+            KN.disc_bwd(G.xvT, G.t, self.phi.data, G.vbar, self.W, self.q, gslab=G.slab_v, act=act)
         else:
-            KN.disc_bwd(G.xvT_pts, None, self.phi.data, G.vbar.view(1, -1), self.W, self.q, tpp=G.tpp, gslab=G.slab_v)
+            KN.disc_bwd(G.xvT_pts, None, self.phi.data, G.vbar.view(1, -1), self.W, self.q, tpp=G.tpp, gslab=G.slab_v, act=act)
 
     def _disc_back(self, G):
         lr, st = self.config['v_rate'], self.adam_v
@@ -474,7 +483,7 @@ class Engine:
 
     def discriminator_step(self, G):
         """one pass of the discriminator sub-step body; loss_v is left in scal[5] (device)"""
-        sfx = self._v_fresh(G)
+        sfx = self._v_fresh(G, store=True)
         self._phi_version += 1                                    # phi changes at the end of this sub-step
         if self.world is None:
             self._run(G, 'disc' + sfx, self._disc_all)

@@ -148,9 +148,17 @@ def ode_bwd(xT, t, start, theta, Y, ubar, method, H, K, m, want_x=True, want_par
     return (gx if want_x else None), (gs if want_x else None), (gslab if want_params else None)
 
 
-def disc_fwd(xT, t, phi, W, q, tpp=None, want_vt=True, v=None, vt=None, gxv=None, gtv=None, ngrad=0, max_blocks=0):
+def disc_act_rows(W, q):
+    """rows of the activation record disc_fwd can store for disc_bwd: the inputs of the q tied layers + tanh(a_q)"""
+    r = lib.xw_disc_act_rows(W, q)
+    check(min(r, 0), 'xw_disc_act_rows')
+    return r
+
+
+def disc_fwd(xT, t, phi, W, q, tpp=None, want_vt=True, v=None, vt=None, gxv=None, gtv=None, ngrad=0, max_blocks=0, act=None):
     """v_phi and dv/dt.  Path mode: points (t[l], x_n) -> [L,N].  Point mode (tpp[N]): points (tpp[n], x_n) -> [1,N].
-    gxv[d,ngrad] / gtv[ngrad]: also return the input gradient of v at the leading ngrad points (time-major order)."""
+    gxv[d,ngrad] / gtv[ngrad]: also return the input gradient of v at the leading ngrad points (time-major order).
+    act[disc_act_rows(W, q), L*N]: also store the layer inputs, for disc_bwd(act=...)."""
     _need_gpu()
     d, N = xT.shape
     L = 1 if tpp is not None else t.shape[0]
@@ -162,8 +170,10 @@ def disc_fwd(xT, t, phi, W, q, tpp=None, want_vt=True, v=None, vt=None, gxv=None
     _chk(v, F64, (L, N), 'v'); _chk(vt, F64, (L, N), 'vt')
     if gxv is not None:
         _chk(gxv, F64, (d, ngrad), 'gxv'); _chk(gtv, F64, (ngrad,), 'gtv')
+    if act is not None:
+        _chk(act, F64, (disc_act_rows(W, q), L * N), 'act')
     check(lib.xw_disc_fwd(_p(xT), _p(t), _p(tpp), _p(phi), N, L, d, W, q, _p(v), _p(vt if want_vt else None), _p(gxv), _p(gtv),
-                          int(ngrad), int(max_blocks), _stream()), 'xw_disc_fwd')
+                          int(ngrad), int(max_blocks), _p(act), _stream()), 'xw_disc_fwd')
     return v, (vt if want_vt else None)
 
 
@@ -186,8 +196,9 @@ def disc_bwd_slabs(N, L):
     return lib.xw_disc_bwd_slabs(N, L)
 
 
-def disc_bwd(xT, t, phi, vbar, W, q, tpp=None, gslab=None):
-    """parameter gradient of <vbar, v> as partial slabs [nslab, P_v]."""
+def disc_bwd(xT, t, phi, vbar, W, q, tpp=None, gslab=None, act=None):
+    """parameter gradient of <vbar, v> as partial slabs [nslab, P_v].  act: the record disc_fwd stored for the same phi and
+    points (skips the forward recompute)."""
     _need_gpu()
     d, N = xT.shape
     L = 1 if tpp is not None else t.shape[0]
@@ -197,7 +208,10 @@ def disc_bwd(xT, t, phi, vbar, W, q, tpp=None, gslab=None):
     ns = disc_bwd_slabs(N, L)
     gslab = torch.empty(ns, P, dtype=F64, device=xT.device) if gslab is None else gslab
     _chk(gslab, F64, (ns, P), 'gslab')
-    check(lib.xw_disc_bwd(_p(xT), _p(t), _p(tpp), _p(phi), _p(vbar), N, L, d, W, q, _p(gslab), _stream()), 'xw_disc_bwd')
+    if act is not None:
+        _chk(act, F64, (disc_act_rows(W, q), L * N), 'act')
+    check(lib.xw_disc_bwd(_p(xT), _p(t), _p(tpp), _p(phi), _p(vbar), N, L, d, W, q, _p(act), _p(gslab), _stream()),
+          'xw_disc_bwd')
     return gslab
 
 
