@@ -178,7 +178,7 @@ def main():
                 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_FP64_MATRIX_TFLOPS, 4), 'traffic': traffic,
                 'alg_flop_per_launch': alg_flops[dominant], 'avg_launch_ms': round(kern[dominant]['avg_ms'], 4)}
     if dominant == 'disc_fwd' and not args.no_solo:
-        # The production launches above are capped at 3/4 (generator) and 7/8 (discriminator sub-step) of the resident block
+        # The production launches above are capped at 3/4 of the resident block
         # slots (Engine.v_blocks, v_blocks_disc) so that the stepper's waves find room next to them; the same kernel given the
         # whole chip, for reference:
         roofline['launch_blocks'] = {'generator_substep': eng.v_blocks, 'discriminator_substep': eng.v_blocks_disc, 'slots': 512}
