@@ -166,17 +166,24 @@ def main():
     }
     dominant = max((k for k in kern if k in alg_flops), key=lambda k: kern[k]['ms_per_step'])
     ach = alg_flops[dominant] / (kern[dominant]['avg_ms'] * 1e-3) / 1e12
-    traffic = None                                         # HBM bytes per launch from the committed PMC passes (profiles/)
+    traffic, traffic_by_variant = None, None                # HBM bytes per launch from the committed PMC passes (profiles/)
     pmc_path = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
     default_workload = (args.dim, args.n_r, args.n_b, args.n_t) == (20, 4096, 4096, 32)
     if os.path.exists(pmc_path) and default_workload:
         pmc = json.load(open(pmc_path))['kernels']
-        key = {'disc_fwd': 'k_disc_fwd<50>', 'disc_bwd': 'k_disc_bwd<50,9,1,true,false>'}.get(dominant)
-        if key in pmc:
-            traffic = pmc[key]['hbm_bytes_per_launch_corrected']
+        # k_disc_fwd runs in two variants: plain (generator sub-steps, 3.9 MB of inputs + outputs) and with the activation
+        # record for the backward (discriminator sub-step, +524 MB of stores by design): average over the g,g,d cycle, like avg_ms
+        keys = {'disc_fwd': ['k_disc_fwd<50,false>', 'k_disc_fwd<50,true>'],
+                'disc_bwd': ['k_disc_bwd<50,9,1,true,false,true>']}.get(dominant, [])
+        if keys and all(k in pmc for k in keys):
+            wts = [schedule.count('g'), schedule.count('d')] if len(keys) == 2 else [1]     # launches per g,g,d cycle
+            traffic = int(sum(w_ * pmc[k]['hbm_bytes_per_launch_corrected'] for w_, k in zip(wts, keys)) / sum(wts))
+            traffic_by_variant = {k: pmc[k]['hbm_bytes_per_launch_corrected'] for k in keys}
     roofline = {'bound': 'mfma', 'kernel': dominant, 'achieved': round(ach, 3), 'peak': PEAK_FP64_MATRIX_TFLOPS,
                 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_FP64_MATRIX_TFLOPS, 4), 'traffic': traffic,
                 'alg_flop_per_launch': alg_flops[dominant], 'avg_launch_ms': round(kern[dominant]['avg_ms'], 4)}
+    if traffic_by_variant:
+        roofline['traffic_by_variant'] = traffic_by_variant
     if dominant == 'disc_fwd' and not args.no_solo:
         # The production launches above are capped at 3/4 of the resident block
         # slots (Engine.v_blocks, v_blocks_disc) so that the stepper's waves find room next to them; the same kernel given the
