@@ -124,8 +124,9 @@ __global__ void __launch_bounds__(256, 2) k_disc_fwd(const double* __restrict__ 
     const double* pht = ph;                                             // laundered: keeps the input-layer fragment
     asm volatile("" : "+s"(pht));                                       // addresses out of the loop-invariant (spilled) set
     input_layer<W>(pht, o, xT, N, d, pt, a, ad);
-    for (int j = 0; j < q; ++j) {
-      d4 nw[D::MT], nd[D::MT];
+    // one tied layer (value and d/dt tangent): (ai, adi) -> (nw, nd).  The loop below alternates two register sets so
+    // that no layer ends with 32 register moves (a wave's VALU work does not overlap its FP64 MFMAs).
+    auto layer = [&](int j, const d4 (&ai)[D::MT], const d4 (&adi)[D::MT], d4 (&nw)[D::MT], d4 (&nd)[D::MT]) {
 #pragma unroll
       for (int mt = 0; mt < D::MT; ++mt) {
 #pragma unroll
@@ -137,7 +138,7 @@ __global__ void __launch_bounds__(256, 2) k_disc_fwd(const double* __restrict__ 
 #pragma unroll
         for (int mt = 0; mt < D::MT; ++mt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) mask |= (a[mt][r] > 0.0 ? 1u : 0u) << (4 * mt + r);
+          for (int r = 0; r < 4; ++r) mask |= (ai[mt][r] > 0.0 ? 1u : 0u) << (4 * mt + r);
         sMask[j][threadIdx.x] = (unsigned short)mask;
       }
       double tv[D::TR], td[D::TR];                          // partial dot products of the tail rows (this lane's k = 4 ks + g)
@@ -145,9 +146,9 @@ __global__ void __launch_bounds__(256, 2) k_disc_fwd(const double* __restrict__ 
       for (int r = 0; r < D::TR; ++r) tv[r] = td[r] = 0.0;
 #pragma unroll
       for (int ks = 0; ks < D::KS; ++ks) {
-        const double av = a[ks >> 2][ks & 3];
+        const double av = ai[ks >> 2][ks & 3];
         const double b = av > 0.0 ? av : 0.0;
-        const double bd = av > 0.0 ? ad[ks >> 2][ks & 3] : 0.0;
+        const double bd = av > 0.0 ? adi[ks >> 2][ks & 3] : 0.0;
         if (ACT) {   // activation store: row j W + k of the record is the layer input relu(a_j)[k], point-major
           double* __restrict__ rowp = actl + ((long)j * W + 4 * ks) * P;        // uniform pointer + 32-bit lane offset
           if (4 * ks + g < W && pt.valid) rowp[aoff] = b;
@@ -181,10 +182,21 @@ __global__ void __launch_bounds__(256, 2) k_disc_fwd(const double* __restrict__ 
         nw[D::MT - 1] = tw;
         nd[D::MT - 1] = tdd;
       }
+    };
+    {
+      d4 b0[D::MT], bd0[D::MT];
+      int j = 0;
+      for (; j + 1 < q; j += 2) {
+        layer(j, a, ad, b0, bd0);
+        layer(j + 1, b0, bd0, a, ad);
+      }
+      if (j < q) {
+        layer(j, a, ad, b0, bd0);
 #pragma unroll
-      for (int mt = 0; mt < D::MT; ++mt) {
-        a[mt] = nw[mt];
-        ad[mt] = nd[mt];
+        for (int mt = 0; mt < D::MT; ++mt) {
+          a[mt] = b0[mt];
+          ad[mt] = bd0[mt];
+        }
       }
     }
     double sv = 0.0, sd = 0.0;
