@@ -107,21 +107,25 @@ __global__ void __launch_bounds__(256) k_weak_partials(const double* __restrict_
     if (l == 0) {
       const double hn = h[n];
       double s31;
-      if (s3x != nullptr) {
-        s31 = s3x[n];
-      } else {
-        // a = identity, b = 0:  sum_i d_i phi d_i u  with  nabla phi = w nabla v + v nabla w  (at t_0, on the v-sample)
-        // and  nabla u = G_n = d(sum_l u)/dx_n + d(sum_l u)/d(start) nabla h   
-        s31 = 0.0;
-        const double w0n = w0[n], gsn = gs[n];
-        for (int i = 0; i < d; ++i) {
-          const long q = (long)i * N + n;
-          s31 += (w0n * gxv[q] + vl * gwx0T[q]) * (gx[q] + gsn * ghT[q]);
-        }
-      }
+      s31 = s3x != nullptr ? s3x[n] : 0.0;            // (a = identity, b = 0: contracted below, spread over the time rows)
       s3 += s31;                                      // src/loss.py:66-69 (only non-zero at l = 0)
       I -= cN * hn * vl;                              // s1, src/loss.py:64
       acc[2] += (ul - hn) * (ul - hn);                // src/loss.py:79
+    }
+    if (s3x == nullptr) {
+      // a = identity, b = 0:  s31_n = sum_i d_i phi d_i u  with  nabla phi = w nabla v + v nabla w  (at t_0, on the
+      // v-sample) and  nabla u = G_n = d(sum_l u)/dx_n + d(sum_l u)/d(start) nabla h   (SURVEY Appendix A Q3).
+      // The term belongs to the l = 0 point of path n; the thread of (l, n) adds the dimensions i = l, l + L, ... so that
+      // the d-long contraction is spread over all L time rows instead of loading the first N threads 20-fold.
+      double part = 0.0;
+      if (l < d) {
+        const double w0n = w0[n], gsn = gs[n], v0n = v[n];
+        for (int i = l; i < d; i += L) {
+          const long q = (long)i * N + n;
+          part += (w0n * gxv[q] + v0n * gwx0T[q]) * (gx[q] + gsn * ghT[q]);
+        }
+      }
+      I += cNL * part;
     }
     if (l == L - 1) I += cN * ul * vl;
     I -= cNL * (ul * phit - s3);                      // -(s2 - s3), src/loss.py:65,71-73

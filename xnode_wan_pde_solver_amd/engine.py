@@ -263,27 +263,18 @@ class Engine:
             for ev in events:
                 cur.wait_event(ev)
 
-    def _test_net(self, G, e0, blocks=None, store=False):
-        """test network on side stream 0: v, dv/dt at all points; nabla_x v at the first time index rides along in the
-        same launch (fused reverse chain).  Returns the completion event."""
-        if getattr(G, 'skip_v', False):          # v, dv/dt, nabla_x v(t_0) in the buffers are still valid (see _v_fresh)
-            return e0
-        return self._launch_test_net(G, e0, blocks=blocks, store=store)
-
-    def _launch_test_net(self, G, *events, blocks=None, store=False):
-        ph = self.phi.data
-        blocks = blocks or self.v_blocks
-        # the record of layer inputs is wanted by the discriminator sub-step's backward; when evaluations are shared
-        # (reuse_test_net) the one that runs must leave it behind for that later sub-step
-        act = G.vact if getattr(G, 'vact_valid', False) else None      # (decided in _v_fresh, outside the captured code)
-        with self._side(0, *events):
-            if G.tpp is not None:
-                KN.disc_fwd(G.xvT_pts, None, ph, self.W, self.q, tpp=G.tpp, v=G.v.view(1, -1), vt=G.vt.view(1, -1),
-                            gxv=G.gxv, gtv=G.gtv, ngrad=G.N, max_blocks=blocks, act=act)
-            else:
-                KN.disc_fwd(G.xvT, G.t, ph, self.W, self.q, v=G.v, vt=G.vt, gxv=G.gxv, gtv=G.gtv, ngrad=G.N,
-                            max_blocks=blocks, act=act)
-            return self._mark()
+    def _launch_test_net_here(self, G, blocks=None):
+        """test network on the CURRENT stream (the sub-step's critical chain): v, dv/dt at all points; nabla_x v at the first
+        time index rides along in the same launch (fused reverse chain); optionally the record of layer inputs for the
+        backward (decided in _v_fresh, outside the captured code)"""
+        ph, blocks = self.phi.data, blocks or self.v_blocks
+        act = G.vact if getattr(G, 'vact_valid', False) else None
+        if G.tpp is not None:
+            KN.disc_fwd(G.xvT_pts, None, ph, self.W, self.q, tpp=G.tpp, v=G.v.view(1, -1), vt=G.vt.view(1, -1),
+                        gxv=G.gxv, gtv=G.gtv, ngrad=G.N, max_blocks=blocks, act=act)
+        else:
+            KN.disc_fwd(G.xvT, G.t, ph, self.W, self.q, v=G.v, vt=G.vt, gxv=G.gxv, gtv=G.gtv, ngrad=G.N,
+                        max_blocks=blocks, act=act)
 
     def _reaction(self, G):
         """c(u, t, x): linear fast path, or the user's callable differentiated by autograd (not graph-capturable)"""
@@ -336,48 +327,49 @@ class Engine:
 
     def _gen_front(self, G):
         """everything up to (not including) the exchange: leaves slabA, slabB and scal[0..3] complete.
-        Kernel chains:  main   u-forward (interior + boundary, one launch) -> cotangent A, boundary residual
-                               -> parameter sweeps {interior/A, boundary} (one launch)
-                        side 0 test network v, dv/dt and (fused) nabla_x v(t_0)  (independent of theta)
-                               (sweep A also returns nabla_x u: same adjoint as the helper backward)
-                        side 2 cotangent B = dI/du -> parameter sweep B          (after the forward and v)"""
+        Kernel chains:  main   test network v, dv/dt and (fused) nabla_x v(t_0) -> cotangent B = dI/du -> parameter
+                               sweep B -> [join] -> I, sum v^2, SSE, loss values            (the critical path: one stream,
+                               dependent launches of one stream follow each other without the ~10 us cross-queue hop)
+                        side 1 u-forward (interior + boundary, one launch) -> boundary residual -> cotangent A
+                               -> parameter sweeps {interior/A, boundary} (one launch; sweep A also returns nabla_x u:
+                               same adjoint as the helper backward)"""
         th = self.theta.data
         M = (self.method, self.H, self.K, self.m)
         e0 = self._mark()
-        e_v = self._test_net(G, e0)
-        joint = G.Nb and G.same_grid           # boundary paths on the interior's time grid: one launch for both
-        KN.ode_fwd_multi([self._job(G, 'i')] + ([self._job(G, 'b')] if joint else []), G.t, th, *M, zero16=self.scal)
-        if G.Nb and not joint:
-            KN.ode_fwd_multi([self._job(G, 'b')], G.tb, th, *M)
-        self._reaction(G)
-        e_f = self._mark()
-        if G.Nb:
-            KN.bdry_partials(G.ub, G.g, self.alpha, G.Nbglob, self.scal, G.work_b, ubar_b=G.ubar_b)
-            e_f = self._mark()
-        # With the reference's pollution (cotangent A = ones + the initial-value term at t_0) sweep A and the helper
-        # backward u.backward(ones) are the same adjoint: one launch returns the parameter gradient of A and nabla_x u.
         fused_x = self.pollution == 1.0
+        joint = G.Nb and G.same_grid           # boundary paths on the interior's time grid: one launch for both
         e_x = None
-        if not fused_x:
-            with self._side(1, e_f):
-                KN.ode_bwd_multi([self._job(G, 'i', want_x=True)], G.t, th, *M, want_x=True, want_params=False)
-                e_x = self._mark()
-        with self._side(2, e_f, e_v):
-            KN.gen_cotangents(G.u, G.v, G.w, G.h, G.Vol, G.Nglob, self.alpha, None, G.ubarB, c=G.c, cp=G.cp, ckappa=G.ck,
+        if not getattr(G, 'skip_v', False):
+            self._launch_test_net_here(G)                        # enqueued first: its blocks must be resident before the
+        with self._side(1, e0):                                  # stepper's waves spread over the CUs
+            KN.ode_fwd_multi([self._job(G, 'i')] + ([self._job(G, 'b')] if joint else []), G.t, th, *M, zero16=self.scal)
+            if G.Nb and not joint:
+                KN.ode_fwd_multi([self._job(G, 'b')], G.tb, th, *M)
+            self._reaction(G)
+            e_f = self._mark()
+            if G.Nb:
+                KN.bdry_partials(G.ub, G.g, self.alpha, G.Nbglob, self.scal, G.work_b, ubar_b=G.ubar_b)
+            # With the reference's pollution (cotangent A = ones + the initial-value term at t_0) sweep A and the helper
+            # backward u.backward(ones) are the same adjoint: one launch returns the parameter gradient of A and nabla_x u.
+            if not fused_x:
+                with self._side(2, e_f):
+                    KN.ode_bwd_multi([self._job(G, 'i', want_x=True)], G.t, th, *M, want_x=True, want_params=False)
+                    e_x = self._mark()
+            KN.gen_cotangents(G.u, None, G.w, G.h, G.Vol, G.Nglob, self.alpha, G.ubarA, None, c=G.c, cp=G.cp, ckappa=G.ck,
                               pollution=self.pollution)
-            KN.ode_bwd_multi([self._job(G, 'i', G.ubarB, G.slabB)], G.t, th, *M, want_x=False, want_params=True)
-            e_B = self._mark()
-        KN.gen_cotangents(G.u, None, G.w, G.h, G.Vol, G.Nglob, self.alpha, G.ubarA, None, c=G.c, cp=G.cp, ckappa=G.ck,
+            sweeps = [self._job(G, 'i', G.ubarA, G.slabA[:G.ns_u], want_x=fused_x)]
+            if joint:
+                sweeps.append(self._job(G, 'b', G.ubar_b, G.slabA[G.ns_u:]))
+            KN.ode_bwd_multi(sweeps, G.t, th, *M, want_x=fused_x, want_params=True, x_cot_ones=fused_x)
+            if G.Nb and not joint:
+                KN.ode_bwd_multi([self._job(G, 'b', G.ubar_b, G.slabA[G.ns_u:])], G.tb, th, *M, want_x=False, want_params=True)
+            e_A = self._mark()
+        self._join(e_f)
+        KN.gen_cotangents(G.u, G.v, G.w, G.h, G.Vol, G.Nglob, self.alpha, None, G.ubarB, c=G.c, cp=G.cp, ckappa=G.ck,
                           pollution=self.pollution)
-        sweeps = [self._job(G, 'i', G.ubarA, G.slabA[:G.ns_u], want_x=fused_x)]
-        if joint:
-            sweeps.append(self._job(G, 'b', G.ubar_b, G.slabA[G.ns_u:]))
-        KN.ode_bwd_multi(sweeps, G.t, th, *M, want_x=fused_x, want_params=True, x_cot_ones=fused_x)
-        if G.Nb and not joint:
-            KN.ode_bwd_multi([self._job(G, 'b', G.ubar_b, G.slabA[G.ns_u:])], G.tb, th, *M, want_x=False, want_params=True)
-        self._join(e_v) if fused_x else self._join(e_x, e_v)
+        KN.ode_bwd_multi([self._job(G, 'i', G.ubarB, G.slabB)], G.t, th, *M, want_x=False, want_params=True)
+        self._join(e_A) if e_x is None else self._join(e_A, e_x)
         self._contract(G, self.adam_u)                           # -> scal[0..2], loss values
-        self._join(e_B)
 
     def begin_substep(self, which, accumulate):
         """start of a generator ('u') / discriminator ('v') sub-iteration over several groups: zero the carried gradient"""
@@ -442,14 +434,18 @@ class Engine:
     # discriminator sub-step (src/training.py:152-162)
     # ------------------------------------------------------------------------------------------------------------
     def _disc_front(self, G):
+        """main: test network (+ its record) -> [join] -> I, sum v^2, loss values;  side 1: u-forward -> x-sweep"""
         th = self.theta.data
         M = (self.method, self.H, self.K, self.m)
         e0 = self._mark()
-        e_v = self._test_net(G, e0, blocks=self.v_blocks_disc, store=True)
-        KN.ode_fwd_multi([self._job(G, 'i')], G.t, th, *M, zero16=self.scal)
-        self._reaction(G)
-        KN.ode_bwd_multi([self._job(G, 'i', want_x=True)], G.t, th, *M, want_x=True, want_params=False)
-        self._join(e_v)
+        if not getattr(G, 'skip_v', False):
+            self._launch_test_net_here(G, blocks=self.v_blocks_disc)
+        with self._side(1, e0):
+            KN.ode_fwd_multi([self._job(G, 'i')], G.t, th, *M, zero16=self.scal)
+            self._reaction(G)
+            KN.ode_bwd_multi([self._job(G, 'i', want_x=True)], G.t, th, *M, want_x=True, want_params=False)
+            e_x = self._mark()
+        self._join(e_x)
         self._contract(G, self.adam_v)
 
     def _disc_mid(self, G):
