@@ -364,12 +364,17 @@ class Engine:
             if G.Nb and not joint:
                 KN.ode_bwd_multi([self._job(G, 'b', G.ubar_b, G.slabA[G.ns_u:])], G.tb, th, *M, want_x=False, want_params=True)
             e_A = self._mark()
+        e_v = self._mark()
         self._join(e_f)
         KN.gen_cotangents(G.u, G.v, G.w, G.h, G.Vol, G.Nglob, self.alpha, None, G.ubarB, c=G.c, cp=G.cp, ckappa=G.ck,
                           pollution=self.pollution)
         KN.ode_bwd_multi([self._job(G, 'i', G.ubarB, G.slabB)], G.t, th, *M, want_x=False, want_params=True)
-        self._join(e_A) if e_x is None else self._join(e_A, e_x)
-        self._contract(G, self.adam_u)                           # -> scal[0..2], loss values
+        # the reduction needs nabla_x u (sweep A) and v, not sweep B: it runs behind sweep A on the side stream, next to
+        # the tail of sweep B, instead of after it
+        with self._side(3, e_A, e_v, *([] if e_x is None else [e_x])):   # (re-entering side 1 here crashes hipStreamEndCapture)
+            self._contract(G, self.adam_u)                       # -> scal[0..2], loss values
+            e_C = self._mark()
+        self._join(e_C)
 
     def begin_substep(self, which, accumulate):
         """start of a generator ('u') / discriminator ('v') sub-iteration over several groups: zero the carried gradient"""
