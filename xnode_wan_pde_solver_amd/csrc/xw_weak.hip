@@ -231,20 +231,24 @@ __global__ void __launch_bounds__(256) k_disc_cot(const double* __restrict__ u, 
 // torch.optim.Adam (betas, eps defaults; no weight decay, no amsgrad) fused with the reduction of the per-wave gradient
 // slabs:   g = eA + sum_s A[s] + coefB * (eB + sum_s B[s]),   coefB = scal ? 2 / scal[0] : 1
 // (A: cotangent basis that needs no global scalar, B: the dI/du basis scaled by d log(I^2)/dI).
-// Block = 64 parameters x 16 slab groups; grid = P / 64.
+// Block = 16 parameters x 64 slab groups; grid = P / 16.
+#define XW_ADAM_PARAMS 16
+#define XW_ADAM_GROUPS 64
 __global__ void __launch_bounds__(1024) k_adam(double* __restrict__ param, const double* __restrict__ gA, int nA,
                                                const double* __restrict__ eA, const double* __restrict__ gB, int nB,
                                                const double* __restrict__ eB, const double* __restrict__ scal,
                                                double* __restrict__ m, double* __restrict__ v,
                                                const long long* __restrict__ step, int step_is_current, int P, double lr,
                                                double beta1, double beta2, double eps, double* __restrict__ gsum_out) {
-  __shared__ double red[2][16][64];
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const int i = blockIdx.x * 64 + tx;
+  // block = 16 parameters (one 128-byte line per slab row) x 64 slab groups: P / 16 blocks spread the 10 MB of slabs of
+  // a generator sub-step over ~100 CUs (64 parameters per block used 26 of them and took 17 us)
+  __shared__ double red[2][XW_ADAM_GROUPS][XW_ADAM_PARAMS];
+  const int tx = threadIdx.x % XW_ADAM_PARAMS, ty = threadIdx.x / XW_ADAM_PARAMS;
+  const int i = blockIdx.x * XW_ADAM_PARAMS + tx;
   double a = 0.0, b = 0.0;
   if (i < P) {
-    for (int s = ty; s < nA; s += 16) a += gA[(long)s * P + i];
-    for (int s = ty; s < nB; s += 16) b += gB[(long)s * P + i];
+    for (int s = ty; s < nA; s += XW_ADAM_GROUPS) a += gA[(long)s * P + i];
+    for (int s = ty; s < nB; s += XW_ADAM_GROUPS) b += gB[(long)s * P + i];
   }
   red[0][ty][tx] = a;
   red[1][ty][tx] = b;
@@ -252,8 +256,8 @@ __global__ void __launch_bounds__(1024) k_adam(double* __restrict__ param, const
   if (ty != 0 || i >= P) return;
   a = eA != nullptr ? eA[i] : 0.0;
   b = eB != nullptr ? eB[i] : 0.0;
-#pragma unroll
-  for (int k = 0; k < 16; ++k) {
+#pragma unroll 8
+  for (int k = 0; k < XW_ADAM_GROUPS; ++k) {
     a += red[0][k][tx];
     b += red[1][k][tx];
   }
@@ -344,7 +348,7 @@ extern "C" int xw_adam(double* param, const double* gslabA, int nA, const double
   // bump_step: 1 = this call advances the counter after the update; 0 = the counter was left alone (caller advances it
   // later);  -1 = the counter was ALREADY advanced for this update (xw_losses ran first), use it as is
   if (!param || !m || !v || !step || P <= 0 || nA < 0 || nB < 0 || (nA > 0 && !gslabA) || (nB > 0 && !gslabB)) return XW_E_ARG;
-  hipLaunchKernelGGL(k_adam, dim3((P + 63) / 64), dim3(1024), 0, (hipStream_t)stream, param, gslabA, nA, gextraA, gslabB,
+  hipLaunchKernelGGL(k_adam, dim3((P + XW_ADAM_PARAMS - 1) / XW_ADAM_PARAMS), dim3(1024), 0, (hipStream_t)stream, param, gslabA, nA, gextraA, gslabB,
                      nB, gextraB, scal, m, v, step, bump_step < 0 ? 1 : 0, P, lr, beta1, beta2, eps, gsum_out);
   if (bump_step > 0) hipLaunchKernelGGL(k_step_inc, dim3(1), dim3(1), 0, (hipStream_t)stream, step);
   return xw_launch_status();
