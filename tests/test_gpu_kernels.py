@@ -260,11 +260,11 @@ def test_disc_backward_from_stored_activations(N, L, d):
     xT, tc, blob = x.double().t().contiguous().cuda(), t.double().cuda(), _blob(phi, V_ORDER)
     rows = KN.disc_act_rows(W, Q)
     assert rows == (Q + 1) * W
-    act = torch.full((rows, L * N), float('nan'), dtype=F64, device='cuda')
+    act = torch.full((rows, KN.disc_act_cols(L * N)), float('nan'), dtype=F64, device='cuda')
     v0, vt0 = KN.disc_fwd(xT, tc, blob, W, Q)
     v1, vt1 = KN.disc_fwd(xT, tc, blob, W, Q, act=act)
     assert torch.equal(v0, v1) and torch.equal(vt0, vt1)
-    assert torch.isfinite(act).all() and bool((act[:Q * W] >= 0).all())          # relu outputs, every row written
+    assert torch.isfinite(act[:, :L * N]).all() and bool((act[:Q * W, :L * N] >= 0).all())   # relu outputs, every row written
     s0 = KN.slab_sum(KN.disc_bwd(xT, tc, blob, vbar, W, Q))
     s1 = KN.slab_sum(KN.disc_bwd(xT, tc, blob, vbar, W, Q, act=act))
     _close(s1, s0, 1e-12, 'phi gradient from the stored record')

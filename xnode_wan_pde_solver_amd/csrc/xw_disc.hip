@@ -120,7 +120,8 @@ __global__ void __launch_bounds__(256, 2) k_disc_fwd(const double* __restrict__ 
     d4 a[D::MT], ad[D::MT];
     double* actl = act;                                                 // laundered like pht below: the record's row
     asm volatile("" : "+s"(actl));                                      // addresses are formed per tile, not hoisted
-    const int aoff = g * (int)P + pt.p;
+    const long Pp = (P + 15) & ~15L;                                    // row stride of the record: whole tiles, so that
+    const int aoff = g * (int)Pp + (int)(tile * 16) + (lane & 15);      // every lane of the last tile has its own column
     const double* pht = ph;                                             // laundered: keeps the input-layer fragment
     asm volatile("" : "+s"(pht));                                       // addresses out of the loop-invariant (spilled) set
     input_layer<W>(pht, o, xT, N, d, pt, a, ad);
@@ -150,8 +151,8 @@ __global__ void __launch_bounds__(256, 2) k_disc_fwd(const double* __restrict__ 
         const double b = av > 0.0 ? av : 0.0;
         const double bd = av > 0.0 ? adi[ks >> 2][ks & 3] : 0.0;
         if (ACT) {   // activation store: row j W + k of the record is the layer input relu(a_j)[k], point-major
-          double* __restrict__ rowp = actl + ((long)j * W + 4 * ks) * P;        // uniform pointer + 32-bit lane offset
-          if (4 * ks + g < W && pt.valid) rowp[aoff] = b;
+          double* __restrict__ rowp = actl + ((long)j * W + 4 * ks) * Pp;       // uniform pointer + 32-bit lane offset
+          if (4 * ks + 3 < W || 4 * ks + g < W) rowp[aoff] = b;                 // (unconditional but for the last k-step)
         }
         if ((ks & 1) == 0) asm volatile("" ::: "memory");   // bound the LDS loads in flight (else all 52 are hoisted -> spills)
 #pragma unroll
@@ -206,8 +207,8 @@ __global__ void __launch_bounds__(256, 2) k_disc_fwd(const double* __restrict__ 
       for (int r = 0; r < 4; ++r)
         if (16 * mt + 4 * r < W) {  // rows 16 mt + 4 r + g >= W only carry zero padding
           const double th = xw_tanh(a[mt][r]);
-          if (ACT && 16 * mt + 4 * r + g < W && pt.valid)
-            (actl + ((long)q * W + 16 * mt + 4 * r) * P)[aoff] = th;           // last rows of the record: tanh(a_q)
+          if (ACT && (16 * mt + 4 * r + 3 < W || 16 * mt + 4 * r + g < W))
+            (actl + ((long)q * W + 16 * mt + 4 * r) * Pp)[aoff] = th;          // last rows of the record: tanh(a_q)
           const double vo = sB[16 * D::MT + 16 * mt + g + 4 * r];
           sv += vo * th;
           sd += vo * (1.0 - th * th) * ad[mt][r];
@@ -354,9 +355,10 @@ __global__ void __launch_bounds__(256) k_disc_bwd(const double* __restrict__ xT,
     d4 ck[NSEG][D::MT];
     d4 a[D::MT], ad[D::MT];
     // one layer's inputs from the activation store (rows >= W of the last tile: zero)
-    const int aoff = g * (int)P + pt.p;                // 32-bit lane offset; row pointers below are uniform
+    const long Pp = (P + 15) & ~15L;                   // row stride of the record (whole tiles)
+    const int aoff = g * (int)Pp + pt.p;               // 32-bit lane offset; row pointers below are uniform
     auto load_layer = [&](int j, d4 (&r)[D::MT]) {
-      const double* base = act + (long)j * W * P;
+      const double* base = act + (long)j * W * Pp;
       asm volatile("" : "+s"(base));                   // form the row addresses here, not hoisted out of the tile loop
 #pragma unroll
       for (int mt = 0; mt < D::MT; ++mt)
@@ -364,7 +366,7 @@ __global__ void __launch_bounds__(256) k_disc_bwd(const double* __restrict__ xT,
         for (int q_ = 0; q_ < 4; ++q_)
           if (q_ < D::LR(mt)) {
             const int row = 16 * mt + 4 * q_ + g;
-            r[mt][q_] = (16 * mt + 4 * q_ + 3 < W || row < W) ? (base + (long)(16 * mt + 4 * q_) * P)[aoff] : 0.0;
+            r[mt][q_] = (16 * mt + 4 * q_ + 3 < W || row < W) ? (base + (long)(16 * mt + 4 * q_) * Pp)[aoff] : 0.0;
           }
     };
     d4 rnext[D::MT];                                   // SAVED: inputs of the layer that is reversed next (prefetch)

@@ -155,10 +155,15 @@ def disc_act_rows(W, q):
     return r
 
 
+def disc_act_cols(P):
+    """columns of that record for P points: whole 16-point tiles"""
+    return (P + 15) // 16 * 16
+
+
 def disc_fwd(xT, t, phi, W, q, tpp=None, want_vt=True, v=None, vt=None, gxv=None, gtv=None, ngrad=0, max_blocks=0, act=None):
     """v_phi and dv/dt.  Path mode: points (t[l], x_n) -> [L,N].  Point mode (tpp[N]): points (tpp[n], x_n) -> [1,N].
     gxv[d,ngrad] / gtv[ngrad]: also return the input gradient of v at the leading ngrad points (time-major order).
-    act[disc_act_rows(W, q), L*N]: also store the layer inputs, for disc_bwd(act=...)."""
+    act[disc_act_rows(W, q), disc_act_cols(L*N)]: also store the layer inputs, for disc_bwd(act=...)."""
     _need_gpu()
     d, N = xT.shape
     L = 1 if tpp is not None else t.shape[0]
@@ -171,7 +176,7 @@ def disc_fwd(xT, t, phi, W, q, tpp=None, want_vt=True, v=None, vt=None, gxv=None
     if gxv is not None:
         _chk(gxv, F64, (d, ngrad), 'gxv'); _chk(gtv, F64, (ngrad,), 'gtv')
     if act is not None:
-        _chk(act, F64, (disc_act_rows(W, q), L * N), 'act')
+        _chk(act, F64, (disc_act_rows(W, q), disc_act_cols(L * N)), 'act')
     check(lib.xw_disc_fwd(_p(xT), _p(t), _p(tpp), _p(phi), N, L, d, W, q, _p(v), _p(vt if want_vt else None), _p(gxv), _p(gtv),
                           int(ngrad), int(max_blocks), _p(act), _stream()), 'xw_disc_fwd')
     return v, (vt if want_vt else None)
@@ -209,7 +214,7 @@ def disc_bwd(xT, t, phi, vbar, W, q, tpp=None, gslab=None, act=None):
     gslab = torch.empty(ns, P, dtype=F64, device=xT.device) if gslab is None else gslab
     _chk(gslab, F64, (ns, P), 'gslab')
     if act is not None:
-        _chk(act, F64, (disc_act_rows(W, q), L * N), 'act')
+        _chk(act, F64, (disc_act_rows(W, q), disc_act_cols(L * N)), 'act')
     check(lib.xw_disc_bwd(_p(xT), _p(t), _p(tpp), _p(phi), _p(vbar), N, L, d, W, q, _p(act), _p(gslab), _stream()),
           'xw_disc_bwd')
     return gslab
