@@ -11,7 +11,8 @@ v = torch.empty(L, N, dtype=torch.float64, device=dev); vt = torch.empty_like(v)
 gxv = torch.empty(d, N, dtype=torch.float64, device=dev); gtv = torch.empty(N, dtype=torch.float64, device=dev)
 vbar = torch.randn(L, N, generator=g, dtype=torch.float64).to(dev)
 slv = torch.empty(KN.disc_bwd_slabs(N, L), ph.numel(), dtype=torch.float64, device=dev)
+rec = torch.empty(KN.disc_act_rows(W, q), KN.disc_act_cols(L * N), dtype=torch.float64, device=dev) if os.environ.get('XW_RECORD', '1') == '1' else None
 for _ in range(5):
-    KN.disc_fwd(xT, t, ph, W, q, v=v, vt=vt, gxv=gxv, gtv=gtv, ngrad=N)
-    KN.disc_bwd(xT, t, ph, vbar, W, q, gslab=slv)
+    KN.disc_fwd(xT, t, ph, W, q, v=v, vt=vt, gxv=gxv, gtv=gtv, ngrad=N, act=rec)
+    KN.disc_bwd(xT, t, ph, vbar, W, q, gslab=slv, act=rec)
 torch.cuda.synchronize()

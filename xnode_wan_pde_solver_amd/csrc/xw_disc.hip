@@ -318,7 +318,7 @@ __global__ void __launch_bounds__(256) k_disc_bwd(const double* __restrict__ xT,
     sB[16 * D::MT + threadIdx.x] = (int)threadIdx.x < W ? ph[o.Vo + threadIdx.x] : 0.0;
   }
   if (PARAMS)
-    for (int i = 0; i < 16; ++i) sO[(wave * 64 + lane) * 16 + i] = 0.0;
+    for (int i = 0; i < 16; ++i) sO[i * 256 + wave * 64 + lane] = 0.0;   // [slot][thread]: lane-contiguous, no bank conflicts
   __syncthreads();
 
   d4 accH[D::MT], accIn[CTG * 4];
@@ -400,7 +400,7 @@ __global__ void __launch_bounds__(256) k_disc_bwd(const double* __restrict__ xT,
         double th = 0.0;
         if (16 * mt + 4 * r < W) th = SAVED ? (r < D::LR(mt) ? a[mt][r] : 0.0) : xw_tanh(a[mt][r]);
         dl[mt][r] = sB[16 * D::MT + 16 * mt + g + 4 * r] * (1.0 - th * th) * vb;
-        if (PARAMS) sO[(wave * 64 + lane) * 16 + mt * 4 + r] += (mt == D::MT - 1 && r == 3) ? (g == 0 ? vb : 0.0) : vb * th;
+        if (PARAMS) sO[(mt * 4 + r) * 256 + wave * 64 + lane] += (mt == D::MT - 1 && r == 3) ? (g == 0 ? vb : 0.0) : vb * th;
       }
     // ---- reverse chain, segment by segment
 #pragma unroll
@@ -564,11 +564,11 @@ __global__ void __launch_bounds__(256) k_disc_bwd(const double* __restrict__ xT,
       if (tid < W) {
         const int mt = tid >> 4, gg = tid & 3, r = (tid & 15) >> 2;
         for (int wv = 0; wv < 4; ++wv)
-          for (int nn = 0; nn < 16; ++nn) s += sO[(wv * 64 + gg * 16 + nn) * 16 + mt * 4 + r];
+          for (int nn = 0; nn < 16; ++nn) s += sO[(mt * 4 + r) * 256 + wv * 64 + gg * 16 + nn];
         slab[o.Vo + tid] = s;
       } else {
         for (int wv = 0; wv < 4; ++wv)
-          for (int nn = 0; nn < 16; ++nn) s += sO[(wv * 64 + nn) * 16 + 15];
+          for (int nn = 0; nn < 16; ++nn) s += sO[15 * 256 + wv * 64 + nn];
         slab[o.Vob] = s;
       }
     }
