@@ -78,6 +78,11 @@ __device__ __forceinline__ double xw_fragAT(const double* __restrict__ Mx, int l
   const int r = r0 + (l & 15), c = c0 + (l >> 4);
   return (r < cols && c < rows) ? Mx[c * ld + r] : 0.0;
 }
+// the same with the lane id passed in (a laundered copy: keeps the address arithmetic where the caller wants it)
+__device__ __forceinline__ double xw_fragAT_l(const double* __restrict__ Mx, int ld, int rows, int cols, int r0, int c0, int l) {
+  const int r = r0 + (l & 15), c = c0 + (l >> 4);
+  return (r < cols && c < rows) ? Mx[c * ld + r] : 0.0;
+}
 // chain-layout vector broadcast over the 16 columns: rows r0 + g + 4 r of b[rows]
 __device__ __forceinline__ d4 xw_vecD(const double* __restrict__ b, int rows, int r0) {
   const int g = xw_lane() >> 4;

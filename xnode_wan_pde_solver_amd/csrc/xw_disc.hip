@@ -228,6 +228,8 @@ __global__ void __launch_bounds__(256, 2) k_disc_fwd(const double* __restrict__ 
       // loop they spilled to scratch in every wave's prologue (17 MB of scratch writes per launch in the PMC pass).
       const double* phg = ph;
       asm volatile("" : "+s"(phg));
+      int ll = lane;                         // (the lane-offset part of those addresses is loop-invariant too: a copy of the
+      asm volatile("" : "+v"(ll));           //  lane id the compiler cannot see through keeps it here as well)
       d4 (&dl)[D::MT] = a;
       for (int j = q - 1; j >= 0; --j) {
         d4 nd[D::MT];
@@ -238,7 +240,7 @@ __global__ void __launch_bounds__(256, 2) k_disc_fwd(const double* __restrict__ 
           const double b = dl[ks >> 2][ks & 3];
           asm volatile("" ::: "memory");   // a few loads in flight, not all 52 (register pressure)
 #pragma unroll
-          for (int mt = 0; mt < D::MT; ++mt) nd[mt] = XW_MFMA(xw_fragAT(phg + o.Vh, W, W, W, 16 * mt, 4 * ks), b, nd[mt]);
+          for (int mt = 0; mt < D::MT; ++mt) nd[mt] = XW_MFMA(xw_fragAT_l(phg + o.Vh, W, W, W, 16 * mt, 4 * ks, ll), b, nd[mt]);
         }
         const unsigned int mask = sMask[j][threadIdx.x];
 #pragma unroll
@@ -246,18 +248,20 @@ __global__ void __launch_bounds__(256, 2) k_disc_fwd(const double* __restrict__ 
 #pragma unroll
           for (int r = 0; r < 4; ++r) dl[mt][r] = ((mask >> (4 * mt + r)) & 1u) ? nd[mt][r] : 0.0;
       }
-      const bool gl = pt.valid && pt.p < ngrad;
+      int ngl = ngrad;                       // laundered: keeps the (lane-dependent) row offsets i * ngrad of the gxv stores
+      asm volatile("" : "+s"(ngl));          // out of the loop-invariant set (they were spilled in every wave's prologue)
+      const bool gl = pt.valid && pt.p < ngl;
       for (int rt = 0; rt < (d + 15) / 16; ++rt) {
         d4 vv = xw_zero4();
 #pragma unroll
         for (int ks = 0; ks < D::KS; ++ks) {
           if ((ks & 3) == 0) asm volatile("" ::: "memory");
-          vv = XW_MFMA(xw_fragAT(phg + o.Vin + 1, o.ldin, W, d, 16 * rt, 4 * ks), dl[ks >> 2][ks & 3], vv);
+          vv = XW_MFMA(xw_fragAT_l(phg + o.Vin + 1, o.ldin, W, d, 16 * rt, 4 * ks, ll), dl[ks >> 2][ks & 3], vv);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int i = 16 * rt + g + 4 * r;
-          if (i < d && gl) gxv[(long)i * ngrad + pt.p] = vv[r];
+          if (i < d && gl) gxv[(long)i * ngl + pt.p] = vv[r];
         }
       }
       double st_ = 0.0;
