@@ -665,8 +665,12 @@ __global__ void __launch_bounds__(64) k_ode_bwd(const BwdJobs jobs, const double
   double ub0 = 0.0;            // cotangent of u at the first time index (the last one visited)
 
   // read-out u_l = FL y_l + b at time index l: cotangent into lam, gradients of the read-out layer
-  auto readout = [&](int l, const d4 (&yl)[D::HT]) {
-    const double ub = valid ? (ubar != nullptr ? ubar[(long)l * N + base + n] : 1.0) : 0.0;
+  // cotangent of u at time index l.  Loaded at the START of the step that ends with its read-out: behind the fences of
+  // the outer products the load could not be hoisted and its HBM latency sat on the chain once per step.
+  auto load_ub = [&](int l) -> double {
+    return valid ? (ubar != nullptr ? ubar[(long)l * N + base + n] : 1.0) : 0.0;
+  };
+  auto readout = [&](int l, const d4 (&yl)[D::HT], double ub) {
     ub0 = ub;
 #pragma unroll
     for (int ht = 0; ht < D::HT; ++ht) {
@@ -699,40 +703,42 @@ __global__ void __launch_bounds__(64) k_ode_bwd(const BwdJobs jobs, const double
         if (j < i && T::a(i, j) != 0.0) t_axpy(kb[j][ht], dt * T::a(i, j), psi[ht], D::HR(ht));
     }
   };
-  auto end_step = [&](int l, const d4 (&y_l)[D::HT]) {
+  auto end_step = [&](int l, const d4 (&y_l)[D::HT], double ub) {
 #pragma unroll
     for (int ht = 0; ht < D::HT; ++ht) t_add(lam[ht], psum[ht], D::HR(ht));
-    readout(l, y_l);
+    readout(l, y_l, ub);
   };
 
   if constexpr (SAVED) {
     {
       d4 yl[D::HT];
       load_ckpt<H, K>(Y, L - 1, N, ncl, yl);
-      readout(L - 1, yl);
+      readout(L - 1, yl, load_ub(L - 1));
     }
     StageRec<H, K, M> sa, sb;
     if constexpr (T::S == 2) {
       // stage 1 always lives in sa, stage 0 in sb: each is loaded while the other one is reversed
       if (L > 1) load_stage<H, K, M, METHOD>(Y, act, L - 2, 1, N, ncl, sa);
       for (int l = L - 2; l >= 0; --l) {
+        const double ub = load_ub(l);
         load_stage<H, K, M, METHOD>(Y, act, l, 0, N, ncl, sb);
         begin_step(l);
         reverse_stage(l, 1, sa.yi, sa.sv);
         load_stage<H, K, M, METHOD>(Y, act, l > 0 ? l - 1 : 0, 1, N, ncl, sa);
         reverse_stage(l, 0, sb.yi, sb.sv);
-        end_step(l, sb.yi);                               // stage 0's input is y_l itself
+        end_step(l, sb.yi, ub);                           // stage 0's input is y_l itself
       }
     } else {
       if (L > 1) load_stage<H, K, M, METHOD>(Y, act, L - 2, 0, N, ncl, sa);
       int l = L - 2;
       for (; l >= 1; l -= 2) {
+        const double ub1 = load_ub(l), ub2 = load_ub(l - 1);
         load_stage<H, K, M, METHOD>(Y, act, l - 1, 0, N, ncl, sb);
-        begin_step(l); reverse_stage(l, 0, sa.yi, sa.sv); end_step(l, sa.yi);
+        begin_step(l); reverse_stage(l, 0, sa.yi, sa.sv); end_step(l, sa.yi, ub1);
         load_stage<H, K, M, METHOD>(Y, act, l >= 2 ? l - 2 : 0, 0, N, ncl, sa);
-        begin_step(l - 1); reverse_stage(l - 1, 0, sb.yi, sb.sv); end_step(l - 1, sb.yi);
+        begin_step(l - 1); reverse_stage(l - 1, 0, sb.yi, sb.sv); end_step(l - 1, sb.yi, ub2);
       }
-      if (l == 0) { begin_step(0); reverse_stage(0, 0, sa.yi, sa.sv); end_step(0, sa.yi); }
+      if (l == 0) { begin_step(0); reverse_stage(0, 0, sa.yi, sa.sv); end_step(0, sa.yi, load_ub(0)); }
     }
   } else if constexpr (T::S <= 2) {
     load_field<H, K>(th, o, d, w);
@@ -741,14 +747,15 @@ __global__ void __launch_bounds__(64) k_ode_bwd(const BwdJobs jobs, const double
     {
       d4 yl[D::HT];
       load_ckpt<H, K>(Y, L - 1, N, ncl, yl);
-      readout(L - 1, yl);
+      readout(L - 1, yl, load_ub(L - 1));
     }
     for (int l = L - 2; l >= 0; --l) {
+      const double ub = load_ub(l);
       recompute<H, K, M, METHOD>(w, xp, Y, tf, l, N, ncl, cur);
       begin_step(l);
 #pragma unroll
       for (int i = T::S - 1; i >= 0; --i) reverse_stage(l, i, cur.yi[i], cur.sv[i]);
-      end_step(l, cur.yi[0]);
+      end_step(l, cur.yi[0], ub);
     }
   } else {
     load_field<H, K>(th, o, d, w);
