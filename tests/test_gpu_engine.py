@@ -339,6 +339,25 @@ def test_reused_test_net_is_dropped_when_phi_moves_outside_the_engine(golden_dir
     assert torch.equal(thetas[0], thetas[1])
 
 
+def test_activation_stores_do_not_change_the_step(golden_dir):
+    """sweeps / test-network backward reading the stored layer inputs (default) == recomputing them (keep_activations off)"""
+    z, params = load(golden_dir, 'ref_plumb_midpoint')
+    outs = []
+    for keep in (True, False):
+        S = make_solver(params, 0)
+        domain, pts = first_sample(S)
+        S.engine.keep_activations = keep
+        G = S.engine.load_group(pts.interioru, pts.interiorv, pts.boundary, domain)
+        assert (G.act is not None) == keep and (G.vact is not None) == keep
+        S.engine.generator_step(G)
+        S.engine.generator_step(G)
+        S.engine.discriminator_step(G)
+        outs.append((S.engine.theta.data.clone(), S.engine.phi.data.clone(), S.engine.scal.clone()))
+    close(outs[0][0], outs[1][0], 1e-9, 1e-12, 'theta')
+    close(outs[0][1], outs[1][1], 1e-9, 1e-12, 'phi')
+    close(outs[0][2][:6], outs[1][2][:6], 1e-10, 0.0, 'sums and losses')
+
+
 def test_evaluation_off_the_boundary_matches_reference(golden_dir):
     """u_net on paths that start neither at T0 nor on the boundary: bound_pad / fillt densified grid (src/model.py:92-106)"""
     z, params = load(golden_dir, 'ref_boundpad')
