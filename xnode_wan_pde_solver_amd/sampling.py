@@ -198,17 +198,11 @@ class NSphere_THourglass(_NSphereBase):
     def _half(self):
         return (self.T - self.T0) / 2
 
-    def _entry_padded(self, piece):
-        x0 = piece[0, 1:]
-        t_in = (torch.sqrt(torch.sum(x0 ** 2, 0)) / self.r).view(1, 1)
-        return torch.cat((torch.cat((t_in, x0.unsqueeze(0)), 1), piece), 0)
-
-    @staticmethod
-    def _by_length(pieces):
-        pieces = sorted((p.unsqueeze(0) for p in pieces), key=lambda p: p.shape[1])
-        return [torch.cat(tuple(grp), 0) for _, grp in groupby(pieces, key=lambda p: p.shape[1])]
-
     def interior(self, N_r):
+        """Same groups, same order and the same bits as the reference's per-path loop (src/dataset.py:62-104), without the
+        loop: a path is inside for its first n_first samples, outside for a contiguous middle stretch, inside again for
+        its last n_late samples.  Groups = pieces bucketed by length (paths in sample order within a bucket), first pieces
+        before re-entry pieces of the same length."""
         pts = self._ball(N_r)
         L = self.N_t
         tcol = self.times.repeat(N_r, 1).unsqueeze(2)
@@ -217,19 +211,32 @@ class NSphere_THourglass(_NSphereBase):
         bound = torch.zeros_like(P[:, :, 0]).unsqueeze(2)
         bound[early] = self.r * ((self.T - self.T0) - tcol)[early].double()
         bound[~early] = self.r * tcol[~early].double()
-        inside = (torch.sqrt(torch.sum(P ** 2, 2)).unsqueeze(2) < bound).squeeze()
+        inside = (torch.sqrt(torch.sum(P ** 2, 2)).unsqueeze(2) < bound).squeeze(2)
         paths = torch.cat((tcol, P), 2)
-        first, late = [], []
-        for k in range(N_r):
-            rows = paths[k, inside[k]]
-            gone = torch.nonzero(inside[k] == False)  # noqa: E712
-            if gone.shape[0] != 0:
-                a, b = rows.split([int(gone[0]), L - int(gone[-1]) - 1], dim=0)
-                first.append(a)
-                late.append(self._entry_padded(b))
-            else:
-                first.append(rows)
-        return sorted([*self._by_length(first), *self._by_length(late)], key=lambda g: g.shape[1])
+        out = ~inside
+        any_out = out.any(1)
+        idx = torch.arange(L).expand(N_r, L)
+        first_out = torch.where(out, idx, torch.full_like(idx, L)).min(1).values        # = L when the path never leaves
+        last_out = torch.where(out, idx, torch.full_like(idx, -1)).max(1).values
+        n_first = torch.where(any_out, first_out, torch.full_like(first_out, L))
+        n_late = torch.where(any_out, L - last_out - 1, torch.zeros_like(last_out))
+        if bool((out.sum(1) != (L - n_first - n_late)).any()):
+            raise RuntimeError('a sampled path leaves the hourglass more than once')        # (the reference's split would raise)
+        # entry point of the re-entering pieces on the moving boundary: time |x| / r
+        X = paths[:, 0, 1:]
+        t_in = torch.sqrt(torch.sum(X[any_out] ** 2, 1)) / self.r
+        entry = torch.cat((t_in.view(-1, 1, 1), X[any_out].unsqueeze(1)), 2)               # [n_out, 1, 1 + d]
+        late_rows = any_out.nonzero().view(-1)
+        groups_first, groups_late = [], []
+        for ell in sorted(set(n_first.tolist())):
+            ks = (n_first == ell).nonzero().view(-1)
+            groups_first.append(paths[ks, :ell])
+        nl = n_late[late_rows]
+        for ell in sorted(set(nl.tolist())):
+            sel = (nl == ell).nonzero().view(-1)
+            ks = late_rows[sel]
+            groups_late.append(torch.cat((entry[sel], paths[ks, L - ell:]), 1))
+        return sorted([*groups_first, *groups_late], key=lambda g: g.shape[1])
 
     def boundary(self, N_b):
         span, half = self.T - self.T0, self._half()
