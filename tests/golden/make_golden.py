@@ -344,6 +344,42 @@ def bound_pad_vectors():
     print('wrote ref_boundpad.npz', k, 'cases', [tuple(out['%d/u' % i].shape) for i in range(k)])
 
 
+def bound_pad_hourglass_vectors():
+    """The same evaluation path on the hourglass domain (NSphere_THourglass.bound_pad, src/dataset.py:127-152: per-path
+    padded grids bucketed by length).  The reference only survives some inputs (e.g. it raises when no gap of the
+    prepended time vector exceeds (T - T0) / N_t); the cases below are ones it evaluates."""
+    training, dataset, lossmod, F = load_reference()
+    d = 3
+    params = make_params(d, 8, 12, 6, 'midpoint')
+    params.update({'domain': 'NSphere_THourglass', 'shape_param': 1.0})
+    torch.manual_seed(7)
+    np.random.seed(7)
+    S = training.NODE_WAN_solver(params, F.func_a, F.func_b, F.func_c, F.func_h, F.func_f, F.func_g, torch.device('cpu'), './',
+                                 func_u_sol=F.func_u_sol, p=2)
+    g = torch.Generator().manual_seed(5)
+    out = {'params_json': np.array(json.dumps(params)), 'seed': np.array(7)}
+    k = 0
+    for times, scale in (([0.6, 0.8, 0.9], 0.4), ([0.7, 0.7, 0.7], 0.4), ([0.3, 0.6, 0.9], 0.4), ([0.7], 0.4),
+                         ([0.75, 0.95], -0.7), ([0.72, 0.8, 1.0], -0.7), ([0.9, 1.0], -0.85)):
+        if scale > 0:
+            x = (torch.rand(7, 1, d, generator=g) - 0.5) * scale
+        else:       # radii spread up to |scale|: paths that left the domain and re-entered at different times |x| / r
+            x = torch.randn(7, 1, d, generator=g)
+            x = x / torch.sqrt(torch.sum(x ** 2, 2, keepdim=True)) * torch.linspace(0.2, -scale, 7).view(7, 1, 1)
+        X = torch.cat((torch.tensor(times).view(1, -1, 1).repeat(7, 1, 1), x.repeat(1, len(times), 1)), 2)
+        try:
+            with torch.no_grad():
+                u = S.u_net(X)
+        except (IndexError, RuntimeError) as exc:       # the reference does not survive every input on this branch
+            print('   reference fails on', times, scale, '->', repr(exc)[:80])
+            continue
+        out['%d/X' % k], out['%d/u' % k] = npy(X), npy(u)
+        k += 1
+    out['n'] = np.array(k)
+    np.savez_compressed(os.path.join(HERE, 'ref_boundpad_hourglass.npz'), **out)
+    print('wrote ref_boundpad_hourglass.npz', k, 'cases', [tuple(out['%d/u' % i].shape) for i in range(k)])
+
+
 def fillt_vectors():
     """src/dataset.py:13-32 on a few hand-picked time vectors (the helper has surprising edge behaviour that the
     product reproduces verbatim: it can drop a sample and return indices past the filled vector)."""
@@ -370,6 +406,7 @@ if __name__ == '__main__':
     if not args.only_traj:
         fillt_vectors()
         bound_pad_vectors()
+        bound_pad_hourglass_vectors()
         sphere_groups('ref_cone_groups', 'NSphere_TCone', 3, 64, 40, 8, 1)
         sphere_groups('ref_hourglass_groups', 'NSphere_THourglass', 3, 64, 40, 8, 1)
         one_iteration('ref_tiny_midpoint', 3, 8, 12, 6, 7, 'midpoint', True)

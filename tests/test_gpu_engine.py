@@ -370,6 +370,19 @@ def test_evaluation_off_the_boundary_matches_reference(golden_dir):
         close(u, z['%d/u' % k], F32TOL, F32TOL, 'case %d' % k)
 
 
+def test_evaluation_off_the_boundary_on_the_hourglass_matches_reference(golden_dir):
+    """the per-path padded grids of NSphere_THourglass.bound_pad (src/dataset.py:127-152): buckets by grid length, every
+    bucket on the grid of its first path, results ordered bucket by bucket -- on the inputs the reference survives"""
+    z, params = load(golden_dir, 'ref_boundpad_hourglass')
+    S = make_solver(params, int(z['seed']))
+    for k in range(int(z['n'])):
+        X = torch.from_numpy(z['%d/X' % k])
+        with torch.no_grad():
+            u = S.u_net(X)
+        assert tuple(u.shape) == z['%d/u' % k].shape
+        close(u, z['%d/u' % k], F32TOL, F32TOL, 'case %d' % k)
+
+
 def test_checkpoint_resume_is_bit_exact(golden_dir, tmp_path):
     """train 2+2 outer iterations with a save/load in the middle == train 4 outer iterations in one go"""
     z, params = load(golden_dir, 'ref_tiny_midpoint')

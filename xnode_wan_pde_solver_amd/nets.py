@@ -199,7 +199,17 @@ class XNODE(nn.Module):
                 # over the densified grid of domain.bound_pad / fillt and keep the states at the requested times
                 path_i, gather, filled = self.domain.bound_pad(inputs.detach())
                 if path_i is not None:
-                    raise XnwanError('per-path padded grids (hourglass bound_pad) are not built yet')
+                    # per-bucket grids (hourglass): like the reference, ALL paths are integrated over the bucket's grid
+                    # and the bucket's rows / columns are kept; the result is ordered bucket by bucket (src/model.py:104-109)
+                    start = self.start_values(inputs)
+                    outs = []
+                    for rows, cols, grid in zip(path_i, gather, filled):
+                        grid = grid.to(inputs.device).to(inputs.dtype).reshape(-1)
+                        padded = inputs[:, :1, :].repeat(1, grid.shape[0], 1)
+                        padded[:, :, 0] = grid.view(1, -1)
+                        out = _OdeFn.apply(padded.to(dev), start.to(dev), self, *self.blob.params)
+                        outs.append(out[rows.to(dev)][:, cols.long().to(dev), :])
+                    return torch.cat(outs, dim=0)
                 grid = filled.to(inputs.device).to(inputs.dtype)
                 padded = inputs[:, :1, :].repeat(1, grid.shape[0], 1)
                 padded[:, :, 0] = grid.view(1, -1)

@@ -252,8 +252,37 @@ class NSphere_THourglass(_NSphereBase):
         return res
 
     def bound_pad(self, x):
-        raise NotImplementedError('hourglass bound_pad (off-boundary evaluation, reference src/dataset.py:127-152) is '
-                                  'not built yet -- SURVEY.md section 8(f) row 3')
+        """Per-path densified grids for the evaluation of paths that start neither at T0 nor on the boundary
+        (reference src/dataset.py:127-152).  A path whose first sample lies in the widening half is integrated from its
+        entry point on the moving boundary (time |x| / r, or T0 if it never left); paths are bucketed by the length of
+        their filled grid and -- like the reference -- every bucket uses the grid and the index map of its FIRST path.
+        Returns (path indices per bucket, index map per bucket, grid per bucket)."""
+        t_first = x[0, 0, 0]
+        on_bdry = None
+        if t_first < self._half():
+            t_in = self.T0 * torch.ones_like(x[:, 0, 0])
+        else:
+            rad = torch.sqrt(torch.sum(x[:, 0, 1:] ** 2, dim=-1))
+            never_left = torch.le(rad, self.r * self._half())
+            t_in = torch.zeros_like(x[:, 0, 0])
+            t_in[never_left] = self.T0
+            t_in[~never_left] = rad[~never_left] / self.r
+            on_bdry = torch.le(self.func_w(x[:, 0].unsqueeze(1)), 1e-5).squeeze().int()
+        t_all = torch.cat((t_in.unsqueeze(1), x[:, :, 0]), dim=1)
+        n = t_all.shape[0]
+        grids = [fillt(t_all[k], self.T, self.T0, self.N_t)[1] for k in range(n)]
+        if on_bdry is None:
+            maps = [fillt(t_all[k], self.T, self.T0, self.N_t)[0] for k in range(n)]
+        else:   # a first sample that sits on the boundary is its own entry point: drop the prepended time for the map
+            maps = [fillt(t_all[k][int(on_bdry[k]):], self.T, self.T0, self.N_t)[0][1 - int(on_bdry[k]):] for k in range(n)]
+        order = sorted(range(n), key=lambda k: grids[k].shape[0])
+        path_i, idx, data = [], [], []
+        for _, bucket in groupby(order, key=lambda k: grids[k].shape[0]):
+            ks = list(bucket)
+            path_i.append(torch.tensor(ks))
+            idx.append(maps[ks[0]])
+            data.append(grids[ks[0]])
+        return path_i, idx, data
 
     def V(self):
         d1 = self.dim + 1
