@@ -252,11 +252,6 @@ class Engine:
     def _mark(self):
         return torch.cuda.current_stream().record_event()
 
-    def _join_side(self, i, *events):
-        if self.use_streams:
-            for ev in events:
-                self.streams[i].wait_event(ev)
-
     def _join(self, *events):
         if self.use_streams:
             cur = torch.cuda.current_stream()
