@@ -19,6 +19,8 @@ Data layout in HBM (per group of N equal-length paths, L sample times, d dimensi
   t             float64 [L]      shared time grid
   u, v, vt, f, ubar, vbar ...    float64 [L, N]   time-major point arrays (coalesced for one-lane-per-path kernels)
   Y             float64 [L, H, N]  hidden-state checkpoints of the stepper (written by the forward, read by the sweeps)
+  act, act_b    float64 [L-1, rows, N]   stage activations of every step (forward -> sweeps: no field re-evaluation)
+  vact          float64 [(q+1) W, N L]   layer inputs of the test network (its forward -> its backward)
   slabs         float64 [n_slab, P]  per-wave partial parameter gradients, summed inside the Adam kernel
 """
 import os
@@ -108,7 +110,7 @@ class Engine:
         # opt-in: v, dv/dt, nabla_x v(t_0) of a group are reused while phi and the sample are unchanged (exact: the
         # reference recomputes identical values in every sub-step of an outer iteration).  Off by default.
         self.reuse_test_net = os.environ.get('XW_REUSE_V', '0') == '1'
-        # the forward pass stores the stage activations of every step for the sweeps (see include/xnwan.h, XwOdeFwdJob.act)
+        # both forwards store their layer inputs for their backwards (include/xnwan.h: XwOdeFwdJob.act, xw_disc_fwd act)
         self.keep_activations = os.environ.get('XW_KEEP_ACT', '1') == '1'
         # The test network's launch is persistent (grid-stride over point tiles) and at 2 blocks per CU it owns every SIMD's
         # register file: the stepper's waves, launched next to it, then wait until it drains.  Capping it at 3/4 of the
