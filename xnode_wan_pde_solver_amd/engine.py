@@ -424,13 +424,16 @@ class Engine:
         if self.world is None:
             self._run(G, 'gen' + sfx, self._gen_all)
             return
-        self._run(G, 'gen_front' + sfx, self._gen_front)
-        if self.world is not None:
-            P = self.Pu
-            KN.slab_sum(G.slabA, out=self.pack_u[:P])
-            KN.slab_sum(G.slabB, out=self.pack_u[P:2 * P])
-            self.world.all_reduce(self.pack_u)                    # the ONE exchange of the generator sub-step
+        self._run(G, 'gen_front' + sfx, self._gen_front_packed)   # ... -> pack_u = [sum A | sum B | scal]
+        self.world.all_reduce(self.pack_u)                        # the ONE exchange of the generator sub-step
         self._run(G, 'gen_back', self._gen_back)
+
+    def _gen_front_packed(self, G):
+        """several GPUs: the front segment ends with the slab sums into the exchange buffer (same captured graph)"""
+        self._gen_front(G)
+        P = self.Pu
+        KN.slab_sum(G.slabA, out=self.pack_u[:P])
+        KN.slab_sum(G.slabB, out=self.pack_u[P:2 * P])
 
     # ------------------------------------------------------------------------------------------------------------
     # discriminator sub-step (src/training.py:152-162)
@@ -458,6 +461,10 @@ class Engine:
             KN.disc_bwd(G.xvT, G.t, self.phi.data, G.vbar, self.W, self.q, gslab=G.slab_v, act=act)
         else:
             KN.disc_bwd(G.xvT_pts, None, self.phi.data, G.vbar.view(1, -1), self.W, self.q, tpp=G.tpp, gslab=G.slab_v, act=act)
+
+    def _disc_mid_packed(self, G):
+        self._disc_mid(G)
+        KN.slab_sum(G.slab_v, out=self.grad_v)
 
     def _disc_back(self, G):
         lr, st = self.config['v_rate'], self.adam_v
@@ -488,8 +495,7 @@ class Engine:
             return
         self._run(G, 'disc_front' + sfx, self._disc_front)
         self.world.all_reduce(self.scal[0:4])                     # I and sum v^2 must be global before the cotangent
-        self._run(G, 'disc_mid', self._disc_mid)
-        KN.slab_sum(G.slab_v, out=self.grad_v)
+        self._run(G, 'disc_mid' + ('_act' if getattr(G, 'vact_valid', False) else ''), self._disc_mid_packed)
         self.world.all_reduce(self.grad_v)
         self._run(G, 'disc_back', self._disc_back)
 
