@@ -327,3 +327,40 @@ def test_dims_outside_the_compiled_set_fail_loudly():
     with pytest.raises(XnwanError):
         KN.ode_fwd(x.cpu(), t, torch.zeros(16, dtype=torch.float64).cuda(),
                    torch.zeros(KN.theta_size(3, 20, 10), dtype=torch.float64).cuda(), 1, 20, 10, 8)
+
+
+def test_empty_and_malformed_inputs_are_refused_by_the_c_abi():
+    """the library never launches on an empty group or with missing / inconsistent buffers: negative XW_E_* status codes"""
+    import ctypes
+    from xnode_wan_pde_solver_amd import kernels as KN, _lib
+    from xnode_wan_pde_solver_amd._lib import XnwanError, lib
+    d, N, L = 3, 16, 4
+    th = torch.zeros(KN.theta_size(d, H, K), dtype=F64).cuda()
+    ph = torch.zeros(KN.phi_size(d, W), dtype=F64).cuda()
+    x, t, s = torch.zeros(d, N, dtype=F64).cuda(), torch.linspace(0, 1, L, dtype=F64).cuda(), torch.zeros(N, dtype=F64).cuda()
+    u = torch.empty(L, N, dtype=F64).cuda()
+    p = lambda a: ctypes.c_void_p(a.data_ptr())   # noqa: E731
+    null = ctypes.c_void_p(0)
+    # N = 0, L = 0, missing pointers, unknown method, mode 0, x_cot_ones without both outputs
+    assert lib.xw_ode_fwd(p(x), p(t), p(s), p(th), 1, 0, L, d, H, K, 8, p(u), null, null) < 0
+    assert lib.xw_ode_fwd(p(x), p(t), p(s), p(th), 1, N, 0, d, H, K, 8, p(u), null, null) < 0
+    assert lib.xw_ode_fwd(null, p(t), p(s), p(th), 1, N, L, d, H, K, 8, p(u), null, null) < 0
+    assert lib.xw_ode_fwd(p(x), p(t), p(s), p(th), 7, N, L, d, H, K, 8, p(u), null, null) < 0
+    Y = torch.empty(L, H, N, dtype=F64).cuda()
+    gx, gs = torch.empty(d, N, dtype=F64).cuda(), torch.empty(N, dtype=F64).cuda()
+    assert lib.xw_ode_bwd(p(x), p(t), p(s), p(th), p(Y), null, 1, N, L, d, H, K, 8, 0, p(gx), p(gs), null, null) < 0
+    assert lib.xw_ode_bwd(p(x), p(t), p(s), p(th), p(Y), null, 1, N, L, d, H, K, 8, 5, p(gx), p(gs), null, null) < 0
+    assert lib.xw_ode_bwd(p(x), p(t), p(s), p(th), p(Y), null, 1, N, L, d, H, K, 8, 2, null, null, null, null) < 0   # no slabs
+    v = torch.empty(L, N, dtype=F64).cuda()
+    assert lib.xw_disc_fwd(p(x), p(t), null, p(ph), 0, L, d, W, Q, p(v), null, null, null, 0, 0, null, null) < 0
+    assert lib.xw_disc_fwd(p(x), null, null, p(ph), N, L, d, W, Q, p(v), null, null, null, 0, 0, null, null) < 0       # no times
+    assert lib.xw_disc_fwd(p(x), p(t), p(s), p(ph), N, L, d, W, Q, p(v), null, null, null, 0, 0, null, null) < 0       # tpp with L > 1
+    assert lib.xw_disc_fwd(p(x), p(t), null, p(ph), N, L, d, 48, Q, p(v), null, null, null, 0, 0, null, null) < 0      # width
+    # and the Python layer turns shape / dtype mismatches into XnwanError before anything reaches the device
+    with pytest.raises(XnwanError):
+        KN.disc_fwd(x, t, ph[:-1].contiguous(), W, Q)
+    with pytest.raises(XnwanError):
+        KN.ode_fwd(x.float(), t, s, th, 1, H, K, 8)
+    with pytest.raises(XnwanError):
+        KN.ode_bwd_multi([dict(xT=x, start=s, Y=Y, ubar=None, gx=gx, gs=gs)], t, th, 1, H, K, 8, want_x=True, want_params=False,
+                         x_cot_ones=True)
