@@ -157,11 +157,13 @@ def test_module_autograd_path_reproduces_reference_gradients(golden_dir):
     assert S.v_net(torch.rand(7, 3, S.setup['dim'] + 1)).shape == (7, 3, 1)
 
 
-def test_engine_against_oracle_general_coefficients():
-    """non-identity a, non-zero b, non-linear c(u): the structured fast paths are off, everything goes the general way"""
+@pytest.mark.parametrize('m,q', [(8, 9), (3, 4)])
+def test_engine_against_oracle_general_coefficients(m, q):
+    """non-identity a, non-zero b, non-linear c(u): the structured fast paths are off, everything goes the general way.
+    Second case: network depths other than the YAML's (the test network then always runs from its activation record)"""
     from oracle import refspec as R
     d = 4
-    params = {'alpha': 1e3, 'u_layers': 8, 'u_hidden_dim': 20, 'u_hidden_hidden_dim': 10, 'v_layers': 9, 'v_hidden_dim': 50,
+    params = {'alpha': 1e3, 'u_layers': m, 'u_hidden_dim': 20, 'u_hidden_hidden_dim': 10, 'v_layers': q, 'v_hidden_dim': 50,
               'n1': 2, 'n2': 1, 'u_rate': 0.015, 'v_rate': 0.04, 'min_steps': 5, 'adjoint': False, 'solver': 'midpoint',
               'dim': d, 'N_t': 9, 'N_r': 83, 'N_b': 45, 'T0': 0, 'T': 1, 'shape_param': [-1, 1], 'iterations': 1,
               'domain': 'Hypercube'}
@@ -183,7 +185,7 @@ def test_engine_against_oracle_general_coefficients():
     assert not st.a_identity and not st.b_zero and st.c_kappa is None
     torch.manual_seed(5)
     O = R.Solver(params, funcs, u_sol=P.func_u_sol, p=2)
-    for n_, k_ in R.u_names(8):
+    for n_, k_ in R.u_names(m):
         assert torch.equal(dict(S.u_net.named_parameters())[n_].detach().cpu(), O.theta[k_])
     rng = torch.get_rng_state()
     domain, pts = first_sample(S)
@@ -195,7 +197,7 @@ def test_engine_against_oracle_general_coefficients():
         if step == 'u':
             o = O.generator_step()
             S.engine.generator_step(G)
-            got, blob, names = S.engine.grad_u, S.engine.theta, R.u_names(8)
+            got, blob, names = S.engine.grad_u, S.engine.theta, R.u_names(m)
             close(S.engine.scal[4], o['loss'], 1e-8)
         else:
             o = O.discriminator_step()

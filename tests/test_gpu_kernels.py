@@ -248,6 +248,42 @@ def test_disc_backward(N, L, d):
         off += n
 
 
+@pytest.mark.parametrize('q', [0, 1, 4, 12])
+@pytest.mark.parametrize('N,L,d', [(37, 4, 5), (50, 3, 70)])
+def test_disc_other_depths(N, L, d, q):
+    """v_layers other than the YAML's 9: the forward takes the depth at run time, the reverse kernels run from the record
+    (the C ABI refuses the recomputing form, the host wrapper stores the record first)"""
+    from oracle import refspec as R
+    from xnode_wan_pde_solver_amd import kernels as KN, _lib
+    cfg = dict(_cfg(), v_layers=q)
+    torch.manual_seed(61)
+    _, phi = R.init_parameters(cfg, _setup(d, 2))
+    for p_ in phi.values():
+        if p_.dim() == 1:
+            p_.copy_(0.3 * torch.randn_like(p_))
+    ph = {k: v.clone().requires_grad_(True) for k, v in phi.items()}
+    x, t, X = _sample(N, L, d, 62)
+    vbar = torch.randn(N, L, dtype=F64, generator=torch.Generator().manual_seed(63))
+    Xd = X.double().requires_grad_(True)
+    v_ref = R.v_net(ph, cfg, Xd)
+    used = [k for k in V_ORDER if q > 0 or not k.startswith('Vh')]
+    grads = dict(zip(used, torch.autograd.grad((v_ref * vbar).sum(), [ph[k] for k in used], retain_graph=True)))
+    gX = torch.autograd.grad(v_ref.sum(), Xd)[0]
+    xT, tc, blob = x.double().t().contiguous().cuda(), t.double().cuda(), _blob(phi, V_ORDER)
+    v, vt = KN.disc_fwd(xT, tc, blob, W, q)
+    _close(v.t(), v_ref, 1e-12, 'v'); _close(vt.t(), gX[:, :, 0], 1e-11, 'dv/dt')
+    got = KN.slab_sum(KN.disc_bwd(xT, tc, blob, vbar.t().contiguous().cuda(), W, q)).cpu()
+    ref = torch.cat([(grads[k] if k in grads else torch.zeros_like(phi[k])).reshape(-1) for k in V_ORDER])
+    _close(got, ref, 1e-10, 'phi gradient')
+    w0 = torch.randn(N, dtype=F64, generator=torch.Generator().manual_seed(64))
+    gxv, gtv = KN.disc_gradx(xT, tc, blob, W, q, vbar=w0.cuda())
+    _close(gxv.t(), gX[:, 0, 1:] * w0[:, None], 1e-11, 'nabla_x v'); _close(gtv, gX[:, 0, 0] * w0, 1e-11, 'dv/dt at t0')
+    if q != 9:   # the C entry point itself: no silent fallback
+        slab = torch.empty(KN.disc_bwd_slabs(N, L), blob.numel(), dtype=F64, device='cuda')
+        rc = _lib.lib.xw_disc_bwd(KN._p(xT), KN._p(tc), None, KN._p(blob), None, N, L, d, W, q, None, KN._p(slab), None)
+        assert rc == -1
+
+
 @pytest.mark.parametrize('N,L,d', [(37, 4, 5), (64, 3, 20), (50, 3, 70)])
 def test_disc_backward_from_stored_activations(N, L, d):
     """xw_disc_fwd can leave the layer inputs of every point behind; xw_disc_bwd given that record skips its forward

@@ -291,14 +291,18 @@ template <int W> struct BwdLds {
 
 // SAVED: the layer inputs relu(a_j) and tanh(a_q) come from the record k_disc_fwd stored (xw_disc_fwd `act`): no forward
 // recompute at all -- the kernel is the reverse chain + the weight-gradient outer products.
+// Q: number of tied layers, unrolled; Q = 0 takes the depth from the argument `qrt` at run time (SAVED only: the record
+// is indexed by layer, the recomputing variants keep their checkpoints in registers and need a compile-time depth).
 template <int W, int Q, int CTG, bool PARAMS, bool INGRAD, bool SAVED = false>
 __global__ void __launch_bounds__(256) k_disc_bwd(const double* __restrict__ xT, const double* __restrict__ tf,
                                                   const double* __restrict__ tpp, const double* __restrict__ ph,
                                                   const double* __restrict__ vbar, int N, int L, int d,
                                                   double* __restrict__ gslab, double* __restrict__ gxv,
-                                                  double* __restrict__ gtv, const double* __restrict__ act) {
+                                                  double* __restrict__ gtv, const double* __restrict__ act, int qrt) {
+  static_assert(Q > 0 || SAVED, "run-time depth needs the activation record");
   typedef VDim<W> D;
   typedef BwdLds<W> S;
+  const int nq = Q > 0 ? Q : qrt;
   __shared__ double lds[S::total];
   double* sVh = lds + S::oVh;
   double* sVhT = lds + S::oVhT;
@@ -351,7 +355,8 @@ __global__ void __launch_bounds__(256) k_disc_bwd(const double* __restrict__ xT,
   // nothing is recomputed -- 497 vs 558 us at SEG = 3 even with 48 spilled registers.  The wide-input variant (CTG = 2,
   // d > 62) carries 32 more accumulator registers and keeps the 3-layer segments.
   constexpr int SEG = (CTG == 1 || SAVED) ? 1 : 3;
-  constexpr int NSEG = (Q + SEG - 1) / SEG;
+  constexpr int NSEG = Q > 0 ? (Q + SEG - 1) / SEG : 1;
+  const int nseg = Q > 0 ? NSEG : nq;
   for (long st = blockIdx.x; st < nsuper; st += gridDim.x) {
     const Pt pt = locate(st * 4 + wave, P, N, tf, tpp);
     // ---- forward: only r_0, r_3, r_6 (= relu(a_j)) are kept; the layers in between are recomputed per segment, so the
@@ -375,8 +380,8 @@ __global__ void __launch_bounds__(256) k_disc_bwd(const double* __restrict__ xT,
     };
     d4 rnext[D::MT];                                   // SAVED: inputs of the layer that is reversed next (prefetch)
     if constexpr (SAVED) {
-      load_layer(Q, a);                                // tanh(a_q)
-      load_layer(Q - 1, rnext);
+      load_layer(nq, a);                               // tanh(a_q)
+      if (nq > 0) load_layer(nq - 1, rnext);
     } else {
       input_layer<W>(ph, o, xT, N, d, pt, a, ad);
 #pragma unroll
@@ -408,19 +413,19 @@ __global__ void __launch_bounds__(256) k_disc_bwd(const double* __restrict__ xT,
       }
     // ---- reverse chain, segment by segment
 #pragma unroll
-    for (int sg = NSEG - 1; sg >= 0; --sg) {
+    for (int sg = nseg - 1; sg >= 0; --sg) {
       d4 seg[SEG][D::MT];
 #pragma unroll
       for (int mt = 0; mt < D::MT; ++mt)
 #pragma unroll
         for (int q_ = 0; q_ < 4; ++q_)
-          if (q_ < D::LR(mt)) seg[0][mt][q_] = SAVED ? rnext[mt][q_] : ck[sg][mt][q_];
+          if (q_ < D::LR(mt)) seg[0][mt][q_] = SAVED ? rnext[mt][q_] : ck[Q > 0 ? sg : 0][mt][q_];
       if constexpr (SAVED) {
         if (sg > 0) load_layer(sg - 1, rnext);         // in flight while this layer is reversed
       }
 #pragma unroll
       for (int k = 1; k < SEG; ++k)
-        if (sg * SEG + k < Q) {
+        if (sg * SEG + k < nq) {
           d4 tmp[D::MT];
           layer(seg[k - 1], tmp);
 #pragma unroll
@@ -431,7 +436,7 @@ __global__ void __launch_bounds__(256) k_disc_bwd(const double* __restrict__ xT,
         }
 #pragma unroll
       for (int k = SEG - 1; k >= 0; --k) {
-        if (sg * SEG + k >= Q) continue;
+        if (sg * SEG + k >= nq) continue;
         if (PARAMS) {
 #pragma unroll
           for (int mt = 0; mt < D::MT; ++mt) {
@@ -612,28 +617,32 @@ extern "C" int xw_disc_fwd(const double* xT, const double* t, const double* tpp,
 
 extern "C" int xw_disc_bwd_slabs(int N, int L) { return bwd_blocks((long)N * L); }
 
-#define XW_DISC_BWD(PARAMS, INGRAD, SAVED)                                                                               \
+#define XW_DISC_BWD(Q, PARAMS, INGRAD, SAVED)                                                                            \
   if (d + 2 <= 64)                                                                                                       \
-    hipLaunchKernelGGL((k_disc_bwd<50, 9, 1, PARAMS, INGRAD, SAVED>), dim3(blocks), dim3(256), 0, s, xT, t, tpp, phi, vbar, \
-                       N, L, d, gslab, gxv, gtv, act);                                                                   \
+    hipLaunchKernelGGL((k_disc_bwd<50, Q, 1, PARAMS, INGRAD, SAVED>), dim3(blocks), dim3(256), 0, s, xT, t, tpp, phi, vbar, \
+                       N, L, d, gslab, gxv, gtv, act, q);                                                                \
   else                                                                                                                   \
-    hipLaunchKernelGGL((k_disc_bwd<50, 9, 2, PARAMS, INGRAD, SAVED>), dim3(blocks), dim3(256), 0, s, xT, t, tpp, phi, vbar, \
-                       N, L, d, gslab, gxv, gtv, act);
+    hipLaunchKernelGGL((k_disc_bwd<50, Q, 2, PARAMS, INGRAD, SAVED>), dim3(blocks), dim3(256), 0, s, xT, t, tpp, phi, vbar, \
+                       N, L, d, gslab, gxv, gtv, act, q);
 
 extern "C" int xw_disc_bwd(const double* xT, const double* t, const double* tpp, const double* phi, const double* vbar,
                            int N, int L, int d, int W, int q, const double* act, double* gslab, void* stream) {
   if (!xT || !phi || !gslab || N <= 0 || L <= 0 || d <= 0) return XW_E_ARG;
   if (!tpp && !t) return XW_E_ARG;
   if (tpp && L != 1) return XW_E_ARG;
-  if (W != 50 || q != 9 || d + 2 > 128) return XW_E_DIMS;
+  // depth 9 (the reference's YAML) is unrolled, with or without the record; every other depth runs from the record
+  if (W != 50 || q < 0 || d + 2 > 128 || (q != 9 && act == nullptr)) return XW_E_DIMS;
+  if ((long)N * L * 4 >= (1L << 31)) return XW_E_ARG;
   hipStream_t s = (hipStream_t)stream;
   const int blocks = bwd_blocks((long)N * L);
   double* gxv = nullptr;
   double* gtv = nullptr;
-  if (act != nullptr) {
-    XW_DISC_BWD(true, false, true)
+  if (act != nullptr && q == 9) {
+    XW_DISC_BWD(9, true, false, true)
+  } else if (act != nullptr) {
+    XW_DISC_BWD(0, true, false, true)
   } else {
-    XW_DISC_BWD(true, false, false)
+    XW_DISC_BWD(9, true, false, false)
   }
   return xw_launch_status();
 }
@@ -648,6 +657,6 @@ extern "C" int xw_disc_gradx(const double* xT, const double* t, const double* tp
   const int blocks = bwd_blocks((long)N);
   double* gslab = nullptr;
   const double* act = nullptr;
-  XW_DISC_BWD(false, true, false)
+  XW_DISC_BWD(9, false, true, false)
   return xw_launch_status();
 }

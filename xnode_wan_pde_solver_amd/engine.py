@@ -225,7 +225,9 @@ class Engine:
         G.act_b = e(max(Lb - 1, 1), ar, Nb) if (ar and Nb) else None
         # layer inputs of the test network at every point, stored by its forward in the discriminator sub-step and read
         # back by its backward (524 MB at 131072 points)
-        G.vact = e(KN.disc_act_rows(self.W, self.q), KN.disc_act_cols(L * N)) if self.keep_activations else None
+        # (depths other than the unrolled one have no recomputing reverse kernel: they always run from the record)
+        keep_v = self.keep_activations or self.q != KN.DISC_UNROLLED_DEPTH
+        G.vact = e(KN.disc_act_rows(self.W, self.q), KN.disc_act_cols(L * N)) if keep_v else None
         G.ns_u = KN.ode_bwd_slabs(N)
         G.ns_b = KN.ode_bwd_slabs(Nb) if Nb else 0
         G.slabA = e(G.ns_u + G.ns_b, self.Pu)          # sweep with cotangent A (interior) + the boundary sweep

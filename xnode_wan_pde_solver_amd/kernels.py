@@ -148,6 +148,9 @@ def ode_bwd(xT, t, start, theta, Y, ubar, method, H, K, m, want_x=True, want_par
     return (gx if want_x else None), (gs if want_x else None), (gslab if want_params else None)
 
 
+DISC_UNROLLED_DEPTH = 9   # v_layers of the reference's YAML: the depth the recomputing reverse kernels are compiled for
+
+
 def disc_act_rows(W, q):
     """rows of the activation record disc_fwd can store for disc_bwd: the inputs of the q tied layers + tanh(a_q)"""
     r = lib.xw_disc_act_rows(W, q)
@@ -193,6 +196,14 @@ def disc_gradx(xT, t, phi, W, q, tpp=None, vbar=None, gxv=None, gtv=None):
     if vbar is not None:
         vbar = vbar.reshape(-1)
         _chk(vbar, F64, (N,), 'vbar')
+    if q != DISC_UNROLLED_DEPTH:
+        # other depths: the forward kernel's fused input gradient (any q <= 16), scaled by the cotangent
+        t0 = t[:1] if tpp is None else None
+        disc_fwd(xT, t0, phi, W, q, tpp=tpp, want_vt=False, gxv=gxv, gtv=gtv, ngrad=N)
+        if vbar is not None:
+            gxv.mul_(vbar)
+            gtv.mul_(vbar)
+        return gxv, gtv
     check(lib.xw_disc_gradx(_p(xT), _p(t), _p(tpp), _p(phi), _p(vbar), N, d, W, q, _p(gxv), _p(gtv), _stream()), 'xw_disc_gradx')
     return gxv, gtv
 
@@ -213,6 +224,10 @@ def disc_bwd(xT, t, phi, vbar, W, q, tpp=None, gslab=None, act=None):
     ns = disc_bwd_slabs(N, L)
     gslab = torch.empty(ns, P, dtype=F64, device=xT.device) if gslab is None else gslab
     _chk(gslab, F64, (ns, P), 'gslab')
+    if act is None and q != DISC_UNROLLED_DEPTH:
+        # the recomputing kernel exists at the reference's depth only: store the record first, then reverse from it
+        act = torch.empty(disc_act_rows(W, q), disc_act_cols(L * N), dtype=F64, device=xT.device)
+        disc_fwd(xT, t, phi, W, q, tpp=tpp, want_vt=False, act=act)
     if act is not None:
         _chk(act, F64, (disc_act_rows(W, q), disc_act_cols(L * N)), 'act')
     check(lib.xw_disc_bwd(_p(xT), _p(t), _p(tpp), _p(phi), _p(vbar), N, L, d, W, q, _p(act), _p(gslab), _stream()),
