@@ -163,3 +163,24 @@ def test_sphere_domains_sample_like_the_reference(golden_dir, case, name):
         assert np.array_equal(g.detach().numpy(), z['boundary/%d' % k])
         assert float(domain.func_w(g.detach()).abs().max()) < 1e-12                          # boundary points sit on the boundary
     assert len(list(pts)) == min(len(pts.interioru), len(pts.boundary))                      # silent truncation (Q7)
+
+
+def test_incremental_json_files_are_byte_identical_to_json_dump(tmp_path):
+    """losses_NODE_{d}.json / Time_NODE_{d}.json are rewritten after every sub-iteration (src/training.py:133-134,166-167);
+    the host loop formats them incrementally, the bytes on disk must be those of json.dump(whole list)"""
+    import json
+    from xnode_wan_pde_solver_amd.solver import _JsonList
+    g = torch.Generator().manual_seed(3)
+    vals = [1.5, 1e-300, float('inf'), float('nan'), -0.0, 7, 1e22, 0.1 + 0.2]
+    vals += [float(x) * 10.0 ** int(e) for x, e in zip(torch.rand(64, generator=g, dtype=torch.float64),
+                                                        torch.randint(-6, 9, (64,), generator=g))]
+    got, ref = _JsonList([0.25]), [0.25]
+    path = tmp_path / 'l.json'
+    for x in vals:
+        got.append(x); ref.append(x)
+        got.write(path)
+        assert path.read_text() == json.dumps(ref)
+    assert list(got) == ref or all(a == b or (a != a and b != b) for a, b in zip(got, ref))
+    empty = _JsonList()
+    empty.write(path)
+    assert path.read_text() == '[]'

@@ -70,6 +70,25 @@ def build_networks(config, setup, func_h, func_g, domain_cls):
     return u_net, v_net
 
 
+
+class _JsonList(list):
+    """A list whose JSON text is kept up to date as it grows.  The reference rewrites losses_NODE_{d}.json and
+    Time_NODE_{d}.json with json.dump(whole list) after every sub-iteration (src/training.py:133-134,166-167): formatting
+    k floats per write is milliseconds once k is in the thousands, more than the GPU work of the iteration it follows.
+    The files written here are byte-identical to json.dump's; only the formatting is incremental."""
+
+    def __init__(self, items=()):
+        super().__init__(items)
+        self._text = ', '.join(json.dumps(x) for x in self)
+
+    def append(self, x):
+        self._text += (', ' if len(self) else '') + json.dumps(x)
+        super().append(x)
+
+    def write(self, path):
+        with open(path, 'w') as fh:
+            fh.write('[' + self._text + ']')
+
 class FusedAdam:
     """Stands where the reference has torch.optim.Adam (attributes optimizer_u / optimizer_v).  step() applies the
     fused HIP Adam kernel to the blob using the .grad of the parameters (for user code that went through autograd);
@@ -118,6 +137,8 @@ class NODE_WAN_solver:
                                           # sample itself is still drawn with the host RNG, draw-for-draw like the reference);
                                           # True: tabulate on the host exactly like the reference's CPU path (bitwise h, f, g)
         self.device_sampling = False      # True: draw the cube samples with the device RNG (no seed parity, fastest)
+        self.overlap_sampling = True      # draw the next host samples on a helper thread while the GPU works (same draws,
+                                          # same order, nothing beyond the last iteration); off when a stop callback is set
         self.host_threads = 4             # intra-op CPU threads while train() runs (None: leave torch's setting alone).  The
                                           # host side of an outer iteration is a few small tensor ops (sampling, JSON,
                                           # torch.save); fanned out over every core of a big host they take 5x longer
@@ -205,15 +226,43 @@ class NODE_WAN_solver:
             torch.set_num_threads(threads)
 
     def _train(self, report, report_it, show_plt):
-        past_losses = []
-        times = [time.time()]
+        past_losses = _JsonList()
+        times = _JsonList([time.time()])
+        # The host draws (CPU generator, for the reference's seeds) cost about as much as the GPU work of an iteration.
+        # They depend on nothing the steps compute, so one helper thread draws the post-step diagnostic sample of this
+        # iteration and the domain + sample of the next one WHILE the main thread waits for the GPU -- in the reference's
+        # order, and nothing beyond the last iteration, so the generator ends where the reference's does.  A user stop
+        # callback may draw random numbers itself between those calls: then everything stays in line.
+        pool = None
+        if self.overlap_sampling and self.stop is None and not self.device_sampling:
+            from concurrent.futures import ThreadPoolExecutor
+            pool = ThreadPoolExecutor(max_workers=1, initializer=torch.set_num_threads, initargs=(torch.get_num_threads(),))
+
+        def draw_ahead(domain, last):
+            after = self._loader(domain)
+            if last:
+                return after, None, None
+            nxt = self._new_domain()
+            return after, nxt, self._loader(nxt)
+
+        try:
+            return self._iterate(report, report_it, show_plt, past_losses, times, pool, draw_ahead)
+        finally:
+            if pool is not None:
+                pool.shutdown(wait=True)
+
+    def _iterate(self, report, report_it, show_plt, past_losses, times, pool, draw_ahead):
         d = self.setup['dim']
         eng = self.engine
+        nxt_domain = nxt_points = None
         with torch.cuda.device(self.device):
             for k in range(self.iterations):
-                domain = self._new_domain()
-                points = self._loader(domain)
-                L2 = self._l_norm(points, domain.V())
+                domain = nxt_domain if nxt_domain is not None else self._new_domain()
+                points = nxt_points if nxt_points is not None else self._loader(domain)
+                nxt_domain = nxt_points = None
+                ahead = pool.submit(draw_ahead, domain, k == self.iterations - 1) if pool is not None else None
+                # (the reference also evaluates L_norm here, src/training.py:123, and overwrites the value unread at :167;
+                #  the call draws no random numbers and writes nothing, so it is not repeated)
                 shards = self._shard(self._groups(points))
                 if len(self._group_cache) != len(shards):
                     self._group_cache = [None] * len(shards)
@@ -232,8 +281,7 @@ class NODE_WAN_solver:
                         self.av_l += self.last_loss_u
                     past_losses.append(self.av_l)
                     if self._is_main():
-                        with open('losses_NODE_' + str(d) + '.json', 'w') as fh:
-                            json.dump(past_losses, fh)
+                        past_losses.write('losses_NODE_' + str(d) + '.json')
                     if self.stop is not None and self.stop(self, points.interioru, domain):
                         if self._is_main():
                             torch.save(self.u_net.state_dict(), self.path + 'best_model_weights_NODE.pth')
@@ -250,14 +298,16 @@ class NODE_WAN_solver:
                     for G in groups:
                         eng.discriminator_step(G)
                         self.last_loss_v = eng.loss_v().item()
-                points = self._loader(domain)
+                if ahead is not None:
+                    points, nxt_domain, nxt_points = ahead.result()
+                else:
+                    points = self._loader(domain)
                 L2 = self._l_norm(points, domain.V())
                 times.append(time.time())
                 if self._is_main():
                     with open('L2_NODE_' + str(d) + '.json', 'w') as fh:
                         json.dump([L2], fh)
-                    with open('Time_NODE_' + str(d) + '.json', 'w') as fh:
-                        json.dump(times, fh)
+                    times.write('Time_NODE_' + str(d) + '.json')
                 if report and k % report_it == 0 and self._is_main():
                     print('iteration: ' + str(k), 'Loss u: ' + str(self.last_loss_u), 'Loss v: ' + str(self.last_loss_v))
                     if self.func_u_sol is not None:
