@@ -357,6 +357,7 @@ __global__ void __launch_bounds__(256) k_disc_bwd(const double* __restrict__ xT,
   constexpr int SEG = (CTG == 1 || SAVED) ? 1 : 3;
   constexpr int NSEG = Q > 0 ? (Q + SEG - 1) / SEG : 1;
   const int nseg = Q > 0 ? NSEG : nq;
+  constexpr int UNROLL = Q > 0 ? NSEG : 1;           // run-time depth: the layer loop stays a loop
   for (long st = blockIdx.x; st < nsuper; st += gridDim.x) {
     const Pt pt = locate(st * 4 + wave, P, N, tf, tpp);
     // ---- forward: only r_0, r_3, r_6 (= relu(a_j)) are kept; the layers in between are recomputed per segment, so the
@@ -412,7 +413,7 @@ __global__ void __launch_bounds__(256) k_disc_bwd(const double* __restrict__ xT,
         if (PARAMS) sO[(mt * 4 + r) * 256 + wave * 64 + lane] += (mt == D::MT - 1 && r == 3) ? (g == 0 ? vb : 0.0) : vb * th;
       }
     // ---- reverse chain, segment by segment
-#pragma unroll
+#pragma unroll UNROLL
     for (int sg = nseg - 1; sg >= 0; --sg) {
       d4 seg[SEG][D::MT];
 #pragma unroll
