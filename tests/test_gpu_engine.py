@@ -403,3 +403,22 @@ def test_checkpoint_resume_is_bit_exact(golden_dir, tmp_path):
         os.chdir(cwd)
     assert torch.equal(A.engine.theta.data, C.engine.theta.data) and torch.equal(A.engine.phi.data, C.engine.phi.data)
     assert int(C.engine.adam_u['step'].item()) == 8 and int(C.engine.adam_v['step'].item()) == 4
+
+
+def test_notebook_flow_runs_end_to_end(tmp_path, monkeypatch):
+    """examples/notebook_flow.py = the reference's example.ipynb as a script (imports of cell 0, params dict of cell 10
+    without shape_param, train(report=True) of cell 11 with the contour plots written to files): runs unchanged and
+    the error on a fresh sample has dropped well below the untrained network's"""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location('notebook_flow', os.path.join(os.path.dirname(__file__), '..', 'examples',
+                                                                               'notebook_flow.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    monkeypatch.chdir(tmp_path)
+    torch.manual_seed(0)
+    solver, err = mod.main(iterations=120, report_it=60, show_plt=False, workdir=str(tmp_path))
+    assert err < 0.3
+    files = set(os.listdir(tmp_path))
+    assert {'losses_NODE_5.json', 'L2_NODE_5.json', 'Time_NODE_5.json', 'best_model_weights_NODE.pth'} <= files
+    assert any(f.endswith('.png') for f in files), files
