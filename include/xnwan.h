@@ -107,8 +107,8 @@ int xw_disc_gradx(const double* xT, const double* t, const double* tpp, const do
 int xw_disc_bwd_slabs(int N, int L);
 /* parameter gradient of <vbar, v>: slabs gslab[xw_disc_bwd_slabs][P_v] (input gradient: xw_disc_gradx).
  * act: the record xw_disc_fwd stored for the same phi and points, or NULL (the forward is then recomputed per tile).
- * Any depth q >= 0 runs from the record; the recomputing form keeps its checkpoints in registers and is compiled for
- * the reference's q = 9 only (XW_E_DIMS otherwise). */
+ * Any depth q >= 0 runs from the record (two resident blocks per CU); the recomputing form keeps its checkpoints in
+ * registers and is compiled for the reference's q = 9 only (XW_E_DIMS otherwise). */
 int xw_disc_bwd(const double* xT, const double* t, const double* tpp, const double* phi, const double* vbar,
                 int N, int L, int d, int W, int q, const double* act, double* gslab, void* stream);
 

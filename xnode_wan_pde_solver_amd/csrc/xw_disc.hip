@@ -289,20 +289,15 @@ template <int W> struct BwdLds {
   static_assert(total * 8 <= 160 * 1024, "LDS budget of one CU");
 };
 
-// SAVED: the layer inputs relu(a_j) and tanh(a_q) come from the record k_disc_fwd stored (xw_disc_fwd `act`): no forward
-// recompute at all -- the kernel is the reverse chain + the weight-gradient outer products.
-// Q: number of tied layers, unrolled; Q = 0 takes the depth from the argument `qrt` at run time (SAVED only: the record
-// is indexed by layer, the recomputing variants keep their checkpoints in registers and need a compile-time depth).
-template <int W, int Q, int CTG, bool PARAMS, bool INGRAD, bool SAVED = false>
+// (the parameter gradient from the activation record is k_disc_rec below; this kernel recomputes the forward per tile)
+template <int W, int Q, int CTG, bool PARAMS, bool INGRAD>
 __global__ void __launch_bounds__(256) k_disc_bwd(const double* __restrict__ xT, const double* __restrict__ tf,
                                                   const double* __restrict__ tpp, const double* __restrict__ ph,
                                                   const double* __restrict__ vbar, int N, int L, int d,
                                                   double* __restrict__ gslab, double* __restrict__ gxv,
-                                                  double* __restrict__ gtv, const double* __restrict__ act, int qrt) {
-  static_assert(Q > 0 || SAVED, "run-time depth needs the activation record");
+                                                  double* __restrict__ gtv) {
   typedef VDim<W> D;
   typedef BwdLds<W> S;
-  const int nq = Q > 0 ? Q : qrt;
   __shared__ double lds[S::total];
   double* sVh = lds + S::oVh;
   double* sVhT = lds + S::oVhT;
@@ -354,51 +349,28 @@ __global__ void __launch_bounds__(256) k_disc_bwd(const double* __restrict__ xT,
   // layers per checkpoint segment.  1: every layer input r_j stays in registers (13 live f64 per layer at W = 50) and
   // nothing is recomputed -- 497 vs 558 us at SEG = 3 even with 48 spilled registers.  The wide-input variant (CTG = 2,
   // d > 62) carries 32 more accumulator registers and keeps the 3-layer segments.
-  constexpr int SEG = (CTG == 1 || SAVED) ? 1 : 3;
-  constexpr int NSEG = Q > 0 ? (Q + SEG - 1) / SEG : 1;
-  const int nseg = Q > 0 ? NSEG : nq;
-  constexpr int UNROLL = Q > 0 ? NSEG : 1;           // run-time depth: the layer loop stays a loop
+  constexpr int SEG = CTG == 1 ? 1 : 3;
+  constexpr int NSEG = (Q + SEG - 1) / SEG;
   for (long st = blockIdx.x; st < nsuper; st += gridDim.x) {
     const Pt pt = locate(st * 4 + wave, P, N, tf, tpp);
     // ---- forward: only r_0, r_3, r_6 (= relu(a_j)) are kept; the layers in between are recomputed per segment, so the
     //      live activations are 2 x SEG tiles instead of Q (which did not fit the 512-register file and spilled)
     d4 ck[NSEG][D::MT];
     d4 a[D::MT], ad[D::MT];
-    // one layer's inputs from the activation store (rows >= W of the last tile: zero)
-    const long Pp = (P + 15) & ~15L;                   // row stride of the record (whole tiles)
-    const int aoff = g * (int)Pp + pt.p;               // 32-bit lane offset; row pointers below are uniform
-    auto load_layer = [&](int j, d4 (&r)[D::MT]) {
-      const double* base = act + (long)j * W * Pp;
-      asm volatile("" : "+s"(base));                   // form the row addresses here, not hoisted out of the tile loop
+    input_layer<W>(ph, o, xT, N, d, pt, a, ad);
 #pragma unroll
-      for (int mt = 0; mt < D::MT; ++mt)
+    for (int j = 0; j < Q; ++j) {
+      d4 r[D::MT];
+#pragma unroll
+      for (int mt = 0; mt < D::MT; ++mt) {
 #pragma unroll
         for (int q_ = 0; q_ < 4; ++q_)
           if (q_ < D::LR(mt)) {
-            const int row = 16 * mt + 4 * q_ + g;
-            r[mt][q_] = (16 * mt + 4 * q_ + 3 < W || row < W) ? (base + (long)(16 * mt + 4 * q_) * Pp)[aoff] : 0.0;
+            r[mt][q_] = a[mt][q_] > 0.0 ? a[mt][q_] : 0.0;
+            if (j % SEG == 0) ck[j / SEG][mt][q_] = r[mt][q_];
           }
-    };
-    d4 rnext[D::MT];                                   // SAVED: inputs of the layer that is reversed next (prefetch)
-    if constexpr (SAVED) {
-      load_layer(nq, a);                               // tanh(a_q)
-      if (nq > 0) load_layer(nq - 1, rnext);
-    } else {
-      input_layer<W>(ph, o, xT, N, d, pt, a, ad);
-#pragma unroll
-      for (int j = 0; j < Q; ++j) {
-        d4 r[D::MT];
-#pragma unroll
-        for (int mt = 0; mt < D::MT; ++mt) {
-#pragma unroll
-          for (int q_ = 0; q_ < 4; ++q_)
-            if (q_ < D::LR(mt)) {
-              r[mt][q_] = a[mt][q_] > 0.0 ? a[mt][q_] : 0.0;
-              if (j % SEG == 0) ck[j / SEG][mt][q_] = r[mt][q_];
-            }
-        }
-        layer(r, a);
       }
+      layer(r, a);
     }
     // ---- output layer and its cotangent
     const double vb = pt.valid ? (vbar != nullptr ? vbar[pt.p] : 1.0) : 0.0;
@@ -408,25 +380,22 @@ __global__ void __launch_bounds__(256) k_disc_bwd(const double* __restrict__ xT,
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         double th = 0.0;
-        if (16 * mt + 4 * r < W) th = SAVED ? (r < D::LR(mt) ? a[mt][r] : 0.0) : xw_tanh(a[mt][r]);
+        if (16 * mt + 4 * r < W) th = xw_tanh(a[mt][r]);
         dl[mt][r] = sB[16 * D::MT + 16 * mt + g + 4 * r] * (1.0 - th * th) * vb;
         if (PARAMS) sO[(mt * 4 + r) * 256 + wave * 64 + lane] += (mt == D::MT - 1 && r == 3) ? (g == 0 ? vb : 0.0) : vb * th;
       }
     // ---- reverse chain, segment by segment
-#pragma unroll UNROLL
-    for (int sg = nseg - 1; sg >= 0; --sg) {
+#pragma unroll
+    for (int sg = NSEG - 1; sg >= 0; --sg) {
       d4 seg[SEG][D::MT];
 #pragma unroll
       for (int mt = 0; mt < D::MT; ++mt)
 #pragma unroll
         for (int q_ = 0; q_ < 4; ++q_)
-          if (q_ < D::LR(mt)) seg[0][mt][q_] = SAVED ? rnext[mt][q_] : ck[Q > 0 ? sg : 0][mt][q_];
-      if constexpr (SAVED) {
-        if (sg > 0) load_layer(sg - 1, rnext);         // in flight while this layer is reversed
-      }
+          if (q_ < D::LR(mt)) seg[0][mt][q_] = ck[sg][mt][q_];
 #pragma unroll
       for (int k = 1; k < SEG; ++k)
-        if (sg * SEG + k < nq) {
+        if (sg * SEG + k < Q) {
           d4 tmp[D::MT];
           layer(seg[k - 1], tmp);
 #pragma unroll
@@ -437,7 +406,7 @@ __global__ void __launch_bounds__(256) k_disc_bwd(const double* __restrict__ xT,
         }
 #pragma unroll
       for (int k = SEG - 1; k >= 0; --k) {
-        if (sg * SEG + k >= nq) continue;
+        if (sg * SEG + k >= Q) continue;
         if (PARAMS) {
 #pragma unroll
           for (int mt = 0; mt < D::MT; ++mt) {
@@ -585,9 +554,274 @@ __global__ void __launch_bounds__(256) k_disc_bwd(const double* __restrict__ xT,
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// k_disc_rec: the parameter gradient from the activation record, two blocks per CU.
+// k_disc_bwd<SAVED> above keeps the LDS plan of the recomputing kernel (157 KB: one block per CU, one wave per SIMD, and
+// every barrier / transpose stall of that wave is idle matrix-pipe time).  This kernel only ever runs from the record, so
+//   * the forward fragments of Vh are gone, and of Vh^T only the three full row tiles stay in LDS: rows 48, 49 of the
+//     reverse chain (W = 50) are contracted on the vector ALU from a 104-double table, as in k_disc_fwd -- 39 instead of
+//     52 chain MFMAs per layer;
+//   * the last transposed tile of every set stores its one live 4-row group (rows 48..51) instead of 16 rows; operand
+//     rows read past it (lane & 15 >= 4, folded back with & 3) only reach accumulator rows / columns that are never stored;
+//   * the dVo partial sums are reduced over the 16 points of a tile before they go to LDS (256 instead of 4096 doubles);
+//   * the input-layer gradient is contracted in groups of 48 input rows (three full tiles);
+// -> 78 KB per block, <= 256 registers per wave: two blocks share a CU and cover each other's barriers.
+template <int W> struct RecLds {
+  typedef VDim<W> D;
+  static_assert(D::VTAIL && D::LR(D::MT - 1) == 1, "short last row tile: vector-ALU tail + one live 4-row group");
+  static constexpr int T3 = 4 * XW_TSTRIDE;                       // trimmed last tile
+  static constexpr int wset = (D::MT - 1) * XW_TTILE + T3;        // one wave's set of transposed tiles
+  static constexpr int oVhT = 0;                                  // [MTF][KS][64]
+  static constexpr int oTT = oVhT + D::MTF * D::KS * 64;          // [4 KS][TR]: Vh[k][16 (MT-1) + r]
+  static constexpr int oVo = oTT + 4 * D::KS * D::TR;             // Vo, zero-padded to 16 MT rows
+  static constexpr int oD = oVo + 16 * D::MT;
+  static constexpr int oR = oD + 4 * wset;
+  static constexpr int oO = oR + 4 * wset;                        // [16 slots][4 waves][4 g]
+  static constexpr int total = oO + 16 * 16;
+  static_assert(total * 8 <= 80 * 1024, "two blocks per CU");
+  __device__ static constexpr int toff(int mt) { return mt * XW_TTILE; }
+};
+
+// operand read from a wave's tile set: tile mt, folded back into the live rows when it is the trimmed one
+template <int W> __device__ __forceinline__ double rec_readT(const double* set, int mt, int ks) {
+  const int l = xw_lane();
+  const int row = mt == VDim<W>::MT - 1 ? (l & 3) : (l & 15);
+  return set[RecLds<W>::toff(mt) + row * XW_TSTRIDE + 4 * ks + (l >> 4)];
+}
+
+template <int W, int Q, int NG>
+__global__ void __launch_bounds__(256, 2) k_disc_rec(const double* __restrict__ xT, const double* __restrict__ tf,
+                                                     const double* __restrict__ tpp, const double* __restrict__ ph,
+                                                     const double* __restrict__ vbar, int N, int L, int d,
+                                                     double* __restrict__ gslab, const double* __restrict__ act, int qrt) {
+  typedef VDim<W> D;
+  typedef RecLds<W> S;
+  __shared__ double lds[S::total];
+  double* sVhT = lds + S::oVhT;
+  double* sTT = lds + S::oTT;
+  double* sVo = lds + S::oVo;
+  double* sO = lds + S::oO;
+  const int lane = xw_lane(), g = lane >> 4, n = lane & 15;
+  const int wave = threadIdx.x >> 6;
+  double* myD = lds + S::oD + wave * S::wset;
+  double* myR = lds + S::oR + wave * S::wset;
+  const VOff o = v_offsets(d, W);
+  const long P = (long)N * L;
+  const long nsuper = (P + 63) / 64;
+  const int nq = Q > 0 ? Q : qrt;
+  constexpr int UNROLL = Q > 0 ? Q : 1;
+
+  for (int idx = wave; idx < D::MTF * D::KS; idx += 4) {
+    const int mt = idx / D::KS, ks = idx - mt * D::KS;
+    sVhT[idx * 64 + lane] = xw_fragAT(ph + o.Vh, W, W, W, 16 * mt, 4 * ks);
+  }
+  for (int idx = threadIdx.x; idx < 4 * D::KS * D::TR; idx += blockDim.x) {
+    const int r = idx % D::TR, k = idx / D::TR;                          // reverse chain: nd[48 + r] = sum_k Vh[k][48 + r] dl[k]
+    sTT[idx] = k < W ? ph[o.Vh + (long)k * W + 16 * (D::MT - 1) + r] : 0.0;
+  }
+  if (threadIdx.x < 16 * D::MT) sVo[threadIdx.x] = (int)threadIdx.x < W ? ph[o.Vo + threadIdx.x] : 0.0;
+  sO[threadIdx.x] = 0.0;
+  __syncthreads();
+
+  d4 accH[D::MT];
+#pragma unroll
+  for (int ct = 0; ct < D::MT; ++ct) accH[ct] = xw_zero4();
+  double* slab = gslab + (long)blockIdx.x * o.total;
+
+  for (long st = blockIdx.x; st < nsuper; st += gridDim.x) {
+    const Pt pt = locate(st * 4 + wave, P, N, tf, tpp);
+    const long Pp = (P + 15) & ~15L;
+    const int aoff = g * (int)Pp + pt.p;
+    auto load_layer = [&](int j, d4 (&r)[D::MT]) {
+      const double* base = act + (long)j * W * Pp;
+      asm volatile("" : "+s"(base));
+#pragma unroll
+      for (int mt = 0; mt < D::MT; ++mt)
+#pragma unroll
+        for (int q_ = 0; q_ < 4; ++q_)
+          if (q_ < D::LR(mt)) {
+            const int row = 16 * mt + 4 * q_ + g;
+            r[mt][q_] = (16 * mt + 4 * q_ + 3 < W || row < W) ? (base + (long)(16 * mt + 4 * q_) * Pp)[aoff] : 0.0;
+          }
+    };
+    d4 a[D::MT], rnext[D::MT];
+    load_layer(nq, a);                                 // tanh(a_q)
+    if (nq > 0) load_layer(nq - 1, rnext);
+    const double vb = pt.valid ? (vbar != nullptr ? vbar[pt.p] : 1.0) : 0.0;
+    // ---- output layer: cotangent of a_q, and dVo / dVo.b reduced over the 16 points of the tile
+    d4 dl[D::MT];
+#pragma unroll
+    for (int mt = 0; mt < D::MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (r < D::LR(mt) && 16 * mt + 4 * r < W) {
+          const double th = a[mt][r];
+          dl[mt][r] = sVo[16 * mt + g + 4 * r] * (1.0 - th * th) * vb;
+          const double s_ = xw_sum_over_n(vb * th);
+          if (n == 0) sO[(mt * 4 + r) * 16 + wave * 4 + g] += s_;
+        } else {
+          dl[mt][r] = 0.0;
+        }
+      }
+    {
+      const double s_ = xw_sum_over_n(vb);
+      if (lane == 0) sO[15 * 16 + wave * 4] += s_;
+    }
+    // ---- reverse chain, one layer at a time; the next layer's inputs are in flight meanwhile
+#pragma unroll UNROLL
+    for (int sg = nq - 1; sg >= 0; --sg) {
+      // the layer's inputs are only needed transposed in LDS and, afterwards, as the ReLU mask: 13 sign bits, not 26 registers
+      unsigned int mask = 0;
+#pragma unroll
+      for (int mt = 0; mt < D::MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (r < D::LR(mt)) mask |= (rnext[mt][r] > 0.0 ? 1u : 0u) << (4 * mt + r);
+#pragma unroll
+      for (int mt = 0; mt < D::MT; ++mt) {
+        d4 rr = rnext[mt];
+        if (mt == (W >> 4)) {
+          if (g == ((W & 15) & 3)) rr[(W & 15) >> 2] = 1.0;            // ones row -> column W of dVh collects dVh.b
+        }
+        if (mt < D::MT - 1) {
+          xw_writeT(myD + S::toff(mt), dl[mt]);
+          xw_writeT(myR + S::toff(mt), rr);
+        } else {
+          xw_writeT_n<1>(myD + S::toff(mt), dl[mt]);
+          xw_writeT_n<1>(myR + S::toff(mt), rr);
+        }
+      }
+      if (sg > 0) load_layer(sg - 1, rnext);                           // in flight while this layer is reversed
+      // reverse chain: three row tiles on the matrix pipe, rows 16 (MT-1) + r on the vector ALU
+      d4 nd[D::MT];
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int mt = 0; mt < D::MT; ++mt) nd[mt] = xw_zero4();
+      double tv[D::TR];
+#pragma unroll
+      for (int r = 0; r < D::TR; ++r) tv[r] = 0.0;
+#pragma unroll
+      for (int ks = 0; ks < D::KS; ++ks) {
+        const double b = dl[ks >> 2][ks & 3];
+        if ((ks & 1) == 0) asm volatile("" ::: "memory");   // bound the LDS loads in flight (else they are all hoisted -> spills)
+#pragma unroll
+        for (int mt = 0; mt < D::MTF; ++mt) nd[mt] = XW_MFMA(sVhT[(mt * D::KS + ks) * 64 + lane], b, nd[mt]);
+#pragma unroll
+        for (int r = 0; r < D::TR; ++r) tv[r] = fma(sTT[(4 * ks + g) * D::TR + r], b, tv[r]);
+      }
+#pragma unroll
+      for (int r = 0; r < D::TR; ++r) {
+        const double s_ = xw_sum_over_g(tv[r]);
+        if (g == r) nd[D::MT - 1][0] = s_;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int pw = 0; pw < 4; ++pw) {
+        const double* setD = lds + S::oD + pw * S::wset;
+        const double* setR = lds + S::oR + pw * S::wset;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          if ((ks & 1) == 0) asm volatile("" ::: "memory");
+          const double av = rec_readT<W>(setD, wave, ks);
+#pragma unroll
+          for (int ct = 0; ct < D::MT; ++ct) accH[ct] = XW_MFMA(av, rec_readT<W>(setR, ct, ks), accH[ct]);
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int mt = 0; mt < D::MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dl[mt][r] = (r < D::LR(mt) && ((mask >> (4 * mt + r)) & 1u)) ? nd[mt][r] : 0.0;
+    }
+    // ---- dl = cotangent of a_0.  Input layer: dVin = dl (x) [t; x; 1], 48 input rows at a time
+#pragma unroll
+    for (int mt = 0; mt < D::MT; ++mt) {
+      if (mt < D::MT - 1) xw_writeT(myD + S::toff(mt), dl[mt]);
+      else xw_writeT_n<1>(myD + S::toff(mt), dl[mt]);
+    }
+    const double* xl = xT;                    // laundered: the per-lane row addresses of x and of the slab are formed here,
+    double* sl = slab;                        // not hoisted out of the tile loop into (spilled) registers
+    int gl = g, nl = n;                       // (and copies of the lane coordinates the compiler cannot see through)
+    asm volatile("" : "+s"(xl), "+s"(sl), "+v"(gl), "+v"(nl));
+#pragma unroll
+    for (int grp = 0; grp < NG; ++grp) {
+#pragma unroll
+      for (int rr = 0; rr < 12; ++rr) {
+        const int cl = gl + 4 * rr;           // local row 0..47 of this group
+        const int c = 48 * grp + cl;          // input row: 0 = t, 1..d = x, d+1 = ones
+        double val = 0.0;
+        if (pt.valid) {
+          if (c == 0) val = pt.t;
+          else if (c <= d) val = xl[(long)(c - 1) * N + pt.n];
+          else if (c == d + 1) val = 1.0;
+        }
+        myR[S::toff(cl >> 4) + (cl & 15) * XW_TSTRIDE + nl] = val;
+      }
+      __syncthreads();
+      d4 accIn[3];
+#pragma unroll
+      for (int ct = 0; ct < 3; ++ct) accIn[ct] = xw_zero4();
+#pragma unroll
+      for (int pw = 0; pw < 4; ++pw) {
+        const double* setD = lds + S::oD + pw * S::wset;
+        const double* setR = lds + S::oR + pw * S::wset;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const double av = rec_readT<W>(setD, wave, ks);
+#pragma unroll
+          for (int ct = 0; ct < 3; ++ct) accIn[ct] = XW_MFMA(av, rec_readT<W>(setR, ct, ks), accIn[ct]);
+        }
+      }
+      __syncthreads();
+      // dVin is touched once per 64 points: it is accumulated in the block's slab (L2), not in 24 registers per group that
+      // would be live through every layer above.  Wave `wave` owns rows [16 wave, 16 wave + 16).
+      const bool first = st == (long)blockIdx.x;
+#pragma unroll
+      for (int ct = 0; ct < 3; ++ct) {
+        const int c = 48 * grp + 16 * ct + nl;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * wave + gl + 4 * r;
+          if (row < W && c <= d + 1) {
+            double* dst = c <= d ? sl + o.Vin + row * o.ldin + c : sl + o.Vinb + row;
+            *dst = first ? accIn[ct][r] : *dst + accIn[ct][r];
+          }
+        }
+      }
+    }
+  }
+
+  // wave `wave` owns rows [16 wave, 16 wave + 16) of dVh
+#pragma unroll
+  for (int ct = 0; ct < D::MT; ++ct) {
+    const int c = 16 * ct + n;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * wave + g + 4 * r;
+      if (row < W) {
+        if (c < W) slab[o.Vh + row * W + c] = accH[ct][r];
+        else if (c == W) slab[o.Vhb + row] = accH[ct][r];
+      }
+    }
+  }
+  __syncthreads();
+  const int tid = threadIdx.x;
+  if (tid <= W) {
+    double s_ = 0.0;
+    if (tid < W) {
+      const int mt = tid >> 4, gg = tid & 3, r = (tid & 15) >> 2;
+      for (int wv = 0; wv < 4; ++wv) s_ += sO[(mt * 4 + r) * 16 + wv * 4 + gg];
+      slab[o.Vo + tid] = s_;
+    } else {
+      for (int wv = 0; wv < 4; ++wv) s_ += sO[15 * 16 + wv * 4];
+      slab[o.Vob] = s_;
+    }
+  }
+}
+
 int bwd_blocks(long P) {
   long nsuper = (P + 63) / 64;
-  return (int)(nsuper < 256 ? nsuper : 256);
+  return (int)(nsuper < 512 ? nsuper : 512);     // two resident blocks per CU (k_disc_rec); k_disc_bwd grid-strides
 }
 
 }  // namespace
@@ -618,13 +852,13 @@ extern "C" int xw_disc_fwd(const double* xT, const double* t, const double* tpp,
 
 extern "C" int xw_disc_bwd_slabs(int N, int L) { return bwd_blocks((long)N * L); }
 
-#define XW_DISC_BWD(Q, PARAMS, INGRAD, SAVED)                                                                            \
+#define XW_DISC_BWD(PARAMS, INGRAD)                                                                                      \
   if (d + 2 <= 64)                                                                                                       \
-    hipLaunchKernelGGL((k_disc_bwd<50, Q, 1, PARAMS, INGRAD, SAVED>), dim3(blocks), dim3(256), 0, s, xT, t, tpp, phi, vbar, \
-                       N, L, d, gslab, gxv, gtv, act, q);                                                                \
+    hipLaunchKernelGGL((k_disc_bwd<50, 9, 1, PARAMS, INGRAD>), dim3(blocks), dim3(256), 0, s, xT, t, tpp, phi, vbar,     \
+                       N, L, d, gslab, gxv, gtv);                                                                        \
   else                                                                                                                   \
-    hipLaunchKernelGGL((k_disc_bwd<50, Q, 2, PARAMS, INGRAD, SAVED>), dim3(blocks), dim3(256), 0, s, xT, t, tpp, phi, vbar, \
-                       N, L, d, gslab, gxv, gtv, act, q);
+    hipLaunchKernelGGL((k_disc_bwd<50, 9, 2, PARAMS, INGRAD>), dim3(blocks), dim3(256), 0, s, xT, t, tpp, phi, vbar,     \
+                       N, L, d, gslab, gxv, gtv);
 
 extern "C" int xw_disc_bwd(const double* xT, const double* t, const double* tpp, const double* phi, const double* vbar,
                            int N, int L, int d, int W, int q, const double* act, double* gslab, void* stream) {
@@ -638,12 +872,18 @@ extern "C" int xw_disc_bwd(const double* xT, const double* t, const double* tpp,
   const int blocks = bwd_blocks((long)N * L);
   double* gxv = nullptr;
   double* gtv = nullptr;
-  if (act != nullptr && q == 9) {
-    XW_DISC_BWD(9, true, false, true)
-  } else if (act != nullptr) {
-    XW_DISC_BWD(0, true, false, true)
+  if (act != nullptr) {
+    const int ng = d + 2 <= 48 ? 1 : d + 2 <= 96 ? 2 : 3;
+#define XW_DISC_REC(Q, NG)                                                                                              \
+    hipLaunchKernelGGL((k_disc_rec<50, Q, NG>), dim3(blocks), dim3(256), 0, s, xT, t, tpp, phi, vbar, N, L, d, gslab, act, q);
+    if (q == 9) {
+      if (ng == 1) { XW_DISC_REC(9, 1) } else if (ng == 2) { XW_DISC_REC(9, 2) } else { XW_DISC_REC(9, 3) }
+    } else {
+      if (ng == 1) { XW_DISC_REC(0, 1) } else if (ng == 2) { XW_DISC_REC(0, 2) } else { XW_DISC_REC(0, 3) }
+    }
+#undef XW_DISC_REC
   } else {
-    XW_DISC_BWD(9, true, false, false)
+    XW_DISC_BWD(true, false)
   }
   return xw_launch_status();
 }
@@ -657,7 +897,6 @@ extern "C" int xw_disc_gradx(const double* xT, const double* t, const double* tp
   const int L = 1;
   const int blocks = bwd_blocks((long)N);
   double* gslab = nullptr;
-  const double* act = nullptr;
-  XW_DISC_BWD(9, false, true, false)
+  XW_DISC_BWD(false, true)
   return xw_launch_status();
 }
