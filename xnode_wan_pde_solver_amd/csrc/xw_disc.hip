@@ -610,6 +610,8 @@ __global__ void __launch_bounds__(256, 2) k_disc_rec(const double* __restrict__ 
   const long nsuper = (P + 63) / 64;
   const int nq = Q > 0 ? Q : qrt;
   constexpr int UNROLL = Q > 0 ? Q : 1;
+  static_assert(D::MT == 4, "2 x 2 waves x 2 x 2 tiles of dVh");
+  const int wi = wave >> 1, wj = wave & 1;
 
   for (int idx = wave; idx < D::MTF * D::KS; idx += 4) {
     const int mt = idx / D::KS, ks = idx - mt * D::KS;
@@ -722,9 +724,13 @@ __global__ void __launch_bounds__(256, 2) k_disc_rec(const double* __restrict__ 
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
           if ((ks & 1) == 0) asm volatile("" ::: "memory");
-          const double av = rec_readT<W>(setD, wave, ks);
-#pragma unroll
-          for (int ct = 0; ct < D::MT; ++ct) accH[ct] = XW_MFMA(av, rec_readT<W>(setR, ct, ks), accH[ct]);
+          // 2 x 2 tiles of dVh per wave: four operand reads feed four MFMAs (a 1 x 4 strip needs five)
+          const double a0 = rec_readT<W>(setD, 2 * wi, ks), a1 = rec_readT<W>(setD, 2 * wi + 1, ks);
+          const double b0 = rec_readT<W>(setR, 2 * wj, ks), b1 = rec_readT<W>(setR, 2 * wj + 1, ks);
+          accH[0] = XW_MFMA(a0, b0, accH[0]);
+          accH[1] = XW_MFMA(a0, b1, accH[1]);
+          accH[2] = XW_MFMA(a1, b0, accH[2]);
+          accH[3] = XW_MFMA(a1, b1, accH[3]);
         }
       }
       __syncthreads();
@@ -791,16 +797,16 @@ __global__ void __launch_bounds__(256, 2) k_disc_rec(const double* __restrict__ 
     }
   }
 
-  // wave `wave` owns rows [16 wave, 16 wave + 16) of dVh
+  // wave (wi, wj) owns row tiles 2 wi, 2 wi + 1 x column tiles 2 wj, 2 wj + 1 of dVh
 #pragma unroll
-  for (int ct = 0; ct < D::MT; ++ct) {
-    const int c = 16 * ct + n;
+  for (int t4 = 0; t4 < 4; ++t4) {
+    const int c = 16 * (2 * wj + (t4 & 1)) + n;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int row = 16 * wave + g + 4 * r;
+      const int row = 16 * (2 * wi + (t4 >> 1)) + g + 4 * r;
       if (row < W) {
-        if (c < W) slab[o.Vh + row * W + c] = accH[ct][r];
-        else if (c == W) slab[o.Vhb + row] = accH[ct][r];
+        if (c < W) slab[o.Vh + row * W + c] = accH[t4][r];
+        else if (c == W) slab[o.Vhb + row] = accH[t4][r];
       }
     }
   }
