@@ -3,7 +3,7 @@ import csv, re, sys
 rows = [r for r in csv.DictReader(open(sys.argv[1])) if re.search(r'\bk_\w+', r['Kernel_Name'])]
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 back = int(sys.argv[2]) if len(sys.argv) > 2 else 8
-idx = [i for i, r in enumerate(rows) if 'k_disc_bwd' in r['Kernel_Name']]
+idx = [i for i, r in enumerate(rows) if 'k_disc_bwd' in r['Kernel_Name'] or 'k_disc_rec' in r['Kernel_Name']]
 i0 = idx[-back - 1]
 i1 = idx[-back]
 t0 = int(rows[i0]['End_Timestamp'])
