@@ -8,8 +8,11 @@
 // (4 row tiles x 13 k-steps of v_mfma_f64_16x16x4_f64 per layer per 16 points, 75 % useful after padding 50 -> 64/52).
 //
 //   k_disc_fwd : value and d/dt (forward-mode tangent: the weak form needs d(phi)/dt at every sample point but
-//                nabla_x phi only at the initial time).  Vh lives in registers as 52 A-fragments;
-//                activations never leave the chain layout.  No HBM traffic besides x, t in and v, dv/dt out.
+//                nabla_x phi only at the initial time).  Vh rows 0..47 as 39 A-fragments in LDS
+//                (shared by the 4 waves of a block, two waves per SIMD), rows 48, 49 on the vector ALU; activations never
+//                leave the chain layout.  HBM traffic: x, t in, v, dv/dt out -- plus, on request, the record of layer
+//                inputs (500 doubles per point) that k_disc_rec reads instead of recomputing the forward.
+//   k_disc_rec : parameter gradient from that record: reverse chain + MFMA outer products, 78 KB of LDS, two blocks/CU.
 //   k_disc_bwd : recomputes the forward for a tile of 16 points per wave (activations stay in registers), runs the
 //                reverse chain with Vh^T fragments from LDS, and accumulates  dVh += delta_{j+1} (x) relu(a_j)  as MFMA
 //                outer products over the points (LDS transpose; 4 waves of a block own one 16-row band of dVh each).
@@ -556,8 +559,8 @@ __global__ void __launch_bounds__(256) k_disc_bwd(const double* __restrict__ xT,
 
 // ------------------------------------------------------------------------------------------------------------------
 // k_disc_rec: the parameter gradient from the activation record, two blocks per CU.
-// k_disc_bwd<SAVED> above keeps the LDS plan of the recomputing kernel (157 KB: one block per CU, one wave per SIMD, and
-// every barrier / transpose stall of that wave is idle matrix-pipe time).  This kernel only ever runs from the record, so
+// k_disc_bwd above needs 157 KB of LDS (one block per CU, one wave per SIMD: every barrier / transpose stall of that
+// wave is idle matrix-pipe time).  This kernel only ever runs from the record, so
 //   * the forward fragments of Vh are gone, and of Vh^T only the three full row tiles stay in LDS: rows 48, 49 of the
 //     reverse chain (W = 50) are contracted on the vector ALU from a 104-double table, as in k_disc_fwd -- 39 instead of
 //     52 chain MFMAs per layer;
