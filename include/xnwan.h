@@ -69,7 +69,14 @@ int xw_ode_bwd_slabs(int N);
  * mode bit 2 (only with bits 0 and 1): the caller guarantees ubar == 1 at every time index >= 1; gx, gs are then
  *   returned for the ALL-ONES cotangent (the helper backward of src/loss.py:55) while the parameter gradients use ubar
  *   itself -- the pollution sweep and the nabla_x u sweep of a generator sub-step are the same adjoint, run once.
- *   In the multi-group form jobs with gx == gs == NULL simply produce no x outputs. */
+ *   In the multi-group form jobs with gx == gs == NULL simply produce no x outputs.
+ * mode bit 3 (not with bit 2): adjoint = True of the reference (src/model.py:103, torchdiffeq.odeint_adjoint, 0.1.1):
+ *   the continuous adjoint instead of the reverse of the steps taken.  For i = L-1 .. 1 the augmented state
+ *   (y, a, theta-bar) is restarted from the checkpoint y(t_i) and advanced by ONE step of `method` from t_i to t_{i-1}
+ *   under  d/dt (y, a, theta-bar) = (f, -a^T df/dy, -a^T df/dtheta);  then a += flw * ubar[i-1].  The sample point x is
+ *   not an input of that adjoint: gx is returned as zero, gs (through the lift) and the parameter gradients as usual.
+ *   Differs from the discrete sweep by O(dt^p); the activation store is not used.  torchdiffeq is absent from the
+ *   reference tree: restated from its published algorithm, parity unpinned. */
 int xw_ode_bwd(const double* xT, const double* t, const double* start, const double* theta, const double* Y,
                const double* ubar, int method, int N, int L, int d, int H, int K, int m, int mode,
                double* gx, double* gs, double* gslab, void* stream);

@@ -26,7 +26,8 @@ torchdiffeq==0.1.1 (requirements.txt:7), which is neither vendored under the ref
 nor installed/installable here; `odeint_fixed` below restates the published fixed-grid
 schemes of that package (grid == requested times, times cast to the state dtype, explicit
 euler / explicit midpoint / 3/8-rule rk4) and the golden vectors were generated with a
-stand-in that uses the same definition.
+stand-in that uses the same definition.  The same holds, without any fixture, for
+config['adjoint'] = True: `_OdeintAdjoint` restates that package's odeint_adjoint.
 
 Semantics are the ones the reference has ON A GPU: helper
 backward passes pollute the parameter gradients (Q1); nabla u and nabla phi enter I as
@@ -213,6 +214,72 @@ def odeint_fixed(f, y0, t, method):
     return torch.stack(ys, 1)  # [N, L, H]
 
 
+def _rk_step_tuple(f, t0, dt, ys, method):
+    """one fixed-grid step of `method` for a state that is a list of tensors (the same tableaux as odeint_fixed)"""
+    def axpy(base, terms):
+        return [b_ + sum(c * k[i] for c, k in terms) for i, b_ in enumerate(base)]
+    if method == 'euler':
+        return axpy(ys, [(dt, f(t0, ys))])
+    if method == 'midpoint':
+        k1 = f(t0, ys)
+        return axpy(ys, [(dt, f(t0 + dt / 2, axpy(ys, [(dt / 2, k1)])))])
+    if method == 'rk4':
+        k1 = f(t0, ys)
+        k2 = f(t0 + dt / 3, axpy(ys, [(dt / 3, k1)]))
+        k3 = f(t0 + 2 * dt / 3, axpy(ys, [(-dt / 3, k1), (dt, k2)]))
+        k4 = f(t0 + dt, axpy(ys, [(dt, k1), (-dt, k2), (dt, k3)]))
+        return axpy(ys, [(dt / 8, k1), (3 * dt / 8, k2), (3 * dt / 8, k3), (dt / 8, k4)])
+    raise ValueError('unsupported fixed-grid solver: %r' % (method,))
+
+
+class _OdeintAdjoint(torch.autograd.Function):
+    """torchdiffeq.odeint_adjoint for a fixed-grid method, restated from the published torchdiffeq 0.1.1
+    (OdeintAdjointMethod; the package is absent from the reference tree -- PARITY UNPINNED, like odeint_fixed):
+    the forward pass keeps no graph; the backward pass integrates, for i = L-1 .. 1, the augmented system
+        d/dt (y, a, p) = ( f(t, y), -a^T df/dy, -a^T df/dparams )
+    from t_i to t_{i-1} with the same method on the two-point grid [t_i, t_{i-1}] (one step), every interval restarted
+    from the forward solution y(t_i), and adds the incoming cotangent of y(t_{i-1}) to `a` after it.
+    `make_f(params)` builds the field from the module's parameters: whatever else the field closes over (the sample
+    point x of src/model.py:99,146-156) receives no gradient -- it is not among odeint_adjoint's inputs."""
+
+    @staticmethod
+    def forward(ctx, y0, t, method, make_f, *params):
+        with torch.no_grad():
+            ans = odeint_fixed(make_f(params), y0, t, method)
+        ctx.method, ctx.make_f = method, make_f
+        ctx.save_for_backward(t, ans, *params)
+        return ans
+
+    @staticmethod
+    def backward(ctx, grad_ans):
+        t, ans, *params = ctx.saved_tensors
+        t = t.to(ans.dtype)
+        make_f, method = ctx.make_f, ctx.method
+
+        def aug(tt, state):
+            y, a = state[0], state[1]
+            with torch.enable_grad():
+                y_ = y.detach().requires_grad_(True)
+                p_ = [p.detach().requires_grad_(True) for p in params]
+                fe = make_f(p_)(tt, y_)
+                vj = torch.autograd.grad(fe, [y_] + p_, -a, allow_unused=True)
+            vj = [torch.zeros_like(x) if g is None else g for g, x in zip(vj, [y_] + p_)]
+            return [fe.detach()] + vj
+
+        L = ans.shape[1]
+        adj_y = grad_ans[:, L - 1].clone()
+        adj_p = [torch.zeros_like(p) for p in params]
+        with torch.no_grad():
+            for i in range(L - 1, 0, -1):
+                state = _rk_step_tuple(aug, t[i], t[i - 1] - t[i], [ans[:, i], adj_y] + adj_p, method)
+                adj_y = state[1] + grad_ans[:, i - 1]
+                adj_p = state[2:]
+        return (adj_y, None, None, None) + tuple(adj_p)
+
+
+FIELD_KEYS = ('Win', 'Win_b', 'Wh', 'Wh_b', 'Wo', 'Wo_b')
+
+
 def u_net(theta, config, X, start_value):
     """NeuralODE.forward for a group that starts at T0 or on the boundary (src/model.py:92-110).
     X [N,L,d+1] float32 (may require grad); start_value [N] = h(X[:,0,:]) or g(X[:,0,:]); returns [N,L] float64."""
@@ -224,7 +291,15 @@ def u_net(theta, config, X, start_value):
         return (y0 @ theta['FL_w'].T + theta['FL_b'])                          # :89-91 (single-slice group)
     x64 = X[:, 0, 1:].to(F64)                                                  # :99 (x from slice 0 only)
     times = X[0, :, 0]                                                         # :92 (path 0's time column)
-    ys = odeint_fixed(lambda t, y: field(theta, m, x64, t, y), y0, times, config['solver'])
+    if config.get('adjoint'):                                                  # :103 odeint_adjoint
+        xc = x64.detach()
+
+        def make_f(params):
+            th = dict(zip(FIELD_KEYS, params))
+            return lambda t, y: field(th, m, xc, t, y)
+        ys = _OdeintAdjoint.apply(y0, times, config['solver'], make_f, *[theta[k] for k in FIELD_KEYS])
+    else:
+        ys = odeint_fixed(lambda t, y: field(theta, m, x64, t, y), y0, times, config['solver'])
     return (ys @ theta['FL_w'].T + theta['FL_b']).squeeze(2)                   # :110
 
 

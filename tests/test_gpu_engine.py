@@ -157,14 +157,41 @@ def test_module_autograd_path_reproduces_reference_gradients(golden_dir):
     assert S.v_net(torch.rand(7, 3, S.setup['dim'] + 1)).shape == (7, 3, 1)
 
 
-@pytest.mark.parametrize('m,q', [(8, 9), (3, 4)])
-def test_engine_against_oracle_general_coefficients(m, q):
+def test_module_autograd_path_with_adjoint_true():
+    """u_net(X).backward() with config['adjoint'] = True: the module's autograd bridge asks the sweep for the continuous
+    adjoint; x only receives the gradient that flows through the start value h(x)"""
+    from oracle import refspec as R
+    d = 3
+    params = {'alpha': 1e3, 'u_layers': 8, 'u_hidden_dim': 20, 'u_hidden_hidden_dim': 10, 'v_layers': 9, 'v_hidden_dim': 50,
+              'n1': 2, 'n2': 1, 'u_rate': 0.015, 'v_rate': 0.04, 'min_steps': 5, 'adjoint': True, 'solver': 'midpoint',
+              'dim': d, 'N_t': 6, 'N_r': 21, 'N_b': 12, 'T0': 0, 'T': 1, 'shape_param': [-1, 1], 'iterations': 1,
+              'domain': 'Hypercube'}
+    S = make_solver(params, 3)
+    assert S.u_net.module.adjoint and S.engine.adjoint
+    domain, pts = first_sample(S)
+    X = pts.interioru.detach().clone().requires_grad_(True)
+    g = torch.Generator().manual_seed(4)
+    wgt = torch.randn(X.shape[0], X.shape[1], dtype=torch.float64, generator=g)
+    (S.u_net(X).squeeze(2).cpu() * wgt).sum().backward()
+    names = R.u_names(8)
+    theta = {k_: dict(S.u_net.named_parameters())[n_].detach().cpu().clone().requires_grad_(True) for n_, k_ in names}
+    Xo = pts.interioru.detach().clone().requires_grad_(True)
+    (R.u_net(theta, params, Xo, P.func_h(Xo[:, 0, :])) * wgt).sum().backward()
+    gmax = max(float(theta[k_].grad.abs().max()) for _, k_ in names)
+    for n_, k_ in names:
+        close(dict(S.u_net.named_parameters())[n_].grad, theta[k_].grad, 1e-6, 1e-8 * gmax, 'adjoint-mode grad ' + k_)
+    close(X.grad[:, 0, 1:], Xo.grad[:, 0, 1:], 1e-5, 1e-7, 'nabla_x u (through the start value only)')
+
+
+@pytest.mark.parametrize('m,q,adjoint', [(8, 9, False), (3, 4, False), (8, 9, True)])
+def test_engine_against_oracle_general_coefficients(m, q, adjoint):
     """non-identity a, non-zero b, non-linear c(u): the structured fast paths are off, everything goes the general way.
-    Second case: network depths other than the YAML's (the test network then always runs from its activation record)"""
+    Second case: network depths other than the YAML's (the test network then always runs from its activation record).
+    Third case: adjoint=True, the sweeps integrate torchdiffeq's continuous adjoint (oracle restatement, parity unpinned)"""
     from oracle import refspec as R
     d = 4
     params = {'alpha': 1e3, 'u_layers': m, 'u_hidden_dim': 20, 'u_hidden_hidden_dim': 10, 'v_layers': q, 'v_hidden_dim': 50,
-              'n1': 2, 'n2': 1, 'u_rate': 0.015, 'v_rate': 0.04, 'min_steps': 5, 'adjoint': False, 'solver': 'midpoint',
+              'n1': 2, 'n2': 1, 'u_rate': 0.015, 'v_rate': 0.04, 'min_steps': 5, 'adjoint': adjoint, 'solver': 'midpoint',
               'dim': d, 'N_t': 9, 'N_r': 83, 'N_b': 45, 'T0': 0, 'T': 1, 'shape_param': [-1, 1], 'iterations': 1,
               'domain': 'Hypercube'}
 

@@ -129,6 +129,49 @@ def test_ode_backward(N, L, d, solver, ones):
 
 
 @pytest.mark.parametrize('solver', ['euler', 'midpoint', 'rk4'])
+@pytest.mark.parametrize('N,L,d', [(37, 7, 5), (16, 2, 3)])
+def test_ode_backward_continuous_adjoint(N, L, d, solver):
+    """config['adjoint'] = True (src/model.py:103): xw_ode_bwd mode bit 3 against the oracle's restatement of
+    torchdiffeq.odeint_adjoint -- restart from the forward solution at every grid point, one step of the same method on
+    the augmented system, no gradient to x through the field.  (Parity unpinned: torchdiffeq is not in the reference tree.)"""
+    from oracle import refspec as R
+    from xnode_wan_pde_solver_amd import kernels as KN
+    theta, _ = _params(d, 8, 81)
+    th = {k: v.clone().requires_grad_(True) for k, v in theta.items()}
+    x, t, X = _sample(N, L, d, 82)
+    g = torch.Generator().manual_seed(83)
+    start = torch.randn(N, dtype=F64, generator=g).requires_grad_(True)
+    ubar = torch.randn(N, L, dtype=F64, generator=g)
+    x64 = x.double().requires_grad_(True)
+    Xd = torch.cat((t.double().view(1, L, 1).expand(N, L, 1), x64.view(N, 1, d).expand(N, L, d)), 2)
+    cfg = dict(_cfg(8, solver), adjoint=True)
+    u_ref = R.u_net(th, cfg, Xd, start)
+    grads = torch.autograd.grad((u_ref * ubar).sum(), [x64, start] + [th[k] for k in U_ORDER], allow_unused=True)
+    assert grads[0] is None or float(grads[0].abs().max()) == 0.0        # x is not an input of odeint_adjoint
+    # the discrete gradient is a different number (O(dt^p) away): the two modes must not be confused
+    g_disc = torch.autograd.grad((R.u_net(th, _cfg(8, solver), Xd, start) * ubar).sum(), [th['Wh']])[0]
+    assert float((g_disc - grads[2 + U_ORDER.index('Wh')]).abs().max()) > 1e-6 * float(g_disc.abs().max())
+    xT, tc, sc, blob = x.double().t().contiguous().cuda(), t.double().cuda(), start.detach().cuda(), _blob(theta, U_ORDER)
+    mid = KN.method_id(solver)
+    u, Y = KN.ode_fwd(xT, tc, sc, blob, mid, H, K, 8)
+    _close(u.t(), u_ref, 1e-12, 'u')
+    ub = ubar.t().contiguous().cuda()
+    gx, gs, _ = KN.ode_bwd(xT, tc, sc, blob, Y, ub, mid, H, K, 8, want_x=True, want_params=False, adjoint=True)
+    assert float(gx.abs().max()) == 0.0
+    _close(gs, grads[1], 1e-10, 'gs (x-only sweep)')
+    gx2, gs2, slab = KN.ode_bwd(xT, tc, sc, blob, Y, ub, mid, H, K, 8, want_x=True, want_params=True, adjoint=True)
+    assert float(gx2.abs().max()) == 0.0
+    _close(gs2, grads[1], 1e-10, 'gs (param sweep)')
+    gth = KN.slab_sum(slab).cpu()
+    ref = torch.cat([g_.reshape(-1) for g_ in grads[2:]])
+    off = 0
+    for k, g_ in zip(U_ORDER, grads[2:]):
+        n = g_.numel()
+        _close(gth[off:off + n], g_.reshape(-1), 1e-10 * max(1.0, float(ref.abs().max()) / max(float(g_.abs().max()), 1e-300)), 'grad ' + k)
+        off += n
+
+
+@pytest.mark.parametrize('solver', ['euler', 'midpoint', 'rk4'])
 def test_ode_backward_pollution_and_x_sweep_in_one(solver):
     """mode 7: cotangent = ones + (initial-value term at time index 0).  One sweep must return the parameter gradient of
     that cotangent AND the x / start gradients of the all-ones cotangent (the helper backward of src/loss.py:55),

@@ -612,10 +612,18 @@ __device__ __forceinline__ void load_stage(const double* __restrict__ Y, const d
 }
 
 // SAVED: the stage activations come from the forward pass's store (euler, midpoint); otherwise they are recomputed
-template <int H, int K, int M, int METHOD, bool PARAMS, bool SAVED>
+// ADJ: the reference's adjoint=True (src/model.py:103: torchdiffeq.odeint_adjoint) -- not the reverse of the steps that
+//   were taken but the continuous adjoint, integrated with the same fixed-grid method.  torchdiffeq 0.1.1 (absent here,
+//   restated from its published OdeintAdjointMethod.backward): for i = L-1 .. 1 the augmented state (y, a, theta-bar) starts
+//   from the FORWARD solution y(t_i) and takes ONE step of `method` from t_i to t_{i-1} (h < 0) under
+//       d/dt (y, a, theta-bar) = ( f(t, y), -a^T df/dy, -a^T df/dtheta ),
+//   then a += the cotangent of y(t_{i-1}).  Its parameter set is the field module's parameters; the sample point x is a
+//   plain attribute of that module, so no gradient reaches x through the field (only through the start value).
+template <int H, int K, int M, int METHOD, bool PARAMS, bool SAVED, bool ADJ = false>
 __global__ void __launch_bounds__(64) k_ode_bwd(const BwdJobs jobs, const double* __restrict__ tf,
                                                 const double* __restrict__ th, int L, int d) {
   static_assert(!SAVED || RK<METHOD>::S <= 2, "the activation store is used by euler and midpoint");
+  static_assert(!(SAVED && ADJ), "the continuous adjoint evaluates the field at its own stage points");
   typedef Dim<H, K> D;
   typedef RK<METHOD> T;
   __builtin_amdgcn_s_setprio(XW_ODE_PRIO);
@@ -709,7 +717,64 @@ __global__ void __launch_bounds__(64) k_ode_bwd(const BwdJobs jobs, const double
     readout(l, y_l, ub);
   };
 
-  if constexpr (SAVED) {
+  if constexpr (ADJ) {
+    load_field<H, K>(th, o, d, w);
+    const d4 xp = project_x<H, K>(th, o, xT, N, d, ncl);
+    {
+      d4 yl[D::HT];
+      load_ckpt<H, K>(Y, L - 1, N, ncl, yl);
+      readout(L - 1, yl, load_ub(L - 1));
+    }
+    for (int l = L - 2; l >= 0; --l) {
+      const double ub = load_ub(l);
+      const double t1 = tf[l + 1], dt = t1 - tf[l];             // the step goes from t1 back to t1 - dt
+      d4 y1[D::HT];
+      load_ckpt<H, K>(Y, l + 1, N, ncl, y1);
+      d4 ky[T::S][D::HT], ps[T::S][D::HT], asum[D::HT];          // stage derivatives of y; a_s^T df/dy; update of the adjoint
+#pragma unroll
+      for (int ht = 0; ht < D::HT; ++ht) asum[ht] = xw_zero4();
+#pragma unroll
+      for (int i = 0; i < T::S; ++i) {
+        d4 ys[D::HT], as[D::HT];
+#pragma unroll
+        for (int ht = 0; ht < D::HT; ++ht) {
+          ys[ht] = y1[ht];
+          as[ht] = lam[ht];
+#pragma unroll
+          for (int j = 0; j < i; ++j)
+            if (T::a(i, j) != 0.0) {
+              ys[ht] -= (dt * T::a(i, j)) * ky[j][ht];           // h = -dt;  dy/dt = f
+              as[ht] += (dt * T::a(i, j)) * ps[j][ht];           //           da/dt = -a^T df/dy
+            }
+        }
+        const double ti = t1 - T::c(i) * dt;
+        Save<M> sv;
+        field_fwd<H, K, M, true>(w, ti, xp, ys, ky[i], SinkSave<M>{sv});
+        if (T::b(i) != 0.0) {
+          // this stage enters the update: the vector-Jacobian product is taken of (dt b_i) a_s, so that the weight-gradient
+          // outer products inside it accumulate  -h b_i a_s^T df/dtheta  directly
+          d4 cot[D::HT], psi[D::HT];
+#pragma unroll
+          for (int ht = 0; ht < D::HT; ++ht) cot[ht] = (dt * T::b(i)) * as[ht];
+          field_vjp<H, K, M, PARAMS>(w, wT, ti, sv, ys, cot, psi, xpb, G, lds);
+#pragma unroll
+          for (int ht = 0; ht < D::HT; ++ht) {
+            asum[ht] += psi[ht];
+            ps[i][ht] = (1.0 / (dt * T::b(i))) * psi[ht];
+          }
+        } else {
+          d4 xdummy = xw_zero4();
+          FieldG<H, K> Gd;                                       // (untouched: no parameter products in this call)
+          field_vjp<H, K, M, false>(w, wT, ti, sv, ys, as, ps[i], xdummy, Gd, lds);
+        }
+      }
+#pragma unroll
+      for (int ht = 0; ht < D::HT; ++ht) lam[ht] += asum[ht];
+      d4 yl[D::HT];
+      load_ckpt<H, K>(Y, l, N, ncl, yl);
+      readout(l, yl, ub);
+    }
+  } else if constexpr (SAVED) {
     {
       d4 yl[D::HT];
       load_ckpt<H, K>(Y, L - 1, N, ncl, yl);
@@ -833,8 +898,10 @@ __global__ void __launch_bounds__(64) k_ode_bwd(const BwdJobs jobs, const double
   if (gx != nullptr) {
     for (int rt = 0; rt < (d + 15) / 16; ++rt) {
       d4 v = xw_zero4();
+      if (!ADJ) {                // (odeint_adjoint: x is not among the inputs the adjoint differentiates with respect to)
 #pragma unroll
-      for (int ks = 0; ks < D::KSK; ++ks) v = XW_MFMA(xw_fragAT(th + o.Win, o.ldin, K, d, 16 * rt, 4 * ks), xpb[ks], v);
+        for (int ks = 0; ks < D::KSK; ++ks) v = XW_MFMA(xw_fragAT(th + o.Win, o.ldin, K, d, 16 * rt, 4 * ks), xpb[ks], v);
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int i = 16 * rt + g + 4 * r;
@@ -981,8 +1048,17 @@ int launch_fwd(int method, const FwdJobs& jobs, const double* t, const double* t
   return xw_launch_status();
 }
 template <int H, int K, int M, bool PARAMS>
-int launch_bwd(int method, const BwdJobs& jobs, const double* t, const double* theta, int L, int d, hipStream_t s) {
+int launch_bwd(int method, const BwdJobs& jobs, const double* t, const double* theta, int L, int d, bool adj, hipStream_t s) {
   const dim3 grid(jobs.tile0[jobs.n]), block(64);
+  if (adj) {
+    switch (method) {
+      case 0: hipLaunchKernelGGL((k_ode_bwd<H, K, M, 0, PARAMS, false, true>), grid, block, 0, s, jobs, t, theta, L, d); break;
+      case 1: hipLaunchKernelGGL((k_ode_bwd<H, K, M, 1, PARAMS, false, true>), grid, block, 0, s, jobs, t, theta, L, d); break;
+      case 2: hipLaunchKernelGGL((k_ode_bwd<H, K, M, 2, PARAMS, false, true>), grid, block, 0, s, jobs, t, theta, L, d); break;
+      default: return XW_E_ARG;
+    }
+    return xw_launch_status();
+  }
   bool act = true;                                     // all jobs or none (checked by the caller)
   for (int i = 0; i < jobs.n; ++i) act = act && jobs.act[i] != nullptr;
   switch (method * 2 + (act ? 1 : 0)) {
@@ -1057,7 +1133,7 @@ extern "C" int xw_ode_fwd(const double* xT, const double* t, const double* start
 
 extern "C" int xw_ode_bwd_multi(const XwOdeBwdJob* jobs, int njobs, const double* t, const double* theta, int method, int L,
                                 int d, int H, int K, int m, int mode, void* stream) {
-  if (!jobs || njobs < 1 || njobs > XW_MAXJOBS || !t || !theta || L <= 0 || d <= 0 || m < 1 || (mode & 3) == 0 || ((mode & 4) && (mode & 3) != 3)) return XW_E_ARG;
+  if (!jobs || njobs < 1 || njobs > XW_MAXJOBS || !t || !theta || L <= 0 || d <= 0 || m < 1 || (mode & 3) == 0 || ((mode & 4) && (mode & 3) != 3) || ((mode & 8) && (mode & 4))) return XW_E_ARG;
   BwdJobs J;
   J.n = njobs;
   J.x_ones = (mode & 4) ? 1 : 0;
@@ -1073,7 +1149,7 @@ extern "C" int xw_ode_bwd_multi(const XwOdeBwdJob* jobs, int njobs, const double
     J.xT[i] = on ? jobs[i].xT : nullptr;
     J.start[i] = on ? jobs[i].start : nullptr;
     J.Y[i] = on ? jobs[i].Y : nullptr;
-    J.act[i] = (on && method != 2) ? jobs[i].act : nullptr;
+    J.act[i] = (on && method != 2 && !(mode & 8)) ? jobs[i].act : nullptr;   // (rk4 and the continuous adjoint recompute)
     if (on && (J.act[i] != nullptr) != (J.act[0] != nullptr)) return XW_E_ARG;   // all groups of a launch, or none
     J.ubar[i] = on ? jobs[i].ubar : nullptr;
     J.gx[i] = (on && (mode & 1)) ? jobs[i].gx : nullptr;
@@ -1084,8 +1160,8 @@ extern "C" int xw_ode_bwd_multi(const XwOdeBwdJob* jobs, int njobs, const double
   }
   hipStream_t s = (hipStream_t)stream;
 #define CALL(HH, KK, MM)                                                             \
-  return (mode & 2) ? launch_bwd<HH, KK, MM, true>(method, J, t, theta, L, d, s)     \
-                    : launch_bwd<HH, KK, MM, false>(method, J, t, theta, L, d, s);
+  return (mode & 2) ? launch_bwd<HH, KK, MM, true>(method, J, t, theta, L, d, (mode & 8) != 0, s)     \
+                    : launch_bwd<HH, KK, MM, false>(method, J, t, theta, L, d, (mode & 8) != 0, s);
   XW_ODE_DISPATCH(CALL)
 #undef CALL
 }

@@ -86,6 +86,9 @@ class Engine:
         self.H, self.K, self.m = config['u_hidden_dim'], config['u_hidden_hidden_dim'], config['u_layers']
         self.W, self.q = config['v_hidden_dim'], config['v_layers']
         self.method = KN.method_id(config['solver'])
+        # config['adjoint'] (src/model.py:103): the sweeps integrate torchdiffeq's continuous adjoint instead of reversing
+        # the steps taken (include/xnwan.h, xw_ode_bwd mode bit 3); nabla_x u then only flows through the start value
+        self.adjoint = bool(config.get('adjoint', False))
         self.alpha = float(config['alpha'])
         self.pollution = 1.0
         sp = setup.get('shape_param', [-1, 1])
@@ -220,7 +223,7 @@ class Engine:
         G.ubarA, G.ubarB, G.vbar, G.s3x = e(L, N), e(L, N), e(L, N), e(N)
         G.c = G.cp = None
         # stage activations of every step, written by the forward, read back by the sweeps (183 MB at N = 4096, L = 32)
-        ar = KN.ode_act_rows(self.method, H, self.K, self.m) if self.keep_activations else 0
+        ar = KN.ode_act_rows(self.method, H, self.K, self.m) if self.keep_activations and not self.adjoint else 0
         G.act = e(max(L - 1, 1), ar, N) if ar else None
         G.act_b = e(max(Lb - 1, 1), ar, Nb) if (ar and Nb) else None
         # layer inputs of the test network at every point, stored by its forward in the discriminator sub-step and read
@@ -335,7 +338,7 @@ class Engine:
         th = self.theta.data
         M = (self.method, self.H, self.K, self.m)
         e0 = self._mark()
-        fused_x = self.pollution == 1.0
+        fused_x = self.pollution == 1.0 and not self.adjoint
         joint = G.Nb and G.same_grid           # boundary paths on the interior's time grid: one launch for both
         e_x = None
         if not getattr(G, 'skip_v', False):
@@ -352,22 +355,22 @@ class Engine:
             # backward u.backward(ones) are the same adjoint: one launch returns the parameter gradient of A and nabla_x u.
             if not fused_x:
                 with self._side(2, e_f):
-                    KN.ode_bwd_multi([self._job(G, 'i', want_x=True)], G.t, th, *M, want_x=True, want_params=False)
+                    KN.ode_bwd_multi([self._job(G, 'i', want_x=True)], G.t, th, *M, want_x=True, want_params=False, adjoint=self.adjoint)
                     e_x = self._mark()
             KN.gen_cotangents(G.u, None, G.w, G.h, G.Vol, G.Nglob, self.alpha, G.ubarA, None, c=G.c, cp=G.cp, ckappa=G.ck,
                               pollution=self.pollution)
             sweeps = [self._job(G, 'i', G.ubarA, G.slabA[:G.ns_u], want_x=fused_x)]
             if joint:
                 sweeps.append(self._job(G, 'b', G.ubar_b, G.slabA[G.ns_u:]))
-            KN.ode_bwd_multi(sweeps, G.t, th, *M, want_x=fused_x, want_params=True, x_cot_ones=fused_x)
+            KN.ode_bwd_multi(sweeps, G.t, th, *M, want_x=fused_x, want_params=True, x_cot_ones=fused_x, adjoint=self.adjoint)
             if G.Nb and not joint:
-                KN.ode_bwd_multi([self._job(G, 'b', G.ubar_b, G.slabA[G.ns_u:])], G.tb, th, *M, want_x=False, want_params=True)
+                KN.ode_bwd_multi([self._job(G, 'b', G.ubar_b, G.slabA[G.ns_u:])], G.tb, th, *M, want_x=False, want_params=True, adjoint=self.adjoint)
             e_A = self._mark()
         e_v = self._mark()
         self._join(e_f)
         KN.gen_cotangents(G.u, G.v, G.w, G.h, G.Vol, G.Nglob, self.alpha, None, G.ubarB, c=G.c, cp=G.cp, ckappa=G.ck,
                           pollution=self.pollution)
-        KN.ode_bwd_multi([self._job(G, 'i', G.ubarB, G.slabB)], G.t, th, *M, want_x=False, want_params=True)
+        KN.ode_bwd_multi([self._job(G, 'i', G.ubarB, G.slabB)], G.t, th, *M, want_x=False, want_params=True, adjoint=self.adjoint)
         # the reduction needs nabla_x u (sweep A) and v, not sweep B: it runs behind sweep A on the side stream, next to
         # the tail of sweep B, instead of after it
         with self._side(3, e_A, e_v, *([] if e_x is None else [e_x])):   # (re-entering side 1 here crashes hipStreamEndCapture)
@@ -450,7 +453,7 @@ class Engine:
         with self._side(1, e0):
             KN.ode_fwd_multi([self._job(G, 'i')], G.t, th, *M, zero16=self.scal)
             self._reaction(G)
-            KN.ode_bwd_multi([self._job(G, 'i', want_x=True)], G.t, th, *M, want_x=True, want_params=False)
+            KN.ode_bwd_multi([self._job(G, 'i', want_x=True)], G.t, th, *M, want_x=True, want_params=False, adjoint=self.adjoint)
             e_x = self._mark()
         self._join(e_x)
         self._contract(G, self.adam_v)

@@ -85,10 +85,12 @@ def ode_fwd_multi(jobs, t, theta, method, H, K, m, zero16=None):
     check(lib.xw_ode_fwd_multi(arr, len(jobs), _p(t), _p(theta), method, L, d, H, K, m, _p(zero16), _stream()), 'xw_ode_fwd_multi')
 
 
-def ode_bwd_multi(jobs, t, theta, method, H, K, m, want_x, want_params, x_cot_ones=False):
+def ode_bwd_multi(jobs, t, theta, method, H, K, m, want_x, want_params, x_cot_ones=False, adjoint=False):
     """jobs: list of dicts(xT, start, Y, ubar or None, gx, gs, gslab); ONE launch for all groups.
     x_cot_ones (with want_x and want_params): gx, gs for the all-ones cotangent, parameter gradients for ubar, which must
-    equal 1 at every time index >= 1; jobs without gx / gs produce no x outputs."""
+    equal 1 at every time index >= 1; jobs without gx / gs produce no x outputs.
+    adjoint: the continuous adjoint of torchdiffeq.odeint_adjoint (config['adjoint'] = True) instead of the reverse of
+    the steps taken; ignores the activation store."""
     _need_gpu()
     L = t.shape[0]
     d = jobs[0]['xT'].shape[0]
@@ -110,7 +112,9 @@ def ode_bwd_multi(jobs, t, theta, method, H, K, m, want_x, want_params, x_cot_on
         a.gx, a.gs, a.gslab = _p(j.get('gx')), _p(j.get('gs')), _p(j.get('gslab'))
     if x_cot_ones and not (want_x and want_params):
         raise XnwanError('x_cot_ones needs want_x and want_params')
-    mode = (1 if want_x else 0) | (2 if want_params else 0) | (4 if x_cot_ones else 0)
+    if x_cot_ones and adjoint:
+        raise XnwanError('x_cot_ones is not available with the continuous adjoint')
+    mode = (1 if want_x else 0) | (2 if want_params else 0) | (4 if x_cot_ones else 0) | (8 if adjoint else 0)
     check(lib.xw_ode_bwd_multi(arr, len(jobs), _p(t), _p(theta), method, L, d, H, K, m, mode, _stream()), 'xw_ode_bwd_multi')
 
 
@@ -125,7 +129,8 @@ def ode_act_rows(method, H, K, m):
     return r
 
 
-def ode_bwd(xT, t, start, theta, Y, ubar, method, H, K, m, want_x=True, want_params=False, gx=None, gs=None, gslab=None):
+def ode_bwd(xT, t, start, theta, Y, ubar, method, H, K, m, want_x=True, want_params=False, gx=None, gs=None, gslab=None,
+            adjoint=False):
     """reverse sweep: returns (gx[d,N], gs[N], gslab[nslab,P_u]) -- entries not requested are None."""
     _need_gpu()
     d, N = xT.shape
@@ -133,7 +138,7 @@ def ode_bwd(xT, t, start, theta, Y, ubar, method, H, K, m, want_x=True, want_par
     P = theta_size(d, H, K)
     _chk(xT, F64, (d, N), 'xT'); _chk(t, F64, (L,), 't'); _chk(start, F64, (N,), 'start'); _chk(theta, F64, (P,), 'theta')
     _chk(Y, F64, (L, H, N), 'Y'); _chk(ubar, F64, (L, N), 'ubar')
-    mode = (1 if want_x else 0) | (2 if want_params else 0)
+    mode = (1 if want_x else 0) | (2 if want_params else 0) | (8 if adjoint else 0)
     if want_x:
         gx = torch.empty(d, N, dtype=F64, device=xT.device) if gx is None else gx
         gs = torch.empty(N, dtype=F64, device=xT.device) if gs is None else gs

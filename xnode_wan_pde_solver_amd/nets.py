@@ -90,7 +90,7 @@ class _OdeFn(torch.autograd.Function):
         ubar = gu.squeeze(2).t().contiguous().to(F64)
         want_p = any(ctx.needs_input_grad[3:])
         gx, gs, slab = KN.ode_bwd(xT, t, s, net.blob.data, Y, ubar, net.method, net.hidden_dim, net.hidden_hidden_dim,
-                                  net.num_layers, want_x=True, want_params=want_p)
+                                  net.num_layers, want_x=True, want_params=want_p, adjoint=bool(net.adjoint))
         gX = None
         if ctx.needs_input_grad[0]:
             # nabla_x u is deposited at time index 0 (the model reads x from slice 0 only, src/model.py:99); the time
@@ -159,9 +159,6 @@ class XNODE(nn.Module):
         super().__init__()
         if output_dim != 1:
             raise XnwanError('the PDE solution is scalar: output_dim must be 1')
-        if adjoint:
-            raise XnwanError("adjoint=True (continuous adjoint) is not built; gradients are the exact reverse of the "
-                             "discrete stepper, i.e. the reference's default adjoint=False")
         self.hidden_dim, self.output_dim, self.hidden_hidden_dim = hidden_dim, output_dim, hidden_hidden_dim
         self.h, self.g, self.setup, self.num_layers, self.domain = func_h, func_g, setup, num_layers, domain
         self.solver, self.min_steps, self.adjoint = solver, min_steps, adjoint
