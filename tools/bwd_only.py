@@ -1,6 +1,6 @@
 """time the test-network backward (from the record, and recomputing) at the headline size"""
 import os, sys
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch
 from xnode_wan_pde_solver_amd import kernels as KN, _lib
 N, L, d, W, q = 4096, 32, int(os.environ.get('D', 20)), 50, 9
