@@ -174,7 +174,7 @@ def main():
         # k_disc_fwd runs in two variants: plain (generator sub-steps, 3.9 MB of inputs + outputs) and with the activation
         # record for the backward (discriminator sub-step, +524 MB of stores by design): average over the g,g,d cycle, like avg_ms
         keys = {'disc_fwd': ['k_disc_fwd<50,false>', 'k_disc_fwd<50,true>'],
-                'disc_bwd': ['k_disc_bwd<50,9,1,true,false,true>']}.get(dominant, [])
+                'disc_bwd': ['k_disc_rec<50,9,1>']}.get(dominant, [])
         if keys and all(k in pmc for k in keys):
             wts = [schedule.count('g'), schedule.count('d')] if len(keys) == 2 else [1]     # launches per g,g,d cycle
             traffic = int(sum(w_ * pmc[k]['hbm_bytes_per_launch_corrected'] for w_, k in zip(wts, keys)) / sum(wts))
