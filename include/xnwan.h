@@ -98,8 +98,9 @@ int xw_ode_bwd_multi(const XwOdeBwdJob* jobs, int njobs, const double* t, const 
 int xw_disc_fwd(const double* xT, const double* t, const double* tpp, const double* phi,
                 int N, int L, int d, int W, int q, double* v, double* vt, double* gxv, double* gtv, int ngrad,
                 int max_blocks, double* act, void* stream);
-/* act (may be NULL): activation record [xw_disc_act_rows(W, q)][N L rounded up to a multiple of 16] = the inputs
- * relu(a_j) of the q tied layers and tanh(a_q), point-major.  Given to xw_disc_bwd it replaces that kernel's forward recompute (500 doubles per point =
+/* act (may be NULL): activation record of xw_disc_act_rows(W, q) x (N L rounded up to a multiple of 16) doubles = the
+ * inputs relu(a_j) of the q tied layers and tanh(a_q).  Its layout is the kernels' own (tile-major: [tile of 16 points]
+ * [row j W + k][16], so that a wave's accesses are contiguous); callers only size it.  Given to xw_disc_bwd it replaces that kernel's forward recompute (500 doubles per point =
  * 524 MB at the headline size; written at ~2 TB/s next to a matrix-bound kernel, read once by the backward). */
 int xw_disc_act_rows(int W, int q);
 

@@ -110,7 +110,7 @@ def test_test_network_at_full_size(d, N, L):
     # backward: record == recompute, linear in the cotangent
     act = torch.empty(KN.disc_act_rows(W, Q), KN.disc_act_cols(P), dtype=F64, device=dev)
     v3, _ = KN.disc_fwd(xT, t, ph, W, Q, act=act)
-    assert torch.equal(v3, v) and torch.isfinite(act[:, :P]).all()
+    assert torch.equal(v3, v) and torch.isfinite(act).all()      # (P is a multiple of 16: every slot of the record is a point's)
     b1 = torch.randn(L, N, generator=g, dtype=F64).to(dev)
     b2 = torch.randn(L, N, generator=g, dtype=F64).to(dev)
     g1 = KN.slab_sum(KN.disc_bwd(xT, t, ph, b1, W, Q, act=act))

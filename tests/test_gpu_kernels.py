@@ -343,7 +343,9 @@ def test_disc_backward_from_stored_activations(N, L, d):
     v0, vt0 = KN.disc_fwd(xT, tc, blob, W, Q)
     v1, vt1 = KN.disc_fwd(xT, tc, blob, W, Q, act=act)
     assert torch.equal(v0, v1) and torch.equal(vt0, vt1)
-    assert torch.isfinite(act[:, :L * N]).all() and bool((act[:Q * W, :L * N] >= 0).all())   # relu outputs, every row written
+    rec = KN.disc_act_view(act, W, Q)                           # [tiles, (Q+1) W rows, 16 points]
+    assert torch.isfinite(rec).all() and bool((rec[:, :Q * W, :] >= 0).all())    # relu outputs, every slot written
+    assert bool((rec[:, Q * W:, :].abs() <= 1).all())                                 # tanh(a_q)
     s0 = KN.slab_sum(KN.disc_bwd(xT, tc, blob, vbar, W, Q))
     s1 = KN.slab_sum(KN.disc_bwd(xT, tc, blob, vbar, W, Q, act=act))
     _close(s1, s0, 1e-12, 'phi gradient from the stored record')

@@ -121,10 +121,13 @@ __global__ void __launch_bounds__(256, 2) k_disc_fwd(const double* __restrict__ 
     // order) also get the input gradient of v, by a reverse chain through the masks stashed below
     const bool want_grad = gxv != nullptr && tile * 16 < ngrad;         // wave-uniform
     d4 a[D::MT], ad[D::MT];
-    double* actl = act;                                                 // laundered like pht below: the record's row
-    asm volatile("" : "+s"(actl));                                      // addresses are formed per tile, not hoisted
-    const long Pp = (P + 15) & ~15L;                                    // row stride of the record: whole tiles, so that
-    const int aoff = g * (int)Pp + (int)(tile * 16) + (lane & 15);      // every lane of the last tile has its own column
+    // The record is TILE-MAJOR: [tile of 16 points][(q+1) W rows][16] -- the 4 rows x 16 points a store instruction
+    // covers are 512 contiguous bytes, and everything a wave writes (or k_disc_rec reads) for one tile is one 64 KB
+    // stretch (row-major, the same accesses were 128-byte pieces 1 MB apart).  Every lane of the last tile has a slot.
+    const long tu = __builtin_amdgcn_readfirstlane((int)tile);          // wave-uniform by construction: a scalar base
+    double* actl = act + tu * ((long)(q + 1) * W * 16);                 // (laundered like pht below: the row addresses
+    asm volatile("" : "+s"(actl));                                      //  are formed per tile, not hoisted)
+    const int aoff = lane;                                              // (g, n) -> row offset g, point n
     const double* pht = ph;                                             // laundered: keeps the input-layer fragment
     asm volatile("" : "+s"(pht));                                       // addresses out of the loop-invariant (spilled) set
     input_layer<W>(pht, o, xT, N, d, pt, a, ad);
@@ -154,7 +157,7 @@ __global__ void __launch_bounds__(256, 2) k_disc_fwd(const double* __restrict__ 
         const double b = av > 0.0 ? av : 0.0;
         const double bd = av > 0.0 ? adi[ks >> 2][ks & 3] : 0.0;
         if (ACT) {   // activation store: row j W + k of the record is the layer input relu(a_j)[k], point-major
-          double* __restrict__ rowp = actl + ((long)j * W + 4 * ks) * Pp;       // uniform pointer + 32-bit lane offset
+          double* __restrict__ rowp = actl + (j * W + 4 * ks) * 16;             // uniform pointer + 32-bit lane offset
           if (4 * ks + 3 < W || 4 * ks + g < W) rowp[aoff] = b;                 // (unconditional but for the last k-step)
         }
         if ((ks & 1) == 0) asm volatile("" ::: "memory");   // bound the LDS loads in flight (else all 52 are hoisted -> spills)
@@ -211,7 +214,7 @@ __global__ void __launch_bounds__(256, 2) k_disc_fwd(const double* __restrict__ 
         if (16 * mt + 4 * r < W) {  // rows 16 mt + 4 r + g >= W only carry zero padding
           const double th = xw_tanh(a[mt][r]);
           if (ACT && (16 * mt + 4 * r + 3 < W || 16 * mt + 4 * r + g < W))
-            (actl + ((long)q * W + 16 * mt + 4 * r) * Pp)[aoff] = th;          // last rows of the record: tanh(a_q)
+            (actl + (q * W + 16 * mt + 4 * r) * 16)[aoff] = th;                // last rows of the record: tanh(a_q)
           const double vo = sB[16 * D::MT + 16 * mt + g + 4 * r];
           sv += vo * th;
           sd += vo * (1.0 - th * th) * ad[mt][r];
@@ -635,10 +638,13 @@ __global__ void __launch_bounds__(256, 2) k_disc_rec(const double* __restrict__ 
 
   for (long st = blockIdx.x; st < nsuper; st += gridDim.x) {
     const Pt pt = locate(st * 4 + wave, P, N, tf, tpp);
-    const long Pp = (P + 15) & ~15L;
-    const int aoff = g * (int)Pp + pt.p;
+    // tile-major record (see k_disc_fwd): this wave's tile is one contiguous stretch, a layer 13 x 512 contiguous bytes
+    const long ntile = (P + 15) >> 4;
+    const long tl = st * 4 + wave < ntile ? st * 4 + wave : ntile - 1;  // (a wave past the end re-reads the last tile; vb = 0)
+    const double* tbase = act + (long)__builtin_amdgcn_readfirstlane((int)tl) * ((long)(nq + 1) * W * 16);
+    const int aoff = lane;
     auto load_layer = [&](int j, d4 (&r)[D::MT]) {
-      const double* base = act + (long)j * W * Pp;
+      const double* base = tbase + j * W * 16;
       asm volatile("" : "+s"(base));
 #pragma unroll
       for (int mt = 0; mt < D::MT; ++mt)
@@ -646,7 +652,7 @@ __global__ void __launch_bounds__(256, 2) k_disc_rec(const double* __restrict__ 
         for (int q_ = 0; q_ < 4; ++q_)
           if (q_ < D::LR(mt)) {
             const int row = 16 * mt + 4 * q_ + g;
-            r[mt][q_] = (16 * mt + 4 * q_ + 3 < W || row < W) ? (base + (long)(16 * mt + 4 * q_) * Pp)[aoff] : 0.0;
+            r[mt][q_] = (16 * mt + 4 * q_ + 3 < W || row < W) ? (base + (16 * mt + 4 * q_) * 16)[aoff] : 0.0;
           }
     };
     d4 a[D::MT], rnext[D::MT];

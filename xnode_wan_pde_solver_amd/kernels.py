@@ -163,6 +163,13 @@ def disc_act_rows(W, q):
     return r
 
 
+def disc_act_view(act, W, q):
+    """the record as [tiles of 16 points, (q+1) W rows, 16]: row j W + k of a tile = input k of tied layer j (relu(a_j)),
+    the last W rows tanh(a_q) -- the layout the kernels use (tile-major; the [rows, cols] shape is only its size)"""
+    rows = disc_act_rows(W, q)
+    return act.reshape(-1)[:act.numel()].view(act.shape[1] // 16, rows, 16)
+
+
 def disc_act_cols(P):
     """columns of that record for P points: whole 16-point tiles"""
     return (P + 15) // 16 * 16
