@@ -47,7 +47,8 @@ int xw_ode_fwd(const double* xT, const double* t, const double* start, const dou
 
 /* The same for up to 4 independent groups of paths in ONE launch (interior + boundary sample, ...): one wave per 16
  * paths fills only a quarter of an MI355X at N = 4096, so independent groups are co-scheduled explicitly. */
-/* act (may be NULL): activation store [L-1][xw_ode_act_rows()][N] -- the forward pass keeps the layer inputs of every
+/* act (may be NULL): activation store of (L-1) x xw_ode_act_rows() x (N rounded up to a multiple of 16) doubles (its
+ * layout is the kernels' own: [step][tile of 16 paths][row][16]) -- the forward pass keeps the layer inputs of every
  * stage of every step so that the sweeps (XwOdeBwdJob.act) read them back instead of re-evaluating the field: the
  * record is 180 doubles per path and step at (H, K, m) = (20, 10, 8) with midpoint, HBM capacity and bandwidth are idle
  * on this path, and the lone sweep wave saves 58 MFMAs + two tanh blocks per step.  Ignored by rk4. */

@@ -39,7 +39,7 @@ def test_stepper_sweeps_at_full_size(d, N, L):
     Mth = (1, H, K, M)                                             # midpoint
     rows = KN.ode_act_rows(1, H, K, M)
     u, Y = torch.empty(L, N, dtype=F64, device=dev), torch.empty(L, H, N, dtype=F64, device=dev)
-    act = torch.empty(L - 1, rows, N, dtype=F64, device=dev)
+    act = torch.empty(L - 1, rows, KN.ode_act_cols(N), dtype=F64, device=dev)
     job = dict(xT=xT, start=start, u=u, Y=Y, act=act)
     KN.ode_fwd_multi([job], t, th, *Mth)
     assert torch.isfinite(u).all() and torch.isfinite(act).all()

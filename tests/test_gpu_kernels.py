@@ -219,7 +219,7 @@ def test_ode_backward_from_stored_activations(solver):
     u0, Y0 = KN.ode_fwd(xT, tc, sc, blob, mid, H, K, 8)
     gx0, gs0, slab0 = KN.ode_bwd(xT, tc, sc, blob, Y0, ub, mid, H, K, 8, want_x=True, want_params=True)
     u, Y = torch.empty_like(u0), torch.empty_like(Y0)
-    act = torch.full((L - 1, max(rows, 1), N), float('nan'), dtype=F64, device='cuda')
+    act = torch.full((L - 1, max(rows, 1), KN.ode_act_cols(N)), float('nan'), dtype=F64, device='cuda')
     job = dict(xT=xT, start=sc, u=u, Y=Y, act=act if rows else None)
     KN.ode_fwd_multi([job], tc, blob, mid, H, K, 8)
     assert torch.equal(u, u0) and torch.equal(Y, Y0)
@@ -372,7 +372,7 @@ def test_smallest_and_widest_inputs(N, L, d):
     gXv = torch.autograd.grad(v_ref.sum(), x64)[0]
     xT, tc, sc = x.double().t().contiguous().cuda(), t.double().cuda(), start.detach().cuda()
     bu, bv = _blob(theta, U_ORDER), _blob(phi, V_ORDER)
-    act = torch.empty(L - 1, KN.ode_act_rows(1, H, K, 8), N, dtype=F64, device='cuda')
+    act = torch.empty(L - 1, KN.ode_act_rows(1, H, K, 8), KN.ode_act_cols(N), dtype=F64, device='cuda')
     ub = ubar.t().contiguous().cuda()
     for a_ in (None, act):
         u, Y = torch.empty(L, N, dtype=F64, device='cuda'), torch.empty(L, H, N, dtype=F64, device='cuda')

@@ -388,8 +388,10 @@ template <typename J> __device__ __forceinline__ int find_job(const J& jobs) {
 // The sweeps need, for every stage of every step, the layer inputs relu(z_j), the tanh output and the stage input.
 // Recomputing them from the checkpoint y_l costs the lone sweep wave 58 MFMAs and ~280 FP64 VALU instructions per step
 // (two tanh blocks); HBM has 288 GB and is idle on this path, so the forward can simply store them:
-//   act[l][row][n],  l = 0 .. L-2,  rows: stage i -> i * M K + j K + k  (j < M-1: relu(z_j), j = M-1: tanh(z_{M-1})),
-//                                         then the inputs of the stages i >= 1: S M K + (i-1) H + h.
+//   act[l][tile of 16 paths][row][16],  l = 0 .. L-2,  rows: stage i -> i * M K + j K + k  (j < M-1: relu(z_j),
+//   j = M-1: tanh(z_{M-1})), then the inputs of the stages i >= 1: S M K + (i-1) H + h.  Tile-major: what a wave stores
+//   or loads for one step is ONE contiguous stretch (23 KB at 180 rows); path-major rows made it 180 pieces of 128 bytes,
+//   32 KB apart, and the x-only sweep (183 MB in 0.1 ms) ran at the DRAM efficiency of that pattern.
 // 180 doubles per path and step at (H, K, m) = (20, 10, 8), midpoint: 183 MB for 4096 paths x 32 times.
 template <int H, int K, int M, int S> struct ActLayout {
   static constexpr int STAGE = M * K;
@@ -465,7 +467,8 @@ __global__ void __launch_bounds__(64, 2) k_ode_fwd(const FwdJobs jobs, const dou
 #pragma unroll
   for (int ht = 0; ht < D::HT; ++ht) flw[ht] = xw_vecD(th + o.FLw, H, 16 * ht);
   const double flb = th[o.FLb];
-  const ActLane aq = act_lane(N, base + n, valid, K);
+  const ActLane aq = act_lane(16, n, true, K);           // every lane of the tile has a slot (padding paths: finite copies)
+  const long ntile = (N + 15) >> 4, tile = base >> 4;
   for (int l = 0; l < L; ++l) {
     double part = 0.0;
 #pragma unroll
@@ -494,13 +497,13 @@ __global__ void __launch_bounds__(64, 2) k_ode_fwd(const FwdJobs jobs, const dou
       if (!ACT) {
         field_fwd<H, K, M, true>(w, t0 + T::c(i) * dt, xp, yi, k[i], SinkNone{});
       } else {
-        double* __restrict__ A = act + (long)l * AL::ROWS * N;
+        double* __restrict__ A = act + ((long)l * ntile + tile) * (AL::ROWS * 16);
         if (i > 0) {
 #pragma unroll
           for (int ht = 0; ht < D::HT; ++ht)
-            act_store(A, AL::YI + (i - 1) * H + 16 * ht, H - 16 * ht < 16 ? H - 16 * ht : 16, N, aq, yi[ht]);
+            act_store(A, AL::YI + (i - 1) * H + 16 * ht, H - 16 * ht < 16 ? H - 16 * ht : 16, 16, aq, yi[ht]);
         }
-        field_fwd<H, K, M, true>(w, t0 + T::c(i) * dt, xp, yi, k[i], SinkAct<K, M>{A, i * AL::STAGE, N, aq});
+        field_fwd<H, K, M, true>(w, t0 + T::c(i) * dt, xp, yi, k[i], SinkAct<K, M>{A, i * AL::STAGE, 16, aq});
       }
     }
 #pragma unroll
@@ -597,18 +600,19 @@ __device__ __forceinline__ void load_stage(const double* __restrict__ Y, const d
                                            int N, int ncl, StageRec<H, K, M>& R) {
   typedef Dim<H, K> D;
   typedef ActLayout<H, K, M, RK<METHOD>::S> AL;
-  const double* __restrict__ A = act + (long)l * AL::ROWS * N;
-  const ActLane q = act_lane(N, ncl, true, K);
+  const long ntile = (N + 15) >> 4, tile = __builtin_amdgcn_readfirstlane(ncl >> 4);   // (clamped lanes stay in the tile)
+  const double* __restrict__ A = act + ((long)l * ntile + tile) * (AL::ROWS * 16);
+  const ActLane q = act_lane(16, xw_lane() & 15, true, K);
   if (i == 0) {
     load_ckpt<H, K>(Y, l, N, ncl, R.yi);
   } else {
 #pragma unroll
     for (int ht = 0; ht < D::HT; ++ht)
-      R.yi[ht] = act_load(A, AL::YI + (i - 1) * H + 16 * ht, H - 16 * ht < 16 ? H - 16 * ht : 16, N, q);
+      R.yi[ht] = act_load(A, AL::YI + (i - 1) * H + 16 * ht, H - 16 * ht < 16 ? H - 16 * ht : 16, 16, q);
   }
 #pragma unroll
-  for (int j = 0; j < M - 1; ++j) R.sv.z[j] = act_load(A, i * AL::STAGE + j * K, K, N, q);
-  R.sv.a = act_load(A, i * AL::STAGE + (M - 1) * K, K, N, q);
+  for (int j = 0; j < M - 1; ++j) R.sv.z[j] = act_load(A, i * AL::STAGE + j * K, K, 16, q);
+  R.sv.a = act_load(A, i * AL::STAGE + (M - 1) * K, K, 16, q);
 }
 
 // SAVED: the stage activations come from the forward pass's store (euler, midpoint); otherwise they are recomputed

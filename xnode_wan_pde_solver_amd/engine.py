@@ -224,8 +224,8 @@ class Engine:
         G.c = G.cp = None
         # stage activations of every step, written by the forward, read back by the sweeps (183 MB at N = 4096, L = 32)
         ar = KN.ode_act_rows(self.method, H, self.K, self.m) if self.keep_activations and not self.adjoint else 0
-        G.act = e(max(L - 1, 1), ar, N) if ar else None
-        G.act_b = e(max(Lb - 1, 1), ar, Nb) if (ar and Nb) else None
+        G.act = e(max(L - 1, 1), ar, KN.ode_act_cols(N)) if ar else None
+        G.act_b = e(max(Lb - 1, 1), ar, KN.ode_act_cols(Nb)) if (ar and Nb) else None
         # layer inputs of the test network at every point, stored by its forward in the discriminator sub-step and read
         # back by its backward (524 MB at 131072 points)
         # (depths other than the unrolled one have no recomputing reverse kernel: they always run from the record)

@@ -79,7 +79,7 @@ def ode_fwd_multi(jobs, t, theta, method, H, K, m, zero16=None):
         _chk(j['xT'], F64, (d, N), 'xT'); _chk(j['start'], F64, (N,), 'start'); _chk(j['u'], F64, (L, N), 'u')
         _chk(j.get('Y'), F64, (L, H, N), 'Y')
         if j.get('act') is not None:
-            _chk(j['act'], F64, (max(L - 1, 1), ode_act_rows(method, H, K, m), N), 'act')
+            _chk(j['act'], F64, (max(L - 1, 1), ode_act_rows(method, H, K, m), ode_act_cols(N)), 'act')
         a.xT, a.start, a.u, a.Y, a.act, a.N = _p(j['xT']), _p(j['start']), _p(j['u']), _p(j.get('Y')), _p(j.get('act')), N
     _chk(zero16, F64, (16,), 'zero16')
     check(lib.xw_ode_fwd_multi(arr, len(jobs), _p(t), _p(theta), method, L, d, H, K, m, _p(zero16), _stream()), 'xw_ode_fwd_multi')
@@ -106,7 +106,7 @@ def ode_bwd_multi(jobs, t, theta, method, H, K, m, want_x, want_params, x_cot_on
         if want_params:
             _chk(j['gslab'], F64, (ode_bwd_slabs(N), P), 'gslab')
         if j.get('act') is not None:
-            _chk(j['act'], F64, (max(L - 1, 1), ode_act_rows(method, H, K, m), N), 'act')
+            _chk(j['act'], F64, (max(L - 1, 1), ode_act_rows(method, H, K, m), ode_act_cols(N)), 'act')
         a.xT, a.start, a.Y, a.ubar, a.N = _p(j['xT']), _p(j['start']), _p(j['Y']), _p(j.get('ubar')), N
         a.act = _p(j.get('act'))
         a.gx, a.gs, a.gslab = _p(j.get('gx')), _p(j.get('gs')), _p(j.get('gslab'))
@@ -120,6 +120,11 @@ def ode_bwd_multi(jobs, t, theta, method, H, K, m, want_x, want_params, x_cot_on
 
 def ode_bwd_slabs(N):
     return lib.xw_ode_bwd_slabs(N)
+
+
+def ode_act_cols(N):
+    """columns of the activation store for N paths: whole tiles of 16 (the store is tile-major inside a step)"""
+    return (N + 15) // 16 * 16
 
 
 def ode_act_rows(method, H, K, m):
