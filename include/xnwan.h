@@ -50,7 +50,7 @@ int xw_ode_fwd(const double* xT, const double* t, const double* start, const dou
 /* act (may be NULL): activation store of (L-1) x xw_ode_act_rows() x (N rounded up to a multiple of 16) doubles (its
  * layout is the kernels' own: [step][tile of 16 paths][row][16]) -- the forward pass keeps the layer inputs of every
  * stage of every step so that the sweeps (XwOdeBwdJob.act) read them back instead of re-evaluating the field: the
- * record is 180 doubles per path and step at (H, K, m) = (20, 10, 8) with midpoint, HBM capacity and bandwidth are idle
+ * record is 180 doubles (+ 4 of ReLU-mask words, all an x-only sweep reads besides the tanh rows) per path and step at (H, K, m) = (20, 10, 8) with midpoint, HBM capacity and bandwidth are idle
  * on this path, and the lone sweep wave saves 58 MFMAs + two tanh blocks per step.  Ignored by rk4. */
 typedef struct { const double* xT; const double* start; double* u; double* Y; double* act; int N; } XwOdeFwdJob;
 /* rows of the activation record per step (0: this method's sweeps recompute; negative: XW_E_*) */

@@ -215,7 +215,7 @@ def test_ode_backward_from_stored_activations(solver):
     xT, tc, sc, blob = x.double().t().contiguous().cuda(), t.double().cuda(), start.cuda(), _blob(theta, U_ORDER)
     mid = KN.method_id(solver)
     rows = KN.ode_act_rows(mid, H, K, 8)
-    assert rows == {'euler': 80, 'midpoint': 180, 'rk4': 0}[solver]
+    assert rows == {'euler': 80 + 2, 'midpoint': 180 + 4, 'rk4': 0}[solver]      # layer inputs + 2 rows of mask words per stage
     u0, Y0 = KN.ode_fwd(xT, tc, sc, blob, mid, H, K, 8)
     gx0, gs0, slab0 = KN.ode_bwd(xT, tc, sc, blob, Y0, ub, mid, H, K, 8, want_x=True, want_params=True)
     u, Y = torch.empty_like(u0), torch.empty_like(Y0)

@@ -12,6 +12,7 @@
 //
 // Memory traffic per path: x (d floats) once, the checkpoint y[L,H] written once / read once, u[L] -- everything else
 // stays on chip.  At the headline size this kernel is bound by the FP64 matrix pipe, not by HBM.
+#include <type_traits>
 #include "xw_common.h"
 #include "xnwan.h"
 
@@ -72,6 +73,15 @@ template <int H, int K> struct FieldWT {     // transposed operands for the vect
 template <int M> struct Save {               // what the VJP of one field evaluation needs
   d4 z[M > 1 ? M - 1 : 1];                   // relu(z_0) .. relu(z_{m-2}): layer inputs; their sign pattern is the ReLU mask
   d4 a;                                      // tanh(z_{m-1})
+  __device__ __forceinline__ bool pos(int j, int r) const { return z[j][r] > 0.0; }
+};
+// the same for a sweep without weight gradients: the layer inputs are only needed as their ReLU masks, 4 bits per layer
+// (registers 0..3 of the K-tile) in one word -- the x-only sweep then loads 1 word + tanh instead of m K doubles per stage
+template <int M> struct SaveX {
+  static_assert(4 * (M - 1) <= 32, "mask word");
+  d4 a;
+  unsigned bits;
+  __device__ __forceinline__ bool pos(int j, int r) const { return (bits >> (4 * j + r)) & 1u; }
 };
 
 template <int H, int K>
@@ -254,8 +264,8 @@ __device__ __forceinline__ void outer_take(d4& acc, const double* qt, const doub
 // in yb, adds the cotangent of z0 into xpb (= cotangent of the x-projection and of Win.b), and (PARAMS) accumulates the
 // parameter gradients (outer products over the 16 paths; a row of ones / the time row in the R tile makes the bias and
 // time-column gradients ride along as an extra accumulator column).
-template <int H, int K, int M, bool PARAMS>
-__device__ __forceinline__ void field_vjp(const FieldW<H, K>& w, const FieldWT<H, K>& wT, double t, const Save<M>& sv,
+template <int H, int K, int M, bool PARAMS, class SV>
+__device__ __forceinline__ void field_vjp(const FieldW<H, K>& w, const FieldWT<H, K>& wT, double t, const SV& sv,
                                           const d4 (&yin)[Dim<H, K>::HT], const d4 (&ob)[Dim<H, K>::HT],
                                           d4 (&yb)[Dim<H, K>::HT], d4& xpb, FieldG<H, K>& G, double* lds) {
   typedef Dim<H, K> D;
@@ -277,13 +287,13 @@ __device__ __forceinline__ void field_vjp(const FieldW<H, K>& w, const FieldWT<H
   for (int r = 0; r < D::KSK; ++r) zb[r] = ab[r] * (1.0 - sv.a[r] * sv.a[r]);
 #pragma unroll
   for (int j = M - 2; j >= 0; --j) {
-    if (PARAMS) outer_post_ones<D::KSK, K>(zb, sv.z[j], lds);
+    if constexpr (PARAMS) outer_post_ones<D::KSK, K>(zb, sv.z[j], lds);
     d4 tt = xw_zero4();
 #pragma unroll
     for (int ks = 0; ks < D::KSK; ++ks) tt = XW_MFMA(wT.WhT[ks], zb[ks], tt);
     if (PARAMS) outer_take(G.Wh, lds, rt1);
 #pragma unroll
-    for (int r = 0; r < D::KSK; ++r) zb[r] = sv.z[j][r] > 0.0 ? tt[r] : 0.0;
+    for (int r = 0; r < D::KSK; ++r) zb[r] = sv.pos(j, r) ? tt[r] : 0.0;
   }
 #pragma unroll
   for (int r = 0; r < D::KSK; ++r) xpb[r] += zb[r];
@@ -397,6 +407,8 @@ template <int H, int K, int M, int S> struct ActLayout {
   static constexpr int STAGE = M * K;
   static constexpr int YI = S * STAGE;
   static constexpr int ROWS = S * STAGE + (S - 1) * H;
+  static constexpr int MASK = ROWS;                      // + 2 rows (64 words) per stage: the ReLU masks of SaveX
+  static constexpr int TOTAL = ROWS + 2 * S;
 };
 // rows [row0, row0 + nrows) of the record <-> the first registers of a chain tile (row g + 4 r).  Addresses are
 // formed as  (uniform row pointer) + (32-bit lane offset)  so that they cost SGPRs, not a VGPR pair per stored row.
@@ -435,7 +447,12 @@ template <int K, int M> struct SinkAct {
   double* __restrict__ A;      // record of this step
   int row0, N;
   const ActLane& q;
-  __device__ __forceinline__ void z(int j, d4 r) const { act_store(A, row0 + j * K, K, N, q, r); }
+  unsigned& bits;              // ReLU masks of the stage (SaveX layout), stored by the caller after the evaluation
+  __device__ __forceinline__ void z(int j, d4 r) const {
+    act_store(A, row0 + j * K, K, N, q, r);
+#pragma unroll
+    for (int c = 0; c < (K + 3) / 4; ++c) bits |= (r[c] > 0.0 ? 1u : 0u) << (4 * j + c);
+  }
   __device__ __forceinline__ void a(d4 v) const { act_store(A, row0 + (M - 1) * K, K, N, q, v); }
 };
 
@@ -497,13 +514,15 @@ __global__ void __launch_bounds__(64, 2) k_ode_fwd(const FwdJobs jobs, const dou
       if (!ACT) {
         field_fwd<H, K, M, true>(w, t0 + T::c(i) * dt, xp, yi, k[i], SinkNone{});
       } else {
-        double* __restrict__ A = act + ((long)l * ntile + tile) * (AL::ROWS * 16);
+        double* __restrict__ A = act + ((long)l * ntile + tile) * (AL::TOTAL * 16);
         if (i > 0) {
 #pragma unroll
           for (int ht = 0; ht < D::HT; ++ht)
             act_store(A, AL::YI + (i - 1) * H + 16 * ht, H - 16 * ht < 16 ? H - 16 * ht : 16, 16, aq, yi[ht]);
         }
-        field_fwd<H, K, M, true>(w, t0 + T::c(i) * dt, xp, yi, k[i], SinkAct<K, M>{A, i * AL::STAGE, 16, aq});
+        unsigned bits = 0;
+        field_fwd<H, K, M, true>(w, t0 + T::c(i) * dt, xp, yi, k[i], SinkAct<K, M>{A, i * AL::STAGE, 16, aq, bits});
+        reinterpret_cast<unsigned*>(A + (AL::MASK + 2 * i) * 16)[lane] = bits;
       }
     }
 #pragma unroll
@@ -591,18 +610,23 @@ __device__ __forceinline__ void recompute(const FieldW<H, K>& w, d4 xp, const do
 // one stage of that record read back from the forward pass's activation store (k_ode_fwd<ACT>): loads only.
 // Stage granularity: while one stage is reversed the loads of the next one are in flight -- a whole step ahead would
 // keep twice as many registers occupied.
-template <int H, int K, int M> struct StageRec {
-  d4 yi[Dim<H, K>::HT];
-  Save<M> sv;
+template <int H, int K, int M, class SV = Save<M>> struct StageRec {
+  d4 yi[Dim<H, K>::HT];        // (not loaded for SaveX: a sweep without weight gradients never reads the stage input)
+  SV sv;
 };
-template <int H, int K, int M, int METHOD>
+template <int H, int K, int M, int METHOD, class SV>
 __device__ __forceinline__ void load_stage(const double* __restrict__ Y, const double* __restrict__ act, int l, int i,
-                                           int N, int ncl, StageRec<H, K, M>& R) {
+                                           int N, int ncl, StageRec<H, K, M, SV>& R) {
   typedef Dim<H, K> D;
   typedef ActLayout<H, K, M, RK<METHOD>::S> AL;
   const long ntile = (N + 15) >> 4, tile = __builtin_amdgcn_readfirstlane(ncl >> 4);   // (clamped lanes stay in the tile)
-  const double* __restrict__ A = act + ((long)l * ntile + tile) * (AL::ROWS * 16);
+  const double* __restrict__ A = act + ((long)l * ntile + tile) * (AL::TOTAL * 16);
   const ActLane q = act_lane(16, xw_lane() & 15, true, K);
+  if constexpr (std::is_same<SV, SaveX<M>>::value) {
+    R.sv.bits = reinterpret_cast<const unsigned*>(A + (AL::MASK + 2 * i) * 16)[xw_lane()];
+    R.sv.a = act_load(A, i * AL::STAGE + (M - 1) * K, K, 16, q);
+    return;
+  }
   if (i == 0) {
     load_ckpt<H, K>(Y, l, N, ncl, R.yi);
   } else {
@@ -610,9 +634,11 @@ __device__ __forceinline__ void load_stage(const double* __restrict__ Y, const d
     for (int ht = 0; ht < D::HT; ++ht)
       R.yi[ht] = act_load(A, AL::YI + (i - 1) * H + 16 * ht, H - 16 * ht < 16 ? H - 16 * ht : 16, 16, q);
   }
+  if constexpr (std::is_same<SV, Save<M>>::value) {
 #pragma unroll
-  for (int j = 0; j < M - 1; ++j) R.sv.z[j] = act_load(A, i * AL::STAGE + j * K, K, 16, q);
-  R.sv.a = act_load(A, i * AL::STAGE + (M - 1) * K, K, 16, q);
+    for (int j = 0; j < M - 1; ++j) R.sv.z[j] = act_load(A, i * AL::STAGE + j * K, K, 16, q);
+    R.sv.a = act_load(A, i * AL::STAGE + (M - 1) * K, K, 16, q);
+  }
 }
 
 // SAVED: the stage activations come from the forward pass's store (euler, midpoint); otherwise they are recomputed
@@ -703,7 +729,7 @@ __global__ void __launch_bounds__(64) k_ode_bwd(const BwdJobs jobs, const double
         if (i == 0) psum[ht] = xw_zero4();
       }
   };
-  auto reverse_stage = [&](int l, int i, const d4 (&yin)[D::HT], const Save<M>& sv) {
+  auto reverse_stage = [&](int l, int i, const d4 (&yin)[D::HT], const auto& sv) {
     const double t0 = tf[l], dt = tf[l + 1] - t0;
     d4 psi[D::HT];
     field_vjp<H, K, M, PARAMS>(w, wT, t0 + T::c(i) * dt, sv, yin, kb[i], psi, xpb, G, lds);
@@ -784,7 +810,9 @@ __global__ void __launch_bounds__(64) k_ode_bwd(const BwdJobs jobs, const double
       load_ckpt<H, K>(Y, L - 1, N, ncl, yl);
       readout(L - 1, yl, load_ub(L - 1));
     }
-    StageRec<H, K, M> sa, sb;
+    // (without weight gradients the sweep only needs tanh(z_{m-1}) and the ReLU masks of a stage)
+    typedef typename std::conditional<PARAMS, Save<M>, SaveX<M>>::type SV;
+    StageRec<H, K, M, SV> sa, sb;
     if constexpr (T::S == 2) {
       // stage 1 always lives in sa, stage 0 in sb: each is loaded while the other one is reversed
       if (L > 1) load_stage<H, K, M, METHOD>(Y, act, L - 2, 1, N, ncl, sa);
@@ -1101,7 +1129,7 @@ extern "C" int xw_ode_bwd_slabs(int N) { return (N + 15) / 16; }
 extern "C" int xw_ode_act_rows(int method, int H, int K, int m) {
   if (H != 20 || K != 10 || m < 1 || m > 8) return XW_E_DIMS;
   const int S = method == 0 ? 1 : method == 1 ? 2 : 0;           // rk4: the sweeps recompute
-  return S == 0 ? 0 : S * m * K + (S - 1) * H;
+  return S == 0 ? 0 : S * m * K + (S - 1) * H + 2 * S;             // (+ the ReLU-mask words of every stage)
 }
 
 extern "C" int xw_ode_fwd_multi(const XwOdeFwdJob* jobs, int njobs, const double* t, const double* theta, int method, int L,
