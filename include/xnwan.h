@@ -52,7 +52,10 @@ int xw_ode_fwd(const double* xT, const double* t, const double* start, const dou
  * stage of every step so that the sweeps (XwOdeBwdJob.act) read them back instead of re-evaluating the field: the
  * record is 180 doubles (+ 4 of ReLU-mask words, all an x-only sweep reads besides the tanh rows) per path and step at (H, K, m) = (20, 10, 8) with midpoint, HBM capacity and bandwidth are idle
  * on this path, and the lone sweep wave saves 58 MFMAs + two tanh blocks per step.  Ignored by rk4. */
-typedef struct { const double* xT; const double* start; double* u; double* Y; double* act; int N; } XwOdeFwdJob;
+typedef struct { const double* xT; const double* start; double* u; double* Y; double* act; int N;
+                 int act_x_only;   /* != 0: store only what a sweep WITHOUT weight gradients (mode 1) reads back -- the tanh
+                                      rows and the ReLU-mask words, 1/7 of the bytes; same for every job of a launch */
+               } XwOdeFwdJob;
 /* rows of the activation record per step (0: this method's sweeps recompute; negative: XW_E_*) */
 int xw_ode_act_rows(int method, int H, int K, int m);
 /* zero16 (may be NULL): 16 doubles cleared by the launch -- the sub-step's partial-sum slots scal[], so that no separate

@@ -229,6 +229,17 @@ def test_ode_backward_from_stored_activations(solver):
     KN.ode_bwd_multi([dict(job, ubar=ub, gx=gx, gs=gs, gslab=slab)], tc, blob, mid, H, K, 8, want_x=True, want_params=True)
     _close(gx, gx0, 1e-12, 'gx'); _close(gs, gs0, 1e-12, 'gs')
     _close(KN.slab_sum(slab), KN.slab_sum(slab0), 1e-12, 'theta gradient')
+    if rows:
+        # a store that will only serve a sweep without weight gradients: tanh rows + ReLU mask words (XwOdeFwdJob.act_x_only)
+        actx = torch.full_like(act, float('nan'))
+        KN.ode_fwd_multi([dict(job, act=actx)], tc, blob, mid, H, K, 8, act_x_only=True)
+        assert torch.equal(u, u0) and int(torch.isfinite(actx).sum()) < int(torch.isfinite(act).sum()) // 3
+        gx1, gs1 = torch.empty_like(gx0), torch.empty_like(gs0)
+        KN.ode_bwd_multi([dict(job, act=actx, ubar=ub, gx=gx1, gs=gs1)], tc, blob, mid, H, K, 8, want_x=True, want_params=False)
+        gx2, gs2 = torch.empty_like(gx0), torch.empty_like(gs0)
+        KN.ode_bwd_multi([dict(job, ubar=ub, gx=gx2, gs=gs2)], tc, blob, mid, H, K, 8, want_x=True, want_params=False)
+        assert torch.equal(gx1, gx2) and torch.equal(gs1, gs2)
+        _close(gx1, gx0, 1e-12, 'gx (x-only store)'); _close(gs1, gs0, 1e-12, 'gs (x-only store)')
 
 
 @pytest.mark.parametrize('N,L,d', CASES + [(50, 3, 70)])

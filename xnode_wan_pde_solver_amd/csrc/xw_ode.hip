@@ -365,6 +365,7 @@ struct FwdJobs {
   int N[XW_MAXJOBS];
   int tile0[XW_MAXJOBS + 1];   // first block of each job
   int n;
+  int x_only;                  // the stores of this launch only serve x-only sweeps (XwOdeFwdJob.act_x_only)
   double* zero16;              // optional: 16 doubles cleared by block 0 (the sub-step's partial-sum slots)
 };
 struct BwdJobs {
@@ -443,20 +444,22 @@ __device__ __forceinline__ d4 act_load(const double* __restrict__ A, int row0, i
 }
 
 // streams the layer inputs of one stage into the activation store as they are produced (no register copy kept)
-template <int K, int M> struct SinkAct {
+// FULL = false: only what a sweep WITHOUT weight gradients reads back (the tanh rows and the mask words)
+template <int K, int M, bool FULL = true> struct SinkAct {
   double* __restrict__ A;      // record of this step
   int row0, N;
   const ActLane& q;
   unsigned& bits;              // ReLU masks of the stage (SaveX layout), stored by the caller after the evaluation
   __device__ __forceinline__ void z(int j, d4 r) const {
-    act_store(A, row0 + j * K, K, N, q, r);
+    if (FULL) act_store(A, row0 + j * K, K, N, q, r);
 #pragma unroll
     for (int c = 0; c < (K + 3) / 4; ++c) bits |= (r[c] > 0.0 ? 1u : 0u) << (4 * j + c);
   }
   __device__ __forceinline__ void a(d4 v) const { act_store(A, row0 + (M - 1) * K, K, N, q, v); }
 };
 
-template <int H, int K, int M, int METHOD, bool ACT>
+// ACT: 0 = no activation store, 1 = the full store, 2 = only what an x-only sweep reads (tanh rows + ReLU mask words)
+template <int H, int K, int M, int METHOD, int ACT>
 __global__ void __launch_bounds__(64, 2) k_ode_fwd(const FwdJobs jobs, const double* __restrict__ tf,
                                                 const double* __restrict__ th, int L, int d) {
   typedef Dim<H, K> D;
@@ -515,13 +518,13 @@ __global__ void __launch_bounds__(64, 2) k_ode_fwd(const FwdJobs jobs, const dou
         field_fwd<H, K, M, true>(w, t0 + T::c(i) * dt, xp, yi, k[i], SinkNone{});
       } else {
         double* __restrict__ A = act + ((long)l * ntile + tile) * (AL::TOTAL * 16);
-        if (i > 0) {
+        if (i > 0 && ACT == 1) {
 #pragma unroll
           for (int ht = 0; ht < D::HT; ++ht)
             act_store(A, AL::YI + (i - 1) * H + 16 * ht, H - 16 * ht < 16 ? H - 16 * ht : 16, 16, aq, yi[ht]);
         }
         unsigned bits = 0;
-        field_fwd<H, K, M, true>(w, t0 + T::c(i) * dt, xp, yi, k[i], SinkAct<K, M>{A, i * AL::STAGE, 16, aq, bits});
+        field_fwd<H, K, M, true>(w, t0 + T::c(i) * dt, xp, yi, k[i], SinkAct<K, M, ACT == 1>{A, i * AL::STAGE, 16, aq, bits});
         reinterpret_cast<unsigned*>(A + (AL::MASK + 2 * i) * 16)[lane] = bits;
       }
     }
@@ -1067,14 +1070,16 @@ __global__ void __launch_bounds__(64) k_ode_bwd(const BwdJobs jobs, const double
 template <int H, int K, int M>
 int launch_fwd(int method, const FwdJobs& jobs, const double* t, const double* theta, int L, int d, hipStream_t s) {
   const dim3 grid(jobs.tile0[jobs.n]), block(64);
-  bool act = true;                                     // all jobs or none (checked by the caller)
+  bool act = true;                                     // all jobs or none, all in the same mode (checked by the caller)
   for (int i = 0; i < jobs.n; ++i) act = act && jobs.act[i] != nullptr;
-  switch (method * 2 + (act ? 1 : 0)) {
-    case 0: hipLaunchKernelGGL((k_ode_fwd<H, K, M, 0, false>), grid, block, 0, s, jobs, t, theta, L, d); break;
-    case 1: hipLaunchKernelGGL((k_ode_fwd<H, K, M, 0, true>), grid, block, 0, s, jobs, t, theta, L, d); break;
-    case 2: hipLaunchKernelGGL((k_ode_fwd<H, K, M, 1, false>), grid, block, 0, s, jobs, t, theta, L, d); break;
-    case 3: hipLaunchKernelGGL((k_ode_fwd<H, K, M, 1, true>), grid, block, 0, s, jobs, t, theta, L, d); break;
-    case 4: hipLaunchKernelGGL((k_ode_fwd<H, K, M, 2, false>), grid, block, 0, s, jobs, t, theta, L, d); break;
+  switch (method * 3 + (act ? (jobs.x_only ? 2 : 1) : 0)) {
+    case 0: hipLaunchKernelGGL((k_ode_fwd<H, K, M, 0, 0>), grid, block, 0, s, jobs, t, theta, L, d); break;
+    case 1: hipLaunchKernelGGL((k_ode_fwd<H, K, M, 0, 1>), grid, block, 0, s, jobs, t, theta, L, d); break;
+    case 2: hipLaunchKernelGGL((k_ode_fwd<H, K, M, 0, 2>), grid, block, 0, s, jobs, t, theta, L, d); break;
+    case 3: hipLaunchKernelGGL((k_ode_fwd<H, K, M, 1, 0>), grid, block, 0, s, jobs, t, theta, L, d); break;
+    case 4: hipLaunchKernelGGL((k_ode_fwd<H, K, M, 1, 1>), grid, block, 0, s, jobs, t, theta, L, d); break;
+    case 5: hipLaunchKernelGGL((k_ode_fwd<H, K, M, 1, 2>), grid, block, 0, s, jobs, t, theta, L, d); break;
+    case 6: hipLaunchKernelGGL((k_ode_fwd<H, K, M, 2, 0>), grid, block, 0, s, jobs, t, theta, L, d); break;
     default: return XW_E_ARG;
   }
   return xw_launch_status();
@@ -1138,10 +1143,12 @@ extern "C" int xw_ode_fwd_multi(const XwOdeFwdJob* jobs, int njobs, const double
   FwdJobs J;
   J.n = njobs;
   J.zero16 = zero16;
+  J.x_only = jobs[0].act_x_only ? 1 : 0;
   J.tile0[0] = 0;
   for (int i = 0; i < XW_MAXJOBS; ++i) {
     const bool on = i < njobs;
     if (on && (!jobs[i].xT || !jobs[i].start || !jobs[i].u || jobs[i].N <= 0)) return XW_E_ARG;
+    if (on && (jobs[i].act_x_only ? 1 : 0) != J.x_only) return XW_E_ARG;         // one store mode per launch
     J.xT[i] = on ? jobs[i].xT : nullptr;
     J.start[i] = on ? jobs[i].start : nullptr;
     J.u[i] = on ? jobs[i].u : nullptr;
@@ -1159,7 +1166,7 @@ extern "C" int xw_ode_fwd_multi(const XwOdeFwdJob* jobs, int njobs, const double
 
 extern "C" int xw_ode_fwd(const double* xT, const double* t, const double* start, const double* theta, int method, int N,
                           int L, int d, int H, int K, int m, double* u, double* Y, void* stream) {
-  XwOdeFwdJob j = {xT, start, u, Y, nullptr, N};
+  XwOdeFwdJob j = {xT, start, u, Y, nullptr, N, 0};
   return xw_ode_fwd_multi(&j, 1, t, theta, method, L, d, H, K, m, nullptr, stream);
 }
 

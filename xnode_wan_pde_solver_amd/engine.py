@@ -451,7 +451,8 @@ class Engine:
         if not getattr(G, 'skip_v', False):
             self._launch_test_net_here(G, blocks=self.v_blocks_disc)
         with self._side(1, e0):
-            KN.ode_fwd_multi([self._job(G, 'i')], G.t, th, *M, zero16=self.scal)
+            # (the only sweep of this sub-step has no weight gradients: the forward stores a seventh of the record)
+            KN.ode_fwd_multi([self._job(G, 'i')], G.t, th, *M, zero16=self.scal, act_x_only=True)
             self._reaction(G)
             KN.ode_bwd_multi([self._job(G, 'i', want_x=True)], G.t, th, *M, want_x=True, want_params=False, adjoint=self.adjoint)
             e_x = self._mark()
