@@ -128,11 +128,13 @@ class Engine:
     # ------------------------------------------------------------------------------------------------------------
     # per-sample preparation (once per outer iteration; everything here is parameter-independent)
     # ------------------------------------------------------------------------------------------------------------
-    def load_group(self, X, XV, BX, domain, n_glob=None, nb_glob=None, into=None):
+    def load_group(self, X, XV, BX, domain, n_glob=None, nb_glob=None, into=None, shared_grid_t0=None):
         """Prepare one group.  The user's callables (h, f, g, func_w, a, b) are evaluated on the device the given
         tensors live on and only their results are uploaded: pass the loader's host tensors to tabulate exactly like
         the reference's CPU path, or device tensors to tabulate on the GPU (float32 transcendental functions then
-        differ from the host's in the last bit).  `into`: a Group of the same shapes to refill in place."""
+        differ from the host's in the last bit).  `into`: a Group of the same shapes to refill in place.
+        `shared_grid_t0`: the caller built X, XV and BX from ONE time grid whose first time is this value (compact cube
+        samples): the checks that would otherwise read the device tensors back (four host syncs) are skipped."""
         dev, d = self.dev, self.d
         X, XV = X.detach(), XV.detach()
         BX = BX.detach() if BX is not None else None
@@ -147,13 +149,13 @@ class Engine:
         # the test network is pointwise on XV: when the paths of a group do not share one time column (late-entry groups
         # of the hourglass: every path has its own entry time at l = 0) it runs in point mode on all L*N points
         S['tpp'] = S['tpp0'] = S['xvT_pts'] = None
-        if not bool(torch.all(XV[:, :, 0] == XV[:1, :, 0])):
+        if shared_grid_t0 is None and not bool(torch.all(XV[:, :, 0] == XV[:1, :, 0])):
             S['tpp'] = XV[:, :, 0].to(dev).to(F64).t().contiguous().reshape(-1)              # time-major: p = l*N + n
             S['tpp0'] = XV[:, 0, 0].to(dev).to(F64).contiguous()
             S['xvT_pts'] = S['xvT'].unsqueeze(1).expand(d, L, N).reshape(d, L * N).contiguous()
         # start values and their x-gradient (the h -> y0 path of nabla_x u, src/model.py:95)
         X0 = X[:, 0, :].clone().requires_grad_(True)
-        starts_T0 = float(X[0, 0, 0]) == self.setup['T0']
+        starts_T0 = (float(X[0, 0, 0]) if shared_grid_t0 is None else float(shared_grid_t0)) == self.setup['T0']
         s = self.funcs['h'](X0) if starts_T0 else self.funcs['g'](X0.unsqueeze(1)).reshape(-1)
         S['start'] = s.detach().to(dev).to(F64).reshape(-1).contiguous()
         if s.requires_grad:
@@ -179,9 +181,9 @@ class Engine:
         if BX is not None:
             Lb = BX.shape[1]
             S['tb'] = BX[0, :, 0].to(dev).to(F64).contiguous()
-            same_grid = Lb == L and bool(torch.equal(S['tb'], S['t']))
+            same_grid = Lb == L and (shared_grid_t0 is not None or bool(torch.equal(S['tb'], S['t'])))
             S['xbT'] = BX[:, 0, 1:].to(dev).to(F64).t().contiguous()
-            b_T0 = float(BX[0, 0, 0]) == self.setup['T0']
+            b_T0 = (float(BX[0, 0, 0]) if shared_grid_t0 is None else float(shared_grid_t0)) == self.setup['T0']
             sb = self.funcs['h'](BX[:, 0, :]) if b_T0 else self.funcs['g'](BX[:, 0, :].unsqueeze(1)).reshape(-1)
             S['start_b'] = sb.detach().to(dev).to(F64).reshape(-1).contiguous()
             S['g'] = _to_LN(self.funcs['g'](BX), dev)

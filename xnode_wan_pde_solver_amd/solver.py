@@ -186,10 +186,13 @@ class NODE_WAN_solver:
         """(u, v, boundary) groups of a loader.  `tabulate_on_host=True` hands the engine the loader's HOST
         tensors, so that h, f, g, w are tabulated exactly like the reference's CPU path; False (default) builds the path tensors
         on the GPU from the compact sample and tabulates there."""
+        self._grid_hint = None
         if not self.tabulate_on_host or self.device_sampling:
             comp = points.compact() if hasattr(points, 'compact') else None
             if comp is not None:
                 times, xu, xv, xb = comp
+                if not times.is_cuda:
+                    self._grid_hint = float(times[0])       # one shared grid: the engine need not read the tensors back
                 mk = lambda x: sampling._paths(times.to(self.device), x.to(self.device))  # noqa: E731
                 return [(mk(xu), mk(xv), mk(xb))]
             return list(points)
@@ -266,7 +269,7 @@ class NODE_WAN_solver:
                 shards = self._shard(self._groups(points))
                 if len(self._group_cache) != len(shards):
                     self._group_cache = [None] * len(shards)
-                groups = [eng.load_group(du, dv, bd, domain, ng, nbg, into=old)
+                groups = [eng.load_group(du, dv, bd, domain, ng, nbg, into=old, shared_grid_t0=self._grid_hint)
                           for (du, dv, bd, ng, nbg), old in zip(shards, self._group_cache)]
                 self._group_cache = groups
                 several = len(groups) > 1
