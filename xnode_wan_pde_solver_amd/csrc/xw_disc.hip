@@ -158,7 +158,7 @@ __global__ void __launch_bounds__(256, 2) k_disc_fwd(const double* __restrict__ 
         const double bd = av > 0.0 ? adi[ks >> 2][ks & 3] : 0.0;
         if (ACT) {   // activation store: row j W + k of the record is the layer input relu(a_j)[k], point-major
           double* __restrict__ rowp = actl + (j * W + 4 * ks) * 16;             // uniform pointer + 32-bit lane offset
-          if (4 * ks + 3 < W || 4 * ks + g < W) rowp[aoff] = b;                 // (unconditional but for the last k-step)
+          if (4 * ks + 3 < W || 4 * ks + g < W) __builtin_nontemporal_store(b, rowp + aoff);   // (streamed: read once, much later)
         }
         if ((ks & 1) == 0) asm volatile("" ::: "memory");   // bound the LDS loads in flight (else all 52 are hoisted -> spills)
 #pragma unroll
@@ -214,7 +214,7 @@ __global__ void __launch_bounds__(256, 2) k_disc_fwd(const double* __restrict__ 
         if (16 * mt + 4 * r < W) {  // rows 16 mt + 4 r + g >= W only carry zero padding
           const double th = xw_tanh(a[mt][r]);
           if (ACT && (16 * mt + 4 * r + 3 < W || 16 * mt + 4 * r + g < W))
-            (actl + (q * W + 16 * mt + 4 * r) * 16)[aoff] = th;                // last rows of the record: tanh(a_q)
+            __builtin_nontemporal_store(th, actl + (q * W + 16 * mt + 4 * r) * 16 + aoff);   // last rows: tanh(a_q)
           const double vo = sB[16 * D::MT + 16 * mt + g + 4 * r];
           sv += vo * th;
           sd += vo * (1.0 - th * th) * ad[mt][r];
@@ -652,7 +652,7 @@ __global__ void __launch_bounds__(256, 2) k_disc_rec(const double* __restrict__ 
         for (int q_ = 0; q_ < 4; ++q_)
           if (q_ < D::LR(mt)) {
             const int row = 16 * mt + 4 * q_ + g;
-            r[mt][q_] = (16 * mt + 4 * q_ + 3 < W || row < W) ? (base + (16 * mt + 4 * q_) * 16)[aoff] : 0.0;
+            r[mt][q_] = (16 * mt + 4 * q_ + 3 < W || row < W) ? __builtin_nontemporal_load(base + (16 * mt + 4 * q_) * 16 + aoff) : 0.0;
           }
     };
     d4 a[D::MT], rnext[D::MT];

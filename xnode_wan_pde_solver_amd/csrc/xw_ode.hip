@@ -429,7 +429,7 @@ __device__ __forceinline__ void act_store(double* __restrict__ A, int row0, int 
   for (int r = 0; r < 4; ++r)
     if (4 * r < nrows) {
       double* __restrict__ rowp = A + (long)(row0 + 4 * r) * N;             // uniform
-      if (g + 4 * r < nrows && q.valid) rowp[q.off] = v[r];
+      if (g + 4 * r < nrows && q.valid) __builtin_nontemporal_store(v[r], rowp + q.off);   // (streamed: read once, by a sweep)
     }
 }
 __device__ __forceinline__ d4 act_load(const double* __restrict__ A, int row0, int nrows, int N, const ActLane& q) {
@@ -438,7 +438,7 @@ __device__ __forceinline__ d4 act_load(const double* __restrict__ A, int row0, i
   for (int r = 0; r < 4; ++r)
     if (4 * r < nrows) {
       const double* __restrict__ rowp = A + (long)(row0 + 4 * r) * N;       // uniform
-      v[r] = rowp[4 * r + 4 <= nrows ? q.off : q.off_part];                  // padding rows: any finite value
+      v[r] = __builtin_nontemporal_load(rowp + (4 * r + 4 <= nrows ? q.off : q.off_part));   // padding rows: any finite value
     }
   return v;
 }
