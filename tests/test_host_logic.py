@@ -111,6 +111,12 @@ def test_cabi_exports_match_header():
         m = re.search(r'int\s+' + name + r'\s*\((.*?)\)\s*;', hdr, flags=re.S)
         n_hdr = 0 if m.group(1).strip() == 'void' else len(m.group(1).split(','))
         assert n_hdr == len(args), name
+    # the job structs: same field names in the same order as the ctypes mirrors
+    for cname, ctype in (('XwOdeFwdJob', _lib.XwOdeFwdJob), ('XwOdeBwdJob', _lib.XwOdeBwdJob)):
+        body = re.search(r'typedef struct \{([^}]*)\}\s*' + cname + r'\s*;', hdr).group(1)
+        body = re.sub(r'/\*.*?\*/', '', body, flags=re.S)
+        fields = [re.split(r'[\s\*]+', decl.strip())[-1] for decl in body.split(';') if decl.strip()]
+        assert fields == [f[0] for f in ctype._fields_], (cname, fields)
     # host-side (no GPU) entry points are callable
     assert _lib.lib.xw_abi_version() == _lib.ABI_VERSION
     assert _lib.lib.xw_theta_size(20, 20, 10) == 1651 and _lib.lib.xw_phi_size(20, 50) == 3701
