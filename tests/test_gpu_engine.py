@@ -449,3 +449,23 @@ def test_notebook_flow_runs_end_to_end(tmp_path, monkeypatch):
     files = set(os.listdir(tmp_path))
     assert {'losses_NODE_5.json', 'L2_NODE_5.json', 'Time_NODE_5.json', 'best_model_weights_NODE.pth'} <= files
     assert any(f.endswith('.png') for f in files), files
+
+
+def test_sampling_drawn_ahead_changes_nothing(tmp_path, monkeypatch):
+    """train() draws the next host samples on a helper thread while the GPU works (solver.overlap_sampling): the losses,
+    the parameters and the position of both random generators afterwards are those of the in-line loop"""
+    monkeypatch.chdir(tmp_path)
+    params = {'alpha': 1e3, 'u_layers': 8, 'u_hidden_dim': 20, 'u_hidden_hidden_dim': 10, 'v_layers': 9, 'v_hidden_dim': 50,
+              'n1': 2, 'n2': 1, 'u_rate': 0.015, 'v_rate': 0.04, 'min_steps': 5, 'adjoint': False, 'solver': 'midpoint',
+              'dim': 4, 'N_t': 8, 'N_r': 96, 'N_b': 48, 'T0': 0, 'T': 1, 'shape_param': [-1, 1], 'iterations': 7,
+              'domain': 'Hypercube'}
+    out = []
+    for ahead in (True, False):
+        S = make_solver(params, 11)
+        S.overlap_sampling = ahead
+        losses = list(S.train())
+        out.append((losses, S.engine.theta.data.clone(), S.engine.phi.data.clone(), torch.get_rng_state().clone(),
+                    np.random.get_state()[1].copy(), open('losses_NODE_4.json').read(), open('L2_NODE_4.json').read()))
+    a, b = out
+    assert a[0] == b[0] and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    assert torch.equal(a[3], b[3]) and (a[4] == b[4]).all() and a[5] == b[5] and a[6] == b[6]
