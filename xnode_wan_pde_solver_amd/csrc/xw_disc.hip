@@ -115,7 +115,14 @@ __global__ void __launch_bounds__(256, 2) k_disc_fwd(const double* __restrict__ 
     }
   __syncthreads();
   const double vob = ph[o.Vob];
-  for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long)gridDim.x * 4) {
+  // Static split: wave gw takes tiles gw, gw + G, ... (G waves in the grid), so ntiles mod G waves carry one tile more
+  // than the others.  The tiles of the first time index also run the fused reverse chain (about one more tile's worth of
+  // work): the first round is rotated so that THEY land on waves with the smaller count -- the launch ends with the
+  // slowest wave, 6 tile-times instead of 7 at the headline size (5.33 tiles per wave).
+  const long G = (long)gridDim.x * 4;
+  const long rot = ntiles >= G ? ntiles % G : 0;
+  for (long it = (long)blockIdx.x * 4 + wave; it < ntiles; it += G) {
+    const long tile = it < G ? it - rot + (it < rot ? G : 0) : it;
     const Pt pt = locate(tile, P, N, tf, tpp);
     // nabla phi is only read at the first time index: the leading `ngrad` points (time-major
     // order) also get the input gradient of v, by a reverse chain through the masks stashed below
