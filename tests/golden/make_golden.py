@@ -67,7 +67,12 @@ odeint_adjoint = odeint
 '''
 
 
-def load_reference():
+def load_reference(funcs_module='configs.Ex4_1_funcs', dim=None):
+    """funcs_module = 'configs.Ex4_3_funcs' needs a third harness-level shim: that file reads
+    the dimension from `NODE_GAN.main.params` (configs/Ex4_3_funcs.py:3), a module that does not exist in the reference
+    tree; a stand-in module carrying only {'dim': dim} is registered before the import."""
+    if 'src.training' in sys.modules and getattr(load_reference, 'ready', False):
+        return _reference_modules(funcs_module, dim)
     shim = tempfile.mkdtemp(prefix='tdq_standin_')
     os.makedirs(os.path.join(shim, 'torchdiffeq'))
     with open(os.path.join(shim, 'torchdiffeq', '__init__.py'), 'w') as fh:
@@ -81,8 +86,21 @@ def load_reference():
     class _NP:
         sum = staticmethod(builtins.sum)
     sys.modules['src.loss'].np = _NP
+    load_reference.ready = True
+    return _reference_modules(funcs_module, dim)
+
+
+def _reference_modules(funcs_module, dim):
     import importlib
-    funcs = importlib.import_module('configs.Ex4_1_funcs')
+    import types
+    if funcs_module.endswith('Ex4_3_funcs'):
+        if 'NODE_GAN.main' not in sys.modules:
+            pkg, main = types.ModuleType('NODE_GAN'), types.ModuleType('NODE_GAN.main')
+            main.params = {}
+            pkg.main = main
+            sys.modules['NODE_GAN'], sys.modules['NODE_GAN.main'] = pkg, main
+        sys.modules['NODE_GAN.main'].params['dim'] = dim      # (the functions read params['dim'] at call time)
+    funcs = importlib.import_module(funcs_module)
     return sys.modules['src.training'], sys.modules['src.dataset'], sys.modules['src.loss'], funcs
 
 
@@ -260,17 +278,19 @@ def trajectory(case, d, N_r, N_b, N_t, seed, outer_iters, gpu_loader_semantics):
     print('wrote', path, 'steps', len(log), 'wall %.1fs' % wall, 'final rel-L2', log[-1])
 
 
-def sphere_groups(case, domain_name, d, N_r, N_b, N_t, seed):
+def sphere_groups(case, domain_name, d, N_r, N_b, N_t, seed, funcs_module='configs.Ex4_1_funcs'):
     """Time-varying ball domains (src/dataset.py:48-229): the sampled groups themselves, and one generator sub-iteration,
     one more, and one discriminator sub-iteration over hand-paired (interior, boundary) groups with the reference's own
     modules -- zero_grad() once per sub-iteration, optimizer.step() after every group (src/training.py:127-138,152-162),
     GPU loader semantics (fresh copies per pass).  Only groups with >= 2 samples and boundary times != T0 are used:
     for single-slice groups the reference returns [N,1] instead of [N,1,1] (src/model.py:89-91) and its loss broadcasts
     to [N,N] pairwise terms (src/loss.py:65,79,84); the engine implements the elementwise intent there."""
-    training, dataset, lossmod, F = load_reference()
+    training, dataset, lossmod, F = load_reference(funcs_module, d)
     params = make_params(d, N_r, N_b, N_t, 'midpoint')
     params['domain'] = domain_name
     params['shape_param'] = 1.0
+    if not funcs_module.endswith('Ex4_1_funcs'):
+        params['funcs'] = funcs_module.split('.')[-1]      # (read back by the tests to pick the callables)
     dev = torch.device('cpu')
     torch.manual_seed(seed)
     np.random.seed(seed)
@@ -401,9 +421,16 @@ if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('--traj', action='store_true', help='also produce the 800-step trajectory fixtures (slow)')
     ap.add_argument('--only-traj', action='store_true')
+    ap.add_argument('--round2', action='store_true', help='only the fixtures added in round 2 (BASELINE configs[2], configs[4])')
     args = ap.parse_args()
     torch.set_num_threads(4)
-    if not args.only_traj:
+    if args.round2 or not args.only_traj:
+        # BASELINE configs[2] shape family: d = 50, N_t = 64 (small N so that the reference runs in seconds)
+        one_iteration('ref_d50_nt64_small_midpoint', 50, 32, 100, 64, 4, 'midpoint', False)
+        # BASELINE configs[4]: the time-varying ball domains with the Ex4_3 functions at d = 10
+        sphere_groups('ref_cone_ex43_d10_groups', 'NSphere_TCone', 10, 384, 120, 12, 2, 'configs.Ex4_3_funcs')
+        sphere_groups('ref_hourglass_ex43_d10_groups', 'NSphere_THourglass', 10, 384, 120, 12, 2, 'configs.Ex4_3_funcs')
+    if not args.only_traj and not args.round2:
         fillt_vectors()
         bound_pad_vectors()
         bound_pad_hourglass_vectors()

@@ -22,7 +22,8 @@ pytestmark = pytest.mark.gpu
 
 import configs.Ex4_1_funcs as P  # noqa: E402
 
-CASES = ['ref_tiny_midpoint', 'ref_tiny_euler', 'ref_tiny_rk4', 'ref_plumb_midpoint', 'ref_d20_small_midpoint']
+CASES = ['ref_tiny_midpoint', 'ref_tiny_euler', 'ref_tiny_rk4', 'ref_plumb_midpoint', 'ref_d20_small_midpoint',
+         'ref_d50_nt64_small_midpoint']       # the last one: BASELINE configs[2] family (d = 50, N_t = 64)
 FUNCS = dict(h=P.func_h, f=P.func_f, g=P.func_g, a=P.func_a, b=P.func_b, c=P.func_c)
 
 
@@ -31,12 +32,12 @@ def load(golden_dir, case):
     return z, json.loads(str(z['params_json']))
 
 
-def make_solver(params, seed, **kw):
+def make_solver(params, seed, F=P, **kw):
     from src.training import NODE_WAN_solver
     torch.manual_seed(seed)
     np.random.seed(seed)
-    return NODE_WAN_solver(params, P.func_a, P.func_b, P.func_c, P.func_h, P.func_f, P.func_g, torch.device('cuda'), './',
-                           func_u_sol=P.func_u_sol, p=2, **kw)
+    return NODE_WAN_solver(params, F.func_a, F.func_b, F.func_c, F.func_h, F.func_f, F.func_g, torch.device('cuda'), './',
+                           func_u_sol=F.func_u_sol, p=2, **kw)
 
 
 def _np(x):
@@ -271,7 +272,9 @@ def test_trained_error_trajectory_matches_reference(golden_dir, tmp_path):
     assert 'module.ODE_rhs.net.14.weight' in sd and sd['module.final_linear.weight'].shape == (1, 20)
 
 
-@pytest.mark.parametrize('case,name', [('ref_cone_groups', 'NSphere_TCone'), ('ref_hourglass_groups', 'NSphere_THourglass')])
+@pytest.mark.parametrize('case,name', [('ref_cone_groups', 'NSphere_TCone'), ('ref_hourglass_groups', 'NSphere_THourglass'),
+                                       ('ref_cone_ex43_d10_groups', 'NSphere_TCone'),
+                                       ('ref_hourglass_ex43_d10_groups', 'NSphere_THourglass')])
 def test_sphere_domain_groups_against_reference_vectors(golden_dir, case, name):
     """time-varying ball domains (BASELINE config 5 family): float64 groups of different lengths, late-entry groups that
     start on the moving boundary (g start values), time-dependent weight w, single-time boundary groups, and the
@@ -279,14 +282,24 @@ def test_sphere_domain_groups_against_reference_vectors(golden_dir, case, name):
     from src.dataset import Comb_loader
     from utils.auxillary_funcs import L_norm
     z, params = load(golden_dir, case)
-    S = make_solver(params, int(z['seed']))
+    # the last two cases are BASELINE configs[4]: the Ex4_3 problem (configs/Ex4_3_funcs.py:6-49 of the reference: every
+    # coordinate enters u_sol, c = -u) at d = 10, recorded from the reference with its own Ex4_3 callables
+    F = P
+    if params.pop('funcs', 'Ex4_1_funcs') == 'Ex4_3_funcs':
+        import configs.Ex4_3_funcs as F
+    assert params['domain'] == name
+    S = make_solver(params, int(z['seed']), F=F)
     s = S.setup
     domain = S.domain(s['shape_param'], s['dim'], s['T0'], s['T'], s['N_t'])
     pts = Comb_loader(s['N_r'], s['N_b'], domain, S.device)
-    assert len(pts.interioru) == int(z['n_interior'])
+    assert len(pts.interioru) == int(z['n_interior']) and len(pts.boundary) == int(z['n_boundary'])
+    for k, g_ in enumerate(pts.interioru):
+        assert np.array_equal(g_.detach().cpu().numpy(), z['interior/%d' % k]), 'interior group %d' % k
+    for k, g_ in enumerate(pts.boundary):
+        assert np.array_equal(g_.detach().cpu().numpy(), z['boundary/%d' % k]), 'boundary group %d' % k
     # (the reference's L_norm broadcasts [N,1] - [N] to [N,N] on single-slice groups, utils/auxillary_funcs.py:19, so its
     #  list-domain diagnostic is not comparable; the product computes the elementwise norm)
-    assert np.isfinite(float(L_norm(pts.interioru, S.u_net, 2, P.func_u_sol, domain.V(), s['N_r'])))
+    assert np.isfinite(float(L_norm(pts.interioru, S.u_net, 2, F.func_u_sol, domain.V(), s['N_r'])))
     eng = S.engine
     pairs = [tuple(p) for p in z['pairs']]
     groups = [eng.load_group(pts.interioru[ki], pts.interiorv[ki], pts.boundary[kb], domain) for ki, kb in pairs]

@@ -1,6 +1,7 @@
 """Parity at the BASELINE.json sizes (where the oracle would take minutes): size-independent properties of the kernels.
 
-Sizes: configs[1] (headline: d=20, N=4096 paths, L=32 times) and the per-GPU share of configs[3] (d=100, N=8192, L=32).
+Sizes: configs[1] (headline: d=20, N=4096 paths, L=32 times), the per-GPU shares of configs[2] (d=50, N=2048, L=64) and
+configs[3] (d=100, N=8192, L=32), and configs[4] (Ex4_3 on the time-varying balls, d=10, N_r=N_b=8192, N_t=20) whole.
 Properties: linearity of the reverse sweeps / the test-network backward in their cotangent, agreement of the fused and
 the separate forms (pollution sweep + nabla_x u, stored activations vs recompute, fused vs stand-alone input gradient),
 equivariance under a permutation of the paths, the reductions against a second formulation in torch on the same device,
@@ -13,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 F64 = torch.float64
 H, K, M, W, Q = 20, 10, 8, 50, 9
-SIZES = [(20, 4096, 32), (100, 8192, 32)]
+SIZES = [(20, 4096, 32), (50, 2048, 64), (100, 8192, 32)]      # configs[1]; per-GPU shares of configs[2] and configs[3]
 
 
 def _rel(a, b):
@@ -185,3 +186,54 @@ def test_headline_substeps_are_bit_reproducible():
         outs.append((S.engine.theta.data.clone(), S.engine.phi.data.clone(), S.engine.scal.clone()))
         assert torch.isfinite(outs[-1][0]).all() and torch.isfinite(outs[-1][1]).all()
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+
+
+@pytest.mark.parametrize('name', ['NSphere_TCone', 'NSphere_THourglass'])
+def test_config5_time_varying_ball_at_full_size(name, tmp_path, monkeypatch):
+    """BASELINE configs[4]: Ex4_3 functions (configs/Ex4_3_funcs.py:6-49 of the reference) on the time-varying balls
+    (src/dataset.py:48-229), d = 10, N_r = N_b = 8192, N_t = 20 -- the whole list-domain protocol at full size: the
+    groups the engine steps through are the sampler's (every path in exactly one interior group, equal lengths inside a
+    group, inside the domain, boundary groups on the boundary), one outer iteration (n1 = 2 generator + n2 = 1
+    discriminator sub-iterations, one optimiser step per group) is finite and bit-reproducible from the seed."""
+    import configs.Ex4_3_funcs as F
+    from src.training import NODE_WAN_solver
+    from src.dataset import Comb_loader
+    monkeypatch.chdir(tmp_path)
+    d, N_r, N_t = 10, 8192, 20
+    params = {'alpha': 1e4, 'u_layers': 8, 'u_hidden_dim': 20, 'u_hidden_hidden_dim': 10, 'v_layers': 9, 'v_hidden_dim': 50,
+              'n1': 2, 'n2': 1, 'u_rate': 0.015, 'v_rate': 0.04, 'min_steps': 5, 'adjoint': False, 'solver': 'midpoint',
+              'dim': d, 'N_t': N_t, 'N_r': N_r, 'N_b': N_r, 'T0': 0, 'T': 1, 'shape_param': 1.0, 'iterations': 1, 'domain': name}
+    outs = []
+    for rep in range(2):
+        torch.manual_seed(11)
+        np.random.seed(11)
+        S = NODE_WAN_solver(params, F.func_a, F.func_b, F.func_c, F.func_h, F.func_f, F.func_g, torch.device('cuda'), './',
+                            func_u_sol=F.func_u_sol, p=2)
+        assert S.engine.structure.a_identity and S.engine.structure.b_zero and S.engine.structure.c_kappa == -1.0
+        if rep == 0:
+            rng_t, rng_n = torch.get_rng_state(), np.random.get_state()
+            s = S.setup
+            domain = S.domain(s['shape_param'], d, s['T0'], s['T'], N_t)
+            pts = Comb_loader(N_r, N_r, domain, S.device)
+            torch.set_rng_state(rng_t)
+            np.random.set_state(rng_n)
+            # the sampler's groups
+            assert isinstance(pts.interioru, list) and len(pts.interioru) >= 2 and len(pts.boundary) >= 2
+            n_paths = 0
+            for g_ in pts.interioru:
+                assert g_.dtype == F64 and g_.shape[2] == d + 1 and 1 <= g_.shape[1] <= N_t
+                assert bool(torch.all(g_[:, 1:, 0] >= g_[:, :-1, 0]))                        # sorted times along a path
+                assert bool(torch.all(g_[:, :, 1:] == g_[:, :1, 1:]))                         # vertical paths
+                assert float(domain.func_w(g_.detach()).min()) >= -1e-12                      # inside the moving ball
+                n_paths += g_.shape[0] if float(g_[0, 0, 0]) == 0.0 or name == 'NSphere_TCone' else 0
+            if name == 'NSphere_TCone':
+                assert n_paths == N_r                                                         # every path in exactly one group
+            for g_ in pts.boundary:
+                assert g_.shape[1] == 1 and float(domain.func_w(g_.detach()).abs().max()) < 1e-9
+            n_groups = min(len(pts.interioru), len(pts.boundary))
+        losses = S.train()
+        assert len(losses) == 2 and all(np.isfinite(losses))
+        assert int(S.engine.adam_u['step'].item()) == 2 * n_groups and int(S.engine.adam_v['step'].item()) == n_groups
+        assert torch.isfinite(S.engine.theta.data).all() and torch.isfinite(S.engine.phi.data).all()
+        outs.append((list(losses), S.engine.theta.data.clone(), S.engine.phi.data.clone()))
+    assert outs[0][0] == outs[1][0] and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])

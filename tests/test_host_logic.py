@@ -14,7 +14,7 @@ import configs.Ex4_1_funcs as P
 from xnode_wan_pde_solver_amd import sampling, solver as S, _lib
 from xnode_wan_pde_solver_amd.engine import Structure
 
-CASES = ['ref_tiny_midpoint', 'ref_plumb_midpoint', 'ref_d20_small_midpoint']
+CASES = ['ref_tiny_midpoint', 'ref_plumb_midpoint', 'ref_d20_small_midpoint', 'ref_d50_nt64_small_midpoint']
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -148,9 +148,12 @@ def test_product_never_imports_the_oracle():
     assert 'oracle' not in main_txt
 
 
-@pytest.mark.parametrize('case,name', [('ref_cone_groups', 'NSphere_TCone'), ('ref_hourglass_groups', 'NSphere_THourglass')])
+@pytest.mark.parametrize('case,name', [('ref_cone_groups', 'NSphere_TCone'), ('ref_hourglass_groups', 'NSphere_THourglass'),
+                                       ('ref_cone_ex43_d10_groups', 'NSphere_TCone'),              # BASELINE configs[4]:
+                                       ('ref_hourglass_ex43_d10_groups', 'NSphere_THourglass')])   # d = 10, Ex4_3 functions
 def test_sphere_domains_sample_like_the_reference(golden_dir, case, name):
     z, params = load(golden_dir, case)
+    params.pop('funcs', None)
     config, setup, _ = S.split_params(params)
     torch.manual_seed(int(z['seed']))
     np.random.seed(int(z['seed']))
