@@ -293,10 +293,12 @@ def test_sphere_domain_groups_against_reference_vectors(golden_dir, case, name):
     domain = S.domain(s['shape_param'], s['dim'], s['T0'], s['T'], s['N_t'])
     pts = Comb_loader(s['N_r'], s['N_b'], domain, S.device)
     assert len(pts.interioru) == int(z['n_interior']) and len(pts.boundary) == int(z['n_boundary'])
+    # (bit-exact in this container, tests/test_host_logic.py; the GPU box's host CPU rounds a few of the float64 entry
+    #  times of late-entry paths differently in the last bit)
     for k, g_ in enumerate(pts.interioru):
-        assert np.array_equal(g_.detach().cpu().numpy(), z['interior/%d' % k]), 'interior group %d' % k
+        close(g_, z['interior/%d' % k], 1e-13, 1e-15, 'interior group %d' % k)
     for k, g_ in enumerate(pts.boundary):
-        assert np.array_equal(g_.detach().cpu().numpy(), z['boundary/%d' % k]), 'boundary group %d' % k
+        close(g_, z['boundary/%d' % k], 1e-13, 1e-15, 'boundary group %d' % k)
     # (the reference's L_norm broadcasts [N,1] - [N] to [N,N] on single-slice groups, utils/auxillary_funcs.py:19, so its
     #  list-domain diagnostic is not comparable; the product computes the elementwise norm)
     assert np.isfinite(float(L_norm(pts.interioru, S.u_net, 2, F.func_u_sol, domain.V(), s['N_r'])))

@@ -225,7 +225,7 @@ def test_config5_time_varying_ball_at_full_size(name, tmp_path, monkeypatch):
                 assert bool(torch.all(g_[:, 1:, 0] >= g_[:, :-1, 0]))                        # sorted times along a path
                 assert bool(torch.all(g_[:, :, 1:] == g_[:, :1, 1:]))                         # vertical paths
                 assert float(domain.func_w(g_.detach()).min()) >= -1e-12                      # inside the moving ball
-                n_paths += g_.shape[0] if float(g_[0, 0, 0]) == 0.0 or name == 'NSphere_TCone' else 0
+                n_paths += g_.shape[0] if float(g_.detach()[0, 0, 0]) == 0.0 or name == 'NSphere_TCone' else 0
             if name == 'NSphere_TCone':
                 assert n_paths == N_r                                                         # every path in exactly one group
             for g_ in pts.boundary:
