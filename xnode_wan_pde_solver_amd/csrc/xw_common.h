@@ -16,6 +16,11 @@
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 #define XW_MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
+// v_mfma_f64_4x4x4_4b_f64: four independent 4x4x4 products.  Lane maps (tools/probe_mfma4.hip):
+//     A[blk][i][k] : lane = i + 4 blk + 16 k      B[blk][k][j] : lane = j + 4 blk + 16 k      D[blk][i][j] : lane = j + 4 blk + 16 i
+// With the same A in all four blocks it is  D[4 rows x 16 columns] += A[4 x 4] B[4 x 16]: B is register k-block and D
+// register row-block of the chain layout below, so it chains like the 16x16x4 form, at 4-row granularity (18 clocks).
+#define XW_MFMA4(a, b, c) __builtin_amdgcn_mfma_f64_4x4x4f64((a), (b), (c), 0, 0, 0)
 
 #define XW_E_DIMS (-1)
 #define XW_E_ARG (-2)
@@ -83,6 +88,22 @@ __device__ __forceinline__ double xw_fragAT_l(const double* __restrict__ Mx, int
   const int r = r0 + (l & 15), c = c0 + (l >> 4);
   return (r < cols && c < rows) ? Mx[c * ld + r] : 0.0;
 }
+// A-operand of XW_MFMA4: the 4x4 block (rows r0.., columns c0..) of a row-major matrix, replicated over the lane blocks
+__device__ __forceinline__ double xw_fragA4(const double* __restrict__ Mx, int ld, int rows, int cols, int r0, int c0) {
+  const int l = xw_lane();
+  const int r = r0 + (l & 3), c = c0 + (l >> 4);
+  return (r < rows && c < cols) ? Mx[r * ld + c] : 0.0;
+}
+// the same block of the TRANSPOSE of Mx
+__device__ __forceinline__ double xw_fragAT4(const double* __restrict__ Mx, int ld, int rows, int cols, int r0, int c0) {
+  const int l = xw_lane();
+  const int r = r0 + (l & 3), c = c0 + (l >> 4);
+  return (r < cols && c < rows) ? Mx[c * ld + r] : 0.0;
+}
+// relu of one register: v_max_f64 (+ the compiler's canonicalising v_max in front of it; NaN -> 0 like `x > 0 ? x : 0`).
+// NOT as inline asm: the hazard recogniser does not see into it and issues it right behind the MFMA that writes its
+// input (6 wait states are required there) -- wrong results.
+__device__ __forceinline__ double xw_relu1(double x) { return __builtin_fmax(x, 0.0); }
 // chain-layout vector broadcast over the 16 columns: rows r0 + g + 4 r of b[rows]
 __device__ __forceinline__ d4 xw_vecD(const double* __restrict__ b, int rows, int r0) {
   const int g = xw_lane() >> 4;

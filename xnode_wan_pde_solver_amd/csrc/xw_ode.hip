@@ -51,6 +51,8 @@ template <int H, int K> struct Dim {
   static constexpr int KSH = (H + 3) / 4;    // k-steps of a contraction over H
   static constexpr int KSK = (K + 3) / 4;    // k-steps of a contraction over K
   static constexpr int KR = (K + 1 + 3) / 4;   // live registers of a K-tile incl. the ones row (rows 0 .. K)
+  static constexpr int KB = (K + 3) / 4;     // 4-row blocks of a K-vector (= live registers of its chain tile)
+  static constexpr int HB = (H + 3) / 4;     // 4-row blocks of an H-vector
   __device__ static constexpr int HR(int ht) { return (H - 16 * ht) >= 16 ? 4 : (H - 16 * ht + 3) / 4; }        // rows of y
   __device__ static constexpr int HR1(int ht) { return (H + 1 - 16 * ht) >= 16 ? 4 : (H + 1 - 16 * ht + 3) / 4; }  // + time row
   static_assert(K <= 15, "one padding row of the K-tile carries the bias column of the outer products");
@@ -58,17 +60,23 @@ template <int H, int K> struct Dim {
   static_assert(HT <= 2, "H <= 31");
 };
 
-template <int H, int K> struct FieldW {      // forward operands
-  double Wy[Dim<H, K>::KSH];                 // Win[:, d+1:]  [K x H]
-  double Wh[Dim<H, K>::KSK];                 // Wh            [K x K]
-  double Wo[Dim<H, K>::HT][Dim<H, K>::KSK];  // Wo            [H x K]
+// The field's layers run on v_mfma_f64_4x4x4_4b_f64: one instruction = a 4x4 weight block times 4 rows x 16 paths of
+// the chain layout (its four "blocks" are the four groups of 4 paths; the weight block is replicated over them -- the
+// CBSZ/ABID broadcast does nothing on the f64 form, profiles/r02_probe_mfma4b.txt).  A [K x K] layer is KB x KB = 9
+// instructions of 18 clocks on KB INDEPENDENT accumulators instead of 3 dependent 16x16x4 instructions of 64 + 17 clocks
+// on a tile with 10 of 16 rows live: 185 instead of 276 clocks per layer for the lone wave of a stepper tile, 16 % less
+// matrix-pipe time when the chip is shared (same probe).
+template <int H, int K> struct FieldW {      // forward operands: 4x4 blocks (row block, k block)
+  double Wy[Dim<H, K>::KB][Dim<H, K>::HB];   // Win[:, d+1:]  [K x H]
+  double Wh[Dim<H, K>::KB][Dim<H, K>::KB];   // Wh            [K x K]
+  double Wo[Dim<H, K>::HB][Dim<H, K>::KB];   // Wo            [H x K]
   d4 wt, bh;                                 // Win[:, d] (time column), Wh.b
   d4 bo[Dim<H, K>::HT];                      // Wo.b
 };
 template <int H, int K> struct FieldWT {     // transposed operands for the vector-Jacobian product
-  double WyT[Dim<H, K>::HT][Dim<H, K>::KSK]; // [H x K]
-  double WhT[Dim<H, K>::KSK];                // [K x K]
-  double WoT[Dim<H, K>::KSH];                // [K x H]
+  double WyT[Dim<H, K>::HB][Dim<H, K>::KB];  // [H x K]
+  double WhT[Dim<H, K>::KB][Dim<H, K>::KB];  // [K x K]
+  double WoT[Dim<H, K>::KB][Dim<H, K>::HB];  // [K x H]
 };
 template <int M> struct Save {               // what the VJP of one field evaluation needs
   d4 z[M > 1 ? M - 1 : 1];                   // relu(z_0) .. relu(z_{m-2}): layer inputs; their sign pattern is the ReLU mask
@@ -89,15 +97,18 @@ __device__ __forceinline__ void load_field(const double* __restrict__ th, const 
   typedef Dim<H, K> D;
   const double* Wy = th + o.Win + d + 1;
 #pragma unroll
-  for (int ks = 0; ks < D::KSH; ++ks) w.Wy[ks] = xw_fragA(Wy, o.ldin, K, H, 0, 4 * ks);
+  for (int rb = 0; rb < D::KB; ++rb) {
 #pragma unroll
-  for (int ks = 0; ks < D::KSK; ++ks) w.Wh[ks] = xw_fragA(th + o.Wh, K, K, K, 0, 4 * ks);
+    for (int kb = 0; kb < D::HB; ++kb) w.Wy[rb][kb] = xw_fragA4(Wy, o.ldin, K, H, 4 * rb, 4 * kb);
 #pragma unroll
-  for (int ht = 0; ht < D::HT; ++ht) {
-#pragma unroll
-    for (int ks = 0; ks < D::KSK; ++ks) w.Wo[ht][ks] = xw_fragA(th + o.Wo, K, H, K, 16 * ht, 4 * ks);
-    w.bo[ht] = xw_vecD(th + o.Wob, H, 16 * ht);
+    for (int kb = 0; kb < D::KB; ++kb) w.Wh[rb][kb] = xw_fragA4(th + o.Wh, K, K, K, 4 * rb, 4 * kb);
   }
+#pragma unroll
+  for (int rb = 0; rb < D::HB; ++rb)
+#pragma unroll
+    for (int kb = 0; kb < D::KB; ++kb) w.Wo[rb][kb] = xw_fragA4(th + o.Wo, K, H, K, 4 * rb, 4 * kb);
+#pragma unroll
+  for (int ht = 0; ht < D::HT; ++ht) w.bo[ht] = xw_vecD(th + o.Wob, H, 16 * ht);
   w.wt = xw_vecD_strided(th + o.Win + d, o.ldin, K, 0);
   w.bh = xw_vecD(th + o.Whb, K, 0);
 }
@@ -106,13 +117,16 @@ __device__ __forceinline__ void load_field_T(const double* __restrict__ th, cons
   typedef Dim<H, K> D;
   const double* Wy = th + o.Win + d + 1;
 #pragma unroll
-  for (int ht = 0; ht < D::HT; ++ht)
+  for (int rb = 0; rb < D::HB; ++rb)
 #pragma unroll
-    for (int ks = 0; ks < D::KSK; ++ks) w.WyT[ht][ks] = xw_fragAT(Wy, o.ldin, K, H, 16 * ht, 4 * ks);
+    for (int kb = 0; kb < D::KB; ++kb) w.WyT[rb][kb] = xw_fragAT4(Wy, o.ldin, K, H, 4 * rb, 4 * kb);
 #pragma unroll
-  for (int ks = 0; ks < D::KSK; ++ks) w.WhT[ks] = xw_fragAT(th + o.Wh, K, K, K, 0, 4 * ks);
+  for (int rb = 0; rb < D::KB; ++rb) {
 #pragma unroll
-  for (int ks = 0; ks < D::KSH; ++ks) w.WoT[ks] = xw_fragAT(th + o.Wo, K, H, K, 0, 4 * ks);
+    for (int kb = 0; kb < D::KB; ++kb) w.WhT[rb][kb] = xw_fragAT4(th + o.Wh, K, K, K, 4 * rb, 4 * kb);
+#pragma unroll
+    for (int kb = 0; kb < D::HB; ++kb) w.WoT[rb][kb] = xw_fragAT4(th + o.Wo, K, H, K, 4 * rb, 4 * kb);
+  }
 }
 
 // F([x, t, y]) of src/model.py:153-156: z0 = Win [x;t;y] + b (x part pre-contracted into xp), (m-1) tied ReLU layers,
@@ -131,34 +145,38 @@ template <int H, int K, int M, bool OUT = true, class Sink>
 __device__ __forceinline__ void field_fwd(const FieldW<H, K>& w, double t, d4 xp, const d4 (&y)[Dim<H, K>::HT],
                                           d4 (&out)[Dim<H, K>::HT], const Sink& sink) {
   typedef Dim<H, K> D;
+  // (k block outer, row block inner: consecutive instructions write different accumulators)
   d4 z = xw_zero4();
 #pragma unroll
-  for (int r = 0; r < D::KSK; ++r) z[r] = fma(w.wt[r], t, xp[r]);
+  for (int r = 0; r < D::KB; ++r) z[r] = fma(w.wt[r], t, xp[r]);
 #pragma unroll
-  for (int ks = 0; ks < D::KSH; ++ks) z = XW_MFMA(w.Wy[ks], y[ks >> 2][ks & 3], z);
+  for (int kb = 0; kb < D::HB; ++kb)
+#pragma unroll
+    for (int rb = 0; rb < D::KB; ++rb) z[rb] = XW_MFMA4(w.Wy[rb][kb], y[kb >> 2][kb & 3], z[rb]);
 #pragma unroll
   for (int j = 0; j < M - 1; ++j) {
     d4 r = xw_zero4();
 #pragma unroll
-    for (int ks = 0; ks < D::KSK; ++ks) r[ks] = z[ks] > 0.0 ? z[ks] : 0.0;
+    for (int kb = 0; kb < D::KB; ++kb) r[kb] = xw_relu1(z[kb]);
     sink.z(j, r);
     d4 nz = w.bh;
 #pragma unroll
-    for (int ks = 0; ks < D::KSK; ++ks) nz = XW_MFMA(w.Wh[ks], r[ks], nz);
+    for (int kb = 0; kb < D::KB; ++kb)
+#pragma unroll
+      for (int rb = 0; rb < D::KB; ++rb) nz[rb] = XW_MFMA4(w.Wh[rb][kb], r[kb], nz[rb]);
     z = nz;
   }
   d4 a = xw_zero4();
 #pragma unroll
-  for (int ks = 0; ks < D::KSK; ++ks) a[ks] = xw_tanh(z[ks]);
+  for (int kb = 0; kb < D::KB; ++kb) a[kb] = xw_tanh(z[kb]);
   sink.a(a);
   if (!OUT) return;
 #pragma unroll
-  for (int ht = 0; ht < D::HT; ++ht) {
-    d4 o = w.bo[ht];
+  for (int ht = 0; ht < D::HT; ++ht) out[ht] = w.bo[ht];
 #pragma unroll
-    for (int ks = 0; ks < D::KSK; ++ks) o = XW_MFMA(w.Wo[ht][ks], a[ks], o);
-    out[ht] = o;
-  }
+  for (int kb = 0; kb < D::KB; ++kb)
+#pragma unroll
+    for (int rb = 0; rb < D::HB; ++rb) out[rb >> 2][rb & 3] = XW_MFMA4(w.Wo[rb][kb], a[kb], out[rb >> 2][rb & 3]);
 }
 
 // parameter-gradient accumulators of the field (chain-layout tiles of the gradient matrices)
@@ -252,64 +270,132 @@ __device__ __forceinline__ void outer_post_ones(d4 q, d4 r, double* lds) {      
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_sched_barrier(0);
 }
-__device__ __forceinline__ void outer_take(d4& acc, const double* qt, const double* rt) {
+// The operand loads of an outer product are issued right behind its stores (the LDS executes one wave's accesses in
+// order) and BEFORE the chain's next matrix instructions, the four accumulating MFMAs after them: with the 18-clock
+// 4x4x4 chain a layer's 9 instructions no longer cover a store -> load -> use round trip started behind them (the sweep
+// with weight gradients stood at 209 us where the chain alone had gained 30 %).
+struct OuterOps { double a[4], b[4]; };
+__device__ __forceinline__ void outer_fetch(OuterOps& o, const double* qt, const double* rt) {
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    o.a[ks] = xw_readT(qt, ks);
+    o.b[ks] = xw_readT(rt, ks);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+// operands of two products that share one side (two row tiles against one R tile, or one Q tile against two R tiles)
+__device__ __forceinline__ void outer_fetch1(double (&x)[4], const double* t) {
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) x[ks] = xw_readT(t, ks);
+  __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ void outer_fire(d4& acc, const double (&a)[4], const double (&b)[4]) {
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) acc = XW_MFMA(xw_readT(qt, ks), xw_readT(rt, ks), acc);
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
+  for (int ks = 0; ks < 4; ++ks) acc = XW_MFMA(a[ks], b[ks], acc);
+  __builtin_amdgcn_sched_barrier(0);
 }
+// LDS plan of a sweep block (one wave): tiles of XW_TTILE doubles
+//   0 Q | 1 R | 2 R of K rows + a permanent row of ones | 3 second Q (last H row tile) | 4 second R (last H column tile)
+#define XW_SWEEP_TILES 5
 
 // vector-Jacobian product of one field evaluation.  ob: cotangent of F's output; returns the cotangent of the y input
 // in yb, adds the cotangent of z0 into xpb (= cotangent of the x-projection and of Win.b), and (PARAMS) accumulates the
 // parameter gradients (outer products over the 16 paths; a row of ones / the time row in the R tile makes the bias and
 // time-column gradients ride along as an extra accumulator column).
-template <int H, int K, int M, bool PARAMS, class SV>
+// OUTER: 0 = no weight gradients, 1 = this wave forms them itself (outer products through its own LDS tiles),
+//        2 = "duo" sweep: this wave only posts the cotangent tiles (transposed) into `lds` = the evaluation's Q buffer
+//            (DuoPlan), a partner wave of the block contracts them with the activations it loads itself.
+template <int H, int K, int M> struct DuoPlan {
+  static constexpr int HT = Dim<H, K>::HT;
+  static constexpr int NQ = HT + (M - 1) + 1;     // Q tiles of one field evaluation: cot(out) x HT, cot(z_{j+1}) for j = M-2 .. 0, cot(z_0)
+  static constexpr int BUF = NQ * XW_TTILE;       // doubles; two such buffers alternate
+};
+template <int H, int K, int M, int OUTER, class SV>
 __device__ __forceinline__ void field_vjp(const FieldW<H, K>& w, const FieldWT<H, K>& wT, double t, const SV& sv,
                                           const d4 (&yin)[Dim<H, K>::HT], const d4 (&ob)[Dim<H, K>::HT],
                                           d4 (&yb)[Dim<H, K>::HT], d4& xpb, FieldG<H, K>& G, double* lds) {
   typedef Dim<H, K> D;
+  constexpr bool PARAMS = OUTER == 1;
+  static_assert(D::HT <= 2, "two Q / R tile pairs in the LDS plan");
   const double* rt1 = lds + 2 * XW_TTILE;
-  if (PARAMS) outer_post_ones<D::HR(0), K>(ob[0], sv.a, lds);
+  OuterOps o0;
+  double q1[4];
+  if (OUTER == 2) {
+#pragma unroll
+    for (int ht = 0; ht < D::HT; ++ht) {
+      if (ht == 0) xw_writeT_n<D::HR(0)>(lds, ob[0]);
+      else xw_writeT_n<D::HR(D::HT - 1)>(lds + ht * XW_TTILE, ob[ht]);
+    }
+  }
+  if (PARAMS) {
+    outer_post_ones<D::HR(0), K>(ob[0], sv.a, lds);
+    if (D::HT > 1) {
+      xw_writeT_n<D::HR(D::HT - 1)>(lds + 3 * XW_TTILE, ob[D::HT - 1]);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    outer_fetch(o0, lds, rt1);
+    if (D::HT > 1) outer_fetch1(q1, lds + 3 * XW_TTILE);
+  }
   d4 ab = xw_zero4();
 #pragma unroll
-  for (int ks = 0; ks < D::KSH; ++ks) ab = XW_MFMA(wT.WoT[ks], ob[ks >> 2][ks & 3], ab);
-  if (PARAMS) {
-    outer_take(G.Wo[0], lds, rt1);
+  for (int kb = 0; kb < D::HB; ++kb)
 #pragma unroll
-    for (int ht = 1; ht < D::HT; ++ht) {
-      outer_post_ones<D::HR(1), K>(ob[ht], sv.a, lds);
-      outer_take(G.Wo[ht], lds, rt1);
-    }
+    for (int rb = 0; rb < D::KB; ++rb) ab[rb] = XW_MFMA4(wT.WoT[rb][kb], ob[kb >> 2][kb & 3], ab[rb]);
+  if (PARAMS) {
+    outer_fire(G.Wo[0], o0.a, o0.b);
+    if (D::HT > 1) outer_fire(G.Wo[D::HT - 1], q1, o0.b);
   }
   d4 zb = xw_zero4();
 #pragma unroll
   for (int r = 0; r < D::KSK; ++r) zb[r] = ab[r] * (1.0 - sv.a[r] * sv.a[r]);
 #pragma unroll
   for (int j = M - 2; j >= 0; --j) {
-    if constexpr (PARAMS) outer_post_ones<D::KSK, K>(zb, sv.z[j], lds);
+    if constexpr (PARAMS) {
+      outer_post_ones<D::KSK, K>(zb, sv.z[j], lds);
+      outer_fetch(o0, lds, rt1);
+    }
+    if (OUTER == 2) xw_writeT_n<D::KSK>(lds + (D::HT + (M - 2 - j)) * XW_TTILE, zb);
     d4 tt = xw_zero4();
 #pragma unroll
-    for (int ks = 0; ks < D::KSK; ++ks) tt = XW_MFMA(wT.WhT[ks], zb[ks], tt);
-    if (PARAMS) outer_take(G.Wh, lds, rt1);
+    for (int kb = 0; kb < D::KB; ++kb)
+#pragma unroll
+      for (int rb = 0; rb < D::KB; ++rb) tt[rb] = XW_MFMA4(wT.WhT[rb][kb], zb[kb], tt[rb]);
+    if (PARAMS) outer_fire(G.Wh, o0.a, o0.b);
 #pragma unroll
     for (int r = 0; r < D::KSK; ++r) zb[r] = sv.pos(j, r) ? tt[r] : 0.0;
   }
 #pragma unroll
   for (int r = 0; r < D::KSK; ++r) xpb[r] += zb[r];
-#pragma unroll
-  for (int ht = 0; ht < D::HT; ++ht) {
-    if (PARAMS) {
-      d4 yy = yin[ht];
-      if (ht == (H >> 4)) set_row(yy, H & 15, t);  // time row -> column H collects the time-column gradient
-      if (ht == 0) outer_post<D::KSK, D::HR1(0)>(zb, yy, lds);
-      else outer_post<D::KSK, D::HR1(1)>(zb, yy, lds);
+  if (OUTER == 2) xw_writeT_n<D::KSK>(lds + (D::HT + M - 1) * XW_TTILE, zb);
+  double r1[4];
+  if (PARAMS) {
+    // one Q tile (the cotangent of z0) against the column tiles of [y ; t]: the time row makes column H collect the
+    // time-column gradient
+    d4 y0 = yin[0], y1 = yin[D::HT - 1];
+    if (D::HT == 1) set_row(y0, H & 15, t);
+    else set_row(y1, H & 15, t);
+    outer_post<D::KSK, D::HR1(0)>(zb, y0, lds);
+    if (D::HT > 1) {
+      xw_writeT_n<D::HR1(D::HT - 1)>(lds + 4 * XW_TTILE, y1);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
     }
-    d4 v = xw_zero4();
+    outer_fetch(o0, lds, lds + XW_TTILE);
+    if (D::HT > 1) outer_fetch1(r1, lds + 4 * XW_TTILE);
+  }
 #pragma unroll
-    for (int ks = 0; ks < D::KSK; ++ks) v = XW_MFMA(wT.WyT[ht][ks], zb[ks], v);
-    yb[ht] = v;
-    if (PARAMS) outer_take(G.Wy[ht], lds, lds + XW_TTILE);
+  for (int ht = 0; ht < D::HT; ++ht) yb[ht] = xw_zero4();
+#pragma unroll
+  for (int kb = 0; kb < D::KB; ++kb)
+#pragma unroll
+    for (int rb = 0; rb < D::HB; ++rb) yb[rb >> 2][rb & 3] = XW_MFMA4(wT.WyT[rb][kb], zb[kb], yb[rb >> 2][rb & 3]);
+  if (PARAMS) {
+    outer_fire(G.Wy[0], o0.a, o0.b);
+    if (D::HT > 1) outer_fire(G.Wy[D::HT - 1], o0.a, r1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
   static_assert((H + 1 + 15) / 16 == Dim<H, K>::HT, "the time column lives in the last H-tile");
 }
@@ -566,6 +652,27 @@ __device__ __forceinline__ void storeRowSums(double* dst, int rows, int r0, d4 q
   }
 }
 
+// the field's weight-gradient accumulators -> one slab
+template <int H, int K, bool HID = true, bool IO = true>
+__device__ __forceinline__ void store_field_grads(double* slab, const UOff& o, int d, const FieldG<H, K>& G) {
+  typedef Dim<H, K> D;
+  if (HID) {
+    storeD(slab + o.Wh, K, K, K, 0, 0, G.Wh);
+    storeDcol(slab + o.Whb, 1, K, 0, K, G.Wh);
+  }
+  if (!IO) return;
+#pragma unroll
+  for (int ct = 0; ct < (H + 1 + 15) / 16; ++ct) {
+    storeD(slab + o.Win + d + 1, o.ldin, K, H, 0, 16 * ct, G.Wy[ct]);
+    if (ct == (H >> 4)) storeDcol(slab + o.Win + d, o.ldin, K, 0, H & 15, G.Wy[ct]);
+  }
+#pragma unroll
+  for (int ht = 0; ht < D::HT; ++ht) {
+    storeD(slab + o.Wo, K, H, K, 16 * ht, 0, G.Wo[ht]);
+    storeDcol(slab + o.Wob, 1, H, 16 * ht, K, G.Wo[ht]);
+  }
+}
+
 // what the reverse of one step l -> l+1 needs from the forward pass: the stage inputs and the stage activations
 template <int H, int K, int M, int S> struct Rec {
   d4 yi[S][Dim<H, K>::HT];
@@ -652,15 +759,23 @@ __device__ __forceinline__ void load_stage(const double* __restrict__ Y, const d
 //       d/dt (y, a, theta-bar) = ( f(t, y), -a^T df/dy, -a^T df/dtheta ),
 //   then a += the cotangent of y(t_{i-1}).  Its parameter set is the field module's parameters; the sample point x is a
 //   plain attribute of that module, so no gradient reaches x through the field (only through the start value).
-template <int H, int K, int M, int METHOD, bool PARAMS, bool SAVED, bool ADJ = false>
-__global__ void __launch_bounds__(64) k_ode_bwd(const BwdJobs jobs, const double* __restrict__ tf,
-                                                const double* __restrict__ th, int L, int d) {
+// DUO (with PARAMS and SAVED): the "duo" sweep.  This wave runs the adjoint chain exactly like the sweep without weight
+//   gradients (ReLU mask words + tanh rows from the store) and posts the cotangent tiles of every field evaluation into
+//   one of two alternating LDS buffers (qbuf); a second wave of the block (duo_outer) contracts them with the layer
+//   inputs, which it loads from the activation store directly in operand layout -- one workgroup barrier per field
+//   evaluation.  One wave per 16 paths left three quarters of the SIMDs idle at N = 4096 and bound the sweep by the
+//   latency of ONE instruction stream (chain, LDS round trips, loads); the split doubles the waves and halves the stream.
+template <int H, int K, int M, int METHOD, bool PARAMS, bool SAVED, bool ADJ, bool DUO>
+__device__ __forceinline__ void sweep_body(const BwdJobs& jobs, const double* __restrict__ tf, const double* __restrict__ th,
+                                           int L, int d, double* lds, double* qbuf) {
   static_assert(!SAVED || RK<METHOD>::S <= 2, "the activation store is used by euler and midpoint");
   static_assert(!(SAVED && ADJ), "the continuous adjoint evaluates the field at its own stage points");
+  static_assert(!DUO || (PARAMS && SAVED), "the duo sweep is the sweep with weight gradients from the activation store");
   typedef Dim<H, K> D;
   typedef RK<METHOD> T;
+  constexpr int OUTER = DUO ? 2 : (PARAMS ? 1 : 0);
   __builtin_amdgcn_s_setprio(XW_ODE_PRIO);
-  __shared__ double lds[3 * XW_TTILE];          // Q tile | R tile | R tile of K rows + a permanent row of ones
+  int qflip = 0;                                 // DUO: which of the two Q buffers the next field evaluation posts into
   if (PARAMS) {
     if (xw_lane() < 16) lds[2 * XW_TTILE + K * XW_TSTRIDE + xw_lane()] = 1.0;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -735,7 +850,13 @@ __global__ void __launch_bounds__(64) k_ode_bwd(const BwdJobs jobs, const double
   auto reverse_stage = [&](int l, int i, const d4 (&yin)[D::HT], const auto& sv) {
     const double t0 = tf[l], dt = tf[l + 1] - t0;
     d4 psi[D::HT];
-    field_vjp<H, K, M, PARAMS>(w, wT, t0 + T::c(i) * dt, sv, yin, kb[i], psi, xpb, G, lds);
+    field_vjp<H, K, M, OUTER>(w, wT, t0 + T::c(i) * dt, sv, yin, kb[i], psi, xpb, G,
+                              DUO ? qbuf + qflip * DuoPlan<H, K, M>::BUF : lds);
+    if (DUO) {      // the tiles of this evaluation are complete: hand them over (the partner is one evaluation behind)
+      // (LDS only: a workgroup-scope release fence would also drain vmcnt, i.e. wait for the next stage's prefetch loads)
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      qflip ^= 1;
+    }
 #pragma unroll
     for (int ht = 0; ht < D::HT; ++ht) {
       t_add(psum[ht], psi[ht], D::HR(ht));
@@ -789,7 +910,7 @@ __global__ void __launch_bounds__(64) k_ode_bwd(const BwdJobs jobs, const double
           d4 cot[D::HT], psi[D::HT];
 #pragma unroll
           for (int ht = 0; ht < D::HT; ++ht) cot[ht] = (dt * T::b(i)) * as[ht];
-          field_vjp<H, K, M, PARAMS>(w, wT, ti, sv, ys, cot, psi, xpb, G, lds);
+          field_vjp<H, K, M, PARAMS ? 1 : 0>(w, wT, ti, sv, ys, cot, psi, xpb, G, lds);
 #pragma unroll
           for (int ht = 0; ht < D::HT; ++ht) {
             asum[ht] += psi[ht];
@@ -798,7 +919,7 @@ __global__ void __launch_bounds__(64) k_ode_bwd(const BwdJobs jobs, const double
         } else {
           d4 xdummy = xw_zero4();
           FieldG<H, K> Gd;                                       // (untouched: no parameter products in this call)
-          field_vjp<H, K, M, false>(w, wT, ti, sv, ys, as, ps[i], xdummy, Gd, lds);
+          field_vjp<H, K, M, 0>(w, wT, ti, sv, ys, as, ps[i], xdummy, Gd, lds);
         }
       }
 #pragma unroll
@@ -814,31 +935,49 @@ __global__ void __launch_bounds__(64) k_ode_bwd(const BwdJobs jobs, const double
       readout(L - 1, yl, load_ub(L - 1));
     }
     // (without weight gradients the sweep only needs tanh(z_{m-1}) and the ReLU masks of a stage)
-    typedef typename std::conditional<PARAMS, Save<M>, SaveX<M>>::type SV;
+    // (the duo sweep's chain wave neither: its partner reads the layer inputs)
+    typedef typename std::conditional<PARAMS && !DUO, Save<M>, SaveX<M>>::type SV;
     StageRec<H, K, M, SV> sa, sb;
+    // y_l for the read-out layer's weight gradient: the stage-0 record carries it, except in the duo sweep
+    auto y_of = [&](int l, const d4 (&rec)[D::HT], d4 (&yl)[D::HT]) {
+      if (DUO) load_ckpt<H, K>(Y, l, N, ncl, yl);
+      else {
+#pragma unroll
+        for (int ht = 0; ht < D::HT; ++ht) yl[ht] = rec[ht];
+      }
+    };
     if constexpr (T::S == 2) {
       // stage 1 always lives in sa, stage 0 in sb: each is loaded while the other one is reversed
       if (L > 1) load_stage<H, K, M, METHOD>(Y, act, L - 2, 1, N, ncl, sa);
       for (int l = L - 2; l >= 0; --l) {
         const double ub = load_ub(l);
+        d4 yl[D::HT];
         load_stage<H, K, M, METHOD>(Y, act, l, 0, N, ncl, sb);
+        y_of(l, sb.yi, yl);
         begin_step(l);
         reverse_stage(l, 1, sa.yi, sa.sv);
         load_stage<H, K, M, METHOD>(Y, act, l > 0 ? l - 1 : 0, 1, N, ncl, sa);
         reverse_stage(l, 0, sb.yi, sb.sv);
-        end_step(l, sb.yi, ub);                           // stage 0's input is y_l itself
+        end_step(l, yl, ub);                              // stage 0's input is y_l itself
       }
     } else {
       if (L > 1) load_stage<H, K, M, METHOD>(Y, act, L - 2, 0, N, ncl, sa);
       int l = L - 2;
       for (; l >= 1; l -= 2) {
         const double ub1 = load_ub(l), ub2 = load_ub(l - 1);
+        d4 yl[D::HT];
         load_stage<H, K, M, METHOD>(Y, act, l - 1, 0, N, ncl, sb);
-        begin_step(l); reverse_stage(l, 0, sa.yi, sa.sv); end_step(l, sa.yi, ub1);
+        y_of(l, sa.yi, yl);
+        begin_step(l); reverse_stage(l, 0, sa.yi, sa.sv); end_step(l, yl, ub1);
         load_stage<H, K, M, METHOD>(Y, act, l >= 2 ? l - 2 : 0, 0, N, ncl, sa);
-        begin_step(l - 1); reverse_stage(l - 1, 0, sb.yi, sb.sv); end_step(l - 1, sb.yi, ub2);
+        y_of(l - 1, sb.yi, yl);
+        begin_step(l - 1); reverse_stage(l - 1, 0, sb.yi, sb.sv); end_step(l - 1, yl, ub2);
       }
-      if (l == 0) { begin_step(0); reverse_stage(0, 0, sa.yi, sa.sv); end_step(0, sa.yi, load_ub(0)); }
+      if (l == 0) {
+        d4 yl[D::HT];
+        y_of(0, sa.yi, yl);
+        begin_step(0); reverse_stage(0, 0, sa.yi, sa.sv); end_step(0, yl, load_ub(0));
+      }
     }
   } else if constexpr (T::S <= 2) {
     load_field<H, K>(th, o, d, w);
@@ -905,7 +1044,7 @@ __global__ void __launch_bounds__(64) k_ode_bwd(const BwdJobs jobs, const double
           }
           const double ti = t0 + T::c(i) * dt;
           field_fwd<H, K, M, true>(w, ti, xp, yi, ko, SinkSave<M>{sv});
-          field_vjp<H, K, M, PARAMS>(w, wT, ti, sv, yi, kb[i], psi, xpb, G, lds);
+          field_vjp<H, K, M, PARAMS ? 1 : 0>(w, wT, ti, sv, yi, kb[i], psi, xpb, G, lds);
   #pragma unroll
           for (int ht = 0; ht < D::HT; ++ht) {
             psum[ht] += psi[ht];
@@ -963,19 +1102,9 @@ __global__ void __launch_bounds__(64) k_ode_bwd(const BwdJobs jobs, const double
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     storeRowSums(slab + o.Winb, K, 0, xpb);
-    storeD(slab + o.Wh, K, K, K, 0, 0, G.Wh);
-    storeDcol(slab + o.Whb, 1, K, 0, K, G.Wh);
+    if (!DUO) store_field_grads<H, K>(slab, o, d, G);      // (duo sweep: the partner wave holds and stores them)
 #pragma unroll
-    for (int ct = 0; ct < (H + 1 + 15) / 16; ++ct) {
-      storeD(slab + o.Win + d + 1, o.ldin, K, H, 0, 16 * ct, G.Wy[ct]);
-      if (ct == (H >> 4)) storeDcol(slab + o.Win + d, o.ldin, K, 0, H & 15, G.Wy[ct]);
-    }
-#pragma unroll
-    for (int ht = 0; ht < D::HT; ++ht) {
-      storeD(slab + o.Wo, K, H, K, 16 * ht, 0, G.Wo[ht]);
-      storeDcol(slab + o.Wob, 1, H, 16 * ht, K, G.Wo[ht]);
-      storeRowSums(slab + o.FLw, H, 16 * ht, accFL[ht]);
-    }
+    for (int ht = 0; ht < D::HT; ++ht) storeRowSums(slab + o.FLw, H, 16 * ht, accFL[ht]);
     const double sb = xw_sum_over_n(accFLb);
     if (lane == 0) slab[o.FLb] = sb;
   }
@@ -1067,6 +1196,205 @@ __global__ void __launch_bounds__(64) k_ode_bwd(const BwdJobs jobs, const double
   }
 }
 
+// ---- the duo sweep's second wave: weight gradients of the field -------------------------------------------------------
+// For every field evaluation (same order as the chain wave, one evaluation behind it):
+//     dWo += cot(out) (x) [tanh(z_{m-1}) ; 1]     dWh += sum_j cot(z_{j+1}) (x) [relu(z_j) ; 1]     dWy += cot(z_0) (x) [y_in ; t]
+// as 16x16x4 MFMA outer products over the 16 paths of the tile.  The cotangent tiles come transposed from the chain
+// wave's LDS buffer (A operands, xw_readT); the layer inputs are loaded from the activation store / the checkpoints
+// DIRECTLY as B operands (lane (row j, k) reads element (row j, path 4 ks + k): no LDS round trip), one whole evaluation
+// ahead: a register of the operand set is reloaded for the next evaluation as soon as its MFMA has been issued.
+// Rows past the data of a tile (the ones row that collects the bias gradient, zero padding) live in lanes the loads
+// never touch.
+template <int H, int K, int M, int S> struct DuoOps {
+  double a[4];                                 // tanh rows + ones row
+  double r[M > 1 ? M - 1 : 1][4];              // relu(z_j) + ones row, j = 0 .. M-2
+  double y[Dim<H, K>::HT][4];                  // stage input (+ the time row in its last tile)
+};
+// where the operands of field evaluation e (chain-wave order: steps L-2 .. 0, stages S-1 .. 0) come from
+template <int H, int K, int M, int METHOD> struct DuoSrc {
+  const double* __restrict__ A;      // activation record of the step
+  const double* __restrict__ Yl;     // checkpoint y_l of the step (stage 0's input)
+  int i;                             // stage
+  double ti;                         // its time
+  __device__ __forceinline__ DuoSrc(const double* __restrict__ Y, const double* __restrict__ act,
+                                    const double* __restrict__ tf, int e, int L, int N, int tile) {
+    typedef RK<METHOD> T;
+    typedef ActLayout<H, K, M, T::S> AL;
+    const int l = L - 2 - e / T::S;
+    i = T::S - 1 - e % T::S;
+    A = act + ((long)l * ((N + 15) >> 4) + tile) * (AL::TOTAL * 16);
+    Yl = Y + (long)l * H * N;
+    const double t0 = tf[l];
+    ti = t0 + T::c(i) * (tf[l + 1] - t0);
+  }
+};
+// one operand tile = 4 registers (k-steps).  B-operand layout: lane (j = lane & 15, k = lane >> 4) holds element
+// (row j, path 4 ks + k) of the 16-row tile.  Lanes of rows the tile has no data for (the ones row that collects the
+// bias gradient, zero padding) read a constant table instead: every lane loads, no divergent branch -- behind exec-masked
+// loads the compiler's wait-count bookkeeping gives up and drains vmcnt(0) once per evaluation, which exposed the whole
+// HBM latency of the operands fetched an evaluation ahead.
+typedef const double __attribute__((address_space(1)))* xw_gptr;
+__device__ const double xw_duo_const[2][16] = {{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+                                               {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1}};
+template <int H, int K, int M, int METHOD>
+__device__ __forceinline__ void duo_load_act(double (&x)[4], const DuoSrc<H, K, M, METHOD>& s, int jrow /* layer, M-1 = tanh */) {
+  typedef ActLayout<H, K, M, RK<METHOD>::S> AL;
+  const int lane = xw_lane(), j = lane & 15, k = lane >> 4;
+  // (explicitly GLOBAL pointers: a select between a kernel argument and the address of a __device__ object is a generic
+  //  pointer to the compiler, and flat loads return out of order -- every use would drain vmcnt(0) again)
+  const xw_gptr src = j < K ? (xw_gptr)(s.A + (s.i * AL::STAGE + jrow * K + j) * 16 + k) : (xw_gptr)&xw_duo_const[j == K ? 1 : 0][0];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) x[ks] = __builtin_nontemporal_load(src + 4 * ks);
+}
+// stage input tile ht: rows of y_l (checkpoints, stage 0) or of the activation record (later stages).  Branch-free: the
+// helper's loop must stay ONE basic block, or the compiler's wait-count bookkeeping falls back to vmcnt(0) at its head.
+template <int H, int K, int M, int METHOD>
+__device__ __forceinline__ void duo_load_y(double (&x)[4], const DuoSrc<H, K, M, METHOD>& s, int ht, int N, int tile) {
+  typedef ActLayout<H, K, M, RK<METHOD>::S> AL;
+  const int lane = xw_lane(), j = lane & 15, k = lane >> 4;
+  const int row = 16 * ht + j;
+  const bool first = s.i == 0;                                // (wave-uniform)
+  const double* __restrict__ base = first ? s.Yl : s.A + (long)(AL::YI + (s.i > 0 ? s.i - 1 : 0) * H) * 16;
+  const long rs = first ? N : 16, c0 = first ? tile * 16 : 0, cmax = first ? N - 1 : 15;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const long col = c0 + 4 * ks + k;
+    const xw_gptr src = row < H ? (xw_gptr)(base + row * rs + (col < cmax ? col : cmax)) : (xw_gptr)&xw_duo_const[0][0];
+    x[ks] = __builtin_nontemporal_load(src);
+  }
+  // (the time row of the last tile is patched in where the tile is USED: a select here would wait for the loads)
+}
+// ROLE 1: dWh (the M-1 tied hidden layers: 4 (M-1) matrix instructions per evaluation);  ROLE 2: dWo and dWy (4 HT each).
+// Two partner waves instead of one: with all 44 instructions (2816 clocks + operand traffic) in one stream the partner,
+// not the chain, set the pace (127 us against 92 us for the chain wave alone at N = 4096).
+template <int H, int K, int M, int METHOD, int ROLE>
+__device__ __forceinline__ void duo_outer(const BwdJobs& jobs, const double* __restrict__ tf, const double* __restrict__ th,
+                                          int L, int d, const double* qbuf) {
+  typedef Dim<H, K> D;
+  typedef RK<METHOD> T;
+  typedef DuoPlan<H, K, M> P;
+  typedef DuoSrc<H, K, M, METHOD> Src;
+  __builtin_amdgcn_s_setprio(XW_ODE_PRIO);
+  const int job = find_job(jobs);
+  const double* __restrict__ Y = jobs.Y[job];
+  const double* __restrict__ act = jobs.act[job];
+  const int N = jobs.N[job];
+  const int tile = (int)blockIdx.x - jobs.tile0[job];
+  const int lane = xw_lane(), j = lane & 15;
+  const UOff o = u_offsets(d, H, K);
+  FieldG<H, K> G;
+  G.Wh = xw_zero4();
+#pragma unroll
+  for (int ct = 0; ct < (H + 1 + 15) / 16; ++ct) G.Wy[ct] = xw_zero4();
+#pragma unroll
+  for (int ht = 0; ht < D::HT; ++ht) G.Wo[ht] = xw_zero4();
+  DuoOps<H, K, M, T::S> R;
+  {  // lanes the loads never write: the ones row (row K of the activation tiles), zero padding
+    const double c = j == K ? 1.0 : 0.0;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      R.a[ks] = c;
+#pragma unroll
+      for (int q = 0; q < (M > 1 ? M - 1 : 1); ++q) R.r[q][ks] = c;
+#pragma unroll
+      for (int ht = 0; ht < D::HT; ++ht) R.y[ht][ks] = 0.0;
+    }
+  }
+  const int E = (L - 1) * T::S;                 // field evaluations of the sweep
+  double ti_cur = 0.0;                          // time of the evaluation whose operands are in R
+  if (E > 0) {
+    const Src s0(Y, act, tf, 0, L, N, tile);
+    ti_cur = s0.ti;
+    if (ROLE == 2) duo_load_act<H, K, M, METHOD>(R.a, s0, M - 1);
+    if (ROLE == 1) {
+#pragma unroll
+      for (int jj = M - 2; jj >= 0; --jj) duo_load_act<H, K, M, METHOD>(R.r[jj], s0, jj);
+    }
+    if (ROLE == 2) {
+#pragma unroll
+      for (int ht = 0; ht < D::HT; ++ht) duo_load_y<H, K, M, METHOD>(R.y[ht], s0, ht, N, tile);
+    }
+  }
+  for (int e = 0; e < E; ++e) {
+    // the chain wave has posted evaluation e (and is free to start e + 1).  No fence: an acquire would drain vmcnt and
+    // with it the operand loads issued a whole evaluation ahead; LDS reads behind the barrier see the posted tiles.
+    asm volatile("s_barrier" ::: "memory");
+    const double* q = qbuf + (e & 1) * P::BUF;
+#if defined(XW_DUO_DBG) && XW_DUO_DBG == 3
+    const Src sn(Y, act, tf, 0, L, N, tile);
+#else
+    const Src sn(Y, act, tf, e + 1 < E ? e + 1 : e, L, N, tile);   // (the last evaluation reloads its own operands: no branch)
+#endif
+    // all A operands of the evaluation first (distinct registers: issued back to back, one exposed LDS latency per
+    // evaluation instead of one per pair of matrix instructions), then, tile by tile, the matrix instructions and
+    // right behind them the loads that refill the tile's B registers for the NEXT evaluation (a whole evaluation of
+    // matrix work ahead of their use: HBM latency is never exposed)
+    constexpr int T0 = ROLE == 1 ? D::HT : 0, T1 = ROLE == 1 ? D::HT + M - 1 : P::NQ;      // Q tiles this role reads
+    double A[P::NQ][4];
+#pragma unroll
+    for (int tq = T0; tq < T1; ++tq)
+      if (ROLE == 1 || tq < D::HT || tq == P::NQ - 1) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) A[tq][ks] = xw_readT(q + tq * XW_TTILE, ks);
+      }
+    __builtin_amdgcn_sched_barrier(0);
+    if (ROLE == 2) {
+      // cot(out) tiles against [tanh ; 1]
+#pragma unroll
+      for (int ht = 0; ht < D::HT; ++ht)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) G.Wo[ht] = XW_MFMA(A[ht][ks], R.a[ks], G.Wo[ht]);
+      __builtin_amdgcn_sched_barrier(0);
+      duo_load_act<H, K, M, METHOD>(R.a, sn, M - 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (ROLE == 1) {
+      // cot(z_{j+1}) against [relu(z_j) ; 1], j = M-2 .. 0 (tile order of the chain wave)
+#pragma unroll
+      for (int jj = M - 2; jj >= 0; --jj) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) G.Wh = XW_MFMA(A[D::HT + (M - 2 - jj)][ks], R.r[jj][ks], G.Wh);
+        __builtin_amdgcn_sched_barrier(0);
+        duo_load_act<H, K, M, METHOD>(R.r[jj], sn, jj);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (ROLE == 2) {
+      // cot(z_0) against [y_in ; t]: column H of dWy (the time row of the last tile) is the time-column gradient
+#pragma unroll
+      for (int ht = 0; ht < D::HT; ++ht) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const double b = (16 * ht <= H && H < 16 * ht + 16 && 16 * ht + j == H) ? ti_cur : R.y[ht][ks];
+          G.Wy[ht] = XW_MFMA(A[D::HT + M - 1][ks], b, G.Wy[ht]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        duo_load_y<H, K, M, METHOD>(R.y[ht], sn, ht, N, tile);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    ti_cur = sn.ti;
+  }
+  store_field_grads<H, K, ROLE == 1, ROLE == 2>(jobs.gslab[job] + (long)tile * o.total, o, d, G);
+}
+
+template <int H, int K, int M, int METHOD, bool PARAMS, bool SAVED, bool ADJ = false>
+__global__ void __launch_bounds__(64) k_ode_bwd(const BwdJobs jobs, const double* __restrict__ tf,
+                                                const double* __restrict__ th, int L, int d) {
+  __shared__ double lds[XW_SWEEP_TILES * XW_TTILE];   // (plan: XW_SWEEP_TILES)
+  sweep_body<H, K, M, METHOD, PARAMS, SAVED, ADJ, false>(jobs, tf, th, L, d, lds, nullptr);
+}
+// the duo sweep: wave 0 = adjoint chain, waves 1, 2 = weight gradients of the field (see sweep_body / duo_outer)
+#define XW_DUO_THREADS 192
+template <int H, int K, int M, int METHOD>
+__global__ void __launch_bounds__(XW_DUO_THREADS) k_ode_bwd_duo(const BwdJobs jobs, const double* __restrict__ tf,
+                                                                const double* __restrict__ th, int L, int d) {
+  __shared__ double lds[XW_SWEEP_TILES * XW_TTILE + 2 * DuoPlan<H, K, M>::BUF];
+  if (threadIdx.x < 64) sweep_body<H, K, M, METHOD, true, true, false, true>(jobs, tf, th, L, d, lds, lds + XW_SWEEP_TILES * XW_TTILE);
+  else if (threadIdx.x < 128) duo_outer<H, K, M, METHOD, 1>(jobs, tf, th, L, d, lds + XW_SWEEP_TILES * XW_TTILE);
+  else duo_outer<H, K, M, METHOD, 2>(jobs, tf, th, L, d, lds + XW_SWEEP_TILES * XW_TTILE);
+}
+
 template <int H, int K, int M>
 int launch_fwd(int method, const FwdJobs& jobs, const double* t, const double* theta, int L, int d, hipStream_t s) {
   const dim3 grid(jobs.tile0[jobs.n]), block(64);
@@ -1100,9 +1428,15 @@ int launch_bwd(int method, const BwdJobs& jobs, const double* t, const double* t
   for (int i = 0; i < jobs.n; ++i) act = act && jobs.act[i] != nullptr;
   switch (method * 2 + (act ? 1 : 0)) {
     case 0: hipLaunchKernelGGL((k_ode_bwd<H, K, M, 0, PARAMS, false>), grid, block, 0, s, jobs, t, theta, L, d); break;
-    case 1: hipLaunchKernelGGL((k_ode_bwd<H, K, M, 0, PARAMS, true>), grid, block, 0, s, jobs, t, theta, L, d); break;
+    case 1:
+      if (PARAMS) hipLaunchKernelGGL((k_ode_bwd_duo<H, K, M, 0>), grid, dim3(XW_DUO_THREADS), 0, s, jobs, t, theta, L, d);
+      else hipLaunchKernelGGL((k_ode_bwd<H, K, M, 0, false, true>), grid, block, 0, s, jobs, t, theta, L, d);
+      break;
     case 2: hipLaunchKernelGGL((k_ode_bwd<H, K, M, 1, PARAMS, false>), grid, block, 0, s, jobs, t, theta, L, d); break;
-    case 3: hipLaunchKernelGGL((k_ode_bwd<H, K, M, 1, PARAMS, true>), grid, block, 0, s, jobs, t, theta, L, d); break;
+    case 3:
+      if (PARAMS) hipLaunchKernelGGL((k_ode_bwd_duo<H, K, M, 1>), grid, dim3(XW_DUO_THREADS), 0, s, jobs, t, theta, L, d);
+      else hipLaunchKernelGGL((k_ode_bwd<H, K, M, 1, false, true>), grid, block, 0, s, jobs, t, theta, L, d);
+      break;
     case 4: hipLaunchKernelGGL((k_ode_bwd<H, K, M, 2, PARAMS, false>), grid, block, 0, s, jobs, t, theta, L, d); break;
     default: return XW_E_ARG;
   }
