@@ -309,7 +309,16 @@ __device__ __forceinline__ void outer_fire(d4& acc, const double (&a)[4], const 
 template <int H, int K, int M> struct DuoPlan {
   static constexpr int HT = Dim<H, K>::HT;
   static constexpr int NQ = HT + (M - 1) + 1;     // Q tiles of one field evaluation: cot(out) x HT, cot(z_{j+1}) for j = M-2 .. 0, cot(z_0)
-  static constexpr int BUF = NQ * XW_TTILE;       // doubles; two such buffers alternate
+  // Tiles are packed by their LIVE rows (4-row groups): a partner reads 16 rows of every tile (xw_readT), the rows past a
+  // tile's own are its successor's -- finite values that only reach accumulator rows which are never stored.  43 -> 16 KB
+  // per buffer at (20, 10, 8): 4 instead of 2 resident sweep blocks per CU (the third job of a sub-step queued for LDS).
+  static constexpr int HLAST = 4 * Dim<H, K>::HR(HT - 1);                   // rows of the last cot(out) tile
+  static constexpr int KROWS = 4 * Dim<H, K>::KSK;                          // rows of a K-tile
+  __device__ static constexpr int off(int t) {                             // first double of tile t
+    return XW_TSTRIDE * (t < HT ? 16 * t : 16 * (HT - 1) + HLAST + KROWS * (t - HT));
+  }
+  static constexpr int BUF = XW_TSTRIDE * (16 * (HT - 1) + HLAST + KROWS * M + 16);   // (+ 16 rows: reads past the last tile)
+  static_assert(BUF >= 3 * XW_TTILE, "the chain wave's epilogue borrows a buffer for its three transpose tiles");
 };
 template <int H, int K, int M, int OUTER, class SV>
 __device__ __forceinline__ void field_vjp(const FieldW<H, K>& w, const FieldWT<H, K>& wT, double t, const SV& sv,
@@ -325,7 +334,7 @@ __device__ __forceinline__ void field_vjp(const FieldW<H, K>& w, const FieldWT<H
 #pragma unroll
     for (int ht = 0; ht < D::HT; ++ht) {
       if (ht == 0) xw_writeT_n<D::HR(0)>(lds, ob[0]);
-      else xw_writeT_n<D::HR(D::HT - 1)>(lds + ht * XW_TTILE, ob[ht]);
+      else xw_writeT_n<D::HR(D::HT - 1)>(lds + DuoPlan<H, K, M>::off(ht), ob[ht]);
     }
   }
   if (PARAMS) {
@@ -356,7 +365,7 @@ __device__ __forceinline__ void field_vjp(const FieldW<H, K>& w, const FieldWT<H
       outer_post_ones<D::KSK, K>(zb, sv.z[j], lds);
       outer_fetch(o0, lds, rt1);
     }
-    if (OUTER == 2) xw_writeT_n<D::KSK>(lds + (D::HT + (M - 2 - j)) * XW_TTILE, zb);
+    if (OUTER == 2) xw_writeT_n<D::KSK>(lds + DuoPlan<H, K, M>::off(D::HT + (M - 2 - j)), zb);
     d4 tt = xw_zero4();
 #pragma unroll
     for (int kb = 0; kb < D::KB; ++kb)
@@ -368,7 +377,7 @@ __device__ __forceinline__ void field_vjp(const FieldW<H, K>& w, const FieldWT<H
   }
 #pragma unroll
   for (int r = 0; r < D::KSK; ++r) xpb[r] += zb[r];
-  if (OUTER == 2) xw_writeT_n<D::KSK>(lds + (D::HT + M - 1) * XW_TTILE, zb);
+  if (OUTER == 2) xw_writeT_n<D::KSK>(lds + DuoPlan<H, K, M>::off(D::HT + M - 1), zb);
   double r1[4];
   if (PARAMS) {
     // one Q tile (the cotangent of z0) against the column tiles of [y ; t]: the time row makes column H collect the
@@ -776,7 +785,7 @@ __device__ __forceinline__ void sweep_body(const BwdJobs& jobs, const double* __
   constexpr int OUTER = DUO ? 2 : (PARAMS ? 1 : 0);
   __builtin_amdgcn_s_setprio(XW_ODE_PRIO);
   int qflip = 0;                                 // DUO: which of the two Q buffers the next field evaluation posts into
-  if (PARAMS) {
+  if (PARAMS && !DUO) {
     if (xw_lane() < 16) lds[2 * XW_TTILE + K * XW_TSTRIDE + xw_lane()] = 1.0;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -1068,6 +1077,9 @@ __device__ __forceinline__ void sweep_body(const BwdJobs& jobs, const double* __
     }
   }
 
+  // (duo sweep: the three transpose tiles of the epilogue live in the Q buffer that is NOT in flight -- the partners are
+  //  reading the one the last evaluation was posted into; they finished with the other one before the last barrier)
+  if (DUO) lds = qbuf + qflip * DuoPlan<H, K, M>::BUF;
   // ---- x-projection: cotangent of x, gradients of Win[:, :d] and Win.b -----------------------------------------
   if (gx != nullptr) {
     for (int rt = 0; rt < (d + 15) / 16; ++rt) {
@@ -1335,7 +1347,7 @@ __device__ __forceinline__ void duo_outer(const BwdJobs& jobs, const double* __r
     for (int tq = T0; tq < T1; ++tq)
       if (ROLE == 1 || tq < D::HT || tq == P::NQ - 1) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) A[tq][ks] = xw_readT(q + tq * XW_TTILE, ks);
+        for (int ks = 0; ks < 4; ++ks) A[tq][ks] = xw_readT(q + P::off(tq), ks);
       }
     __builtin_amdgcn_sched_barrier(0);
     if (ROLE == 2) {
@@ -1389,10 +1401,10 @@ __global__ void __launch_bounds__(64) k_ode_bwd(const BwdJobs jobs, const double
 template <int H, int K, int M, int METHOD>
 __global__ void __launch_bounds__(XW_DUO_THREADS) k_ode_bwd_duo(const BwdJobs jobs, const double* __restrict__ tf,
                                                                 const double* __restrict__ th, int L, int d) {
-  __shared__ double lds[XW_SWEEP_TILES * XW_TTILE + 2 * DuoPlan<H, K, M>::BUF];
-  if (threadIdx.x < 64) sweep_body<H, K, M, METHOD, true, true, false, true>(jobs, tf, th, L, d, lds, lds + XW_SWEEP_TILES * XW_TTILE);
-  else if (threadIdx.x < 128) duo_outer<H, K, M, METHOD, 1>(jobs, tf, th, L, d, lds + XW_SWEEP_TILES * XW_TTILE);
-  else duo_outer<H, K, M, METHOD, 2>(jobs, tf, th, L, d, lds + XW_SWEEP_TILES * XW_TTILE);
+  __shared__ double lds[2 * DuoPlan<H, K, M>::BUF];
+  if (threadIdx.x < 64) sweep_body<H, K, M, METHOD, true, true, false, true>(jobs, tf, th, L, d, nullptr, lds);
+  else if (threadIdx.x < 128) duo_outer<H, K, M, METHOD, 1>(jobs, tf, th, L, d, lds);
+  else duo_outer<H, K, M, METHOD, 2>(jobs, tf, th, L, d, lds);
 }
 
 template <int H, int K, int M>
