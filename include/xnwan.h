@@ -28,6 +28,7 @@ extern "C" {
 #define XW_E_DIMS     (-1) /* (H,K) or W not among the compiled instantiations */
 #define XW_E_ARG      (-2) /* null pointer / non-positive size / bad enum */
 #define XW_E_WORKSPACE (-3) /* workspace too small */
+#define XW_E_COMM     (-4) /* RCCL not available / a collective call failed */
 
 /* library identification; also lets the host check that the .so it loaded is this ABI */
 int xw_abi_version(void);
@@ -179,6 +180,21 @@ int xw_adam(double* param, const double* gslabA, int nA, const double* gextraA, 
             double lr, double beta1, double beta2, double eps, double* gsum_out, void* stream);
 /* plain slab reduction: out[P] = (accumulate ? out : 0) + sum_s gslab[s][P] */
 int xw_slab_sum(const double* gslab, int nslab, int P, int accumulate, double* out, void* stream);
+
+/* ---- the exchange step of the sharded path (replaces nn.DataParallel's scatter / gather / reduce-add around both nets,
+ * src/training.py:93-97).  One process per GPU; every rank owns a contiguous share of the Monte-Carlo paths; per
+ * generator sub-step ONE packed buffer [J^T ubarA | J^T ubarB | partial sums] is summed over the ranks, per
+ * discriminator sub-step the partial sums (I, sum v^2) and then the packed gradient (dist.py).  RCCL over xGMI, bound
+ * with dlopen (the library loads without it; these four calls then return XW_E_COMM).
+ *   xw_comm_unique_id : rank 0 creates the 128-byte rendezvous id; the host side carries it to the other ranks
+ *   xw_comm_init      : collective over all ranks, on the caller's current HIP device; *comm is an opaque handle
+ *   xw_allreduce      : in-place float64 sum of buf[count] over the ranks; only enqueues on `stream` (graph-capture
+ *                       safe: a sub-step and its exchange replay as one HIP graph)
+ *   xw_comm_destroy   : releases the handle */
+int xw_comm_unique_id(unsigned char* id128);
+int xw_comm_init(const unsigned char* id128, int nranks, int rank, void** comm);
+int xw_allreduce(double* buf, int count, void* comm, void* stream);
+int xw_comm_destroy(void* comm);
 
 #ifdef __cplusplus
 }

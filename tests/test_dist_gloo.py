@@ -108,3 +108,44 @@ def test_bounds_cover_everything_once():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(spans[:-1], spans[1:]))
             assert max(hi - lo for lo, hi in spans) - min(hi - lo for lo, hi in spans) <= 1
+
+
+def _sampling_worker(rank, size, port, out_dir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(size), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from xnode_wan_pde_solver_amd import dist as xdist, sampling
+    world, _ = xdist.init_from_env('gloo')
+    torch.manual_seed(21)                                 # the shared seed of the job
+    N_r, N_b, d = 1001, 403, 5
+    out = []
+    for it in range(2):                                   # two outer iterations: domain (time grid) + rank-local sample
+        dom = sampling.Hypercube([-1, 1], d, 0, 1, 7)
+        pts = sampling.RankCubeLoader(N_r, N_b, dom, torch.device('cpu'), world.rank, world.size)
+        t, xu, xv, xb = pts.compact()
+        out.append(dict(t=t.clone(), xu=xu.clone(), xv=xv.clone(), xb=xb.clone(), n=pts.n_local, nb=pts.nb_local))
+    out.append(dict(after=torch.rand(3)))                 # the shared stream is in the same place on every rank
+    torch.save(out, os.path.join(out_dir, 'samp%d.pt' % rank))
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_rank_local_sampling_draws_only_the_shard(tmp_path):
+    """sampling.RankCubeLoader (solver.rank_local_sampling): every rank draws its share only; shares add up to the global
+    counts, the time grids and the shared RNG stream stay common, the points are different draws on every rank, interior
+    points are uniform in the cube and boundary points sit on faces in the global proportions"""
+    size = 2
+    mp.spawn(_sampling_worker, args=(size, _free_port(), str(tmp_path)), nprocs=size, join=True)
+    r0, r1 = (torch.load(tmp_path / ('samp%d.pt' % r)) for r in range(size))
+    assert torch.equal(r0[2]['after'], r1[2]['after'])
+    for a, b in zip(r0[:2], r1[:2]):
+        assert a['n'] + b['n'] == 1001 and a['nb'] + b['nb'] == 403 and abs(a['n'] - b['n']) <= 1
+        assert torch.equal(a['t'], b['t'])
+        assert a['xu'].shape == (a['n'], 5) and a['xb'].shape == (a['nb'], 5)
+        assert not torch.equal(a['xu'][:100], b['xu'][:100]) and not torch.equal(a['xu'], a['xv'])
+        for r in (a, b):
+            assert float(r['xu'].abs().max()) <= 1.0 and abs(float(r['xu'].mean())) < 0.1
+            on_face = (r['xb'].abs() == 1.0)
+            assert bool(torch.all(on_face.sum(1) >= 1))
+            per_axis = on_face.sum(0).double() / r['nb']
+            assert float(per_axis.min()) > 0.08 and float(per_axis.max()) < 0.35      # ~ 1 / d each
+    assert not torch.equal(r0[0]['xu'], r0[1]['xu'])       # a new draw every iteration

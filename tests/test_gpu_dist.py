@@ -72,3 +72,78 @@ def test_two_ranks_on_one_gpu_match_single_process(tmp_path):
         np.testing.assert_allclose(r['theta'].numpy(), one['theta'].numpy(), rtol=1e-8, atol=1e-10)
         np.testing.assert_allclose(r['phi'].numpy(), one['phi'].numpy(), rtol=1e-8, atol=1e-10)
     assert torch.equal(ranks[0]['theta'], ranks[1]['theta'])      # replicas stay bit-identical without broadcasts
+
+
+def _native_worker(rank, size, port, out_dir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(size), LOCAL_RANK=str(rank),
+                      HSA_ENABLE_IPC_MODE_LEGACY='0')
+    from xnode_wan_pde_solver_amd import dist as xdist
+    torch.cuda.set_device(rank)
+    torch.distributed.init_process_group('nccl', rank=rank, world_size=size, device_id=torch.device('cuda', rank))
+    world = xdist.World()
+    assert world.capturable                                # RCCL communicator behind xw_allreduce
+    x = torch.full((37,), float(rank + 1), dtype=torch.float64, device='cuda')
+    world.all_reduce(x)
+    assert torch.equal(x.cpu(), torch.full((37,), size * (size + 1) / 2.0, dtype=torch.float64))
+    _run_on(world, os.path.join(out_dir, 'native%d.pt' % rank), rank)
+    world.close()
+    torch.distributed.destroy_process_group()
+
+
+def _run_on(world, out_path, dev_index):
+    import configs.Ex4_1_funcs as P
+    from src.training import NODE_WAN_solver
+    from src.dataset import Comb_loader
+    torch.manual_seed(11)
+    S = NODE_WAN_solver(PARAMS, P.func_a, P.func_b, P.func_c, P.func_h, P.func_f, P.func_g, torch.device('cuda', dev_index), './',
+                        func_u_sol=P.func_u_sol, p=2, world=world)
+    assert world is None or S.engine.capture_exchange
+    s = S.setup
+    domain = S.domain(s['shape_param'], s['dim'], s['T0'], s['T'], s['N_t'])
+    pts = Comb_loader(s['N_r'], s['N_b'], domain, S.device)
+    shard = S._shard(S._groups(pts))[0]
+    G = S.engine.load_group(*shard[:3], domain, shard[3], shard[4])
+    losses = []
+    for kind in ('g', 'g', 'd', 'g', 'g', 'd'):           # second cycle = graph REPLAYS (exchange inside the graph)
+        if kind == 'g':
+            S.engine.generator_step(G)
+            losses.append(float(S.engine.scal[4]))
+        else:
+            S.engine.discriminator_step(G)
+            losses.append(float(S.engine.scal[5]))
+    torch.cuda.synchronize()
+    keys = sorted(G.graphs)
+    torch.save({'theta': S.engine.theta.data.cpu(), 'phi': S.engine.phi.data.cpu(), 'losses': losses, 'N': G.N, 'graphs': keys}, out_path)
+
+
+@pytest.mark.timeout(900)
+def test_native_allreduce_inside_the_captured_substep_one_rank(tmp_path):
+    """xw_allreduce (RCCL behind the C ABI) on a 1-rank communicator on the test box's single GPU: the distributed code
+    path of the engine -- packed exchange buffer, slab sums, all-reduce CAPTURED into the sub-step's HIP graph, Adam from
+    the exchanged buffers -- must reproduce the single-GPU path (different summation order of the slabs: 1e-9)."""
+    mp.spawn(_native_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    _run_on(None, str(tmp_path / 'single.pt'), 0)
+    one, nat = torch.load(tmp_path / 'single.pt'), torch.load(tmp_path / 'native0.pt')
+    assert any(k.startswith('gen_dist') for k in nat['graphs']) and any(k.startswith('disc_dist') for k in nat['graphs']), nat['graphs']
+    np.testing.assert_allclose(nat['losses'], one['losses'], rtol=1e-9)
+    np.testing.assert_allclose(nat['theta'].numpy(), one['theta'].numpy(), rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(nat['phi'].numpy(), one['phi'].numpy(), rtol=1e-8, atol=1e-10)
+
+
+@pytest.mark.timeout(900)
+def test_two_gpus_nccl_match_single_process(tmp_path):
+    """the same on two real GPUs with the `nccl` (RCCL) backend and device-buffer exchanges between graph replays;
+    skipped on the one-GPU test box"""
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs two GPUs')
+    size = 2
+    mp.spawn(_native_worker, args=(size, _free_port(), str(tmp_path)), nprocs=size, join=True)
+    _run_on(None, str(tmp_path / 'single.pt'), 0)
+    one = torch.load(tmp_path / 'single.pt')
+    ranks = [torch.load(tmp_path / ('native%d.pt' % r)) for r in range(size)]
+    assert sum(r['N'] for r in ranks) == one['N']
+    for r in ranks:
+        np.testing.assert_allclose(r['losses'], one['losses'], rtol=1e-9)
+        np.testing.assert_allclose(r['theta'].numpy(), one['theta'].numpy(), rtol=1e-8, atol=1e-10)
+        np.testing.assert_allclose(r['phi'].numpy(), one['phi'].numpy(), rtol=1e-8, atol=1e-10)
+    assert torch.equal(ranks[0]['theta'], ranks[1]['theta'])

@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('XW_LIBRARY') or os.path.join(_HERE, 'libxnwan.so')   # (override: kernel experiments only)
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 c_f32p = ctypes.c_void_p   # coordinates / time grid: const double* (device)   [name kept from the float32 era]
 c_f64p = ctypes.c_void_p   # double*       (device)
@@ -58,11 +58,16 @@ SIGNATURES = {
     'xw_adam': [c_f64p, c_f64p, c_int, c_f64p, c_f64p, c_int, c_f64p, c_f64p, c_f64p, c_f64p, c_i64p, c_int, c_int, c_dbl,
                 c_dbl, c_dbl, c_dbl, c_f64p, c_vp],
     'xw_slab_sum': [c_f64p, c_int, c_int, c_int, c_f64p, c_vp],
+    'xw_comm_unique_id': [ctypes.c_char_p],
+    'xw_comm_init': [ctypes.c_char_p, c_int, c_int, ctypes.POINTER(c_vp)],
+    'xw_allreduce': [c_f64p, c_int, c_vp, c_vp],
+    'xw_comm_destroy': [c_vp],
 }
 
 ERRORS = {-1: 'XW_E_DIMS: network widths/depths not among the compiled kernel instantiations',
           -2: 'XW_E_ARG: null pointer, non-positive size or bad enum',
-          -3: 'XW_E_WORKSPACE: workspace too small'}
+          -3: 'XW_E_WORKSPACE: workspace too small',
+          -4: 'XW_E_COMM: RCCL is not available in this process, or a collective call failed'}
 
 
 class XnwanError(RuntimeError):

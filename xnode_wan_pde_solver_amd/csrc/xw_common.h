@@ -25,6 +25,7 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 #define XW_E_DIMS (-1)
 #define XW_E_ARG (-2)
 #define XW_E_WORKSPACE (-3)
+#define XW_E_COMM (-4)
 
 // ---- parameter blob layouts (named_parameters() order of the reference modules) ---------------------------------
 struct UOff {  // u_theta, src/model.py:78,85,130-138

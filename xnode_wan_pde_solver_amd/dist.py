@@ -15,6 +15,7 @@ Every rank applies the identical fused Adam update, so parameters stay bit-ident
 messages are latency-bound (RCCL LL protocol on the fully connected xGMI mesh).  The 1/N, 1/(N L), 1/(N_b L) factors
 use GLOBAL counts on every rank.
 """
+import ctypes
 import os
 
 import torch
@@ -22,14 +23,46 @@ import torch.distributed as dist
 
 
 class World:
-    def __init__(self, group=None):
+    """The ranks of one job.  On the `nccl` (= RCCL) backend the exchanges go through the library's own entry point
+    xw_allreduce (include/xnwan.h) on a communicator created here: the call only enqueues on torch's current stream, so
+    the engine captures a sub-step TOGETHER with its exchange into one HIP graph (Engine.capture_exchange).
+    torch.distributed remains the rendezvous (it carries the 128-byte RCCL id to the ranks) and the `gloo` rehearsal path."""
+
+    def __init__(self, group=None, native=None):
         if not dist.is_initialized():
             raise RuntimeError('torch.distributed is not initialised')
         self.group = group
         self.rank = dist.get_rank(group)
         self.size = dist.get_world_size(group)
+        self.comm = None
+        if native is None:
+            native = dist.get_backend(group) == 'nccl' and os.environ.get('XW_NATIVE_ALLREDUCE', '1') == '1'
+        if native:
+            self._init_native()
+
+    def _init_native(self):
+        from ._lib import lib, check
+        ident = ctypes.create_string_buffer(128)
+        if self.rank == 0:
+            check(lib.xw_comm_unique_id(ident), 'xw_comm_unique_id')
+        box = [ident.raw if self.rank == 0 else None]
+        dist.broadcast_object_list(box, src=0, group=self.group)
+        comm = ctypes.c_void_p()
+        check(lib.xw_comm_init(box[0], self.size, self.rank, ctypes.byref(comm)), 'xw_comm_init')
+        self.comm = comm
+
+    @property
+    def capturable(self):
+        """exchanges may be recorded into a HIP graph (device-side call on the current stream, no host staging)"""
+        return self.comm is not None
 
     def all_reduce(self, t):
+        if self.comm is not None:
+            from ._lib import lib, check
+            if not (t.is_cuda and t.dtype == torch.float64 and t.is_contiguous()):
+                raise RuntimeError('xw_allreduce sums contiguous float64 device buffers')
+            check(lib.xw_allreduce(t.data_ptr(), t.numel(), self.comm, torch.cuda.current_stream().cuda_stream), 'xw_allreduce')
+            return t
         if t.is_cuda and dist.get_backend(self.group) == 'gloo':
             # rehearsal mode (several ranks sharing one GPU, or no RCCL): stage through the host
             h = t.detach().cpu()
@@ -44,6 +77,12 @@ class World:
         base, rem = divmod(n, self.size)
         lo = self.rank * base + min(self.rank, rem)
         return lo, lo + base + (1 if self.rank < rem else 0)
+
+    def close(self):
+        if self.comm is not None:
+            from ._lib import lib
+            lib.xw_comm_destroy(self.comm)
+            self.comm = None
 
     def shard_group(self, du, dv, bd):
         """this rank's slice of a group (every rank sampled the same global group from the same seed)"""

@@ -124,6 +124,12 @@ class Engine:
         self.v_blocks_disc = int(os.environ.get('XW_V_BLOCKS_DISC', '0')) or (3 * 2 * cus) // 4
         self._phi_version = 0
         self.streams = [torch.cuda.Stream(device=device) for _ in range(4)]
+        # several GPUs on RCCL: the exchanges are device-side calls on the current stream (dist.World.capturable), so a
+        # sub-step and its exchange(s) are captured into ONE HIP graph instead of graph / host call / graph
+        self.capture_exchange = (world is not None and getattr(world, 'capturable', False)
+                                 and os.environ.get('XW_CAPTURE_EXCHANGE', '1') == '1')
+        if self.capture_exchange:
+            world.all_reduce(self.scal)           # (zeros) first use outside any capture: RCCL sets up its channels here
 
     # ------------------------------------------------------------------------------------------------------------
     # per-sample preparation (once per outer iteration; everything here is parameter-independent)
@@ -431,9 +437,18 @@ class Engine:
         if self.world is None:
             self._run(G, 'gen' + sfx, self._gen_all)
             return
+        if self.capture_exchange:
+            self._run(G, 'gen_dist' + sfx, self._gen_all_dist)
+            return
         self._run(G, 'gen_front' + sfx, self._gen_front_packed)   # ... -> pack_u = [sum A | sum B | scal]
         self.world.all_reduce(self.pack_u)                        # the ONE exchange of the generator sub-step
         self._run(G, 'gen_back', self._gen_back)
+
+    def _gen_all_dist(self, G):
+        """several GPUs, capturable exchange: front segment, the ONE all-reduce and the update as one graph"""
+        self._gen_front_packed(G)
+        self.world.all_reduce(self.pack_u)
+        self._gen_back(G)
 
     def _gen_front_packed(self, G):
         """several GPUs: the front segment ends with the slab sums into the exchange buffer (same captured graph)"""
@@ -494,12 +509,23 @@ class Engine:
         self._disc_mid(G)
         self._disc_back(G)
 
+    def _disc_all_dist(self, G):
+        """several GPUs, capturable exchanges: the whole discriminator sub-step with its two all-reduces as one graph"""
+        self._disc_front(G)
+        self.world.all_reduce(self.scal[0:4])
+        self._disc_mid_packed(G)
+        self.world.all_reduce(self.grad_v)
+        self._disc_back(G)
+
     def discriminator_step(self, G):
         """one pass of the discriminator sub-step body; loss_v is left in scal[5] (device)"""
         sfx = self._v_fresh(G, store=True)
         self._phi_version += 1                                    # phi changes at the end of this sub-step
         if self.world is None:
             self._run(G, 'disc' + sfx, self._disc_all)
+            return
+        if self.capture_exchange:
+            self._run(G, 'disc_dist' + sfx, self._disc_all_dist)
             return
         self._run(G, 'disc_front' + sfx, self._disc_front)
         self.world.all_reduce(self.scal[0:4])                     # I and sum v^2 must be global before the cotangent

@@ -372,6 +372,69 @@ class DeviceCubeLoader:
         return self.interioru, self.interiorv, self.boundary
 
 
+class RankCubeLoader:
+    """This rank's share of a cube sample, drawn WITHOUT generating the global sample (multi-GPU training).
+
+    Comb_loader on R ranks draws the whole global sample on every rank from the shared seed and keeps a slice: exact seed
+    parity with the single-GPU run, but a host cost that grows with the global batch on every rank (65,536 x 100 x 3
+    uniforms per resample at BASELINE configs[3]).  Here every rank draws ONE integer from the shared stream (so the
+    streams of all ranks stay in step: the time grids of later iterations, which must be common, keep coming out
+    identical) and seeds a private generator with (that integer, rank) for its own N/R interior, N/R test-function and
+    N_b/R boundary points.  Consequence, documented in DESIGN section 6: same distribution, NOT the same numbers as the
+    unsharded draw of that seed -- a run with R ranks is reproducible for that R, not bit-comparable across R."""
+
+    def __init__(self, N_r, N_b, shape, device, rank, size):
+        if not (hasattr(shape, 'interior_x') and hasattr(shape, 'boundary_x')):
+            raise ValueError('rank-local sampling needs a domain with compact draws (Hypercube)')
+        self.N_r, self.N_b, self.shape, self.device, self.rank, self.size = N_r, N_b, shape, device, rank, size
+        base = int(torch.randint(0, 2 ** 62, (1,)).item())
+        gen = torch.Generator().manual_seed((base + 0x9E3779B97F4A7C15 * (rank + 1)) % (2 ** 63 - 1))
+        lo, hi = _bounds(N_r, rank, size)
+        blo, bhi = _bounds(N_b, rank, size)
+        self.n_local, self.nb_local = hi - lo, bhi - blo
+        if self.n_local == 0 or self.nb_local == 0:
+            raise RuntimeError('sample of %d/%d paths is too small for %d ranks' % (N_r, N_b, size))
+        d, span = shape.dim, shape.top - shape.bot
+        draw = lambda n: torch.rand(n, d, generator=gen) * span + shape.bot   # noqa: E731
+        xu, xv, xb = draw(self.n_local), draw(self.n_local), draw(self.nb_local)
+        # faces: the global sample pins int(N_b / d / 2) points to each of the 2 d faces (the last face takes the
+        # remainder) and shuffles; a shard of a shuffled sample has those proportions in expectation: draw the face per point
+        block = int(N_b / d / 2)
+        cuts = torch.tensor([block * i for i in range(2 * d)] + [N_b])
+        face = torch.bucketize(torch.randint(0, N_b, (self.nb_local,), generator=gen), cuts[1:], right=True).clamp_(max=2 * d - 1)
+        rows = torch.arange(self.nb_local)
+        xb[rows, face // 2] = torch.where(face % 2 == 0, torch.tensor(float(shape.top)), torch.tensor(float(shape.bot)))
+        self._x = (xu, xv, xb)
+        self._cache = {}
+
+    def _get(self, i, name):
+        if name not in self._cache:
+            self._cache[name] = _paths(self.shape.times, self._x[i]).requires_grad_(True)
+        return self._cache[name]
+
+    interioru = property(lambda self: self._get(0, 'interioru'))
+    interiorv = property(lambda self: self._get(1, 'interiorv'))
+    boundary = property(lambda self: self._get(2, 'boundary'))
+
+    def compact(self):
+        return (self.shape.times,) + tuple(self._x)
+
+    def __len__(self):
+        return 1
+
+    def __getitem__(self, idx):
+        if idx != 0:
+            raise IndexError
+        return tuple(t.to(self.device) for t in (self.interioru, self.interiorv, self.boundary))
+
+
+def _bounds(n, rank, size):
+    """contiguous, balanced split of n items: rank r owns [lo, hi)   (same rule as dist.World.bounds)"""
+    base, rem = divmod(n, size)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
 DOMAINS = {'Hypercube': Hypercube, 'NSphere_TCone': NSphere_TCone, 'NSphere_THourglass': NSphere_THourglass}
 
 

@@ -143,6 +143,9 @@ class NODE_WAN_solver:
                                           # host side of an outer iteration is a few small tensor ops (sampling, JSON,
                                           # torch.save); fanned out over every core of a big host they take 5x longer
                                           # and delay the kernel launches (measured: 67 -> 11 ms per outer iteration)
+        self.rank_local_sampling = False  # several GPUs: True = every rank draws only its own share of the cube sample
+                                          # (sampling.RankCubeLoader: no seed parity across rank counts); False = every
+                                          # rank draws the global sample from the shared seed and keeps its slice
         self.reuse_test_net = True        # v, dv/dt, nabla_x v(t_0) are evaluated once per (phi, sample) and shared by the
                                           # sub-steps of an outer iteration -- bit-identical results (the reference
                                           # recomputes the same values); bench.py times the sub-steps WITHOUT it
@@ -178,6 +181,8 @@ class NODE_WAN_solver:
         return self.domain(s['shape_param'], s['dim'], s['T0'], s['T'], s['N_t'])
 
     def _loader(self, domain):
+        if self.world is not None and self.rank_local_sampling and hasattr(domain, 'interior_x'):
+            return sampling.RankCubeLoader(self.setup['N_r'], self.setup['N_b'], domain, self.device, self.world.rank, self.world.size)
         if self.device_sampling and hasattr(domain, 'device_sample'):
             return sampling.DeviceCubeLoader(self.setup['N_r'], self.setup['N_b'], domain, self.device)
         return sampling.Comb_loader(self.setup['N_r'], self.setup['N_b'], domain, self.device)
@@ -187,6 +192,7 @@ class NODE_WAN_solver:
         tensors, so that h, f, g, w are tabulated exactly like the reference's CPU path; False (default) builds the path tensors
         on the GPU from the compact sample and tabulates there."""
         self._grid_hint = None
+        self._rank_local = isinstance(points, sampling.RankCubeLoader)
         if not self.tabulate_on_host or self.device_sampling:
             comp = points.compact() if hasattr(points, 'compact') else None
             if comp is not None:
@@ -205,12 +211,22 @@ class NODE_WAN_solver:
         """this rank's contiguous share of every group (dist.py); identity on one GPU"""
         if self.world is None:
             return [(du, dv, bd, None, None) for (du, dv, bd) in points]
+        if self._rank_local:                       # the loader already drew this rank's share only
+            return [(du, dv, bd, self.setup['N_r'], self.setup['N_b']) for (du, dv, bd) in points]
         return [self.world.shard_group(du, dv, bd) for (du, dv, bd) in points]
 
     def _l_norm(self, points, volume):
         from utils.auxillary_funcs import L_norm
         if self.func_u_sol is None:
             return float('nan')
+        if isinstance(points, sampling.RankCubeLoader):
+            # every rank holds its own paths: combine the p-th power sums with the global 1/N_r (one 8-byte exchange)
+            comp = points.compact()
+            X = sampling._paths(comp[0].to(self.device), comp[1].to(self.device))
+            local = L_norm(X, self.u_net, self.p, self.func_u_sol, volume, points.n_local)
+            part = (local.double() ** self.p / volume * (points.n_local / self.setup['N_r'])).reshape(1).to(self.device).contiguous()
+            self.world.all_reduce(part)
+            return float((volume * part[0]) ** (1.0 / self.p))
         if not self.tabulate_on_host or self.device_sampling:
             comp = points.compact() if hasattr(points, 'compact') else None
             if comp is not None:          # diagnostic entirely on the device
