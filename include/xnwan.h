@@ -146,6 +146,15 @@ int xw_weak_partials(const double* u, const double* v, const double* vt, const d
                      const double* f, const double* h, int N, int L, double Vol, double Nglob, double* work, double* scal,
                      int finalize, int Lb, double Nbglob, double alpha, long long* step, void* stream);
 int xw_reduce_work_size(void);
+/* The l = 0 gradient-contraction term for GENERAL coefficients (src/loss.py:66-69 with the a[d,d,N,L] / b[d,N,L] tables of
+ * src/training.py:32-41 -- of which only time index 0 can ever contribute, so only that slice is tabulated):
+ *   s3x[n] = sum_ij a_ij(t_0, x_n) d_i phi d_j u + phi sum_i b_i(t_0, x_n) d_i u,
+ *   nabla phi = w0 gxv + v0 gwx0T,   nabla u = gx + gs ghT,   phi = v0 w0          (all [d,N] / [N] as in xw_weak_partials)
+ * amode: 0 a = identity (A0 ignored), 1 A0[d,d] constant matrix, 2 A0[d,N] diagonal, 3 A0[d,d,N] full table.
+ * B0[d,N] or NULL (b = 0).  The result feeds xw_weak_partials(s3x = ...). */
+int xw_weak_contract_general(const double* A0, int amode, const double* B0, const double* gx, const double* gs,
+                             const double* ghT, const double* gxv, const double* w0, const double* gwx0T, const double* v0,
+                             int d, int N, double* s3x, void* stream);
 /* boundary penalty partial: scal[3] += sum (u_b - g)^2 ; ubar_b = alpha * 2 (u_b - g) / (Nbglob * L) */
 int xw_bdry_partials(const double* ub, const double* g, int Nb, int L, double alpha, double Nbglob,
                      double* ubar_b, double* work, double* scal, void* stream);

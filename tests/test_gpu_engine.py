@@ -484,3 +484,90 @@ def test_sampling_drawn_ahead_changes_nothing(tmp_path, monkeypatch):
     a, b = out
     assert a[0] == b[0] and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
     assert torch.equal(a[3], b[3]) and (a[4] == b[4]).all() and a[5] == b[5] and a[6] == b[6]
+
+
+def test_general_contraction_kernel_forms():
+    """xw_weak_contract_general against torch.einsum for the four forms of a (identity, one matrix, diagonal, full table)
+    with and without b, at a size with a ragged last block"""
+    from xnode_wan_pde_solver_amd import kernels as KN
+    d, N = 7, 1000
+    g = torch.Generator().manual_seed(5)
+    r = lambda *s: torch.randn(*s, generator=g, dtype=torch.float64).cuda()   # noqa: E731
+    gx, ghT, gxv, gwx0T, gs, w0, v0 = r(d, N), r(d, N), r(d, N), r(d, N), r(N), r(N), r(N)
+    Gx, dphi = gx + gs * ghT, w0 * gxv + v0 * gwx0T
+    full, diag, const, B0 = r(d, d, N), r(d, N), r(d, d), r(d, N)
+    const.xw_constant = True
+    for A0, ref in ((None, (dphi * Gx).sum(0)), (const, torch.einsum('ij,in,jn->n', const, dphi, Gx)),
+                    (diag, (diag * dphi * Gx).sum(0)), (full, torch.einsum('ijn,in,jn->n', full, dphi, Gx))):
+        for B in (None, B0):
+            out = torch.empty(N, dtype=torch.float64, device='cuda')
+            KN.weak_contract_general(A0, B, gx, gs, ghT, gxv, w0, gwx0T, v0, out)
+            want = ref if B is None else ref + v0 * w0 * (B * Gx).sum(0)
+            close(out, want, 1e-12, 1e-12)
+
+
+def test_general_coefficients_are_captured_and_batched():
+    """general a written with tensor operations: ONE batched tabulation call, exact compression (diagonal / constant
+    forms), the contraction kernel inside the captured graph, and a black-box c(u) replayed from the graph too"""
+    from src.training import NODE_WAN_solver
+    d = 5
+    params = {'alpha': 1e3, 'u_layers': 8, 'u_hidden_dim': 20, 'u_hidden_hidden_dim': 10, 'v_layers': 9, 'v_hidden_dim': 50,
+              'n1': 2, 'n2': 1, 'u_rate': 0.015, 'v_rate': 0.04, 'min_steps': 5, 'adjoint': False, 'solver': 'midpoint',
+              'dim': d, 'N_t': 7, 'N_r': 130, 'N_b': 60, 'T0': 0, 'T': 1, 'shape_param': [-1, 1], 'iterations': 1,
+              'domain': 'Hypercube'}
+    calls = {'a': 0}
+
+    def fa(X, i, j):                          # tensor-friendly: works with index tensors (diagonal, varies with x)
+        calls['a'] += 1
+        return (1.0 + 0.5 * X[..., 1] ** 2) * (i == j)
+
+    def fb(X, i):
+        return 0.3 * X[..., 0] * (i + 1.0)
+
+    def fc(X, u):
+        return -u ** 2 + torch.sin(X[..., 1:2])
+
+    outs = []
+    for graphs in (True, False):
+        torch.manual_seed(5)
+        S = NODE_WAN_solver(params, fa, fb, fc, P.func_h, P.func_f, P.func_g, torch.device('cuda'), './', func_u_sol=P.func_u_sol, p=2)
+        S.engine.use_graphs = graphs
+        domain, pts = first_sample(S)
+        calls['a'] = 0
+        G = S.engine.load_group(pts.interioru, pts.interiorv, pts.boundary, domain)
+        assert calls['a'] <= 1 + 3                                  # one batched call + the three spot checks
+        assert tuple(G.A0.shape) == (d, G.N) and tuple(G.B0.shape) == (d, G.N)      # stored as a diagonal
+        for _ in range(2):
+            S.engine.generator_step(G)
+            S.engine.generator_step(G)
+            S.engine.discriminator_step(G)
+        if graphs:
+            assert all(v is not False for v in G.graphs.values()) and len(G.graphs) >= 2, G.graphs    # every segment captured
+        outs.append((S.engine.theta.data.clone(), S.engine.phi.data.clone(), S.engine.scal.clone()))
+    close(outs[0][0], outs[1][0], 1e-10, 1e-13, 'theta: graph replay == eager')
+    close(outs[0][1], outs[1][1], 1e-10, 1e-13, 'phi')
+
+
+def test_structure_guard_catches_region_dependent_coefficients():
+    """a coefficient that looks like the identity on the probe points but deviates elsewhere must not silently take the
+    fused fast path: the guard on the actual sample raises"""
+    from xnode_wan_pde_solver_amd._lib import XnwanError
+    from xnode_wan_pde_solver_amd.engine import Structure
+    z_params = {'alpha': 1e3, 'u_layers': 8, 'u_hidden_dim': 20, 'u_hidden_hidden_dim': 10, 'v_layers': 9, 'v_hidden_dim': 50,
+                'n1': 2, 'n2': 1, 'u_rate': 0.015, 'v_rate': 0.04, 'min_steps': 5, 'adjoint': False, 'solver': 'midpoint',
+                'dim': 3, 'N_t': 5, 'N_r': 400, 'N_b': 60, 'T0': 0, 'T': 1, 'shape_param': [-1, 1], 'iterations': 1,
+                'domain': 'Hypercube'}
+
+    def fa(X, i, j):                          # identity except in a slab none of the 18 (fixed-seed) probe points lies in
+        base = torch.ones(X.shape[:-1]) if i == j else torch.zeros(X.shape[:-1])
+        return base.to(X.device) + (1.0 if i == j else 0.0) * ((X[..., 1] > 0.66) & (X[..., 1] < 0.80)).float()
+
+    funcs = dict(FUNCS, a=fa)
+    st = Structure(funcs, 3)
+    assert st.a_identity                      # the probe is fooled ...
+    from src.training import NODE_WAN_solver
+    torch.manual_seed(5)
+    S = NODE_WAN_solver(z_params, fa, P.func_b, P.func_c, P.func_h, P.func_f, P.func_g, torch.device('cuda'), './', func_u_sol=P.func_u_sol, p=2)
+    domain, pts = first_sample(S)
+    with pytest.raises(XnwanError):
+        S.engine.load_group(pts.interioru, pts.interiorv, pts.boundary, domain)

@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('XW_LIBRARY') or os.path.join(_HERE, 'libxnwan.so')   # (override: kernel experiments only)
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 c_f32p = ctypes.c_void_p   # coordinates / time grid: const double* (device)   [name kept from the float32 era]
 c_f64p = ctypes.c_void_p   # double*       (device)
@@ -50,6 +50,7 @@ SIGNATURES = {
                          c_dbl, c_i64p, c_vp],
     'xw_bdry_partials': [c_f64p, c_f64p, c_int, c_int, c_dbl, c_dbl, c_f64p, c_f64p, c_f64p, c_vp],
     'xw_reduce_work_size': [],
+    'xw_weak_contract_general': [c_f64p, c_int, c_f64p, c_f64p, c_f64p, c_f64p, c_f64p, c_f64p, c_f64p, c_f64p, c_int, c_int, c_f64p, c_vp],
     'xw_gen_cotangents': [c_f64p, c_f64p, c_f64p, c_int, c_f64p, c_f64p, c_dbl, c_f64p, c_int, c_int, c_dbl, c_dbl, c_dbl,
                           c_dbl, c_f64p, c_f64p, c_f64p, c_vp],
     'xw_disc_cotangent': [c_f64p, c_f64p, c_f64p, c_int, c_f64p, c_dbl, c_f64p, c_f64p, c_int, c_int, c_dbl, c_dbl, c_dbl,

@@ -289,6 +289,42 @@ inline int blocks_for(long n, int per, int cap) {
   return (int)(b > cap ? cap : b);
 }
 
+
+// s3x[n] = sum_ij a_ij d_i(phi) d_j(u) + phi sum_i b_i d_i(u)  at the first time index (src/loss.py:66-69; nabla u only
+// exists there), with  nabla phi = w nabla v + v nabla w  and  nabla u = gx + gs nabla h.
+// a is given in the cheapest form the caller has: amode 0 identity, 1 one matrix A0[d,d] for all points, 2 a diagonal
+// A0[d,N], 3 the full table A0[d,d,N] (row-major over (i, j), paths fastest: consecutive lanes = consecutive paths).
+// One lane per path, d^2 coalesced loads of a: HBM-streaming (8 d^2 N bytes: 655 MB at d = 100, N = 8192).
+__global__ void __launch_bounds__(256) k_weak_contract(const double* __restrict__ A0, int amode,
+                                                       const double* __restrict__ B0, const double* __restrict__ gx,
+                                                       const double* __restrict__ gs, const double* __restrict__ ghT,
+                                                       const double* __restrict__ gxv, const double* __restrict__ w0,
+                                                       const double* __restrict__ gwx0T, const double* __restrict__ v0,
+                                                       int d, int N, double* __restrict__ s3x) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const double w = w0[n], v = v0[n], gsn = gs[n];
+  double acc = 0.0, bsum = 0.0;
+  for (int i = 0; i < d; ++i) {
+    const double dphi = w * gxv[(long)i * N + n] + v * gwx0T[(long)i * N + n];
+    const double dui = gx[(long)i * N + n] + gsn * ghT[(long)i * N + n];
+    if (B0 != nullptr) bsum += B0[(long)i * N + n] * dui;
+    if (amode == 0) {
+      acc += dphi * dui;
+    } else if (amode == 2) {
+      acc += A0[(long)i * N + n] * dphi * dui;
+    } else {
+      double row = 0.0;
+      for (int j = 0; j < d; ++j) {
+        const double duj = gx[(long)j * N + n] + gsn * ghT[(long)j * N + n];
+        const double a = amode == 1 ? A0[i * d + j] : A0[((long)i * d + j) * N + n];
+        row += a * duj;
+      }
+      acc += dphi * row;
+    }
+  }
+  s3x[n] = acc + v * w * bsum;
+}
 }  // namespace
 
 extern "C" int xw_weak_partials(const double* u, const double* v, const double* vt, const double* w, int w_per_point,
@@ -360,7 +396,7 @@ extern "C" int xw_slab_sum(const double* gslab, int nslab, int P, int accumulate
   return xw_launch_status();
 }
 
-extern "C" int xw_abi_version(void) { return 16; }
+extern "C" int xw_abi_version(void) { return 17; }
 extern "C" int xw_reduce_work_size(void) { return 3 * 1024 + 8; }
 
 extern "C" int xw_supported_dims(char* buf, int buflen) {
@@ -373,3 +409,14 @@ extern "C" int xw_supported_dims(char* buf, int buflen) {
 
 extern "C" int xw_theta_size(int d, int H, int K) { return u_offsets(d, H, K).total; }
 extern "C" int xw_phi_size(int d, int W) { return v_offsets(d, W).total; }
+
+extern "C" int xw_weak_contract_general(const double* A0, int amode, const double* B0, const double* gx, const double* gs,
+                                        const double* ghT, const double* gxv, const double* w0, const double* gwx0T,
+                                        const double* v0, int d, int N, double* s3x, void* stream) {
+  if (!gx || !gs || !ghT || !gxv || !w0 || !gwx0T || !v0 || !s3x || d <= 0 || N <= 0 || amode < 0 || amode > 3 ||
+      (amode != 0 && !A0))
+    return XW_E_ARG;
+  hipLaunchKernelGGL(k_weak_contract, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, A0, amode, B0, gx, gs, ghT, gxv,
+                     w0, gwx0T, v0, d, N, s3x);
+  return xw_launch_status();
+}

@@ -91,6 +91,7 @@ class Engine:
         self.adjoint = bool(config.get('adjoint', False))
         self.alpha = float(config['alpha'])
         self.pollution = 1.0
+        self.verify_structure = os.environ.get('XW_VERIFY_STRUCTURE', '1') == '1'    # (_check_structure)
         sp = setup.get('shape_param', [-1, 1])
         lo, hi = (sp[0], sp[1]) if isinstance(sp, (list, tuple)) else (-sp, sp)
         self.structure = structure if structure is not None else Structure(funcs, self.d, lo, hi)
@@ -130,6 +131,83 @@ class Engine:
                                  and os.environ.get('XW_CAPTURE_EXCHANGE', '1') == '1')
         if self.capture_exchange:
             world.all_reduce(self.scal)           # (zeros) first use outside any capture: RCCL sets up its channels here
+
+    # ------------------------------------------------------------------------------------------------------------
+    # coefficient tables (src/training.py:32-41).  Only time index 0 can contribute (Q3), so that slice is all that is
+    # tabulated: [d,d,N] instead of the reference's [d,d,N,L].
+    # ------------------------------------------------------------------------------------------------------------
+    def _tabulate_a(self, X1):
+        """a_ij(t_0, x_n) on the sample X1 [N,1,d+1].  ONE batched call of the user's callable with index tensors
+        i[d,1,1,1], j[1,d,1,1] when it is written with tensor operations (checked against scalar calls on three index
+        pairs); otherwise the reference's d^2 scalar calls.  The table is then stored in the cheapest EXACT form: one
+        [d,d] matrix if it does not vary over the sample, its diagonal [d,N] if every off-diagonal entry is exactly zero."""
+        d, dev, fa = self.d, self.dev, self.funcs['a']
+        N = X1.shape[0]
+        A = None
+        try:
+            ii = torch.arange(d, device=X1.device).view(d, 1, 1, 1)
+            jj = torch.arange(d, device=X1.device).view(1, d, 1, 1)
+            out = fa(X1.unsqueeze(0).unsqueeze(0), ii, jj)
+            if torch.is_tensor(out) and tuple(out.shape) == (d, d, N, 1):
+                A = out[..., 0].to(dev).to(F64)
+                g = torch.Generator().manual_seed(d * 7919 + N)
+                for _ in range(3):
+                    i, j = (int(k) for k in torch.randint(0, d, (2,), generator=g))
+                    if not torch.equal(A[i, j], fa(X1, i, j).to(dev).to(F64)[:, 0]):
+                        A = None
+                        break
+        except Exception:               # the callable branches on (i, j) in Python, indexes with them, ...: scalar calls
+            A = None
+        if A is None:
+            A = torch.stack([torch.stack([fa(X1, i, j).to(dev).to(F64)[:, 0] for j in range(d)], 0) for i in range(d)], 0)
+        off = A.clone()
+        off.diagonal(dim1=0, dim2=1).zero_()
+        if bool(torch.all(A == A[:, :, :1])):
+            A = A[:, :, 0].contiguous()
+            A.xw_constant = True
+            return A
+        if bool(torch.all(off == 0)):
+            return A.diagonal(dim1=0, dim2=1).t().contiguous()         # [d, N]
+        return A.contiguous()
+
+    def _tabulate_b(self, X1):
+        d, dev, fb = self.d, self.dev, self.funcs['b']
+        N = X1.shape[0]
+        try:
+            out = fb(X1.unsqueeze(0), torch.arange(d, device=X1.device).view(d, 1, 1))
+            if torch.is_tensor(out) and tuple(out.shape) == (d, N, 1):
+                B = out[..., 0].to(dev).to(F64)
+                if all(torch.equal(B[i], fb(X1, i).to(dev).to(F64)[:, 0]) for i in (0, d // 2, d - 1)):
+                    return B.contiguous()
+        except Exception:
+            pass
+        return torch.stack([fb(X1, i).to(dev).to(F64)[:, 0] for i in range(d)], 0).contiguous()
+
+    def _check_structure(self, X, version):
+        """The fused fast paths (a = identity, b = 0, c = kappa u) were chosen from a probe on random points
+        (Structure).  Guard them on the ACTUAL sample, every time one is loaded: the whole diagonal of a, one rotating
+        off-diagonal per row (all pairs are visited over d samples), every b_i, and c against kappa u -- a coefficient
+        that only deviates in part of the domain raises here instead of silently training the wrong PDE."""
+        st, d = self.structure, self.d
+        X1 = X[:, :1, :]
+        bad = []                                   # (device-side flags, ONE host sync for the whole check)
+        if st.a_identity:
+            for i in range(d):
+                j = (i + 1 + version % max(d - 1, 1)) % d
+                bad.append(('func_a[%d,%d] == 1' % (i, i), torch.any(self.funcs['a'](X1, i, i) != 1)))
+                if d > 1:
+                    bad.append(('func_a[%d,%d] == 0' % (i, j), torch.any(self.funcs['a'](X1, i, j) != 0)))
+        if st.b_zero:
+            for i in range(d):
+                bad.append(('func_b[%d] == 0' % i, torch.any(self.funcs['b'](X1, i) != 0)))
+        if st.c_kappa is not None:
+            g = torch.Generator().manual_seed(1 + version)
+            up = torch.randn(X.shape[0], X.shape[1], 1, generator=g, dtype=F64).to(X.device)
+            bad.append(('func_c(X, u) == %g u' % st.c_kappa, torch.any(self.funcs['c'](X, up) != st.c_kappa * up)))
+        if bad and bool(torch.stack([b.to(X.device) for _, b in bad]).any()):
+            which = [name for name, b in bad if bool(b)]
+            raise XnwanError('the PDE coefficients do not have the structure the probe at construction saw (%s): violated on this '
+                             'sample: %s.  Build the solver with an explicit engine.Structure.' % (st.describe(), ', '.join(which[:4])))
 
     # ------------------------------------------------------------------------------------------------------------
     # per-sample preparation (once per outer iteration; everything here is parameter-independent)
@@ -197,12 +275,11 @@ class Engine:
         S['X'] = X.to(dev) if st.c_kappa is None else None      # only read by a general reaction callable c(u, t, x)
         S['A0'] = S['B0'] = None
         if not st.a_identity:
-            X1 = X[:, :1, :]
-            S['A0'] = torch.stack([torch.stack([self.funcs['a'](X1, i, j).to(dev).to(F64)[:, 0] for j in range(d)], 0)
-                                   for i in range(d)], 0).contiguous()     # [d, d, N] at time index 0
+            S['A0'] = self._tabulate_a(X[:, :1, :])            # [d,d,N] / [d,N] (diagonal) / [d,d] (constant) at time index 0
         if not st.b_zero:
-            X1 = X[:, :1, :]
-            S['B0'] = torch.stack([self.funcs['b'](X1, i).to(dev).to(F64)[:, 0] for i in range(d)], 0).contiguous()
+            S['B0'] = self._tabulate_b(X[:, :1, :])            # [d, N]
+        if self.verify_structure:
+            self._check_structure(X, getattr(into, 'sample_version', 0) if into is not None else 0)
         vol = float(domain.V())
         nglob = float(n_glob if n_glob is not None else N)
         nbglob = float(nb_glob if nb_glob is not None else max(Nb, 1))
@@ -294,7 +371,10 @@ class Engine:
             with torch.enable_grad():
                 c = self.funcs['c'](G.X, ul)
                 cp = torch.autograd.grad(c.sum(), ul)[0] if c.requires_grad else torch.zeros_like(ul)
-            G.c, G.cp = _to_LN(c.squeeze(2), self.dev), _to_LN(cp.squeeze(2), self.dev)
+            if G.c is None:
+                G.c, G.cp = torch.empty_like(G.u), torch.empty_like(G.u)     # (persistent: captured graphs keep reading them)
+            G.c.copy_(c.detach().squeeze(2).t())
+            G.cp.copy_(cp.detach().squeeze(2).t())
             ck = 0.0
         G.ck = ck
 
@@ -318,12 +398,8 @@ class Engine:
             KN.weak_partials(G.u, G.v, G.vt, G.w, G.f, G.h, G.Vol, G.Nglob, self.scal, G.work_i, c=G.c, ckappa=G.ck, wt=G.wt,
                              contract=dict(gx=G.gx, gs=G.gs, ghT=G.ghT, gxv=G.gxv, w0=G.w0, gwx0T=G.gwx0T), finalize=fin)
             return
-        Gx = G.gx + G.gs.unsqueeze(0) * G.ghT                                              # [d, N]
-        dphi0 = G.w0.unsqueeze(0) * G.gxv + G.v[0].unsqueeze(0) * G.gwx0T                  # nabla_x phi at t_0, [d, N]
-        s3x = (dphi0 * Gx).sum(0) if G.A0 is None else torch.einsum('ijn,in,jn->n', G.A0, dphi0, Gx)
-        if G.B0 is not None:
-            s3x = s3x + G.v[0] * G.w0 * (G.B0 * Gx).sum(0)
-        G.s3x.copy_(s3x)
+        # general a_ij / b_i: the l = 0 contraction as one streaming kernel over the tabulated slice (graph-capturable)
+        KN.weak_contract_general(G.A0, G.B0, G.gx, G.gs, G.ghT, G.gxv, G.w0, G.gwx0T, G.v[0], G.s3x)
         KN.weak_partials(G.u, G.v, G.vt, G.w, G.f, G.h, G.Vol, G.Nglob, self.scal, G.work_i, s3x=G.s3x, c=G.c, ckappa=G.ck,
                          wt=G.wt, finalize=fin)
 
@@ -536,27 +612,37 @@ class Engine:
     # ------------------------------------------------------------------------------------------------------------
     def _run(self, G, key, fn):
         """execute fn(G) eagerly, or capture it once into a HIP graph (per group and segment) and replay it"""
-        capturable = (self.use_graphs and self.structure.c_kappa is not None and self.accum_u is None
-                      and self.accum_v is None and getattr(G, 'persistent', True))
-        if not capturable:
+        capturable = (self.use_graphs and self.accum_u is None and self.accum_v is None and getattr(G, 'persistent', True))
+        g = G.graphs.get(key) if capturable else False
+        if g is False:                            # not capturable, or capture of THIS segment was refused before
             fn(G)
             return
-        g = G.graphs.get(key)
         if g is None:
+            if self.structure.c_kappa is None:
+                fn(G)                             # a black-box c(u, t, x): one eager pass first (allocations, lazy init of its ops)
             g = torch.cuda.CUDAGraph()
             torch.cuda.synchronize()
             try:
                 # thread_local: other threads (the RCCL watchdog polls events) must not invalidate the capture
                 with torch.cuda.graph(g, stream=self._capture_stream(), capture_error_mode='thread_local'):
                     fn(G)
-            except Exception as exc:  # capture refused by the runtime: run this and all later segments eagerly
+            except Exception as exc:
+                # Capture refused (typically a user callable that syncs with the host or builds CPU tensors): THIS segment
+                # of THIS group runs eagerly from now on -- several times slower, so say it loudly, once per segment, and
+                # leave every other segment captured (XW_STRICT_GRAPHS=1 turns the cliff into an error)
+                if os.environ.get('XW_STRICT_GRAPHS', '0') == '1':
+                    raise
                 import warnings
-                warnings.warn('HIP graph capture of %r failed (%s); falling back to eager launches' % (key, exc))
-                self.use_graphs = False
+                warnings.warn('HIP graph capture of sub-step segment %r failed (%s: %s); this segment now runs as eager kernel launches '
+                              '(expect a several times lower step rate)' % (key, type(exc).__name__, exc), RuntimeWarning, stacklevel=2)
+                G.graphs[key] = False
+                self.eager_segments = getattr(self, 'eager_segments', 0) + 1
                 torch.cuda.synchronize()
                 fn(G)
                 return
             G.graphs[key] = g
+            if self.structure.c_kappa is None:
+                return                            # (the eager pass above was this call's step; the capture only recorded)
         g.replay()
 
     def _capture_stream(self):
