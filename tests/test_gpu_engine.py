@@ -571,3 +571,67 @@ def test_structure_guard_catches_region_dependent_coefficients():
     domain, pts = first_sample(S)
     with pytest.raises(XnwanError):
         S.engine.load_group(pts.interioru, pts.interiorv, pts.boundary, domain)
+
+
+@pytest.mark.parametrize('Hh,Kk,Ww,m,q', [(16, 8, 32, 8, 9), (24, 9, 40, 5, 4), (20, 12, 50, 8, 9), (32, 12, 50, 3, 9),
+                                          (20, 10, 50, 1, 9), (7, 3, 11, 2, 2)])
+def test_engine_at_other_network_widths(Hh, Kk, Ww, m, q):
+    """src/model.py:30-43,62-85,130-138 accept any u_hidden_dim, u_hidden_hidden_dim, v_hidden_dim and u_layers >= 1.  A
+    network narrower than a kernel instantiation runs EXACTLY inside the next larger one (zero-padded blob, nets.Blob):
+    same initial draws as the reference's construction order, sub-steps against the oracle at the true widths, the
+    padding still identically zero after the updates, state_dict with the true shapes."""
+    from oracle import refspec as R
+    from src.training import NODE_WAN_solver
+    from xnode_wan_pde_solver_amd import kernels as KN
+    d = 4
+    params = {'alpha': 1e3, 'u_layers': m, 'u_hidden_dim': Hh, 'u_hidden_hidden_dim': Kk, 'v_layers': q, 'v_hidden_dim': Ww,
+              'n1': 2, 'n2': 1, 'u_rate': 0.015, 'v_rate': 0.04, 'min_steps': 5, 'adjoint': False, 'solver': 'midpoint',
+              'dim': d, 'N_t': 7, 'N_r': 75, 'N_b': 41, 'T0': 0, 'T': 1, 'shape_param': [-1, 1], 'iterations': 1,
+              'domain': 'Hypercube'}
+    torch.manual_seed(9)
+    S = NODE_WAN_solver(params, P.func_a, P.func_b, P.func_c, P.func_h, P.func_f, P.func_g, torch.device('cuda'), './',
+                        func_u_sol=P.func_u_sol, p=2)
+    assert (S.engine.H, S.engine.K) == KN.ode_container(Hh, Kk) and S.engine.W == KN.disc_container(Ww)
+    torch.manual_seed(9)
+    O = R.Solver(params, FUNCS, u_sol=P.func_u_sol, p=2)
+    # (u_layers = 1: a field without the tied hidden layer, src/model.py:130 -- no such parameters in the module)
+    unames = [(n_, k_) for n_, k_ in R.u_names(m) if m > 1 or k_ not in ('Wh', 'Wh_b')]
+    for n_, k_ in unames:
+        assert torch.equal(dict(S.u_net.named_parameters())[n_].detach().cpu(), O.theta[k_]), n_
+    for n_, k_ in R.V_NAME_MAP:
+        assert torch.equal(dict(S.v_net.named_parameters())[n_].detach().cpu(), O.phi[k_]), n_
+    sd = S.u_net.state_dict()
+    assert sd['module.final_linear.weight'].shape == (1, Hh) and sd['module.initial_layers.2.weight'].shape == (Hh, Hh)
+    rng = torch.get_rng_state()
+    domain, pts = first_sample(S)
+    torch.set_rng_state(rng)
+    O.new_sample()
+    G = S.engine.load_group(pts.interioru, pts.interiorv, pts.boundary, domain)
+    for step in ('u', 'u', 'v', 'u'):
+        if step == 'u':
+            o = O.generator_step()
+            S.engine.generator_step(G)
+            got, blob, names = S.engine.grad_u, S.engine.theta, unames
+            close(S.engine.scal[4], o['loss'], 1e-7)           # (the oracle rounds nabla u, nabla phi to float32 like the reference)
+        else:
+            o = O.discriminator_step()
+            S.engine.discriminator_step(G)
+            got, blob, names = S.engine.grad_v, S.engine.phi, R.V_NAME_MAP
+            close(S.engine.scal[5], o['loss'], 1e-6, 1e-6)     # (-int = a difference of two logs: can sit near zero)
+        gmax = max(float(o['grad'][k].abs().max()) for _, k in names)
+        for (n_, k_), g_ in zip(names, blob.split(got)):
+            close(g_, o['grad'][k_], 1e-5, 1e-6 * gmax, 'grad ' + k_)
+    for (n_, k_), p_ in zip(unames, S.engine.theta.params):
+        close(p_, O.theta[k_], 1e-6, 1e-8, 'theta after the updates: ' + k_)
+    # the padding of the container blobs never left zero (weights, Adam moments): mask of the real entries
+    for blob, st in ((S.engine.theta, S.engine.adam_u), (S.engine.phi, S.engine.adam_v)):
+        real = torch.zeros_like(blob.data, dtype=torch.bool)
+        for piece in blob.split(real):
+            piece.fill_(True)
+        assert int(real.sum()) == sum(blob.sizes)
+        pad = ~real
+        assert float(blob.data[pad].abs().sum()) == 0.0 and float(st['m'][pad].abs().sum()) == 0.0 and float(st['v'][pad].abs().sum()) == 0.0
+    # module path at these widths
+    with torch.no_grad():
+        out = S.u_net(pts.interioru)
+    close(out.squeeze(2), R.u_net(O.theta, params, O.X, P.func_h(O.X[:, 0, :])), 1e-5, 1e-7)     # (parameters agree to 1e-6 after four updates)

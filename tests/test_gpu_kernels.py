@@ -502,3 +502,56 @@ def test_empty_and_malformed_inputs_are_refused_by_the_c_abi():
     with pytest.raises(XnwanError):
         KN.ode_bwd_multi([dict(xT=x, start=s, Y=Y, ubar=None, gx=gx, gs=gs)], t, th, 1, H, K, 8, want_x=True, want_params=False,
                          x_cot_ones=True)
+
+
+# ---- widths other than the YAML's (src/model.py:62-85,130-138 accept any u_hidden_dim / u_hidden_hidden_dim) ----------------
+@pytest.mark.parametrize('solver', ['euler', 'midpoint', 'rk4'])
+@pytest.mark.parametrize('Hh,Kk,m', [(32, 12, 8), (32, 12, 3), (32, 12, 1)])
+def test_ode_kernels_at_the_wide_instantiation(Hh, Kk, m, solver):
+    """the (32, 12) stepper object: H a multiple of 16 (the time row of [y ; t] is a tile of its own), K = 12 (no padding
+    row inside the 4-row blocks) -- forward 1e-12, sweep (x, start, every weight gradient) 1e-10 against the oracle,
+    with and without the activation store (duo sweep / single-wave sweep)"""
+    from oracle import refspec as R
+    from xnode_wan_pde_solver_amd import kernels as KN
+    N, L, d = 37, 6, 5
+    cfg = dict(_cfg(m, solver), u_hidden_dim=Hh, u_hidden_hidden_dim=Kk)
+    torch.manual_seed(31)
+    theta, _ = R.init_parameters(cfg, _setup(d, 2))
+    for p in theta.values():
+        if p.dim() == 1:
+            p.copy_(0.3 * torch.randn(p.shape, dtype=torch.float64))
+    th = {k: v.clone().requires_grad_(True) for k, v in theta.items()}
+    x, t, X = _sample(N, L, d, 32)
+    g = torch.Generator().manual_seed(33)
+    start = torch.randn(N, dtype=torch.float64, generator=g).requires_grad_(True)
+    ubar = torch.randn(N, L, dtype=torch.float64, generator=g)
+    x64 = x.double().requires_grad_(True)
+    Xd = torch.cat((t.double().view(1, L, 1).expand(N, L, 1), x64.view(N, 1, d).expand(N, L, d)), 2)
+    u_ref = R.u_net(th, cfg, Xd, start)
+    order = [k for k in U_ORDER if k in theta]
+    grads = torch.autograd.grad((u_ref * ubar).sum(), [x64, start] + [th[k] for k in order], allow_unused=True)
+    grads = [g_ if g_ is not None else torch.zeros_like(p_) for g_, p_ in zip(grads, [x64, start] + [th[k] for k in order])]
+    blob = torch.cat([(theta[k] if k in theta else torch.zeros(Kk * Kk if k == 'Wh' else Kk, dtype=torch.float64)).reshape(-1)
+                      for k in U_ORDER]).cuda()
+    xT, tc, sc = x.double().t().contiguous().cuda(), t.double().cuda(), start.detach().cuda()
+    mid = KN.method_id(solver)
+    u, Y = KN.ode_fwd(xT, tc, sc, blob, mid, Hh, Kk, m)
+    _close(u.t(), u_ref.detach(), 1e-12, 'u')
+    rows = KN.ode_act_rows(mid, Hh, Kk, m)
+    for with_act in ([False, True] if rows else [False]):
+        job = dict(xT=xT, start=sc, u=torch.empty_like(u), Y=torch.empty_like(Y))
+        if with_act:
+            job['act'] = torch.empty(L - 1, rows, KN.ode_act_cols(N), dtype=torch.float64, device='cuda')
+        KN.ode_fwd_multi([job], tc, blob, mid, Hh, Kk, m)
+        gx, gs = torch.empty(d, N, dtype=torch.float64, device='cuda'), torch.empty(N, dtype=torch.float64, device='cuda')
+        slab = torch.empty(KN.ode_bwd_slabs(N), blob.numel(), dtype=torch.float64, device='cuda')
+        KN.ode_bwd_multi([dict(job, ubar=ubar.t().contiguous().cuda(), gx=gx, gs=gs, gslab=slab)], tc, blob, mid, Hh, Kk, m,
+                         want_x=True, want_params=True)
+        _close(gx.t(), grads[0], 1e-10, 'gx act=%s' % with_act)
+        _close(gs, grads[1], 1e-10, 'gs act=%s' % with_act)
+        flat, off = KN.slab_sum(slab).cpu(), 0
+        for k in U_ORDER:
+            n = theta[k].numel() if k in theta else (Kk * Kk if k == 'Wh' else Kk)
+            if k in theta:
+                _close(flat[off:off + n].view(theta[k].shape), grads[2 + order.index(k)], 1e-10, 'grad %s act=%s' % (k, with_act))
+            off += n

@@ -54,10 +54,10 @@ template <int H, int K> struct Dim {
   static constexpr int KB = (K + 3) / 4;     // 4-row blocks of a K-vector (= live registers of its chain tile)
   static constexpr int HB = (H + 3) / 4;     // 4-row blocks of an H-vector
   __device__ static constexpr int HR(int ht) { return (H - 16 * ht) >= 16 ? 4 : (H - 16 * ht + 3) / 4; }        // rows of y
-  __device__ static constexpr int HR1(int ht) { return (H + 1 - 16 * ht) >= 16 ? 4 : (H + 1 - 16 * ht + 3) / 4; }  // + time row
-  static_assert(K <= 15, "one padding row of the K-tile carries the bias column of the outer products");
-  static_assert((H % 16) != 0 && (H % 16) <= 15, "one padding row of the last H-tile carries the time column");
-  static_assert(HT <= 2, "H <= 31");
+  __device__ static constexpr int HR1(int ct) { return (H + 1 - 16 * ct) >= 16 ? 4 : (H + 1 - 16 * ct + 3) / 4; }  // + time row
+  static constexpr int CT = (H + 16) / 16;   // 16-row tiles of [y ; t]: the time row H is its own tile when H % 16 == 0
+  static_assert(K <= 15, "row K of the 16-row K-tile is the ones row that collects the bias gradients");
+  static_assert(HT <= 2 && CT <= 3, "H <= 32");
 };
 
 // The field's layers run on v_mfma_f64_4x4x4_4b_f64: one instruction = a 4x4 weight block times 4 rows x 16 paths of
@@ -182,7 +182,7 @@ __device__ __forceinline__ void field_fwd(const FieldW<H, K>& w, double t, d4 xp
 // parameter-gradient accumulators of the field (chain-layout tiles of the gradient matrices)
 template <int H, int K> struct FieldG {
   d4 Wh;                                          // rows K, cols K (+ column K = bias via a ones row)
-  d4 Wy[(H + 1 + 15) / 16];                       // rows K, cols H (+ column H = time column)
+  d4 Wy[Dim<H, K>::CT];                           // rows K, cols H (+ column H = time column)
   d4 Wo[Dim<H, K>::HT];                           // rows H, cols K (+ column K = bias)
 };
 
@@ -296,8 +296,8 @@ __device__ __forceinline__ void outer_fire(d4& acc, const double (&a)[4], const 
   __builtin_amdgcn_sched_barrier(0);
 }
 // LDS plan of a sweep block (one wave): tiles of XW_TTILE doubles
-//   0 Q | 1 R | 2 R of K rows + a permanent row of ones | 3 second Q (last H row tile) | 4 second R (last H column tile)
-#define XW_SWEEP_TILES 5
+//   0 Q | 1 R | 2 R of K rows + a permanent row of ones | 3 second Q (last H row tile) | 4, 5 further R tiles of [y ; t]
+#define XW_SWEEP_TILES 6
 
 // vector-Jacobian product of one field evaluation.  ob: cotangent of F's output; returns the cotangent of the y input
 // in yb, adds the cotangent of z0 into xpb (= cotangent of the x-projection and of Win.b), and (PARAMS) accumulates the
@@ -378,21 +378,26 @@ __device__ __forceinline__ void field_vjp(const FieldW<H, K>& w, const FieldWT<H
 #pragma unroll
   for (int r = 0; r < D::KSK; ++r) xpb[r] += zb[r];
   if (OUTER == 2) xw_writeT_n<D::KSK>(lds + DuoPlan<H, K, M>::off(D::HT + M - 1), zb);
-  double r1[4];
+  double rr[D::CT][4];
   if (PARAMS) {
     // one Q tile (the cotangent of z0) against the column tiles of [y ; t]: the time row makes column H collect the
-    // time-column gradient
-    d4 y0 = yin[0], y1 = yin[D::HT - 1];
-    if (D::HT == 1) set_row(y0, H & 15, t);
-    else set_row(y1, H & 15, t);
-    outer_post<D::KSK, D::HR1(0)>(zb, y0, lds);
-    if (D::HT > 1) {
-      xw_writeT_n<D::HR1(D::HT - 1)>(lds + 4 * XW_TTILE, y1);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
+    // time-column gradient (row H & 15 of tile H >> 4: a tile of its own when H is a multiple of 16)
+    xw_writeT_n<D::KSK>(lds, zb);
+#pragma unroll
+    for (int ct = 0; ct < D::CT; ++ct) {
+      d4 yy = ct < D::HT ? yin[ct < D::HT ? ct : 0] : xw_zero4();
+      if (ct == (H >> 4)) set_row(yy, H & 15, t);
+      double* rt = lds + (ct == 0 ? 1 : 3 + ct) * XW_TTILE;            // tiles 1, 4, 5
+      if (ct == 0) xw_writeT_n<D::HR1(0)>(rt, yy);
+      else if (ct == 1) xw_writeT_n<D::HR1(1)>(rt, yy);
+      else xw_writeT_n<D::HR1(2)>(rt, yy);
     }
-    outer_fetch(o0, lds, lds + XW_TTILE);
-    if (D::HT > 1) outer_fetch1(r1, lds + 4 * XW_TTILE);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    outer_fetch1(o0.a, lds);
+#pragma unroll
+    for (int ct = 0; ct < D::CT; ++ct) outer_fetch1(rr[ct], lds + (ct == 0 ? 1 : 3 + ct) * XW_TTILE);
   }
 #pragma unroll
   for (int ht = 0; ht < D::HT; ++ht) yb[ht] = xw_zero4();
@@ -401,12 +406,11 @@ __device__ __forceinline__ void field_vjp(const FieldW<H, K>& w, const FieldWT<H
 #pragma unroll
     for (int rb = 0; rb < D::HB; ++rb) yb[rb >> 2][rb & 3] = XW_MFMA4(wT.WyT[rb][kb], zb[kb], yb[rb >> 2][rb & 3]);
   if (PARAMS) {
-    outer_fire(G.Wy[0], o0.a, o0.b);
-    if (D::HT > 1) outer_fire(G.Wy[D::HT - 1], o0.a, r1);
+#pragma unroll
+    for (int ct = 0; ct < D::CT; ++ct) outer_fire(G.Wy[ct], o0.a, rr[ct]);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }
-  static_assert((H + 1 + 15) / 16 == Dim<H, K>::HT, "the time column lives in the last H-tile");
 }
 
 // start scalar -> hidden state: initial_layers of src/model.py:78,97
@@ -1220,7 +1224,7 @@ __device__ __forceinline__ void sweep_body(const BwdJobs& jobs, const double* __
 template <int H, int K, int M, int S> struct DuoOps {
   double a[4];                                 // tanh rows + ones row
   double r[M > 1 ? M - 1 : 1][4];              // relu(z_j) + ones row, j = 0 .. M-2
-  double y[Dim<H, K>::HT][4];                  // stage input (+ the time row in its last tile)
+  double y[Dim<H, K>::CT][4];                  // stage input tiles of [y ; t] (the time row is patched in at use)
 };
 // where the operands of field evaluation e (chain-wave order: steps L-2 .. 0, stages S-1 .. 0) come from
 template <int H, int K, int M, int METHOD> struct DuoSrc {
@@ -1309,7 +1313,7 @@ __device__ __forceinline__ void duo_outer(const BwdJobs& jobs, const double* __r
 #pragma unroll
       for (int q = 0; q < (M > 1 ? M - 1 : 1); ++q) R.r[q][ks] = c;
 #pragma unroll
-      for (int ht = 0; ht < D::HT; ++ht) R.y[ht][ks] = 0.0;
+      for (int ht = 0; ht < D::CT; ++ht) R.y[ht][ks] = 0.0;
     }
   }
   const int E = (L - 1) * T::S;                 // field evaluations of the sweep
@@ -1324,7 +1328,7 @@ __device__ __forceinline__ void duo_outer(const BwdJobs& jobs, const double* __r
     }
     if (ROLE == 2) {
 #pragma unroll
-      for (int ht = 0; ht < D::HT; ++ht) duo_load_y<H, K, M, METHOD>(R.y[ht], s0, ht, N, tile);
+      for (int ht = 0; ht < D::CT; ++ht) duo_load_y<H, K, M, METHOD>(R.y[ht], s0, ht, N, tile);
     }
   }
   for (int e = 0; e < E; ++e) {
@@ -1374,7 +1378,7 @@ __device__ __forceinline__ void duo_outer(const BwdJobs& jobs, const double* __r
     if (ROLE == 2) {
       // cot(z_0) against [y_in ; t]: column H of dWy (the time row of the last tile) is the time-column gradient
 #pragma unroll
-      for (int ht = 0; ht < D::HT; ++ht) {
+      for (int ht = 0; ht < D::CT; ++ht) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
           const double b = (16 * ht <= H && H < 16 * ht + 16 && 16 * ht + j == H) ? ti_cur : R.y[ht][ks];
@@ -1457,34 +1461,30 @@ int launch_bwd(int method, const BwdJobs& jobs, const double* t, const double* t
 
 }  // namespace
 
-// instantiated (u_hidden_dim, u_hidden_hidden_dim, u_layers) triples: the reference's YAML / notebook widths (20, 10) at
-// every depth 1..8.  Other widths are template parameters (H <= 31 and not a multiple of 16, K <= 15).
+// One object per stepper width (Makefile: -DXW_ODE_H=.. -DXW_ODE_K=..), every depth m = 1..8 in it; the public entry
+// points live in xw_ode_abi.hip and pick the object by (H, K).  Narrower networks run zero-padded inside the next larger
+// width (exact: padding units stay identically zero, nets.Blob).
+#if !defined(XW_ODE_H) || !defined(XW_ODE_K)
+#error "compile with -DXW_ODE_H=<u_hidden_dim> -DXW_ODE_K=<u_hidden_hidden_dim>"
+#endif
+#define XW_CAT4_(a, b, c, d) a##b##c##d
+#define XW_CAT4(a, b, c, d) XW_CAT4_(a, b, c, d)
+#define XW_ODE_FN(name) XW_CAT4(name, XW_ODE_H, _, XW_ODE_K)
 #define XW_ODE_DISPATCH(CALL)                                    \
-  if (H == 20 && K == 10) {                                      \
-    switch (m) {                                                 \
-      case 1: { CALL(20, 10, 1) }                                \
-      case 2: { CALL(20, 10, 2) }                                \
-      case 3: { CALL(20, 10, 3) }                                \
-      case 4: { CALL(20, 10, 4) }                                \
-      case 5: { CALL(20, 10, 5) }                                \
-      case 6: { CALL(20, 10, 6) }                                \
-      case 7: { CALL(20, 10, 7) }                                \
-      case 8: { CALL(20, 10, 8) }                                \
-      default: return XW_E_DIMS;                                 \
-    }                                                            \
-  }                                                              \
-  return XW_E_DIMS;
+  switch (m) {                                                   \
+    case 1: { CALL(XW_ODE_H, XW_ODE_K, 1) }                      \
+    case 2: { CALL(XW_ODE_H, XW_ODE_K, 2) }                      \
+    case 3: { CALL(XW_ODE_H, XW_ODE_K, 3) }                      \
+    case 4: { CALL(XW_ODE_H, XW_ODE_K, 4) }                      \
+    case 5: { CALL(XW_ODE_H, XW_ODE_K, 5) }                      \
+    case 6: { CALL(XW_ODE_H, XW_ODE_K, 6) }                      \
+    case 7: { CALL(XW_ODE_H, XW_ODE_K, 7) }                      \
+    case 8: { CALL(XW_ODE_H, XW_ODE_K, 8) }                      \
+    default: return XW_E_DIMS;                                   \
+  }
 
-extern "C" int xw_ode_bwd_slabs(int N) { return (N + 15) / 16; }
-
-extern "C" int xw_ode_act_rows(int method, int H, int K, int m) {
-  if (H != 20 || K != 10 || m < 1 || m > 8) return XW_E_DIMS;
-  const int S = method == 0 ? 1 : method == 1 ? 2 : 0;           // rk4: the sweeps recompute
-  return S == 0 ? 0 : S * m * K + (S - 1) * H + 2 * S;             // (+ the ReLU-mask words of every stage)
-}
-
-extern "C" int xw_ode_fwd_multi(const XwOdeFwdJob* jobs, int njobs, const double* t, const double* theta, int method, int L,
-                                int d, int H, int K, int m, double* zero16, void* stream) {
+extern "C" int XW_ODE_FN(xw_ode_fwd_multi_w)(const XwOdeFwdJob* jobs, int njobs, const double* t, const double* theta, int method,
+                                             int L, int d, int m, double* zero16, void* stream) {
   if (!jobs || njobs < 1 || njobs > XW_MAXJOBS || !t || !theta || L <= 0 || d <= 0 || m < 1) return XW_E_ARG;
   FwdJobs J;
   J.n = njobs;
@@ -1510,14 +1510,8 @@ extern "C" int xw_ode_fwd_multi(const XwOdeFwdJob* jobs, int njobs, const double
 #undef CALL
 }
 
-extern "C" int xw_ode_fwd(const double* xT, const double* t, const double* start, const double* theta, int method, int N,
-                          int L, int d, int H, int K, int m, double* u, double* Y, void* stream) {
-  XwOdeFwdJob j = {xT, start, u, Y, nullptr, N, 0};
-  return xw_ode_fwd_multi(&j, 1, t, theta, method, L, d, H, K, m, nullptr, stream);
-}
-
-extern "C" int xw_ode_bwd_multi(const XwOdeBwdJob* jobs, int njobs, const double* t, const double* theta, int method, int L,
-                                int d, int H, int K, int m, int mode, void* stream) {
+extern "C" int XW_ODE_FN(xw_ode_bwd_multi_w)(const XwOdeBwdJob* jobs, int njobs, const double* t, const double* theta, int method,
+                                             int L, int d, int m, int mode, void* stream) {
   if (!jobs || njobs < 1 || njobs > XW_MAXJOBS || !t || !theta || L <= 0 || d <= 0 || m < 1 || (mode & 3) == 0 || ((mode & 4) && (mode & 3) != 3) || ((mode & 8) && (mode & 4))) return XW_E_ARG;
   BwdJobs J;
   J.n = njobs;
@@ -1549,11 +1543,4 @@ extern "C" int xw_ode_bwd_multi(const XwOdeBwdJob* jobs, int njobs, const double
                     : launch_bwd<HH, KK, MM, false>(method, J, t, theta, L, d, (mode & 8) != 0, s);
   XW_ODE_DISPATCH(CALL)
 #undef CALL
-}
-
-extern "C" int xw_ode_bwd(const double* xT, const double* t, const double* start, const double* theta, const double* Y,
-                          const double* ubar, int method, int N, int L, int d, int H, int K, int m, int mode, double* gx,
-                          double* gs, double* gslab, void* stream) {
-  XwOdeBwdJob j = {xT, start, Y, nullptr, ubar, gx, gs, gslab, N};
-  return xw_ode_bwd_multi(&j, 1, t, theta, method, L, d, H, K, m, mode, stream);
 }

@@ -1,0 +1,56 @@
+// xw_ode_abi.hip -- public entry points of the stepper (include/xnwan.h): argument checks that do not depend on the
+// width, and the choice of the object compiled for (H, K) (xw_ode.hip, one object per width).
+#include "xw_common.h"
+#include "xnwan.h"
+
+#define XW_ODE_WIDTHS(X) X(20, 10) X(32, 12)      /* keep in step with the Makefile and kernels.ODE_WIDTHS */
+
+#define DECL(H, K)                                                                                                         \
+  extern "C" int xw_ode_fwd_multi_w##H##_##K(const XwOdeFwdJob*, int, const double*, const double*, int, int, int, int, double*, void*); \
+  extern "C" int xw_ode_bwd_multi_w##H##_##K(const XwOdeBwdJob*, int, const double*, const double*, int, int, int, int, int, void*);
+XW_ODE_WIDTHS(DECL)
+#undef DECL
+
+extern "C" int xw_ode_bwd_slabs(int N) { return (N + 15) / 16; }
+
+static bool width_compiled(int H, int K) {
+#define TEST(HH, KK) if (H == HH && K == KK) return true;
+  XW_ODE_WIDTHS(TEST)
+#undef TEST
+  return false;
+}
+
+extern "C" int xw_ode_act_rows(int method, int H, int K, int m) {
+  if (!width_compiled(H, K) || m < 1 || m > 8) return XW_E_DIMS;
+  const int S = method == 0 ? 1 : method == 1 ? 2 : 0;           // rk4: the sweeps recompute
+  return S == 0 ? 0 : S * m * K + (S - 1) * H + 2 * S;             // (+ the ReLU-mask words of every stage)
+}
+
+extern "C" int xw_ode_fwd_multi(const XwOdeFwdJob* jobs, int njobs, const double* t, const double* theta, int method, int L,
+                                int d, int H, int K, int m, double* zero16, void* stream) {
+#define CALL(HH, KK) if (H == HH && K == KK) return xw_ode_fwd_multi_w##HH##_##KK(jobs, njobs, t, theta, method, L, d, m, zero16, stream);
+  XW_ODE_WIDTHS(CALL)
+#undef CALL
+  return XW_E_DIMS;
+}
+
+extern "C" int xw_ode_fwd(const double* xT, const double* t, const double* start, const double* theta, int method, int N,
+                          int L, int d, int H, int K, int m, double* u, double* Y, void* stream) {
+  XwOdeFwdJob j = {xT, start, u, Y, nullptr, N, 0};
+  return xw_ode_fwd_multi(&j, 1, t, theta, method, L, d, H, K, m, nullptr, stream);
+}
+
+extern "C" int xw_ode_bwd_multi(const XwOdeBwdJob* jobs, int njobs, const double* t, const double* theta, int method, int L,
+                                int d, int H, int K, int m, int mode, void* stream) {
+#define CALL(HH, KK) if (H == HH && K == KK) return xw_ode_bwd_multi_w##HH##_##KK(jobs, njobs, t, theta, method, L, d, m, mode, stream);
+  XW_ODE_WIDTHS(CALL)
+#undef CALL
+  return XW_E_DIMS;
+}
+
+extern "C" int xw_ode_bwd(const double* xT, const double* t, const double* start, const double* theta, const double* Y,
+                          const double* ubar, int method, int N, int L, int d, int H, int K, int m, int mode, double* gx,
+                          double* gs, double* gslab, void* stream) {
+  XwOdeBwdJob j = {xT, start, Y, nullptr, ubar, gx, gs, gslab, N};
+  return xw_ode_bwd_multi(&j, 1, t, theta, method, L, d, H, K, m, mode, stream);
+}

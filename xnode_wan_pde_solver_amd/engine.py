@@ -83,8 +83,6 @@ class Engine:
     def __init__(self, config, setup, u_mod, v_mod, funcs, device, world=None, structure=None):
         self.config, self.setup, self.u, self.v, self.funcs, self.dev, self.world = config, setup, u_mod, v_mod, funcs, device, world
         self.d = setup['dim']
-        self.H, self.K, self.m = config['u_hidden_dim'], config['u_hidden_hidden_dim'], config['u_layers']
-        self.W, self.q = config['v_hidden_dim'], config['v_layers']
         self.method = KN.method_id(config['solver'])
         # config['adjoint'] (src/model.py:103): the sweeps integrate torchdiffeq's continuous adjoint instead of reversing
         # the steps taken (include/xnwan.h, xw_ode_bwd mode bit 3); nabla_x u then only flows through the start value
@@ -97,6 +95,10 @@ class Engine:
         self.structure = structure if structure is not None else Structure(funcs, self.d, lo, hi)
         if u_mod.blob is None or v_mod.blob is None:
             raise XnwanError('bind() the networks to the device before building the engine')
+        # widths of the kernel instantiations the two networks run in (>= the configured widths: nets.Blob embeds a narrower
+        # network exactly, zero-padded, in the next larger instantiation)
+        (self.H, self.K), self.m = u_mod.kdims, config['u_layers']
+        self.W, self.q = v_mod.kwidth, config['v_layers']
         self.theta, self.phi = u_mod.blob, v_mod.blob
         self.Pu, self.Pv = self.theta.data.numel(), self.phi.data.numel()
         z = lambda n: torch.zeros(n, dtype=F64, device=device)  # noqa: E731

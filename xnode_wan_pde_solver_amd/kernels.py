@@ -43,6 +43,29 @@ def method_id(name):
     return METHODS[name]
 
 
+# Kernel instantiations (csrc/xw_ode.hip XW_ODE_DISPATCH, csrc/xw_disc.hip): widths the kernels are compiled for.  Any
+# smaller network runs EXACTLY inside the next larger instantiation: its parameters are embedded in a zero-padded blob
+# (nets.Blob) -- padding units have zero in- and outgoing weights and zero bias, so they stay identically zero through
+# relu / tanh, contribute exact zeros to every sum, and receive exactly zero gradients (Adam leaves them at zero).
+ODE_WIDTHS = [(20, 10), (32, 12)]          # (u_hidden_dim, u_hidden_hidden_dim) containers, smallest first
+DISC_WIDTHS = [50]                         # v_hidden_dim containers (W = 50: 3 MFMA row tiles + a 2-row vector tail)
+
+
+def ode_container(H, K):
+    for Hc, Kc in ODE_WIDTHS:
+        if H <= Hc and K <= Kc and lib.xw_theta_size(1, Hc, Kc) > 0 and lib.xw_ode_act_rows(0, Hc, Kc, 1) >= 0:
+            return Hc, Kc
+    raise XnwanError('u_hidden_dim = %d, u_hidden_hidden_dim = %d: the stepper kernels are compiled for widths up to %s'
+                     % (H, K, ODE_WIDTHS[-1]))
+
+
+def disc_container(W):
+    for Wc in DISC_WIDTHS:
+        if W <= Wc and lib.xw_disc_act_rows(Wc, 1) >= 0:
+            return Wc
+    raise XnwanError('v_hidden_dim = %d: the test-network kernels are compiled for widths up to %d' % (W, DISC_WIDTHS[-1]))
+
+
 def theta_size(d, H, K):
     return lib.xw_theta_size(d, H, K)
 

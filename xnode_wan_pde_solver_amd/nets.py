@@ -35,28 +35,49 @@ def init_weights(layer):
 # flat parameter storage
 # ----------------------------------------------------------------------------------------------------------------------
 class Blob:
-    """One contiguous float64 vector holding all parameters of a network in named_parameters() order."""
+    """One contiguous float64 vector holding all parameters of a network in the kernels' layout (include/xnwan.h:
+    named_parameters() order, row-major matrices) -- at the width of the kernel instantiation the network runs in.
 
-    def __init__(self, module, device):
+    `slots`: for every parameter of named_parameters() its place in the blob, (offset, rows, cols, leading dimension[,
+    column offset]); missing slots (a field without hidden layer, u_layers = 1) stay zero.  When the network is as wide as
+    the instantiation the parameters are contiguous pieces; a narrower network is EMBEDDED: every matrix is the leading
+    block of its zero-padded container (the y-columns of Win keep their place behind x and t), so the module's parameters
+    become strided views and the padding never leaves zero (kernels.ODE_WIDTHS)."""
+
+    def __init__(self, module, device, slots=None, total=None):
         params = [p for _, p in module.named_parameters()]      # de-duplicated: tied layers appear once
         self.names = [n for n, _ in module.named_parameters()]
         self.shapes = [tuple(p.shape) for p in params]
         self.sizes = [p.numel() for p in params]
-        self.data = torch.empty(sum(self.sizes), dtype=F64, device=device)
+        if slots is None:                                       # plain concatenation
+            slots, off = [], 0
+            for p in params:
+                r, c = (p.shape[0], p.shape[1]) if p.dim() == 2 else (1, p.numel())
+                slots.append((off, r, c, c))
+                off += p.numel()
+            total = off
+        self.data = torch.zeros(total, dtype=F64, device=device)
         self.grad = torch.zeros_like(self.data)
-        off = 0
-        self.offsets = []
-        for p, n in zip(params, self.sizes):
+        self.slots = slots
+        self.offsets = [sl[0] for sl in slots]
+        for p, (off, r, c, ld) in zip(params, slots):
             if p.dtype != F64:
                 raise XnwanError('network parameters must be float64 (the reference computes in float64 throughout)')
-            self.data[off:off + n].copy_(p.data.reshape(-1))
-            p.data = self.data[off:off + n].view(p.shape)       # parameter now aliases the blob
-            self.offsets.append(off)
-            off += n
+            view = self._view(self.data, p.shape, off, ld)
+            view.copy_(p.data)
+            p.data = view                                       # parameter now aliases the blob
         self.params = params
+        self.embedded = any(p.dim() == 2 and sl[3] != p.shape[1] for p, sl in zip(params, slots)) or total != sum(self.sizes)
+
+    @staticmethod
+    def _view(flat, shape, off, ld):
+        if len(shape) == 2:
+            return flat.as_strided(tuple(shape), (ld, 1), off)
+        return flat[off:off + shape[0]]
 
     def split(self, flat):
-        return [flat[o:o + n].view(s) for o, n, s in zip(self.offsets, self.sizes, self.shapes)]
+        """the per-parameter pieces of a vector laid out like the blob (a gradient), as tensors of the parameters' shapes"""
+        return [self._view(flat, s, sl[0], sl[3]) for s, sl in zip(self.shapes, self.slots)]
 
     def check_alias(self):
         """The kernels read the blob, user code sees the Parameters: make sure they are still the same memory."""
@@ -64,6 +85,39 @@ class Blob:
             if p.data.data_ptr() != self.data.data_ptr() + 8 * o:
                 raise XnwanError('a parameter no longer aliases its blob (module moved/cast after construction?) -- '
                                  'call solver.rebind() after .to()/.double()')
+
+
+def _u_slots(d, H, K, Hc, Kc, has_hidden):
+    """places of u_theta's parameters (named_parameters() order) in the blob of width (Hc, Kc); include/xnwan.h layout"""
+    ldin, p = d + 1 + Hc, 0
+    sl = []
+    for r, c, rc, cc in ((H, 1, Hc, 1), (H, None, Hc, None), (H, H, Hc, Hc), (H, None, Hc, None), (H, H, Hc, Hc), (H, None, Hc, None)):
+        sl.append((p, r, c if c else 1, cc if cc else 1))       # IL0.w, IL0.b, IL2.w, IL2.b, IL4.w, IL4.b
+        p += rc * (cc if cc else 1)
+    sl.append((p, K, d + 1 + H, ldin)); p += Kc * ldin          # Win (x | t | y columns: the y block keeps its offset d + 1)
+    sl.append((p, K, 1, 1)); p += Kc                            # Win.b
+    if has_hidden:
+        sl.append((p, K, K, Kc))
+    p += Kc * Kc                                                # Wh (slot kept zero when the field has no hidden layer)
+    if has_hidden:
+        sl.append((p, K, 1, 1))
+    p += Kc
+    sl.append((p, H, K, Kc)); p += Hc * Kc                      # Wo
+    sl.append((p, H, 1, 1)); p += Hc                            # Wo.b
+    sl.append((p, 1, H, Hc)); p += Hc                           # FL.w
+    sl.append((p, 1, 1, 1)); p += 1                             # FL.b
+    return sl, p
+
+
+def _v_slots(d, W, Wc):
+    p, sl = 0, []
+    sl.append((p, W, d + 1, d + 1)); p += Wc * (d + 1)          # Vin
+    sl.append((p, W, 1, 1)); p += Wc
+    sl.append((p, W, W, Wc)); p += Wc * Wc                      # Vh
+    sl.append((p, W, 1, 1)); p += Wc
+    sl.append((p, 1, W, Wc)); p += Wc                           # Vo
+    sl.append((p, 1, 1, 1)); p += 1
+    return sl, p
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -78,7 +132,7 @@ class _OdeFn(torch.autograd.Function):
         blob = net.blob
         blob.check_alias()
         need = any(ctx.needs_input_grad)
-        u, Y = KN.ode_fwd(xT, t, s, blob.data, net.method, net.hidden_dim, net.hidden_hidden_dim, net.num_layers, want_Y=need)
+        u, Y = KN.ode_fwd(xT, t, s, blob.data, net.method, net.kdims[0], net.kdims[1], net.num_layers, want_Y=need)
         ctx.net, ctx.x_dtype, ctx.x_shape, ctx.s_shape, ctx.s_dtype = net, X.dtype, X.shape, start.shape, start.dtype
         ctx.save_for_backward(xT, t, s, Y if need else None)
         return u.t().unsqueeze(2)
@@ -89,7 +143,7 @@ class _OdeFn(torch.autograd.Function):
         xT, t, s, Y = ctx.saved_tensors
         ubar = gu.squeeze(2).t().contiguous().to(F64)
         want_p = any(ctx.needs_input_grad[3:])
-        gx, gs, slab = KN.ode_bwd(xT, t, s, net.blob.data, Y, ubar, net.method, net.hidden_dim, net.hidden_hidden_dim,
+        gx, gs, slab = KN.ode_bwd(xT, t, s, net.blob.data, Y, ubar, net.method, net.kdims[0], net.kdims[1],
                                   net.num_layers, want_x=True, want_params=want_p, adjoint=bool(net.adjoint))
         gX = None
         if ctx.needs_input_grad[0]:
@@ -111,7 +165,7 @@ class _DiscFn(torch.autograd.Function):
         xT = pts[:, 1:].to(F64).t().contiguous()
         tpp = pts[:, 0].to(F64).contiguous()
         net.blob.check_alias()
-        v, _ = KN.disc_fwd(xT, None, net.blob.data, net.hidden_dim, net.num_layers, tpp=tpp, want_vt=False)
+        v, _ = KN.disc_fwd(xT, None, net.blob.data, net.kwidth, net.num_layers, tpp=tpp, want_vt=False)
         ctx.net, ctx.shape, ctx.dtype = net, XV.shape, XV.dtype
         ctx.save_for_backward(xT, tpp)
         return v.view(XV.shape[:-1]).unsqueeze(-1)
@@ -123,11 +177,11 @@ class _DiscFn(torch.autograd.Function):
         vbar = gv.reshape(1, -1).contiguous().to(F64)
         gX = None
         if ctx.needs_input_grad[0]:
-            gxv, gtv = KN.disc_gradx(xT, None, net.blob.data, net.hidden_dim, net.num_layers, tpp=tpp, vbar=vbar)
+            gxv, gtv = KN.disc_gradx(xT, None, net.blob.data, net.kwidth, net.num_layers, tpp=tpp, vbar=vbar)
             gX = torch.cat((gtv.view(-1, 1), gxv.t()), 1).view(ctx.shape).to(ctx.dtype)
         gp = [None] * len(net.blob.params)
         if any(ctx.needs_input_grad[2:]):
-            gp = net.blob.split(KN.slab_sum(KN.disc_bwd(xT, None, net.blob.data, vbar, net.hidden_dim, net.num_layers, tpp=tpp)))
+            gp = net.blob.split(KN.slab_sum(KN.disc_bwd(xT, None, net.blob.data, vbar, net.kwidth, net.num_layers, tpp=tpp)))
         return (gX, None) + tuple(gp)
 
 
@@ -140,9 +194,9 @@ class HiddenField(nn.Module):
     def __init__(self, input_dim, setup, num_layers, hidden_dim):
         super().__init__()
         self.input_dim, self.hidden_dim, self.num_layers = input_dim, hidden_dim, num_layers
-        if num_layers < 2:
-            raise XnwanError('u_layers must be >= 2: the kernels\' parameter blob always carries the tied hidden layer '
-                             '(with u_layers = 1 the reference builds a field without it, src/model.py:127)')
+        if num_layers < 1:
+            raise XnwanError('u_layers must be >= 1 (u_layers = 0 is the reference\'s degenerate Linear(H, H-1) field, src/model.py:138)')
+        # (u_layers = 1: a field without the tied hidden layer, src/model.py:130; its slot in the blob stays zero)
         tied = [nn.ReLU(), nn.Linear(hidden_dim, hidden_dim)] * (num_layers - 1) if num_layers > 1 else []
         self.net = nn.Sequential(nn.Linear(input_dim + setup['dim'] + 1, hidden_dim), *tied, nn.Tanh(),
                                  nn.Linear(hidden_dim, input_dim)).double()
@@ -171,8 +225,14 @@ class XNODE(nn.Module):
         self.blob = None
 
     def bind(self, device):
+        """move to the device and alias the parameters to the kernels' blob, at the width of the smallest stepper
+        instantiation that holds this network (kernels.ode_container; equal widths: plain concatenation)"""
         self.to(device)
-        self.blob = Blob(self, device)
+        H, K, d = self.hidden_dim, self.hidden_hidden_dim, self.setup['dim']
+        self.kdims = KN.ode_container(H, K)
+        slots, total = _u_slots(d, H, K, self.kdims[0], self.kdims[1], self.num_layers > 1)
+        assert total == KN.theta_size(d, *self.kdims)
+        self.blob = Blob(self, device, slots, total)
         return self.blob
 
     def start_values(self, inputs):
@@ -235,7 +295,11 @@ class TestNet(nn.Module):
 
     def bind(self, device):
         self.to(device)
-        self.blob = Blob(self, device)
+        d = self.input.in_features - 1
+        self.kwidth = KN.disc_container(self.hidden_dim)
+        slots, total = _v_slots(d, self.hidden_dim, self.kwidth)
+        assert total == KN.phi_size(d, self.kwidth)
+        self.blob = Blob(self, device, slots, total)
         return self.blob
 
     def forward(self, XV):
