@@ -214,7 +214,63 @@ class Engine:
     # ------------------------------------------------------------------------------------------------------------
     # per-sample preparation (once per outer iteration; everything here is parameter-independent)
     # ------------------------------------------------------------------------------------------------------------
-    def load_group(self, X, XV, BX, domain, n_glob=None, nb_glob=None, into=None, shared_grid_t0=None):
+    def tabulate_sample(self, triples, domain):
+        """List domains (src/dataset.py:48-229: 11-20 groups per sample): evaluate the user's callables h, f, g and the
+        domain's weight w (with their input gradients) ONCE on the points of ALL groups instead of group by group, and
+        hand every group its slices (load_group(tab=...)).  The callables are PDE data -- functions of the point (t, x) --
+        so evaluating them on a concatenation is the same arithmetic per point; that is CHECKED on the first group of the
+        first sample (bitwise against the per-group call) and batching is switched off with a warning if it does not hold.
+        Per outer iteration this removes ~140 of ~150 callable evaluations, each a dozen tiny kernel launches."""
+        if getattr(self, '_batch_tab', True) is False or len(triples) < 2:
+            return [None] * len(triples)
+        d, T0 = self.d, self.setup['T0']
+        Xs = [t_[0].detach() for t_ in triples]
+        XVs = [t_[1].detach() for t_ in triples]
+        BXs = [t_[2].detach() for t_ in triples]
+        first_t = torch.stack([x[0, 0, 0] for x in Xs] + [b[0, 0, 0] for b in BXs]).tolist()       # ONE host sync for all start times
+        at0 = [float(v) == T0 for v in first_t[:len(Xs)]]
+        bat0 = [float(v) == T0 for v in first_t[len(Xs):]]
+        pts = lambda ts: torch.cat([t_.reshape(-1, 1, d + 1) for t_ in ts], 0)                      # noqa: E731  [P, 1, d+1]
+        cuts = lambda ts: [t_.shape[0] * t_.shape[1] for t_ in ts]                                  # noqa: E731
+        f_all = self.funcs['f'](pts(Xs)).detach().reshape(-1).split(cuts(Xs))
+        g_all = self.funcs['g'](pts(BXs)).detach().reshape(-1).split(cuts(BXs))
+        XVp = pts(XVs).clone().requires_grad_(True)
+        w_all = domain.func_w(XVp)
+        gw_all = torch.autograd.grad(w_all.sum(), XVp)[0] if w_all.requires_grad else torch.zeros_like(XVp)
+        w_all, gw_all = w_all.detach().reshape(-1).split(cuts(XVs)), gw_all.reshape(-1, d + 1).split(cuts(XVs))
+        # start values with their x-gradient: h for groups that start at T0, g for groups that start on the boundary
+        X0 = torch.cat([x[:, 0, :] for x in Xs], 0).clone().requires_grad_(True)
+        n0 = [x.shape[0] for x in Xs]
+        hv = self.funcs['h'](X0).reshape(-1)
+        gv = self.funcs['g'](X0.unsqueeze(1)).reshape(-1) if not all(at0) else hv
+        sel = torch.cat([torch.full((n,), a, dtype=torch.bool) for n, a in zip(n0, at0)]).to(X0.device)
+        start = torch.where(sel, hv, gv)
+        gh = torch.autograd.grad(start.sum(), X0)[0][:, 1:] if start.requires_grad else torch.zeros(X0.shape[0], d, device=X0.device, dtype=X0.dtype)
+        B0 = torch.cat([b[:, 0, :] for b in BXs], 0)
+        nb0 = [b.shape[0] for b in BXs]
+        hb = self.funcs['h'](B0).detach().reshape(-1)
+        gb = self.funcs['g'](B0.unsqueeze(1)).detach().reshape(-1) if not all(bat0) else hb
+        selb = torch.cat([torch.full((n,), a, dtype=torch.bool) for n, a in zip(nb0, bat0)]).to(B0.device)
+        sb = torch.where(selb, hb, gb)
+        tabs = []
+        for k, (x, xv, bx) in enumerate(zip(Xs, XVs, BXs)):
+            N, L = x.shape[0], x.shape[1]
+            tabs.append(dict(starts_T0=at0[k], start=start.detach().split(n0)[k], gh=gh.split(n0)[k], h=hv.detach().split(n0)[k],
+                             f=f_all[k].view(N, L), w=w_all[k].view(N, L), gw=gw_all[k].view(N, L, d + 1),
+                             b_T0=bat0[k], start_b=sb.split(nb0)[k], g=g_all[k].view(bx.shape[0], bx.shape[1])))
+        if not getattr(self, '_batch_tab_checked', False):
+            self._batch_tab_checked = True
+            x, t0 = Xs[0], tabs[0]
+            if not (torch.equal(self.funcs['f'](x).detach(), t0['f']) and torch.equal(self.funcs['h'](x[:, 0, :]).detach().reshape(-1), t0['h'])
+                    and torch.equal(domain.func_w(XVs[0]).detach(), t0['w'])):
+                import warnings
+                warnings.warn('the PDE callables give different values on a concatenation of groups than group by group (not pointwise?): '
+                              'tabulating group by group', RuntimeWarning)
+                self._batch_tab = False
+                return [None] * len(triples)
+        return tabs
+
+    def load_group(self, X, XV, BX, domain, n_glob=None, nb_glob=None, into=None, shared_grid_t0=None, tab=None, verify=True):
         """Prepare one group.  The user's callables (h, f, g, func_w, a, b) are evaluated on the device the given
         tensors live on and only their results are uploaded: pass the loader's host tensors to tabulate exactly like
         the reference's CPU path, or device tensors to tabulate on the GPU (float32 transcendental functions then
@@ -240,20 +296,28 @@ class Engine:
             S['tpp0'] = XV[:, 0, 0].to(dev).to(F64).contiguous()
             S['xvT_pts'] = S['xvT'].unsqueeze(1).expand(d, L, N).reshape(d, L * N).contiguous()
         # start values and their x-gradient (the h -> y0 path of nabla_x u, src/model.py:95)
-        X0 = X[:, 0, :].clone().requires_grad_(True)
-        starts_T0 = (float(X[0, 0, 0]) if shared_grid_t0 is None else float(shared_grid_t0)) == self.setup['T0']
-        s = self.funcs['h'](X0) if starts_T0 else self.funcs['g'](X0.unsqueeze(1)).reshape(-1)
-        S['start'] = s.detach().to(dev).to(F64).reshape(-1).contiguous()
-        if s.requires_grad:
-            S['ghT'] = torch.autograd.grad(s.sum(), X0)[0][:, 1:].to(dev).to(F64).t().contiguous()
+        if tab is not None:                   # (tabulate_sample: evaluated once for all groups of the sample)
+            S['start'] = tab['start'].to(dev).to(F64).reshape(-1).contiguous()
+            S['ghT'] = tab['gh'].to(dev).to(F64).t().contiguous()
+            S['h'] = tab['h'].to(dev).to(F64).reshape(-1).contiguous()
+            S['f'] = _to_LN(tab['f'], dev)
+            w, gw = tab['w'], tab['gw']
         else:
-            S['ghT'] = torch.zeros(d, N, dtype=F64, device=dev)
-        S['h'] = self.funcs['h'](X[:, 0, :]).detach().to(dev).to(F64).reshape(-1).contiguous()
-        S['f'] = _to_LN(self.funcs['f'](X), dev)
-        # distance weight on the v-sample and its gradient (nabla phi = w nabla v + v nabla w, src/loss.py:51-63)
-        XVl = XV.clone().requires_grad_(True)
-        w = domain.func_w(XVl)
-        gw = torch.autograd.grad(w.sum(), XVl)[0] if w.requires_grad else torch.zeros_like(XVl)
+            X0 = X[:, 0, :].clone().requires_grad_(True)
+            starts_T0 = (float(X[0, 0, 0]) if shared_grid_t0 is None else float(shared_grid_t0)) == self.setup['T0']
+            s = self.funcs['h'](X0) if starts_T0 else self.funcs['g'](X0.unsqueeze(1)).reshape(-1)
+            S['start'] = s.detach().to(dev).to(F64).reshape(-1).contiguous()
+            if s.requires_grad:
+                S['ghT'] = torch.autograd.grad(s.sum(), X0)[0][:, 1:].to(dev).to(F64).t().contiguous()
+            else:
+                S['ghT'] = torch.zeros(d, N, dtype=F64, device=dev)
+            # (a group that starts at T0: h(X[:, 0, :]) is the start value itself)
+            S['h'] = S['start'] if starts_T0 else self.funcs['h'](X[:, 0, :]).detach().to(dev).to(F64).reshape(-1).contiguous()
+            S['f'] = _to_LN(self.funcs['f'](X), dev)
+            # distance weight on the v-sample and its gradient (nabla phi = w nabla v + v nabla w, src/loss.py:51-63)
+            XVl = XV.clone().requires_grad_(True)
+            w = domain.func_w(XVl)
+            gw = torch.autograd.grad(w.sum(), XVl)[0] if w.requires_grad else torch.zeros_like(XVl)
         if getattr(domain, 'time_independent', False):
             S['w'] = w[:, 0].detach().to(dev).to(F64).contiguous()
             S['wt'] = None
@@ -269,10 +333,14 @@ class Engine:
             S['tb'] = BX[0, :, 0].to(dev).to(F64).contiguous()
             same_grid = Lb == L and (shared_grid_t0 is not None or bool(torch.equal(S['tb'], S['t'])))
             S['xbT'] = BX[:, 0, 1:].to(dev).to(F64).t().contiguous()
-            b_T0 = (float(BX[0, 0, 0]) if shared_grid_t0 is None else float(shared_grid_t0)) == self.setup['T0']
-            sb = self.funcs['h'](BX[:, 0, :]) if b_T0 else self.funcs['g'](BX[:, 0, :].unsqueeze(1)).reshape(-1)
-            S['start_b'] = sb.detach().to(dev).to(F64).reshape(-1).contiguous()
-            S['g'] = _to_LN(self.funcs['g'](BX), dev)
+            if tab is not None:
+                S['start_b'] = tab['start_b'].to(dev).to(F64).reshape(-1).contiguous()
+                S['g'] = _to_LN(tab['g'], dev)
+            else:
+                b_T0 = (float(BX[0, 0, 0]) if shared_grid_t0 is None else float(shared_grid_t0)) == self.setup['T0']
+                sb = self.funcs['h'](BX[:, 0, :]) if b_T0 else self.funcs['g'](BX[:, 0, :].unsqueeze(1)).reshape(-1)
+                S['start_b'] = sb.detach().to(dev).to(F64).reshape(-1).contiguous()
+                S['g'] = _to_LN(self.funcs['g'](BX), dev)
         st = self.structure
         S['X'] = X.to(dev) if st.c_kappa is None else None      # only read by a general reaction callable c(u, t, x)
         S['A0'] = S['B0'] = None
@@ -280,7 +348,7 @@ class Engine:
             S['A0'] = self._tabulate_a(X[:, :1, :])            # [d,d,N] / [d,N] (diagonal) / [d,d] (constant) at time index 0
         if not st.b_zero:
             S['B0'] = self._tabulate_b(X[:, :1, :])            # [d, N]
-        if self.verify_structure:
+        if self.verify_structure and verify:
             self._check_structure(X, getattr(into, 'sample_version', 0) if into is not None else 0)
         vol = float(domain.V())
         nglob = float(n_glob if n_glob is not None else N)

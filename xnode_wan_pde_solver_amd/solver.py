@@ -285,8 +285,12 @@ class NODE_WAN_solver:
                 shards = self._shard(self._groups(points))
                 if len(self._group_cache) != len(shards):
                     self._group_cache = [None] * len(shards)
-                groups = [eng.load_group(du, dv, bd, domain, ng, nbg, into=old, shared_grid_t0=self._grid_hint)
-                          for (du, dv, bd, ng, nbg), old in zip(shards, self._group_cache)]
+                # list domains: the callables are evaluated once for all groups of the sample; the structure guard runs on the
+                # largest group of the sample (all groups are slices of the same draw)
+                tabs = eng.tabulate_sample([sh[:3] for sh in shards], domain) if len(shards) > 1 else [None]
+                big = max(range(len(shards)), key=lambda i: shards[i][0].shape[0] * shards[i][0].shape[1])
+                groups = [eng.load_group(du, dv, bd, domain, ng, nbg, into=old, shared_grid_t0=self._grid_hint, tab=tb, verify=(i == big))
+                          for i, ((du, dv, bd, ng, nbg), old, tb) in enumerate(zip(shards, self._group_cache, tabs))]
                 self._group_cache = groups
                 several = len(groups) > 1
                 for G in groups:
@@ -294,10 +298,15 @@ class NODE_WAN_solver:
                 for _ in range(self.n1):
                     self.av_l = 0
                     eng.begin_substep('u', several)
+                    lu = []
                     for G in groups:
                         eng.generator_step(G)
-                        self.last_loss_u = eng.loss_u().item()
-                        self.av_l += self.last_loss_u
+                        lu.append(eng.loss_u().clone() if several else eng.loss_u())
+                    lu = torch.stack(lu).tolist() if several else [lu[0].item()]     # ONE read-back per sub-iteration
+                    self.last_loss_u = lu[-1]
+                    self.av_l = 0
+                    for x_ in lu:
+                        self.av_l += x_                   # (summed in group order, like the reference's running sum)
                     past_losses.append(self.av_l)
                     if self._is_main():
                         past_losses.write('losses_NODE_' + str(d) + '.json')
@@ -316,7 +325,7 @@ class NODE_WAN_solver:
                     eng.begin_substep('v', several)
                     for G in groups:
                         eng.discriminator_step(G)
-                        self.last_loss_v = eng.loss_v().item()
+                    self.last_loss_v = eng.loss_v().item()
                 if ahead is not None:
                     points, nxt_domain, nxt_points = ahead.result()
                 else:
