@@ -635,3 +635,27 @@ def test_engine_at_other_network_widths(Hh, Kk, Ww, m, q):
     with torch.no_grad():
         out = S.u_net(pts.interioru)
     close(out.squeeze(2), R.u_net(O.theta, params, O.X, P.func_h(O.X[:, 0, :])), 1e-5, 1e-7)     # (parameters agree to 1e-6 after four updates)
+
+
+def test_custom_operators_pass_opcheck(golden_dir):
+    """the registered operators (ops.py) against torch.library.opcheck's schema / fake-tensor / dispatch checks on real inputs"""
+    z, params = load(golden_dir, 'ref_tiny_midpoint')
+    S = make_solver(params, int(z['seed']))
+    domain, pts = first_sample(S)
+    X = pts.interioru.detach().cuda()
+    net = S.u_net.module
+    start = net.start_values(pts.interioru.detach()).cuda()
+    args = (X, start, net.blob.data, net.method, net.kdims[0], net.kdims[1], net.num_layers, True)
+    torch.library.opcheck(torch.ops.xnwan.xnode_forward, args, test_utils=('test_schema', 'test_faketensor'))
+    u, Y = torch.ops.xnwan.xnode_forward(*args)
+    close(u.squeeze(2), z['gen1/u'], F32TOL, F32TOL)
+    torch.library.opcheck(torch.ops.xnwan.xnode_backward, (torch.ones_like(u), X, start, Y, net.blob.data, net.method, net.kdims[0],
+                                                           net.kdims[1], net.num_layers, False, True),
+                          test_utils=('test_schema', 'test_faketensor'))
+    vn = S.v_net.module
+    XV = pts.interiorv.detach().cuda()
+    torch.library.opcheck(torch.ops.xnwan.testnet_forward, (XV, vn.blob.data, vn.kwidth, vn.num_layers), test_utils=('test_schema', 'test_faketensor'))
+    v = torch.ops.xnwan.testnet_forward(XV, vn.blob.data, vn.kwidth, vn.num_layers)
+    close(v.squeeze(2), z['gen1/v'], 1e-10, 1e-12)
+    torch.library.opcheck(torch.ops.xnwan.testnet_backward, (torch.ones_like(v), XV, vn.blob.data, vn.kwidth, vn.num_layers, True, True),
+                          test_utils=('test_schema', 'test_faketensor'))

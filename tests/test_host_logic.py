@@ -193,3 +193,21 @@ def test_incremental_json_files_are_byte_identical_to_json_dump(tmp_path):
     empty = _JsonList()
     empty.write(path)
     assert path.read_text() == '[]'
+
+
+def test_custom_operators_are_registered():
+    """north_star: 'driven from Python through PyTorch-ROCm custom ops' -- the module-level call surface dispatches to
+    torch.library operators (ops.py); here only their registration and schemas (no GPU)"""
+    from xnode_wan_pde_solver_amd import ops
+    for name in ('xnode_forward', 'xnode_backward', 'testnet_forward', 'testnet_backward'):
+        op = getattr(torch.ops.xnwan, name)
+        assert 'xnwan::' + name in str(op.default._schema)
+    assert len(ops.OPS) == 4
+    # shape inference without a device (fake tensors): what torch.compile / meta tracing sees
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    with FakeTensorMode():
+        X = torch.empty(33, 7, 6)
+        u, Y = torch.ops.xnwan.xnode_forward(X, torch.empty(33, dtype=torch.float64), torch.empty(100, dtype=torch.float64), 1, 20, 10, 8, True)
+        assert u.shape == (33, 7, 1) and Y.shape == (7, 20, 33) and u.dtype == torch.float64
+        v = torch.ops.xnwan.testnet_forward(torch.empty(5, 3, 6), torch.empty(100, dtype=torch.float64), 50, 9)
+        assert v.shape == (5, 3, 1)

@@ -1,6 +1,6 @@
 """a few launches of the stepper kernels at the headline size (for counter passes)"""
 import os, sys
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch
 from xnode_wan_pde_solver_amd import kernels as KN, _lib
 N, L, d, H, K, m = 4096, 32, 20, 20, 10, 8

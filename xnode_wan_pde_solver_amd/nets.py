@@ -19,6 +19,7 @@ import torch
 from torch import nn
 
 from . import kernels as KN
+from . import ops as _ops  # noqa: F401  (registers the xnwan:: operators)
 from ._lib import XnwanError
 
 F64 = torch.float64
@@ -124,65 +125,56 @@ def _v_slots(d, W, Wc):
 # autograd bridges (compat path for user code; the training loop calls the kernels directly)
 # ----------------------------------------------------------------------------------------------------------------------
 class _OdeFn(torch.autograd.Function):
+    """u_net(X).backward(): both directions are the registered operators xnwan::xnode_forward / xnode_backward (ops.py);
+    this Function only routes the flat parameter gradient to the module's parameters (views of the blob)."""
+
     @staticmethod
     def forward(ctx, X, start, net, *params):
-        xT = X[:, 0, 1:].detach().to(F64).t().contiguous()
-        t = X[0, :, 0].detach().to(F64).contiguous()
-        s = start.detach().to(F64).reshape(-1).contiguous()
         blob = net.blob
         blob.check_alias()
         need = any(ctx.needs_input_grad)
-        u, Y = KN.ode_fwd(xT, t, s, blob.data, net.method, net.kdims[0], net.kdims[1], net.num_layers, want_Y=need)
-        ctx.net, ctx.x_dtype, ctx.x_shape, ctx.s_shape, ctx.s_dtype = net, X.dtype, X.shape, start.shape, start.dtype
-        ctx.save_for_backward(xT, t, s, Y if need else None)
-        return u.t().unsqueeze(2)
+        u, Y = torch.ops.xnwan.xnode_forward(X, start, blob.data, net.method, net.kdims[0], net.kdims[1], net.num_layers, need)
+        ctx.net, ctx.x_dtype, ctx.s_shape, ctx.s_dtype = net, X.dtype, start.shape, start.dtype
+        ctx.save_for_backward(X.detach(), start.detach(), Y)
+        return u
 
     @staticmethod
     def backward(ctx, gu):
         net = ctx.net
-        xT, t, s, Y = ctx.saved_tensors
-        ubar = gu.squeeze(2).t().contiguous().to(F64)
+        X, start, Y = ctx.saved_tensors
         want_p = any(ctx.needs_input_grad[3:])
-        gx, gs, slab = KN.ode_bwd(xT, t, s, net.blob.data, Y, ubar, net.method, net.kdims[0], net.kdims[1],
-                                  net.num_layers, want_x=True, want_params=want_p, adjoint=bool(net.adjoint))
+        gx, gs, gflat = torch.ops.xnwan.xnode_backward(gu.contiguous(), X, start, Y, net.blob.data, net.method, net.kdims[0],
+                                                       net.kdims[1], net.num_layers, bool(net.adjoint), want_p)
         gX = None
         if ctx.needs_input_grad[0]:
             # nabla_x u is deposited at time index 0 (the model reads x from slice 0 only, src/model.py:99); the time
             # channel's gradient (non-zero only on path 0 in the reference, never read by the loss) is returned as 0
-            gX = torch.zeros(ctx.x_shape, dtype=ctx.x_dtype, device=gu.device)
-            gX[:, 0, 1:] = gx.t().to(ctx.x_dtype)
+            gX = torch.zeros(X.shape, dtype=ctx.x_dtype, device=gu.device)
+            gX[:, 0, 1:] = gx.to(ctx.x_dtype)
         gS = gs.view(ctx.s_shape).to(ctx.s_dtype) if ctx.needs_input_grad[1] else None
-        gp = [None] * len(net.blob.params)
-        if want_p:
-            gp = net.blob.split(KN.slab_sum(slab))
+        gp = net.blob.split(gflat) if want_p else [None] * len(net.blob.params)
         return (gX, gS, None) + tuple(gp)
 
 
 class _DiscFn(torch.autograd.Function):
+    """v_net(XV).backward() through xnwan::testnet_forward / testnet_backward (ops.py)"""
+
     @staticmethod
     def forward(ctx, XV, net, *params):
-        pts = XV.detach().reshape(-1, XV.shape[-1])
-        xT = pts[:, 1:].to(F64).t().contiguous()
-        tpp = pts[:, 0].to(F64).contiguous()
         net.blob.check_alias()
-        v, _ = KN.disc_fwd(xT, None, net.blob.data, net.kwidth, net.num_layers, tpp=tpp, want_vt=False)
-        ctx.net, ctx.shape, ctx.dtype = net, XV.shape, XV.dtype
-        ctx.save_for_backward(xT, tpp)
-        return v.view(XV.shape[:-1]).unsqueeze(-1)
+        ctx.net, ctx.dtype = net, XV.dtype
+        ctx.save_for_backward(XV.detach())
+        return torch.ops.xnwan.testnet_forward(XV, net.blob.data, net.kwidth, net.num_layers)
 
     @staticmethod
     def backward(ctx, gv):
         net = ctx.net
-        xT, tpp = ctx.saved_tensors
-        vbar = gv.reshape(1, -1).contiguous().to(F64)
-        gX = None
-        if ctx.needs_input_grad[0]:
-            gxv, gtv = KN.disc_gradx(xT, None, net.blob.data, net.kwidth, net.num_layers, tpp=tpp, vbar=vbar)
-            gX = torch.cat((gtv.view(-1, 1), gxv.t()), 1).view(ctx.shape).to(ctx.dtype)
-        gp = [None] * len(net.blob.params)
-        if any(ctx.needs_input_grad[2:]):
-            gp = net.blob.split(KN.slab_sum(KN.disc_bwd(xT, None, net.blob.data, vbar, net.kwidth, net.num_layers, tpp=tpp)))
-        return (gX, None) + tuple(gp)
+        XV, = ctx.saved_tensors
+        want_p = any(ctx.needs_input_grad[2:])
+        gX, gflat = torch.ops.xnwan.testnet_backward(gv.contiguous(), XV, net.blob.data, net.kwidth, net.num_layers,
+                                                     bool(ctx.needs_input_grad[0]), want_p)
+        gp = net.blob.split(gflat) if want_p else [None] * len(net.blob.params)
+        return (gX.to(ctx.dtype) if ctx.needs_input_grad[0] else None, None) + tuple(gp)
 
 
 # ----------------------------------------------------------------------------------------------------------------------
