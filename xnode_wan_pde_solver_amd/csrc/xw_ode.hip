@@ -1215,17 +1215,19 @@ __device__ __forceinline__ void sweep_body(const BwdJobs& jobs, const double* __
 // ---- the duo sweep's second wave: weight gradients of the field -------------------------------------------------------
 // For every field evaluation (same order as the chain wave, one evaluation behind it):
 //     dWo += cot(out) (x) [tanh(z_{m-1}) ; 1]     dWh += sum_j cot(z_{j+1}) (x) [relu(z_j) ; 1]     dWy += cot(z_0) (x) [y_in ; t]
-// as 16x16x4 MFMA outer products over the 16 paths of the tile.  The cotangent tiles come transposed from the chain
-// wave's LDS buffer (A operands, xw_readT); the layer inputs are loaded from the activation store / the checkpoints
-// DIRECTLY as B operands (lane (row j, k) reads element (row j, path 4 ks + k): no LDS round trip), one whole evaluation
-// ahead: a register of the operand set is reloaded for the next evaluation as soon as its MFMA has been issued.
-// Rows past the data of a tile (the ones row that collects the bias gradient, zero padding) live in lanes the loads
-// never touch.
-template <int H, int K, int M, int S> struct DuoOps {
-  double a[4];                                 // tanh rows + ones row
-  double r[M > 1 ? M - 1 : 1][4];              // relu(z_j) + ones row, j = 0 .. M-2
-  double y[Dim<H, K>::CT][4];                  // stage input tiles of [y ; t] (the time row is patched in at use)
-};
+// contractions over the 16 paths of the tile, on v_mfma_f64_4x4x4_4b_f64 with the instruction's four blocks = the four
+// GROUPS OF FOUR PATHS:  acc[g][i][j] += sum_{k<4} q[4 rb + i][path 4 g + k] * r[4 cb + j][path 4 g + k].  One instruction
+// covers a 4 x 4 block of the gradient over ALL 16 paths (every block does useful work, 4-row / 4-column granularity: dWh
+// is 3 x 3 instructions per layer, 76 % of their multiply-adds useful, against 4 16x16x4 instructions at 43 %: 96 x 18
+// instead of 44 x 66 clocks per evaluation); the four per-group partial sums of an accumulator are added ONCE, at the end
+// of the sweep.  A operands: the cotangent tiles the chain wave posted (transposed) in LDS, lane (i, g, k) reads row
+// 4 rb + i, path 4 g + k.  B operands: the layer inputs straight from the activation store / the checkpoints in that same
+// lane layout, fetched a whole evaluation ahead (a register is reloaded for the next evaluation right behind the last
+// instruction that reads it).  Rows a block has no data for (the ones row that collects the bias gradient, zero padding)
+// read a constant table -- every lane loads, the loop stays ONE basic block (see duo_b_ptr).
+typedef const double __attribute__((address_space(1)))* xw_gptr;
+__device__ const double xw_duo_const[2][16] = {{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+                                               {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1}};
 // where the operands of field evaluation e (chain-wave order: steps L-2 .. 0, stages S-1 .. 0) come from
 template <int H, int K, int M, int METHOD> struct DuoSrc {
   const double* __restrict__ A;      // activation record of the step
@@ -1244,154 +1246,180 @@ template <int H, int K, int M, int METHOD> struct DuoSrc {
     ti = t0 + T::c(i) * (tf[l + 1] - t0);
   }
 };
-// one operand tile = 4 registers (k-steps).  B-operand layout: lane (j = lane & 15, k = lane >> 4) holds element
-// (row j, path 4 ks + k) of the 16-row tile.  Lanes of rows the tile has no data for (the ones row that collects the
-// bias gradient, zero padding) read a constant table instead: every lane loads, no divergent branch -- behind exec-masked
-// loads the compiler's wait-count bookkeeping gives up and drains vmcnt(0) once per evaluation, which exposed the whole
-// HBM latency of the operands fetched an evaluation ahead.
-typedef const double __attribute__((address_space(1)))* xw_gptr;
-__device__ const double xw_duo_const[2][16] = {{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
-                                               {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1}};
+template <int H, int K, int M> struct Duo4 {
+  static constexpr int KB1 = (K + 1 + 3) / 4;     // column blocks of [layer input ; 1]
+  static constexpr int HB1 = (H + 1 + 3) / 4;     // column blocks of [y ; t]
+  static constexpr int KB = Dim<H, K>::KB, HB = Dim<H, K>::HB;
+};
+// B operand of column block cb of a K-row activation tile [rows ; ones row ; zero padding]
+// (explicitly GLOBAL pointers: a select between a kernel argument and the address of a __device__ object is a generic
+//  pointer to the compiler, and flat loads return out of order -- every use would drain vmcnt(0))
 template <int H, int K, int M, int METHOD>
-__device__ __forceinline__ void duo_load_act(double (&x)[4], const DuoSrc<H, K, M, METHOD>& s, int jrow /* layer, M-1 = tanh */) {
+__device__ __forceinline__ double duo_load_act(const DuoSrc<H, K, M, METHOD>& s, int jrow /* layer, M-1 = tanh */, int cb) {
   typedef ActLayout<H, K, M, RK<METHOD>::S> AL;
-  const int lane = xw_lane(), j = lane & 15, k = lane >> 4;
-  // (explicitly GLOBAL pointers: a select between a kernel argument and the address of a __device__ object is a generic
-  //  pointer to the compiler, and flat loads return out of order -- every use would drain vmcnt(0) again)
-  const xw_gptr src = j < K ? (xw_gptr)(s.A + (s.i * AL::STAGE + jrow * K + j) * 16 + k) : (xw_gptr)&xw_duo_const[j == K ? 1 : 0][0];
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) x[ks] = __builtin_nontemporal_load(src + 4 * ks);
+  const int lane = xw_lane(), j = lane & 3, pg = (lane >> 2) & 3, k = lane >> 4;
+  const int row = 4 * cb + j;
+  const xw_gptr src = row < K ? (xw_gptr)(s.A + (s.i * AL::STAGE + jrow * K + row) * 16 + 4 * pg + k) : (xw_gptr)&xw_duo_const[row == K ? 1 : 0][0];
+  return __builtin_nontemporal_load(src);
 }
-// stage input tile ht: rows of y_l (checkpoints, stage 0) or of the activation record (later stages).  Branch-free: the
-// helper's loop must stay ONE basic block, or the compiler's wait-count bookkeeping falls back to vmcnt(0) at its head.
+// ... of [y_in ; t ; zero padding]: rows of y_l (checkpoints, stage 0) or of the activation record (later stages);
+// branch-free (the loop must stay one basic block, or the compiler's wait-count bookkeeping falls back to vmcnt(0) at
+// its head); the time row is patched in where the block is USED (a select here would wait for the load)
 template <int H, int K, int M, int METHOD>
-__device__ __forceinline__ void duo_load_y(double (&x)[4], const DuoSrc<H, K, M, METHOD>& s, int ht, int N, int tile) {
+__device__ __forceinline__ double duo_load_y(const DuoSrc<H, K, M, METHOD>& s, int cb, int N, int tile) {
   typedef ActLayout<H, K, M, RK<METHOD>::S> AL;
-  const int lane = xw_lane(), j = lane & 15, k = lane >> 4;
-  const int row = 16 * ht + j;
+  const int lane = xw_lane(), j = lane & 3, pg = (lane >> 2) & 3, k = lane >> 4;
+  const int row = 4 * cb + j;
   const bool first = s.i == 0;                                // (wave-uniform)
   const double* __restrict__ base = first ? s.Yl : s.A + (long)(AL::YI + (s.i > 0 ? s.i - 1 : 0) * H) * 16;
   const long rs = first ? N : 16, c0 = first ? tile * 16 : 0, cmax = first ? N - 1 : 15;
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) {
-    const long col = c0 + 4 * ks + k;
-    const xw_gptr src = row < H ? (xw_gptr)(base + row * rs + (col < cmax ? col : cmax)) : (xw_gptr)&xw_duo_const[0][0];
-    x[ks] = __builtin_nontemporal_load(src);
-  }
-  // (the time row of the last tile is patched in where the tile is USED: a select here would wait for the loads)
+  const long col = c0 + 4 * pg + k;
+  const xw_gptr src = row < H ? (xw_gptr)(base + row * rs + (col < cmax ? col : cmax)) : (xw_gptr)&xw_duo_const[0][0];
+  return __builtin_nontemporal_load(src);
 }
-// ROLE 1: dWh (the M-1 tied hidden layers: 4 (M-1) matrix instructions per evaluation);  ROLE 2: dWo and dWy (4 HT each).
-// Two partner waves instead of one: with all 44 instructions (2816 clocks + operand traffic) in one stream the partner,
-// not the chain, set the pace (127 us against 92 us for the chain wave alone at N = 4096).
-template <int H, int K, int M, int METHOD, int ROLE>
+// A operand: rows 4 rb .. 4 rb + 3 of a transposed cotangent tile in LDS (tile[row * XW_TSTRIDE + path])
+__device__ __forceinline__ double duo_readA(const double* tile, int rb) {
+  const int l = xw_lane();
+  return tile[(4 * rb + (l & 3)) * XW_TSTRIDE + ((l >> 2) & 3) * 4 + (l >> 4)];
+}
+// sum of an accumulator's four path-group partials (lane bits 2, 3), then element (row 4 rb + i, col 4 cb + j) from lane j + 16 i
+__device__ __forceinline__ double duo_fold(double x) {
+  x += __shfl_xor(x, 4);
+  x += __shfl_xor(x, 8);
+  return x;
+}
+template <int H, int K, int M, int METHOD>
 __device__ __forceinline__ void duo_outer(const BwdJobs& jobs, const double* __restrict__ tf, const double* __restrict__ th,
                                           int L, int d, const double* qbuf) {
   typedef Dim<H, K> D;
   typedef RK<METHOD> T;
   typedef DuoPlan<H, K, M> P;
+  typedef Duo4<H, K, M> Q;
   typedef DuoSrc<H, K, M, METHOD> Src;
+  constexpr int NH = M > 1 ? M - 1 : 1;
   __builtin_amdgcn_s_setprio(XW_ODE_PRIO);
   const int job = find_job(jobs);
   const double* __restrict__ Y = jobs.Y[job];
   const double* __restrict__ act = jobs.act[job];
   const int N = jobs.N[job];
   const int tile = (int)blockIdx.x - jobs.tile0[job];
-  const int lane = xw_lane(), j = lane & 15;
+  const int lane = xw_lane();
   const UOff o = u_offsets(d, H, K);
-  FieldG<H, K> G;
-  G.Wh = xw_zero4();
+  double gWh[Q::KB][Q::KB1], gWo[Q::HB][Q::KB1], gWy[Q::KB][Q::HB1];
 #pragma unroll
-  for (int ct = 0; ct < (H + 1 + 15) / 16; ++ct) G.Wy[ct] = xw_zero4();
+  for (int rb = 0; rb < Q::KB; ++rb) {
 #pragma unroll
-  for (int ht = 0; ht < D::HT; ++ht) G.Wo[ht] = xw_zero4();
-  DuoOps<H, K, M, T::S> R;
-  {  // lanes the loads never write: the ones row (row K of the activation tiles), zero padding
-    const double c = j == K ? 1.0 : 0.0;
+    for (int cb = 0; cb < Q::KB1; ++cb) gWh[rb][cb] = 0.0;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      R.a[ks] = c;
-#pragma unroll
-      for (int q = 0; q < (M > 1 ? M - 1 : 1); ++q) R.r[q][ks] = c;
-#pragma unroll
-      for (int ht = 0; ht < D::CT; ++ht) R.y[ht][ks] = 0.0;
-    }
+    for (int cb = 0; cb < Q::HB1; ++cb) gWy[rb][cb] = 0.0;
   }
-  const int E = (L - 1) * T::S;                 // field evaluations of the sweep
-  double ti_cur = 0.0;                          // time of the evaluation whose operands are in R
+#pragma unroll
+  for (int rb = 0; rb < Q::HB; ++rb)
+#pragma unroll
+    for (int cb = 0; cb < Q::KB1; ++cb) gWo[rb][cb] = 0.0;
+  double Ra[Q::KB1], Rr[NH][Q::KB1], Ry[Q::HB1];          // B operands of the evaluation in flight
+  const int E = (L - 1) * T::S;                            // field evaluations of the sweep
+  double ti_cur = 0.0;                                     // time of the evaluation whose operands are in R*
   if (E > 0) {
     const Src s0(Y, act, tf, 0, L, N, tile);
     ti_cur = s0.ti;
-    if (ROLE == 2) duo_load_act<H, K, M, METHOD>(R.a, s0, M - 1);
-    if (ROLE == 1) {
 #pragma unroll
-      for (int jj = M - 2; jj >= 0; --jj) duo_load_act<H, K, M, METHOD>(R.r[jj], s0, jj);
-    }
-    if (ROLE == 2) {
+    for (int cb = 0; cb < Q::KB1; ++cb) Ra[cb] = duo_load_act<H, K, M, METHOD>(s0, M - 1, cb);
 #pragma unroll
-      for (int ht = 0; ht < D::CT; ++ht) duo_load_y<H, K, M, METHOD>(R.y[ht], s0, ht, N, tile);
-    }
+    for (int jj = M - 2; jj >= 0; --jj)
+#pragma unroll
+      for (int cb = 0; cb < Q::KB1; ++cb) Rr[jj][cb] = duo_load_act<H, K, M, METHOD>(s0, jj, cb);
+#pragma unroll
+    for (int cb = 0; cb < Q::HB1; ++cb) Ry[cb] = duo_load_y<H, K, M, METHOD>(s0, cb, N, tile);
   }
+  const bool trow = (lane & 3) == (H & 3);                 // lanes of the time row inside its column block H >> 2
   for (int e = 0; e < E; ++e) {
     // the chain wave has posted evaluation e (and is free to start e + 1).  No fence: an acquire would drain vmcnt and
     // with it the operand loads issued a whole evaluation ahead; LDS reads behind the barrier see the posted tiles.
     asm volatile("s_barrier" ::: "memory");
     const double* q = qbuf + (e & 1) * P::BUF;
-#if defined(XW_DUO_DBG) && XW_DUO_DBG == 3
-    const Src sn(Y, act, tf, 0, L, N, tile);
-#else
     const Src sn(Y, act, tf, e + 1 < E ? e + 1 : e, L, N, tile);   // (the last evaluation reloads its own operands: no branch)
-#endif
-    // all A operands of the evaluation first (distinct registers: issued back to back, one exposed LDS latency per
-    // evaluation instead of one per pair of matrix instructions), then, tile by tile, the matrix instructions and
-    // right behind them the loads that refill the tile's B registers for the NEXT evaluation (a whole evaluation of
-    // matrix work ahead of their use: HBM latency is never exposed)
-    constexpr int T0 = ROLE == 1 ? D::HT : 0, T1 = ROLE == 1 ? D::HT + M - 1 : P::NQ;      // Q tiles this role reads
-    double A[P::NQ][4];
+    // all A operands of the evaluation first (distinct registers, issued back to back: one exposed LDS latency per
+    // evaluation), then block by block the matrix instructions and right behind them the reloads for the next evaluation
+    double Ao[Q::HB], Az[M][Q::KB];
 #pragma unroll
-    for (int tq = T0; tq < T1; ++tq)
-      if (ROLE == 1 || tq < D::HT || tq == P::NQ - 1) {
+    for (int rb = 0; rb < Q::HB; ++rb) Ao[rb] = duo_readA(q + P::off(rb >> 2), rb & 3);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) A[tq][ks] = xw_readT(q + P::off(tq), ks);
-      }
+    for (int tq = 0; tq < M; ++tq)
+#pragma unroll
+      for (int rb = 0; rb < Q::KB; ++rb) Az[tq][rb] = duo_readA(q + P::off(D::HT + tq), rb);
     __builtin_amdgcn_sched_barrier(0);
-    if (ROLE == 2) {
-      // cot(out) tiles against [tanh ; 1]
+    // cot(out) against [tanh ; 1]
 #pragma unroll
-      for (int ht = 0; ht < D::HT; ++ht)
+    for (int cb = 0; cb < Q::KB1; ++cb)
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) G.Wo[ht] = XW_MFMA(A[ht][ks], R.a[ks], G.Wo[ht]);
+      for (int rb = 0; rb < Q::HB; ++rb) gWo[rb][cb] = XW_MFMA4(Ao[rb], Ra[cb], gWo[rb][cb]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int cb = 0; cb < Q::KB1; ++cb) Ra[cb] = duo_load_act<H, K, M, METHOD>(sn, M - 1, cb);
+    __builtin_amdgcn_sched_barrier(0);
+    // cot(z_{j+1}) against [relu(z_j) ; 1], j = M-2 .. 0 (tile order of the chain wave)
+#pragma unroll
+    for (int jj = M - 2; jj >= 0; --jj) {
+#pragma unroll
+      for (int cb = 0; cb < Q::KB1; ++cb)
+#pragma unroll
+        for (int rb = 0; rb < Q::KB; ++rb) gWh[rb][cb] = XW_MFMA4(Az[M - 2 - jj][rb], Rr[jj][cb], gWh[rb][cb]);
       __builtin_amdgcn_sched_barrier(0);
-      duo_load_act<H, K, M, METHOD>(R.a, sn, M - 1);
+#pragma unroll
+      for (int cb = 0; cb < Q::KB1; ++cb) Rr[jj][cb] = duo_load_act<H, K, M, METHOD>(sn, jj, cb);
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (ROLE == 1) {
-      // cot(z_{j+1}) against [relu(z_j) ; 1], j = M-2 .. 0 (tile order of the chain wave)
+    // cot(z_0) against [y_in ; t]: column H of dWy (the time row) is the time-column gradient
 #pragma unroll
-      for (int jj = M - 2; jj >= 0; --jj) {
+    for (int cb = 0; cb < Q::HB1; ++cb) {
+      const double b = (cb == (H >> 2) && trow) ? ti_cur : Ry[cb];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) G.Wh = XW_MFMA(A[D::HT + (M - 2 - jj)][ks], R.r[jj][ks], G.Wh);
-        __builtin_amdgcn_sched_barrier(0);
-        duo_load_act<H, K, M, METHOD>(R.r[jj], sn, jj);
-        __builtin_amdgcn_sched_barrier(0);
-      }
+      for (int rb = 0; rb < Q::KB; ++rb) gWy[rb][cb] = XW_MFMA4(Az[M - 1][rb], b, gWy[rb][cb]);
     }
-    if (ROLE == 2) {
-      // cot(z_0) against [y_in ; t]: column H of dWy (the time row of the last tile) is the time-column gradient
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int ht = 0; ht < D::CT; ++ht) {
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          const double b = (16 * ht <= H && H < 16 * ht + 16 && 16 * ht + j == H) ? ti_cur : R.y[ht][ks];
-          G.Wy[ht] = XW_MFMA(A[D::HT + M - 1][ks], b, G.Wy[ht]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        duo_load_y<H, K, M, METHOD>(R.y[ht], sn, ht, N, tile);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
+    for (int cb = 0; cb < Q::HB1; ++cb) Ry[cb] = duo_load_y<H, K, M, METHOD>(sn, cb, N, tile);
+    __builtin_amdgcn_sched_barrier(0);
     ti_cur = sn.ti;
   }
-  store_field_grads<H, K, ROLE == 1, ROLE == 2>(jobs.gslab[job] + (long)tile * o.total, o, d, G);
+  // ---- fold the path groups and store this tile's slab pieces: lane j + 16 i of block (rb, cb) holds (4 rb + i, 4 cb + j)
+  double* slab = jobs.gslab[job] + (long)tile * o.total;
+  const int i = lane >> 4, j = lane & 3;
+  const bool owner = ((lane >> 2) & 3) == 0;
+#pragma unroll
+  for (int rb = 0; rb < Q::KB; ++rb)
+#pragma unroll
+    for (int cb = 0; cb < Q::KB1; ++cb) {
+      const double x = duo_fold(gWh[rb][cb]);
+      const int row = 4 * rb + i, col = 4 * cb + j;
+      if (owner && row < K) {
+        if (col < K) slab[o.Wh + row * K + col] = x;
+        else if (col == K) slab[o.Whb + row] = x;
+      }
+    }
+#pragma unroll
+  for (int rb = 0; rb < Q::HB; ++rb)
+#pragma unroll
+    for (int cb = 0; cb < Q::KB1; ++cb) {
+      const double x = duo_fold(gWo[rb][cb]);
+      const int row = 4 * rb + i, col = 4 * cb + j;
+      if (owner && row < H) {
+        if (col < K) slab[o.Wo + row * K + col] = x;
+        else if (col == K) slab[o.Wob + row] = x;
+      }
+    }
+#pragma unroll
+  for (int rb = 0; rb < Q::KB; ++rb)
+#pragma unroll
+    for (int cb = 0; cb < Q::HB1; ++cb) {
+      const double x = duo_fold(gWy[rb][cb]);
+      const int row = 4 * rb + i, col = 4 * cb + j;
+      if (owner && row < K) {
+        if (col < H) slab[o.Win + row * o.ldin + d + 1 + col] = x;
+        else if (col == H) slab[o.Win + row * o.ldin + d] = x;
+      }
+    }
 }
 
 template <int H, int K, int M, int METHOD, bool PARAMS, bool SAVED, bool ADJ = false>
@@ -1400,15 +1428,14 @@ __global__ void __launch_bounds__(64) k_ode_bwd(const BwdJobs jobs, const double
   __shared__ double lds[XW_SWEEP_TILES * XW_TTILE];   // (plan: XW_SWEEP_TILES)
   sweep_body<H, K, M, METHOD, PARAMS, SAVED, ADJ, false>(jobs, tf, th, L, d, lds, nullptr);
 }
-// the duo sweep: wave 0 = adjoint chain, waves 1, 2 = weight gradients of the field (see sweep_body / duo_outer)
-#define XW_DUO_THREADS 192
+// the duo sweep: wave 0 = adjoint chain, wave 1 = weight gradients of the field (see sweep_body / duo_outer)
+#define XW_DUO_THREADS 128
 template <int H, int K, int M, int METHOD>
 __global__ void __launch_bounds__(XW_DUO_THREADS) k_ode_bwd_duo(const BwdJobs jobs, const double* __restrict__ tf,
                                                                 const double* __restrict__ th, int L, int d) {
   __shared__ double lds[2 * DuoPlan<H, K, M>::BUF];
   if (threadIdx.x < 64) sweep_body<H, K, M, METHOD, true, true, false, true>(jobs, tf, th, L, d, nullptr, lds);
-  else if (threadIdx.x < 128) duo_outer<H, K, M, METHOD, 1>(jobs, tf, th, L, d, lds);
-  else duo_outer<H, K, M, METHOD, 2>(jobs, tf, th, L, d, lds);
+  else duo_outer<H, K, M, METHOD>(jobs, tf, th, L, d, lds);
 }
 
 template <int H, int K, int M>
