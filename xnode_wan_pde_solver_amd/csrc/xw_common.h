@@ -133,6 +133,14 @@ __device__ __forceinline__ d4 xw_relu(d4 z) {
   for (int r = 0; r < 4; ++r) o[r] = z[r] > 0.0 ? z[r] : 0.0;
   return o;
 }
+// x where b > 0, else +0, for b >= 0 (a ReLU output): the 64-bit pattern of b is non-zero exactly when b > 0, so the gate is
+// a mask  -(min(lo | hi, 1))  and two 32-bit ANDs -- five 2.3-clock instructions where a compare and two v_cndmask_b32
+// cost 4.6 + 2 x 6 clocks of the SIMD (profiles/r02_probe_coexec.txt)
+__device__ __forceinline__ double xw_gate_pos(double b, double x) {
+  const unsigned t = (unsigned)__double2loint(b) | (unsigned)__double2hiint(b);
+  const int m = -(int)(t < 1u ? t : 1u);
+  return __hiloint2double(__double2hiint(x) & m, __double2loint(x) & m);
+}
 __device__ __forceinline__ d4 xw_zero4() { d4 z = {0.0, 0.0, 0.0, 0.0}; return z; }
 
 // tanh(x) = sign(x) (1 - e) / (1 + e), e = exp(-2|x|): ~32 f64 VALU ops instead of the ~93 of the library tanh, which

@@ -162,7 +162,7 @@ __global__ void __launch_bounds__(256, 2) k_disc_fwd(const double* __restrict__ 
       for (int ks = 0; ks < D::KS; ++ks) {
         const double av = ai[ks >> 2][ks & 3];
         const double b = av > 0.0 ? av : 0.0;
-        const double bd = av > 0.0 ? adi[ks >> 2][ks & 3] : 0.0;
+        const double bd = xw_gate_pos(b, adi[ks >> 2][ks & 3]);
         if (ACT) {   // activation store: row j W + k of the record is the layer input relu(a_j)[k], point-major
           double* __restrict__ rowp = actl + (j * W + 4 * ks) * 16;             // uniform pointer + 32-bit lane offset
           if (4 * ks + 3 < W || 4 * ks + g < W) __builtin_nontemporal_store(b, rowp + aoff);   // (streamed: read once, much later)

@@ -82,6 +82,7 @@ template <int M> struct Save {               // what the VJP of one field evalua
   d4 z[M > 1 ? M - 1 : 1];                   // relu(z_0) .. relu(z_{m-2}): layer inputs; their sign pattern is the ReLU mask
   d4 a;                                      // tanh(z_{m-1})
   __device__ __forceinline__ bool pos(int j, int r) const { return z[j][r] > 0.0; }
+  __device__ __forceinline__ double gate(int j, int r, double x) const { return z[j][r] > 0.0 ? x : 0.0; }   // relu'(z_j) * x
 };
 // the same for a sweep without weight gradients: the layer inputs are only needed as their ReLU masks, 4 bits per layer
 // (registers 0..3 of the K-tile) in one word -- the x-only sweep then loads 1 word + tanh instead of m K doubles per stage
@@ -90,6 +91,13 @@ template <int M> struct SaveX {
   d4 a;
   unsigned bits;
   __device__ __forceinline__ bool pos(int j, int r) const { return (bits >> (4 * j + r)) & 1u; }
+  // relu'(z_j) * x as two 32-bit ANDs with the mask bit spread to 0 / ~0 (one v_bfe_i32 that does not depend on x):
+  // a v_cndmask_b32 costs ~6 clocks of the SIMD, a v_and_b32 2.3 (profiles/r02_probe_coexec.txt), and the gate sits on the
+  // adjoint chain's critical path once per layer and register
+  __device__ __forceinline__ double gate(int j, int r, double x) const {
+    const int m = __builtin_amdgcn_sbfe((int)bits, 4 * j + r, 1);
+    return __hiloint2double(__double2hiint(x) & m, __double2loint(x) & m);
+  }
 };
 
 template <int H, int K>
@@ -373,7 +381,7 @@ __device__ __forceinline__ void field_vjp(const FieldW<H, K>& w, const FieldWT<H
       for (int rb = 0; rb < D::KB; ++rb) tt[rb] = XW_MFMA4(wT.WhT[rb][kb], zb[kb], tt[rb]);
     if (PARAMS) outer_fire(G.Wh, o0.a, o0.b);
 #pragma unroll
-    for (int r = 0; r < D::KSK; ++r) zb[r] = sv.pos(j, r) ? tt[r] : 0.0;
+    for (int r = 0; r < D::KSK; ++r) zb[r] = sv.gate(j, r, tt[r]);
   }
 #pragma unroll
   for (int r = 0; r < D::KSK; ++r) xpb[r] += zb[r];
