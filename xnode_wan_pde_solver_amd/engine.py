@@ -124,8 +124,9 @@ class Engine:
         # resident slots leaves a quarter of the SIMDs to the stepper chains (measured: 1221 vs 1159 steps/s).
         cus = torch.cuda.get_device_properties(device).multi_processor_count
         self.v_blocks = int(os.environ.get('XW_V_BLOCKS', '0')) or (3 * 2 * cus) // 4
-        # (discriminator sub-step, where the launch also stores the layer inputs: same 3/4 -- 0.840 ms vs 0.862 at 7/8)
-        self.v_blocks_disc = int(os.environ.get('XW_V_BLOCKS_DISC', '0')) or (3 * 2 * cus) // 4
+        # (discriminator sub-step: only the stepper forward and the x-only sweep run beside it, 33 us of SIMD time: 7/8 of the
+        #  slots -- 0.630 ms against 0.643 at 3/4, 0.681 at 15/16, 0.706 at all of them)
+        self.v_blocks_disc = int(os.environ.get('XW_V_BLOCKS_DISC', '0')) or (7 * 2 * cus) // 8
         self._phi_version = 0
         self.streams = [torch.cuda.Stream(device=device) for _ in range(4)]
         # several GPUs on RCCL: the exchanges are device-side calls on the current stream (dist.World.capturable), so a
