@@ -269,6 +269,31 @@ def test_disc_forward_and_time_tangent(N, L, d):
     _close(gtv, gX[:, 0, 0], 1e-11, 'fused dv/dt at t0')
 
 
+def test_disc_forward_ticket_queue_matches_static_split_over_many_launches():
+    """more tiles than waves: the tiles after a wave's first one come from ticket counters (k_disc_fwd DYN) that the last wave
+    of a launch zeroes again.  Which wave computes a tile cannot change its result: every launch -- more of them than there are
+    queue slots, over several grid caps, with and without the record and the fused gradient -- must be BIT-identical to a launch
+    with one wave per tile (static split)."""
+    from xnode_wan_pde_solver_amd import kernels as KN
+    N, L, d = 1000, 7, 20                                    # 438 tiles (the last one ragged)
+    _, phi = _params(d, 8, 51)
+    x, t, _ = _sample(N, L, d, 52)
+    xT, tc, blob = x.double().t().contiguous().cuda(), t.double().cuda(), _blob(phi, V_ORDER)
+    gx0, gt0 = torch.empty(d, N, dtype=torch.float64).cuda(), torch.empty(N, dtype=torch.float64).cuda()
+    v0, vt0 = KN.disc_fwd(xT, tc, blob, W, Q, gxv=gx0, gtv=gt0, ngrad=N)          # 110 blocks: one tile per wave
+    rec0 = torch.zeros(KN.disc_act_rows(W, Q), KN.disc_act_cols(L * N), dtype=torch.float64).cuda()
+    KN.disc_fwd(xT, tc, blob, W, Q, act=rec0)
+    for k in range(150):
+        cap = (1, 2, 3, 7, 33, 40, 64, 100)[k % 8]
+        gx, gt = torch.full_like(gx0, float('nan')), torch.full_like(gt0, float('nan'))
+        v, vt = KN.disc_fwd(xT, tc, blob, W, Q, gxv=gx, gtv=gt, ngrad=N, max_blocks=cap)
+        assert torch.equal(v, v0) and torch.equal(vt, vt0) and torch.equal(gx, gx0) and torch.equal(gt, gt0), (k, cap)
+        if k % 10 == 0:
+            rec = torch.zeros_like(rec0)
+            v, vt = KN.disc_fwd(xT, tc, blob, W, Q, act=rec, max_blocks=cap)
+            assert torch.equal(v, v0) and torch.equal(vt, vt0) and torch.equal(rec, rec0), (k, cap)
+
+
 @pytest.mark.parametrize('N,d', [(37, 5), (64, 20), (20, 70)])
 def test_disc_input_gradient(N, d):
     from oracle import refspec as R

@@ -18,6 +18,8 @@
 //                outer products over the points (LDS transpose; 4 waves of a block own one 16-row band of dVh each).
 //                Optionally also returns the input gradient (nabla_x v, dv/dt) -- used for nabla phi at t0.
 #include "xw_common.h"
+#include <atomic>
+#include <cstdlib>
 
 namespace {
 
@@ -81,12 +83,25 @@ __device__ __forceinline__ void input_layer(const double* __restrict__ ph, const
 // ------------------------------------------------------------------------------------------------------------------
 #define XW_QMAX 16   // deepest test network whose ReLU masks fit the LDS stash of k_disc_fwd's fused input gradient
 
-template <int W, bool ACT>
+// DYN: only a wave's first tile is its static one; every later tile comes from ticket counters (one returning atomic per
+// tile by lane 0, issued before the input layer and read after it).  A SIMD's vector and FP64 matrix instructions add up
+// across all waves it hosts (profiles/r02_probe_coexec.txt), and with 3/4 of the block slots every second CU hosts two
+// blocks of this kernel and the others one block plus the stepper's waves: a static split ends with the most loaded SIMD.
+// The waves of a launch move in step, so their fetches come in bursts and one word serves only ~88 atomics/us: the tiles
+// after the first round are dealt round-robin to XW_DISC_NQ sub-queues (one 256-byte line each), a block's home queue is
+// blockIdx mod NQ, and a wave whose queue ran dry tries the next XW_DISC_STEAL ones before it stops.  The last wave out
+// (LDS count per block, then one global count) zeroes the words for the slot's next launch.
+#define XW_DISC_NQ 32
+#define XW_DISC_STEAL 3
+#define XW_DISC_QSTRIDE 64
+#define XW_DISC_SLOTS 64
+__device__ unsigned int xw_disc_queue[XW_DISC_SLOTS][(XW_DISC_NQ + 1) * XW_DISC_QSTRIDE];
+template <int W, bool ACT, bool DYN>
 __global__ void __launch_bounds__(256, 2) k_disc_fwd(const double* __restrict__ xT, const double* __restrict__ tf,
                                                      const double* __restrict__ tpp, const double* __restrict__ ph, int N,
                                                      int L, int d, int q, double* __restrict__ v, double* __restrict__ vt,
                                                      double* __restrict__ gxv, double* __restrict__ gtv, int ngrad,
-                                                     double* __restrict__ act) {
+                                                     double* __restrict__ act, unsigned int* __restrict__ queue) {
   typedef VDim<W> D;
   // Vh as MFMA A-fragments in LDS (26.6 KB), shared by the 4 waves of the block: one ds_read_b64 feeds two 64-cycle MFMAs
   // (value and d/dt tangent), and keeping them out of the register file lets two waves share a SIMD so that one wave's
@@ -95,6 +110,9 @@ __global__ void __launch_bounds__(256, 2) k_disc_fwd(const double* __restrict__ 
   __shared__ double sB[2 * 16 * D::MT];
   __shared__ double sT[D::KS * 4 * (D::VTAIL ? D::TR : 1)];   // Vh[16 (MT-1) + r][4 ks + g]: the tail rows, per lane group
   __shared__ unsigned short sMask[XW_QMAX][256];   // ReLU masks (16 rows per lane) of the layers, for the fused reverse chain
+  __shared__ unsigned int sDone;
+  if (DYN && threadIdx.x == 0) sDone = 0;
+  // (s_setprio for this kernel's waves: no gain at 1, -5 % at 3 -- the sub-step's SIMD time is conserved)
   const int lane = xw_lane(), g = lane >> 4;
   const int wave = threadIdx.x >> 6;
   const VOff o = v_offsets(d, W);
@@ -121,8 +139,15 @@ __global__ void __launch_bounds__(256, 2) k_disc_fwd(const double* __restrict__ 
   // slowest wave, 6 tile-times instead of 7 at the headline size (5.33 tiles per wave).
   const long G = (long)gridDim.x * 4;
   const long rot = ntiles >= G ? ntiles % G : 0;
-  for (long it = (long)blockIdx.x * 4 + wave; it < ntiles; it += G) {
-    const long tile = it < G ? it - rot + (it < rot ? G : 0) : it;
+  // (wave-uniform) sub-queues of this launch -- every one has a home block, which only stops once it is dry --, the one in
+  // use, dry queues seen
+  const int nq = (int)gridDim.x < XW_DISC_NQ ? (int)gridDim.x : XW_DISC_NQ;
+  int cur = blockIdx.x % nq, tries = 0;
+  for (long it = (long)blockIdx.x * 4 + wave; it < ntiles;) {
+    const long tile = DYN ? it : (it < G ? it - rot + (it < rot ? G : 0) : it);
+    long nxt = it + G;
+    unsigned int ticket = 0;
+    if (DYN && lane == 0) ticket = atomicAdd(queue + cur * XW_DISC_QSTRIDE, 1u);
     const Pt pt = locate(tile, P, N, tf, tpp);
     // nabla phi is only read at the first time index: the leading `ngrad` points (time-major
     // order) also get the input gradient of v, by a reverse chain through the masks stashed below
@@ -138,6 +163,15 @@ __global__ void __launch_bounds__(256, 2) k_disc_fwd(const double* __restrict__ 
     const double* pht = ph;                                             // laundered: keeps the input-layer fragment
     asm volatile("" : "+s"(pht));                                       // addresses out of the loop-invariant (spilled) set
     input_layer<W>(pht, o, xT, N, d, pt, a, ad);
+    if (DYN) {
+      nxt = G + cur + (long)nq * (unsigned int)__builtin_amdgcn_readfirstlane((int)ticket);
+      while (nxt >= ntiles && tries < XW_DISC_STEAL && tries + 1 < nq) {      // home queue dry: the neighbours' (rare, end of the launch)
+        ++tries;
+        cur = cur + 1 < nq ? cur + 1 : 0;
+        if (lane == 0) ticket = atomicAdd(queue + cur * XW_DISC_QSTRIDE, 1u);
+        nxt = G + cur + (long)nq * (unsigned int)__builtin_amdgcn_readfirstlane((int)ticket);
+      }
+    }
     // one tied layer (value and d/dt tangent): (ai, adi) -> (nw, nd).  The loop below alternates two register sets so
     // that no layer ends with 32 register moves (a wave's VALU work does not overlap its FP64 MFMAs).
     auto layer = [&](int j, const d4 (&ai)[D::MT], const d4 (&adi)[D::MT], d4 (&nw)[D::MT], d4 (&nd)[D::MT]) {
@@ -287,6 +321,11 @@ __global__ void __launch_bounds__(256, 2) k_disc_fwd(const double* __restrict__ 
       st_ = xw_sum_over_g(st_);
       if (gtv != nullptr && g == 0 && gl) gtv[pt.p] = st_;
     }
+    it = nxt;
+  }
+  if (DYN && lane == 0) {
+    if (atomicAdd(&sDone, 1u) == 3u && atomicAdd(queue + XW_DISC_NQ * XW_DISC_QSTRIDE, 1u) == gridDim.x - 1u)
+      for (int s_ = 0; s_ <= XW_DISC_NQ; ++s_) atomicExch(queue + s_ * XW_DISC_QSTRIDE, 0u);
   }
 }
 
@@ -863,12 +902,22 @@ extern "C" int xw_disc_fwd(const double* xT, const double* t, const double* tpp,
   long cap = max_blocks > 0 ? max_blocks : 512;   // default: 2 blocks per CU resident (launch bounds), grid-stride over tiles
   if (blocks > cap) blocks = cap;
   if ((long)N * L * 4 >= (1L << 31)) return XW_E_ARG;                  // 32-bit lane offsets into the activation record
-  if (act != nullptr)
-    hipLaunchKernelGGL((k_disc_fwd<50, true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, xT, t, tpp, phi, N,
-                       L, d, q, v, vt, gxv, gtv, ngrad, act);
-  else
-    hipLaunchKernelGGL((k_disc_fwd<50, false>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, xT, t, tpp, phi, N,
-                       L, d, q, v, vt, gxv, gtv, ngrad, act);
+  // more than one round of tiles per wave: tickets (see k_disc_fwd).  Every launch takes the next queue slot; a captured
+  // launch keeps its slot for all replays, and launches that can overlap in time never share one.
+  static const bool dyn_on = [] { const char* e = getenv("XW_DISC_DYNAMIC"); return !(e && e[0] == '0'); }();
+  static unsigned int* qbase = [] { void* p = nullptr; (void)hipGetSymbolAddress(&p, HIP_SYMBOL(xw_disc_queue)); return (unsigned int*)p; }();
+  static std::atomic<unsigned int> next_slot{0};
+  const bool dyn = dyn_on && qbase != nullptr && ntiles > 4 * blocks;
+  unsigned int* queue = dyn ? qbase + (size_t)(next_slot.fetch_add(1) % XW_DISC_SLOTS) * ((XW_DISC_NQ + 1) * XW_DISC_QSTRIDE) : nullptr;
+#define XW_DISC_FWD(ACT_, DYN_)                                                                                           \
+  hipLaunchKernelGGL((k_disc_fwd<50, ACT_, DYN_>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, xT, t, tpp, \
+                     phi, N, L, d, q, v, vt, gxv, gtv, ngrad, act, queue)
+  if (act != nullptr) {
+    if (dyn) XW_DISC_FWD(true, true); else XW_DISC_FWD(true, false);
+  } else {
+    if (dyn) XW_DISC_FWD(false, true); else XW_DISC_FWD(false, false);
+  }
+#undef XW_DISC_FWD
   return xw_launch_status();
 }
 

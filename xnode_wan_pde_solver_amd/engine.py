@@ -120,12 +120,14 @@ class Engine:
         # both forwards store their layer inputs for their backwards (include/xnwan.h: XwOdeFwdJob.act, xw_disc_fwd act)
         self.keep_activations = os.environ.get('XW_KEEP_ACT', '1') == '1'
         # The test network's launch is persistent (grid-stride over point tiles) and at 2 blocks per CU it owns every SIMD's
-        # register file: the stepper's waves, launched next to it, then wait until it drains.  Capping it at 3/4 of the
-        # resident slots leaves a quarter of the SIMDs to the stepper chains (measured: 1221 vs 1159 steps/s).
+        # register file: the stepper's waves, launched next to it, then wait until it drains.  Capping it below the
+        # resident slots leaves SIMDs to the stepper chains.  With the kernel's ticket queues (tiles go to whichever wave is
+        # free) the generator sub-step is flat between 9/16 and 11/16 of the slots (0.518 - 0.521 ms; 0.527 at 3/4, 0.533 at
+        # 1/2); the static split needed exactly 3/4 (0.5225 ms, 0.58 either side).
         cus = torch.cuda.get_device_properties(device).multi_processor_count
-        self.v_blocks = int(os.environ.get('XW_V_BLOCKS', '0')) or (3 * 2 * cus) // 4
+        self.v_blocks = int(os.environ.get('XW_V_BLOCKS', '0')) or (11 * 2 * cus) // 16
         # (discriminator sub-step: only the stepper forward and the x-only sweep run beside it, 33 us of SIMD time: 7/8 of the
-        #  slots -- 0.630 ms against 0.643 at 3/4, 0.681 at 15/16, 0.706 at all of them)
+        #  slots -- 0.615 ms against 0.638 at 3/4, 0.681 at 15/16, 0.735 at all of them)
         self.v_blocks_disc = int(os.environ.get('XW_V_BLOCKS_DISC', '0')) or (7 * 2 * cus) // 8
         self._phi_version = 0
         self.streams = [torch.cuda.Stream(device=device) for _ in range(4)]
