@@ -212,7 +212,7 @@ def main():
         roofline['traffic_by_variant'] = traffic_by_variant
         roofline['traffic_source'] = traffic_source
     if dominant == 'disc_fwd' and not args.no_solo:
-        # The production launches above are capped at 3/4 of the resident block
+        # The production launches above are capped below the resident block
         # slots (Engine.v_blocks, v_blocks_disc) so that the stepper's waves find room next to them; the same kernel given the
         # whole chip, for reference:
         roofline['launch_blocks'] = {'generator_substep': eng.v_blocks, 'discriminator_substep': eng.v_blocks_disc, 'slots': 512}

@@ -112,16 +112,16 @@ int xw_disc_act_rows(int W, int q);
 /* input gradient of <vbar, v> at a set of points (reverse mode, no parameter gradients): gxv[d,N] (nabla_x) and
  * gtv[N] (d/dt), for the N points (t_n, x_n) with t_n = tpp ? tpp[n] : t[0]; vbar[N] or NULL (= ones).
  * (XV.grad of src/loss.py:60-63; the fused step only needs it at the first time index)
- * Compiled for the reference's depth q = 9; other depths (XW_E_DIMS here) take the same gradient from xw_disc_fwd's
- * gxv/gtv outputs, which run at any q <= 16, and scale it by vbar. */
+ * Compiled for the reference's width and depth, W = 50, q = 9; other depths and W = 64 (XW_E_DIMS here) take the same
+ * gradient from xw_disc_fwd's gxv/gtv outputs, which run at any q <= 16, and scale it by vbar. */
 int xw_disc_gradx(const double* xT, const double* t, const double* tpp, const double* phi, const double* vbar,
                   int N, int d, int W, int q, double* gxv, double* gtv, void* stream);
 
 int xw_disc_bwd_slabs(int N, int L);
 /* parameter gradient of <vbar, v>: slabs gslab[xw_disc_bwd_slabs][P_v] (input gradient: xw_disc_gradx).
  * act: the record xw_disc_fwd stored for the same phi and points, or NULL (the forward is then recomputed per tile).
- * Any depth q >= 0 runs from the record (two resident blocks per CU); the recomputing form keeps its checkpoints in
- * registers and is compiled for the reference's q = 9 only (XW_E_DIMS otherwise). */
+ * Any depth q >= 0 and both widths (W = 50, 64) run from the record; the recomputing form keeps its checkpoints in
+ * registers and is compiled for the reference's W = 50, q = 9 only (XW_E_DIMS otherwise). */
 int xw_disc_bwd(const double* xT, const double* t, const double* tpp, const double* phi, const double* vbar,
                 int N, int L, int d, int W, int q, const double* act, double* gslab, void* stream);
 

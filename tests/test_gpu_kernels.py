@@ -269,6 +269,50 @@ def test_disc_forward_and_time_tangent(N, L, d):
     _close(gtv, gX[:, 0, 0], 1e-11, 'fused dv/dt at t0')
 
 
+@pytest.mark.parametrize('N,L,d,q', [(37, 7, 5, 9), (64, 6, 20, 4), (100, 3, 70, 1), (16, 2, 3, 12), (700, 9, 6, 9)])
+def test_disc_kernels_at_width_64(N, L, d, q):
+    """the second compiled test-network width (64 = four full MFMA row tiles, container of v_hidden_dim 51..64): forward,
+    d/dt tangent, fused input gradient, record and the reverse from the record (dVh.b summed on the vector ALU: no padding
+    row left for the ones-row trick) against the oracle at v_hidden_dim = 64.  No recomputing reverse kernels at this width."""
+    from oracle import refspec as R
+    from xnode_wan_pde_solver_amd import kernels as KN
+    Ww = 64
+    cfg = dict(_cfg(), v_hidden_dim=Ww, v_layers=q)
+    torch.manual_seed(61)
+    _, phi = R.init_parameters(cfg, _setup(d, 2))
+    for p_ in phi.values():
+        if p_.dim() == 1:
+            p_.copy_(0.3 * torch.randn_like(p_))
+    ph = {k: v_.clone().requires_grad_(True) for k, v_ in phi.items()}
+    x, t, X = _sample(N, L, d, 62)
+    Xd = X.double().requires_grad_(True)
+    vbar = torch.randn(N, L, dtype=torch.float64, generator=torch.Generator().manual_seed(63))
+    v_ref = R.v_net(ph, cfg, Xd)
+    gX = torch.autograd.grad(v_ref.sum(), Xd, retain_graph=True)[0]
+    grads = torch.autograd.grad((v_ref * vbar).sum(), [ph[k] for k in V_ORDER])
+    xT, tc, blob = x.double().t().contiguous().cuda(), t.double().cuda(), _blob(phi, V_ORDER)
+    assert blob.numel() == KN.phi_size(d, Ww) and KN.disc_container(51) == 64 and KN.disc_container(64) == 64
+    gxv, gtv = torch.empty(d, N, dtype=torch.float64).cuda(), torch.empty(N, dtype=torch.float64).cuda()
+    rec = torch.empty(KN.disc_act_rows(Ww, q), KN.disc_act_cols(L * N), dtype=torch.float64).cuda()
+    v, vt = KN.disc_fwd(xT, tc, blob, Ww, q, gxv=gxv, gtv=gtv, ngrad=N, act=rec, max_blocks=5)
+    _close(v.t(), v_ref, 1e-12, 'v'); _close(vt.t(), gX[:, :, 0], 1e-11, 'dv/dt')
+    _close(gxv.t(), gX[:, 0, 1:], 1e-11, 'fused nabla_x v at t0'); _close(gtv, gX[:, 0, 0], 1e-11, 'fused dv/dt at t0')
+    got = KN.slab_sum(KN.disc_bwd(xT, tc, blob, vbar.t().contiguous().cuda(), Ww, q, act=rec)).cpu()
+    ref = torch.cat([g_.reshape(-1) for g_ in grads])
+    off = 0
+    for k, g_ in zip(V_ORDER, grads):
+        n_ = g_.numel()
+        _close(got[off:off + n_], ref[off:off + n_], 1e-10, 'grad ' + k)
+        off += n_
+    # without a record the Python layer stores one first (kernels.disc_bwd); the raw entry point refuses
+    got2 = KN.slab_sum(KN.disc_bwd(xT, tc, blob, vbar.t().contiguous().cuda(), Ww, q)).cpu()
+    _close(got2, got, 1e-13, 'gradient via an implicit record')
+    gx2, gt2 = KN.disc_gradx(xT, tc, blob, Ww, q)
+    _close(gx2.t(), gX[:, 0, 1:], 1e-11, 'disc_gradx'); _close(gt2, gX[:, 0, 0], 1e-11, 'disc_gradx dt')
+    from xnode_wan_pde_solver_amd._lib import lib
+    assert lib.xw_disc_gradx(xT.data_ptr(), tc.data_ptr(), None, blob.data_ptr(), None, N, d, Ww, 9, gxv.data_ptr(), gtv.data_ptr(), None) == -1   # XW_E_DIMS
+
+
 def test_disc_forward_ticket_queue_matches_static_split_over_many_launches():
     """more tiles than waves: the tiles after a wave's first one come from ticket counters (k_disc_fwd DYN) that the last wave
     of a launch zeroes again.  Which wave computes a tile cannot change its result: every launch -- more of them than there are

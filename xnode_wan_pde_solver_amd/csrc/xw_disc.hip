@@ -34,8 +34,10 @@ template <int W> struct VDim {
   // live registers (4-row groups) of row tile mt, counting the ones row W of the outer products: elementwise work,
   // checkpoints and transposes skip the padding rows (a lone wave pays ~9 clocks per FP64 VALU instruction)
   __device__ static constexpr int LR(int mt) { return (W + 1 - 16 * mt) >= 16 ? 4 : (W + 1 - 16 * mt + 3) / 4; }
-  static_assert(MT == 4, "the backward kernel maps the 4 row tiles of dVh onto the 4 waves of a block");
-  static_assert((W % 16) != 0, "a padding row of the last tile carries the bias column of the outer products");
+  // W not a multiple of 16: a padding row of the last tile is set to one, so that column W of the dVh outer products
+  // collects dVh.b for free; otherwise (W = 64) the bias gradient is summed on the vector ALU
+  static constexpr bool BIASROW = (W % 16) != 0;
+  static_assert(MT == 4, "the backward kernels map the 4 row tiles of dVh onto the 4 waves of a block");
 };
 
 // point -> (time, path) ; path mode: p = l*N + n ; point mode (tpp != null): p = n, L == 1
@@ -350,6 +352,7 @@ __global__ void __launch_bounds__(256) k_disc_bwd(const double* __restrict__ xT,
                                                   double* __restrict__ gtv) {
   typedef VDim<W> D;
   typedef BwdLds<W> S;
+  static_assert(D::BIASROW, "the recomputing reverse kernel takes dVh.b from the ones row");
   __shared__ double lds[S::total];
   double* sVh = lds + S::oVh;
   double* sVhT = lds + S::oVhT;
@@ -620,29 +623,32 @@ __global__ void __launch_bounds__(256) k_disc_bwd(const double* __restrict__ xT,
 // -> 78 KB per block, <= 256 registers per wave: two blocks share a CU and cover each other's barriers.
 template <int W> struct RecLds {
   typedef VDim<W> D;
-  static_assert(D::VTAIL && D::LR(D::MT - 1) == 1, "short last row tile: vector-ALU tail + one live 4-row group");
-  static constexpr int T3 = 4 * XW_TSTRIDE;                       // trimmed last tile
+  // W = 49..51: short last row tile -- vector-ALU tail + one live 4-row group, 78 KB, two blocks per CU.  Otherwise
+  // (W = 64, the container of the widths above 50) four full tiles everywhere: 105 KB, one block per CU.
+  static constexpr bool VT = D::VTAIL;
+  static_assert(!VT || D::LR(D::MT - 1) == 1, "short last row tile: vector-ALU tail + one live 4-row group");
+  static constexpr int T3 = VT ? 4 * XW_TSTRIDE : XW_TTILE;       // trimmed last tile
   static constexpr int wset = (D::MT - 1) * XW_TTILE + T3;        // one wave's set of transposed tiles
   static constexpr int oVhT = 0;                                  // [MTF][KS][64]
   static constexpr int oTT = oVhT + D::MTF * D::KS * 64;          // [4 KS][TR]: Vh[k][16 (MT-1) + r]
-  static constexpr int oVo = oTT + 4 * D::KS * D::TR;             // Vo, zero-padded to 16 MT rows
+  static constexpr int oVo = oTT + (VT ? 4 * D::KS * D::TR : 0);  // Vo, zero-padded to 16 MT rows
   static constexpr int oD = oVo + 16 * D::MT;
   static constexpr int oR = oD + 4 * wset;
-  static constexpr int oO = oR + 4 * wset;                        // [16 slots][4 waves][4 g]
-  static constexpr int total = oO + 16 * 16;
-  static_assert(total * 8 <= 80 * 1024, "two blocks per CU");
+  static constexpr int oO = oR + 4 * wset;                        // [16 row slots + dVo.b][4 waves][4 g]
+  static constexpr int total = oO + 17 * 16;
+  static_assert(total * 8 <= (VT ? 80 : 160) * 1024, "two blocks per CU (short tail) / one");
   __device__ static constexpr int toff(int mt) { return mt * XW_TTILE; }
 };
 
 // operand read from a wave's tile set: tile mt, folded back into the live rows when it is the trimmed one
 template <int W> __device__ __forceinline__ double rec_readT(const double* set, int mt, int ks) {
   const int l = xw_lane();
-  const int row = mt == VDim<W>::MT - 1 ? (l & 3) : (l & 15);
+  const int row = (RecLds<W>::VT && mt == VDim<W>::MT - 1) ? (l & 3) : (l & 15);
   return set[RecLds<W>::toff(mt) + row * XW_TSTRIDE + 4 * ks + (l >> 4)];
 }
 
 template <int W, int Q, int NG>
-__global__ void __launch_bounds__(256, 2) k_disc_rec(const double* __restrict__ xT, const double* __restrict__ tf,
+__global__ void __launch_bounds__(256, RecLds<W>::VT ? 2 : 1) k_disc_rec(const double* __restrict__ xT, const double* __restrict__ tf,
                                                      const double* __restrict__ tpp, const double* __restrict__ ph,
                                                      const double* __restrict__ vbar, int N, int L, int d,
                                                      double* __restrict__ gslab, const double* __restrict__ act, int qrt) {
@@ -669,17 +675,19 @@ __global__ void __launch_bounds__(256, 2) k_disc_rec(const double* __restrict__ 
     const int mt = idx / D::KS, ks = idx - mt * D::KS;
     sVhT[idx * 64 + lane] = xw_fragAT(ph + o.Vh, W, W, W, 16 * mt, 4 * ks);
   }
-  for (int idx = threadIdx.x; idx < 4 * D::KS * D::TR; idx += blockDim.x) {
-    const int r = idx % D::TR, k = idx / D::TR;                          // reverse chain: nd[48 + r] = sum_k Vh[k][48 + r] dl[k]
-    sTT[idx] = k < W ? ph[o.Vh + (long)k * W + 16 * (D::MT - 1) + r] : 0.0;
-  }
+  if (S::VT)
+    for (int idx = threadIdx.x; idx < 4 * D::KS * D::TR; idx += blockDim.x) {
+      const int r = idx % D::TR, k = idx / D::TR;                        // reverse chain: nd[48 + r] = sum_k Vh[k][48 + r] dl[k]
+      sTT[idx] = k < W ? ph[o.Vh + (long)k * W + 16 * (D::MT - 1) + r] : 0.0;
+    }
   if (threadIdx.x < 16 * D::MT) sVo[threadIdx.x] = (int)threadIdx.x < W ? ph[o.Vo + threadIdx.x] : 0.0;
   sO[threadIdx.x] = 0.0;
+  if (threadIdx.x < 16) sO[256 + threadIdx.x] = 0.0;
   __syncthreads();
 
-  d4 accH[D::MT];
+  d4 accH[D::MT], accB[D::MT];                       // accB: dVh.b without the ones row (W a multiple of 16)
 #pragma unroll
-  for (int ct = 0; ct < D::MT; ++ct) accH[ct] = xw_zero4();
+  for (int ct = 0; ct < D::MT; ++ct) accH[ct] = accB[ct] = xw_zero4();
   double* slab = gslab + (long)blockIdx.x * o.total;
 
   for (long st = blockIdx.x; st < nsuper; st += gridDim.x) {
@@ -722,7 +730,7 @@ __global__ void __launch_bounds__(256, 2) k_disc_rec(const double* __restrict__ 
       }
     {
       const double s_ = xw_sum_over_n(vb);
-      if (lane == 0) sO[15 * 16 + wave * 4] += s_;
+      if (lane == 0) sO[16 * 16 + wave * 4] += s_;
     }
     // ---- reverse chain, one layer at a time; the next layer's inputs are in flight meanwhile
 #pragma unroll UNROLL
@@ -737,10 +745,11 @@ __global__ void __launch_bounds__(256, 2) k_disc_rec(const double* __restrict__ 
 #pragma unroll
       for (int mt = 0; mt < D::MT; ++mt) {
         d4 rr = rnext[mt];
-        if (mt == (W >> 4)) {
+        if (D::BIASROW && mt == (W >> 4)) {
           if (g == ((W & 15) & 3)) rr[(W & 15) >> 2] = 1.0;            // ones row -> column W of dVh collects dVh.b
         }
-        if (mt < D::MT - 1) {
+        if (!D::BIASROW) accB[mt] = accB[mt] + dl[mt];
+        if (mt < D::MT - 1 || !S::VT) {
           xw_writeT(myD + S::toff(mt), dl[mt]);
           xw_writeT(myR + S::toff(mt), rr);
         } else {
@@ -763,13 +772,17 @@ __global__ void __launch_bounds__(256, 2) k_disc_rec(const double* __restrict__ 
         if ((ks & 1) == 0) asm volatile("" ::: "memory");   // bound the LDS loads in flight (else they are all hoisted -> spills)
 #pragma unroll
         for (int mt = 0; mt < D::MTF; ++mt) nd[mt] = XW_MFMA(sVhT[(mt * D::KS + ks) * 64 + lane], b, nd[mt]);
+        if (S::VT) {
 #pragma unroll
-        for (int r = 0; r < D::TR; ++r) tv[r] = fma(sTT[(4 * ks + g) * D::TR + r], b, tv[r]);
+          for (int r = 0; r < D::TR; ++r) tv[r] = fma(sTT[(4 * ks + g) * D::TR + r], b, tv[r]);
+        }
       }
+      if (S::VT) {
 #pragma unroll
-      for (int r = 0; r < D::TR; ++r) {
-        const double s_ = xw_sum_over_g(tv[r]);
-        if (g == r) nd[D::MT - 1][0] = s_;
+        for (int r = 0; r < D::TR; ++r) {
+          const double s_ = xw_sum_over_g(tv[r]);
+          if (g == r) nd[D::MT - 1][0] = s_;
+        }
       }
       __syncthreads();
 #pragma unroll
@@ -797,7 +810,7 @@ __global__ void __launch_bounds__(256, 2) k_disc_rec(const double* __restrict__ 
     // ---- dl = cotangent of a_0.  Input layer: dVin = dl (x) [t; x; 1], 48 input rows at a time
 #pragma unroll
     for (int mt = 0; mt < D::MT; ++mt) {
-      if (mt < D::MT - 1) xw_writeT(myD + S::toff(mt), dl[mt]);
+      if (mt < D::MT - 1 || !S::VT) xw_writeT(myD + S::toff(mt), dl[mt]);
       else xw_writeT_n<1>(myD + S::toff(mt), dl[mt]);
     }
     const double* xl = xT;                    // laundered: the per-lane row addresses of x and of the slab are formed here,
@@ -867,6 +880,18 @@ __global__ void __launch_bounds__(256, 2) k_disc_rec(const double* __restrict__ 
   }
   __syncthreads();
   const int tid = threadIdx.x;
+  if (!D::BIASROW) {   // dVh.b: the waves' sums over their points, [4 waves][16 MT rows] in the idle tile area
+    double* sBsum = lds + S::oD;
+#pragma unroll
+    for (int mt = 0; mt < D::MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double s_ = xw_sum_over_n(accB[mt][r]);
+        if (n == 0) sBsum[wave * 16 * D::MT + 16 * mt + 4 * r + g] = s_;
+      }
+    __syncthreads();
+    if (tid < W) slab[o.Vhb + tid] = sBsum[tid] + sBsum[16 * D::MT + tid] + sBsum[32 * D::MT + tid] + sBsum[48 * D::MT + tid];
+  }
   if (tid <= W) {
     double s_ = 0.0;
     if (tid < W) {
@@ -874,7 +899,7 @@ __global__ void __launch_bounds__(256, 2) k_disc_rec(const double* __restrict__ 
       for (int wv = 0; wv < 4; ++wv) s_ += sO[(mt * 4 + r) * 16 + wv * 4 + gg];
       slab[o.Vo + tid] = s_;
     } else {
-      for (int wv = 0; wv < 4; ++wv) s_ += sO[15 * 16 + wv * 4];
+      for (int wv = 0; wv < 4; ++wv) s_ += sO[16 * 16 + wv * 4];
       slab[o.Vob] = s_;
     }
   }
@@ -887,7 +912,10 @@ int bwd_blocks(long P) {
 
 }  // namespace
 
-extern "C" int xw_disc_act_rows(int W, int q) { return (W == 50 && q >= 0) ? (q + 1) * W : XW_E_DIMS; }
+// compiled widths: 50 (the reference's YAML; all kernels) and 64 (container of the widths above 50: forward with the
+// fused input gradient + reverse from the record, any depth; no recomputing reverse kernels)
+static bool disc_width_ok(int W) { return W == 50 || W == 64; }
+extern "C" int xw_disc_act_rows(int W, int q) { return (disc_width_ok(W) && q >= 0) ? (q + 1) * W : XW_E_DIMS; }
 
 extern "C" int xw_disc_fwd(const double* xT, const double* t, const double* tpp, const double* phi, int N, int L, int d,
                            int W, int q, double* v, double* vt, double* gxv, double* gtv, int ngrad, int max_blocks,
@@ -896,7 +924,7 @@ extern "C" int xw_disc_fwd(const double* xT, const double* t, const double* tpp,
   if (!tpp && !t) return XW_E_ARG;
   if (tpp && L != 1) return XW_E_ARG;
   if (gxv && (ngrad <= 0 || (long)ngrad > (long)N * L || q > XW_QMAX)) return XW_E_ARG;
-  if (W != 50) return XW_E_DIMS;
+  if (!disc_width_ok(W)) return XW_E_DIMS;
   const long ntiles = ((long)N * L + 15) / 16;
   long blocks = (ntiles + 3) / 4;
   long cap = max_blocks > 0 ? max_blocks : 512;   // default: 2 blocks per CU resident (launch bounds), grid-stride over tiles
@@ -909,14 +937,17 @@ extern "C" int xw_disc_fwd(const double* xT, const double* t, const double* tpp,
   static std::atomic<unsigned int> next_slot{0};
   const bool dyn = dyn_on && qbase != nullptr && ntiles > 4 * blocks;
   unsigned int* queue = dyn ? qbase + (size_t)(next_slot.fetch_add(1) % XW_DISC_SLOTS) * ((XW_DISC_NQ + 1) * XW_DISC_QSTRIDE) : nullptr;
-#define XW_DISC_FWD(ACT_, DYN_)                                                                                           \
-  hipLaunchKernelGGL((k_disc_fwd<50, ACT_, DYN_>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, xT, t, tpp, \
+#define XW_DISC_FWD(W_, ACT_, DYN_)                                                                                       \
+  hipLaunchKernelGGL((k_disc_fwd<W_, ACT_, DYN_>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, xT, t, tpp, \
                      phi, N, L, d, q, v, vt, gxv, gtv, ngrad, act, queue)
-  if (act != nullptr) {
-    if (dyn) XW_DISC_FWD(true, true); else XW_DISC_FWD(true, false);
-  } else {
-    if (dyn) XW_DISC_FWD(false, true); else XW_DISC_FWD(false, false);
+#define XW_DISC_FWD_W(W_)                                                                                                 \
+  if (act != nullptr) {                                                                                                   \
+    if (dyn) XW_DISC_FWD(W_, true, true); else XW_DISC_FWD(W_, true, false);                                              \
+  } else {                                                                                                                \
+    if (dyn) XW_DISC_FWD(W_, false, true); else XW_DISC_FWD(W_, false, false);                                            \
   }
+  if (W == 50) { XW_DISC_FWD_W(50) } else { XW_DISC_FWD_W(64) }
+#undef XW_DISC_FWD_W
 #undef XW_DISC_FWD
   return xw_launch_status();
 }
@@ -937,7 +968,7 @@ extern "C" int xw_disc_bwd(const double* xT, const double* t, const double* tpp,
   if (!tpp && !t) return XW_E_ARG;
   if (tpp && L != 1) return XW_E_ARG;
   // depth 9 (the reference's YAML) is unrolled, with or without the record; every other depth runs from the record
-  if (W != 50 || q < 0 || d + 2 > 128 || (q != 9 && act == nullptr)) return XW_E_DIMS;
+  if (!disc_width_ok(W) || q < 0 || d + 2 > 128 || ((q != 9 || W != 50) && act == nullptr)) return XW_E_DIMS;
   if ((long)N * L * 4 >= (1L << 31)) return XW_E_ARG;
   hipStream_t s = (hipStream_t)stream;
   const int blocks = bwd_blocks((long)N * L);
@@ -945,12 +976,14 @@ extern "C" int xw_disc_bwd(const double* xT, const double* t, const double* tpp,
   double* gtv = nullptr;
   if (act != nullptr) {
     const int ng = d + 2 <= 48 ? 1 : d + 2 <= 96 ? 2 : 3;
-#define XW_DISC_REC(Q, NG)                                                                                              \
-    hipLaunchKernelGGL((k_disc_rec<50, Q, NG>), dim3(blocks), dim3(256), 0, s, xT, t, tpp, phi, vbar, N, L, d, gslab, act, q);
-    if (q == 9) {
-      if (ng == 1) { XW_DISC_REC(9, 1) } else if (ng == 2) { XW_DISC_REC(9, 2) } else { XW_DISC_REC(9, 3) }
+#define XW_DISC_REC(W_, Q, NG)                                                                                          \
+    hipLaunchKernelGGL((k_disc_rec<W_, Q, NG>), dim3(blocks), dim3(256), 0, s, xT, t, tpp, phi, vbar, N, L, d, gslab, act, q);
+    if (W == 64) {
+      if (ng == 1) { XW_DISC_REC(64, 0, 1) } else if (ng == 2) { XW_DISC_REC(64, 0, 2) } else { XW_DISC_REC(64, 0, 3) }
+    } else if (q == 9) {
+      if (ng == 1) { XW_DISC_REC(50, 9, 1) } else if (ng == 2) { XW_DISC_REC(50, 9, 2) } else { XW_DISC_REC(50, 9, 3) }
     } else {
-      if (ng == 1) { XW_DISC_REC(0, 1) } else if (ng == 2) { XW_DISC_REC(0, 2) } else { XW_DISC_REC(0, 3) }
+      if (ng == 1) { XW_DISC_REC(50, 0, 1) } else if (ng == 2) { XW_DISC_REC(50, 0, 2) } else { XW_DISC_REC(50, 0, 3) }
     }
 #undef XW_DISC_REC
   } else {

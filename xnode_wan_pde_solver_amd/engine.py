@@ -395,8 +395,8 @@ class Engine:
         G.act_b = e(max(Lb - 1, 1), ar, KN.ode_act_cols(Nb)) if (ar and Nb) else None
         # layer inputs of the test network at every point, stored by its forward in the discriminator sub-step and read
         # back by its backward (524 MB at 131072 points)
-        # (depths other than the unrolled one have no recomputing reverse kernel: they always run from the record)
-        keep_v = self.keep_activations or self.q != KN.DISC_UNROLLED_DEPTH
+        # (only the reference's width and depth have a recomputing reverse kernel: everything else always runs from the record)
+        keep_v = self.keep_activations or not KN.disc_recompute(self.W, self.q)
         G.vact = e(KN.disc_act_rows(self.W, self.q), KN.disc_act_cols(L * N)) if keep_v else None
         G.ns_u = KN.ode_bwd_slabs(N)
         G.ns_b = KN.ode_bwd_slabs(Nb) if Nb else 0

@@ -48,7 +48,7 @@ def method_id(name):
 # (nets.Blob) -- padding units have zero in- and outgoing weights and zero bias, so they stay identically zero through
 # relu / tanh, contribute exact zeros to every sum, and receive exactly zero gradients (Adam leaves them at zero).
 ODE_WIDTHS = [(20, 10), (32, 12)]          # (u_hidden_dim, u_hidden_hidden_dim) containers, smallest first
-DISC_WIDTHS = [50]                         # v_hidden_dim containers (W = 50: 3 MFMA row tiles + a 2-row vector tail)
+DISC_WIDTHS = [50, 64]                     # v_hidden_dim containers (W = 50: 3 MFMA row tiles + a 2-row vector tail; 64: 4 tiles)
 
 
 def ode_container(H, K):
@@ -187,6 +187,12 @@ def ode_bwd(xT, t, start, theta, Y, ubar, method, H, K, m, want_x=True, want_par
 DISC_UNROLLED_DEPTH = 9   # v_layers of the reference's YAML: the depth the recomputing reverse kernels are compiled for
 
 
+def disc_recompute(W, q):
+    """True when the recomputing reverse kernels (xw_disc_gradx, xw_disc_bwd without a record) exist for this container
+    width and depth: the reference's YAML shape only.  Everything else reverses from the record / the fused gradient."""
+    return W == 50 and q == DISC_UNROLLED_DEPTH
+
+
 def disc_act_rows(W, q):
     """rows of the activation record disc_fwd can store for disc_bwd: the inputs of the q tied layers + tanh(a_q)"""
     r = lib.xw_disc_act_rows(W, q)
@@ -239,8 +245,8 @@ def disc_gradx(xT, t, phi, W, q, tpp=None, vbar=None, gxv=None, gtv=None):
     if vbar is not None:
         vbar = vbar.reshape(-1)
         _chk(vbar, F64, (N,), 'vbar')
-    if q != DISC_UNROLLED_DEPTH:
-        # other depths: the forward kernel's fused input gradient (any q <= 16), scaled by the cotangent
+    if not disc_recompute(W, q):
+        # other depths / widths: the forward kernel's fused input gradient (any q <= 16), scaled by the cotangent
         t0 = t[:1] if tpp is None else None
         disc_fwd(xT, t0, phi, W, q, tpp=tpp, want_vt=False, gxv=gxv, gtv=gtv, ngrad=N)
         if vbar is not None:
@@ -267,8 +273,8 @@ def disc_bwd(xT, t, phi, vbar, W, q, tpp=None, gslab=None, act=None):
     ns = disc_bwd_slabs(N, L)
     gslab = torch.empty(ns, P, dtype=F64, device=xT.device) if gslab is None else gslab
     _chk(gslab, F64, (ns, P), 'gslab')
-    if act is None and q != DISC_UNROLLED_DEPTH:
-        # the recomputing kernel exists at the reference's depth only: store the record first, then reverse from it
+    if act is None and not disc_recompute(W, q):
+        # the recomputing kernel exists at the reference's width and depth only: store the record first, then reverse from it
         act = torch.empty(disc_act_rows(W, q), disc_act_cols(L * N), dtype=F64, device=xT.device)
         disc_fwd(xT, t, phi, W, q, tpp=tpp, want_vt=False, act=act)
     if act is not None:
