@@ -33,7 +33,14 @@ def _p(t):
     return 0 if t is None else t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
 def _stream():
+    """raw handle of torch's current stream on the current device (the C call: no Stream object per launch -- a list
+    domain issues ~500 launches per outer iteration from Python)"""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
