@@ -198,9 +198,11 @@ def main():
         pmc = json.load(open(pmc_path))['kernels']
         # k_disc_fwd runs in two variants: plain (generator sub-steps, 3.9 MB of inputs + outputs) and with the activation
         # record for the backward (discriminator sub-step, +524 MB of stores by design): average over the g,g,d cycle, like avg_ms
-        keys = {'disc_fwd': ['k_disc_fwd<50,false>', 'k_disc_fwd<50,true>'],
-                'disc_bwd': ['k_disc_rec<50,9,1>']}.get(dominant, [])
-        if keys and all(k in pmc for k in keys):
+        # (kernel names as rocprofv3 prints them, matched by prefix: k_disc_fwd<W, record?, ticket queue?>)
+        prefixes = {'disc_fwd': ['k_disc_fwd<50,false', 'k_disc_fwd<50,true'],
+                    'disc_bwd': ['k_disc_rec<50,9,1']}.get(dominant, [])
+        keys = [next((k for k in sorted(pmc) if k.startswith(pre)), None) for pre in prefixes]
+        if keys and all(k is not None for k in keys):
             wts = [schedule.count('g'), schedule.count('d')] if len(keys) == 2 else [1]     # launches per g,g,d cycle
             traffic = int(sum(w_ * pmc[k]['hbm_bytes_per_launch_corrected'] for w_, k in zip(wts, keys)) / sum(wts))
             traffic_by_variant = {k: pmc[k]['hbm_bytes_per_launch_corrected'] for k in keys}

@@ -489,11 +489,12 @@ struct BwdJobs {
   int n;
   int x_ones;                  // gx, gs are those of the all-ones cotangent (ubar == 1 at every time index >= 1)
 };
-template <typename J> __device__ __forceinline__ int find_job(const J& jobs) {
+// vb: the 16-path tile of the launch this wave works on (= blockIdx.x in the one-tile-per-block kernels)
+template <typename J> __device__ __forceinline__ int find_job(const J& jobs, int vb) {
   int j = 0;
 #pragma unroll
   for (int k = 1; k < XW_MAXJOBS; ++k)
-    if (k < jobs.n && (int)blockIdx.x >= jobs.tile0[k]) j = k;
+    if (k < jobs.n && vb >= jobs.tile0[k]) j = k;
   return j;
 }
 
@@ -571,7 +572,7 @@ __global__ void __launch_bounds__(64, 2) k_ode_fwd(const FwdJobs jobs, const dou
                                                 const double* __restrict__ th, int L, int d) {
   typedef Dim<H, K> D;
   typedef RK<METHOD> T;
-  const int job = find_job(jobs);
+  const int job = find_job(jobs, (int)blockIdx.x);
   const double* __restrict__ xT = jobs.xT[job];
   const double* __restrict__ start = jobs.start[job];
   double* __restrict__ u = jobs.u[job];
@@ -788,7 +789,7 @@ __device__ __forceinline__ void load_stage(const double* __restrict__ Y, const d
 //   latency of ONE instruction stream (chain, LDS round trips, loads); the split doubles the waves and halves the stream.
 template <int H, int K, int M, int METHOD, bool PARAMS, bool SAVED, bool ADJ, bool DUO>
 __device__ __forceinline__ void sweep_body(const BwdJobs& jobs, const double* __restrict__ tf, const double* __restrict__ th,
-                                           int L, int d, double* lds, double* qbuf) {
+                                           int L, int d, double* lds, double* qbuf, int vb) {
   static_assert(!SAVED || RK<METHOD>::S <= 2, "the activation store is used by euler and midpoint");
   static_assert(!(SAVED && ADJ), "the continuous adjoint evaluates the field at its own stage points");
   static_assert(!DUO || (PARAMS && SAVED), "the duo sweep is the sweep with weight gradients from the activation store");
@@ -802,7 +803,7 @@ __device__ __forceinline__ void sweep_body(const BwdJobs& jobs, const double* __
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }
-  const int job = find_job(jobs);
+  const int job = find_job(jobs, vb);
   const double* __restrict__ xT = jobs.xT[job];
   const double* __restrict__ start = jobs.start[job];
   const double* __restrict__ Y = jobs.Y[job];
@@ -812,7 +813,7 @@ __device__ __forceinline__ void sweep_body(const BwdJobs& jobs, const double* __
   double* __restrict__ gs = jobs.gs[job];
   double* __restrict__ gslab = jobs.gslab[job];
   const int N = jobs.N[job];
-  const int tile = (int)blockIdx.x - jobs.tile0[job];
+  const int tile = vb - jobs.tile0[job];
   const int lane = xw_lane(), g = lane >> 4, n = lane & 15;
   const int base = tile * 16;
   const bool valid = base + n < N;
@@ -1298,19 +1299,19 @@ __device__ __forceinline__ double duo_fold(double x) {
 }
 template <int H, int K, int M, int METHOD>
 __device__ __forceinline__ void duo_outer(const BwdJobs& jobs, const double* __restrict__ tf, const double* __restrict__ th,
-                                          int L, int d, const double* qbuf) {
+                                          int L, int d, const double* qbuf, int vb) {
   typedef Dim<H, K> D;
   typedef RK<METHOD> T;
   typedef DuoPlan<H, K, M> P;
   typedef Duo4<H, K, M> Q;
   typedef DuoSrc<H, K, M, METHOD> Src;
   constexpr int NH = M > 1 ? M - 1 : 1;
-  __builtin_amdgcn_s_setprio(XW_ODE_PRIO);
-  const int job = find_job(jobs);
+  __builtin_amdgcn_s_setprio(XW_ODE_PRIO);          // (a lower priority for this wave than for the chain: no difference)
+  const int job = find_job(jobs, vb);
   const double* __restrict__ Y = jobs.Y[job];
   const double* __restrict__ act = jobs.act[job];
   const int N = jobs.N[job];
-  const int tile = (int)blockIdx.x - jobs.tile0[job];
+  const int tile = vb - jobs.tile0[job];
   const int lane = xw_lane();
   const UOff o = u_offsets(d, H, K);
   double gWh[Q::KB][Q::KB1], gWo[Q::HB][Q::KB1], gWy[Q::KB][Q::HB1];
@@ -1434,16 +1435,23 @@ template <int H, int K, int M, int METHOD, bool PARAMS, bool SAVED, bool ADJ = f
 __global__ void __launch_bounds__(64) k_ode_bwd(const BwdJobs jobs, const double* __restrict__ tf,
                                                 const double* __restrict__ th, int L, int d) {
   __shared__ double lds[XW_SWEEP_TILES * XW_TTILE];   // (plan: XW_SWEEP_TILES)
-  sweep_body<H, K, M, METHOD, PARAMS, SAVED, ADJ, false>(jobs, tf, th, L, d, lds, nullptr);
+  sweep_body<H, K, M, METHOD, PARAMS, SAVED, ADJ, false>(jobs, tf, th, L, d, lds, nullptr, (int)blockIdx.x);
 }
-// the duo sweep: wave 0 = adjoint chain, wave 1 = weight gradients of the field (see sweep_body / duo_outer)
+// the duo sweep: wave 0 = adjoint chain, wave 1 = weight gradients of the field (see sweep_body / duo_outer).
+// Placement (tools/probe_place.hip, profiles/r02_probe_place.txt): the dispatcher puts a block's waves on consecutive
+// SIMDs and starts the next block of the same CU ONE SIMD further, so two of these blocks on a CU land on SIMDs (0,1),
+// (1,2).  Both remedies were built and measured at 1 / 2 / 3 concurrent jobs of 4096 paths (this form: 105 / 147 / 170 us):
+// a spacer wave that ends at once (blocks on (0,2), (1,3); but a block then needs three waves' registers to start, two
+// blocks per CU instead of four): 105 / 142 / 181 us, generator sub-step 0.572 ms against 0.518; two tiles per four-wave
+// block (every SIMD of the CU, tiles coupled through the block barrier, a job on half the CUs): 118 / 126 / 216 us,
+// generator sub-step 0.533 ms.  Two tiles on one CU slow each other by a quarter wherever their waves sit.
 #define XW_DUO_THREADS 128
 template <int H, int K, int M, int METHOD>
 __global__ void __launch_bounds__(XW_DUO_THREADS) k_ode_bwd_duo(const BwdJobs jobs, const double* __restrict__ tf,
                                                                 const double* __restrict__ th, int L, int d) {
   __shared__ double lds[2 * DuoPlan<H, K, M>::BUF];
-  if (threadIdx.x < 64) sweep_body<H, K, M, METHOD, true, true, false, true>(jobs, tf, th, L, d, nullptr, lds);
-  else duo_outer<H, K, M, METHOD>(jobs, tf, th, L, d, lds);
+  if (threadIdx.x < 64) sweep_body<H, K, M, METHOD, true, true, false, true>(jobs, tf, th, L, d, nullptr, lds, (int)blockIdx.x);
+  else duo_outer<H, K, M, METHOD>(jobs, tf, th, L, d, lds, (int)blockIdx.x);
 }
 
 template <int H, int K, int M>
@@ -1477,15 +1485,16 @@ int launch_bwd(int method, const BwdJobs& jobs, const double* t, const double* t
   }
   bool act = true;                                     // all jobs or none (checked by the caller)
   for (int i = 0; i < jobs.n; ++i) act = act && jobs.act[i] != nullptr;
+  const dim3 duo_grid(jobs.tile0[jobs.n]);
   switch (method * 2 + (act ? 1 : 0)) {
     case 0: hipLaunchKernelGGL((k_ode_bwd<H, K, M, 0, PARAMS, false>), grid, block, 0, s, jobs, t, theta, L, d); break;
     case 1:
-      if (PARAMS) hipLaunchKernelGGL((k_ode_bwd_duo<H, K, M, 0>), grid, dim3(XW_DUO_THREADS), 0, s, jobs, t, theta, L, d);
+      if (PARAMS) hipLaunchKernelGGL((k_ode_bwd_duo<H, K, M, 0>), duo_grid, dim3(XW_DUO_THREADS), 0, s, jobs, t, theta, L, d);
       else hipLaunchKernelGGL((k_ode_bwd<H, K, M, 0, false, true>), grid, block, 0, s, jobs, t, theta, L, d);
       break;
     case 2: hipLaunchKernelGGL((k_ode_bwd<H, K, M, 1, PARAMS, false>), grid, block, 0, s, jobs, t, theta, L, d); break;
     case 3:
-      if (PARAMS) hipLaunchKernelGGL((k_ode_bwd_duo<H, K, M, 1>), grid, dim3(XW_DUO_THREADS), 0, s, jobs, t, theta, L, d);
+      if (PARAMS) hipLaunchKernelGGL((k_ode_bwd_duo<H, K, M, 1>), duo_grid, dim3(XW_DUO_THREADS), 0, s, jobs, t, theta, L, d);
       else hipLaunchKernelGGL((k_ode_bwd<H, K, M, 1, false, true>), grid, block, 0, s, jobs, t, theta, L, d);
       break;
     case 4: hipLaunchKernelGGL((k_ode_bwd<H, K, M, 2, PARAMS, false>), grid, block, 0, s, jobs, t, theta, L, d); break;
