@@ -511,6 +511,14 @@ template <typename J> __device__ __forceinline__ int find_job(const J& jobs, int
 //   j = M-1: tanh(z_{M-1})), then the inputs of the stages i >= 1: S M K + (i-1) H + h.  Tile-major: what a wave stores
 //   or loads for one step is ONE contiguous stretch (23 KB at 180 rows); path-major rows made it 180 pieces of 128 bytes,
 //   32 KB apart, and the x-only sweep (183 MB in 0.1 ms) ran at the DRAM efficiency of that pattern.
+//   Inside a tile every block of p <= 4 rows that one register of a chain tile covers is stored PATH-major,
+//   [16 paths][p rows]: the partner wave of the duo sweep needs such a block as the B operand of a 4x4x4 MFMA -- lane
+//   j + 4 b + 16 k = (row j, path 4 k + b) -- which is then lane-linear, 512 contiguous bytes.  Row-major, the four lanes of a
+//   quad sat in four different 128-byte lines and the CU's address unit was stalled by the L1 a quarter of the launch
+//   with three sweep tiles on a CU (TA_ADDR_STALLED_BY_TC 24.8 M -> 7.7 M cycles per three-job launch, average vector-memory
+//   latency per instruction 29 -> 17 units; three concurrent jobs 170 -> 163 us, 16384 paths 244 -> 215 us, generator
+//   sub-step 0.518 -> 0.510 ms).  What still separates two tiles of a CU (102 us alone, 148 us each) is the amount of
+//   read data in flight per CU: 12.7 KB per field evaluation and tile at ~570 clocks of L2 latency.
 // 180 doubles per path and step at (H, K, m) = (20, 10, 8), midpoint: 183 MB for 4096 paths x 32 times.
 template <int H, int K, int M, int S> struct ActLayout {
   static constexpr int STAGE = M * K;
@@ -522,22 +530,23 @@ template <int H, int K, int M, int S> struct ActLayout {
 // rows [row0, row0 + nrows) of the record <-> the first registers of a chain tile (row g + 4 r).  Addresses are
 // formed as  (uniform row pointer) + (32-bit lane offset)  so that they cost SGPRs, not a VGPR pair per stored row.
 struct ActLane {
-  int off;        // g * N + column (clamped column for loads)
-  int off_part;   // the same with g clamped into a partially filled register of a K-row tile
+  int off;        // inside a full block of four rows: 4 * column + g
+  int off_part;   // inside the last, partially filled block of a K-row tile (p = K mod 4 rows): p * column + min(g, p - 1)
   bool valid;
 };
 __device__ __forceinline__ ActLane act_lane(int N, int col, bool valid, int krows) {
-  const int g = xw_lane() >> 4;
-  const int gp = (krows & 3) ? (g < (krows & 3) ? g : (krows & 3) - 1) : g;
-  return ActLane{g * N + col, gp * N + col, valid};
+  const int g = xw_lane() >> 4, p = krows & 3;
+  const int gp = p ? (g < p ? g : p - 1) : g;
+  return ActLane{4 * col + g, (p ? p : 4) * col + gp, valid};
 }
 __device__ __forceinline__ void act_store(double* __restrict__ A, int row0, int nrows, int N, const ActLane& q, d4 v) {
   const int g = xw_lane() >> 4;
 #pragma unroll
   for (int r = 0; r < 4; ++r)
     if (4 * r < nrows) {
-      double* __restrict__ rowp = A + (long)(row0 + 4 * r) * N;             // uniform
-      if (g + 4 * r < nrows && q.valid) __builtin_nontemporal_store(v[r], rowp + q.off);   // (streamed: read once, by a sweep)
+      double* __restrict__ blk = A + (long)(row0 + 4 * r) * N;              // uniform: the block of rows 4 r .. 4 r + 3
+      if (g + 4 * r < nrows && q.valid)                                     // (streamed: read once, by a sweep)
+        __builtin_nontemporal_store(v[r], blk + (4 * r + 4 <= nrows ? q.off : q.off_part));
     }
 }
 __device__ __forceinline__ d4 act_load(const double* __restrict__ A, int row0, int nrows, int N, const ActLane& q) {
@@ -545,8 +554,8 @@ __device__ __forceinline__ d4 act_load(const double* __restrict__ A, int row0, i
 #pragma unroll
   for (int r = 0; r < 4; ++r)
     if (4 * r < nrows) {
-      const double* __restrict__ rowp = A + (long)(row0 + 4 * r) * N;       // uniform
-      v[r] = __builtin_nontemporal_load(rowp + (4 * r + 4 <= nrows ? q.off : q.off_part));   // padding rows: any finite value
+      const double* __restrict__ blk = A + (long)(row0 + 4 * r) * N;        // uniform
+      v[r] = __builtin_nontemporal_load(blk + (4 * r + 4 <= nrows ? q.off : q.off_part));   // padding rows: any finite value
     }
   return v;
 }
@@ -1266,9 +1275,13 @@ template <int H, int K, int M> struct Duo4 {
 template <int H, int K, int M, int METHOD>
 __device__ __forceinline__ double duo_load_act(const DuoSrc<H, K, M, METHOD>& s, int jrow /* layer, M-1 = tanh */, int cb) {
   typedef ActLayout<H, K, M, RK<METHOD>::S> AL;
-  const int lane = xw_lane(), j = lane & 3, pg = (lane >> 2) & 3, k = lane >> 4;
+  const int lane = xw_lane(), j = lane & 3;
   const int row = 4 * cb + j;
-  const xw_gptr src = row < K ? (xw_gptr)(s.A + (s.i * AL::STAGE + jrow * K + row) * 16 + 4 * pg + k) : (xw_gptr)&xw_duo_const[row == K ? 1 : 0][0];
+  // lane j + 4 b + 16 k = (row 4 cb + j, path 4 k + b): lane-linear inside a full path-major block; a partial last block
+  // of p rows holds (row, path) at p * path + row
+  const int p = K - 4 * cb < 4 ? K - 4 * cb : 4;               // (compile-time after unrolling)
+  const int off = p == 4 ? lane : p * (lane >> 2) + j;
+  const xw_gptr src = row < K ? (xw_gptr)(s.A + (s.i * AL::STAGE + jrow * K + 4 * cb) * 16 + off) : (xw_gptr)&xw_duo_const[row == K ? 1 : 0][0];
   return __builtin_nontemporal_load(src);
 }
 // ... of [y_in ; t ; zero padding]: rows of y_l (checkpoints, stage 0) or of the activation record (later stages);
@@ -1277,19 +1290,21 @@ __device__ __forceinline__ double duo_load_act(const DuoSrc<H, K, M, METHOD>& s,
 template <int H, int K, int M, int METHOD>
 __device__ __forceinline__ double duo_load_y(const DuoSrc<H, K, M, METHOD>& s, int cb, int N, int tile) {
   typedef ActLayout<H, K, M, RK<METHOD>::S> AL;
-  const int lane = xw_lane(), j = lane & 3, pg = (lane >> 2) & 3, k = lane >> 4;
+  static_assert(H % 4 == 0, "the stage inputs are whole path-major blocks");
+  const int lane = xw_lane(), j = lane & 3, b = (lane >> 2) & 3, k = lane >> 4;
   const int row = 4 * cb + j;
   const bool first = s.i == 0;                                // (wave-uniform)
-  const double* __restrict__ base = first ? s.Yl : s.A + (long)(AL::YI + (s.i > 0 ? s.i - 1 : 0) * H) * 16;
-  const long rs = first ? N : 16, c0 = first ? tile * 16 : 0, cmax = first ? N - 1 : 15;
-  const long col = c0 + 4 * pg + k;
-  const xw_gptr src = row < H ? (xw_gptr)(base + row * rs + (col < cmax ? col : cmax)) : (xw_gptr)&xw_duo_const[0][0];
+  // stage 0: the checkpoint y_l [H][N] (row-major); later stages: path-major blocks of the record, lane-linear
+  const long col = (long)tile * 16 + 4 * k + b;
+  const double* __restrict__ src_y = s.Yl + (long)row * N + (col < N - 1 ? col : N - 1);
+  const double* __restrict__ src_a = s.A + (long)(AL::YI + (s.i > 0 ? s.i - 1 : 0) * H + 4 * cb) * 16 + lane;
+  const xw_gptr src = row < H ? (xw_gptr)(first ? src_y : src_a) : (xw_gptr)&xw_duo_const[0][0];
   return __builtin_nontemporal_load(src);
 }
 // A operand: rows 4 rb .. 4 rb + 3 of a transposed cotangent tile in LDS (tile[row * XW_TSTRIDE + path])
 __device__ __forceinline__ double duo_readA(const double* tile, int rb) {
   const int l = xw_lane();
-  return tile[(4 * rb + (l & 3)) * XW_TSTRIDE + ((l >> 2) & 3) * 4 + (l >> 4)];
+  return tile[(4 * rb + (l & 3)) * XW_TSTRIDE + (l >> 4) * 4 + ((l >> 2) & 3)];   // lane i + 4 b + 16 k = (row i, path 4 k + b)
 }
 // sum of an accumulator's four path-group partials (lane bits 2, 3), then element (row 4 rb + i, col 4 cb + j) from lane j + 16 i
 __device__ __forceinline__ double duo_fold(double x) {
