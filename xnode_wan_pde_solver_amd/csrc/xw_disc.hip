@@ -96,7 +96,7 @@ __device__ __forceinline__ void input_layer(const double* __restrict__ ph, const
 #define XW_DISC_NQ 32
 #define XW_DISC_STEAL 3
 #define XW_DISC_QSTRIDE 64
-#define XW_DISC_SLOTS 64
+#define XW_DISC_SLOTS 128
 __device__ unsigned int xw_disc_queue[XW_DISC_SLOTS][(XW_DISC_NQ + 1) * XW_DISC_QSTRIDE];
 template <int W, bool ACT, bool DYN>
 __global__ void __launch_bounds__(256, 2) k_disc_fwd(const double* __restrict__ xT, const double* __restrict__ tf,
@@ -934,9 +934,18 @@ extern "C" int xw_disc_fwd(const double* xT, const double* t, const double* tpp,
   // launch keeps its slot for all replays, and launches that can overlap in time never share one.
   static const bool dyn_on = [] { const char* e = getenv("XW_DISC_DYNAMIC"); return !(e && e[0] == '0'); }();
   static unsigned int* qbase = [] { void* p = nullptr; (void)hipGetSymbolAddress(&p, HIP_SYMBOL(xw_disc_queue)); return (unsigned int*)p; }();
-  static std::atomic<unsigned int> next_slot{0};
+  static std::atomic<unsigned int> next_slot[2];        // [0]: eager launches, [1]: launches recorded into a graph
   const bool dyn = dyn_on && qbase != nullptr && ntiles > 4 * blocks;
-  unsigned int* queue = dyn ? qbase + (size_t)(next_slot.fetch_add(1) % XW_DISC_SLOTS) * ((XW_DISC_NQ + 1) * XW_DISC_QSTRIDE) : nullptr;
+  unsigned int* queue = nullptr;
+  if (dyn) {
+    // a captured launch keeps its slot for every replay: the two kinds draw from separate halves of the slot array, so
+    // that an eager launch (module calls between sub-steps, other streams) can never meet a replay on the same words
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing((hipStream_t)stream, &cs) != hipSuccess) cs = hipStreamCaptureStatusNone;
+    const int half = cs == hipStreamCaptureStatusActive ? 1 : 0;
+    const unsigned int slot = half * (XW_DISC_SLOTS / 2) + next_slot[half].fetch_add(1) % (XW_DISC_SLOTS / 2);
+    queue = qbase + (size_t)slot * ((XW_DISC_NQ + 1) * XW_DISC_QSTRIDE);
+  }
 #define XW_DISC_FWD(W_, ACT_, DYN_)                                                                                       \
   hipLaunchKernelGGL((k_disc_fwd<W_, ACT_, DYN_>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, xT, t, tpp, \
                      phi, N, L, d, q, v, vt, gxv, gtv, ngrad, act, queue)
