@@ -88,7 +88,15 @@ int xw_ode_bwd(const double* xT, const double* t, const double* start, const dou
 
 /* multi-group form: every job has its own sample, checkpoints, cotangent and outputs; `mode` is common to all jobs */
 typedef struct { const double* xT; const double* start; const double* Y; const double* act; const double* ubar;
-                 double* gx; double* gs; double* gslab; int N; } XwOdeBwdJob;
+                 double* gx; double* gs; double* gslab; int N;
+                 /* cotangent formed from a residual on the fly instead of a stored one (res_u != NULL; ubar must then be
+                  * NULL):  ubar[l][n] = res_base + res_coef (res_u[l][n] - ref),  with ref = res_ref[l][n] at every time
+                  * index (res_first_only == 0: the boundary penalty of src/loss.py:84, res_u = u on the boundary paths,
+                  * res_ref = g) or ref = res_ref[n] and only at l = 0 (res_first_only != 0: the initial-value penalty of
+                  * src/loss.py:79 on top of the constant res_base).  The sweeps that only need these penalties start right
+                  * behind the forward pass, without a cotangent kernel in between. */
+                 int res_first_only; const double* res_u; const double* res_ref; double res_coef; double res_base;
+               } XwOdeBwdJob;
 int xw_ode_bwd_multi(const XwOdeBwdJob* jobs, int njobs, const double* t, const double* theta,
                      int method, int L, int d, int H, int K, int m, int mode, void* stream);
 

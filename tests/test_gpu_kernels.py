@@ -242,6 +242,50 @@ def test_ode_backward_from_stored_activations(solver):
         _close(gx1, gx0, 1e-12, 'gx (x-only store)'); _close(gs1, gs0, 1e-12, 'gs (x-only store)')
 
 
+@pytest.mark.parametrize('solver', ['euler', 'midpoint', 'rk4'])
+def test_ode_sweep_with_residual_cotangents(solver):
+    """XwOdeBwdJob.res_*: the cotangent base + coef (u - ref) formed inside the sweep (initial-value penalty: ref[n], l = 0
+    only; boundary penalty: ref[l][n] at every l) must give the outputs of the same cotangent handed over as a stored array
+    (to rounding: the kernel forms base + coef * r with one fused multiply-add) -- with and without the activation store,
+    with weight gradients (duo sweep) and with x outputs."""
+    from xnode_wan_pde_solver_amd import kernels as KN
+    N, L, d = 300, 6, 5
+    theta, _ = _params(d, 8, 71)
+    x, t, _ = _sample(N, L, d, 72)
+    g = torch.Generator().manual_seed(73)
+    start = torch.randn(N, dtype=torch.float64, generator=g).cuda()
+    href = torch.randn(N, dtype=torch.float64, generator=g).cuda()
+    gref = torch.randn(L, N, dtype=torch.float64, generator=g).cuda()
+    xT, tc, blob, mid = x.double().t().contiguous().cuda(), t.double().cuda(), _blob(theta, U_ORDER), KN.method_id(solver)
+    rows = KN.ode_act_rows(mid, H, K, 8)
+    for with_act in ([False, True] if rows else [False]):
+        u, Y = torch.empty(L, N, dtype=F64).cuda(), torch.empty(L, H, N, dtype=F64).cuda()
+        job = dict(xT=xT, start=start, u=u, Y=Y)
+        if with_act:
+            job['act'] = torch.empty(L - 1, rows, KN.ode_act_cols(N), dtype=F64).cuda()
+        KN.ode_fwd_multi([job], tc, blob, mid, H, K, 8)
+        for first_only, ref, coef, base in ((True, href, 0.37, 1.0), (False, gref, -1.3, 0.0)):
+            ubar = torch.full((L, N), base, dtype=F64).cuda()
+            if first_only:
+                ubar[0] += coef * (u[0] - ref)
+            else:
+                ubar += coef * (u - ref)
+            res = dict(u=u, ref=ref, coef=coef, base=base, first_only=first_only)
+            outs = []
+            for kw in (dict(ubar=ubar), dict(res=res)):
+                gx, gs = torch.empty(d, N, dtype=F64).cuda(), torch.empty(N, dtype=F64).cuda()
+                slab = torch.empty(KN.ode_bwd_slabs(N), blob.numel(), dtype=F64).cuda()
+                KN.ode_bwd_multi([dict(job, gx=gx, gs=gs, gslab=slab, **kw)], tc, blob, mid, H, K, 8, want_x=True, want_params=True,
+                                 x_cot_ones=first_only)
+                slab2 = torch.empty_like(slab)
+                KN.ode_bwd_multi([dict(job, gslab=slab2, **kw)], tc, blob, mid, H, K, 8, want_x=False, want_params=True)
+                outs.append((gx, gs, slab, slab2))
+            for a_, b_, what in zip(outs[0], outs[1], ('gx', 'gs', 'slab (with x outputs)', 'slab')):
+                _close(a_, b_, 1e-13, '%s: %s, store %s, first_only %s' % (what, solver, with_act, first_only))
+    with pytest.raises(Exception):
+        KN.ode_bwd_multi([dict(job, gslab=slab, ubar=ubar, res=res)], tc, blob, mid, H, K, 8, want_x=False, want_params=True)
+
+
 @pytest.mark.parametrize('N,L,d', CASES + [(50, 3, 70)])
 def test_disc_forward_and_time_tangent(N, L, d):
     from oracle import refspec as R

@@ -488,7 +488,27 @@ struct BwdJobs {
   int tile0[XW_MAXJOBS + 1];
   int n;
   int x_ones;                  // gx, gs are those of the all-ones cotangent (ubar == 1 at every time index >= 1)
+  // cotangent from a residual (XwOdeBwdJob.res_*): ubar[l][n] = base + coef (res_u[l][n] - ref)
+  const double* res_u[XW_MAXJOBS];
+  const double* res_ref[XW_MAXJOBS];
+  double res_coef[XW_MAXJOBS], res_base[XW_MAXJOBS];
+  int res_first[XW_MAXJOBS];
 };
+// cotangent of u at (time index l, path col) of job `job`: a stored array, all ones, or formed from a residual on the fly
+// (the initial-value and the boundary penalty: no cotangent kernel between the forward pass and these sweeps)
+__device__ __forceinline__ double cot_u(const BwdJobs& jobs, int job, const double* __restrict__ ubar, int l, int N, int col) {
+  const double* __restrict__ ru = jobs.res_u[job];
+  if (ru != nullptr) {
+    double r = jobs.res_base[job];
+    if (jobs.res_first[job]) {
+      if (l == 0) r += jobs.res_coef[job] * (ru[col] - jobs.res_ref[job][col]);
+    } else {
+      r += jobs.res_coef[job] * (ru[(long)l * N + col] - jobs.res_ref[job][(long)l * N + col]);
+    }
+    return r;
+  }
+  return ubar != nullptr ? ubar[(long)l * N + col] : 1.0;
+}
 // vb: the 16-path tile of the launch this wave works on (= blockIdx.x in the one-tile-per-block kernels)
 template <typename J> __device__ __forceinline__ int find_job(const J& jobs, int vb) {
   int j = 0;
@@ -855,7 +875,7 @@ __device__ __forceinline__ void sweep_body(const BwdJobs& jobs, const double* __
   // cotangent of u at time index l.  Loaded at the START of the step that ends with its read-out: behind the fences of
   // the outer products the load could not be hoisted and its HBM latency sat on the chain once per step.
   auto load_ub = [&](int l) -> double {
-    return valid ? (ubar != nullptr ? ubar[(long)l * N + base + n] : 1.0) : 0.0;
+    return valid ? cot_u(jobs, job, ubar, l, N, base + n) : 0.0;
   };
   auto readout = [&](int l, const d4 (&yl)[D::HT], double ub) {
     ub0 = ub;
@@ -1088,7 +1108,7 @@ __device__ __forceinline__ void sweep_body(const BwdJobs& jobs, const double* __
         for (int ht = 0; ht < D::HT; ++ht) lam[ht] += psum[ht];
       }
       // read-out u_l = FL y_l + b
-      const double ub = valid ? (ubar != nullptr ? ubar[(long)l * N + base + n] : 1.0) : 0.0;
+      const double ub = valid ? cot_u(jobs, job, ubar, l, N, base + n) : 0.0;
       ub0 = ub;
   #pragma unroll
       for (int ht = 0; ht < D::HT; ++ht) {
@@ -1590,6 +1610,12 @@ extern "C" int XW_ODE_FN(xw_ode_bwd_multi_w)(const XwOdeBwdJob* jobs, int njobs,
     J.act[i] = (on && method != 2 && !(mode & 8)) ? jobs[i].act : nullptr;   // (rk4 and the continuous adjoint recompute)
     if (on && (J.act[i] != nullptr) != (J.act[0] != nullptr)) return XW_E_ARG;   // all groups of a launch, or none
     J.ubar[i] = on ? jobs[i].ubar : nullptr;
+    J.res_u[i] = on ? jobs[i].res_u : nullptr;
+    J.res_ref[i] = on ? jobs[i].res_ref : nullptr;
+    J.res_coef[i] = on ? jobs[i].res_coef : 0.0;
+    J.res_base[i] = on ? jobs[i].res_base : 0.0;
+    J.res_first[i] = on ? jobs[i].res_first_only : 0;
+    if (on && jobs[i].res_u && (!jobs[i].res_ref || jobs[i].ubar)) return XW_E_ARG;
     J.gx[i] = (on && (mode & 1)) ? jobs[i].gx : nullptr;
     J.gs[i] = (on && (mode & 1)) ? jobs[i].gs : nullptr;
     J.gslab[i] = (on && (mode & 2)) ? jobs[i].gslab : nullptr;

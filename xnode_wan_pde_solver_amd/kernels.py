@@ -120,6 +120,8 @@ def ode_fwd_multi(jobs, t, theta, method, H, K, m, zero16=None, act_x_only=False
 
 def ode_bwd_multi(jobs, t, theta, method, H, K, m, want_x, want_params, x_cot_ones=False, adjoint=False):
     """jobs: list of dicts(xT, start, Y, ubar or None, gx, gs, gslab); ONE launch for all groups.
+    res = dict(u[L,N], ref ([N] with first_only, else [L,N]), coef, base, first_only) instead of ubar: the cotangent
+    base + coef (u - ref) (at l = 0 only with first_only) is formed inside the sweep.
     x_cot_ones (with want_x and want_params): gx, gs for the all-ones cotangent, parameter gradients for ubar, which must
     equal 1 at every time index >= 1; jobs without gx / gs produce no x outputs.
     adjoint: the continuous adjoint of torchdiffeq.odeint_adjoint (config['adjoint'] = True) instead of the reverse of
@@ -143,6 +145,15 @@ def ode_bwd_multi(jobs, t, theta, method, H, K, m, want_x, want_params, x_cot_on
         a.xT, a.start, a.Y, a.ubar, a.N = _p(j['xT']), _p(j['start']), _p(j['Y']), _p(j.get('ubar')), N
         a.act = _p(j.get('act'))
         a.gx, a.gs, a.gslab = _p(j.get('gx')), _p(j.get('gs')), _p(j.get('gslab'))
+        res = j.get('res')
+        if res is not None:
+            # cotangent formed from a residual inside the sweep (XwOdeBwdJob.res_*): base + coef (u - ref)
+            if j.get('ubar') is not None:
+                raise XnwanError('a sweep job takes a stored cotangent (ubar) or a residual (res), not both')
+            first = bool(res['first_only'])
+            _chk(res['u'], F64, (L, N), 'res.u'); _chk(res['ref'], F64, (N,) if first else (L, N), 'res.ref')
+            a.res_first_only, a.res_u, a.res_ref = int(first), _p(res['u']), _p(res['ref'])
+            a.res_coef, a.res_base = float(res['coef']), float(res['base'])
     if x_cot_ones and not (want_x and want_params):
         raise XnwanError('x_cot_ones needs want_x and want_params')
     if x_cot_ones and adjoint:
