@@ -84,6 +84,8 @@ __device__ __forceinline__ void input_layer(const double* __restrict__ ph, const
 
 // ------------------------------------------------------------------------------------------------------------------
 #define XW_QMAX 16   // deepest test network whose ReLU masks fit the LDS stash of k_disc_fwd's fused input gradient
+#define XW_VIN_KS 6  // k-steps of the input layer (d <= 24) whose A-fragments k_disc_fwd keeps in LDS (44 KB per block in all:
+                     // two of its blocks and two blocks of the duo sweep still share a CU's 160 KB)
 
 // DYN: only a wave's first tile is its static one; every later tile comes from ticket counters (one returning atomic per
 // tile by lane 0, issued before the input layer and read after it).  A SIMD's vector and FP64 matrix instructions add up
@@ -98,7 +100,7 @@ __device__ __forceinline__ void input_layer(const double* __restrict__ ph, const
 #define XW_DISC_QSTRIDE 64
 #define XW_DISC_SLOTS 128
 __device__ unsigned int xw_disc_queue[XW_DISC_SLOTS][(XW_DISC_NQ + 1) * XW_DISC_QSTRIDE];
-template <int W, bool ACT, bool DYN>
+template <int W, bool ACT, bool DYN, bool VINLDS>
 __global__ void __launch_bounds__(256, 2) k_disc_fwd(const double* __restrict__ xT, const double* __restrict__ tf,
                                                      const double* __restrict__ tpp, const double* __restrict__ ph, int N,
                                                      int L, int d, int q, double* __restrict__ v, double* __restrict__ vt,
@@ -108,10 +110,15 @@ __global__ void __launch_bounds__(256, 2) k_disc_fwd(const double* __restrict__ 
   // Vh as MFMA A-fragments in LDS (26.6 KB), shared by the 4 waves of the block: one ds_read_b64 feeds two 64-cycle MFMAs
   // (value and d/dt tangent), and keeping them out of the register file lets two waves share a SIMD so that one wave's
   // relu / tanh VALU work overlaps the other's matrix work.
-  __shared__ double sVh[D::MT * D::KS * 64];
+  __shared__ double sVh[D::MTF * D::KS * 64];
   __shared__ double sB[2 * 16 * D::MT];
   __shared__ double sT[D::KS * 4 * (D::VTAIL ? D::TR : 1)];   // Vh[16 (MT-1) + r][4 ks + g]: the tail rows, per lane group
   __shared__ unsigned short sMask[XW_QMAX][256];   // ReLU masks (16 rows per lane) of the layers, for the fused reverse chain
+  // input layer: Vin[:, 1..d] as A-fragments, Vin[:, 0] and Vin.b as row vectors.  From global memory they were 52 loads per
+  // tile (the fragment loads put the four lanes of a quad into four rows) and their address arithmetic, re-formed for
+  // every tile to keep them out of the spilled loop-invariant set
+  __shared__ double sVin[VINLDS ? XW_VIN_KS * D::MT * 64 : 1];
+  __shared__ double sIn[VINLDS ? 2 * 16 * D::MT : 1];
   __shared__ unsigned int sDone;
   if (DYN && threadIdx.x == 0) sDone = 0;
   // (s_setprio for this kernel's waves: no gain at 1, -5 % at 3 -- the sub-step's SIMD time is conserved)
@@ -120,6 +127,8 @@ __global__ void __launch_bounds__(256, 2) k_disc_fwd(const double* __restrict__ 
   const VOff o = v_offsets(d, W);
   const long P = (long)N * L;
   const long ntiles = (P + 15) / 16;
+  // (Vh.b through the padding column W of the k-range, so that a layer's accumulators start from the inline constant zero
+  //  instead of 12 bias registers read from LDS: built, same time -- LDS reads do not cost the SIMD's issue cycles)
   for (int idx = wave; idx < D::MTF * D::KS; idx += 4) {
     const int mt = idx / D::KS, ks = idx - mt * D::KS;
     sVh[idx * 64 + lane] = xw_fragA(ph + o.Vh, W, W, W, 16 * mt, 4 * ks);
@@ -127,7 +136,17 @@ __global__ void __launch_bounds__(256, 2) k_disc_fwd(const double* __restrict__ 
   if (threadIdx.x < 16 * D::MT) {
     sB[threadIdx.x] = (int)threadIdx.x < W ? ph[o.Vhb + threadIdx.x] : 0.0;
     sB[16 * D::MT + threadIdx.x] = (int)threadIdx.x < W ? ph[o.Vo + threadIdx.x] : 0.0;
+    if (VINLDS) {
+      sIn[threadIdx.x] = (int)threadIdx.x < W ? ph[o.Vin + (long)threadIdx.x * o.ldin] : 0.0;
+      sIn[16 * D::MT + threadIdx.x] = (int)threadIdx.x < W ? ph[o.Vinb + threadIdx.x] : 0.0;
+    }
   }
+  const int ksd = (d + 3) / 4;                                 // (VINLDS: <= XW_VIN_KS, checked by the launcher)
+  if (VINLDS)
+    for (int idx = wave; idx < ksd * D::MT; idx += 4) {
+      const int ks = idx / D::MT, mt = idx - ks * D::MT;
+      sVin[idx * 64 + lane] = xw_fragA(ph + o.Vin + 1, o.ldin, W, d, 16 * mt, 4 * ks);
+    }
   if (D::VTAIL)
     for (int idx = threadIdx.x; idx < D::KS * 4 * D::TR; idx += blockDim.x) {
       const int r = idx % D::TR, k = idx / D::TR;                        // k = 4 ks + g
@@ -164,7 +183,23 @@ __global__ void __launch_bounds__(256, 2) k_disc_fwd(const double* __restrict__ 
     const int aoff = lane;                                              // (g, n) -> row offset g, point n
     const double* pht = ph;                                             // laundered: keeps the input-layer fragment
     asm volatile("" : "+s"(pht));                                       // addresses out of the loop-invariant (spilled) set
-    input_layer<W>(pht, o, xT, N, d, pt, a, ad);
+    if (VINLDS) {
+#pragma unroll
+      for (int mt = 0; mt < D::MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          ad[mt][r] = sIn[16 * mt + g + 4 * r];
+          a[mt][r] = sIn[16 * D::MT + 16 * mt + g + 4 * r] + ad[mt][r] * pt.t;
+        }
+      for (int ks = 0; ks < ksd; ++ks) {
+        const int i = 4 * ks + g;
+        const double b = i < d ? xT[(long)i * N + pt.n] : 0.0;
+#pragma unroll
+        for (int mt = 0; mt < D::MT; ++mt) a[mt] = XW_MFMA(sVin[(ks * D::MT + mt) * 64 + lane], b, a[mt]);
+      }
+    } else {
+      input_layer<W>(pht, o, xT, N, d, pt, a, ad);
+    }
     if (DYN) {
       nxt = G + cur + (long)nq * (unsigned int)__builtin_amdgcn_readfirstlane((int)ticket);
       while (nxt >= ntiles && tries < XW_DISC_STEAL && tries + 1 < nq) {      // home queue dry: the neighbours' (rare, end of the launch)
@@ -946,9 +981,12 @@ extern "C" int xw_disc_fwd(const double* xT, const double* t, const double* tpp,
     const unsigned int slot = half * (XW_DISC_SLOTS / 2) + next_slot[half].fetch_add(1) % (XW_DISC_SLOTS / 2);
     queue = qbase + (size_t)slot * ((XW_DISC_NQ + 1) * XW_DISC_QSTRIDE);
   }
-#define XW_DISC_FWD(W_, ACT_, DYN_)                                                                                       \
-  hipLaunchKernelGGL((k_disc_fwd<W_, ACT_, DYN_>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, xT, t, tpp, \
-                     phi, N, L, d, q, v, vt, gxv, gtv, ngrad, act, queue)
+  static const bool vin_on = [] { const char* e = getenv("XW_DISC_VIN_LDS"); return !(e && e[0] == '0'); }();
+  const bool vin_lds = vin_on && (d + 3) / 4 <= XW_VIN_KS;
+#define XW_DISC_FWD2(W_, ACT_, DYN_, VIN_)                                                                                \
+  hipLaunchKernelGGL((k_disc_fwd<W_, ACT_, DYN_, VIN_>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, xT, t,  \
+                     tpp, phi, N, L, d, q, v, vt, gxv, gtv, ngrad, act, queue)
+#define XW_DISC_FWD(W_, ACT_, DYN_) do { if (vin_lds) XW_DISC_FWD2(W_, ACT_, DYN_, true); else XW_DISC_FWD2(W_, ACT_, DYN_, false); } while (0)
 #define XW_DISC_FWD_W(W_)                                                                                                 \
   if (act != nullptr) {                                                                                                   \
     if (dyn) XW_DISC_FWD(W_, true, true); else XW_DISC_FWD(W_, true, false);                                              \
@@ -958,6 +996,7 @@ extern "C" int xw_disc_fwd(const double* xT, const double* t, const double* tpp,
   if (W == 50) { XW_DISC_FWD_W(50) } else { XW_DISC_FWD_W(64) }
 #undef XW_DISC_FWD_W
 #undef XW_DISC_FWD
+#undef XW_DISC_FWD2
   return xw_launch_status();
 }
 
