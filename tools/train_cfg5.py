@@ -20,4 +20,4 @@ print('%s: %d outer iterations, %.1f ms each; groups per sample: %d' % (name, it
 if len(sys.argv) > 3:
     import cProfile, pstats, io
     pr = cProfile.Profile(); pr.enable(); S.iterations = 2; S.train(); torch.cuda.synchronize(); pr.disable()
-    st = io.StringIO(); pstats.Stats(pr, stream=st).sort_stats('cumulative').print_stats(30); print(st.getvalue()[:6000])
+    st = io.StringIO(); pstats.Stats(pr, stream=st).sort_stats(sys.argv[4] if len(sys.argv) > 4 else 'cumulative').print_stats(30); print(st.getvalue()[:6000])

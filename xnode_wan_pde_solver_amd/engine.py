@@ -23,12 +23,15 @@ Data layout in HBM (per group of N equal-length paths, L sample times, d dimensi
   vact          float64 [(q+1) W, N L]   layer inputs of the test network (its forward -> its backward)
   slabs         float64 [n_slab, P]  per-wave partial parameter gradients, summed inside the Adam kernel
 """
+import contextlib
 import os
 
 import torch
 
 from . import kernels as KN
 from ._lib import XnwanError
+
+_NOSTREAM = contextlib.nullcontext()      # Engine._side without side streams
 
 F32, F64 = torch.float32, torch.float64
 
@@ -417,20 +420,22 @@ class Engine:
     def _side(self, i, *events):
         """context: run on side stream i after `events` (falls back to the current stream when streams are off)"""
         if not self.use_streams:
-            return torch.cuda.stream(torch.cuda.current_stream())
+            return _NOSTREAM                      # one stream: program order is the dependency (no contexts, no events)
         st = self.streams[i]
         for ev in events:
-            st.wait_event(ev)
+            if ev is not None:
+                st.wait_event(ev)
         return torch.cuda.stream(st)
 
     def _mark(self):
-        return torch.cuda.current_stream().record_event()
+        return torch.cuda.current_stream().record_event() if self.use_streams else None
 
     def _join(self, *events):
         if self.use_streams:
             cur = torch.cuda.current_stream()
             for ev in events:
-                cur.wait_event(ev)
+                if ev is not None:
+                    cur.wait_event(ev)
 
     def _launch_test_net_here(self, G, blocks=None):
         """test network on the CURRENT stream (the sub-step's critical chain): v, dv/dt at all points; nabla_x v at the first
