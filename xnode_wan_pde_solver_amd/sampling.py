@@ -165,11 +165,16 @@ class NSphere_TCone(_NSphereBase):
         pts = self._ball(N_r)
         tcol = self.times.repeat(N_r, 1).unsqueeze(2)
         groups, k = [], self.N_t
+        # (the reference recomputes the norms of the points still unassigned and np.delete()s the chosen ones at every
+        #  sample time, src/dataset.py:170-185; the norms never change and deletion keeps the order: one norm per point
+        #  and a mask of the unassigned ones give the same groups, bit for bit, in a third of the time)
+        nrm = np.sqrt(np.sum(pts ** 2, 0))
+        left = np.ones(N_r, dtype=bool)
         for t in self.times.numpy()[::-1]:
             # walking back from T: a point first found inside at this time lives for the k samples t_0 .. t_{k-1}
-            alive = np.sqrt(np.sum(pts ** 2, 0)) < self.r * (1 - t)
+            alive = left & (nrm < self.r * (1 - t))
             chosen = torch.from_numpy(pts[:, alive]).t().unsqueeze(1).repeat(1, k, 1)
-            pts = np.delete(pts, alive, 1)
+            left &= ~alive
             if chosen.shape[0] != 0:
                 groups.append(torch.cat((tcol[:chosen.shape[0], :k], chosen), 2).requires_grad_(True))
             k -= 1
