@@ -43,13 +43,23 @@ class World:
     def _init_native(self):
         from ._lib import lib, check
         ident = ctypes.create_string_buffer(128)
-        if self.rank == 0:
-            check(lib.xw_comm_unique_id(ident), 'xw_comm_unique_id')
-        box = [ident.raw if self.rank == 0 else None]
+        have_id = self.rank == 0 and lib.xw_comm_unique_id(ident) == 0
+        box = [ident.raw if have_id else None]
         dist.broadcast_object_list(box, src=0, group=self.group)
         comm = ctypes.c_void_p()
-        check(lib.xw_comm_init(box[0], self.size, self.rank, ctypes.byref(comm)), 'xw_comm_init')
-        self.comm = comm
+        rc = lib.xw_comm_init(box[0], self.size, self.rank, ctypes.byref(comm)) if box[0] is not None else -4
+        # every rank must end up on the same path: agree on the outcome (a rank that could not load or initialise RCCL
+        # sends all of them to torch.distributed's all-reduce between graph segments, loudly, instead of failing the job)
+        ok = torch.tensor([1 if rc == 0 else 0], device='cuda' if dist.get_backend(self.group) == 'nccl' else 'cpu')
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
+        if int(ok[0]) == 1:
+            self.comm = comm
+            return
+        if rc == 0:
+            lib.xw_comm_destroy(comm)
+        import warnings
+        warnings.warn('xw_comm_init failed on a rank (status %d here): the exchanges go through torch.distributed between '
+                      'graph segments instead of RCCL calls inside the captured sub-steps' % rc, RuntimeWarning, stacklevel=3)
 
     @property
     def capturable(self):
