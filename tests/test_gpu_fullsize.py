@@ -123,6 +123,56 @@ def test_test_network_at_full_size(d, N, L):
     assert abs(float(g1[-1]) - float(b1.sum())) < 1e-9 * max(1.0, float(b1.abs().sum()))
 
 
+def test_test_network_width_64_at_full_size():
+    """the second compiled width at the headline size (d = 20, 4096 paths x 32 times): point mode == path mode, the d/dt
+    tangent against a centred difference, fused gradient consistent with the tangent, the reverse from the record linear in
+    the cotangent, checksums of the bias gradients (dVo.b = sum of the cotangent; dVh.b, summed on the vector ALU at this
+    width, against a centred difference of <vbar, v> in the bias of one unit)"""
+    d, N, L, Ww, q = 20, 4096, 32, 64, 9
+    from xnode_wan_pde_solver_amd import kernels as KN, _lib
+    g = torch.Generator().manual_seed(5)
+    dev = torch.device('cuda')
+    ph = (0.2 * torch.randn(_lib.lib.xw_phi_size(d, Ww), generator=g, dtype=F64)).to(dev)
+    xT = (torch.rand(d, N, generator=g, dtype=F64) * 2 - 1).to(dev)
+    t = torch.sort(torch.rand(L, generator=g, dtype=F64)).values
+    t[0], t[-1] = 0.0, 1.0
+    t = t.to(dev)
+    P = N * L
+    gxv, gtv = torch.empty(d, N, dtype=F64, device=dev), torch.empty(N, dtype=F64, device=dev)
+    act = torch.empty(KN.disc_act_rows(Ww, q), KN.disc_act_cols(P), dtype=F64, device=dev)
+    v, vt = KN.disc_fwd(xT, t, ph, Ww, q, gxv=gxv, gtv=gtv, ngrad=N, act=act, max_blocks=352)      # (ticket queues)
+    assert torch.isfinite(v).all() and torch.isfinite(vt).all() and torch.isfinite(act).all()
+    assert _rel(gtv, vt[0]) < 1e-12
+    sel = torch.randint(0, P, (4096,), generator=g)
+    l_idx, n_idx = (sel // N).to(dev), (sel % N).to(dev)
+    vp, vtp = KN.disc_fwd(xT[:, n_idx].contiguous(), None, ph, Ww, q, tpp=t[l_idx].contiguous())
+    assert _rel(vp.view(-1), v[l_idx, n_idx]) < 1e-13 and _rel(vtp.view(-1), vt[l_idx, n_idx]) < 1e-12
+    eps = 1e-6
+    vplus, _ = KN.disc_fwd(xT, t + eps, ph, Ww, q, want_vt=False)
+    vminus, _ = KN.disc_fwd(xT, t - eps, ph, Ww, q, want_vt=False)
+    err = ((vplus - vminus) / (2 * eps) - vt).abs() / float(vt.abs().max())
+    assert float(err.median()) < 1e-8 and float((err > 1e-5).double().mean()) < 2e-3
+    b1 = torch.randn(L, N, generator=g, dtype=F64).to(dev)
+    b2 = torch.randn(L, N, generator=g, dtype=F64).to(dev)
+    g1 = KN.slab_sum(KN.disc_bwd(xT, t, ph, b1, Ww, q, act=act))
+    g2 = KN.slab_sum(KN.disc_bwd(xT, t, ph, b2, Ww, q, act=act))
+    g12 = KN.slab_sum(KN.disc_bwd(xT, t, ph, b1 - 3.0 * b2, Ww, q, act=act))
+    assert _rel(g12, g1 - 3.0 * g2) < 1e-11
+    assert abs(float(g1[-1]) - float(b1.sum())) < 1e-9 * max(1.0, float(b1.abs().sum()))
+    # dVh.b of one hidden unit against a centred difference of sum(v) (all-ones cotangent: no cancellation, so that the
+    # handful of points with a ReLU kink inside the step do not dominate the error; blob layout Vin, Vin.b, Vh, Vh.b, Vo, Vo.b)
+    ones = torch.ones(L, N, dtype=F64, device=dev)
+    g_one = KN.slab_sum(KN.disc_bwd(xT, t, ph, ones, Ww, q, act=act))
+    off_vhb = Ww * (d + 1) + Ww + Ww * Ww
+    k, h = 37, 1e-7
+    php, phm = ph.clone(), ph.clone()
+    php[off_vhb + k] += h
+    phm[off_vhb + k] -= h
+    fp = float(KN.disc_fwd(xT, t, php, Ww, q, want_vt=False)[0].sum())
+    fm = float(KN.disc_fwd(xT, t, phm, Ww, q, want_vt=False)[0].sum())
+    assert abs((fp - fm) / (2 * h) - float(g_one[off_vhb + k])) < 1e-4 * max(1.0, abs(float(g_one[off_vhb + k]))), ((fp - fm) / (2 * h), float(g_one[off_vhb + k]))
+
+
 def test_reductions_against_torch_at_full_size():
     """weak_partials / bdry_partials / cotangent kernels at the headline size against the same formulas in torch"""
     d, N, L = 20, 4096, 32

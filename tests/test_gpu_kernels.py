@@ -313,7 +313,8 @@ def test_disc_forward_and_time_tangent(N, L, d):
     _close(gtv, gX[:, 0, 0], 1e-11, 'fused dv/dt at t0')
 
 
-@pytest.mark.parametrize('N,L,d,q', [(37, 7, 5, 9), (64, 6, 20, 4), (100, 3, 70, 1), (16, 2, 3, 12), (700, 9, 6, 9)])
+@pytest.mark.parametrize('N,L,d,q', [(37, 7, 5, 9), (64, 6, 20, 4), (100, 3, 70, 1), (16, 2, 3, 12), (700, 9, 6, 9),
+                                     (1100, 32, 6, 2)])     # (the last one: more 64-point groups than blocks -- grid-stride)
 def test_disc_kernels_at_width_64(N, L, d, q):
     """the second compiled test-network width (64 = four full MFMA row tiles, container of v_hidden_dim 51..64): forward,
     d/dt tangent, fused input gradient, record and the reverse from the record (dVh.b summed on the vector ALU: no padding
@@ -395,7 +396,7 @@ def test_disc_input_gradient(N, d):
     _close(gtv, g[:, 0], 1e-11, 'dv/dt')
 
 
-@pytest.mark.parametrize('N,L,d', CASES + [(50, 3, 70), (300, 5, 6)])
+@pytest.mark.parametrize('N,L,d', CASES + [(50, 3, 70), (300, 5, 6), (1100, 32, 6)])     # (last: more 64-point groups than blocks)
 def test_disc_backward(N, L, d):
     from oracle import refspec as R
     from xnode_wan_pde_solver_amd import kernels as KN
