@@ -96,6 +96,11 @@ typedef struct { const double* xT; const double* start; const double* Y; const d
                   * src/loss.py:79 on top of the constant res_base).  The sweeps that only need these penalties start right
                   * behind the forward pass, without a cotangent kernel in between. */
                  int res_first_only; const double* res_u; const double* res_ref; double res_coef; double res_base;
+                 /* res_first_only == 2: the weak form's dI/du (basis B of xw_gen_cotangents, src/loss.py:64,70) --
+                  *   ubar[l][n] = res_coef d(c(u) u)/du v w  (+ res_base v at l = L-1),   res_u = u, res_ref = v,
+                  *   w = res_w[n] or res_w[l][n] (res_w_per_point), d(c u)/du = res_c + u res_cp (tabulated c, dc/du) or
+                  *   res_kappa2 u (c = kappa u, res_c == NULL): sweep B starts right behind the test network. */
+                 int res_w_per_point; const double* res_w; const double* res_c; const double* res_cp; double res_kappa2;
                } XwOdeBwdJob;
 int xw_ode_bwd_multi(const XwOdeBwdJob* jobs, int njobs, const double* t, const double* theta,
                      int method, int L, int d, int H, int K, int m, int mode, void* stream);

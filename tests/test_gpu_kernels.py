@@ -282,6 +282,24 @@ def test_ode_sweep_with_residual_cotangents(solver):
                 outs.append((gx, gs, slab, slab2))
             for a_, b_, what in zip(outs[0], outs[1], ('gx', 'gs', 'slab (with x outputs)', 'slab')):
                 _close(a_, b_, 1e-13, '%s: %s, store %s, first_only %s' % (what, solver, with_act, first_only))
+        # the weak form's dI/du (res_first_only = 2) against xw_gen_cotangents' basis B handed over as a stored array:
+        # c = kappa u, and tabulated c, dc/du with a per-point weight
+        v_ = torch.randn(L, N, dtype=F64, generator=g).cuda()
+        w_n, w_ln = torch.rand(N, dtype=F64, generator=g).cuda(), torch.rand(L, N, dtype=F64, generator=g).cuda()
+        c_, cp_ = torch.randn(L, N, dtype=F64, generator=g).cuda(), torch.randn(L, N, dtype=F64, generator=g).cuda()
+        Vol, Ng = 3.7, 1234.0
+        for w_, ctab in ((w_n, False), (w_ln, True)):
+            ubarB = torch.empty(L, N, dtype=F64).cuda()
+            KN.gen_cotangents(u, v_, w_, href, Vol, Ng, 1.0, None, ubarB, c=c_ if ctab else None, cp=cp_ if ctab else None,
+                              ckappa=0.0 if ctab else -0.8)
+            resB = dict(u=u, ref=v_, coef=Vol / Ng / L, base=Vol / Ng,
+                        weak=dict(w=w_, c=c_ if ctab else None, cp=cp_ if ctab else None, ckappa=0.0 if ctab else -0.8))
+            outs = []
+            for kw in (dict(ubar=ubarB), dict(res=resB)):
+                slab = torch.empty(KN.ode_bwd_slabs(N), blob.numel(), dtype=F64).cuda()
+                KN.ode_bwd_multi([dict(job, gslab=slab, **kw)], tc, blob, mid, H, K, 8, want_x=False, want_params=True)
+                outs.append(slab)
+            _close(outs[1], outs[0], 1e-13, 'slab, dI/du formed in the sweep (%s, store %s, tabulated c %s)' % (solver, with_act, ctab))
     with pytest.raises(Exception):
         KN.ode_bwd_multi([dict(job, gslab=slab, ubar=ubar, res=res)], tc, blob, mid, H, K, 8, want_x=False, want_params=True)
 

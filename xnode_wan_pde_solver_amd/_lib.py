@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('XW_LIBRARY') or os.path.join(_HERE, 'libxnwan.so')   # (override: kernel experiments only)
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 c_f32p = ctypes.c_void_p   # coordinates / time grid: const double* (device)   [name kept from the float32 era]
 c_f64p = ctypes.c_void_p   # double*       (device)
@@ -23,7 +23,8 @@ class XwOdeFwdJob(ctypes.Structure):      # include/xnwan.h
 class XwOdeBwdJob(ctypes.Structure):
     _fields_ = [('xT', c_vp), ('start', c_vp), ('Y', c_vp), ('act', c_vp), ('ubar', c_vp), ('gx', c_vp), ('gs', c_vp),
                 ('gslab', c_vp), ('N', c_int), ('res_first_only', c_int), ('res_u', c_vp), ('res_ref', c_vp),
-                ('res_coef', ctypes.c_double), ('res_base', ctypes.c_double)]
+                ('res_coef', ctypes.c_double), ('res_base', ctypes.c_double), ('res_w_per_point', c_int), ('res_w', c_vp),
+                ('res_c', c_vp), ('res_cp', c_vp), ('res_kappa2', ctypes.c_double)]
 
 
 # name -> argument types (return type is always int); mirrors include/xnwan.h line by line

@@ -492,13 +492,29 @@ struct BwdJobs {
   const double* res_u[XW_MAXJOBS];
   const double* res_ref[XW_MAXJOBS];
   double res_coef[XW_MAXJOBS], res_base[XW_MAXJOBS];
-  int res_first[XW_MAXJOBS];
+  int res_first[XW_MAXJOBS];        // XwOdeBwdJob.res_first_only: 0 / 1 residual forms, 2 = the weak form's dI/du
+  const double* res_w[XW_MAXJOBS];
+  const double* res_c[XW_MAXJOBS];
+  const double* res_cp[XW_MAXJOBS];
+  double res_kappa2[XW_MAXJOBS];
+  int res_wpp[XW_MAXJOBS];
 };
 // cotangent of u at (time index l, path col) of job `job`: a stored array, all ones, or formed from a residual on the fly
 // (the initial-value and the boundary penalty: no cotangent kernel between the forward pass and these sweeps)
-__device__ __forceinline__ double cot_u(const BwdJobs& jobs, int job, const double* __restrict__ ubar, int l, int N, int col) {
+__device__ __forceinline__ double cot_u(const BwdJobs& jobs, int job, const double* __restrict__ ubar, int l, int N, int col,
+                                        int L) {
   const double* __restrict__ ru = jobs.res_u[job];
   if (ru != nullptr) {
+    if (jobs.res_first[job] == 2) {
+      // dI/du of the weak form (xw_gen_cotangents' basis B, src/loss.py:64,70): coef d(c(u) u)/du v w, + base v at t_{L-1}
+      const long p = (long)l * N + col;
+      const double ul = ru[p], vl = jobs.res_ref[job][p];
+      const double wl = jobs.res_wpp[job] ? jobs.res_w[job][p] : jobs.res_w[job][col];
+      const double dcu = jobs.res_c[job] != nullptr ? jobs.res_c[job][p] + ul * jobs.res_cp[job][p] : jobs.res_kappa2[job] * ul;
+      double gB = jobs.res_coef[job] * dcu * vl * wl;
+      if (l == L - 1) gB += jobs.res_base[job] * vl;
+      return gB;
+    }
     double r = jobs.res_base[job];
     if (jobs.res_first[job]) {
       if (l == 0) r += jobs.res_coef[job] * (ru[col] - jobs.res_ref[job][col]);
@@ -875,7 +891,7 @@ __device__ __forceinline__ void sweep_body(const BwdJobs& jobs, const double* __
   // cotangent of u at time index l.  Loaded at the START of the step that ends with its read-out: behind the fences of
   // the outer products the load could not be hoisted and its HBM latency sat on the chain once per step.
   auto load_ub = [&](int l) -> double {
-    return valid ? cot_u(jobs, job, ubar, l, N, base + n) : 0.0;
+    return valid ? cot_u(jobs, job, ubar, l, N, base + n, L) : 0.0;
   };
   auto readout = [&](int l, const d4 (&yl)[D::HT], double ub) {
     ub0 = ub;
@@ -1108,7 +1124,7 @@ __device__ __forceinline__ void sweep_body(const BwdJobs& jobs, const double* __
         for (int ht = 0; ht < D::HT; ++ht) lam[ht] += psum[ht];
       }
       // read-out u_l = FL y_l + b
-      const double ub = valid ? cot_u(jobs, job, ubar, l, N, base + n) : 0.0;
+      const double ub = valid ? cot_u(jobs, job, ubar, l, N, base + n, L) : 0.0;
       ub0 = ub;
   #pragma unroll
       for (int ht = 0; ht < D::HT; ++ht) {
@@ -1615,7 +1631,14 @@ extern "C" int XW_ODE_FN(xw_ode_bwd_multi_w)(const XwOdeBwdJob* jobs, int njobs,
     J.res_coef[i] = on ? jobs[i].res_coef : 0.0;
     J.res_base[i] = on ? jobs[i].res_base : 0.0;
     J.res_first[i] = on ? jobs[i].res_first_only : 0;
+    J.res_w[i] = on ? jobs[i].res_w : nullptr;
+    J.res_c[i] = on ? jobs[i].res_c : nullptr;
+    J.res_cp[i] = on ? jobs[i].res_cp : nullptr;
+    J.res_kappa2[i] = on ? jobs[i].res_kappa2 : 0.0;
+    J.res_wpp[i] = on ? jobs[i].res_w_per_point : 0;
     if (on && jobs[i].res_u && (!jobs[i].res_ref || jobs[i].ubar)) return XW_E_ARG;
+    if (on && jobs[i].res_u && jobs[i].res_first_only == 2 && (!jobs[i].res_w || (!jobs[i].res_c != !jobs[i].res_cp))) return XW_E_ARG;
+    if (on && (jobs[i].res_first_only < 0 || jobs[i].res_first_only > 2)) return XW_E_ARG;
     J.gx[i] = (on && (mode & 1)) ? jobs[i].gx : nullptr;
     J.gs[i] = (on && (mode & 1)) ? jobs[i].gs : nullptr;
     J.gslab[i] = (on && (mode & 2)) ? jobs[i].gslab : nullptr;

@@ -51,6 +51,6 @@ extern "C" int xw_ode_bwd_multi(const XwOdeBwdJob* jobs, int njobs, const double
 extern "C" int xw_ode_bwd(const double* xT, const double* t, const double* start, const double* theta, const double* Y,
                           const double* ubar, int method, int N, int L, int d, int H, int K, int m, int mode, double* gx,
                           double* gs, double* gslab, void* stream) {
-  XwOdeBwdJob j = {xT, start, Y, nullptr, ubar, gx, gs, gslab, N, 0, nullptr, nullptr, 0.0, 0.0};
+  XwOdeBwdJob j = {xT, start, Y, nullptr, ubar, gx, gs, gslab, N, 0, nullptr, nullptr, 0.0, 0.0, 0, nullptr, nullptr, nullptr, 0.0};
   return xw_ode_bwd_multi(&j, 1, t, theta, method, L, d, H, K, m, mode, stream);
 }

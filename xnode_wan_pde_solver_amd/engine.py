@@ -390,7 +390,7 @@ class Engine:
         H = self.H
         G.u, G.Y, G.v, G.vt = e(L, N), e(L, H, N), e(L, N), e(L, N)
         G.gxv, G.gtv, G.gx, G.gs = e(d, N), e(N), e(d, N), e(N)
-        G.ubarB, G.vbar, G.s3x = e(L, N), e(L, N), e(N)
+        G.vbar, G.s3x = e(L, N), e(N)
         G.c = G.cp = None
         # stage activations of every step, written by the forward, read back by the sweeps (183 MB at N = 4096, L = 32)
         ar = KN.ode_act_rows(self.method, H, self.K, self.m) if self.keep_activations and not self.adjoint else 0
@@ -548,9 +548,13 @@ class Engine:
             e_A = self._mark()
         e_v = self._mark()
         self._join(e_f)
-        KN.gen_cotangents(G.u, G.v, G.w, G.h, G.Vol, G.Nglob, self.alpha, None, G.ubarB, c=G.c, cp=G.cp, ckappa=G.ck,
-                          pollution=self.pollution)
-        KN.ode_bwd_multi([self._job(G, 'i', G.ubarB, G.slabB)], G.t, th, *M, want_x=False, want_params=True, adjoint=self.adjoint)
+        # cotangent B = dI/du is a pointwise product of what the two forward passes wrote: sweep B forms it on the fly too
+        # (XwOdeBwdJob.res_first_only = 2) and starts right behind the test network: one launch fewer on the critical chain
+        # test network -> sweep B -> Adam (0.5063 -> 0.5034 ms per generator sub-step in the same run)
+        res_B = dict(u=G.u, ref=G.v, coef=G.Vol / G.Nglob / G.L, base=G.Vol / G.Nglob,
+                     weak=dict(w=G.w, c=G.c, cp=G.cp, ckappa=G.ck))
+        KN.ode_bwd_multi([dict(self._job(G, 'i', None, G.slabB), res=res_B)], G.t, th, *M, want_x=False, want_params=True,
+                         adjoint=self.adjoint)
         # the reduction needs nabla_x u (sweep A) and v, not sweep B: it runs behind sweep A on the side stream, next to
         # the tail of sweep B, instead of after it
         with self._side(3, e_A, e_v, *[e for e in (e_x, e_b) if e is not None]):   # (re-entering side 1 here crashes hipStreamEndCapture)

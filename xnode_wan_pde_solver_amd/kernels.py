@@ -150,9 +150,20 @@ def ode_bwd_multi(jobs, t, theta, method, H, K, m, want_x, want_params, x_cot_on
             # cotangent formed from a residual inside the sweep (XwOdeBwdJob.res_*): base + coef (u - ref)
             if j.get('ubar') is not None:
                 raise XnwanError('a sweep job takes a stored cotangent (ubar) or a residual (res), not both')
-            first = bool(res['first_only'])
-            _chk(res['u'], F64, (L, N), 'res.u'); _chk(res['ref'], F64, (N,) if first else (L, N), 'res.ref')
-            a.res_first_only, a.res_u, a.res_ref = int(first), _p(res['u']), _p(res['ref'])
+            if res.get('weak') is not None:
+                # the weak form's dI/du: coef d(c(u) u)/du v w (+ base v at the last time index); ref = v
+                wk = res['weak']
+                wpp = wk['w'].dim() == 2
+                _chk(res['u'], F64, (L, N), 'res.u'); _chk(res['ref'], F64, (L, N), 'res.ref (v)')
+                _chk(wk['w'], F64, (L, N) if wpp else (N,), 'res.weak.w'); _chk(wk.get('c'), F64, (L, N), 'res.weak.c')
+                _chk(wk.get('cp'), F64, (L, N), 'res.weak.cp')
+                a.res_first_only, a.res_u, a.res_ref = 2, _p(res['u']), _p(res['ref'])
+                a.res_w_per_point, a.res_w, a.res_c, a.res_cp = int(wpp), _p(wk['w']), _p(wk.get('c')), _p(wk.get('cp'))
+                a.res_kappa2 = 2.0 * float(wk.get('ckappa', 0.0))
+            else:
+                first = bool(res['first_only'])
+                _chk(res['u'], F64, (L, N), 'res.u'); _chk(res['ref'], F64, (N,) if first else (L, N), 'res.ref')
+                a.res_first_only, a.res_u, a.res_ref = int(first), _p(res['u']), _p(res['ref'])
             a.res_coef, a.res_base = float(res['coef']), float(res['base'])
     if x_cot_ones and not (want_x and want_params):
         raise XnwanError('x_cot_ones needs want_x and want_params')
