@@ -274,12 +274,24 @@ __global__ void __launch_bounds__(1024) k_adam(double* __restrict__ param, const
 }
 __global__ void k_step_inc(long long* step) { *step += 1; }
 
-__global__ void __launch_bounds__(256) k_slab_sum(const double* __restrict__ gslab, int nslab, int P, int accumulate,
-                                                  double* __restrict__ out) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= P) return;
+// sum of the per-wave gradient slabs (several GPUs: into the exchange buffer).  Same shape as the reduction inside k_adam:
+// block = 16 parameters x 64 slab groups, P / 16 blocks, a fixed summation tree.  (One thread per parameter walking all
+// slabs -- 7 blocks for 1551 parameters -- took 120 us for the 512 slabs of a sweep launch: three such launches per
+// sub-step were a third of a multi-GPU sub-step.)
+__global__ void __launch_bounds__(1024) k_slab_sum(const double* __restrict__ gslab, int nslab, int P, int accumulate,
+                                                   double* __restrict__ out) {
+  __shared__ double red[XW_ADAM_GROUPS][XW_ADAM_PARAMS];
+  const int tx = threadIdx.x % XW_ADAM_PARAMS, ty = threadIdx.x / XW_ADAM_PARAMS;
+  const int i = blockIdx.x * XW_ADAM_PARAMS + tx;
+  double a = 0.0;
+  if (i < P)
+    for (int s = ty; s < nslab; s += XW_ADAM_GROUPS) a += gslab[(long)s * P + i];
+  red[ty][tx] = a;
+  __syncthreads();
+  if (ty != 0 || i >= P) return;
   double g = accumulate ? out[i] : 0.0;
-  for (int s = 0; s < nslab; ++s) g += gslab[(long)s * P + i];
+#pragma unroll 8
+  for (int k = 0; k < XW_ADAM_GROUPS; ++k) g += red[k][tx];
   out[i] = g;
 }
 
@@ -392,7 +404,8 @@ extern "C" int xw_adam(double* param, const double* gslabA, int nA, const double
 
 extern "C" int xw_slab_sum(const double* gslab, int nslab, int P, int accumulate, double* out, void* stream) {
   if (!gslab || !out || P <= 0 || nslab <= 0) return XW_E_ARG;
-  hipLaunchKernelGGL(k_slab_sum, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, gslab, nslab, P, accumulate, out);
+  hipLaunchKernelGGL(k_slab_sum, dim3((P + XW_ADAM_PARAMS - 1) / XW_ADAM_PARAMS), dim3(XW_ADAM_PARAMS * XW_ADAM_GROUPS), 0,
+                     (hipStream_t)stream, gslab, nslab, P, accumulate, out);
   return xw_launch_status();
 }
 
