@@ -202,6 +202,9 @@ int xw_adam(double* param, const double* gslabA, int nA, const double* gextraA, 
             double lr, double beta1, double beta2, double eps, double* gsum_out, void* stream);
 /* plain slab reduction: out[P] = (accumulate ? out : 0) + sum_s gslab[s][P] */
 int xw_slab_sum(const double* gslab, int nslab, int P, int accumulate, double* out, void* stream);
+/* two slab sets of the same P in one launch: outA[P] = sum of gA[nA][P], outB[P] = sum of gB[nB][P] (the generator
+ * sub-step's exchange buffer on several GPUs) */
+int xw_slab_sum2(const double* gA, int nA, double* outA, const double* gB, int nB, double* outB, int P, void* stream);
 
 /* ---- the exchange step of the sharded path (replaces nn.DataParallel's scatter / gather / reduce-add around both nets,
  * src/training.py:93-97).  One process per GPU; every rank owns a contiguous share of the Monte-Carlo paths; per

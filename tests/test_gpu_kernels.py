@@ -304,6 +304,23 @@ def test_ode_sweep_with_residual_cotangents(solver):
         KN.ode_bwd_multi([dict(job, gslab=slab, ubar=ubar, res=res)], tc, blob, mid, H, K, 8, want_x=False, want_params=True)
 
 
+def test_slab_sums_against_torch():
+    """xw_slab_sum / xw_slab_sum2 (fixed-tree reductions of the per-wave gradient slabs) against torch.sum, at slab counts
+    below, at and above the 64 groups of a block, with accumulation"""
+    from xnode_wan_pde_solver_amd import kernels as KN
+    g = torch.Generator().manual_seed(91)
+    for ns, P in ((1, 7), (63, 1551), (64, 16), (65, 17), (512, 1551), (256, 3701)):
+        S = torch.randn(ns, P, dtype=F64, generator=g).cuda()
+        out = KN.slab_sum(S)
+        _close(out, S.sum(0), 1e-13, 'slab_sum %d x %d' % (ns, P))
+        out2 = KN.slab_sum(S, out=out.clone(), accumulate=True)
+        _close(out2, 2 * S.sum(0), 1e-13, 'slab_sum accumulate')
+        T = torch.randn(max(ns // 2, 1), P, dtype=F64, generator=g).cuda()
+        a, b = torch.empty(P, dtype=F64).cuda(), torch.empty(P, dtype=F64).cuda()
+        KN.slab_sum2(S, a, T, b)
+        assert torch.equal(a, out) and torch.equal(b, KN.slab_sum(T))
+
+
 @pytest.mark.parametrize('N,L,d', CASES + [(50, 3, 70)])
 def test_disc_forward_and_time_tangent(N, L, d):
     from oracle import refspec as R

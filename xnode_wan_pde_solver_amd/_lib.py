@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('XW_LIBRARY') or os.path.join(_HERE, 'libxnwan.so')   # (override: kernel experiments only)
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 c_f32p = ctypes.c_void_p   # coordinates / time grid: const double* (device)   [name kept from the float32 era]
 c_f64p = ctypes.c_void_p   # double*       (device)
@@ -61,6 +61,7 @@ SIGNATURES = {
     'xw_adam': [c_f64p, c_f64p, c_int, c_f64p, c_f64p, c_int, c_f64p, c_f64p, c_f64p, c_f64p, c_i64p, c_int, c_int, c_dbl,
                 c_dbl, c_dbl, c_dbl, c_f64p, c_vp],
     'xw_slab_sum': [c_f64p, c_int, c_int, c_int, c_f64p, c_vp],
+    'xw_slab_sum2': [c_f64p, c_int, c_f64p, c_f64p, c_int, c_f64p, c_int, c_vp],
     'xw_comm_unique_id': [ctypes.c_char_p],
     'xw_comm_init': [ctypes.c_char_p, c_int, c_int, ctypes.POINTER(c_vp)],
     'xw_allreduce': [c_f64p, c_int, c_vp, c_vp],

@@ -402,6 +402,33 @@ extern "C" int xw_adam(double* param, const double* gslabA, int nA, const double
   return xw_launch_status();
 }
 
+// two slab sets in one launch (blockIdx.y picks the set): the generator sub-step's [sum A | sum B] exchange buffer
+__global__ void __launch_bounds__(1024) k_slab_sum2(const double* __restrict__ gA, int nA, double* __restrict__ outA,
+                                                    const double* __restrict__ gB, int nB, double* __restrict__ outB, int P) {
+  __shared__ double red[XW_ADAM_GROUPS][XW_ADAM_PARAMS];
+  const double* __restrict__ gslab = blockIdx.y == 0 ? gA : gB;
+  const int nslab = blockIdx.y == 0 ? nA : nB;
+  double* __restrict__ out = blockIdx.y == 0 ? outA : outB;
+  const int tx = threadIdx.x % XW_ADAM_PARAMS, ty = threadIdx.x / XW_ADAM_PARAMS;
+  const int i = blockIdx.x * XW_ADAM_PARAMS + tx;
+  double a = 0.0;
+  if (i < P)
+    for (int s = ty; s < nslab; s += XW_ADAM_GROUPS) a += gslab[(long)s * P + i];
+  red[ty][tx] = a;
+  __syncthreads();
+  if (ty != 0 || i >= P) return;
+  double g = 0.0;
+#pragma unroll 8
+  for (int k = 0; k < XW_ADAM_GROUPS; ++k) g += red[k][tx];
+  out[i] = g;
+}
+extern "C" int xw_slab_sum2(const double* gA, int nA, double* outA, const double* gB, int nB, double* outB, int P, void* stream) {
+  if (!gA || !gB || !outA || !outB || P <= 0 || nA <= 0 || nB <= 0) return XW_E_ARG;
+  hipLaunchKernelGGL(k_slab_sum2, dim3((P + XW_ADAM_PARAMS - 1) / XW_ADAM_PARAMS, 2), dim3(XW_ADAM_PARAMS * XW_ADAM_GROUPS), 0,
+                     (hipStream_t)stream, gA, nA, outA, gB, nB, outB, P);
+  return xw_launch_status();
+}
+
 extern "C" int xw_slab_sum(const double* gslab, int nslab, int P, int accumulate, double* out, void* stream) {
   if (!gslab || !out || P <= 0 || nslab <= 0) return XW_E_ARG;
   hipLaunchKernelGGL(k_slab_sum, dim3((P + XW_ADAM_PARAMS - 1) / XW_ADAM_PARAMS), dim3(XW_ADAM_PARAMS * XW_ADAM_GROUPS), 0,
@@ -409,7 +436,7 @@ extern "C" int xw_slab_sum(const double* gslab, int nslab, int P, int accumulate
   return xw_launch_status();
 }
 
-extern "C" int xw_abi_version(void) { return 19; }
+extern "C" int xw_abi_version(void) { return 20; }
 extern "C" int xw_reduce_work_size(void) { return 3 * 1024 + 8; }
 
 extern "C" int xw_supported_dims(char* buf, int buflen) {

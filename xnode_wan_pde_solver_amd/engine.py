@@ -630,8 +630,7 @@ class Engine:
         """several GPUs: the front segment ends with the slab sums into the exchange buffer (same captured graph)"""
         self._gen_front(G)
         P = self.Pu
-        KN.slab_sum(G.slabA, out=self.pack_u[:P])
-        KN.slab_sum(G.slabB, out=self.pack_u[P:2 * P])
+        KN.slab_sum2(G.slabA, self.pack_u[:P], G.slabB, self.pack_u[P:2 * P])
 
     # ------------------------------------------------------------------------------------------------------------
     # discriminator sub-step (src/training.py:152-162)

@@ -437,6 +437,14 @@ def adam(param, gslabA, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, gextra
                       float(lr), float(beta1), float(beta2), float(eps), _p(gsum_out), _stream()), 'xw_adam')
 
 
+def slab_sum2(gA, outA, gB, outB):
+    """outA = sum of the slabs gA[nA, P], outB = sum of gB[nB, P], one launch"""
+    _need_gpu()
+    (nA, P), (nB, P2) = gA.shape, gB.shape
+    _chk(gA, F64, (nA, P), 'gA'); _chk(gB, F64, (nB, P), 'gB'); _chk(outA, F64, (P,), 'outA'); _chk(outB, F64, (P,), 'outB')
+    check(lib.xw_slab_sum2(_p(gA), nA, _p(outA), _p(gB), nB, _p(outB), P, _stream()), 'xw_slab_sum2')
+
+
 def slab_sum(gslab, out=None, accumulate=False):
     _need_gpu()
     ns, P = gslab.shape
