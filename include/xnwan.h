@@ -139,8 +139,10 @@ int xw_disc_bwd(const double* xT, const double* t, const double* tpp, const doub
                 int N, int L, int d, int W, int q, const double* act, double* gslab, void* stream);
 
 /* ---- weak functional and cotangents (src/loss.py:46-96) -----------------------------------------------------------
- * scal[16] (device, float64): 0 I   1 S=sum v^2   2 SSE_init   3 SSE_bdry   4 loss_u   5 loss_v   6 int   (rest reserved)
- * xw_weak_partials ADDS this rank's partial sums into scal[0..2] (zero scal first; all-reduce scal[0..3] across ranks).
+ * scal[16] (device, float64): 0 I   1 S=sum v^2   2 SSE_init   3 SSE_bdry   4 loss_u   5 loss_v   6 int
+ *                             7 sum u   8 sum d(phi)/dt  (pairwise groups only, folded into I by xw_pair_fold)   (rest reserved)
+ * xw_weak_partials ADDS this rank's partial sums into scal[0..2] (and [7..8]); zero scal first; all-reduce scal[0..8]
+ * across ranks.
  *   The grid-wide sums are deterministic (per-block partials + last-block final sum, no float atomics): `work` is a
  *   caller-provided scratch of xw_reduce_work_size() doubles, zero-initialised ONCE (the kernels leave it clean), not
  *   shared between launches that may run concurrently.
@@ -149,6 +151,14 @@ int xw_disc_bwd(const double* xT, const double* t, const double* tpp, const doub
  *           NULL for a = identity, b = 0: then it is contracted in-kernel from gx[d,N], gs[N] (xw_ode_bwd), ghT[d,N]
  *           (nabla_x of the start value), gxv[d,N] (xw_disc_gradx), w0[N], gwx0T[d,N] (w and nabla_x w at t_0)
  *   c, cp: c(u,t,x) and dc/du, [L,N]; both NULL means c = ckappa * u           f[L,N]; h[N]
+ *   pairwise != 0 (needs L == 1): the single-slice group at T0 of a list domain, where NeuralODE.forward returns [N,1]
+ *   instead of [N,1,1] (src/model.py:89-91) and src/loss.py:65,70 broadcast [N] against [N,1] into [N,N] tables over all
+ *   PAIRS of paths, summed over both axes.  The sums factorise (O(N)): the d(phi)/dt term becomes (sum u)(sum dphi/dt) --
+ *   the factors go to scal[7], scal[8] and are folded into scal[0] by the finalisation (or by xw_pair_fold after the
+ *   all-reduce) -- and  sum_mn (s31_m + c_n u_n phi_n + f_m phi_n) = N sum_n (s31_n + c_n u_n phi_n + mean(f) phi_n):
+ *   the caller passes s3_scale = Nglob and f := mean f in every entry.  href[N] (may be NULL = h): reference of the
+ *   initial penalty, := mean h for the pairwise mean of src/loss.py:79, whose sample-only rest var(h) arrives as init_off
+ *   (bdry_off likewise for a single-slice T0 boundary group, src/loss.py:84).  s3_scale = 1, offsets 0 otherwise.
  *   Vol = domain volume; Nglob = global number of interior paths (the 1/N, 1/(N L) factors of src/loss.py:64-71)
  *   finalize != 0 (single-GPU path): the sums of this launch are the global ones, so the block that completes them also
  *   does what xw_losses does (loss values into scal[4..6] from scal[0..3], optimiser counter *step += 1 if step != NULL);
@@ -156,8 +166,12 @@ int xw_disc_bwd(const double* xT, const double* t, const double* tpp, const doub
 int xw_weak_partials(const double* u, const double* v, const double* vt, const double* w, int w_per_point,
                      const double* wt, const double* s3x, const double* gx, const double* gs, const double* ghT,
                      const double* gxv, const double* w0, const double* gwx0T, int d, const double* c, double ckappa,
-                     const double* f, const double* h, int N, int L, double Vol, double Nglob, double* work, double* scal,
-                     int finalize, int Lb, double Nbglob, double alpha, long long* step, void* stream);
+                     const double* f, const double* h, const double* href, int pairwise, double s3_scale, int N, int L,
+                     double Vol, double Nglob, double* work, double* scal, int finalize, int Lb, double Nbglob, double alpha,
+                     double init_off, double bdry_off, long long* step, void* stream);
+/* scal[0] -= (Vol / Nglob) scal[7] scal[8]; scal[7] = scal[8] = 0: the pairwise d(phi)/dt term of a single-slice T0 group,
+ * once its two factors are global (several GPUs: after the all-reduce; one GPU: done by xw_weak_partials' finalisation) */
+int xw_pair_fold(double* scal, double Vol, double Nglob, void* stream);
 int xw_reduce_work_size(void);
 /* The l = 0 gradient-contraction term for GENERAL coefficients (src/loss.py:66-69 with the a[d,d,N,L] / b[d,N,L] tables of
  * src/training.py:32-41 -- of which only time index 0 can ever contribute, so only that slice is tabulated):
@@ -182,24 +196,30 @@ int xw_bdry_partials(const double* ub, const double* g, int Nb, int L, double al
 int xw_gen_cotangents(const double* u, const double* v, const double* w, int w_per_point, const double* c,
                       const double* cp, double ckappa, const double* h, int N, int L, double Vol, double Nglob,
                       double alpha, double pollution, const double* scal, double* ubarA, double* ubarB, void* stream);
-/* discriminator cotangent on v (loss_v of src/loss.py:96 + the pollution of :60); reads I = scal_in[0], S = scal_in[1] */
+/* discriminator cotangent on v (loss_v of src/loss.py:96 + the pollution of :60); reads I = scal_in[0], S = scal_in[1];
+ * s3_scale: 1, or Nglob on a pairwise group (with f := mean f), see xw_weak_partials */
 int xw_disc_cotangent(const double* u, const double* v, const double* w, int w_per_point, const double* c,
                       double ckappa, const double* f, const double* h, int N, int L, double Vol, double Nglob,
-                      double pollution, const double* scal_in, double* vbar, void* stream);
+                      double pollution, double s3_scale, const double* scal_in, double* vbar, void* stream);
 /* scal[4] = loss_u, scal[5] = loss_v, scal[6] = int from the (all-reduced) partial sums scal[0..3] (src/loss.py:87-96);
  * L / Lb: sample times of the interior / boundary paths of the group;
  * step (may be NULL): optimiser step counter to increment here when xw_adam was called with bump_step = 0 */
-int xw_losses(double* scal, int L, int Lb, double Vol, double Nglob, double Nbglob, double alpha, long long* step,
-              void* stream);
+int xw_losses(double* scal, int L, int Lb, double Vol, double Nglob, double Nbglob, double alpha, double init_off,
+              double bdry_off, long long* step, void* stream);
 
 /* ---- optimiser (torch.optim.Adam defaults, src/training.py:103-104) ------------------------------------------------
  * grad = gextraA + sum_s gslabA[s] + coefB * (gextraB + sum_s gslabB[s]),  coefB = scal ? 2 / scal[0] : 1
  * (slab sets [n][P]; gextra*[P] pre-reduced gradients, e.g. after an all-reduce; any of them may be NULL / 0)
  * state: m[P], v[P], step (device int64).  bump_step = 1: incremented here after the update; 0: left alone (a later
- * xw_losses does it); -1: xw_losses already advanced it for this update (lets Adam be the last kernel of a sub-step) */
+ * xw_losses does it); -1: xw_losses already advanced it for this update (lets Adam be the last kernel of a sub-step)
+ * [lag_lo, lag_hi): parameters with their own step count *step - *lag (lag: device int64, may be NULL with an empty
+ * range).  skip != 0: that range is left untouched (no moment decay, no step) and *lag += 1 -- torch.optim.Adam skips a
+ * parameter whose .grad is None, which is the state of u_theta's field parameters while no group of a sub-iteration has
+ * integrated the ODE (single-slice groups of the list domains, src/model.py:89-91 + src/training.py:127,138). */
 int xw_adam(double* param, const double* gslabA, int nA, const double* gextraA, const double* gslabB, int nB,
             const double* gextraB, const double* scal, double* m, double* v, long long* step, int bump_step, int P,
-            double lr, double beta1, double beta2, double eps, double* gsum_out, void* stream);
+            double lr, double beta1, double beta2, double eps, double* gsum_out, int lag_lo, int lag_hi, int skip,
+            long long* lag, void* stream);
 /* plain slab reduction: out[P] = (accumulate ? out : 0) + sum_s gslab[s][P] */
 int xw_slab_sum(const double* gslab, int nslab, int P, int accumulate, double* out, void* stream);
 /* two slab sets of the same P in one launch: outA[P] = sum of gA[nA][P], outB[P] = sum of gB[nB][P] (the generator

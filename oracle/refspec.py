@@ -437,6 +437,168 @@ def discriminator_grad(theta, phi, config, setup, cube, funcs, X, XV, BX):
 
 
 # --------------------------------------------------------------------------------------
+# list domains (time-varying balls, src/dataset.py:48-229): the group loop of src/training.py:127-138,152-162
+# --------------------------------------------------------------------------------------
+class Ball:
+    """func_w and V of NSphere_TCone (src/dataset.py:199-201,225-229) / NSphere_THourglass (:110-117,154-159).
+    Sampling itself is not restated here: the groups come from the fixtures (tests/golden/ref_*_groups.npz)."""
+
+    def __init__(self, kind, r, d, T0, T):
+        assert kind in ('NSphere_TCone', 'NSphere_THourglass')
+        self.kind, self.r, self.d, self.T0, self.T = kind, r, d, T0, T
+
+    def radius(self, t):
+        if self.kind == 'NSphere_TCone':
+            return self.r * (1 - t)                                            # :201
+        half = (self.T - self.T0) / 2
+        return torch.where(t <= half, self.r * ((self.T - self.T0) - t), self.r * t)   # :113-116
+
+    def func_w(self, X):
+        return self.radius(X[:, :, 0]) - torch.sqrt(torch.sum(X[:, :, 1:] ** 2, 2))
+
+    def V(self):
+        d = self.d
+        unit = math.pi ** (d / 2) / math.gamma(d / 2 + 1) * self.r ** d
+        if self.kind == 'NSphere_TCone':
+            tc = (1 - self.T0) ** (d + 1) / (d + 1) - (1 - self.T) ** (d + 1) / (d + 1)       # :227
+        else:
+            tc = 2 * ((1 - self.T0) ** (d + 1) / (d + 1) - (1 - (self.T - self.T0) / 2) ** (d + 1) / (d + 1))   # :157-158
+        return unit * tc
+
+
+def u_net_shaped(theta, config, setup, funcs, X):
+    """NeuralODE.forward WITH THE SHAPE THE REFERENCE RETURNS (src/model.py:87-112): [N,1] for a single-slice group at
+    T0 (the early return of :89-91 skips the trailing unsqueeze), [N,L,1] otherwise.  Start value: h on groups that start
+    at T0, g on groups that start on the moving boundary (:95-96)."""
+    at_T0 = float(X[0, 0, 0].detach()) == setup['T0']
+    start = funcs['h'](X[:, 0, :]) if at_T0 else funcs['g'](X[:, 0, :].unsqueeze(1)).reshape(-1)
+    u = u_net(theta, config, X, start)                                        # [N, L]
+    return u if (X.shape[1] == 1 and at_T0) else u.unsqueeze(2)
+
+
+def weak_I_shaped(setup, V, u_s, v3, w, du, dphi, h, f, a, b, c_s):
+    """loss.I (src/loss.py:46-76) on tensors that carry the reference's shapes: u_s, c_s as returned by u_net_shaped /
+    func_c ([N,1] or [N,L,1]), v3 [N,L,1], w, f [N,L], h [N], du / dphi [N,L,d+1] constants, a [d,d,N,L], b [d,N,L].
+    Every `.squeeze()` of the reference drops ALL unit axes, and the products then broadcast: on a single-slice T0 group
+    (u_s [N,1] -> [N], against [N,1] operands) s2, s32, c u phi + f phi become [N,N] tables of all PAIRS of paths, summed
+    over both axes -- restated literally."""
+    d = setup['dim']
+    N, L = u_s.shape[0], u_s.shape[1]                                         # :49-50
+    phi3 = v3 * w.unsqueeze(2)                                                # :51-52
+    uq, vq, pq, cq = u_s.squeeze(), v3.squeeze(), phi3.squeeze(), c_s.squeeze()
+    s1 = V * (u_s[:, -1].squeeze() * v3[:, -1].squeeze() - h * v3[:, 0].squeeze()) / N          # :64
+    s2 = V * (uq.detach() * dphi[:, :, 0]) / N / L                            # :65 (u-factor: no gradient, Q2)
+    s31 = sum(a[i, j] * dphi[:, :, i + 1] * du[:, :, j + 1] for i, j in product(range(d), repeat=2))   # :66-68
+    s32 = sum(b[i] * pq.detach() * du[:, :, i + 1] for i in range(d))         # :69 (builtin sum: see make_golden shim 2)
+    s3 = (V / N / L) * (s31 + s32 + cq * uq * pq + f * pq)                    # :70-72
+    return torch.sum(s1 - torch.sum(s2 - s3, 1), 0)                           # :73
+
+
+def group_forward(theta, phi, config, setup, domain, funcs, X, XV, BX, need_boundary):
+    """one (datau, datav, bdata) triple of the reference's group loop: outputs, helper-backward constants with their
+    pollution of the parameter gradients (Q1), tabulated PDE data, I, and the penalties -- reference shapes throughout"""
+    V = domain.V()
+    Xl = X.detach().clone().requires_grad_(True)
+    XVl = XV.detach().clone().requires_grad_(True)
+    v3 = v_net(phi, config, XVl).unsqueeze(2)                                 # src/training.py:129
+    u_s = u_net_shaped(theta, config, setup, funcs, Xl)                       # :130
+    Xd, BXd = X.detach(), BX.detach()
+    d = setup['dim']
+    h, f, g = funcs['h'](Xd[:, 0, :]), funcs['f'](Xd), funcs['g'](BXd)        # :25-27
+    c_s = funcs['c'](Xd, u_s)                                                 # :29
+    a = torch.stack([torch.stack([funcs['a'](Xd, i, j) for j in range(d)], 0) for i in range(d)], 0)
+    b = torch.stack([funcs['b'](Xd, i) for i in range(d)], 0)
+    w = domain.func_w(XVl)
+    th_keys = [k for k, p in theta.items() if p.requires_grad]
+    ph_keys = [k for k, p in phi.items() if p.requires_grad]
+    gu = torch.autograd.grad(u_s.sum(), [Xl] + [theta[k] for k in th_keys], retain_graph=True, allow_unused=True)   # src/loss.py:55
+    gp = torch.autograd.grad((v3 * w.unsqueeze(2)).sum(), [XVl] + [phi[k] for k in ph_keys], retain_graph=True,
+                             allow_unused=True)                               # :60
+    du, dphi = gu[0], gp[0]
+    # None = the helper backward never reached the parameter (the field's, when no ODE step was taken): kept as None,
+    # because Adam SKIPS parameters whose .grad is None
+    pol_theta = dict(zip(th_keys, gu[1:]))
+    pol_phi = dict(zip(ph_keys, gp[1:]))
+    I = weak_I_shaped(setup, V, u_s, v3, w.detach(), du, dphi, h, f, a, b, c_s)
+    out = dict(u_s=u_s, v3=v3, w=w.detach(), du=du, dphi=dphi, h=h, f=f, g=g, I=I, V=V, pol_theta=pol_theta, pol_phi=pol_phi)
+    out['int'] = torch.log(I ** 2) - torch.log(V * torch.sum(v3 ** 2) / (v3.shape[0] * v3.shape[1]))     # :87-90
+    if need_boundary:
+        out['init'] = torch.mean((u_s[:, 0] - h.unsqueeze(1)) ** 2)           # :79  ([N] - [N,1] -> all pairs on [N,1] outputs)
+        ub_s = u_net_shaped(theta, config, setup, funcs, BXd)                 # :84
+        out['u_b'] = ub_s
+        out['bdry'] = torch.mean((ub_s - g.unsqueeze(2)) ** 2)                # :84  ([n,1] - [n,1,1] -> [n,n,1])
+    return out
+
+
+def _merge_grad(carried, pol, gr):
+    """.grad after the helper backward(s) and loss.backward(): None stays None only if nothing ever reached it"""
+    out = {}
+    for k in gr:
+        parts = [t for t in (carried.get(k), pol.get(k), gr[k]) if t is not None]
+        out[k] = sum(parts[1:], parts[0]) if parts else None
+    return out
+
+
+def adam_update_sparse(p, g, state, lr, beta1=0.9, beta2=0.999, eps=1e-8):
+    """torch.optim.Adam with per-parameter step counts; parameters whose gradient is None are skipped entirely (no
+    moment decay, no step) -- what torch >= 2.0 does after zero_grad() (set_to_none) for the field of u_theta in the
+    first group(s) of a sub-iteration"""
+    for k in p:
+        if g[k] is None:
+            continue
+        t = state['t_' + k] = state.get('t_' + k, 0) + 1
+        mk = state.setdefault('m_' + k, torch.zeros_like(p[k]))
+        vk = state.setdefault('v_' + k, torch.zeros_like(p[k]))
+        mk.mul_(beta1).add_(g[k], alpha=1 - beta1)
+        vk.mul_(beta2).addcmul_(g[k], g[k], value=1 - beta2)
+        denom = (vk.sqrt() / math.sqrt(1 - beta2 ** t)).add_(eps)
+        p[k] = p[k] - (lr / (1 - beta1 ** t)) * (mk / denom)
+    return p
+
+
+class GroupLoop:
+    """The reference's per-sub-iteration loop over the groups of a list domain (src/training.py:127-138,152-162):
+    zero_grad() once (gradients -> None), then for every triple forward + loss + backward + optimizer.step(), gradients
+    ACCUMULATING over the groups of the sub-iteration."""
+
+    def __init__(self, theta, phi, config, setup, domain, funcs):
+        self.theta, self.phi, self.config, self.setup, self.domain, self.funcs = theta, phi, config, setup, domain, funcs
+        self.adam_u, self.adam_v = {}, {}
+
+    def sub_iteration(self, which, triples):
+        carried, outs = {}, []
+        for (X, XV, BX) in triples:
+            if which == 'u':
+                th = _leaves(self.theta)
+                o = group_forward(th, self.phi, self.config, self.setup, self.domain, self.funcs, X, XV, BX, True)
+                loss = o['int'] + self.config['alpha'] * (o['init'] + o['bdry'])                  # src/loss.py:93
+                gr = dict(zip(th, torch.autograd.grad(loss, list(th.values()), allow_unused=True)))
+                carried = _merge_grad(carried, o['pol_theta'], gr)
+                self.theta = adam_update_sparse(self.theta, carried, self.adam_u, self.config['u_rate'])
+            else:
+                ph = _leaves(self.phi)
+                o = group_forward(self.theta, ph, self.config, self.setup, self.domain, self.funcs, X, XV, BX, False)
+                loss = -o['int']                                                                  # :96
+                gr = dict(zip(ph, torch.autograd.grad(loss, list(ph.values()), allow_unused=True)))
+                carried = _merge_grad(carried, o['pol_phi'], gr)
+                self.phi = adam_update_sparse(self.phi, carried, self.adam_v, self.config['v_rate'])
+            o.update(loss=loss.detach(), grad={k: (None if t is None else t.detach().clone()) for k, t in carried.items()})
+            outs.append(o)
+        return outs
+
+
+def l_norm_groups(theta, config, setup, funcs, u_sol, groups, V, p, N_r, error=True):
+    """L_norm on a list domain (utils/auxillary_funcs.py:16-23): group-weighted means; `u_net(x).squeeze()` against
+    func_u_sol(x) [N,L] -- on a single-slice T0 group [N] against [N,1]: all pairs"""
+    diff = 0
+    for x in groups:
+        with torch.no_grad():
+            fx = u_sol(x) - u_net_shaped(theta, config, setup, funcs, x).squeeze() if error else u_sol(x)
+        diff = diff + x.shape[0] / N_r * torch.mean(torch.abs(fx) ** p)
+    return (V * diff) ** (1 / p)
+
+
+# --------------------------------------------------------------------------------------
 # diagnostics (utils/auxillary_funcs.py:7-30)
 # --------------------------------------------------------------------------------------
 def l_norm(u_pred, u_true, V, p):

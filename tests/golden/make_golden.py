@@ -119,9 +119,13 @@ def npy(t):
     return t.detach().cpu().numpy().copy()
 
 
-def one_iteration(case, d, N_r, N_b, N_t, seed, solver_name, full_tensors):
+def one_iteration(case, d, N_r, N_b, N_t, seed, solver_name, full_tensors, shape_param=None):
     training, dataset, lossmod, F = load_reference()
     params = make_params(d, N_r, N_b, N_t, solver_name)
+    if shape_param is not None:
+        # d = 100: with the YAML's integer [-1, 1] the reference's own diagnostic raises OverflowError (V() is the Python
+        # int 2**100, utils/auxillary_funcs.py:15 multiplies a tensor by it); float bounds are what lets it run at all
+        params['shape_param'] = shape_param
     dev = torch.device('cpu')
     torch.manual_seed(seed)
     np.random.seed(seed)
@@ -279,12 +283,15 @@ def trajectory(case, d, N_r, N_b, N_t, seed, outer_iters, gpu_loader_semantics):
 
 
 def sphere_groups(case, domain_name, d, N_r, N_b, N_t, seed, funcs_module='configs.Ex4_1_funcs'):
-    """Time-varying ball domains (src/dataset.py:48-229): the sampled groups themselves, and one generator sub-iteration,
-    one more, and one discriminator sub-iteration over hand-paired (interior, boundary) groups with the reference's own
-    modules -- zero_grad() once per sub-iteration, optimizer.step() after every group (src/training.py:127-138,152-162),
-    GPU loader semantics (fresh copies per pass).  Only groups with >= 2 samples and boundary times != T0 are used:
-    for single-slice groups the reference returns [N,1] instead of [N,1,1] (src/model.py:89-91) and its loss broadcasts
-    to [N,N] pairwise terms (src/loss.py:65,79,84); the engine implements the elementwise intent there."""
+    """Time-varying ball domains (src/dataset.py:48-229): the sampled groups themselves, then one generator
+    sub-iteration, one more, and one discriminator sub-iteration with the reference's own modules over EXACTLY the
+    (interior, v, boundary) triples its training loop visits -- `for (datau, datav, bdata) in points`
+    (src/training.py:128,153) iterates Comb_loader.__getitem__(k) for k = 0, 1, ... until the first IndexError
+    (src/dataset.py:314-322), i.e. the natural pairing (k, k) up to the shorter of the two lists, INCLUDING the
+    single-slice group 0 at T0 (where NeuralODE.forward returns [N,1], src/model.py:89-91, and loss.I / init / bdry
+    broadcast to [N,N] pairwise terms, src/loss.py:65,70,79,84) and the T0 boundary group.  zero_grad() once per
+    sub-iteration, optimizer.step() after every group (src/training.py:127-138,152-162); GPU loader semantics (fresh
+    copies per pass)."""
     training, dataset, lossmod, F = load_reference(funcs_module, d)
     params = make_params(d, N_r, N_b, N_t, 'midpoint')
     params['domain'] = domain_name
@@ -308,35 +315,104 @@ def sphere_groups(case, domain_name, d, N_r, N_b, N_t, seed, funcs_module='confi
     for k, g in enumerate(points.boundary):
         out['boundary/%d' % k] = npy(g)
     out['L2_start'] = np.array(training.L_norm(points.interioru, S.u_net, S.p, S.func_u_sol, domain.V(), N_r).item())
-    inner = [k for k, g in enumerate(points.interioru) if g.shape[1] >= 2]
-    edge = [k for k, g in enumerate(points.boundary) if float(g[0, 0, 0]) != S.setup['T0']]
-    pairs = list(zip(inner, edge))
+    out['rel_start'] = np.array(training.rel_err(points.interioru, S.u_net, S.func_u_sol, S.p, domain.V(), N_r).item())
+    # the triples the reference's loop visits, through the loader's own iteration protocol
+    n_visited = sum(1 for _ in points)
+    pairs = [(k, k) for k in range(n_visited)]
+    assert n_visited == min(len(points.interioru), len(points.boundary))
     out['pairs'] = np.array(pairs)
     fresh = lambda t: t.detach().clone().requires_grad_(True)  # noqa: E731
     step = 0
     for which, opt, net in (('u', S.optimizer_u, S.u_net), ('u', S.optimizer_u, S.u_net), ('v', S.optimizer_v, S.v_net)):
         opt.zero_grad()
         for (ki, kb) in pairs:
-            datau, datav, bdata = fresh(points.interioru[ki]), fresh(points.interioru[ki]), fresh(points.boundary[kb])
+            datau, datav, bdata = fresh(points.interioru[ki]), fresh(points.interiorv[ki]), fresh(points.boundary[kb])
             pv, pu = S.v_net(datav), S.u_net(datau)
             h, f, g, a, b, c = training.func_eval(datau.clone().detach(), bdata.clone().detach(), S.setup, pu,
                                                   F.func_a, F.func_b, F.func_c, F.func_h, F.func_f, F.func_g)
             Lo = lossmod.loss(S.config['alpha'], a, b, c, h, f, g, S.setup, domain, dev)
+            tag = 'step%d' % step
+            if which == 'u':
+                with torch.no_grad():
+                    out[tag + '/init'] = np.array(Lo.init(pu).item())
+                    out[tag + '/bdry'] = np.array(Lo.bdry(S.u_net, bdata).item())
             L = Lo.u(pu, pv, S.u_net, datau, datav, bdata) if which == 'u' else Lo.v(pu, pv, datau, datav)
             L.backward(retain_graph=True)
-            tag = 'step%d' % step
             out[tag + '/which'] = np.array(which)
             out[tag + '/loss'] = np.array(L.item())
-            out[tag + '/u'] = npy(pu.squeeze(2))
+            out[tag + '/u'] = npy(pu.reshape(pu.shape[0], -1))          # ([N,1] on the single-slice T0 group, else [N,L,1])
             out[tag + '/v'] = npy(pv.squeeze(2))
-            out[tag + '/grad'] = np.concatenate([npy(p.grad).reshape(-1) for p in net.parameters()])
+            # a parameter whose .grad is still None (the field's, while no group of this sub-iteration has integrated the
+            # ODE: zero_grad() sets gradients to None on torch >= 2.0) is SKIPPED by Adam -- recorded as a mask
+            out[tag + '/grad'] = np.concatenate([(npy(p.grad) if p.grad is not None else np.zeros(tuple(p.shape))).reshape(-1)
+                                                 for p in net.parameters()])
+            out[tag + '/has_grad'] = np.concatenate([np.full(p.numel(), p.grad is not None) for p in net.parameters()])
             opt.step()
             out[tag + '/after'] = np.concatenate([npy(p).reshape(-1) for p in net.parameters()])
+            out[tag + '/adam_steps'] = np.array([int(opt.state[p]['step']) if p in opt.state and 'step' in opt.state[p] else 0
+                                                 for p in net.parameters()])
             step += 1
     out['n_steps'] = np.array(step)
     path = os.path.join(HERE, case + '.npz')
     np.savez_compressed(path, **out)
-    print('wrote', path, '%.1f KB' % (os.path.getsize(path) / 1024), 'groups', len(points.interioru), 'pairs', pairs)
+    print('wrote', path, '%.1f KB' % (os.path.getsize(path) / 1024), 'groups', [tuple(g.shape[:2]) for g in points.interioru],
+          'boundary', [g.shape[0] for g in points.boundary], 'pairs', pairs)
+
+
+def sphere_trajectory(case, domain_name, d, N_r, N_b, N_t, seed, outer_iters, funcs_module='configs.Ex4_3_funcs', alpha=100000000):
+    """The reference's own train() on a time-varying ball domain (natural group loop incl. the single-slice groups),
+    GPU loader semantics.  Its on-sample diagnostic is unusable on list domains (utils/auxillary_funcs.py:19 broadcasts
+    [N,1] - [N] to [N,N] on single-slice groups), so the `stop` hook -- called once per generator sub-iteration,
+    src/training.py:142 -- evaluates u_net on a FIXED multi-slice probe group that starts at T0 and stays strictly
+    inside the domain, against func_u_sol: relative L2 error over the probe points."""
+    training, dataset, lossmod, F = load_reference(funcs_module, d)
+    params = make_params(d, N_r, N_b, N_t, 'midpoint', iterations=outer_iters, alpha=alpha)
+    params['domain'] = domain_name
+    params['shape_param'] = 1.0
+    if not funcs_module.endswith('Ex4_1_funcs'):
+        params['funcs'] = funcs_module.split('.')[-1]
+    orig = dataset.Comb_loader.__getitem__
+
+    def getitem(self, idx):
+        r = orig(self, idx)
+        return tuple(t.clone() for t in r)
+    dataset.Comb_loader.__getitem__ = getitem
+    # probe group: 96 points of radius < 0.45, 9 times in [0, 0.5]  (cone radius at t = 0.5 is 0.5; hourglass too)
+    g = torch.Generator().manual_seed(4242)
+    xp = torch.randn(96, d, generator=g, dtype=torch.float64)
+    xp = xp / xp.norm(dim=1, keepdim=True) * (0.45 * torch.rand(96, 1, generator=g, dtype=torch.float64) ** (1.0 / d))
+    tp = torch.linspace(0, 0.5, 9, dtype=torch.float64)
+    probe = torch.cat((tp.view(1, -1, 1).expand(96, -1, 1), xp.view(96, 1, d).expand(-1, 9, -1)), 2).contiguous()
+    sol = F.func_u_sol(probe)
+    log, losses = [], []
+
+    def hook(self, pts, domain):
+        with torch.no_grad():
+            up = self.u_net(probe).squeeze(2)
+            log.append(float(torch.sqrt(torch.mean((up - sol) ** 2) / torch.mean(sol ** 2))))
+        losses.append(self.av_l)
+        return False
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    cwd = os.getcwd()
+    scratch = tempfile.mkdtemp(prefix='ref_traj_')
+    os.chdir(scratch)
+    try:
+        S = training.NODE_WAN_solver(params, F.func_a, F.func_b, F.func_c, F.func_h, F.func_f, F.func_g,
+                                     torch.device('cpu'), './', func_u_sol=F.func_u_sol, p=2, stop=hook)
+        t0 = time.time()
+        S.train(report=False)
+        wall = time.time() - t0
+        with torch.no_grad():
+            up = S.u_net(probe).squeeze(2)
+    finally:
+        os.chdir(cwd)
+        dataset.Comb_loader.__getitem__ = orig
+    path = os.path.join(HERE, case + '.npz')
+    np.savez_compressed(path, rel_l2=np.array(log), gen_loss=np.array(losses), wall_s=np.array(wall),
+                        params_json=np.array(json.dumps(params)), seed=np.array(seed), probe=npy(probe), probe_sol=npy(sol),
+                        probe_u=npy(up))
+    print('wrote', path, 'steps', len(log), 'wall %.1fs' % wall, 'rel-L2 first/last', log[0], log[-1])
 
 
 def bound_pad_vectors():
@@ -422,14 +498,28 @@ if __name__ == '__main__':
     ap.add_argument('--traj', action='store_true', help='also produce the 800-step trajectory fixtures (slow)')
     ap.add_argument('--only-traj', action='store_true')
     ap.add_argument('--round2', action='store_true', help='only the fixtures added in round 2 (BASELINE configs[2], configs[4])')
+    ap.add_argument('--round3', action='store_true', help='only the fixtures added / regenerated in round 3 (natural group pairing on the '
+                    'ball domains, d = 100, the cone trajectory)')
     args = ap.parse_args()
     torch.set_num_threads(4)
+    if args.round3:
+        # BASELINE configs[3] shape family: d = 100, N_t = 32 (N small enough for the reference's a[d,d,N,L] table: 20 MB)
+        one_iteration('ref_d100_small_midpoint', 100, 16, 64, 32, 5, 'midpoint', False, shape_param=[-1.0, 1.0])
+        # ball domains with the NATURAL (k, k) pairing of the reference's loop, single-slice T0 groups included
+        sphere_groups('ref_cone_groups', 'NSphere_TCone', 3, 64, 40, 8, 1)
+        sphere_groups('ref_hourglass_groups', 'NSphere_THourglass', 3, 64, 40, 8, 1)
+        sphere_groups('ref_cone_ex43_d10_groups', 'NSphere_TCone', 10, 384, 120, 12, 2, 'configs.Ex4_3_funcs')
+        sphere_groups('ref_hourglass_ex43_d10_groups', 'NSphere_THourglass', 10, 384, 120, 12, 2, 'configs.Ex4_3_funcs')
+        # trained error on a ball domain through the reference's own train()
+        sphere_trajectory('ref_traj_cone_ex43_d3_seed0', 'NSphere_TCone', 3, 256, 128, 10, 0, 100)
+        sys.exit(0)
     if args.round2 or not args.only_traj:
         # BASELINE configs[2] shape family: d = 50, N_t = 64 (small N so that the reference runs in seconds)
         one_iteration('ref_d50_nt64_small_midpoint', 50, 32, 100, 64, 4, 'midpoint', False)
         # BASELINE configs[4]: the time-varying ball domains with the Ex4_3 functions at d = 10
         sphere_groups('ref_cone_ex43_d10_groups', 'NSphere_TCone', 10, 384, 120, 12, 2, 'configs.Ex4_3_funcs')
         sphere_groups('ref_hourglass_ex43_d10_groups', 'NSphere_THourglass', 10, 384, 120, 12, 2, 'configs.Ex4_3_funcs')
+        one_iteration('ref_d100_small_midpoint', 100, 16, 64, 32, 5, 'midpoint', False, shape_param=[-1.0, 1.0])
     if not args.only_traj and not args.round2:
         fillt_vectors()
         bound_pad_vectors()
@@ -444,3 +534,4 @@ if __name__ == '__main__':
     if args.traj or args.only_traj:
         trajectory('ref_traj_plumb_seed0_gpusem', 5, 256, 64, 16, 0, 400, True)
         trajectory('ref_traj_plumb_seed0_cpusem', 5, 256, 64, 16, 0, 400, False)
+        sphere_trajectory('ref_traj_cone_ex43_d3_seed0', 'NSphere_TCone', 3, 256, 128, 10, 0, 100)

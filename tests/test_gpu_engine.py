@@ -23,7 +23,8 @@ pytestmark = pytest.mark.gpu
 import configs.Ex4_1_funcs as P  # noqa: E402
 
 CASES = ['ref_tiny_midpoint', 'ref_tiny_euler', 'ref_tiny_rk4', 'ref_plumb_midpoint', 'ref_d20_small_midpoint',
-         'ref_d50_nt64_small_midpoint']       # the last one: BASELINE configs[2] family (d = 50, N_t = 64)
+         'ref_d50_nt64_small_midpoint',       # BASELINE configs[2] family (d = 50, N_t = 64)
+         'ref_d100_small_midpoint']           # BASELINE configs[3] family (d = 100, N_t = 32)
 FUNCS = dict(h=P.func_h, f=P.func_f, g=P.func_g, a=P.func_a, b=P.func_b, c=P.func_c)
 
 
@@ -299,12 +300,18 @@ def test_sphere_domain_groups_against_reference_vectors(golden_dir, case, name):
         close(g_, z['interior/%d' % k], 1e-13, 1e-15, 'interior group %d' % k)
     for k, g_ in enumerate(pts.boundary):
         close(g_, z['boundary/%d' % k], 1e-13, 1e-15, 'boundary group %d' % k)
-    # (the reference's L_norm broadcasts [N,1] - [N] to [N,N] on single-slice groups, utils/auxillary_funcs.py:19, so its
-    #  list-domain diagnostic is not comparable; the product computes the elementwise norm)
-    assert np.isfinite(float(L_norm(pts.interioru, S.u_net, 2, F.func_u_sol, domain.V(), s['N_r'])))
+    # the reference's diagnostic on a list domain: `u_net(x).squeeze()` against func_u_sol(x) [N,1] on the single-slice group
+    # is the [N,N] table over all pairs (utils/auxillary_funcs.py:19) -- reproduced
+    from utils.auxillary_funcs import rel_err
+    close(L_norm(pts.interioru, S.u_net, 2, F.func_u_sol, domain.V(), s['N_r']), float(z['L2_start']), 1e-7, what='L_norm on the groups')
+    close(rel_err(pts.interioru, S.u_net, F.func_u_sol, 2, domain.V(), s['N_r']), float(z['rel_start']), 1e-7, what='rel_err on the groups')
     eng = S.engine
+    # the triples the reference's loop visits: (k, k) for every k the loader yields, INCLUDING the single-slice group 0 at
+    # T0 (59 % of the interior paths at d = 10) with its [N,N] pairwise loss terms and the T0 boundary group
     pairs = [tuple(p) for p in z['pairs']]
+    assert pairs == [(k, k) for k in range(min(len(pts.interioru), len(pts.boundary)))] == [(k, k) for k in range(len(S._groups(pts)))]
     groups = [eng.load_group(pts.interioru[ki], pts.interiorv[ki], pts.boundary[kb], domain) for ki, kb in pairs]
+    assert groups[0].L == 1 and groups[0].pair_i and groups[0].pair_b and not any(G.pair_i for G in groups[1:])
     for G in groups:
         G.persistent = False
     step = 0
@@ -322,11 +329,57 @@ def test_sphere_domain_groups_against_reference_vectors(golden_dir, case, name):
             close(G.u.t(), z[tag + '/u'], 1e-5, 1e-7, tag + ' u')
             close(G.v.t(), z[tag + '/v'], 1e-5, 1e-7, tag + ' v')
             close(got_loss, float(z[tag + '/loss']), 1e-5, what=tag + ' loss')
+            if which == 'u':
+                init = float(eng.scal[2]) / G.Nglob + G.init_off
+                bdry = float(eng.scal[3]) / (G.Nbglob * G.Lb) + G.bdry_off
+                close(init, float(z[tag + '/init']), 1e-9, what=tag + ' init penalty')
+                close(bdry, float(z[tag + '/bdry']), 1e-9, what=tag + ' boundary penalty')
             ref = z[tag + '/grad']
             close(got_grad, ref, 1e-5, 1e-6 * float(np.abs(ref).max()), tag + ' grad (carried over the groups)')
             close(blob.data, z[tag + '/after'], 1e-5, 1e-7, tag + ' params after Adam')
             step += 1
     assert step == int(z['n_steps'])
+
+
+def test_cone_training_trajectory_follows_reference(golden_dir, tmp_path):
+    """BASELINE configs[4] family, through train(): NSphere_TCone, Ex4_3, d = 3, N_r = 256, N_b = 128, N_t = 10, seed 0,
+    100 outer iterations of the natural group loop (single-slice T0 groups with the reference's pairwise terms, Adam
+    skipping the field's parameters there).  The `stop` hook evaluates u_theta on the fixture's fixed multi-slice probe
+    group (the reference's own L_norm is all-pairs on list domains).  The REFERENCE DOES NOT CONVERGE on the ball domains
+    (as run on this software stack its probe error grows from 1.4 to > 100, for alpha = 1e2 .. 1e8, both domains, Ex4_1
+    and Ex4_3: DESIGN 8), what is pinned is that the engine FOLLOWS the reference's run, sub-iteration by sub-iteration."""
+    import configs.Ex4_3_funcs as F
+    z, params = load(golden_dir, 'ref_traj_cone_ex43_d3_seed0')
+    params.pop('funcs')
+    ref = z['rel_l2']
+    probe, sol = torch.from_numpy(z['probe']), torch.from_numpy(z['probe_sol'])
+    log = []
+
+    def hook(self, pts, domain):
+        with torch.no_grad():
+            up = self.u_net(probe).squeeze(2).cpu()
+        log.append(float(torch.sqrt(torch.mean((up - sol) ** 2) / torch.mean(sol ** 2))))
+        return False
+    S = make_solver(params, int(z['seed']), F=F, stop=hook)
+    S.tabulate_on_host = True
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        S.train(report=False)
+    finally:
+        os.chdir(cwd)
+    got = np.array(log)
+    out = os.environ.get('XW_DUMP_TRAJ')
+    if out:
+        np.savez(out, got=got, ref=ref)
+    assert got.shape == ref.shape == (200,)
+    # Ball-domain samples are float64 end to end (src/dataset.py:65-96), so nothing rounds to float32 on the way and the two
+    # runs do not decorrelate over these 100 outer iterations (~2400 optimiser steps over all groups): measured on the
+    # MI355X 1.8e-9 relative at worst.  North-star criterion (trained error within 1e-2 absolute of the reference's on the
+    # same seeds): holds at EVERY logged sub-iteration, not only at the end.
+    np.testing.assert_allclose(got, ref, rtol=1e-6)
+    assert np.abs(got - ref).max() < 1e-2
+    assert got[20:].min() > 1.0 and ref[20:].min() > 1.0          # (the run the reference produces here does not converge)
 
 
 def test_sphere_domain_trains_end_to_end(tmp_path):

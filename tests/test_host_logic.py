@@ -14,7 +14,8 @@ import configs.Ex4_1_funcs as P
 from xnode_wan_pde_solver_amd import sampling, solver as S, _lib
 from xnode_wan_pde_solver_amd.engine import Structure
 
-CASES = ['ref_tiny_midpoint', 'ref_plumb_midpoint', 'ref_d20_small_midpoint', 'ref_d50_nt64_small_midpoint']
+CASES = ['ref_tiny_midpoint', 'ref_plumb_midpoint', 'ref_d20_small_midpoint', 'ref_d50_nt64_small_midpoint',
+         'ref_d100_small_midpoint']
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 

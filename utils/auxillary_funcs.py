@@ -11,7 +11,9 @@ import torch
 def _group_mean_p(x, u_net, p, func_u_sol, error):
     target = func_u_sol(x)
     if error:
-        pred = u_net(x).squeeze(-1) if x.shape[1] > 1 else u_net(x).reshape(x.shape[0], 1)
+        # `.squeeze()` as in the reference (:14,20): it drops EVERY unit axis, so on a single-slice group the prediction [N]
+        # meets func_u_sol's [N,1] and the difference is the [N,N] table over all pairs -- reproduced, not "fixed"
+        pred = u_net(x).squeeze()
         dev = pred.device
         diff = target.to(dev) - pred
     else:

@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('XW_LIBRARY') or os.path.join(_HERE, 'libxnwan.so')   # (override: kernel experiments only)
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 c_f32p = ctypes.c_void_p   # coordinates / time grid: const double* (device)   [name kept from the float32 era]
 c_f64p = ctypes.c_void_p   # double*       (device)
@@ -48,18 +48,19 @@ SIGNATURES = {
     'xw_disc_bwd_slabs': [c_int, c_int],
     'xw_disc_bwd': [c_f32p, c_f32p, c_f32p, c_f64p, c_f64p, c_int, c_int, c_int, c_int, c_int, c_f64p, c_f64p, c_vp],
     'xw_weak_partials': [c_f64p, c_f64p, c_f64p, c_f64p, c_int, c_f64p, c_f64p, c_f64p, c_f64p, c_f64p, c_f64p, c_f64p,
-                         c_f64p, c_int, c_f64p, c_dbl, c_f64p, c_f64p, c_int, c_int, c_dbl, c_dbl, c_f64p, c_f64p, c_int, c_int, c_dbl,
-                         c_dbl, c_i64p, c_vp],
+                         c_f64p, c_int, c_f64p, c_dbl, c_f64p, c_f64p, c_f64p, c_int, c_dbl, c_int, c_int, c_dbl, c_dbl, c_f64p, c_f64p,
+                         c_int, c_int, c_dbl, c_dbl, c_dbl, c_dbl, c_i64p, c_vp],
+    'xw_pair_fold': [c_f64p, c_dbl, c_dbl, c_vp],
     'xw_bdry_partials': [c_f64p, c_f64p, c_int, c_int, c_dbl, c_dbl, c_f64p, c_f64p, c_f64p, c_vp],
     'xw_reduce_work_size': [],
     'xw_weak_contract_general': [c_f64p, c_int, c_f64p, c_f64p, c_f64p, c_f64p, c_f64p, c_f64p, c_f64p, c_f64p, c_int, c_int, c_f64p, c_vp],
     'xw_gen_cotangents': [c_f64p, c_f64p, c_f64p, c_int, c_f64p, c_f64p, c_dbl, c_f64p, c_int, c_int, c_dbl, c_dbl, c_dbl,
                           c_dbl, c_f64p, c_f64p, c_f64p, c_vp],
     'xw_disc_cotangent': [c_f64p, c_f64p, c_f64p, c_int, c_f64p, c_dbl, c_f64p, c_f64p, c_int, c_int, c_dbl, c_dbl, c_dbl,
-                          c_f64p, c_f64p, c_vp],
-    'xw_losses': [c_f64p, c_int, c_int, c_dbl, c_dbl, c_dbl, c_dbl, c_i64p, c_vp],
+                          c_dbl, c_f64p, c_f64p, c_vp],
+    'xw_losses': [c_f64p, c_int, c_int, c_dbl, c_dbl, c_dbl, c_dbl, c_dbl, c_dbl, c_i64p, c_vp],
     'xw_adam': [c_f64p, c_f64p, c_int, c_f64p, c_f64p, c_int, c_f64p, c_f64p, c_f64p, c_f64p, c_i64p, c_int, c_int, c_dbl,
-                c_dbl, c_dbl, c_dbl, c_f64p, c_vp],
+                c_dbl, c_dbl, c_dbl, c_f64p, c_int, c_int, c_int, c_i64p, c_vp],
     'xw_slab_sum': [c_f64p, c_int, c_int, c_int, c_f64p, c_vp],
     'xw_slab_sum2': [c_f64p, c_int, c_f64p, c_f64p, c_int, c_f64p, c_int, c_vp],
     'xw_comm_unique_id': [ctypes.c_char_p],

@@ -24,6 +24,7 @@ __device__ __forceinline__ double wave_sum(double x) {
 // (checkpoint/resume, test_test_net_reuse_is_exact).  work: NV * gridDim.x doubles + 1 ticket word (kept at zero
 // between launches: the last block resets it).  Hand-off follows cdna_hip_programming.md Guideline 16: stores ->
 // s_waitcnt vmcnt(0) -> barrier -> lane-0 release fence -> ticket; consumer: ticket -> acquire fence -> barrier -> loads.
+// NV > 3: values 3, 4, ... go to dst[7], dst[8], ... (scal[3..6] are the boundary sum and the loss values)
 template <int NV>
 __device__ __forceinline__ bool grid_sum(double (&val)[NV], double* __restrict__ work, double* __restrict__ dst) {
   __shared__ double red[NV][4];
@@ -67,7 +68,7 @@ __device__ __forceinline__ bool grid_sum(double (&val)[NV], double* __restrict__
   if (threadIdx.x < NV) {
     double tot = 0.0;
     for (int w = 0; w < (int)(blockDim.x >> 6); ++w) tot += red[threadIdx.x][w];
-    dst[threadIdx.x] += tot;
+    dst[threadIdx.x < 3 ? threadIdx.x : threadIdx.x + 4] += tot;
   }
   if (threadIdx.x == 0) *ticket = 0u;
   return true;                                          // this block completed the sum
@@ -78,6 +79,24 @@ __device__ __forceinline__ double interior_loss(const double* scal, double Vol, 
   return log(I * I) - log(Vol * S / (Nglob * (double)L));  // src/loss.py:89-90
 }
 
+// Single-slice groups at T0 of the list domains: NeuralODE.forward returns [N,1] there instead of [N,1,1]
+// (src/model.py:89-91) and the products of src/loss.py:65,70 broadcast to [N,N] tables over all PAIRS of paths, summed over
+// both axes.  The sums factorise: sum_mn u_n dphi0_m = (sum u)(sum dphi0) -- the two factors are accumulated separately
+// (scal[7], scal[8]) and folded into I here, once they are global (after the all-reduce on several GPUs).
+__device__ __forceinline__ void fold_pairs(double* scal, double cN) {
+  scal[0] -= cN * scal[7] * scal[8];
+  scal[7] = 0.0;
+  scal[8] = 0.0;
+}
+__device__ __forceinline__ void loss_values(double* scal, int L, int Lb, double Vol, double Nglob, double Nbglob,
+                                            double alpha, double init_off, double bdry_off) {
+  const double in_ = interior_loss(scal, Vol, Nglob, L);
+  scal[6] = in_;
+  // init_off / bdry_off: the sample-only part of a pairwise mean, mean_nm (u_n - h_m)^2 = mean_n (u_n - mean h)^2 + var h
+  scal[4] = in_ + alpha * ((scal[2] / Nglob + init_off) + (scal[3] / (Nbglob * (double)Lb) + bdry_off));  // src/loss.py:93
+  scal[5] = -in_;                                                                                          // src/loss.py:96
+}
+
 __global__ void __launch_bounds__(256) k_weak_partials(const double* __restrict__ u, const double* __restrict__ v,
                                                        const double* __restrict__ vt, const double* __restrict__ w,
                                                        int w_per_point, const double* __restrict__ wt,
@@ -86,12 +105,16 @@ __global__ void __launch_bounds__(256) k_weak_partials(const double* __restrict_
                                                        const double* __restrict__ gxv, const double* __restrict__ w0,
                                                        const double* __restrict__ gwx0T, int d,
                                                        const double* __restrict__ c, double ckappa,
-                                                       const double* __restrict__ f, const double* __restrict__ h, int N,
-                                                       int L, double Vol, double Nglob, double* __restrict__ work,
+                                                       const double* __restrict__ f, const double* __restrict__ h,
+                                                       const double* __restrict__ href, int pairwise, double s3_scale,
+                                                       int N, int L, double Vol, double Nglob, double* __restrict__ work,
                                                        double* __restrict__ scal, int finalize, int Lb, double Nbglob,
-                                                       double alpha, long long* __restrict__ step) {
+                                                       double alpha, double init_off, double bdry_off,
+                                                       long long* __restrict__ step) {
   // one lane per sample point (time-major: consecutive lanes = consecutive paths of one time index, coalesced)
-  double acc[3] = {0.0, 0.0, 0.0};  // I, sum v^2, SSE_init
+  // pairwise (single-slice T0 group, L == 1): the s2 term is (sum u)(sum dphi0) -- factors in acc[3], acc[4] -- and the
+  // caller passes s3_scale = N with f := mean f, href := mean h (the [N,N] sums of src/loss.py:70,79 factorised)
+  double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};  // I, sum v^2, SSE_init, sum u, sum dphi/dt
   const double cN = Vol / Nglob, cNL = Vol / Nglob / (double)L;
   const long P = (long)N * L;
   for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (long)gridDim.x * blockDim.x) {
@@ -110,7 +133,8 @@ __global__ void __launch_bounds__(256) k_weak_partials(const double* __restrict_
       s31 = s3x != nullptr ? s3x[n] : 0.0;            // (a = identity, b = 0: contracted below, spread over the time rows)
       s3 += s31;                                      // src/loss.py:66-69 (only non-zero at l = 0)
       I -= cN * hn * vl;                              // s1, src/loss.py:64
-      acc[2] += (ul - hn) * (ul - hn);                // src/loss.py:79
+      const double hr = href != nullptr ? href[n] : hn;
+      acc[2] += (ul - hr) * (ul - hr);                // src/loss.py:79
     }
     if (s3x == nullptr) {
       // a = identity, b = 0:  s31_n = sum_i d_i phi d_i u  with  nabla phi = w nabla v + v nabla w  (at t_0, on the
@@ -125,24 +149,28 @@ __global__ void __launch_bounds__(256) k_weak_partials(const double* __restrict_
           part += (w0n * gxv[q] + v0n * gwx0T[q]) * (gx[q] + gsn * ghT[q]);
         }
       }
-      I += cNL * part;
+      I += cNL * s3_scale * part;
     }
     if (l == L - 1) I += cN * ul * vl;
-    I -= cNL * (ul * phit - s3);                      // -(s2 - s3), src/loss.py:65,71-73
+    if (pairwise) {
+      I += cNL * s3_scale * s3;
+      acc[3] += ul;
+      acc[4] += phit;
+    } else {
+      I -= cNL * (ul * phit - s3_scale * s3);         // -(s2 - s3), src/loss.py:65,71-73
+    }
     acc[0] += I;
     acc[1] += vl * vl;
   }
-  const bool last = grid_sum<3>(acc, work, scal);
+  const bool last = grid_sum<5>(acc, work, scal);
   if (finalize && last) {
     // the block that completed the sums also turns them into the loss values (what xw_losses does) -- one launch and
     // one dependency edge less per sub-step; scal[3] (boundary SSE) was completed by an earlier launch on this stream
     __syncthreads();
     if (threadIdx.x == 0) {
       if (step != nullptr) *step += 1;
-      const double in_ = interior_loss(scal, Vol, Nglob, L);
-      scal[6] = in_;
-      scal[4] = in_ + alpha * (scal[2] / Nglob + scal[3] / (Nbglob * (double)Lb));  // src/loss.py:93
-      scal[5] = -in_;                                                                // src/loss.py:96
+      if (pairwise) fold_pairs(scal, cN);
+      loss_values(scal, L, Lb, Vol, Nglob, Nbglob, alpha, init_off, bdry_off);
     }
   }
 }
@@ -196,21 +224,21 @@ __global__ void __launch_bounds__(256) k_gen_cots(const double* __restrict__ u, 
 }
 
 __global__ void k_losses(double* __restrict__ scal, int L, int Lb, double Vol, double Nglob, double Nbglob, double alpha,
-                         long long* __restrict__ step) {
+                         double init_off, double bdry_off, long long* __restrict__ step) {
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     if (step != nullptr) *step += 1;                  // optimiser step counter (after xw_adam has read it)
-    const double in_ = interior_loss(scal, Vol, Nglob, L);
-    scal[6] = in_;
-    scal[4] = in_ + alpha * (scal[2] / Nglob + scal[3] / (Nbglob * (double)Lb));  // src/loss.py:93
-    scal[5] = -in_;                                                                // src/loss.py:96
+    loss_values(scal, L, Lb, Vol, Nglob, Nbglob, alpha, init_off, bdry_off);
   }
+}
+__global__ void k_pair_fold(double* __restrict__ scal, double cN) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) fold_pairs(scal, cN);
 }
 
 __global__ void __launch_bounds__(256) k_disc_cot(const double* __restrict__ u, const double* __restrict__ v,
                                                   const double* __restrict__ w, int w_per_point,
                                                   const double* __restrict__ c, double ckappa,
                                                   const double* __restrict__ f, const double* __restrict__ h, int N,
-                                                  int L, double Vol, double Nglob, double pollution,
+                                                  int L, double Vol, double Nglob, double pollution, double s3_scale,
                                                   const double* __restrict__ scal_in, double* __restrict__ vbar) {
   const double I = scal_in[0], S = scal_in[1];
   const double cI = 2.0 / I;
@@ -221,7 +249,7 @@ __global__ void __launch_bounds__(256) k_disc_cot(const double* __restrict__ u, 
     const double ul = u[p], vl = v[p];
     const double wl = w_per_point ? w[p] : w[n];
     const double cl = c != nullptr ? c[p] : ckappa * ul;
-    double dI = cNL * (cl * ul + f[p]) * wl;          // d I / d v through phi = v w in c u phi + f phi
+    double dI = cNL * s3_scale * (cl * ul + f[p]) * wl;   // d I / d v through phi = v w in c u phi + f phi
     if (l == L - 1) dI += cN * ul;
     if (l == 0) dI -= cN * h[n];
     vbar[p] = pollution * wl - cI * dI + 2.0 * vl / S;  // loss_v = -(log I^2 - log(V S / P))
@@ -239,7 +267,8 @@ __global__ void __launch_bounds__(1024) k_adam(double* __restrict__ param, const
                                                const double* __restrict__ eB, const double* __restrict__ scal,
                                                double* __restrict__ m, double* __restrict__ v,
                                                const long long* __restrict__ step, int step_is_current, int P, double lr,
-                                               double beta1, double beta2, double eps, double* __restrict__ gsum_out) {
+                                               double beta1, double beta2, double eps, double* __restrict__ gsum_out,
+                                               int lag_lo, int lag_hi, int skip, const long long* __restrict__ lag) {
   // block = 16 parameters (one 128-byte line per slab row) x 64 slab groups: P / 16 blocks spread the 10 MB of slabs of
   // a generator sub-step over ~100 CUs (64 parameters per block used 26 of them and took 17 us)
   __shared__ double red[2][XW_ADAM_GROUPS][XW_ADAM_PARAMS];
@@ -264,7 +293,12 @@ __global__ void __launch_bounds__(1024) k_adam(double* __restrict__ param, const
   const double coefB = scal != nullptr ? 2.0 / scal[0] : 1.0;
   const double g = a + coefB * b;
   if (gsum_out != nullptr) gsum_out[i] = g;
-  const long long t = *step + (step_is_current ? 0 : 1);
+  // parameters [lag_lo, lag_hi) (the field of u_theta) have their own step count, *step - *lag: torch's Adam skips a
+  // parameter whose .grad is None -- no moment decay, no step -- which is what the field's are while no group of the
+  // sub-iteration has integrated the ODE (single-slice groups, src/model.py:89-91; zero_grad() of torch >= 2.0)
+  const bool lagged = i >= lag_lo && i < lag_hi;
+  if (lagged && skip) return;
+  const long long t = *step + (step_is_current ? 0 : 1) - (lagged && lag != nullptr ? *lag : 0);
   const double bc1 = 1.0 - pow(beta1, (double)t), bc2 = 1.0 - pow(beta2, (double)t);
   const double mi = beta1 * m[i] + (1.0 - beta1) * g;
   const double vi = beta2 * v[i] + (1.0 - beta2) * g * g;
@@ -342,14 +376,16 @@ __global__ void __launch_bounds__(256) k_weak_contract(const double* __restrict_
 extern "C" int xw_weak_partials(const double* u, const double* v, const double* vt, const double* w, int w_per_point,
                                 const double* wt, const double* s3x, const double* gx, const double* gs, const double* ghT,
                                 const double* gxv, const double* w0, const double* gwx0T, int d, const double* c,
-                                double ckappa, const double* f, const double* h, int N, int L, double Vol, double Nglob,
-                                double* work, double* scal, int finalize, int Lb, double Nbglob, double alpha,
+                                double ckappa, const double* f, const double* h, const double* href, int pairwise,
+                                double s3_scale, int N, int L, double Vol, double Nglob, double* work, double* scal,
+                                int finalize, int Lb, double Nbglob, double alpha, double init_off, double bdry_off,
                                 long long* step, void* stream) {
   if (!u || !v || !vt || !w || !f || !h || !work || !scal || N <= 0 || L <= 0 || (finalize && Lb <= 0)) return XW_E_ARG;
   if (!s3x && (!gx || !gs || !ghT || !gxv || !w0 || !gwx0T || d <= 0)) return XW_E_ARG;
+  if (pairwise && L != 1) return XW_E_ARG;
   hipLaunchKernelGGL(k_weak_partials, dim3(blocks_for((long)N * L, 256, 1024)), dim3(256), 0, (hipStream_t)stream, u, v, vt, w,
-                     w_per_point, wt, s3x, gx, gs, ghT, gxv, w0, gwx0T, d, c, ckappa, f, h, N, L, Vol, Nglob, work, scal, finalize,
-                     Lb, Nbglob, alpha, step);
+                     w_per_point, wt, s3x, gx, gs, ghT, gxv, w0, gwx0T, d, c, ckappa, f, h, href, pairwise, s3_scale, N, L, Vol,
+                     Nglob, work, scal, finalize, Lb, Nbglob, alpha, init_off, bdry_off, step);
   return xw_launch_status();
 }
 
@@ -375,29 +411,42 @@ extern "C" int xw_gen_cotangents(const double* u, const double* v, const double*
 }
 
 extern "C" int xw_losses(double* scal, int L, int Lb, double Vol, double Nglob, double Nbglob, double alpha,
-                         long long* step, void* stream) {
+                         double init_off, double bdry_off, long long* step, void* stream) {
   if (!scal || L <= 0 || Lb <= 0) return XW_E_ARG;
-  hipLaunchKernelGGL(k_losses, dim3(1), dim3(64), 0, (hipStream_t)stream, scal, L, Lb, Vol, Nglob, Nbglob, alpha, step);
+  hipLaunchKernelGGL(k_losses, dim3(1), dim3(64), 0, (hipStream_t)stream, scal, L, Lb, Vol, Nglob, Nbglob, alpha, init_off,
+                     bdry_off, step);
+  return xw_launch_status();
+}
+
+extern "C" int xw_pair_fold(double* scal, double Vol, double Nglob, void* stream) {
+  if (!scal || Nglob <= 0) return XW_E_ARG;
+  hipLaunchKernelGGL(k_pair_fold, dim3(1), dim3(64), 0, (hipStream_t)stream, scal, Vol / Nglob);
   return xw_launch_status();
 }
 
 extern "C" int xw_disc_cotangent(const double* u, const double* v, const double* w, int w_per_point, const double* c,
                                  double ckappa, const double* f, const double* h, int N, int L, double Vol, double Nglob,
-                                 double pollution, const double* scal_in, double* vbar, void* stream) {
+                                 double pollution, double s3_scale, const double* scal_in, double* vbar, void* stream) {
   if (!u || !v || !w || !f || !h || !scal_in || !vbar || N <= 0 || L <= 0) return XW_E_ARG;
   hipLaunchKernelGGL(k_disc_cot, dim3(blocks_for((long)N * L, 256, 2048)), dim3(256), 0, (hipStream_t)stream, u, v, w,
-                     w_per_point, c, ckappa, f, h, N, L, Vol, Nglob, pollution, scal_in, vbar);
+                     w_per_point, c, ckappa, f, h, N, L, Vol, Nglob, pollution, s3_scale, scal_in, vbar);
   return xw_launch_status();
 }
 
 extern "C" int xw_adam(double* param, const double* gslabA, int nA, const double* gextraA, const double* gslabB, int nB,
                        const double* gextraB, const double* scal, double* m, double* v, long long* step, int bump_step,
-                       int P, double lr, double beta1, double beta2, double eps, double* gsum_out, void* stream) {
+                       int P, double lr, double beta1, double beta2, double eps, double* gsum_out, int lag_lo, int lag_hi,
+                       int skip, long long* lag, void* stream) {
   // bump_step: 1 = this call advances the counter after the update; 0 = the counter was left alone (caller advances it
   // later);  -1 = the counter was ALREADY advanced for this update (xw_losses ran first), use it as is
+  // lag_lo..lag_hi: parameter range with its own step count *step - *lag (NULL / empty range: none); skip != 0: that
+  // range is left untouched by this update and *lag advances (torch's Adam skipping parameters without a gradient)
   if (!param || !m || !v || !step || P <= 0 || nA < 0 || nB < 0 || (nA > 0 && !gslabA) || (nB > 0 && !gslabB)) return XW_E_ARG;
+  if (lag_lo < 0 || lag_hi > P || (skip && (!lag || lag_hi <= lag_lo))) return XW_E_ARG;
   hipLaunchKernelGGL(k_adam, dim3((P + XW_ADAM_PARAMS - 1) / XW_ADAM_PARAMS), dim3(1024), 0, (hipStream_t)stream, param, gslabA, nA, gextraA, gslabB,
-                     nB, gextraB, scal, m, v, step, bump_step < 0 ? 1 : 0, P, lr, beta1, beta2, eps, gsum_out);
+                     nB, gextraB, scal, m, v, step, bump_step < 0 ? 1 : 0, P, lr, beta1, beta2, eps, gsum_out, lag_lo, lag_hi, skip,
+                     lag);
+  if (skip) hipLaunchKernelGGL(k_step_inc, dim3(1), dim3(1), 0, (hipStream_t)stream, lag);
   if (bump_step > 0) hipLaunchKernelGGL(k_step_inc, dim3(1), dim3(1), 0, (hipStream_t)stream, step);
   return xw_launch_status();
 }
@@ -436,8 +485,8 @@ extern "C" int xw_slab_sum(const double* gslab, int nslab, int P, int accumulate
   return xw_launch_status();
 }
 
-extern "C" int xw_abi_version(void) { return 20; }
-extern "C" int xw_reduce_work_size(void) { return 3 * 1024 + 8; }
+extern "C" int xw_abi_version(void) { return 21; }
+extern "C" int xw_reduce_work_size(void) { return 5 * 1024 + 8; }
 
 extern "C" int xw_supported_dims(char* buf, int buflen) {
   static const char s[] = "ode (H,K)=(20,10),(32,12), m=1..8; disc_fwd W=50,64 any q; disc_bwd W=50 (q=9 unrolled, any q from the record), W=64 (from the record), d<=126";

@@ -75,8 +75,8 @@ class Structure:
 class Group:
     """Device-resident data of one group of equal-length paths + every buffer its sub-steps need.  Buffers are allocated
     once and refilled in place by Engine.load_group(..., into=G), so captured HIP graphs stay valid across resampling."""
-    SAMPLE_FIELDS = ('t', 'tb', 'tpp', 'tpp0', 'xvT_pts', 'xT', 'xvT', 'xbT', 'start', 'ghT', 'h', 'f', 'w', 'wt', 'w0', 'gwx0T', 'start_b', 'g', 'X',
-                     'A0', 'B0')
+    SAMPLE_FIELDS = ('t', 'tb', 'tpp', 'tpp0', 'xvT_pts', 'xT', 'xvT', 'xbT', 'start', 'ghT', 'h', 'href', 'f', 'w', 'wt', 'w0', 'gwx0T',
+                     'start_b', 'g', 'X', 'A0', 'B0')
 
     def signature(self):
         return tuple((k, tuple(getattr(self, k).shape)) for k in self.SAMPLE_FIELDS if getattr(self, k, None) is not None)
@@ -106,7 +106,20 @@ class Engine:
         self.theta, self.phi = u_mod.blob, v_mod.blob
         self.Pu, self.Pv = self.theta.data.numel(), self.phi.data.numel()
         z = lambda n: torch.zeros(n, dtype=F64, device=device)  # noqa: E731
-        self.adam_u = dict(m=z(self.Pu), v=z(self.Pu), step=torch.zeros(1, dtype=torch.int64, device=device))
+        self.adam_u = dict(m=z(self.Pu), v=z(self.Pu), step=torch.zeros(1, dtype=torch.int64, device=device),
+                           lag=torch.zeros(1, dtype=torch.int64, device=device))
+        # Reference behaviour on the single-slice groups of the list domains (SURVEY A.4 / DESIGN 8 "Q8"), both on by default:
+        #  * NeuralODE.forward returns [N,1] instead of [N,1,1] on a single-slice group at T0 (src/model.py:89-91) and the loss
+        #    then broadcasts [N] against [N,1] into [N,N] tables over all PAIRS of paths (src/loss.py:65,70,79,84): reproduced
+        #    in factorised O(N) form (load_group / xw_weak_partials pairwise).  XW_ELEMENTWISE_SINGLE_SLICE=1: the
+        #    elementwise expressions instead (what the formulas mean; NOT what the reference computes).
+        #  * such a group never integrates the ODE, so the field's parameters get no gradient; after zero_grad() (None on
+        #    torch >= 2.0) Adam SKIPS them -- no moment decay, no step count -- until a group of the sub-iteration has taken an
+        #    ODE step: the field range of the blob keeps its own step count (xw_adam lag / skip).
+        self.pairwise_single_slice = os.environ.get('XW_ELEMENTWISE_SINGLE_SLICE', '0') != '1'
+        self.adam_skips_untouched = os.environ.get('XW_ADAM_NO_SKIP', '0') != '1'
+        self.field_range = (self.theta.slots[6][0], self.theta.slots[-2][0])      # Win .. Wo.b (nets._u_slots order)
+        self._field_touched = False
         self.adam_v = dict(m=z(self.Pv), v=z(self.Pv), step=torch.zeros(1, dtype=torch.int64, device=device))
         self.grad_u, self.grad_v = z(self.Pu), z(self.Pv)   # the gradient Adam saw in the last sub-step
         # generator exchange buffer [sum of A slabs | sum of B slabs | scal]: ONE all-reduce per generator sub-step
@@ -310,6 +323,7 @@ class Engine:
             S['xvT_pts'] = S['xvT'].unsqueeze(1).expand(d, L, N).reshape(d, L * N).contiguous()
         # start values and their x-gradient (the h -> y0 path of nabla_x u, src/model.py:95)
         if tab is not None:                   # (tabulate_sample: evaluated once for all groups of the sample)
+            starts_T0 = bool(tab['starts_T0'])
             S['start'] = tab['start'].to(dev).to(F64).reshape(-1).contiguous()
             S['ghT'] = tab['gh'].to(dev).to(F64).t().contiguous()
             S['h'] = tab['h'].to(dev).to(F64).reshape(-1).contiguous()
@@ -340,13 +354,14 @@ class Engine:
         S['w0'] = w[:, 0].detach().to(dev).to(F64).contiguous()
         S['gwx0T'] = gw[:, 0, 1:].to(dev).to(F64).t().contiguous()
         S['xbT'] = S['start_b'] = S['g'] = S['tb'] = None
-        Lb, same_grid = 0, True
+        Lb, same_grid, b_T0 = 0, True, False
         if BX is not None:
             Lb = BX.shape[1]
             S['tb'] = BX[0, :, 0].to(dev).to(F64).contiguous()
             same_grid = Lb == L and (shared_grid_t0 is not None or bool(torch.equal(S['tb'], S['t'])))
             S['xbT'] = BX[:, 0, 1:].to(dev).to(F64).t().contiguous()
             if tab is not None:
+                b_T0 = bool(tab['b_T0'])
                 S['start_b'] = tab['start_b'].to(dev).to(F64).reshape(-1).contiguous()
                 S['g'] = _to_LN(tab['g'], dev)
             else:
@@ -368,9 +383,37 @@ class Engine:
         vol = float(domain.V())
         nglob = float(n_glob if n_glob is not None else N)
         nbglob = float(nb_glob if nb_glob is not None else max(Nb, 1))
+        # single-slice groups at T0: the reference's [N,N] broadcasts in factorised form.  The sums over m of the pair
+        # tables only involve the SAMPLE (h, f, g), so they are formed here, once per sample:
+        #   mean_nm (u_n - h_m)^2 = mean_n (u_n - mean h)^2 + var h          (src/loss.py:79; :84 likewise with g)
+        #   sum_mn f_m phi_n      = N sum_n mean(f) phi_n                    (src/loss.py:70)
+        pair_i = self.pairwise_single_slice and L == 1 and starts_T0
+        pair_b = self.pairwise_single_slice and Nb > 0 and Lb == 1 and b_T0
+        S['href'] = None
+        init_off = bdry_off = 0.0
+        if pair_i and not st.b_zero:
+            raise XnwanError('func_b != 0 on a single-slice group at T0: the reference sums that term with np.sum over a list of '
+                             'tensors (src/loss.py:69), whose result on its [N,N] broadcast depends on the numpy version -- not '
+                             'reproducible; set XW_ELEMENTWISE_SINGLE_SLICE=1 for the elementwise form')
+        if pair_i or pair_b:
+            zero = torch.zeros((), dtype=F64, device=dev)
+            gsum, gsq = (S['g'].sum(), (S['g'] ** 2).sum()) if pair_b else (zero, zero)
+            stats = torch.stack([S['h'].sum(), (S['h'] ** 2).sum(), S['f'].sum(), gsum, gsq]).contiguous()
+            if self.world is not None:
+                self.world.all_reduce(stats)                 # the means are over ALL paths of the group, not this rank's share
+            sh, shh, sf, sg, sgg = stats.tolist()
+            if pair_i:
+                S['href'] = torch.full((N,), sh / nglob, dtype=F64, device=dev)
+                S['f'] = torch.full_like(S['f'], sf / nglob)
+                init_off = shh / nglob - (sh / nglob) ** 2
+            if pair_b:
+                S['g'] = torch.full_like(S['g'], sg / nbglob)
+                bdry_off = sgg / nbglob - (sg / nbglob) ** 2
+        pair_state = dict(pair_i=pair_i, pair_b=pair_b, init_off=init_off, bdry_off=bdry_off, s3_scale=nglob if pair_i else 1.0)
         if into is not None:
             G = into
-            same = (G.N, G.L, G.Nb, G.Lb, G.same_grid, G.Vol, G.Nglob, G.Nbglob) == (N, L, Nb, Lb, same_grid, vol, nglob, nbglob) and all(
+            same = (G.N, G.L, G.Nb, G.Lb, G.same_grid, G.Vol, G.Nglob, G.Nbglob, G.pair_i, G.pair_b) == (
+                N, L, Nb, Lb, same_grid, vol, nglob, nbglob, pair_i, pair_b) and all(
                 (getattr(G, k) is None) == (S[k] is None) and (S[k] is None or getattr(G, k).shape == S[k].shape)
                 for k in Group.SAMPLE_FIELDS)
             if same:
@@ -378,6 +421,7 @@ class Engine:
                     if S[k] is not None:
                         getattr(G, k).copy_(S[k])
                 G.domain = domain
+                G.__dict__.update(pair_state)
                 G.sample_version += 1
                 return G
         G = Group()
@@ -385,6 +429,7 @@ class Engine:
             setattr(G, k, S[k])
         G.domain, G.N, G.L, G.Nb, G.Vol, G.Nglob, G.Nbglob = domain, N, L, Nb, vol, nglob, nbglob
         G.Lb, G.same_grid = Lb, same_grid
+        G.__dict__.update(pair_state)
         # work buffers
         e = lambda *s_: torch.empty(*s_, dtype=F64, device=dev)  # noqa: E731
         H = self.H
@@ -480,15 +525,16 @@ class Engine:
         counter (`adam_state`); with several GPUs that is done by KN.losses after the all-reduce."""
         fin = None
         if self.world is None and adam_state is not None:
-            fin = dict(Lb=G.Lb, Nbglob=G.Nbglob, alpha=self.alpha, step=adam_state['step'])
+            fin = dict(Lb=G.Lb, Nbglob=G.Nbglob, alpha=self.alpha, step=adam_state['step'], init_off=G.init_off, bdry_off=G.bdry_off)
+        pair = dict(href=G.href, s3_scale=G.s3_scale) if G.pair_i else None
         if G.A0 is None and G.B0 is None:
             KN.weak_partials(G.u, G.v, G.vt, G.w, G.f, G.h, G.Vol, G.Nglob, self.scal, G.work_i, c=G.c, ckappa=G.ck, wt=G.wt,
-                             contract=dict(gx=G.gx, gs=G.gs, ghT=G.ghT, gxv=G.gxv, w0=G.w0, gwx0T=G.gwx0T), finalize=fin)
+                             contract=dict(gx=G.gx, gs=G.gs, ghT=G.ghT, gxv=G.gxv, w0=G.w0, gwx0T=G.gwx0T), finalize=fin, pair=pair)
             return
         # general a_ij / b_i: the l = 0 contraction as one streaming kernel over the tabulated slice (graph-capturable)
         KN.weak_contract_general(G.A0, G.B0, G.gx, G.gs, G.ghT, G.gxv, G.w0, G.gwx0T, G.v[0], G.s3x)
         KN.weak_partials(G.u, G.v, G.vt, G.w, G.f, G.h, G.Vol, G.Nglob, self.scal, G.work_i, s3x=G.s3x, c=G.c, ckappa=G.ck,
-                         wt=G.wt, finalize=fin)
+                         wt=G.wt, finalize=fin, pair=pair)
 
     # ------------------------------------------------------------------------------------------------------------
     # generator sub-step (src/training.py:127-138)
@@ -526,7 +572,8 @@ class Engine:
             # launch and two [L, N] buffers fewer per sub-step; the cycle does not change (1885 steps/s either way): the
             # sweeps start 26 us earlier, next to the test network, whose launch then lasts that much longer -- the first
             # phase of the sub-step is bound by SIMD time, not by this chain.
-            res_A = dict(u=G.u, ref=G.h, coef=2.0 * self.alpha / G.Nglob, base=self.pollution, first_only=True)
+            # (pairwise group: the initial penalty is the mean over all PAIRS (u_n - h_m)^2, whose u-gradient is 2 (u_n - mean h) / N)
+            res_A = dict(u=G.u, ref=G.href if G.pair_i else G.h, coef=2.0 * self.alpha / G.Nglob, base=self.pollution, first_only=True)
             res_b = dict(u=G.ub, ref=G.g, coef=2.0 * self.alpha / (G.Nbglob * G.Lb), base=0.0, first_only=False) if G.Nb else None
             e_b = None
             if G.Nb:
@@ -551,7 +598,7 @@ class Engine:
         # cotangent B = dI/du is a pointwise product of what the two forward passes wrote: sweep B forms it on the fly too
         # (XwOdeBwdJob.res_first_only = 2) and starts right behind the test network: one launch fewer on the critical chain
         # test network -> sweep B -> Adam (0.5063 -> 0.5034 ms per generator sub-step in the same run)
-        res_B = dict(u=G.u, ref=G.v, coef=G.Vol / G.Nglob / G.L, base=G.Vol / G.Nglob,
+        res_B = dict(u=G.u, ref=G.v, coef=G.Vol / G.Nglob / G.L * G.s3_scale, base=G.Vol / G.Nglob,
                      weak=dict(w=G.w, c=G.c, cp=G.cp, ckappa=G.ck))
         KN.ode_bwd_multi([dict(self._job(G, 'i', None, G.slabB), res=res_B)], G.t, th, *M, want_x=False, want_params=True,
                          adjoint=self.adjoint)
@@ -565,6 +612,8 @@ class Engine:
     def begin_substep(self, which, accumulate):
         """start of a generator ('u') / discriminator ('v') sub-iteration over several groups: zero the carried gradient"""
         name, P = ('accum_u', self.Pu) if which == 'u' else ('accum_v', self.Pv)
+        if which == 'u':
+            self._field_touched = False
         if not accumulate:
             setattr(self, name, None)
         elif getattr(self, name) is None:
@@ -575,17 +624,25 @@ class Engine:
     def _gen_back(self, G):
         lr, st = self.config['u_rate'], self.adam_u
         acc = self.accum_u
+        # has any group of this sub-iteration integrated the ODE yet?  (no: the field's parameters have no gradient, Adam
+        # skips them -- Engine.__init__)
+        touched = G.L > 1 or (G.Nb > 0 and G.Lb > 1)
+        self._field_touched = touched or (acc is not None and self._field_touched)
+        lag = dict(lag=st['lag'], lag_range=self.field_range, skip=self.adam_skips_untouched and not self._field_touched)
         if self.world is not None:     # (single GPU: loss values and counter were done by the reduction launch, _contract)
-            KN.losses(self.scal, G.L, G.Lb, G.Vol, G.Nglob, G.Nbglob, self.alpha, step=st['step'])
+            if G.pair_i:
+                KN.pair_fold(self.scal, G.Vol, G.Nglob)
+            KN.losses(self.scal, G.L, G.Lb, G.Vol, G.Nglob, G.Nbglob, self.alpha, step=st['step'], init_off=G.init_off,
+                      bdry_off=G.bdry_off)
         if self.world is None:
             KN.adam(self.theta.data, G.slabA, st['m'], st['v'], st['step'], lr, gslabB=G.slabB, scal=self.scal,
-                    gextraA=acc, gsum_out=self.grad_u, bump_step=-1)
+                    gextraA=acc, gsum_out=self.grad_u, bump_step=-1, **lag)
         else:
             P = self.Pu
             if acc is not None:
                 self.pack_u[:P].add_(acc)
             KN.adam(self.theta.data, None, st['m'], st['v'], st['step'], lr, gextraA=self.pack_u[:P],
-                    gextraB=self.pack_u[P:2 * P], scal=self.scal, gsum_out=self.grad_u, bump_step=-1)
+                    gextraB=self.pack_u[P:2 * P], scal=self.scal, gsum_out=self.grad_u, bump_step=-1, **lag)
         if acc is not None:
             acc.copy_(self.grad_u)
 
@@ -653,7 +710,7 @@ class Engine:
 
     def _disc_mid(self, G):
         KN.disc_cotangent(G.u, G.v, G.w, G.f, G.h, G.Vol, G.Nglob, self.scal, G.vbar, c=G.c, ckappa=G.ck,
-                          pollution=self.pollution)
+                          pollution=self.pollution, s3_scale=G.s3_scale)
         act = G.vact if getattr(G, 'vact_valid', False) else None
         if G.tpp is None:
             KN.disc_bwd(G.xvT, G.t, self.phi.data, G.vbar, self.W, self.q, gslab=G.slab_v, act=act)
@@ -679,6 +736,13 @@ class Engine:
         if acc is not None:
             acc.copy_(self.grad_v)
 
+    def _reduce_sums(self, G):
+        """several GPUs: the partial sums I, sum v^2, SSE (+ the two factors of a pairwise group's d(phi)/dt term, folded
+        into I once they are global)"""
+        self.world.all_reduce(self.scal[0:9])
+        if G.pair_i:
+            KN.pair_fold(self.scal, G.Vol, G.Nglob)
+
     def _disc_all(self, G):
         self._disc_front(G)
         self._disc_mid(G)
@@ -687,7 +751,7 @@ class Engine:
     def _disc_all_dist(self, G):
         """several GPUs, capturable exchanges: the whole discriminator sub-step with its two all-reduces as one graph"""
         self._disc_front(G)
-        self.world.all_reduce(self.scal[0:4])
+        self._reduce_sums(G)
         self._disc_mid_packed(G)
         self.world.all_reduce(self.grad_v)
         self._disc_back(G)
@@ -703,7 +767,7 @@ class Engine:
             self._run(G, 'disc_dist' + sfx, self._disc_all_dist)
             return
         self._run(G, 'disc_front' + sfx, self._disc_front)
-        self.world.all_reduce(self.scal[0:4])                     # I and sum v^2 must be global before the cotangent
+        self._reduce_sums(G)                                      # I and sum v^2 must be global before the cotangent
         self._run(G, 'disc_mid' + ('_act' if getattr(G, 'vact_valid', False) else ''), self._disc_mid_packed)
         self.world.all_reduce(self.grad_v)
         self._run(G, 'disc_back', self._disc_back)
@@ -711,7 +775,9 @@ class Engine:
     # ------------------------------------------------------------------------------------------------------------
     def _run(self, G, key, fn):
         """execute fn(G) eagerly, or capture it once into a HIP graph (per group and segment) and replay it"""
-        capturable = (self.use_graphs and self.accum_u is None and self.accum_v is None and getattr(G, 'persistent', True))
+        # (a pairwise group carries per-sample host constants -- the variance offsets -- into its launches: never captured)
+        capturable = (self.use_graphs and self.accum_u is None and self.accum_v is None and getattr(G, 'persistent', True)
+                      and not (G.pair_i or G.pair_b))
         g = G.graphs.get(key) if capturable else False
         if g is False:                            # not capturable, or capture of THIS segment was refused before
             if not getattr(G, 'persistent', True) and self.use_streams:

@@ -318,11 +318,13 @@ def reduce_work_size():
 
 
 def weak_partials(u, v, vt, w, f, h, Vol, Nglob, scal, work, s3x=None, contract=None, c=None, ckappa=0.0, wt=None,
-                  finalize=None):
+                  finalize=None, pair=None):
     """partial sums of I, sum v^2, SSE_init.  Either s3x[N] (pre-contracted gradient term) or contract = dict(gx, gs, ghT,
     gxv, w0, gwx0T) for the in-kernel contraction with a = identity, b = 0.
-    finalize = dict(Lb, Nbglob, alpha, step) (single GPU): also turn the sums into the loss values and advance `step`,
-    exactly what losses() does."""
+    finalize = dict(Lb, Nbglob, alpha, step[, init_off, bdry_off]) (single GPU): also turn the sums into the loss values
+    and advance `step`, exactly what losses() does.
+    pair = dict(href[N], s3_scale) (L == 1 only): the reference's [N,N] broadcast on a single-slice T0 group, factorised
+    (include/xnwan.h); f must then hold mean(f) in every entry."""
     _need_gpu()
     L, N = u.shape
     for name, a in (('u', u), ('v', v), ('vt', vt), ('f', f)):
@@ -333,6 +335,10 @@ def weak_partials(u, v, vt, w, f, h, Vol, Nglob, scal, work, s3x=None, contract=
     _chk(work, F64, (reduce_work_size(),), 'work')
     fz = finalize or {}
     _chk(fz.get('step'), torch.int64, (1,), 'step')
+    pr = pair or {}
+    _chk(pr.get('href'), F64, (N,), 'href')
+    if pair is not None and L != 1:
+        raise XnwanError('the pairwise form only exists for single-slice groups (L == 1)')
     k, d = {}, 0
     if s3x is None:
         k = contract
@@ -342,10 +348,19 @@ def weak_partials(u, v, vt, w, f, h, Vol, Nglob, scal, work, s3x=None, contract=
         _chk(k['gs'], F64, (N,), 'gs'); _chk(k['w0'], F64, (N,), 'w0')
     check(lib.xw_weak_partials(_p(u), _p(v), _p(vt), _p(w), per_point, _p(wt), _p(s3x), _p(k.get('gx')), _p(k.get('gs')),
                                _p(k.get('ghT')), _p(k.get('gxv')), _p(k.get('w0')), _p(k.get('gwx0T')), d, _p(c),
-                               float(ckappa), _p(f), _p(h), N, L, float(Vol), float(Nglob), _p(work), _p(scal),
+                               float(ckappa), _p(f), _p(h), _p(pr.get('href')), 0 if pair is None else 1,
+                               float(pr.get('s3_scale', 1.0)), N, L, float(Vol), float(Nglob), _p(work), _p(scal),
                                0 if finalize is None else 1, max(int(fz.get('Lb', 1)), 1), float(fz.get('Nbglob', 1.0)),
-                               float(fz.get('alpha', 0.0)), _p(fz.get('step')), _stream()),
+                               float(fz.get('alpha', 0.0)), float(fz.get('init_off', 0.0)), float(fz.get('bdry_off', 0.0)),
+                               _p(fz.get('step')), _stream()),
           'xw_weak_partials')
+
+
+def pair_fold(scal, Vol, Nglob):
+    """scal[0] -= (Vol / Nglob) scal[7] scal[8] (several GPUs: after the all-reduce of the partial sums of a pairwise group)"""
+    _need_gpu()
+    _chk(scal, F64, (16,), 'scal')
+    check(lib.xw_pair_fold(_p(scal), float(Vol), float(Nglob), _stream()), 'xw_pair_fold')
 
 
 def weak_contract_general(A0, B0, gx, gs, ghT, gxv, w0, gwx0T, v0, s3x):
@@ -398,7 +413,7 @@ def gen_cotangents(u, v, w, h, Vol, Nglob, alpha, ubarA, ubarB, c=None, cp=None,
           'xw_gen_cotangents')
 
 
-def disc_cotangent(u, v, w, f, h, Vol, Nglob, scal, vbar, c=None, ckappa=0.0, pollution=1.0):
+def disc_cotangent(u, v, w, f, h, Vol, Nglob, scal, vbar, c=None, ckappa=0.0, pollution=1.0, s3_scale=1.0):
     _need_gpu()
     L, N = u.shape
     per_point = 1 if w.dim() == 2 else 0
@@ -406,20 +421,22 @@ def disc_cotangent(u, v, w, f, h, Vol, Nglob, scal, vbar, c=None, ckappa=0.0, po
     _chk(c, F64, (L, N), 'c'); _chk(f, F64, (L, N), 'f'); _chk(h, F64, (N,), 'h'); _chk(vbar, F64, (L, N), 'vbar')
     _chk(scal, F64, (16,), 'scal')
     check(lib.xw_disc_cotangent(_p(u), _p(v), _p(w), per_point, _p(c), float(ckappa), _p(f), _p(h), N, L, float(Vol),
-                                float(Nglob), float(pollution), _p(scal), _p(vbar), _stream()), 'xw_disc_cotangent')
+                                float(Nglob), float(pollution), float(s3_scale), _p(scal), _p(vbar), _stream()), 'xw_disc_cotangent')
 
 
-def losses(scal, L, Lb, Vol, Nglob, Nbglob, alpha, step=None):
+def losses(scal, L, Lb, Vol, Nglob, Nbglob, alpha, step=None, init_off=0.0, bdry_off=0.0):
     """loss values from the partial sums; also increments `step` when given (pair with adam(..., bump_step=False))"""
     _need_gpu()
     _chk(scal, F64, (16,), 'scal'); _chk(step, torch.int64, (1,), 'step')
-    check(lib.xw_losses(_p(scal), L, max(int(Lb), 1), float(Vol), float(Nglob), float(Nbglob), float(alpha), _p(step), _stream()),
-          'xw_losses')
+    check(lib.xw_losses(_p(scal), L, max(int(Lb), 1), float(Vol), float(Nglob), float(Nbglob), float(alpha), float(init_off),
+                        float(bdry_off), _p(step), _stream()), 'xw_losses')
 
 
 def adam(param, gslabA, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, gextraA=None, gslabB=None, gextraB=None,
-         scal=None, gsum_out=None, bump_step=True):
-    """param -= Adam(g),  g = gextraA + sum(gslabA) + coefB (gextraB + sum(gslabB)),  coefB = 2 / scal[0] if scal else 1"""
+         scal=None, gsum_out=None, bump_step=True, lag=None, lag_range=(0, 0), skip=False):
+    """param -= Adam(g),  g = gextraA + sum(gslabA) + coefB (gextraB + sum(gslabB)),  coefB = 2 / scal[0] if scal else 1
+    lag (device int64[1]) / lag_range: parameters [lo, hi) count their own steps, step - lag; skip: leave that range
+    untouched this time and advance lag (torch's Adam skipping parameters whose .grad is None)"""
     _need_gpu()
     P = param.shape[0]
     _chk(param, F64, (P,), 'param'); _chk(m, F64, (P,), 'm'); _chk(v, F64, (P,), 'v'); _chk(step, torch.int64, (1,), 'step')
@@ -431,10 +448,12 @@ def adam(param, gslabA, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, gextra
         nB = gslabB.shape[0]
         _chk(gslabB, F64, (nB, P), 'gslabB')
     _chk(gextraA, F64, (P,), 'gextraA'); _chk(gextraB, F64, (P,), 'gextraB'); _chk(gsum_out, F64, (P,), 'gsum_out')
-    _chk(scal, F64, (16,), 'scal')
+    _chk(scal, F64, (16,), 'scal'); _chk(lag, torch.int64, (1,), 'lag')
+    lo, hi = (int(lag_range[0]), int(lag_range[1])) if lag is not None else (0, 0)
     check(lib.xw_adam(_p(param), _p(gslabA), nA, _p(gextraA), _p(gslabB), nB, _p(gextraB), _p(scal), _p(m), _p(v), _p(step),
                       (1 if bump_step is True else 0 if bump_step is False else int(bump_step)), P,
-                      float(lr), float(beta1), float(beta2), float(eps), _p(gsum_out), _stream()), 'xw_adam')
+                      float(lr), float(beta1), float(beta2), float(eps), _p(gsum_out), lo, hi, 1 if skip else 0, _p(lag),
+                      _stream()), 'xw_adam')
 
 
 def slab_sum2(gA, outA, gB, outB):

@@ -110,13 +110,17 @@ class FusedAdam:
             self.on_step()
 
     def state_dict(self):
-        return {'m': self.state['m'].clone(), 'v': self.state['v'].clone(), 'step': int(self.state['step'].item()),
-                'lr': self.lr}
+        sd = {'m': self.state['m'].clone(), 'v': self.state['v'].clone(), 'step': int(self.state['step'].item()), 'lr': self.lr}
+        if 'lag' in self.state:            # (u_theta: how many updates skipped the field's parameters, engine.Engine.__init__)
+            sd['lag'] = int(self.state['lag'].item())
+        return sd
 
     def load_state_dict(self, sd):
         self.state['m'].copy_(sd['m'])
         self.state['v'].copy_(sd['v'])
         self.state['step'].fill_(sd['step'])
+        if 'lag' in self.state:
+            self.state['lag'].fill_(sd.get('lag', 0))
 
 
 class NODE_WAN_solver:
