@@ -231,11 +231,14 @@ int xw_slab_sum2(const double* gA, int nA, double* outA, const double* gB, int n
  * generator sub-step ONE packed buffer [J^T ubarA | J^T ubarB | partial sums] is summed over the ranks, per
  * discriminator sub-step the partial sums (I, sum v^2) and then the packed gradient (dist.py).  RCCL over xGMI, bound
  * with dlopen (the library loads without it; these four calls then return XW_E_COMM).
+ *   xw_comm_available : 0 if RCCL could be bound in this process, XW_E_COMM if not; NOT collective -- the ranks agree on
+ *                       it before any of them enters the collective xw_comm_init
  *   xw_comm_unique_id : rank 0 creates the 128-byte rendezvous id; the host side carries it to the other ranks
  *   xw_comm_init      : collective over all ranks, on the caller's current HIP device; *comm is an opaque handle
  *   xw_allreduce      : in-place float64 sum of buf[count] over the ranks; only enqueues on `stream` (graph-capture
  *                       safe: a sub-step and its exchange replay as one HIP graph)
  *   xw_comm_destroy   : releases the handle */
+int xw_comm_available(void);
 int xw_comm_unique_id(unsigned char* id128);
 int xw_comm_init(const unsigned char* id128, int nranks, int rank, void** comm);
 int xw_allreduce(double* buf, int count, void* comm, void* stream);

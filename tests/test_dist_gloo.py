@@ -149,3 +149,115 @@ def test_rank_local_sampling_draws_only_the_shard(tmp_path):
             per_axis = on_face.sum(0).double() / r['nb']
             assert float(per_axis.min()) > 0.08 and float(per_axis.max()) < 0.35      # ~ 1 / d each
     assert not torch.equal(r0[0]['xu'], r0[1]['xu'])       # a new draw every iteration
+
+
+def _fallback_worker(rank, size, port, out_dir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(size), LOCAL_RANK=str(rank))
+    import warnings
+    from xnode_wan_pde_solver_amd import dist as xdist, _lib
+    torch.distributed.init_process_group('gloo')
+    calls = {'init': 0}
+
+    class Lib:                                             # the C ABI as one rank without RCCL would see it
+        def xw_comm_available(self):
+            return -4 if rank == 1 else 0
+
+        def xw_comm_unique_id(self, buf):
+            return 0
+
+        def xw_comm_init(self, *a):
+            calls['init'] += 1                             # collective in the real library: entering it alone = a hang
+            return 0
+
+        def xw_comm_destroy(self, c):
+            return 0
+    real = _lib.lib
+    _lib.lib = Lib()
+    try:
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter('always')
+            world = xdist.World(native=True)
+    finally:
+        _lib.lib = real
+    t = torch.full((3,), float(rank + 1), dtype=torch.float64)
+    world.all_reduce(t)                                    # the torch.distributed path still works
+    torch.save(dict(comm=world.comm is not None, capturable=world.capturable, init_calls=calls['init'], warned=len(w), sum=t.clone()),
+               os.path.join(out_dir, 'fb%d.pt' % rank))
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_a_rank_without_rccl_sends_every_rank_to_the_fallback_before_the_collective_init(tmp_path):
+    """ncclCommInitRank is collective: the ranks agree on `xw_comm_available` first; if one of them cannot bind RCCL NONE of
+    them enters xw_comm_init (the others would block in its bootstrap), all fall back with a warning"""
+    size = 2
+    mp.spawn(_fallback_worker, args=(size, _free_port(), str(tmp_path)), nprocs=size, join=True)
+    for r in range(size):
+        res = torch.load(tmp_path / ('fb%d.pt' % r))
+        assert res['comm'] is False and res['capturable'] is False and res['init_calls'] == 0 and res['warned'] >= 1
+        assert torch.equal(res['sum'], torch.full((3,), 3.0, dtype=torch.float64))
+
+
+def _pairwise_worker(rank, size, port, out_dir, golden_dir):
+    """a single-slice T0 group of a ball domain, sharded: what engine.Engine does per rank (factorised pair sums with
+    GLOBAL means, the two factors of the d(phi)/dt term reduced before they are multiplied) against the oracle's literal
+    [N,N] broadcast on the whole group"""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(size), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    import json
+    import configs.Ex4_3_funcs as F
+    from oracle import refspec as R
+    from xnode_wan_pde_solver_amd import dist as xdist
+    world, _ = xdist.init_from_env('gloo')
+    z = np.load(os.path.join(golden_dir, 'ref_cone_ex43_d10_groups.npz'))
+    params = json.loads(str(z['params_json']))
+    params.pop('funcs')
+    funcs = dict(h=F.func_h, f=F.func_f, g=F.func_g, a=F.func_a, b=F.func_b, c=F.func_c)
+    config, setup = R.split_params(params)
+    torch.manual_seed(int(z['seed']))
+    torch.Tensor(setup['N_t']).uniform_(setup['T0'], setup['T'])
+    theta, phi = R.init_parameters(config, setup)
+    domain = R.Ball(params['domain'], setup['shape_param'], setup['dim'], setup['T0'], setup['T'])
+    X, BX = torch.from_numpy(z['interior/0']), torch.from_numpy(z['boundary/0'])
+    assert X.shape[1] == 1 and BX.shape[1] == 1
+    ref = R.group_forward(theta, phi, config, setup, domain, funcs, X, X, BX, True)
+    Xs, XVs, BXs, n, nb = world.shard_group(X, X, BX)
+    # shard-local quantities (oracle arithmetic on the shard, elementwise shapes)
+    Xl = Xs.clone().requires_grad_(True)
+    XVl = XVs.clone().requires_grad_(True)
+    u = R.u_net(theta, config, Xl, funcs['h'](Xl[:, 0, :]))[:, 0]
+    v = R.v_net(phi, config, XVl)[:, 0]
+    w = domain.func_w(XVl)[:, 0]
+    du = torch.autograd.grad(u.sum(), Xl)[0][:, 0, 1:]
+    dphi = torch.autograd.grad((v * w).sum(), XVl)[0][:, 0, :]
+    h, f = funcs['h'](Xs[:, 0, :]), funcs['f'](Xs)[:, 0]
+    ub = R.u_net(theta, config, BXs, funcs['h'](BXs[:, 0, :]))[:, 0]
+    g = funcs['g'](BXs)[:, 0]
+    stats = torch.stack([h.sum(), (h ** 2).sum(), f.sum(), g.sum(), (g ** 2).sum()]).detach()
+    world.all_reduce(stats)                                # Engine.load_group: the means are over the whole group
+    hbar, fbar, gbar = stats[0] / n, stats[2] / n, stats[3] / nb
+    var_h, var_g = stats[1] / n - hbar ** 2, stats[4] / nb - gbar ** 2
+    V = domain.V()
+    s31 = (dphi[:, 1:] * du).sum(1)                        # a = identity
+    cu = -u                                                # Ex4_3: c = -u
+    part = torch.stack([(V / n * (u * v - h * v) + (V / n) * n * (s31 + cu * u * v * w + fbar * v * w)).sum(), (v ** 2).sum(),
+                        ((u - hbar) ** 2).sum(), ((ub - gbar) ** 2).sum(), torch.zeros(()), torch.zeros(()), torch.zeros(()),
+                        u.sum(), dphi[:, 0].sum()]).detach().to(torch.float64)
+    world.all_reduce(part)                                 # Engine._reduce_sums: scal[0:9]
+    I = part[0] - (V / n) * part[7] * part[8]              # xw_pair_fold
+    init = part[2] / n + var_h
+    bdry = part[3] / nb + var_g
+    res = dict(I=(float(I), float(ref['I'])), init=(float(init), float(ref['init'])), bdry=(float(bdry), float(ref['bdry'])),
+               S=(float(part[1]), float((ref['v3'] ** 2).sum())))
+    torch.save(res, os.path.join(out_dir, 'pw%d.pt' % rank))
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_sharded_pairwise_group_reproduces_the_broadcast_of_the_whole_group(tmp_path, golden_dir):
+    size = 2
+    mp.spawn(_pairwise_worker, args=(size, _free_port(), str(tmp_path), golden_dir), nprocs=size, join=True)
+    for r in range(size):
+        res = torch.load(tmp_path / ('pw%d.pt' % r))
+        for k, (got, want) in res.items():
+            np.testing.assert_allclose(got, want, rtol=1e-9, err_msg=k)

@@ -549,14 +549,22 @@ def test_general_contraction_kernel_forms():
     gx, ghT, gxv, gwx0T, gs, w0, v0 = r(d, N), r(d, N), r(d, N), r(d, N), r(N), r(N), r(N)
     Gx, dphi = gx + gs * ghT, w0 * gxv + v0 * gwx0T
     full, diag, const, B0 = r(d, d, N), r(d, N), r(d, d), r(d, N)
-    const.xw_constant = True
-    for A0, ref in ((None, (dphi * Gx).sum(0)), (const, torch.einsum('ij,in,jn->n', const, dphi, Gx)),
-                    (diag, (diag * dphi * Gx).sum(0)), (full, torch.einsum('ijn,in,jn->n', full, dphi, Gx))):
+    for amode, A0, ref in ((0, None, (dphi * Gx).sum(0)), (1, const, torch.einsum('ij,in,jn->n', const, dphi, Gx)),
+                           (2, diag, (diag * dphi * Gx).sum(0)), (3, full, torch.einsum('ijn,in,jn->n', full, dphi, Gx))):
         for B in (None, B0):
             out = torch.empty(N, dtype=torch.float64, device='cuda')
-            KN.weak_contract_general(A0, B, gx, gs, ghT, gxv, w0, gwx0T, v0, out)
+            KN.weak_contract_general(A0, amode, B, gx, gs, ghT, gxv, w0, gwx0T, v0, out)
             want = ref if B is None else ref + v0 * w0 * (B * Gx).sum(0)
             close(out, want, 1e-12, 1e-12)
+    # N == d: a constant [d,d] matrix and a diagonal [d,N] table have the same shape -- the form is stated, not guessed
+    sq, o1, o2 = r(d, d), torch.empty(d, dtype=torch.float64, device='cuda'), torch.empty(d, dtype=torch.float64, device='cuda')
+    a_ = [t_[:, :d].contiguous() for t_ in (gx, ghT, gxv, gwx0T)]
+    b_ = [t_[:d].contiguous() for t_ in (gs, w0, v0)]
+    KN.weak_contract_general(sq, 1, None, a_[0], b_[0], a_[1], a_[2], b_[1], a_[3], b_[2], o1)
+    KN.weak_contract_general(sq, 2, None, a_[0], b_[0], a_[1], a_[2], b_[1], a_[3], b_[2], o2)
+    Gs, ds = a_[0] + b_[0] * a_[1], b_[1] * a_[2] + b_[2] * a_[3]
+    close(o1, torch.einsum('ij,in,jn->n', sq, ds, Gs), 1e-12, 1e-12)
+    close(o2, (sq * ds * Gs).sum(0), 1e-12, 1e-12)
 
 
 def test_general_coefficients_are_captured_and_batched():

@@ -63,6 +63,7 @@ SIGNATURES = {
                 c_dbl, c_dbl, c_dbl, c_f64p, c_int, c_int, c_int, c_i64p, c_vp],
     'xw_slab_sum': [c_f64p, c_int, c_int, c_int, c_f64p, c_vp],
     'xw_slab_sum2': [c_f64p, c_int, c_f64p, c_f64p, c_int, c_f64p, c_int, c_vp],
+    'xw_comm_available': [],
     'xw_comm_unique_id': [ctypes.c_char_p],
     'xw_comm_init': [ctypes.c_char_p, c_int, c_int, ctypes.POINTER(c_vp)],
     'xw_allreduce': [c_f64p, c_int, c_vp, c_vp],

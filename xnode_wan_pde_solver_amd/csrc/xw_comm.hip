@@ -46,6 +46,11 @@ const Rccl& rccl() {
 const int kNcclFloat64 = 8, kNcclSum = 0;                  // ncclDataType_t::ncclFloat64, ncclRedOp_t::ncclSum (rccl.h)
 }  // namespace
 
+// 0 when RCCL could be bound in this process (all four symbols), XW_E_COMM otherwise.  Not collective: the host side asks
+// every rank BEFORE anyone enters xw_comm_init -- ncclCommInitRank is collective, a rank that returned early from it would
+// leave the others blocked in the bootstrap.
+extern "C" int xw_comm_available(void) { return rccl().ok ? 0 : XW_E_COMM; }
+
 extern "C" int xw_comm_unique_id(unsigned char* id128) {
   if (!id128) return XW_E_ARG;
   if (!rccl().ok) return XW_E_COMM;

@@ -41,23 +41,39 @@ class World:
             self._init_native()
 
     def _init_native(self):
-        from ._lib import lib, check
+        from ._lib import lib
+        import warnings
+        flag_dev = 'cuda' if dist.get_backend(self.group) == 'nccl' else 'cpu'
+
+        def all_agree(ok_here):
+            ok = torch.tensor([1 if ok_here else 0], device=flag_dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
+            return int(ok[0]) == 1
+        # ncclCommInitRank is COLLECTIVE: a rank that cannot bind RCCL would return from xw_comm_init at once and leave
+        # the others blocked in the bootstrap.  So the ranks first agree (non-collective probe + one MIN all-reduce through
+        # torch.distributed) that every one of them has the symbols, and only then enter it.
+        have = lib.xw_comm_available() == 0
+        if not all_agree(have):
+            warnings.warn('RCCL could not be bound on a rank (%s here): the exchanges go through torch.distributed between graph '
+                          'segments instead of RCCL calls inside the captured sub-steps' % ('available' if have else 'NOT available'),
+                          RuntimeWarning, stacklevel=3)
+            return
         ident = ctypes.create_string_buffer(128)
         have_id = self.rank == 0 and lib.xw_comm_unique_id(ident) == 0
         box = [ident.raw if have_id else None]
         dist.broadcast_object_list(box, src=0, group=self.group)
+        if box[0] is None:                # rank 0 could not create the id: every rank sees None and falls back together
+            warnings.warn('xw_comm_unique_id failed on rank 0: exchanges through torch.distributed', RuntimeWarning, stacklevel=3)
+            return
         comm = ctypes.c_void_p()
-        rc = lib.xw_comm_init(box[0], self.size, self.rank, ctypes.byref(comm)) if box[0] is not None else -4
-        # every rank must end up on the same path: agree on the outcome (a rank that could not load or initialise RCCL
-        # sends all of them to torch.distributed's all-reduce between graph segments, loudly, instead of failing the job)
-        ok = torch.tensor([1 if rc == 0 else 0], device='cuda' if dist.get_backend(self.group) == 'nccl' else 'cpu')
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
-        if int(ok[0]) == 1:
+        rc = lib.xw_comm_init(box[0], self.size, self.rank, ctypes.byref(comm))
+        # every rank must end up on the same path: agree on the outcome (a rank whose communicator failed AFTER joining the
+        # bootstrap sends all of them to torch.distributed's all-reduce between graph segments, loudly)
+        if all_agree(rc == 0):
             self.comm = comm
             return
         if rc == 0:
             lib.xw_comm_destroy(comm)
-        import warnings
         warnings.warn('xw_comm_init failed on a rank (status %d here): the exchanges go through torch.distributed between '
                       'graph segments instead of RCCL calls inside the captured sub-steps' % rc, RuntimeWarning, stacklevel=3)
 

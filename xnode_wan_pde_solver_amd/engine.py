@@ -159,7 +159,8 @@ class Engine:
     # tabulated: [d,d,N] instead of the reference's [d,d,N,L].
     # ------------------------------------------------------------------------------------------------------------
     def _tabulate_a(self, X1):
-        """a_ij(t_0, x_n) on the sample X1 [N,1,d+1].  ONE batched call of the user's callable with index tensors
+        """a_ij(t_0, x_n) on the sample X1 [N,1,d+1], returned as (table, amode) -- the form is stated explicitly
+        (xw_weak_contract_general's amode), never guessed from the shape: [d,d] and [d,N] coincide when N == d.  ONE batched call of the user's callable with index tensors
         i[d,1,1,1], j[1,d,1,1] when it is written with tensor operations (checked against scalar calls on three index
         pairs); otherwise the reference's d^2 scalar calls.  The table is then stored in the cheapest EXACT form: one
         [d,d] matrix if it does not vary over the sample, its diagonal [d,N] if every off-diagonal entry is exactly zero."""
@@ -185,12 +186,10 @@ class Engine:
         off = A.clone()
         off.diagonal(dim1=0, dim2=1).zero_()
         if bool(torch.all(A == A[:, :, :1])):
-            A = A[:, :, 0].contiguous()
-            A.xw_constant = True
-            return A
+            return A[:, :, 0].contiguous(), 1                          # [d, d]   one matrix for all points
         if bool(torch.all(off == 0)):
-            return A.diagonal(dim1=0, dim2=1).t().contiguous()         # [d, N]
-        return A.contiguous()
+            return A.diagonal(dim1=0, dim2=1).t().contiguous(), 2      # [d, N]   diagonal
+        return A.contiguous(), 3                                       # [d, d, N] full table
 
     def _tabulate_b(self, X1):
         d, dev, fb = self.d, self.dev, self.funcs['b']
@@ -265,19 +264,30 @@ class Engine:
         gw_all = torch.autograd.grad(w_all.sum(), XVp)[0] if w_all.requires_grad else torch.zeros_like(XVp)
         w_all, gw_all = w_all.detach().reshape(-1).split(cuts(XVs)), gw_all.reshape(-1, d + 1).split(cuts(XVs))
         # start values with their x-gradient: h for groups that start at T0, g for groups that start on the boundary
-        X0 = torch.cat([x[:, 0, :] for x in Xs], 0).clone().requires_grad_(True)
-        n0 = [x.shape[0] for x in Xs]
-        hv = self.funcs['h'](X0).reshape(-1)
-        gv = self.funcs['g'](X0.unsqueeze(1)).reshape(-1) if not all(at0) else hv
-        sel = torch.cat([torch.full((n,), a, dtype=torch.bool) for n, a in zip(n0, at0)]).to(X0.device)
-        start = torch.where(sel, hv, gv)
+        # (h is evaluated ONLY on the start points of the groups that start at T0 and g ONLY on those that start on the
+        #  boundary -- the combinations the per-group path evaluates: a callable that is not finite, or has no finite
+        #  gradient, where it is never asked must not leak a NaN into the other groups through a masked merge)
+        def starts(ts, flags):
+            P0 = torch.cat([x[:, 0, :] for x in ts], 0).clone().requires_grad_(True)
+            n = [x.shape[0] for x in ts]
+            sel = torch.cat([torch.full((k,), a, dtype=torch.bool) for k, a in zip(n, flags)]).to(P0.device)
+            i_h, i_g = torch.nonzero(sel).reshape(-1), torch.nonzero(~sel).reshape(-1)
+            hval = self.funcs['h'](P0.index_select(0, i_h)).reshape(-1) if i_h.numel() else None
+            gval = self.funcs['g'](P0.index_select(0, i_g).unsqueeze(1)).reshape(-1) if i_g.numel() else None
+            ref = hval if hval is not None else gval
+            val = torch.zeros(P0.shape[0], dtype=ref.dtype, device=P0.device)
+            if hval is not None:
+                val = val.index_copy(0, i_h, hval)
+            if gval is not None:
+                val = val.index_copy(0, i_g, gval.to(val.dtype))
+            return P0, n, val
+        X0, n0, start = starts(Xs, at0)
         gh = torch.autograd.grad(start.sum(), X0)[0][:, 1:] if start.requires_grad else torch.zeros(X0.shape[0], d, device=X0.device, dtype=X0.dtype)
-        B0 = torch.cat([b[:, 0, :] for b in BXs], 0)
-        nb0 = [b.shape[0] for b in BXs]
-        hb = self.funcs['h'](B0).detach().reshape(-1)
-        gb = self.funcs['g'](B0.unsqueeze(1)).detach().reshape(-1) if not all(bat0) else hb
-        selb = torch.cat([torch.full((n,), a, dtype=torch.bool) for n, a in zip(nb0, bat0)]).to(B0.device)
-        sb = torch.where(selb, hb, gb)
+        # h on every interior start point (the s1 term and the initial penalty read it on all groups, src/loss.py:64,79;
+        # for the groups that start at T0 it IS the start value)
+        hv = start if all(at0) else self.funcs['h'](X0.detach()).reshape(-1)
+        _, nb0, sb = starts(BXs, bat0)
+        sb = sb.detach()
         tabs = []
         for k, (x, xv, bx) in enumerate(zip(Xs, XVs, BXs)):
             N, L = x.shape[0], x.shape[1]
@@ -286,9 +296,17 @@ class Engine:
                              b_T0=bat0[k], start_b=sb.split(nb0)[k], g=g_all[k].view(bx.shape[0], bx.shape[1])))
         if not getattr(self, '_batch_tab_checked', False):
             self._batch_tab_checked = True
-            x, t0 = Xs[0], tabs[0]
-            if not (torch.equal(self.funcs['f'](x).detach(), t0['f']) and torch.equal(self.funcs['h'](x[:, 0, :]).detach().reshape(-1), t0['h'])
-                    and torch.equal(domain.func_w(XVs[0]).detach(), t0['w'])):
+            # bitwise against the per-group calls: f, h, w on the first group, and g, the start values with their gradient and the
+            # boundary start values on the LAST triple (a late group: boundary-type starts on the hourglass)
+            x, t0, kl = Xs[0], tabs[0], len(Xs) - 1
+            xl, bl, tl = Xs[kl], BXs[kl], tabs[kl]
+            eq = lambda a, b: torch.equal(a.detach().reshape(-1), b.detach().reshape(-1))      # noqa: E731
+            xl0 = xl[:, 0, :].clone().requires_grad_(True)
+            s_l = self.funcs['h'](xl0) if at0[kl] else self.funcs['g'](xl0.unsqueeze(1)).reshape(-1)
+            g_l = torch.autograd.grad(s_l.sum(), xl0)[0][:, 1:] if s_l.requires_grad else torch.zeros_like(xl0[:, 1:])
+            sb_l = self.funcs['h'](bl[:, 0, :]) if bat0[kl] else self.funcs['g'](bl[:, 0, :].unsqueeze(1))
+            if not (eq(self.funcs['f'](x), t0['f']) and eq(self.funcs['h'](x[:, 0, :]), t0['h']) and eq(domain.func_w(XVs[0]), t0['w'])
+                    and eq(self.funcs['g'](bl), tl['g']) and eq(s_l, tl['start']) and eq(g_l, tl['gh']) and eq(sb_l, tl['start_b'])):
                 import warnings
                 warnings.warn('the PDE callables give different values on a concatenation of groups than group by group (not pointwise?): '
                               'tabulating group by group', RuntimeWarning)
@@ -372,8 +390,9 @@ class Engine:
         st = self.structure
         S['X'] = X.to(dev) if st.c_kappa is None else None      # only read by a general reaction callable c(u, t, x)
         S['A0'] = S['B0'] = None
+        amode = 0
         if not st.a_identity:
-            S['A0'] = self._tabulate_a(X[:, :1, :])            # [d,d,N] / [d,N] (diagonal) / [d,d] (constant) at time index 0
+            S['A0'], amode = self._tabulate_a(X[:, :1, :])     # [d,d,N] / [d,N] (diagonal) / [d,d] (constant) at time index 0
         if not st.b_zero:
             S['B0'] = self._tabulate_b(X[:, :1, :])            # [d, N]
         if self.verify_structure and verify:
@@ -412,8 +431,8 @@ class Engine:
         pair_state = dict(pair_i=pair_i, pair_b=pair_b, init_off=init_off, bdry_off=bdry_off, s3_scale=nglob if pair_i else 1.0)
         if into is not None:
             G = into
-            same = (G.N, G.L, G.Nb, G.Lb, G.same_grid, G.Vol, G.Nglob, G.Nbglob, G.pair_i, G.pair_b) == (
-                N, L, Nb, Lb, same_grid, vol, nglob, nbglob, pair_i, pair_b) and all(
+            same = (G.N, G.L, G.Nb, G.Lb, G.same_grid, G.Vol, G.Nglob, G.Nbglob, G.pair_i, G.pair_b, G.amode) == (
+                N, L, Nb, Lb, same_grid, vol, nglob, nbglob, pair_i, pair_b, amode) and all(
                 (getattr(G, k) is None) == (S[k] is None) and (S[k] is None or getattr(G, k).shape == S[k].shape)
                 for k in Group.SAMPLE_FIELDS)
             if same:
@@ -428,7 +447,7 @@ class Engine:
         for k in Group.SAMPLE_FIELDS:
             setattr(G, k, S[k])
         G.domain, G.N, G.L, G.Nb, G.Vol, G.Nglob, G.Nbglob = domain, N, L, Nb, vol, nglob, nbglob
-        G.Lb, G.same_grid = Lb, same_grid
+        G.Lb, G.same_grid, G.amode = Lb, same_grid, amode
         G.__dict__.update(pair_state)
         # work buffers
         e = lambda *s_: torch.empty(*s_, dtype=F64, device=dev)  # noqa: E731
@@ -532,7 +551,7 @@ class Engine:
                              contract=dict(gx=G.gx, gs=G.gs, ghT=G.ghT, gxv=G.gxv, w0=G.w0, gwx0T=G.gwx0T), finalize=fin, pair=pair)
             return
         # general a_ij / b_i: the l = 0 contraction as one streaming kernel over the tabulated slice (graph-capturable)
-        KN.weak_contract_general(G.A0, G.B0, G.gx, G.gs, G.ghT, G.gxv, G.w0, G.gwx0T, G.v[0], G.s3x)
+        KN.weak_contract_general(G.A0, G.amode, G.B0, G.gx, G.gs, G.ghT, G.gxv, G.w0, G.gwx0T, G.v[0], G.s3x)
         KN.weak_partials(G.u, G.v, G.vt, G.w, G.f, G.h, G.Vol, G.Nglob, self.scal, G.work_i, s3x=G.s3x, c=G.c, ckappa=G.ck,
                          wt=G.wt, finalize=fin, pair=pair)
 
@@ -793,7 +812,8 @@ class Engine:
             fn(G)
             return
         if g is None:
-            if self.structure.c_kappa is None:
+            ran_eager = self.structure.c_kappa is None
+            if ran_eager:
                 fn(G)                             # a black-box c(u, t, x): one eager pass first (allocations, lazy init of its ops)
             g = torch.cuda.CUDAGraph()
             torch.cuda.synchronize()
@@ -813,10 +833,11 @@ class Engine:
                 G.graphs[key] = False
                 self.eager_segments = getattr(self, 'eager_segments', 0) + 1
                 torch.cuda.synchronize()
-                fn(G)
+                if not ran_eager:                 # (with a black-box c the eager pass above already WAS this call's step:
+                    fn(G)                         #  running fn again would apply a second optimiser update)
                 return
             G.graphs[key] = g
-            if self.structure.c_kappa is None:
+            if ran_eager:
                 return                            # (the eager pass above was this call's step; the capture only recorded)
         g.replay()
 

@@ -363,9 +363,10 @@ def pair_fold(scal, Vol, Nglob):
     check(lib.xw_pair_fold(_p(scal), float(Vol), float(Nglob), _stream()), 'xw_pair_fold')
 
 
-def weak_contract_general(A0, B0, gx, gs, ghT, gxv, w0, gwx0T, v0, s3x):
+def weak_contract_general(A0, amode, B0, gx, gs, ghT, gxv, w0, gwx0T, v0, s3x):
     """s3x[n] = sum_ij a_ij d_i(phi) d_j(u) + phi sum_i b_i d_i(u) at the first time index for general coefficients.
-    A0: None (identity), [d,d] (one matrix), [d,N] (diagonal) or [d,d,N] (full table at t_0);  B0: None or [d,N]."""
+    amode says what A0 is (never inferred from its shape: [d,d] and [d,N] coincide when N == d):
+    0 identity (A0 None), 1 [d,d] one matrix, 2 [d,N] diagonal, 3 [d,d,N] full table at t_0;  B0: None or [d,N]."""
     _need_gpu()
     d, N = gx.shape
     for name, a in (('gx', gx), ('ghT', ghT), ('gxv', gxv), ('gwx0T', gwx0T)):
@@ -373,17 +374,11 @@ def weak_contract_general(A0, B0, gx, gs, ghT, gxv, w0, gwx0T, v0, s3x):
     for name, a in (('gs', gs), ('w0', w0), ('v0', v0), ('s3x', s3x)):
         _chk(a, F64, (N,), name)
     _chk(B0, F64, (d, N), 'B0')
-    if A0 is None:
-        amode = 0
-    elif A0.dim() == 3:
-        amode = 3
-        _chk(A0, F64, (d, d, N), 'A0')
-    elif tuple(A0.shape) == (d, d) and (N != d or getattr(A0, 'xw_constant', False)):
-        amode = 1
-        _chk(A0, F64, (d, d), 'A0')
-    else:
-        amode = 2
-        _chk(A0, F64, (d, N), 'A0')
+    amode = int(amode)
+    if amode not in (0, 1, 2, 3) or (amode == 0) != (A0 is None):
+        raise XnwanError('weak_contract_general: amode %r does not match A0' % (amode,))
+    if amode:
+        _chk(A0, F64, {1: (d, d), 2: (d, N), 3: (d, d, N)}[amode], 'A0')
     check(lib.xw_weak_contract_general(_p(A0), amode, _p(B0), _p(gx), _p(gs), _p(ghT), _p(gxv), _p(w0), _p(gwx0T), _p(v0), d, N,
                                        _p(s3x), _stream()), 'xw_weak_contract_general')
     return s3x

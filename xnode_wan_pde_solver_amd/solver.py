@@ -314,7 +314,7 @@ class NODE_WAN_solver:
                     past_losses.append(self.av_l)
                     if self._is_main():
                         past_losses.write('losses_NODE_' + str(d) + '.json')
-                    if self.stop is not None and self.stop(self, points.interioru, domain):
+                    if self.stop is not None and self._stop_agreed(points, domain):
                         if self._is_main():
                             torch.save(self.u_net.state_dict(), self.path + 'best_model_weights_NODE.pth')
                         print('Stopping Criterion Reached')
@@ -372,6 +372,18 @@ class NODE_WAN_solver:
         torch.set_rng_state(ck['torch_rng'].cpu())
         np.random.set_state(ck['numpy_rng'])
         self.engine.invalidate_test_net()                # cached / prefetched test-network outputs are stale now
+
+    def _stop_agreed(self, points, domain):
+        """the user's stop hook (src/training.py:142).  With several ranks every rank calls it (it may run u_net, which
+        every rank can do), but the ranks must leave the loop TOGETHER -- one that returned while the others entered the next
+        captured all-reduce would deadlock them -- so rank 0's verdict is the one all of them follow (with rank-local
+        sampling the hook sees different paths on every rank and the verdicts can differ)."""
+        verdict = bool(self.stop(self, points.interioru, domain))
+        if self.world is None:
+            return verdict
+        flag = torch.tensor([1.0 if (verdict and self.world.rank == 0) else 0.0], dtype=torch.float64, device=self.device)
+        self.world.all_reduce(flag)
+        return bool(flag.item() > 0.5)
 
     def _is_main(self):
         return self.world is None or self.world.rank == 0
