@@ -143,19 +143,24 @@ __device__ __forceinline__ double xw_gate_pos(double b, double x) {
 }
 __device__ __forceinline__ d4 xw_zero4() { d4 z = {0.0, 0.0, 0.0, 0.0}; return z; }
 
-// tanh(x) = sign(x) (1 - e) / (1 + e), e = exp(-2|x|): ~32 f64 VALU ops instead of the ~93 of the library tanh, which
-// made tanh the bottleneck of the stepper (one wave per SIMD issues an f64 VALU op every ~9 cycles, a 64-cycle MFMA hides
-// none of it on a dependent chain).  exp: n = rint(y log2 e), Cody-Waite reduction, degree-13 Taylor polynomial on
-// |r| <= ln2/2, ldexp.  Division: v_rcp_f64 + two Newton steps + one residual correction (1 + e is in [1, 2]).
-// Max ABSOLUTE error 3.4e-16 over [-100, 100] (checked against libm on the host); NaN propagates.
+// tanh(x) = sign(x) (1 - e) / (1 + e), e = exp(-2|x|): 29 f64 VALU instructions (the library tanh has ~93; round 2's
+// version of this one 38) -- in the stepper tanh is a fifth of the forward's vector instructions, and every one of them
+// queues behind the test network's 64-clock MFMAs when the two share a SIMD.
+//   |x| clamped to 40 (e < 2^-115);  n = rint(y log2 e) by the 1.5 * 2^52 shift (the integer then sits in the low word
+//   of the shifted sum);  Cody-Waite reduction;  degree-12 Taylor polynomial on |r| <= ln2 / 2 (truncation 1.7e-16
+//   relative to e <= 1);  2^n by an integer add into the exponent field (p is in [0.7, 1.42], n >= -116: always a normal
+//   number);  division: v_rcp_f64 (2^-23) + one Newton step + one residual correction of the quotient.
+// Max ABSOLUTE error 4e-16 over [-100, 100] (tests/test_host_logic.py emulates the sequence on the host).  NaN propagates
+// (x * 0 is added to the result); so does an infinite x -- tanh(+-inf) = NaN here, where libm gives +-1: an infinite
+// pre-activation only occurs in a run that has already diverged.
 __device__ __forceinline__ double xw_tanh(double x) {
-  const double a = fabs(x);
-  const double y = fmax(-2.0 * a, -80.0);
-  const double n = rint(y * 1.4426950408889634);
+  const double am = fmin(fabs(x), 40.0);
+  const double y = -2.0 * am;
+  const double nb = fma(y, 1.4426950408889634, 6755399441055744.0);
+  const double n = nb - 6755399441055744.0;
   double r = fma(n, -6.93147180369123816490e-01, y);
   r = fma(n, -1.90821492927058770002e-10, r);
-  double p = 1.6059043836821613e-10;
-  p = fma(p, r, 2.08767569878681e-09);
+  double p = 2.08767569878681e-09;
   p = fma(p, r, 2.505210838544172e-08);
   p = fma(p, r, 2.755731922398589e-07);
   p = fma(p, r, 2.7557319223985893e-06);
@@ -168,15 +173,13 @@ __device__ __forceinline__ double xw_tanh(double x) {
   p = fma(p, r, 0.5);
   p = fma(p, r, 1.0);
   p = fma(p, r, 1.0);
-  const double e = ldexp(p, (int)n);
+  const double e = __hiloint2double(__double2hiint(p) + (__double2loint(nb) << 20), __double2loint(p));
   const double num = 1.0 - e, den = 1.0 + e;
   double rc = __builtin_amdgcn_rcp(den);
   rc = fma(fma(-den, rc, 1.0), rc, rc);
-  rc = fma(fma(-den, rc, 1.0), rc, rc);
   double q = num * rc;
   q = fma(fma(-den, q, num), rc, q);
-  q = copysign(q, x);
-  return a == a ? q : x;
+  return fma(x, 0.0, copysign(q, x));
 }
 
 // sum over the 4 lane groups g (lanes n, n+16, n+32, n+48): reduces the ROW index of a chain-layout partial
@@ -193,6 +196,32 @@ __device__ __forceinline__ double xw_sum_over_g(double x) {
   a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
   b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
   return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+}
+// Pairwise forms of the same swaps: reduce TWO values by one level with one swap (per 32-bit half) and one add.
+//   xw_fold32(a, b): lanes 0..31 = a[l] + a[l + 32],  lanes 32..63 = b[l - 32] + b[l]
+//   xw_fold16(a, b): row 0 = a.row0 + a.row1, row 1 = b.row0 + b.row1, row 2 = a.row2 + a.row3, row 3 = b.row2 + b.row3
+// (rows = the four 16-lane groups g).  Three folds turn four per-group partials into one register that holds the four
+// totals in the four lane groups -- 6 swaps + 3 adds where four xw_sum_over_g take 16 + 8.
+__device__ __forceinline__ double xw_fold32(double a, double b) {
+  typedef unsigned xw_u2 __attribute__((ext_vector_type(2)));
+  const xw_u2 lo = __builtin_amdgcn_permlane32_swap(__double2loint(a), __double2loint(b), false, false);
+  const xw_u2 hi = __builtin_amdgcn_permlane32_swap(__double2hiint(a), __double2hiint(b), false, false);
+  return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+}
+__device__ __forceinline__ double xw_fold16(double a, double b) {
+  typedef unsigned xw_u2 __attribute__((ext_vector_type(2)));
+  const xw_u2 lo = __builtin_amdgcn_permlane16_swap(__double2loint(a), __double2loint(b), false, false);
+  const xw_u2 hi = __builtin_amdgcn_permlane16_swap(__double2hiint(a), __double2hiint(b), false, false);
+  return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+}
+// x[lane ^ 32]: the upper half's values in the lower half and vice versa
+__device__ __forceinline__ double xw_swap_halves(double x) {
+  typedef unsigned xw_u2 __attribute__((ext_vector_type(2)));
+  const xw_u2 lo = __builtin_amdgcn_permlane32_swap(__double2loint(x), __double2loint(x), false, false);
+  const xw_u2 hi = __builtin_amdgcn_permlane32_swap(__double2hiint(x), __double2hiint(x), false, false);
+  // result 0 = (x[0..31], x[0..31]), result 1 = (x[32..63], x[32..63]): lower lanes take 1, upper lanes take 0
+  const bool up = xw_lane() >= 32;
+  return __hiloint2double(up ? hi[0] : hi[1], up ? lo[0] : lo[1]);
 }
 // sum over the 16 columns n (lanes within a 16-lane row)
 __device__ __forceinline__ double xw_sum_over_n(double x) {

@@ -100,6 +100,9 @@ __device__ __forceinline__ void input_layer(const double* __restrict__ ph, const
 #define XW_DISC_QSTRIDE 64
 #define XW_DISC_SLOTS 128
 __device__ unsigned int xw_disc_queue[XW_DISC_SLOTS][(XW_DISC_NQ + 1) * XW_DISC_QSTRIDE];
+#ifdef XW_CLOCK_PROBE   // diagnostic build only (tools/probe_disc_clock.py): shader clocks / 100 MHz ticks of every wave's tile loop
+__device__ unsigned long long xw_clock_buf[2 * 4096];
+#endif
 template <int W, bool ACT, bool DYN, bool VINLDS>
 __global__ void __launch_bounds__(256, 2) k_disc_fwd(const double* __restrict__ xT, const double* __restrict__ tf,
                                                      const double* __restrict__ tpp, const double* __restrict__ ph, int N,
@@ -164,6 +167,13 @@ __global__ void __launch_bounds__(256, 2) k_disc_fwd(const double* __restrict__ 
   // use, dry queues seen
   const int nq = (int)gridDim.x < XW_DISC_NQ ? (int)gridDim.x : XW_DISC_NQ;
   int cur = blockIdx.x % nq, tries = 0;
+#ifdef XW_DISC_SIGNMASK
+  int zr = 0;                                // zero, opaque to the compiler (see the layer's relu / gate)
+  asm volatile("" : "+v"(zr));
+#endif
+#ifdef XW_CLOCK_PROBE
+  const unsigned long long ck0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
   for (long it = (long)blockIdx.x * 4 + wave; it < ntiles;) {
     const long tile = DYN ? it : (it < G ? it - rot + (it < rot ? G : 0) : it);
     long nxt = it + G;
@@ -229,15 +239,67 @@ __global__ void __launch_bounds__(256, 2) k_disc_fwd(const double* __restrict__ 
       double tv[D::TR], td[D::TR];                          // partial dot products of the tail rows (this lane's k = 4 ks + g)
 #pragma unroll
       for (int r = 0; r < D::TR; ++r) tv[r] = td[r] = 0.0;
+#ifdef XW_DISC_PREFETCH
+      // A-fragments (and the tail rows' weights) of k-step ks + 1 are requested from LDS BEFORE the matrix instructions of
+      // k-step ks: a wave alone on its SIMD (640 of the 1024 SIMDs as launched beside the stepper) otherwise stops at a
+      // wait in front of almost every pair of MFMAs
+      double wn[D::MTF], tn[D::TR];
+#pragma unroll
+      for (int mt = 0; mt < D::MTF; ++mt) wn[mt] = sVh[(mt * D::KS) * 64 + lane];
+      if (D::VTAIL)
+#pragma unroll
+        for (int r = 0; r < D::TR; ++r) tn[r] = sT[g * D::TR + r];
+#endif
 #pragma unroll
       for (int ks = 0; ks < D::KS; ++ks) {
         const double av = ai[ks >> 2][ks & 3];
+#ifdef XW_DISC_SIGNMASK
+        // relu and the tangent's gate from ONE 32-bit word, the sign extension of av's high word: x & ~sgn as a single
+        // v_bfi_b32 per 32-bit half (sgn ? zr : x, zr a register that holds zero but is opaque to the compiler -- with a
+        // visible zero, or a visible sign test, it rewrites the bit operations into compare + v_cndmask_b32 again).
+        // 1 + 4 instructions of 2.3 clocks per k-step where v_max_f64 x 2 (canonicalise + max), v_or, v_mov, v_cmp_ne_u64 and
+        // two v_cndmask_b32 took ~31.  av >= +0 keeps both, av < 0 (or -0) clears both: at av == +0 exactly the gate stays
+        // open where torch's relu' is 0 -- that only happens where the tangent is zero as well (padding units, dead inputs).
+        int sgn = __double2hiint(av) >> 31;
+        asm volatile("" : "+v"(sgn));
+        const double adv = adi[ks >> 2][ks & 3];
+        const double b = __hiloint2double((sgn & zr) | (~sgn & __double2hiint(av)), (sgn & zr) | (~sgn & __double2loint(av)));
+        const double bd = __hiloint2double((sgn & zr) | (~sgn & __double2hiint(adv)), (sgn & zr) | (~sgn & __double2loint(adv)));
+#else
         const double b = av > 0.0 ? av : 0.0;
         const double bd = xw_gate_pos(b, adi[ks >> 2][ks & 3]);
+#endif
         if (ACT) {   // activation store: row j W + k of the record is the layer input relu(a_j)[k], point-major
           double* __restrict__ rowp = actl + (j * W + 4 * ks) * 16;             // uniform pointer + 32-bit lane offset
           if (4 * ks + 3 < W || 4 * ks + g < W) __builtin_nontemporal_store(b, rowp + aoff);   // (streamed: read once, much later)
         }
+#ifdef XW_DISC_PREFETCH
+        double wc[D::MTF], tc[D::TR];
+#pragma unroll
+        for (int mt = 0; mt < D::MTF; ++mt) wc[mt] = wn[mt];
+#pragma unroll
+        for (int r = 0; r < D::TR; ++r) tc[r] = D::VTAIL ? tn[r] : 0.0;
+        if (ks + 1 < D::KS) {
+#pragma unroll
+          for (int mt = 0; mt < D::MTF; ++mt) wn[mt] = sVh[(mt * D::KS + ks + 1) * 64 + lane];
+          if (D::VTAIL)
+#pragma unroll
+            for (int r = 0; r < D::TR; ++r) tn[r] = sT[(4 * (ks + 1) + g) * D::TR + r];
+        }
+        asm volatile("" ::: "memory");                      // the requests stay HERE, one k-step ahead of their use
+#pragma unroll
+        for (int mt = 0; mt < D::MTF; ++mt) {
+          nw[mt] = XW_MFMA(wc[mt], b, nw[mt]);
+          nd[mt] = XW_MFMA(wc[mt], bd, nd[mt]);
+        }
+        if (D::VTAIL) {
+#pragma unroll
+          for (int r = 0; r < D::TR; ++r) {
+            tv[r] = fma(tc[r], b, tv[r]);
+            td[r] = fma(tc[r], bd, td[r]);
+          }
+        }
+#else
         if ((ks & 1) == 0) asm volatile("" ::: "memory");   // bound the LDS loads in flight (else all 52 are hoisted -> spills)
 #pragma unroll
         for (int mt = 0; mt < D::MTF; ++mt) {
@@ -253,7 +315,26 @@ __global__ void __launch_bounds__(256, 2) k_disc_fwd(const double* __restrict__ 
             td[r] = fma(w, bd, td[r]);
           }
         }
+#endif
       }
+#ifdef XW_DISC_TAILFOLD
+      if (D::VTAIL && D::TR == 2) {
+        // the four partials (value / tangent of rows 48, 49) -> ONE register with the totals in the four lane groups
+        // (g = 0: row 48, g = 1: row 49, g = 2, 3: the two tangent totals), then the tangent's copy with the halves swapped.
+        // Rows 50, 51 of both tiles (lane groups 2, 3) then hold finite leftovers instead of zeros: they only ever meet
+        // zero-padded weights (columns >= W of the Vh fragments and of the tail rows, rows >= W of Vo and of Vh^T), and the
+        // record's stores are guarded by row < W.  8 swaps + 4 adds where four separate sums took 16 + 8 and 8 selects.
+        const double R = xw_fold16(xw_fold32(tv[0], td[0]), xw_fold32(tv[1], td[1]));
+        d4 tw = xw_zero4(), tdd = xw_zero4();
+        tw[0] = R + nw[D::MT - 1][0];
+        const unsigned rl = __double2loint(R), rh = __double2hiint(R);
+        typedef unsigned xw_u2 __attribute__((ext_vector_type(2)));
+        const xw_u2 sl = __builtin_amdgcn_permlane32_swap(rl, rl, false, false), sh = __builtin_amdgcn_permlane32_swap(rh, rh, false, false);
+        tdd[0] = __hiloint2double(sh[1], sl[1]);              // (R[32..63], R[32..63]): tangent totals in lane groups 0, 1
+        nw[D::MT - 1] = tw;
+        nd[D::MT - 1] = tdd;
+      } else
+#endif
       if (D::VTAIL) {   // row 16 (MT-1) + r of the chain layout lives in lane group g = r, register 0
         d4 tw = xw_zero4(), tdd = xw_zero4();
 #pragma unroll
@@ -360,6 +441,12 @@ __global__ void __launch_bounds__(256, 2) k_disc_fwd(const double* __restrict__ 
     }
     it = nxt;
   }
+#ifdef XW_CLOCK_PROBE
+  if (lane == 0 && blockIdx.x * 4 + wave < 4096) {
+    xw_clock_buf[2 * (blockIdx.x * 4 + wave)] = __builtin_amdgcn_s_memtime() - ck0;
+    xw_clock_buf[2 * (blockIdx.x * 4 + wave) + 1] = __builtin_amdgcn_s_memrealtime() - rt0;
+  }
+#endif
   if (DYN && lane == 0) {
     if (atomicAdd(&sDone, 1u) == 3u && atomicAdd(queue + XW_DISC_NQ * XW_DISC_QSTRIDE, 1u) == gridDim.x - 1u)
       for (int s_ = 0; s_ <= XW_DISC_NQ; ++s_) atomicExch(queue + s_ * XW_DISC_QSTRIDE, 0u);
@@ -999,6 +1086,12 @@ extern "C" int xw_disc_fwd(const double* xT, const double* t, const double* tpp,
 #undef XW_DISC_FWD2
   return xw_launch_status();
 }
+
+#ifdef XW_CLOCK_PROBE
+extern "C" int xw_debug_clock(unsigned long long* host, int nwaves) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(xw_clock_buf), sizeof(unsigned long long) * 2 * nwaves);
+}
+#endif
 
 extern "C" int xw_disc_bwd_slabs(int N, int L) { return bwd_blocks((long)N * L); }
 

@@ -84,18 +84,25 @@ template <int M> struct Save {               // what the VJP of one field evalua
   __device__ __forceinline__ bool pos(int j, int r) const { return z[j][r] > 0.0; }
   __device__ __forceinline__ double gate(int j, int r, double x) const { return z[j][r] > 0.0 ? x : 0.0; }   // relu'(z_j) * x
 };
-// the same for a sweep without weight gradients: the layer inputs are only needed as their ReLU masks, 4 bits per layer
-// (registers 0..3 of the K-tile) in one word -- the x-only sweep then loads 1 word + tanh instead of m K doubles per stage
+// the same for a sweep without weight gradients: the layer inputs are only needed as their ReLU masks, one bit per live
+// register of the K-tile and layer in one word -- the x-only sweep then loads 1 word + tanh instead of m K doubles per stage.
+// The forward pushes the bit (z > 0) of every pre-activation register into the word as it is produced (a compare and one
+// add-with-carry: word = word + word + carry): (layer j, register r) was push number XW_KB j + r of XW_KB (M - 1) and sits
+// at bit  XW_KB (M - 1) - 1 - (XW_KB j + r).  The test must be z > 0, not the sign bit: a layer whose units are all dead
+// feeds EXACT zeros (+0, the biases start at zero) to the next one, and relu'(+0) = 0 in the reference (torch) -- with sign
+// bits the boundary sweep of the d = 20 fixture was off by 5e-5.
+#define XW_KB ((XW_ODE_K + 3) / 4)
 template <int M> struct SaveX {
-  static_assert(4 * (M - 1) <= 32, "mask word");
+  static_assert(XW_KB * (M - 1) <= 32, "mask word");
   d4 a;
   unsigned bits;
-  __device__ __forceinline__ bool pos(int j, int r) const { return (bits >> (4 * j + r)) & 1u; }
+  __device__ static constexpr int bit(int j, int r) { return XW_KB * (M - 1) - 1 - (XW_KB * j + r); }
+  __device__ __forceinline__ bool pos(int j, int r) const { return (bits >> bit(j, r)) & 1u; }
   // relu'(z_j) * x as two 32-bit ANDs with the mask bit spread to 0 / ~0 (one v_bfe_i32 that does not depend on x):
   // a v_cndmask_b32 costs ~6 clocks of the SIMD, a v_and_b32 2.3 (profiles/r02_probe_coexec.txt), and the gate sits on the
   // adjoint chain's critical path once per layer and register
   __device__ __forceinline__ double gate(int j, int r, double x) const {
-    const int m = __builtin_amdgcn_sbfe((int)bits, 4 * j + r, 1);
+    const int m = __builtin_amdgcn_sbfe((int)bits, bit(j, r), 1);
     return __hiloint2double(__double2hiint(x) & m, __double2loint(x) & m);
   }
 };
@@ -141,11 +148,13 @@ __device__ __forceinline__ void load_field_T(const double* __restrict__ th, cons
 // tanh, output layer.  y/out: HT chain tiles.
 // Where the layer inputs of an evaluation go: nowhere, into registers (Save), or straight to the activation store.
 struct SinkNone {
+  __device__ __forceinline__ double relu(int, int, double z) const { return xw_relu1(z); }
   __device__ __forceinline__ void z(int, d4) const {}
   __device__ __forceinline__ void a(d4) const {}
 };
 template <int M> struct SinkSave {
   Save<M>& sv;
+  __device__ __forceinline__ double relu(int, int, double z) const { return xw_relu1(z); }
   __device__ __forceinline__ void z(int j, d4 r) const { sv.z[j] = r; }
   __device__ __forceinline__ void a(d4 v) const { sv.a = v; }
 };
@@ -165,7 +174,7 @@ __device__ __forceinline__ void field_fwd(const FieldW<H, K>& w, double t, d4 xp
   for (int j = 0; j < M - 1; ++j) {
     d4 r = xw_zero4();
 #pragma unroll
-    for (int kb = 0; kb < D::KB; ++kb) r[kb] = xw_relu1(z[kb]);
+    for (int kb = 0; kb < D::KB; ++kb) r[kb] = sink.relu(j, kb, z[kb]);
     sink.z(j, r);
     d4 nz = w.bh;
 #pragma unroll
@@ -565,33 +574,49 @@ template <int H, int K, int M, int S> struct ActLayout {
 };
 // rows [row0, row0 + nrows) of the record <-> the first registers of a chain tile (row g + 4 r).  Addresses are
 // formed as  (uniform row pointer) + (32-bit lane offset)  so that they cost SGPRs, not a VGPR pair per stored row.
-struct ActLane {
-  int off;        // inside a full block of four rows: 4 * column + g
-  int off_part;   // inside the last, partially filled block of a K-row tile (p = K mod 4 rows): p * column + min(g, p - 1)
+struct ActLane {       // (unsigned: uniform pointer + zero-extended 32-bit lane offset is the scalar-base addressing form of the
+                       //  global loads / stores -- with signed offsets every 4 KB of the record cost a 64-bit vector add)
+  unsigned off;        // BYTES inside a full block of four rows: 8 (4 * column + g)
+  unsigned off_part;   // inside the last, partially filled block of a K-row tile (p = K mod 4 rows): 8 (p * column + min(g, p - 1))
   bool valid;
 };
 __device__ __forceinline__ ActLane act_lane(int N, int col, bool valid, int krows) {
   const int g = xw_lane() >> 4, p = krows & 3;
   const int gp = p ? (g < p ? g : p - 1) : g;
-  return ActLane{4 * col + g, (p ? p : 4) * col + gp, valid};
+  return ActLane{8u * (unsigned)(4 * col + g), 8u * (unsigned)((p ? p : 4) * col + gp), valid};
 }
-__device__ __forceinline__ void act_store(double* __restrict__ A, int row0, int nrows, int N, const ActLane& q, d4 v) {
+// The forward pass writes the record through a BUFFER descriptor of the step's tile (base = the tile's 23 KB, built from
+// scalars once per step): a store is then  descriptor + scalar row offset + 32-bit lane offset  and costs no vector
+// instruction for its address.  With plain global stores the compiler folds all row offsets of a step onto one 64-bit
+// vector address and re-bases it every 4 KB: 58 v_add_co / v_addc per step, each of which queues for the shared pipe.
+typedef unsigned xw_u2v __attribute__((ext_vector_type(2)));
+struct ActBuf {
+  __amdgpu_buffer_rsrc_t rsrc;
+};
+__device__ __forceinline__ ActBuf act_buf(double* A, int bytes) {
+  return ActBuf{__builtin_amdgcn_make_buffer_rsrc(A, 0, bytes, 0x00020000)};
+}
+__device__ __forceinline__ void act_store(const ActBuf& B, int row0, int nrows, int N, const ActLane& q, d4 v) {
   const int g = xw_lane() >> 4;
 #pragma unroll
   for (int r = 0; r < 4; ++r)
     if (4 * r < nrows) {
-      double* __restrict__ blk = A + (long)(row0 + 4 * r) * N;              // uniform: the block of rows 4 r .. 4 r + 3
-      if (g + 4 * r < nrows && q.valid)                                     // (streamed: read once, by a sweep)
-        __builtin_nontemporal_store(v[r], blk + (4 * r + 4 <= nrows ? q.off : q.off_part));
+      const int so = (row0 + 4 * r) * N * 8;                                // uniform: the block of rows 4 r .. 4 r + 3
+      // (the element goes through a scalar first: __builtin_bit_cast applied to v[r] directly reads element 0 of the vector)
+      const double x = v[r];
+      const xw_u2v w2 = {(unsigned)__double2loint(x), (unsigned)__double2hiint(x)};
+      if (g + 4 * r < nrows && q.valid)                                     // (nt: streamed, read once, by a sweep)
+        __builtin_amdgcn_raw_buffer_store_b64(w2, B.rsrc, (int)(4 * r + 4 <= nrows ? q.off : q.off_part), so, 2);
     }
 }
 __device__ __forceinline__ d4 act_load(const double* __restrict__ A, int row0, int nrows, int N, const ActLane& q) {
   d4 v = xw_zero4();
+  const char* base = reinterpret_cast<const char*>(A + (long)row0 * N);
 #pragma unroll
   for (int r = 0; r < 4; ++r)
     if (4 * r < nrows) {
-      const double* __restrict__ blk = A + (long)(row0 + 4 * r) * N;        // uniform
-      v[r] = __builtin_nontemporal_load(blk + (4 * r + 4 <= nrows ? q.off : q.off_part));   // padding rows: any finite value
+      const char* __restrict__ blk = base + (long)(4 * r) * N * 8;         // uniform
+      v[r] = __builtin_nontemporal_load(reinterpret_cast<const double*>(blk + (4 * r + 4 <= nrows ? q.off : q.off_part)));   // padding rows: any finite value
     }
   return v;
 }
@@ -599,14 +624,26 @@ __device__ __forceinline__ d4 act_load(const double* __restrict__ A, int row0, i
 // streams the layer inputs of one stage into the activation store as they are produced (no register copy kept)
 // FULL = false: only what a sweep WITHOUT weight gradients reads back (the tanh rows and the mask words)
 template <int K, int M, bool FULL = true> struct SinkAct {
-  double* __restrict__ A;      // record of this step
+  const ActBuf& A;             // record of this step
   int row0, N;
   const ActLane& q;
-  unsigned& bits;              // ReLU masks of the stage (SaveX layout), stored by the caller after the evaluation
+  unsigned& bits;              // (z > 0) of the stage's pre-activations, pushed in (layer, register) order (SaveX)
+  // relu of one pre-activation register: its bit (z > 0) goes into the mask word (v_cmp_gt_f64 + v_addc_co_u32), then
+  // ONE v_max_f64 (3 vector instructions per register where compare, select, shift-or and two v_max_f64 were 4.5).  As a builtin the maximum comes with a canonicalising v_max_f64 z, z in front of it (45 extra vector
+  // instructions per step); as inline assembly it would escape the hazard recogniser, which must keep a VALU read 6+ wait
+  // states behind the MFMA that wrote z -- so the assembly takes the mask word as an (unused) operand: it then follows the
+  // compare, a visible read of the same MFMA result for which the wait states have been inserted.
+  __device__ __forceinline__ double relu(int, int, double z) const {
+    // (the compare is compiler-visible -- it is the read of z the hazard recogniser sees --, its lane mask goes into the
+    //  assembly as a scalar pair and becomes the carry-in of  word = word + word + carry;  written in C the compiler
+    //  turns the add-with-carry back into compare + select + shift-or)
+    const unsigned long long open = __builtin_amdgcn_ballot_w64(z > 0.0);
+    double r;
+    asm("v_addc_co_u32_e64 %1, vcc, %1, %1, %3\n\tv_max_f64 %0, %2, 0\n\ts_nop 1" : "=v"(r), "+v"(bits) : "v"(z), "s"(open) : "vcc");
+    return r;
+  }
   __device__ __forceinline__ void z(int j, d4 r) const {
     if (FULL) act_store(A, row0 + j * K, K, N, q, r);
-#pragma unroll
-    for (int c = 0; c < (K + 3) / 4; ++c) bits |= (r[c] > 0.0 ? 1u : 0u) << (4 * j + c);
   }
   __device__ __forceinline__ void a(d4 v) const { act_store(A, row0 + (M - 1) * K, K, N, q, v); }
 };
@@ -671,14 +708,15 @@ __global__ void __launch_bounds__(64, 2) k_ode_fwd(const FwdJobs jobs, const dou
         field_fwd<H, K, M, true>(w, t0 + T::c(i) * dt, xp, yi, k[i], SinkNone{});
       } else {
         double* __restrict__ A = act + ((long)l * ntile + tile) * (AL::TOTAL * 16);
+        const ActBuf AB = act_buf(A, AL::TOTAL * 16 * 8);
         if (i > 0 && ACT == 1) {
 #pragma unroll
           for (int ht = 0; ht < D::HT; ++ht)
-            act_store(A, AL::YI + (i - 1) * H + 16 * ht, H - 16 * ht < 16 ? H - 16 * ht : 16, 16, aq, yi[ht]);
+            act_store(AB, AL::YI + (i - 1) * H + 16 * ht, H - 16 * ht < 16 ? H - 16 * ht : 16, 16, aq, yi[ht]);
         }
         unsigned bits = 0;
-        field_fwd<H, K, M, true>(w, t0 + T::c(i) * dt, xp, yi, k[i], SinkAct<K, M, ACT == 1>{A, i * AL::STAGE, 16, aq, bits});
-        reinterpret_cast<unsigned*>(A + (AL::MASK + 2 * i) * 16)[lane] = bits;
+        field_fwd<H, K, M, true>(w, t0 + T::c(i) * dt, xp, yi, k[i], SinkAct<K, M, ACT == 1>{AB, i * AL::STAGE, 16, aq, bits});
+        __builtin_amdgcn_raw_buffer_store_b32(bits, AB.rsrc, lane * 4, (AL::MASK + 2 * i) * 16 * 8, 0);   // 1 = open (SaveX)
       }
     }
 #pragma unroll

@@ -450,7 +450,10 @@ class Engine:
         G.Lb, G.same_grid, G.amode = Lb, same_grid, amode
         G.__dict__.update(pair_state)
         # work buffers
-        e = lambda *s_: torch.empty(*s_, dtype=F64, device=dev)  # noqa: E731
+        # XW_POISON=1 (debugging): work buffers start as NaN instead of whatever the allocator hands out, so that a kernel
+        # reading a slot nobody wrote shows up as NaN in the results instead of as a stale, plausible number
+        poison = os.environ.get('XW_POISON', '0') == '1'
+        e = (lambda *s_: torch.full(s_, float('nan'), dtype=F64, device=dev)) if poison else (lambda *s_: torch.empty(*s_, dtype=F64, device=dev))  # noqa: E731
         H = self.H
         G.u, G.Y, G.v, G.vt = e(L, N), e(L, H, N), e(L, N), e(L, N)
         G.gxv, G.gtv, G.gx, G.gs = e(d, N), e(N), e(d, N), e(N)
