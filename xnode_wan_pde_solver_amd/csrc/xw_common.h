@@ -214,15 +214,6 @@ __device__ __forceinline__ double xw_fold16(double a, double b) {
   const xw_u2 hi = __builtin_amdgcn_permlane16_swap(__double2hiint(a), __double2hiint(b), false, false);
   return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
 }
-// x[lane ^ 32]: the upper half's values in the lower half and vice versa
-__device__ __forceinline__ double xw_swap_halves(double x) {
-  typedef unsigned xw_u2 __attribute__((ext_vector_type(2)));
-  const xw_u2 lo = __builtin_amdgcn_permlane32_swap(__double2loint(x), __double2loint(x), false, false);
-  const xw_u2 hi = __builtin_amdgcn_permlane32_swap(__double2hiint(x), __double2hiint(x), false, false);
-  // result 0 = (x[0..31], x[0..31]), result 1 = (x[32..63], x[32..63]): lower lanes take 1, upper lanes take 0
-  const bool up = xw_lane() >= 32;
-  return __hiloint2double(up ? hi[0] : hi[1], up ? lo[0] : lo[1]);
-}
 // sum over the 16 columns n (lanes within a 16-lane row)
 __device__ __forceinline__ double xw_sum_over_n(double x) {
   x += __shfl_xor(x, 1);

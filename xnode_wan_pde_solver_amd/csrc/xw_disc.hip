@@ -167,10 +167,8 @@ __global__ void __launch_bounds__(256, 2) k_disc_fwd(const double* __restrict__ 
   // use, dry queues seen
   const int nq = (int)gridDim.x < XW_DISC_NQ ? (int)gridDim.x : XW_DISC_NQ;
   int cur = blockIdx.x % nq, tries = 0;
-#ifdef XW_DISC_SIGNMASK
   int zr = 0;                                // zero, opaque to the compiler (see the layer's relu / gate)
   asm volatile("" : "+v"(zr));
-#endif
 #ifdef XW_CLOCK_PROBE
   const unsigned long long ck0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -239,7 +237,6 @@ __global__ void __launch_bounds__(256, 2) k_disc_fwd(const double* __restrict__ 
       double tv[D::TR], td[D::TR];                          // partial dot products of the tail rows (this lane's k = 4 ks + g)
 #pragma unroll
       for (int r = 0; r < D::TR; ++r) tv[r] = td[r] = 0.0;
-#ifdef XW_DISC_PREFETCH
       // A-fragments (and the tail rows' weights) of k-step ks + 1 are requested from LDS BEFORE the matrix instructions of
       // k-step ks: a wave alone on its SIMD (640 of the 1024 SIMDs as launched beside the stepper) otherwise stops at a
       // wait in front of almost every pair of MFMAs
@@ -249,11 +246,9 @@ __global__ void __launch_bounds__(256, 2) k_disc_fwd(const double* __restrict__ 
       if (D::VTAIL)
 #pragma unroll
         for (int r = 0; r < D::TR; ++r) tn[r] = sT[g * D::TR + r];
-#endif
 #pragma unroll
       for (int ks = 0; ks < D::KS; ++ks) {
         const double av = ai[ks >> 2][ks & 3];
-#ifdef XW_DISC_SIGNMASK
         // relu and the tangent's gate from ONE 32-bit word, the sign extension of av's high word: x & ~sgn as a single
         // v_bfi_b32 per 32-bit half (sgn ? zr : x, zr a register that holds zero but is opaque to the compiler -- with a
         // visible zero, or a visible sign test, it rewrites the bit operations into compare + v_cndmask_b32 again).
@@ -265,15 +260,10 @@ __global__ void __launch_bounds__(256, 2) k_disc_fwd(const double* __restrict__ 
         const double adv = adi[ks >> 2][ks & 3];
         const double b = __hiloint2double((sgn & zr) | (~sgn & __double2hiint(av)), (sgn & zr) | (~sgn & __double2loint(av)));
         const double bd = __hiloint2double((sgn & zr) | (~sgn & __double2hiint(adv)), (sgn & zr) | (~sgn & __double2loint(adv)));
-#else
-        const double b = av > 0.0 ? av : 0.0;
-        const double bd = xw_gate_pos(b, adi[ks >> 2][ks & 3]);
-#endif
         if (ACT) {   // activation store: row j W + k of the record is the layer input relu(a_j)[k], point-major
           double* __restrict__ rowp = actl + (j * W + 4 * ks) * 16;             // uniform pointer + 32-bit lane offset
           if (4 * ks + 3 < W || 4 * ks + g < W) __builtin_nontemporal_store(b, rowp + aoff);   // (streamed: read once, much later)
         }
-#ifdef XW_DISC_PREFETCH
         double wc[D::MTF], tc[D::TR];
 #pragma unroll
         for (int mt = 0; mt < D::MTF; ++mt) wc[mt] = wn[mt];
@@ -299,25 +289,7 @@ __global__ void __launch_bounds__(256, 2) k_disc_fwd(const double* __restrict__ 
             td[r] = fma(tc[r], bd, td[r]);
           }
         }
-#else
-        if ((ks & 1) == 0) asm volatile("" ::: "memory");   // bound the LDS loads in flight (else all 52 are hoisted -> spills)
-#pragma unroll
-        for (int mt = 0; mt < D::MTF; ++mt) {
-          const double w = sVh[(mt * D::KS + ks) * 64 + lane];
-          nw[mt] = XW_MFMA(w, b, nw[mt]);
-          nd[mt] = XW_MFMA(w, bd, nd[mt]);
-        }
-        if (D::VTAIL) {
-#pragma unroll
-          for (int r = 0; r < D::TR; ++r) {
-            const double w = sT[(4 * ks + g) * D::TR + r];
-            tv[r] = fma(w, b, tv[r]);
-            td[r] = fma(w, bd, td[r]);
-          }
-        }
-#endif
       }
-#ifdef XW_DISC_TAILFOLD
       if (D::VTAIL && D::TR == 2) {
         // the four partials (value / tangent of rows 48, 49) -> ONE register with the totals in the four lane groups
         // (g = 0: row 48, g = 1: row 49, g = 2, 3: the two tangent totals), then the tangent's copy with the halves swapped.
@@ -334,7 +306,6 @@ __global__ void __launch_bounds__(256, 2) k_disc_fwd(const double* __restrict__ 
         nw[D::MT - 1] = tw;
         nd[D::MT - 1] = tdd;
       } else
-#endif
       if (D::VTAIL) {   // row 16 (MT-1) + r of the chain layout lives in lane group g = r, register 0
         d4 tw = xw_zero4(), tdd = xw_zero4();
 #pragma unroll

@@ -139,12 +139,14 @@ class Engine:
         # register file: the stepper's waves, launched next to it, then wait until it drains.  Capping it below the
         # resident slots leaves SIMDs to the stepper chains.  With the kernel's ticket queues (tiles go to whichever wave is
         # free) the generator sub-step is flat between 9/16 and 11/16 of the slots (0.518 - 0.521 ms; 0.527 at 3/4, 0.533 at
-        # 1/2); the static split needed exactly 3/4 (0.5225 ms, 0.58 either side).
+        # 1/2); the static split needed exactly 3/4 (0.5225 ms, 0.58 either side).  Round 3 (leaner test network and stepper
+        # forward): 10/16 -- cycle 1.546 / 1.541 / 1.554 / 1.557 ms at 9/16, 10/16, 11/16, 12/16.
         cus = torch.cuda.get_device_properties(device).multi_processor_count
-        self.v_blocks = int(os.environ.get('XW_V_BLOCKS', '0')) or (11 * 2 * cus) // 16
+        self.v_blocks = int(os.environ.get('XW_V_BLOCKS', '0')) or (10 * 2 * cus) // 16
         # (discriminator sub-step: only the stepper forward and the x-only sweep run beside it, 33 us of SIMD time: 7/8 of the
-        #  slots -- 0.615 ms against 0.638 at 3/4, 0.681 at 15/16, 0.735 at all of them)
-        self.v_blocks_disc = int(os.environ.get('XW_V_BLOCKS_DISC', '0')) or (7 * 2 * cus) // 8
+        #  slots -- 0.615 ms against 0.638 at 3/4, 0.681 at 15/16, 0.735 at all of them; round 3: 13/16 and 14/16 equal
+        #  (cycle 1.537 / 1.538 ms), 15/16 1.626)
+        self.v_blocks_disc = int(os.environ.get('XW_V_BLOCKS_DISC', '0')) or (13 * 2 * cus) // 16
         self._phi_version = 0
         self.streams = [torch.cuda.Stream(device=device) for _ in range(4)]
         # several GPUs on RCCL: the exchanges are device-side calls on the current stream (dist.World.capturable), so a
