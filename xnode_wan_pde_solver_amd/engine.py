@@ -361,10 +361,16 @@ class Engine:
             # (a group that starts at T0: h(X[:, 0, :]) is the start value itself)
             S['h'] = S['start'] if starts_T0 else self.funcs['h'](X[:, 0, :]).detach().to(dev).to(F64).reshape(-1).contiguous()
             S['f'] = _to_LN(self.funcs['f'](X), dev)
-            # distance weight on the v-sample and its gradient (nabla phi = w nabla v + v nabla w, src/loss.py:51-63)
-            XVl = XV.clone().requires_grad_(True)
-            w = domain.func_w(XVl)
-            gw = torch.autograd.grad(w.sum(), XVl)[0] if w.requires_grad else torch.zeros_like(XVl)
+            # distance weight on the v-sample and its gradient (nabla phi = w nabla v + v nabla w, src/loss.py:51-63): in
+            # closed form where the domain offers it (identical to autograd's, ties included), on the first time slice only
+            # where w does not depend on time
+            XVw = XV[:, :1] if getattr(domain, 'time_independent', False) else XV
+            if hasattr(domain, 'func_w_grad'):
+                w, gw = domain.func_w_grad(XVw)
+            else:
+                XVl = XVw.clone().requires_grad_(True)
+                w = domain.func_w(XVl)
+                gw = torch.autograd.grad(w.sum(), XVl)[0] if w.requires_grad else torch.zeros_like(XVl)
         if getattr(domain, 'time_independent', False):
             S['w'] = w[:, 0].detach().to(dev).to(F64).contiguous()
             S['wt'] = None

@@ -227,19 +227,24 @@ class XNODE(nn.Module):
         self.blob = Blob(self, device, slots, total)
         return self.blob
 
-    def start_values(self, inputs):
+    def start_values(self, inputs, starts_at_T0=None):
         """h(x) for groups that start at T0, g(t0, x) for groups that start on the boundary (src/model.py:95-96);
         evaluated on the device `inputs` lives on (host tensors -> bitwise the reference's CPU values)."""
         first = inputs[:, 0, :]
-        if float(inputs[0, 0, 0].detach()) == self.setup['T0']:
+        if starts_at_T0 is None:
+            starts_at_T0 = float(inputs[0, 0, 0].detach()) == self.setup['T0']
+        if starts_at_T0:
             return self.h(first).reshape(-1).double()
         return self.g(first.unsqueeze(1)).reshape(-1).double()
 
-    def forward(self, inputs):
+    def forward(self, inputs, starts_at_T0=None):
+        """starts_at_T0 (optional): the caller knows whether the paths start at T0 -- saves reading inputs[0, 0, 0] back from
+        the device, which waits for everything queued on it (the training loop's diagnostic passes it)"""
         if self.blob is None:
             raise XnwanError('XNODE.bind(device) has not been called')
         dev = self.blob.data.device
-        starts_at_T0 = float(inputs[0, 0, 0].detach()) == self.setup['T0']
+        if starts_at_T0 is None:
+            starts_at_T0 = float(inputs[0, 0, 0].detach()) == self.setup['T0']
         gather = None
         if not starts_at_T0:
             on_boundary = float(torch.max(self.domain.func_w(inputs[:, 0, :].detach().unsqueeze(1)))) < 1e-5
@@ -265,7 +270,7 @@ class XNODE(nn.Module):
                 start = self.start_values(inputs)
                 out = _OdeFn.apply(padded.to(dev), start.to(dev), self, *self.blob.params)
                 return out[:, gather.long().to(dev), :]
-        out = _OdeFn.apply(inputs.to(dev), self.start_values(inputs).to(dev), self, *self.blob.params)
+        out = _OdeFn.apply(inputs.to(dev), self.start_values(inputs, starts_at_T0).to(dev), self, *self.blob.params)
         if inputs.shape[1] == 1 and starts_at_T0:
             return out[:, 0, :]                                   # reference returns [N, 1] here (src/model.py:89-91)
         return out

@@ -150,6 +150,11 @@ class NODE_WAN_solver:
         self.rank_local_sampling = False  # several GPUs: True = every rank draws only its own share of the cube sample
                                           # (sampling.RankCubeLoader: no seed parity across rank counts); False = every
                                           # rank draws the global sample from the shared seed and keeps its slice
+        self.pipeline = True              # single-group domains without a stop hook: nothing in an outer iteration waits for
+                                          # the GPU -- losses, the diagnostic and the best weights of iteration k are read back,
+                                          # written to the side-effect files and compared while iteration k + 1 runs (same
+                                          # values, same files, one iteration later; everything is flushed before train()
+                                          # returns).  False: every sub-iteration is synchronised like the reference's loop
         self.reuse_test_net = True        # v, dv/dt, nabla_x v(t_0) are evaluated once per (phi, sample) and shared by the
                                           # sub-steps of an outer iteration -- bit-identical results (the reference
                                           # recomputes the same values); bench.py times the sub-steps WITHOUT it
@@ -203,13 +208,20 @@ class NODE_WAN_solver:
                 times, xu, xv, xb = comp
                 if not times.is_cuda:
                     self._grid_hint = float(times[0])       # one shared grid: the engine need not read the tensors back
-                mk = lambda x: sampling._paths(times.to(self.device), x.to(self.device))  # noqa: E731
+                td = self._up(times)
+                mk = lambda x: sampling._paths(td, self._up(x))  # noqa: E731
                 return [(mk(xu), mk(xv), mk(xb))]
             return list(points)
         if isinstance(points.interioru, list):
             n = min(len(points.interioru), len(points.boundary))      # same truncation as iterating the loader
             return [(points.interioru[i], points.interiorv[i], points.boundary[i]) for i in range(n)]
         return [(points.interioru, points.interiorv, points.boundary)]
+
+    def _up(self, t):
+        """host -> device; asynchronous when the source is page-locked (Comb_loader.pin)"""
+        if t.is_cuda:
+            return t
+        return t.to(self.device, non_blocking=True) if t.is_pinned() else t.to(self.device)
 
     def _shard(self, points):
         """this rank's contiguous share of every group (dist.py); identity on one GPU"""
@@ -219,7 +231,15 @@ class NODE_WAN_solver:
             return [(du, dv, bd, self.setup['N_r'], self.setup['N_b']) for (du, dv, bd) in points]
         return [self.world.shard_group(du, dv, bd) for (du, dv, bd) in points]
 
-    def _l_norm(self, points, volume):
+    def _l_norm(self, points, volume, as_tensor=False):
+        """the L^p diagnostic of src/training.py:167; as_tensor: a 0-dim float64 device tensor, nothing read back"""
+        if as_tensor:
+            val = self._l_norm_value(points, volume)
+            return (val if torch.is_tensor(val) else torch.tensor(val)).to(device=self.device, dtype=torch.float64).reshape(())
+        val = self._l_norm_value(points, volume)
+        return val.item() if torch.is_tensor(val) else val
+
+    def _l_norm_value(self, points, volume):
         from utils.auxillary_funcs import L_norm
         if self.func_u_sol is None:
             return float('nan')
@@ -230,13 +250,15 @@ class NODE_WAN_solver:
             local = L_norm(X, self.u_net, self.p, self.func_u_sol, volume, points.n_local)
             part = (local.double() ** self.p / volume * (points.n_local / self.setup['N_r'])).reshape(1).to(self.device).contiguous()
             self.world.all_reduce(part)
-            return float((volume * part[0]) ** (1.0 / self.p))
+            return (volume * part[0]) ** (1.0 / self.p)
         if not self.tabulate_on_host or self.device_sampling:
             comp = points.compact() if hasattr(points, 'compact') else None
-            if comp is not None:          # diagnostic entirely on the device
-                X = sampling._paths(comp[0].to(self.device), comp[1].to(self.device))
-                return L_norm(X, self.u_net, self.p, self.func_u_sol, volume, self.setup['N_r']).item()
-        return L_norm(points.interioru, self.u_net, self.p, self.func_u_sol, volume, self.setup['N_r']).item()
+            if comp is not None:          # diagnostic entirely on the device, nothing read back (the grid's first time is
+                X = sampling._paths(self._up(comp[0]), self._up(comp[1]))   # known on the host: no sync in forward)
+                at_T0 = (float(comp[0][0]) == self.setup['T0']) if not comp[0].is_cuda else None
+                u_fn = lambda x: self.u_net(x, starts_at_T0=at_T0)   # noqa: E731
+                return L_norm(X, u_fn, self.p, self.func_u_sol, volume, self.setup['N_r'])
+        return L_norm(points.interioru, self.u_net, self.p, self.func_u_sol, volume, self.setup['N_r'])
 
     def train(self, report=False, report_it=10, show_plt=False):
         threads = torch.get_num_threads()
@@ -262,17 +284,123 @@ class NODE_WAN_solver:
             pool = ThreadPoolExecutor(max_workers=1, initializer=torch.set_num_threads, initargs=(torch.get_num_threads(),))
 
         def draw_ahead(domain, last):
-            after = self._loader(domain)
+            pin = lambda ld: ld.pin() if hasattr(ld, 'pin') else ld     # noqa: E731  (page-locked: asynchronous uploads)
+            after = pin(self._loader(domain))
             if last:
                 return after, None, None
             nxt = self._new_domain()
-            return after, nxt, self._loader(nxt)
+            return after, nxt, pin(self._loader(nxt))
 
         try:
+            if self.pipeline and self.stop is None and not report and hasattr(self._new_domain_probe(), 'interior_x'):
+                return self._iterate_pipelined(past_losses, times, pool, draw_ahead)
             return self._iterate(report, report_it, show_plt, past_losses, times, pool, draw_ahead)
         finally:
             if pool is not None:
                 pool.shutdown(wait=True)
+
+    def _new_domain_probe(self):
+        """the domain CLASS's compact-draw capability, without constructing an instance (construction draws random numbers)"""
+        return self.domain
+
+    # --------------------------------------------------------------------------------------------------------------
+    # the pipelined loop: same work, same values, same files as _iterate below -- but the host never waits for the GPU
+    # inside an outer iteration.  What the reference reads back after every sub-iteration (loss_u.item() for the loss
+    # list and the best-weights rule, L_norm(...).item()) is copied into a small device ring together with a snapshot of
+    # theta per generator sub-iteration; a side stream carries ring row k to pinned host memory behind an event, and the
+    # host processes row k - 1 (JSON files, best_l, torch.save of the snapshot) while the GPU works on iteration k.
+    # --------------------------------------------------------------------------------------------------------------
+    def _iterate_pipelined(self, past_losses, times, pool, draw_ahead):
+        d, dev, eng = self.setup['dim'], self.device, self.engine
+        R, n1, n2 = 4, self.n1, self.n2
+        ring = torch.zeros(R, n1 + 2, dtype=torch.float64, device=dev)          # loss_u x n1, loss_v, L2
+        snaps = torch.zeros(R, n1, eng.Pu, dtype=torch.float64, device=dev)     # theta after every generator sub-iteration
+        host = torch.zeros(R, n1 + 2, dtype=torch.float64).pin_memory()
+        snap_host = torch.zeros(eng.Pu, dtype=torch.float64).pin_memory()
+        done = [torch.cuda.Event() for _ in range(R)]
+        filled = [torch.cuda.Event() for _ in range(R)]
+        rb = torch.cuda.Stream(device=dev)
+        keys = self._state_dict_layout()
+
+        def process(k):
+            """host side of iteration k (its GPU work has finished or is finishing): files, best weights"""
+            r = k % R
+            done[r].synchronize()
+            row = host[r].tolist()
+            for i in range(n1):
+                self.av_l = row[i]
+                self.last_loss_u = row[i]
+                past_losses.append(self.av_l)
+                if self._is_main():
+                    past_losses.write('losses_NODE_' + str(d) + '.json')
+                if self.av_l < self.best_l:
+                    if self._is_main():
+                        with torch.cuda.stream(rb):
+                            snap_host.copy_(snaps[r, i], non_blocking=True)
+                        rb.synchronize()
+                        torch.save(self._state_dict_from(snap_host, keys), 'best_model_weights_NODE.pth')
+                    self.best_l = self.av_l
+            self.last_loss_v = row[n1]
+            times.append(time.time())
+            if self._is_main():
+                with open('L2_NODE_' + str(d) + '.json', 'w') as fh:
+                    json.dump([row[n1 + 1]], fh)
+                times.write('Time_NODE_' + str(d) + '.json')
+
+        nxt_domain = nxt_points = None
+        with torch.cuda.device(dev):
+            for k in range(self.iterations):
+                domain = nxt_domain if nxt_domain is not None else self._new_domain()
+                points = nxt_points if nxt_points is not None else self._loader(domain)
+                nxt_domain = nxt_points = None
+                ahead = pool.submit(draw_ahead, domain, k == self.iterations - 1) if pool is not None else None
+                (du, dv, bd, ng, nbg), = self._shard(self._groups(points))
+                old = self._group_cache[0] if len(self._group_cache) == 1 else None
+                G = eng.load_group(du, dv, bd, domain, ng, nbg, into=old, shared_grid_t0=self._grid_hint)
+                self._group_cache = [G]
+                G.persistent = True
+                r = k % R
+                if k >= R:
+                    done[r].synchronize()                 # (row r was processed R - 1 iterations ago; its copy is long done)
+                for i in range(n1):
+                    eng.begin_substep('u', False)
+                    eng.generator_step(G)
+                    ring[r, i].copy_(eng.loss_u())
+                    snaps[r, i].copy_(eng.theta.data)
+                for _ in range(n2):
+                    eng.begin_substep('v', False)
+                    eng.discriminator_step(G)
+                ring[r, n1].copy_(eng.loss_v())
+                if ahead is not None:
+                    points_after, nxt_domain, nxt_points = ahead.result()
+                else:
+                    points_after = self._loader(domain)
+                ring[r, n1 + 1].copy_(self._l_norm(points_after, domain.V(), as_tensor=True))
+                filled[r].record()
+                with torch.cuda.stream(rb):
+                    rb.wait_event(filled[r])
+                    host[r].copy_(ring[r], non_blocking=True)
+                    done[r].record(rb)
+                if k > 0:
+                    process(k - 1)
+            if self.iterations > 0:
+                process(self.iterations - 1)
+        return past_losses
+
+    def _state_dict_layout(self):
+        """[(state_dict key, index of its parameter in the blob's parameter list)]: tied layers appear under several keys"""
+        blob = self.u_net.module.blob
+        where = {p.data_ptr(): i for i, p in enumerate(blob.params)}
+        return [(k_, where[v.data_ptr()]) for k_, v in self.u_net.state_dict().items()]
+
+    def _state_dict_from(self, flat_host, keys):
+        """u_net.state_dict() as it was when `flat_host` (a host copy of the parameter blob) was taken"""
+        from collections import OrderedDict
+        parts = self.u_net.module.blob.split(flat_host)
+        sd = OrderedDict()
+        for k_, i in keys:
+            sd[k_] = parts[i].clone()
+        return sd
 
     def _iterate(self, report, report_it, show_plt, past_losses, times, pool, draw_ahead):
         d = self.setup['dim']
