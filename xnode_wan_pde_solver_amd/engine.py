@@ -36,9 +36,17 @@ _NOSTREAM = contextlib.nullcontext()      # Engine._side without side streams
 F32, F64 = torch.float32, torch.float64
 
 
+def _d64(x, dev):
+    """x on `dev` as float64; the tensor itself when it already is (two no-op .to() calls cost ~8 us of host time, and a
+    list-domain sample makes ~400 of them)"""
+    if x.dtype == F64 and x.device == dev:
+        return x
+    return x.to(dev).to(F64)
+
+
 def _to_LN(x, dev):
     """[N, L] (any float dtype, any device) -> contiguous float64 [L, N] on dev"""
-    return x.detach().to(dev).to(F64).t().contiguous()
+    return _d64(x.detach(), dev).t().contiguous()
 
 
 class Structure:
@@ -118,6 +126,7 @@ class Engine:
         #    ODE step: the field range of the blob keeps its own step count (xw_adam lag / skip).
         self.pairwise_single_slice = os.environ.get('XW_ELEMENTWISE_SINGLE_SLICE', '0') != '1'
         self.adam_skips_untouched = os.environ.get('XW_ADAM_NO_SKIP', '0') != '1'
+        self.eager_checked = 10 ** 12 if os.environ.get('XW_ALWAYS_CHECK', '0') == '1' else 256
         self.field_range = (self.theta.slots[6][0], self.theta.slots[-2][0])      # Win .. Wo.b (nets._u_slots order)
         self._field_touched = False
         self.adam_v = dict(m=z(self.Pv), v=z(self.Pv), step=torch.zeros(1, dtype=torch.int64, device=device))
@@ -331,29 +340,29 @@ class Engine:
         if XV.shape[1] != L or XV.shape[0] != N:
             raise XnwanError('u- and v-samples of a group must have the same shape')
         S = {}
-        S['t'] = X[0, :, 0].to(dev).to(F64).contiguous()
-        S['xT'] = X[:, 0, 1:].to(dev).to(F64).t().contiguous()
-        S['xvT'] = XV[:, 0, 1:].to(dev).to(F64).t().contiguous()
+        S['t'] = _d64(X[0, :, 0], dev).contiguous()
+        S['xT'] = _d64(X[:, 0, 1:], dev).t().contiguous()
+        S['xvT'] = _d64(XV[:, 0, 1:], dev).t().contiguous()
         # the test network is pointwise on XV: when the paths of a group do not share one time column (late-entry groups
         # of the hourglass: every path has its own entry time at l = 0) it runs in point mode on all L*N points
         S['tpp'] = S['tpp0'] = S['xvT_pts'] = None
         if shared_grid_t0 is None and not bool(torch.all(XV[:, :, 0] == XV[:1, :, 0])):
-            S['tpp'] = XV[:, :, 0].to(dev).to(F64).t().contiguous().reshape(-1)              # time-major: p = l*N + n
-            S['tpp0'] = XV[:, 0, 0].to(dev).to(F64).contiguous()
+            S['tpp'] = _d64(XV[:, :, 0], dev).t().contiguous().reshape(-1)              # time-major: p = l*N + n
+            S['tpp0'] = _d64(XV[:, 0, 0], dev).contiguous()
             S['xvT_pts'] = S['xvT'].unsqueeze(1).expand(d, L, N).reshape(d, L * N).contiguous()
         # start values and their x-gradient (the h -> y0 path of nabla_x u, src/model.py:95)
         if tab is not None:                   # (tabulate_sample: evaluated once for all groups of the sample)
             starts_T0 = bool(tab['starts_T0'])
-            S['start'] = tab['start'].to(dev).to(F64).reshape(-1).contiguous()
-            S['ghT'] = tab['gh'].to(dev).to(F64).t().contiguous()
-            S['h'] = tab['h'].to(dev).to(F64).reshape(-1).contiguous()
+            S['start'] = _d64(tab['start'], dev).reshape(-1).contiguous()
+            S['ghT'] = _d64(tab['gh'], dev).t().contiguous()
+            S['h'] = _d64(tab['h'], dev).reshape(-1).contiguous()
             S['f'] = _to_LN(tab['f'], dev)
             w, gw = tab['w'], tab['gw']
         else:
             X0 = X[:, 0, :].clone().requires_grad_(True)
             starts_T0 = (float(X[0, 0, 0]) if shared_grid_t0 is None else float(shared_grid_t0)) == self.setup['T0']
             s = self.funcs['h'](X0) if starts_T0 else self.funcs['g'](X0.unsqueeze(1)).reshape(-1)
-            S['start'] = s.detach().to(dev).to(F64).reshape(-1).contiguous()
+            S['start'] = _d64(s.detach(), dev).reshape(-1).contiguous()
             if s.requires_grad:
                 S['ghT'] = torch.autograd.grad(s.sum(), X0)[0][:, 1:].to(dev).to(F64).t().contiguous()
             else:
@@ -372,28 +381,28 @@ class Engine:
                 w = domain.func_w(XVl)
                 gw = torch.autograd.grad(w.sum(), XVl)[0] if w.requires_grad else torch.zeros_like(XVl)
         if getattr(domain, 'time_independent', False):
-            S['w'] = w[:, 0].detach().to(dev).to(F64).contiguous()
+            S['w'] = _d64(w[:, 0].detach(), dev).contiguous()
             S['wt'] = None
         else:
             S['w'] = _to_LN(w, dev)
             S['wt'] = _to_LN(gw[:, :, 0], dev)
-        S['w0'] = w[:, 0].detach().to(dev).to(F64).contiguous()
-        S['gwx0T'] = gw[:, 0, 1:].to(dev).to(F64).t().contiguous()
+        S['w0'] = _d64(w[:, 0].detach(), dev).contiguous()
+        S['gwx0T'] = _d64(gw[:, 0, 1:], dev).t().contiguous()
         S['xbT'] = S['start_b'] = S['g'] = S['tb'] = None
         Lb, same_grid, b_T0 = 0, True, False
         if BX is not None:
             Lb = BX.shape[1]
-            S['tb'] = BX[0, :, 0].to(dev).to(F64).contiguous()
+            S['tb'] = _d64(BX[0, :, 0], dev).contiguous()
             same_grid = Lb == L and (shared_grid_t0 is not None or bool(torch.equal(S['tb'], S['t'])))
-            S['xbT'] = BX[:, 0, 1:].to(dev).to(F64).t().contiguous()
+            S['xbT'] = _d64(BX[:, 0, 1:], dev).t().contiguous()
             if tab is not None:
                 b_T0 = bool(tab['b_T0'])
-                S['start_b'] = tab['start_b'].to(dev).to(F64).reshape(-1).contiguous()
+                S['start_b'] = _d64(tab['start_b'], dev).reshape(-1).contiguous()
                 S['g'] = _to_LN(tab['g'], dev)
             else:
                 b_T0 = (float(BX[0, 0, 0]) if shared_grid_t0 is None else float(shared_grid_t0)) == self.setup['T0']
                 sb = self.funcs['h'](BX[:, 0, :]) if b_T0 else self.funcs['g'](BX[:, 0, :].unsqueeze(1)).reshape(-1)
-                S['start_b'] = sb.detach().to(dev).to(F64).reshape(-1).contiguous()
+                S['start_b'] = _d64(sb.detach(), dev).reshape(-1).contiguous()
                 S['g'] = _to_LN(self.funcs['g'](BX), dev)
         st = self.structure
         S['X'] = X.to(dev) if st.c_kappa is None else None      # only read by a general reaction callable c(u, t, x)
@@ -815,10 +824,15 @@ class Engine:
                 # run out): one stream -- the side-stream contexts and events cost more host time than the overlap returns
                 # (cone outer iteration 28.5 -> 25.4 ms, hourglass 57.5 -> 52.4 ms)
                 self.use_streams = False
+                # (operand validation: every launch of the first `eager_checked` eager segments -- a few outer iterations --
+                #  then the engine trusts its own buffers, kernels.TRUSTED; XW_ALWAYS_CHECK=1 keeps validating)
+                self._eager_seen = getattr(self, '_eager_seen', 0) + 1
+                KN.TRUSTED = self._eager_seen > self.eager_checked
                 try:
                     fn(G)
                 finally:
                     self.use_streams = True
+                    KN.TRUSTED = False
                 return
             fn(G)
             return

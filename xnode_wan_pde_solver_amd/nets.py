@@ -238,15 +238,18 @@ class XNODE(nn.Module):
         return self.g(first.unsqueeze(1)).reshape(-1).double()
 
     def forward(self, inputs, starts_at_T0=None):
-        """starts_at_T0 (optional): the caller knows whether the paths start at T0 -- saves reading inputs[0, 0, 0] back from
-        the device, which waits for everything queued on it (the training loop's diagnostic passes it)"""
+        """starts_at_T0 (optional): the caller knows where the paths start -- True: at T0 (start values h), False: on the
+        moving boundary (start values g; the sampler's late-entry groups).  Saves reading inputs[0, 0, 0] / max(w) back from the
+        device, which waits for everything queued on it (the training loop's diagnostic passes it).  None: looked up, and
+        paths that start neither at T0 nor on the boundary take the evaluation path (bound_pad)."""
         if self.blob is None:
             raise XnwanError('XNODE.bind(device) has not been called')
         dev = self.blob.data.device
+        known = starts_at_T0 is not None
         if starts_at_T0 is None:
             starts_at_T0 = float(inputs[0, 0, 0].detach()) == self.setup['T0']
         gather = None
-        if not starts_at_T0:
+        if not starts_at_T0 and not known:
             on_boundary = float(torch.max(self.domain.func_w(inputs[:, 0, :].detach().unsqueeze(1)))) < 1e-5
             if not on_boundary:
                 # evaluation of points that are neither at T0 nor on the boundary (src/model.py:92-106): integrate from T0

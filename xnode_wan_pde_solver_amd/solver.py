@@ -258,6 +258,16 @@ class NODE_WAN_solver:
                 at_T0 = (float(comp[0][0]) == self.setup['T0']) if not comp[0].is_cuda else None
                 u_fn = lambda x: self.u_net(x, starts_at_T0=at_T0)   # noqa: E731
                 return L_norm(X, u_fn, self.p, self.func_u_sol, volume, self.setup['N_r'])
+            groups = points.interioru
+            if isinstance(groups, list) and groups and not groups[0].is_cuda:
+                # list domain: the groups go to the device, func_u_sol is evaluated ONCE on all their points, u_theta group by
+                # group with the start kind read from the host copy (no read-back between the launches)
+                d1 = self.setup['dim'] + 1
+                at0 = iter([float(g[0, 0, 0].detach()) == self.setup['T0'] for g in groups])
+                Xs = [g.detach().to(self.device) for g in groups]
+                sol = self.func_u_sol(torch.cat([x.reshape(-1, 1, d1) for x in Xs], 0)).reshape(-1)
+                sols = iter([s_.view(x.shape[0], x.shape[1]) for s_, x in zip(sol.split([x.shape[0] * x.shape[1] for x in Xs]), Xs)])
+                return L_norm(Xs, lambda x: self.u_net(x, starts_at_T0=next(at0)), self.p, lambda x: next(sols), volume, self.setup['N_r'])
         return L_norm(points.interioru, self.u_net, self.p, self.func_u_sol, volume, self.setup['N_r'])
 
     def train(self, report=False, report_it=10, show_plt=False):
