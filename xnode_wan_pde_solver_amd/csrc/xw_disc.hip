@@ -85,6 +85,8 @@ __device__ __forceinline__ void input_layer(const double* __restrict__ ph, const
 // ------------------------------------------------------------------------------------------------------------------
 #define XW_QMAX 16   // deepest test network whose ReLU masks fit the LDS stash of k_disc_fwd's fused input gradient
 #define XW_VIN_KS 6  // k-steps of the input layer (d <= 24) whose A-fragments k_disc_fwd keeps in LDS (44 KB per block in all:
+#define XW_VIN_KS_WIDE 13  // second instantiation: d <= 52 entirely from LDS (57 KB per block), wider inputs (d = 100: 25 k-steps)
+                           // take their first 13 k-steps from LDS and the rest from global memory
                      // two of its blocks and two blocks of the duo sweep still share a CU's 160 KB)
 
 // DYN: only a wave's first tile is its static one; every later tile comes from ticket counters (one returning atomic per
@@ -103,7 +105,7 @@ __device__ unsigned int xw_disc_queue[XW_DISC_SLOTS][(XW_DISC_NQ + 1) * XW_DISC_
 #ifdef XW_CLOCK_PROBE   // diagnostic build only (tools/probe_disc_clock.py): shader clocks / 100 MHz ticks of every wave's tile loop
 __device__ unsigned long long xw_clock_buf[2 * 4096];
 #endif
-template <int W, bool ACT, bool DYN, bool VINLDS>
+template <int W, bool ACT, bool DYN, int VKS>      // VKS: k-steps of the input layer kept in LDS (0: none)
 __global__ void __launch_bounds__(256, 2) k_disc_fwd(const double* __restrict__ xT, const double* __restrict__ tf,
                                                      const double* __restrict__ tpp, const double* __restrict__ ph, int N,
                                                      int L, int d, int q, double* __restrict__ v, double* __restrict__ vt,
@@ -120,7 +122,8 @@ __global__ void __launch_bounds__(256, 2) k_disc_fwd(const double* __restrict__ 
   // input layer: Vin[:, 1..d] as A-fragments, Vin[:, 0] and Vin.b as row vectors.  From global memory they were 52 loads per
   // tile (the fragment loads put the four lanes of a quad into four rows) and their address arithmetic, re-formed for
   // every tile to keep them out of the spilled loop-invariant set
-  __shared__ double sVin[VINLDS ? XW_VIN_KS * D::MT * 64 : 1];
+  constexpr bool VINLDS = VKS > 0;
+  __shared__ double sVin[VINLDS ? VKS * D::MT * 64 : 1];
   __shared__ double sIn[VINLDS ? 2 * 16 * D::MT : 1];
   __shared__ unsigned int sDone;
   if (DYN && threadIdx.x == 0) sDone = 0;
@@ -144,9 +147,10 @@ __global__ void __launch_bounds__(256, 2) k_disc_fwd(const double* __restrict__ 
       sIn[16 * D::MT + threadIdx.x] = (int)threadIdx.x < W ? ph[o.Vinb + threadIdx.x] : 0.0;
     }
   }
-  const int ksd = (d + 3) / 4;                                 // (VINLDS: <= XW_VIN_KS, checked by the launcher)
+  const int ksd = (d + 3) / 4;
+  const int ksl = ksd < VKS ? ksd : VKS;                       // k-steps served from LDS; ksl .. ksd - 1 from global memory
   if (VINLDS)
-    for (int idx = wave; idx < ksd * D::MT; idx += 4) {
+    for (int idx = wave; idx < ksl * D::MT; idx += 4) {
       const int ks = idx / D::MT, mt = idx - ks * D::MT;
       sVin[idx * 64 + lane] = xw_fragA(ph + o.Vin + 1, o.ldin, W, d, 16 * mt, 4 * ks);
     }
@@ -199,11 +203,17 @@ __global__ void __launch_bounds__(256, 2) k_disc_fwd(const double* __restrict__ 
           ad[mt][r] = sIn[16 * mt + g + 4 * r];
           a[mt][r] = sIn[16 * D::MT + 16 * mt + g + 4 * r] + ad[mt][r] * pt.t;
         }
-      for (int ks = 0; ks < ksd; ++ks) {
+      for (int ks = 0; ks < ksl; ++ks) {
         const int i = 4 * ks + g;
         const double b = i < d ? xT[(long)i * N + pt.n] : 0.0;
 #pragma unroll
         for (int mt = 0; mt < D::MT; ++mt) a[mt] = XW_MFMA(sVin[(ks * D::MT + mt) * 64 + lane], b, a[mt]);
+      }
+      for (int ks = ksl; ks < ksd; ++ks) {                             // (d > 4 VKS: the rest of the input rows)
+        const int i = 4 * ks + g;
+        const double b = i < d ? xT[(long)i * N + pt.n] : 0.0;
+#pragma unroll
+        for (int mt = 0; mt < D::MT; ++mt) a[mt] = XW_MFMA(xw_fragA(pht + o.Vin + 1, o.ldin, W, d, 16 * mt, 4 * ks), b, a[mt]);
       }
     } else {
       input_layer<W>(pht, o, xT, N, d, pt, a, ad);
@@ -1040,11 +1050,11 @@ extern "C" int xw_disc_fwd(const double* xT, const double* t, const double* tpp,
     queue = qbase + (size_t)slot * ((XW_DISC_NQ + 1) * XW_DISC_QSTRIDE);
   }
   static const bool vin_on = [] { const char* e = getenv("XW_DISC_VIN_LDS"); return !(e && e[0] == '0'); }();
-  const bool vin_lds = vin_on && (d + 3) / 4 <= XW_VIN_KS;
+  const int vks = !vin_on ? 0 : ((d + 3) / 4 <= XW_VIN_KS ? XW_VIN_KS : XW_VIN_KS_WIDE);
 #define XW_DISC_FWD2(W_, ACT_, DYN_, VIN_)                                                                                \
   hipLaunchKernelGGL((k_disc_fwd<W_, ACT_, DYN_, VIN_>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, xT, t,  \
                      tpp, phi, N, L, d, q, v, vt, gxv, gtv, ngrad, act, queue)
-#define XW_DISC_FWD(W_, ACT_, DYN_) do { if (vin_lds) XW_DISC_FWD2(W_, ACT_, DYN_, true); else XW_DISC_FWD2(W_, ACT_, DYN_, false); } while (0)
+#define XW_DISC_FWD(W_, ACT_, DYN_) do { if (vks == XW_VIN_KS) XW_DISC_FWD2(W_, ACT_, DYN_, XW_VIN_KS); else if (vks) XW_DISC_FWD2(W_, ACT_, DYN_, XW_VIN_KS_WIDE); else XW_DISC_FWD2(W_, ACT_, DYN_, 0); } while (0)
 #define XW_DISC_FWD_W(W_)                                                                                                 \
   if (act != nullptr) {                                                                                                   \
     if (dyn) XW_DISC_FWD(W_, true, true); else XW_DISC_FWD(W_, true, false);                                              \
