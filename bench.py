@@ -289,13 +289,14 @@ def main():
         cwd = os.getcwd()
         os.makedirs('/tmp/xnwan_bench', exist_ok=True)
         os.chdir('/tmp/xnwan_bench')
-        traj, wall, done = [], 0.0, 0
+        traj, wall, done, calls = [], 0.0, 0, []
         try:
             while done < args.train_iters:
                 tt0 = time.time()
                 S2.train(report=False)
                 torch.cuda.synchronize()
-                wall += time.time() - tt0
+                calls.append(time.time() - tt0)
+                wall += calls[-1]
                 done += 25
                 rng = torch.get_rng_state()
                 traj.append(round(float(rel_err(Xh, S2.u_net, P.func_u_sol, 2, hold.V(), 16384)), 5))
@@ -306,6 +307,8 @@ def main():
             os.chdir(cwd)
         extras['train'] = {'outer_iterations': done, 'stopped_by': 'rel-L2 < 0.01 (reference stopping rule)' if traj[-1] < 0.01 else 'iteration cap',
                            'wall_s': round(wall, 2), 'ms_per_outer_iteration_incl_resampling_diagnostics_io': round(1e3 * wall / done, 2),
+                           # (the first 25-iteration call carries the library load and the graph captures)
+                           'ms_per_outer_iteration_after_the_first_call': round(1e3 * sum(calls[1:]) / (25 * len(calls[1:])), 2) if len(calls) > 1 else None,
                            'rel_l2_heldout_16384': traj[-1], 'rel_l2_heldout_every_25_iterations': traj}
 
     # ---- CPU baseline: the oracle (port of the reference's CPU/PyTorch path), bounded sample ---------------------------

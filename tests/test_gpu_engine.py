@@ -720,3 +720,53 @@ def test_custom_operators_pass_opcheck(golden_dir):
     close(v.squeeze(2), z['gen1/v'], 1e-10, 1e-12)
     torch.library.opcheck(torch.ops.xnwan.testnet_backward, (torch.ones_like(v), XV, vn.blob.data, vn.kwidth, vn.num_layers, True, True),
                           test_utils=('test_schema', 'test_faketensor'))
+
+
+def test_pipelined_training_loop_leaves_exactly_what_the_synchronous_one_does(tmp_path):
+    """solver.pipeline: losses, diagnostic and best weights of iteration k are read back and written while iteration k + 1
+    runs -- the parameters, the loss list, the files and the best weights must be those of the synchronous loop, bit for bit"""
+    import hashlib
+    params = {'alpha': 1e8, 'u_layers': 8, 'u_hidden_dim': 20, 'u_hidden_hidden_dim': 10, 'v_layers': 9, 'v_hidden_dim': 50,
+              'n1': 2, 'n2': 1, 'u_rate': 0.015, 'v_rate': 0.04, 'min_steps': 5, 'adjoint': False, 'solver': 'midpoint',
+              'dim': 4, 'N_t': 9, 'N_r': 200, 'N_b': 100, 'T0': 0, 'T': 1, 'shape_param': [-1, 1], 'iterations': 12,
+              'domain': 'Hypercube'}
+    out = []
+    cwd = os.getcwd()
+    for pipe in (True, False):
+        wd = tmp_path / ('pipe%d' % pipe)
+        wd.mkdir()
+        os.chdir(wd)
+        try:
+            S = make_solver(params, 3)
+            S.pipeline = pipe
+            losses = list(S.train(report=False))
+            torch.cuda.synchronize()
+            best = torch.load('best_model_weights_NODE.pth')
+            out.append((losses, S.engine.theta.data.cpu(), S.engine.phi.data.cpu(), open('losses_NODE_4.json').read(),
+                        open('L2_NODE_4.json').read(), hashlib.sha1(b''.join(v.cpu().numpy().tobytes() for v in best.values())).hexdigest(),
+                        list(best.keys()), S.best_l))
+        finally:
+            os.chdir(cwd)
+    a, b = out
+    assert len(a[0]) >= 12 and a[0] == b[0] and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    assert a[3] == b[3] and a[4] == b[4] and a[5] == b[5] and a[6] == b[6] and a[7] == b[7]
+
+
+def test_poisoned_work_buffers_change_nothing(golden_dir, monkeypatch):
+    """XW_POISON=1 starts every work buffer as NaN: no kernel may read a slot that nobody wrote (a stale but plausible value
+    from the allocator is how such a read hides), and nothing may depend on timing -- the same three sub-steps, bit for bit"""
+    z, params = load(golden_dir, 'ref_d20_small_midpoint')
+    outs = []
+    for poison in ('0', '1'):
+        monkeypatch.setenv('XW_POISON', poison)
+        S = make_solver(params, int(z['seed']))
+        domain, pts = first_sample(S)
+        G = S.engine.load_group(pts.interioru, pts.interiorv, pts.boundary, domain)
+        if poison == '1':
+            assert torch.isnan(G.Y).all() and torch.isnan(G.act).all()
+        S.engine.generator_step(G)
+        S.engine.generator_step(G)
+        S.engine.discriminator_step(G)
+        outs.append((S.engine.theta.data.clone(), S.engine.phi.data.clone(), S.engine.scal.clone()))
+    assert all(torch.isfinite(t_).all() for t_ in outs[1])
+    assert all(torch.equal(a_, b_) for a_, b_ in zip(*outs))

@@ -212,3 +212,82 @@ def test_custom_operators_are_registered():
         assert u.shape == (33, 7, 1) and Y.shape == (7, 20, 33) and u.dtype == torch.float64
         v = torch.ops.xnwan.testnet_forward(torch.empty(5, 3, 6), torch.empty(100, dtype=torch.float64), 50, 9)
         assert v.shape == (5, 3, 1)
+
+
+def test_cube_weight_gradient_in_closed_form_equals_autograd():
+    """Hypercube.func_w_grad: what torch.autograd.grad(func_w(x).sum(), x) returns, entry for entry -- including ties
+    (equal distances to two faces: torch.minimum splits the gradient), points on a face (|.| has slope 0 at 0) and the
+    coordinate torch.min reports when several are equally close"""
+    from xnode_wan_pde_solver_amd import sampling
+    torch.manual_seed(5)
+    dom = sampling.Hypercube([-1, 1], 6, 0, 1, 5)
+    x = dom.interior(3000)
+    x[0, :, 1] = 0.0                  # equally far from both faces of axis 0 ...
+    x[0, :, 2:] = 0.0                 # ... and of every other axis
+    x[1, :, 2] = 1.0                  # on a face
+    x[2, :, 3] = -1.0
+    x[3, :, 1], x[3, :, 2] = 0.5, -0.5        # top of axis 0 as close as bottom of axis 1
+    x[4, :, 1:] = 0.25                        # all axes equally close to the top
+    xl = x.clone().requires_grad_(True)
+    w = dom.func_w(xl)
+    gw, = torch.autograd.grad(w.sum(), xl)
+    w2, g2 = dom.func_w_grad(x)
+    assert torch.equal(w, w2) and torch.equal(gw, g2)
+    xb = dom.boundary(500)
+    xl = xb.clone().requires_grad_(True)
+    gw, = torch.autograd.grad(dom.func_w(xl).sum(), xl)
+    assert torch.equal(gw, dom.func_w_grad(xb)[1])
+
+
+def test_tanh_instruction_sequence_on_the_host():
+    """xw_tanh (csrc/xw_common.h) step by step in numpy with a fused multiply-add emulated in extended precision and a
+    reciprocal good to 2^-23 like v_rcp_f64: the 29-instruction sequence stays within 4e-16 of tanh over [-100, 100]"""
+    import math
+    import struct
+    ld = np.longdouble
+
+    def fma(a, b, c):
+        return np.float64(ld(a) * ld(b) + ld(c))
+    rng = np.random.default_rng(0)
+
+    def xw_tanh(x):
+        am = min(abs(x), 40.0)
+        y = np.float64(-2.0 * am)
+        nb = fma(y, 1.4426950408889634, 6755399441055744.0)
+        n = np.float64(nb - 6755399441055744.0)
+        r = fma(n, -6.93147180369123816490e-01, y)
+        r = fma(n, -1.90821492927058770002e-10, r)
+        p = np.float64(2.08767569878681e-09)
+        for c in (2.505210838544172e-08, 2.755731922398589e-07, 2.7557319223985893e-06, 2.48015873015873e-05, 0.0001984126984126984,
+                  0.001388888888888889, 0.008333333333333333, 0.041666666666666664, 0.16666666666666666, 0.5, 1.0, 1.0):
+            p = fma(p, r, c)
+        lo, hi = struct.unpack('<II', struct.pack('<d', p))
+        nlo = struct.unpack('<II', struct.pack('<d', nb))[0]
+        e = struct.unpack('<d', struct.pack('<II', lo, (hi + ((nlo << 20) & 0xffffffff)) & 0xffffffff))[0]
+        num, den = np.float64(1.0 - e), np.float64(1.0 + e)
+        rc = np.float64((1.0 / den) * (1.0 + rng.uniform(-1, 1) * 2.0 ** -23))
+        rc = fma(fma(-den, rc, 1.0), rc, rc)
+        q = np.float64(num * rc)
+        q = fma(fma(-den, q, num), rc, q)
+        return math.copysign(float(q), x)
+    xs = np.concatenate([rng.uniform(-100, 100, 3000), rng.uniform(-3, 3, 6000), rng.uniform(-1e-3, 1e-3, 500), [0.0, 40.0, -40.0, 39.9, 1e-8]])
+    worst = max(abs(xw_tanh(float(x)) - math.tanh(float(x))) for x in xs)
+    assert worst < 4e-16, worst
+    assert xw_tanh(0.0) == 0.0 and xw_tanh(50.0) == 1.0 and xw_tanh(-50.0) == -1.0
+
+
+def test_boundary_faces_table_is_the_reference_loop():
+    """Hypercube._faces (one scatter) against the reference's 2 d slice assignments (src/dataset.py:265-272), incl. N_b < 2 d"""
+    from xnode_wan_pde_solver_amd import sampling
+    for d, nb in ((3, 40), (5, 64), (20, 4096), (4, 5), (2, 7)):
+        dom = sampling.Hypercube([-1, 2], d, 0, 1, 4)
+        x = torch.zeros(nb, d)
+        block = int(nb / d / 2)
+        cuts = [block * i for i in range(2 * d)] + [nb]
+        for axis in range(d):
+            x[cuts[2 * axis]:cuts[2 * axis + 1], axis] = dom.top
+            x[cuts[2 * axis + 1]:cuts[2 * axis + 2], axis] = dom.bot
+        y = torch.zeros(nb, d)
+        rows, axis, val = dom._faces(nb)
+        y[rows, axis] = val
+        assert torch.equal(x, y), (d, nb)
