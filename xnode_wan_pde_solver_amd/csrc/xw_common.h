@@ -69,6 +69,18 @@ __host__ __device__ inline VOff v_offsets(int d, int W) {
   return o;
 }
 
+// ---- explicitly GLOBAL loads / stores ---------------------------------------------------------------------------------
+// A pointer that went through an `asm volatile("" : "+s"(p))` (laundered, so that address arithmetic stays where it is
+// written) has lost its address space: the compiler then emits FLAT instructions, which count on the LDS counter as well
+// as on the vector-memory one -- every wait for an LDS read behind them becomes lgkmcnt(0) and drags the memory
+// operation's issue into the LDS queue.  These casts say what the pointer is.
+typedef const double __attribute__((address_space(1)))* xw_gcp;
+typedef double __attribute__((address_space(1)))* xw_gp;
+__device__ __forceinline__ double xw_ld_g(const double* p) { return *(xw_gcp)p; }
+__device__ __forceinline__ void xw_st_g(double v, double* p) { *(xw_gp)p = v; }
+__device__ __forceinline__ double xw_ld_nt(const double* p) { return __builtin_nontemporal_load((xw_gcp)p); }
+__device__ __forceinline__ void xw_st_nt(double v, double* p) { __builtin_nontemporal_store(v, (xw_gp)p); }
+
 // ---- lane helpers -------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int xw_lane() { return threadIdx.x & 63; }
 
@@ -76,30 +88,30 @@ __device__ __forceinline__ int xw_lane() { return threadIdx.x & 63; }
 __device__ __forceinline__ double xw_fragA(const double* __restrict__ Mx, int ld, int rows, int cols, int r0, int c0) {
   const int l = xw_lane();
   const int r = r0 + (l & 15), c = c0 + (l >> 4);
-  return (r < rows && c < cols) ? Mx[r * ld + c] : 0.0;
+  return (r < rows && c < cols) ? xw_ld_g(Mx + (r * ld + c)) : 0.0;
 }
 // A-operand fragment of the TRANSPOSE of Mx: element (r0 + i, c0 + k) of Mx^T, i.e. Mx[c0 + k][r0 + i]
 __device__ __forceinline__ double xw_fragAT(const double* __restrict__ Mx, int ld, int rows, int cols, int r0, int c0) {
   const int l = xw_lane();
   const int r = r0 + (l & 15), c = c0 + (l >> 4);
-  return (r < cols && c < rows) ? Mx[c * ld + r] : 0.0;
+  return (r < cols && c < rows) ? xw_ld_g(Mx + (c * ld + r)) : 0.0;
 }
 // the same with the lane id passed in (a laundered copy: keeps the address arithmetic where the caller wants it)
 __device__ __forceinline__ double xw_fragAT_l(const double* __restrict__ Mx, int ld, int rows, int cols, int r0, int c0, int l) {
   const int r = r0 + (l & 15), c = c0 + (l >> 4);
-  return (r < cols && c < rows) ? Mx[c * ld + r] : 0.0;
+  return (r < cols && c < rows) ? xw_ld_g(Mx + (c * ld + r)) : 0.0;
 }
 // A-operand of XW_MFMA4: the 4x4 block (rows r0.., columns c0..) of a row-major matrix, replicated over the lane blocks
 __device__ __forceinline__ double xw_fragA4(const double* __restrict__ Mx, int ld, int rows, int cols, int r0, int c0) {
   const int l = xw_lane();
   const int r = r0 + (l & 3), c = c0 + (l >> 4);
-  return (r < rows && c < cols) ? Mx[r * ld + c] : 0.0;
+  return (r < rows && c < cols) ? xw_ld_g(Mx + (r * ld + c)) : 0.0;
 }
 // the same block of the TRANSPOSE of Mx
 __device__ __forceinline__ double xw_fragAT4(const double* __restrict__ Mx, int ld, int rows, int cols, int r0, int c0) {
   const int l = xw_lane();
   const int r = r0 + (l & 3), c = c0 + (l >> 4);
-  return (r < cols && c < rows) ? Mx[c * ld + r] : 0.0;
+  return (r < cols && c < rows) ? xw_ld_g(Mx + (c * ld + r)) : 0.0;
 }
 // relu of one register: v_max_f64 (+ the compiler's canonicalising v_max in front of it; NaN -> 0 like `x > 0 ? x : 0`).
 // NOT as inline asm: the hazard recogniser does not see into it and issues it right behind the MFMA that writes its
@@ -112,7 +124,7 @@ __device__ __forceinline__ d4 xw_vecD(const double* __restrict__ b, int rows, in
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int i = r0 + g + 4 * r;
-    v[r] = (i < rows) ? b[i] : 0.0;
+    v[r] = (i < rows) ? xw_ld_g(b + i) : 0.0;
   }
   return v;
 }
@@ -123,7 +135,7 @@ __device__ __forceinline__ d4 xw_vecD_strided(const double* __restrict__ b, int 
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int i = r0 + g + 4 * r;
-    v[r] = (i < rows) ? b[(long)i * stride] : 0.0;
+    v[r] = (i < rows) ? xw_ld_g(b + (long)i * stride) : 0.0;
   }
   return v;
 }

@@ -272,7 +272,7 @@ __global__ void __launch_bounds__(256, 2) k_disc_fwd(const double* __restrict__ 
         const double bd = __hiloint2double((sgn & zr) | (~sgn & __double2hiint(adv)), (sgn & zr) | (~sgn & __double2loint(adv)));
         if (ACT) {   // activation store: row j W + k of the record is the layer input relu(a_j)[k], point-major
           double* __restrict__ rowp = actl + (j * W + 4 * ks) * 16;             // uniform pointer + 32-bit lane offset
-          if (4 * ks + 3 < W || 4 * ks + g < W) __builtin_nontemporal_store(b, rowp + aoff);   // (streamed: read once, much later)
+          if (4 * ks + 3 < W || 4 * ks + g < W) xw_st_nt(b, rowp + aoff);   // (streamed: read once, much later)
         }
         double wc[D::MTF], tc[D::TR];
 #pragma unroll
@@ -354,7 +354,7 @@ __global__ void __launch_bounds__(256, 2) k_disc_fwd(const double* __restrict__ 
         if (16 * mt + 4 * r < W) {  // rows 16 mt + 4 r + g >= W only carry zero padding
           const double th = xw_tanh(a[mt][r]);
           if (ACT && (16 * mt + 4 * r + 3 < W || 16 * mt + 4 * r + g < W))
-            __builtin_nontemporal_store(th, actl + (q * W + 16 * mt + 4 * r) * 16 + aoff);   // last rows: tanh(a_q)
+            xw_st_nt(th, actl + (q * W + 16 * mt + 4 * r) * 16 + aoff);   // last rows: tanh(a_q)
           const double vo = sB[16 * D::MT + 16 * mt + g + 4 * r];
           sv += vo * th;
           sd += vo * (1.0 - th * th) * ad[mt][r];
@@ -724,6 +724,12 @@ __global__ void __launch_bounds__(256) k_disc_bwd(const double* __restrict__ xT,
 //   * the dVo partial sums are reduced over the 16 points of a tile before they go to LDS (256 instead of 4096 doubles);
 //   * the input-layer gradient is contracted in groups of 48 input rows (three full tiles);
 // -> 78 KB per block, <= 256 registers per wave: two blocks share a CU and cover each other's barriers.
+#ifdef XW_REC_PROBE     // diagnostic build only (tools/probe_rec_phases.py): shader clocks per phase of every wave of k_disc_rec
+__device__ unsigned long long xw_rec_clock[12 * 2048];
+#define XW_PH(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); phc[i] += t_ - phl; phl = t_; }
+#else
+#define XW_PH(i)
+#endif
 template <int W> struct RecLds {
   typedef VDim<W> D;
   // W = 49..51: short last row tile -- vector-ALU tail + one live 4-row group, 78 KB, two blocks per CU.  Otherwise
@@ -766,6 +772,9 @@ __global__ void __launch_bounds__(256, RecLds<W>::VT ? 2 : 1) k_disc_rec(const d
   const int wave = threadIdx.x >> 6;
   double* myD = lds + S::oD + wave * S::wset;
   double* myR = lds + S::oR + wave * S::wset;
+#ifdef XW_REC_PROBE
+  const unsigned long long ck_in = __builtin_amdgcn_s_memtime(), rt_in = __builtin_amdgcn_s_memrealtime();
+#endif
   const VOff o = v_offsets(d, W);
   const long P = (long)N * L;
   const long nsuper = (P + 63) / 64;
@@ -791,8 +800,37 @@ __global__ void __launch_bounds__(256, RecLds<W>::VT ? 2 : 1) k_disc_rec(const d
   d4 accH[D::MT], accB[D::MT];                       // accB: dVh.b without the ones row (W a multiple of 16)
 #pragma unroll
   for (int ct = 0; ct < D::MT; ++ct) accH[ct] = accB[ct] = xw_zero4();
+  // ---- short last row tile (W = 50): dVh = 48 x 48 core on 16x16x4 tiles + the two edges on 4x4x4 blocks.
+  // As 4 x 4 tiles of 16 x 16 the outer products ran 16 matrix instructions per k-step for 50 x 51 live entries of 64 x 64
+  // (61 %): 7 of the 16 tiles existed for rows 48, 49 / columns 48..50.  Now, per 16 points,
+  //     core  : 9 tiles x 4 k-steps of 66 clocks -- two tiles per wave (accH[0], accH[1]) and tile (2, 2) of the wave's OWN
+  //             16 points (accH[2]: a partial sum per wave, needs no barrier; the four are added once, at the end);
+  //     edges : rows 48..51 x column blocks 0..12 (waves 0, 1) and row blocks 0..11 x columns 48..51 (waves 2, 3) as
+  //             v_mfma_f64_4x4x4 -- the instruction's four blocks are the four groups of four points, so ONE instruction
+  //             is a 4 x 4 block of dVh over all 16 points (18 clocks; the four partials are folded once, at the end).
+  //             The column edge is computed transposed (A = input rows 48..51, B = cotangent rows), so that all four waves
+  //             run the same code: one fixed operand X, 6-7 varying operands V.
+  // 2826 instead of 4224 matrix clocks per 16 points and layer, 706 +- 14 per wave.
+  constexpr bool EDGE = S::VT;
+  constexpr int NE = 7;
+  double accE[NE];
+#pragma unroll
+  for (int e = 0; e < NE; ++e) accE[e] = 0.0;
+  // core tiles: waves 0..2 row band `wave` x column tiles 0, 1 (one cotangent operand, two input operands per k-step); wave 3
+  // column tile 2 x row bands 0, 1, computed transposed (A = input tile 2, B = the two cotangent tiles): three operand
+  // reads per two matrix instructions in every wave, the same code in all of them
+  const int vstart = wave == 1 ? 7 : wave == 3 ? 6 : 0;
+  const int lane16 = (lane & 15) * XW_TSTRIDE + (lane >> 4);                       // 16x16x4 operand: row i, point 4 ks + k
+  const int lane4 = (lane & 3) * XW_TSTRIDE + ((lane >> 2) & 3) * 4 + (lane >> 4);  // 4x4x4 operand: row i, point 4 blk + k
+  const int offC = (wave < 3 ? S::oD + wave * XW_TTILE : S::oR + 2 * XW_TTILE) + lane16;
+  const int offW = (wave < 3 ? S::oR : S::oD) + lane16;
+  const int offX = (wave < 2 ? S::oD : S::oR) + 48 * XW_TSTRIDE + lane4;
+  const int offV = (wave < 2 ? S::oR : S::oD) + vstart * 4 * XW_TSTRIDE + lane4;
   double* slab = gslab + (long)blockIdx.x * o.total;
 
+#ifdef XW_REC_PROBE
+  unsigned long long phc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, phl = __builtin_amdgcn_s_memtime();
+#endif
   for (long st = blockIdx.x; st < nsuper; st += gridDim.x) {
     const Pt pt = locate(st * 4 + wave, P, N, tf, tpp);
     // tile-major record (see k_disc_fwd): this wave's tile is one contiguous stretch, a layer 13 x 512 contiguous bytes
@@ -809,13 +847,15 @@ __global__ void __launch_bounds__(256, RecLds<W>::VT ? 2 : 1) k_disc_rec(const d
         for (int q_ = 0; q_ < 4; ++q_)
           if (q_ < D::LR(mt)) {
             const int row = 16 * mt + 4 * q_ + g;
-            r[mt][q_] = (16 * mt + 4 * q_ + 3 < W || row < W) ? __builtin_nontemporal_load(base + (16 * mt + 4 * q_) * 16 + aoff) : 0.0;
+            r[mt][q_] = (16 * mt + 4 * q_ + 3 < W || row < W) ? xw_ld_nt(base + (16 * mt + 4 * q_) * 16 + aoff) : 0.0;
           }
     };
+    // (requesting the first two layers of the NEXT tile in front of this tile's input-layer gradient, so that a tile does not
+    //  start with a round trip to memory: 13 spilled registers, no gain -- the other wave of the SIMD covers that wait)
     d4 a[D::MT], rnext[D::MT];
     load_layer(nq, a);                                 // tanh(a_q)
     if (nq > 0) load_layer(nq - 1, rnext);
-    const double vb = pt.valid ? (vbar != nullptr ? vbar[pt.p] : 1.0) : 0.0;
+    const double vb = pt.valid ? (vbar != nullptr ? xw_ld_g(vbar + pt.p) : 1.0) : 0.0;
     // ---- output layer: cotangent of a_q, and dVo / dVo.b reduced over the 16 points of the tile
     d4 dl[D::MT];
 #pragma unroll
@@ -835,16 +875,16 @@ __global__ void __launch_bounds__(256, RecLds<W>::VT ? 2 : 1) k_disc_rec(const d
       const double s_ = xw_sum_over_n(vb);
       if (lane == 0) sO[16 * 16 + wave * 4] += s_;
     }
+    XW_PH(6)
     // ---- reverse chain, one layer at a time; the next layer's inputs are in flight meanwhile
 #pragma unroll UNROLL
     for (int sg = nq - 1; sg >= 0; --sg) {
       // the layer's inputs are only needed transposed in LDS and, afterwards, as the ReLU mask: 13 sign bits, not 26 registers
-      unsigned int mask = 0;
+      bool open[4 * D::MT];                           // (lane masks in scalar register pairs: one compare now, one select later)
 #pragma unroll
       for (int mt = 0; mt < D::MT; ++mt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (r < D::LR(mt)) mask |= (rnext[mt][r] > 0.0 ? 1u : 0u) << (4 * mt + r);
+        for (int r = 0; r < 4; ++r) open[4 * mt + r] = r < D::LR(mt) && rnext[mt][r] > 0.0;
 #pragma unroll
       for (int mt = 0; mt < D::MT; ++mt) {
         d4 rr = rnext[mt];
@@ -861,6 +901,7 @@ __global__ void __launch_bounds__(256, RecLds<W>::VT ? 2 : 1) k_disc_rec(const d
         }
       }
       if (sg > 0) load_layer(sg - 1, rnext);                           // in flight while this layer is reversed
+      XW_PH(0)
       // reverse chain: three row tiles on the matrix pipe, rows 16 (MT-1) + r on the vector ALU
       d4 nd[D::MT];
       asm volatile("" ::: "memory");
@@ -887,28 +928,58 @@ __global__ void __launch_bounds__(256, RecLds<W>::VT ? 2 : 1) k_disc_rec(const d
           if (g == r) nd[D::MT - 1][0] = s_;
         }
       }
+      XW_PH(1)
+      if (EDGE) {
+        // tile (2, 2) over the wave's own points: its own transposed tiles, no barrier needed
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+          accH[2] = XW_MFMA(xw_readT(myD + S::toff(2), ks), xw_readT(myR + S::toff(2), ks), accH[2]);
+      }
+      XW_PH(2)
       __syncthreads();
+      XW_PH(3)
+      if (EDGE) {
 #pragma unroll
-      for (int pw = 0; pw < 4; ++pw) {
-        const double* setD = lds + S::oD + pw * S::wset;
-        const double* setR = lds + S::oR + pw * S::wset;
+        for (int pw = 0; pw < 4; ++pw) {
+          const double* set = lds + pw * S::wset;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          if ((ks & 1) == 0) asm volatile("" ::: "memory");
-          // 2 x 2 tiles of dVh per wave: four operand reads feed four MFMAs (a 1 x 4 strip needs five)
-          const double a0 = rec_readT<W>(setD, 2 * wi, ks), a1 = rec_readT<W>(setD, 2 * wi + 1, ks);
-          const double b0 = rec_readT<W>(setR, 2 * wj, ks), b1 = rec_readT<W>(setR, 2 * wj + 1, ks);
-          accH[0] = XW_MFMA(a0, b0, accH[0]);
-          accH[1] = XW_MFMA(a0, b1, accH[1]);
-          accH[2] = XW_MFMA(a1, b0, accH[2]);
-          accH[3] = XW_MFMA(a1, b1, accH[3]);
+          for (int ks = 0; ks < 4; ++ks) {
+            if ((ks & 1) == 0) asm volatile("" ::: "memory");
+            const double xc = set[offC + 4 * ks], w0 = set[offW + 4 * ks], w1 = set[offW + XW_TTILE + 4 * ks];
+            accH[0] = XW_MFMA(xc, w0, accH[0]);
+            accH[1] = XW_MFMA(xc, w1, accH[1]);
+          }
+          asm volatile("" ::: "memory");
+          const double x = set[offX];
+#pragma unroll
+          for (int e = 0; e < NE; ++e)
+            if (e < NE - 1 || wave == 0) accE[e] = XW_MFMA4(x, set[offV + e * 4 * XW_TSTRIDE], accE[e]);
+        }
+      } else {
+#pragma unroll
+        for (int pw = 0; pw < 4; ++pw) {
+          const double* setD = lds + S::oD + pw * S::wset;
+          const double* setR = lds + S::oR + pw * S::wset;
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) {
+            if ((ks & 1) == 0) asm volatile("" ::: "memory");
+            // 2 x 2 tiles of dVh per wave: four operand reads feed four MFMAs (a 1 x 4 strip needs five)
+            const double a0 = rec_readT<W>(setD, 2 * wi, ks), a1 = rec_readT<W>(setD, 2 * wi + 1, ks);
+            const double b0 = rec_readT<W>(setR, 2 * wj, ks), b1 = rec_readT<W>(setR, 2 * wj + 1, ks);
+            accH[0] = XW_MFMA(a0, b0, accH[0]);
+            accH[1] = XW_MFMA(a0, b1, accH[1]);
+            accH[2] = XW_MFMA(a1, b0, accH[2]);
+            accH[3] = XW_MFMA(a1, b1, accH[3]);
+          }
         }
       }
+      XW_PH(4)
       __syncthreads();
+      XW_PH(5)
 #pragma unroll
       for (int mt = 0; mt < D::MT; ++mt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dl[mt][r] = (r < D::LR(mt) && ((mask >> (4 * mt + r)) & 1u)) ? nd[mt][r] : 0.0;
+        for (int r = 0; r < 4; ++r) dl[mt][r] = open[4 * mt + r] ? nd[mt][r] : 0.0;
     }
     // ---- dl = cotangent of a_0.  Input layer: dVin = dl (x) [t; x; 1], 48 input rows at a time
 #pragma unroll
@@ -922,14 +993,16 @@ __global__ void __launch_bounds__(256, RecLds<W>::VT ? 2 : 1) k_disc_rec(const d
     asm volatile("" : "+s"(xl), "+s"(sl), "+v"(gl), "+v"(nl));
 #pragma unroll
     for (int grp = 0; grp < NG; ++grp) {
+      const int nct = d + 2 - 48 * grp >= 33 ? 3 : d + 2 - 48 * grp >= 17 ? 2 : 1;     // live 16-row tiles of this group
 #pragma unroll
       for (int rr = 0; rr < 12; ++rr) {
+        if (rr >= 4 * nct) continue;
         const int cl = gl + 4 * rr;           // local row 0..47 of this group
         const int c = 48 * grp + cl;          // input row: 0 = t, 1..d = x, d+1 = ones
         double val = 0.0;
         if (pt.valid) {
           if (c == 0) val = pt.t;
-          else if (c <= d) val = xl[(long)(c - 1) * N + pt.n];
+          else if (c <= d) val = xw_ld_g(xl + (long)(c - 1) * N + pt.n);
           else if (c == d + 1) val = 1.0;
         }
         myR[S::toff(cl >> 4) + (cl & 15) * XW_TSTRIDE + nl] = val;
@@ -946,7 +1019,8 @@ __global__ void __launch_bounds__(256, RecLds<W>::VT ? 2 : 1) k_disc_rec(const d
         for (int ks = 0; ks < 4; ++ks) {
           const double av = rec_readT<W>(setD, wave, ks);
 #pragma unroll
-          for (int ct = 0; ct < 3; ++ct) accIn[ct] = XW_MFMA(av, rec_readT<W>(setR, ct, ks), accIn[ct]);
+          for (int ct = 0; ct < 3; ++ct)
+            if (ct < nct) accIn[ct] = XW_MFMA(av, rec_readT<W>(setR, ct, ks), accIn[ct]);
         }
       }
       __syncthreads();
@@ -955,29 +1029,71 @@ __global__ void __launch_bounds__(256, RecLds<W>::VT ? 2 : 1) k_disc_rec(const d
       const bool first = st == (long)blockIdx.x;
 #pragma unroll
       for (int ct = 0; ct < 3; ++ct) {
+        if (ct >= nct) continue;
         const int c = 48 * grp + 16 * ct + nl;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = 16 * wave + gl + 4 * r;
           if (row < W && c <= d + 1) {
             double* dst = c <= d ? sl + o.Vin + row * o.ldin + c : sl + o.Vinb + row;
-            *dst = first ? accIn[ct][r] : *dst + accIn[ct][r];
+            xw_st_g(first ? accIn[ct][r] : xw_ld_g(dst) + accIn[ct][r], dst);
           }
         }
       }
     }
+    XW_PH(7)
   }
+#ifdef XW_REC_PROBE
+  const unsigned long long ck_loop = __builtin_amdgcn_s_memtime();
+#endif
 
-  // wave (wi, wj) owns row tiles 2 wi, 2 wi + 1 x column tiles 2 wj, 2 wj + 1 of dVh
+  if (EDGE) {
+    // core tiles: (row band wave, column tile t) / wave 3 transposed: (row band t, column tile 2)
 #pragma unroll
-  for (int t4 = 0; t4 < 4; ++t4) {
-    const int c = 16 * (2 * wj + (t4 & 1)) + n;
+    for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = 16 * (2 * wi + (t4 >> 1)) + g + 4 * r;
-      if (row < W) {
-        if (c < W) slab[o.Vh + row * W + c] = accH[t4][r];
-        else if (c == W) slab[o.Vhb + row] = accH[t4][r];
+      for (int r = 0; r < 4; ++r) {
+        const int row = wave < 3 ? 16 * wave + g + 4 * r : 16 * t2 + n, c = wave < 3 ? 16 * t2 + n : 32 + g + 4 * r;
+        slab[o.Vh + row * W + c] = accH[t2][r];
+      }
+    // tile (2, 2): the four waves' partial sums, through the idle tile area
+    __syncthreads();
+    double* s22 = lds + S::oD;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s22[wave * 256 + (g + 4 * r) * 16 + n] = accH[2][r];
+    __syncthreads();
+    {
+      const int i = threadIdx.x >> 4, j = threadIdx.x & 15;
+      slab[o.Vh + (32 + i) * W + 32 + j] = (s22[threadIdx.x] + s22[256 + threadIdx.x]) + (s22[512 + threadIdx.x] + s22[768 + threadIdx.x]);
+    }
+    // edges: fold the four point groups (lane bits 2, 3); lane j + 16 i of group 0 holds entry (i, j) of the block
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      double s_ = accE[e];
+      s_ += __shfl_xor(s_, 4);
+      s_ += __shfl_xor(s_, 8);
+      if ((e < NE - 1 || wave == 0) && (lane & 12) == 0) {
+        const int i = lane >> 4, j = lane & 3, blk = vstart + e;
+        // waves 0, 1: (cotangent row 48 + i, input row 4 blk + j); waves 2, 3 transposed: (input row 48 + i, cotangent row 4 blk + j)
+        const int row = wave < 2 ? 48 + i : 4 * blk + j, c = wave < 2 ? 4 * blk + j : 48 + i;
+        if (row < W) {
+          if (c < W) slab[o.Vh + row * W + c] = s_;
+          else if (c == W) slab[o.Vhb + row] = s_;
+        }
+      }
+    }
+  } else {
+    // wave (wi, wj) owns row tiles 2 wi, 2 wi + 1 x column tiles 2 wj, 2 wj + 1 of dVh
+#pragma unroll
+    for (int t4 = 0; t4 < 4; ++t4) {
+      const int c = 16 * (2 * wj + (t4 & 1)) + n;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * (2 * wi + (t4 >> 1)) + g + 4 * r;
+        if (row < W) {
+          if (c < W) slab[o.Vh + row * W + c] = accH[t4][r];
+          else if (c == W) slab[o.Vhb + row] = accH[t4][r];
+        }
       }
     }
   }
@@ -1006,6 +1122,17 @@ __global__ void __launch_bounds__(256, RecLds<W>::VT ? 2 : 1) k_disc_rec(const d
       slab[o.Vob] = s_;
     }
   }
+#ifdef XW_REC_PROBE
+  if (lane == 0 && blockIdx.x * 4 + wave < 2048) {
+    unsigned long long* o_ = xw_rec_clock + 12 * (blockIdx.x * 4 + wave);
+    for (int i = 0; i < 8; ++i) o_[i] = phc[i];
+    const unsigned long long ck_out = __builtin_amdgcn_s_memtime();
+    o_[8] = ck_loop - ck_in - (phc[0] + phc[1] + phc[2] + phc[3] + phc[4] + phc[5] + phc[6] + phc[7]);   // prologue
+    o_[9] = ck_out - ck_loop;                                                                          // epilogue
+    o_[10] = ck_out - ck_in;
+    o_[11] = __builtin_amdgcn_s_memrealtime() - rt_in;
+  }
+#endif
 }
 
 int bwd_blocks(long P) {
@@ -1074,6 +1201,12 @@ extern "C" int xw_debug_clock(unsigned long long* host, int nwaves) {
 }
 #endif
 
+#ifdef XW_REC_PROBE
+extern "C" int xw_debug_rec_clock(unsigned long long* host, int nwaves) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(xw_rec_clock), sizeof(unsigned long long) * 12 * nwaves);
+}
+#endif
+
 extern "C" int xw_disc_bwd_slabs(int N, int L) { return bwd_blocks((long)N * L); }
 
 #define XW_DISC_BWD(PARAMS, INGRAD)                                                                                      \
@@ -1089,7 +1222,8 @@ extern "C" int xw_disc_bwd(const double* xT, const double* t, const double* tpp,
   if (!xT || !phi || !gslab || N <= 0 || L <= 0 || d <= 0) return XW_E_ARG;
   if (!tpp && !t) return XW_E_ARG;
   if (tpp && L != 1) return XW_E_ARG;
-  // depth 9 (the reference's YAML) is unrolled, with or without the record; every other depth runs from the record
+  // from the record: any depth (the layer loop is rolled -- unrolled for q = 9 it spilled and was 2 % slower); without a
+  // record only the recomputing kernel of depth 9 (the reference's YAML) exists
   if (!disc_width_ok(W) || q < 0 || d + 2 > 128 || ((q != 9 || W != 50) && act == nullptr)) return XW_E_DIMS;
   if ((long)N * L * 4 >= (1L << 31)) return XW_E_ARG;
   hipStream_t s = (hipStream_t)stream;
@@ -1102,8 +1236,6 @@ extern "C" int xw_disc_bwd(const double* xT, const double* t, const double* tpp,
     hipLaunchKernelGGL((k_disc_rec<W_, Q, NG>), dim3(blocks), dim3(256), 0, s, xT, t, tpp, phi, vbar, N, L, d, gslab, act, q);
     if (W == 64) {
       if (ng == 1) { XW_DISC_REC(64, 0, 1) } else if (ng == 2) { XW_DISC_REC(64, 0, 2) } else { XW_DISC_REC(64, 0, 3) }
-    } else if (q == 9) {
-      if (ng == 1) { XW_DISC_REC(50, 9, 1) } else if (ng == 2) { XW_DISC_REC(50, 9, 2) } else { XW_DISC_REC(50, 9, 3) }
     } else {
       if (ng == 1) { XW_DISC_REC(50, 0, 1) } else if (ng == 2) { XW_DISC_REC(50, 0, 2) } else { XW_DISC_REC(50, 0, 3) }
     }
