@@ -154,8 +154,10 @@ class Engine:
         self.v_blocks = int(os.environ.get('XW_V_BLOCKS', '0')) or (10 * 2 * cus) // 16
         # (discriminator sub-step: only the stepper forward and the x-only sweep run beside it, 33 us of SIMD time: 7/8 of the
         #  slots -- 0.615 ms against 0.638 at 3/4, 0.681 at 15/16, 0.735 at all of them; round 3: 13/16 and 14/16 equal
-        #  (cycle 1.537 / 1.538 ms), 15/16 1.626)
-        self.v_blocks_disc = int(os.environ.get('XW_V_BLOCKS_DISC', '0')) or (13 * 2 * cus) // 16
+        #  (cycle 1.537 / 1.538 ms), 15/16 1.626; with the record stored through global instead of flat instructions the
+        #  forward is 8 % shorter and the stepper's chain is what the sub-step waits for: 12/16 -- discriminator sub-step
+        #  0.586 / 0.562 / 0.566 / 0.569 / 0.654 ms at 11..15 sixteenths, tools/sweep_caps.py)
+        self.v_blocks_disc = int(os.environ.get('XW_V_BLOCKS_DISC', '0')) or (12 * 2 * cus) // 16
         self._phi_version = 0
         self.streams = [torch.cuda.Stream(device=device) for _ in range(4)]
         # several GPUs on RCCL: the exchanges are device-side calls on the current stream (dist.World.capturable), so a
