@@ -500,8 +500,12 @@ if __name__ == '__main__':
     ap.add_argument('--round2', action='store_true', help='only the fixtures added in round 2 (BASELINE configs[2], configs[4])')
     ap.add_argument('--round3', action='store_true', help='only the fixtures added / regenerated in round 3 (natural group pairing on the '
                     'ball domains, d = 100, the cone trajectory)')
+    ap.add_argument('--traj-hourglass', action='store_true', help='only the hourglass trajectory fixture (round 3, second ball domain)')
     args = ap.parse_args()
     torch.set_num_threads(4)
+    if args.traj_hourglass:
+        sphere_trajectory('ref_traj_hourglass_ex43_d3_seed1', 'NSphere_THourglass', 3, 256, 128, 10, 1, 60)
+        sys.exit(0)
     if args.round3:
         # BASELINE configs[3] shape family: d = 100, N_t = 32 (N small enough for the reference's a[d,d,N,L] table: 20 MB)
         one_iteration('ref_d100_small_midpoint', 100, 16, 64, 32, 5, 'midpoint', False, shape_param=[-1.0, 1.0])
@@ -512,6 +516,7 @@ if __name__ == '__main__':
         sphere_groups('ref_hourglass_ex43_d10_groups', 'NSphere_THourglass', 10, 384, 120, 12, 2, 'configs.Ex4_3_funcs')
         # trained error on a ball domain through the reference's own train()
         sphere_trajectory('ref_traj_cone_ex43_d3_seed0', 'NSphere_TCone', 3, 256, 128, 10, 0, 100)
+        sphere_trajectory('ref_traj_hourglass_ex43_d3_seed1', 'NSphere_THourglass', 3, 256, 128, 10, 1, 60)
         sys.exit(0)
     if args.round2 or not args.only_traj:
         # BASELINE configs[2] shape family: d = 50, N_t = 64 (small N so that the reference runs in seconds)

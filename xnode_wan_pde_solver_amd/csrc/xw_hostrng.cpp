@@ -1,0 +1,74 @@
+// Host-side helper of the samplers (src/dataset.py:248-272: every sample is torch.rand / uniform_ on torch's global CPU
+// generator, and "same seeds" means the same stream): float32 uniform fills straight from the generator's state blob.
+//
+// torch's CPU uniform_ walks a scalar mt19937 (at::mt19937, ATen/core/MT19937RNGEngine.h) element by element: 2.8 ns per
+// number, and a training iteration draws 0.66 M of them on one thread in the reference's order -- the floor of train() once
+// the GPU side is pipelined.  Here the 624-word state is regenerated and tempered in vectorisable loops and the
+// numbers are converted in blocks: same words, same order, same arithmetic as at::uniform_real_distribution<float>
+// ((y & (2^24 - 1)) * 2^-24 * (to - from) + from in float; `fused` says whether the last two operations are one fma -- the
+// caller finds out which by comparing with torch once at import and falls back to torch if neither matches).
+//
+// State blob = torch.get_rng_state() (CPUGeneratorImplStateLegacy, 5056 bytes):
+//   u64 seed | i32 left | i32 seeded | u64 next | u64 state[624] (32-bit words) | normal-distribution cache (untouched)
+#include <cstdint>
+#include <cstring>
+#include <cmath>
+
+namespace {
+constexpr int N = 624, M = 397;
+constexpr uint32_t UPPER = 0x80000000u, LOWER = 0x7fffffffu, MATRIX = 0x9908b0dfu;
+
+inline uint32_t twist(uint32_t u, uint32_t v) { return (((u & UPPER) | (v & LOWER)) >> 1) ^ ((v & 1u) ? MATRIX : 0u); }
+
+// the three classic loops of the regeneration: no loop-carried dependence shorter than M / N - M words, so they vectorise
+__attribute__((target_clones("avx2", "default"))) void regenerate(uint32_t* s) {
+  for (int j = 0; j < N - M; ++j) s[j] = s[j + M] ^ twist(s[j], s[j + 1]);
+  for (int j = N - M; j < N - 1; ++j) s[j] = s[j + M - N] ^ twist(s[j], s[j + 1]);
+  s[N - 1] = s[M - 1] ^ twist(s[N - 1], s[0]);
+}
+
+__attribute__((target_clones("avx2", "default"))) void emit(const uint32_t* s, float* out, int k, float span, float from, int fused) {
+  if (fused) {
+    for (int i = 0; i < k; ++i) {
+      uint32_t y = s[i];
+      y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
+      out[i] = __builtin_fmaf((float)(y & 0xffffffu) * 5.9604644775390625e-8f, span, from);
+    }
+  } else {
+    for (int i = 0; i < k; ++i) {
+      uint32_t y = s[i];
+      y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
+      const float x = (float)(y & 0xffffffu) * 5.9604644775390625e-8f * span;
+      out[i] = x + from;
+    }
+  }
+}
+}  // namespace
+
+extern "C" int xw_mt19937_uniform_f32(void* state_blob, long blob_bytes, float* out, long n, float from, float to, int fused) {
+  if (!state_blob || blob_bytes < 24 + 8 * N || (!out && n > 0) || n < 0) return -2;
+  uint8_t* blob = static_cast<uint8_t*>(state_blob);
+  int32_t left, seeded;
+  uint64_t next;
+  std::memcpy(&left, blob + 8, 4);
+  std::memcpy(&seeded, blob + 12, 4);
+  std::memcpy(&next, blob + 16, 8);
+  if (!seeded || left < 1 || left > N || next > (uint64_t)N) return -2;
+  uint32_t s[N];
+  uint64_t w;
+  for (int j = 0; j < N; ++j) { std::memcpy(&w, blob + 24 + 8 * j, 8); s[j] = (uint32_t)w; }
+  const float span = to - from;
+  long done = 0;
+  while (done < n) {
+    // at::mt19937::operator(): if (--left == 0) next_state() [left = 624, next = 0]; y = state[next++]
+    if (left == 1) { regenerate(s); left = N + 1; next = 0; }
+    const long avail = left - 1;
+    const int k = (int)(n - done < avail ? n - done : avail);
+    emit(s + next, out + done, k, span, from, fused);
+    next += (uint64_t)k; left -= k; done += k;
+  }
+  std::memcpy(blob + 8, &left, 4);
+  std::memcpy(blob + 16, &next, 8);
+  for (int j = 0; j < N; ++j) { w = s[j]; std::memcpy(blob + 24 + 8 * j, &w, 8); }
+  return 0;
+}
