@@ -244,6 +244,14 @@ int xw_comm_init(const unsigned char* id128, int nranks, int rank, void** comm);
 int xw_allreduce(double* buf, int count, void* comm, void* stream);
 int xw_comm_destroy(void* comm);
 
+/* ---- host-side helper of the samplers (no GPU involved) ---------------------------------------------------------------
+ * float32 uniform fill straight from torch's CPU generator state (torch.get_rng_state(), 5056 bytes: at::mt19937, legacy state
+ * layout): the numbers, their order and the state left behind are those of Tensor.uniform_(from, to) on the default
+ * generator (src/dataset.py:248-272 draws every sample that way: "same seeds" = this stream), 8 x faster than the scalar
+ * walk.  fused != 0: the final scale-and-shift is one fma (what torch's build does on x86-64; the caller verifies against
+ * torch once and falls back to torch otherwise).  Returns 0, or XW_E_ARG for a blob that is not such a state. */
+int xw_mt19937_uniform_f32(void* state_blob, long blob_bytes, float* out, long n, float from, float to, int fused);
+
 #ifdef __cplusplus
 }
 #endif

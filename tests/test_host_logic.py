@@ -291,3 +291,34 @@ def test_boundary_faces_table_is_the_reference_loop():
         rows, axis, val = dom._faces(nb)
         y[rows, axis] = val
         assert torch.equal(x, y), (d, nb)
+
+
+def test_native_uniform_fill_is_torchs_stream():
+    """xw_mt19937_uniform_f32 (csrc/xw_hostrng.cpp) behind sampling._uniform_fill: values, order and the generator state left
+    behind are those of Tensor.uniform_ on the default CPU generator -- across regeneration boundaries of the 624-word state,
+    from any position in it, for ranges that round differently with and without a fused multiply-add"""
+    from xnode_wan_pde_solver_amd import sampling
+    fill = sampling._UniformFill()
+    fill(torch.empty(8), 0.0, 1.0)
+    assert fill.mode in (0, 1), 'the native fill did not reproduce torch on this machine (it would silently fall back)'
+    torch.manual_seed(99)
+    torch.rand(311)                                   # somewhere inside a state block
+    for n, lo, hi in ((2048, -1.0, 1.0), (81920, -1.0, 1.0), (4097, 0.25, 7.5), (2671, -3.0, -1.0), (624 * 5, 0.0, 1.0), (100003, -0.1, 0.3)):
+        s0 = torch.get_rng_state()
+        a = torch.empty(n).uniform_(lo, hi)
+        s1 = torch.get_rng_state()
+        torch.set_rng_state(s0)
+        b = fill(torch.empty(n), lo, hi)
+        assert torch.equal(a, b) and torch.equal(s1, torch.get_rng_state()), (n, lo, hi)
+        torch.randn(3)                                # the normal cache in the state blob is carried through untouched
+    # small, non-float32 and non-contiguous tensors take torch's own path -- same stream either way
+    s0 = torch.get_rng_state()
+    a = [torch.empty(10).uniform_(0, 1), torch.empty(5000, dtype=torch.float64).uniform_(0, 1)]
+    torch.set_rng_state(s0)
+    b = [fill(torch.empty(10), 0, 1), fill(torch.empty(5000, dtype=torch.float64), 0, 1)]
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+    # a blob that is not a generator state is refused
+    from xnode_wan_pde_solver_amd._lib import lib
+    junk = torch.zeros(5056, dtype=torch.uint8)
+    assert lib.xw_mt19937_uniform_f32(junk.data_ptr(), junk.numel(), torch.empty(4).data_ptr(), 4, 0.0, 1.0, 1) < 0
+    assert lib.xw_mt19937_uniform_f32(s0.data_ptr(), 100, torch.empty(4).data_ptr(), 4, 0.0, 1.0, 1) < 0

@@ -47,6 +47,7 @@ SIGNATURES = {
     'xw_disc_gradx': [c_f32p, c_f32p, c_f32p, c_f64p, c_f64p, c_int, c_int, c_int, c_int, c_f64p, c_f64p, c_vp],
     'xw_disc_bwd_slabs': [c_int, c_int],
     'xw_disc_bwd': [c_f32p, c_f32p, c_f32p, c_f64p, c_f64p, c_int, c_int, c_int, c_int, c_int, c_f64p, c_f64p, c_vp],
+    'xw_mt19937_uniform_f32': [c_vp, ctypes.c_long, c_vp, ctypes.c_long, ctypes.c_float, ctypes.c_float, c_int],
     'xw_weak_partials': [c_f64p, c_f64p, c_f64p, c_f64p, c_int, c_f64p, c_f64p, c_f64p, c_f64p, c_f64p, c_f64p, c_f64p,
                          c_f64p, c_int, c_f64p, c_dbl, c_f64p, c_f64p, c_f64p, c_int, c_dbl, c_int, c_int, c_dbl, c_dbl, c_f64p, c_f64p,
                          c_int, c_int, c_dbl, c_dbl, c_dbl, c_dbl, c_i64p, c_vp],

@@ -21,13 +21,12 @@ constexpr uint32_t UPPER = 0x80000000u, LOWER = 0x7fffffffu, MATRIX = 0x9908b0df
 inline uint32_t twist(uint32_t u, uint32_t v) { return (((u & UPPER) | (v & LOWER)) >> 1) ^ ((v & 1u) ? MATRIX : 0u); }
 
 // the three classic loops of the regeneration: no loop-carried dependence shorter than M / N - M words, so they vectorise
-__attribute__((target_clones("avx2", "default"))) void regenerate(uint32_t* s) {
+static inline __attribute__((always_inline)) void regenerate_body(uint32_t* s) {
   for (int j = 0; j < N - M; ++j) s[j] = s[j + M] ^ twist(s[j], s[j + 1]);
   for (int j = N - M; j < N - 1; ++j) s[j] = s[j + M - N] ^ twist(s[j], s[j + 1]);
   s[N - 1] = s[M - 1] ^ twist(s[N - 1], s[0]);
 }
-
-__attribute__((target_clones("avx2", "default"))) void emit(const uint32_t* s, float* out, int k, float span, float from, int fused) {
+static inline __attribute__((always_inline)) void emit_body(const uint32_t* s, float* out, int k, float span, float from, int fused) {
   if (fused) {
     for (int i = 0; i < k; ++i) {
       uint32_t y = s[i];
@@ -42,6 +41,19 @@ __attribute__((target_clones("avx2", "default"))) void emit(const uint32_t* s, f
       out[i] = x + from;
     }
   }
+}
+// two builds of the loops, picked once by what the CPU has (AVX2 + FMA: 8-wide, the fused form is one instruction;
+// baseline x86-64: SSE2, the fused form goes through libm's exact fmaf)
+__attribute__((target("avx2,fma"))) void regenerate_v3(uint32_t* s) { regenerate_body(s); }
+__attribute__((target("avx2,fma"))) void emit_v3(const uint32_t* s, float* out, int k, float span, float from, int fused) {
+  emit_body(s, out, k, span, from, fused);
+}
+void regenerate_v1(uint32_t* s) { regenerate_body(s); }
+void emit_v1(const uint32_t* s, float* out, int k, float span, float from, int fused) { emit_body(s, out, k, span, from, fused); }
+const bool wide = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("fma");
+inline void regenerate(uint32_t* s) { wide ? regenerate_v3(s) : regenerate_v1(s); }
+inline void emit(const uint32_t* s, float* out, int k, float span, float from, int fused) {
+  wide ? emit_v3(s, out, k, span, from, fused) : emit_v1(s, out, k, span, from, fused);
 }
 }  // namespace
 
