@@ -30,6 +30,16 @@ import torch
 
 from . import kernels as KN
 from ._lib import XnwanError
+from .sampling import HIP_HOST_LOCK
+
+# Every captured sub-step graph of the process, kept alive until it exits.  On this stack (ROCm 7.2 runtime inside the
+# PyTorch 2.10 wheel) destroying the executable of a multi-branch graph -- which is what Python's garbage collector does to
+# the graphs of a solver that went out of scope -- leaves the runtime's per-graph stream bookkeeping in a state in which a
+# LATER launch of another, live graph dereferences a dead stream: SIGSEGV in hip::Graph::UpdateStreams under
+# hipGraphLaunch (rocgdb backtrace, round 3; it took a particular sequence of 27 tests to line the collector up with a
+# replay).  Collecting before a new engine captures does not help; not destroying does.  A graph is a few dozen kernel
+# nodes and holds no sample buffers (those belong to the group), so the cost of keeping it is small.
+_KEPT_GRAPHS = []
 
 _NOSTREAM = contextlib.nullcontext()      # Engine._side without side streams
 
@@ -846,7 +856,8 @@ class Engine:
             torch.cuda.synchronize()
             try:
                 # thread_local: other threads (the RCCL watchdog polls events) must not invalidate the capture
-                with torch.cuda.graph(g, stream=self._capture_stream(), capture_error_mode='thread_local'):
+                # (HIP_HOST_LOCK: no page-locked allocation of the sampling helper thread during a capture or a launch)
+                with HIP_HOST_LOCK, torch.cuda.graph(g, stream=self._capture_stream(), capture_error_mode='thread_local'):
                     fn(G)
             except Exception as exc:
                 # Capture refused (typically a user callable that syncs with the host or builds CPU tensors): THIS segment
@@ -864,9 +875,11 @@ class Engine:
                     fn(G)                         #  running fn again would apply a second optimiser update)
                 return
             G.graphs[key] = g
+            _KEPT_GRAPHS.append(g)                # (never destroyed: see _KEPT_GRAPHS)
             if ran_eager:
                 return                            # (the eager pass above was this call's step; the capture only recorded)
-        g.replay()
+        with HIP_HOST_LOCK:
+            g.replay()
 
     def _capture_stream(self):
         if not hasattr(self, '_cap'):

@@ -15,6 +15,7 @@ Sampling stays on the host RNG (torch CPU generator) -- it is O(N d) work per ou
 draw-for-draw identical to the reference for "same seeds" parity; the engine uploads only what the kernels need.
 """
 import math
+import threading
 from itertools import groupby
 
 import numpy as np
@@ -22,10 +23,19 @@ import torch
 from torch.utils.data import Dataset
 
 
+HIP_HOST_LOCK = threading.Lock()
+"""Held by whoever allocates page-locked host memory or captures / launches a HIP graph.  The training loop stages the next
+sample on a helper thread while the main thread captures and replays sub-step graphs; a hipHostMalloc that coincides with a
+graph capture or launch in another thread was followed (once, in a test run of round 3, right after the draws had become
+three times faster) by a segmentation fault inside hipGraphLaunch.  The two are never concurrent now; the lock is
+uncontended except during a ring's first use."""
+
+
 class _PinPool:
     """page-locked staging buffers, a ring per (shape, dtype).  pin_memory() allocates (1 ms for the three tensors of a
     cube sample); copying into a buffer that already exists is 30 us.  A buffer comes around again after RING uses -- four
-    outer iterations of the training loop, whose uploads are long done by then."""
+    outer iterations of the training loop, whose uploads are long done by then.  The whole ring of a shape is allocated at
+    its first use, under HIP_HOST_LOCK."""
     RING = 16
 
     def __init__(self):
@@ -33,12 +43,13 @@ class _PinPool:
 
     def stage(self, t):
         key = (tuple(t.shape), t.dtype)
-        ring = self.bufs.setdefault(key, [])
+        ring = self.bufs.get(key)
+        if ring is None:
+            with HIP_HOST_LOCK:
+                ring = self.bufs[key] = [torch.empty(t.shape, dtype=t.dtype).pin_memory() for _ in range(self.RING)]
         i = self.pos.get(key, 0)
-        if len(ring) < self.RING:
-            ring.append(torch.empty(t.shape, dtype=t.dtype).pin_memory())
-        buf = ring[i % len(ring)] if len(ring) == self.RING else ring[-1]
         self.pos[key] = i + 1
+        buf = ring[i % self.RING]
         buf.copy_(t)
         return buf
 

@@ -21,6 +21,7 @@ from itertools import product
 import torch
 
 from . import nets, sampling
+from .sampling import HIP_HOST_LOCK
 from ._lib import XnwanError
 from .engine import Engine
 from .kernels import adam as _adam_kernel
@@ -325,8 +326,9 @@ class NODE_WAN_solver:
         R, n1, n2 = 4, self.n1, self.n2
         ring = torch.zeros(R, n1 + 2, dtype=torch.float64, device=dev)          # loss_u x n1, loss_v, L2
         snaps = torch.zeros(R, n1, eng.Pu, dtype=torch.float64, device=dev)     # theta after every generator sub-iteration
-        host = torch.zeros(R, n1 + 2, dtype=torch.float64).pin_memory()
-        snap_host = torch.zeros(eng.Pu, dtype=torch.float64).pin_memory()
+        with HIP_HOST_LOCK:
+            host = torch.zeros(R, n1 + 2, dtype=torch.float64).pin_memory()
+            snap_host = torch.zeros(eng.Pu, dtype=torch.float64).pin_memory()
         done = [torch.cuda.Event() for _ in range(R)]
         filled = [torch.cuda.Event() for _ in range(R)]
         rb = torch.cuda.Stream(device=dev)
