@@ -341,14 +341,18 @@ class NSphere_THourglass(_NSphereBase):
         before re-entry pieces of the same length."""
         pts = self._ball(N_r)
         L = self.N_t
-        tcol = self.times.repeat(N_r, 1).unsqueeze(2)
-        P = torch.from_numpy(pts).t().unsqueeze(1).repeat(1, L, 1)
-        early = torch.le(tcol, self._half())
-        bound = torch.zeros_like(P[:, :, 0]).unsqueeze(2)
-        bound[early] = self.r * ((self.T - self.T0) - tcol)[early].double()
-        bound[~early] = self.r * tcol[~early].double()
-        inside = (torch.sqrt(torch.sum(P ** 2, 2)).unsqueeze(2) < bound).squeeze(2)
-        paths = torch.cat((tcol, P), 2)
+        # The reference materialises every path as [N, L, 1 + d] float64 and takes norms, bounds and masks on that tensor
+        # (src/dataset.py:88-96).  A path is one point repeated over the time grid: ONE norm per path and one bound per
+        # time index give the same mask bit for bit (same reduction over the same d contiguous numbers; the bound is
+        # float32 arithmetic on the float32 grid, then widened, as there), and the groups are assembled from [N, d] and [L]
+        # directly -- 15 MB of traffic per sample instead of 100.
+        X = torch.from_numpy(pts).t().contiguous()                                        # [N, d] float64
+        t32 = self.times
+        early = torch.le(t32, self._half())
+        bound = torch.where(early, (self.r * ((self.T - self.T0) - t32)).double(), (self.r * t32).double())   # [L]
+        nrm = torch.sqrt(torch.sum(X ** 2, 1))
+        inside = nrm.view(N_r, 1) < bound.view(1, L)
+        t64 = t32.double()
         out = ~inside
         any_out = out.any(1)
         idx = torch.arange(L).expand(N_r, L)
@@ -358,20 +362,23 @@ class NSphere_THourglass(_NSphereBase):
         n_late = torch.where(any_out, L - last_out - 1, torch.zeros_like(last_out))
         if bool((out.sum(1) != (L - n_first - n_late)).any()):
             raise RuntimeError('a sampled path leaves the hourglass more than once')        # (the reference's split would raise)
+
+        def piece(ks, lo, hi):          # samples lo .. hi - 1 of the paths ks, [len(ks), hi - lo, 1 + d]
+            k, n = ks.shape[0], hi - lo
+            return torch.cat((t64[lo:hi].view(1, n, 1).expand(k, n, 1), X[ks].view(k, 1, -1).expand(k, n, X.shape[1])), 2)
         # entry point of the re-entering pieces on the moving boundary: time |x| / r
-        X = paths[:, 0, 1:]
         t_in = torch.sqrt(torch.sum(X[any_out] ** 2, 1)) / self.r
         entry = torch.cat((t_in.view(-1, 1, 1), X[any_out].unsqueeze(1)), 2)               # [n_out, 1, 1 + d]
         late_rows = any_out.nonzero().view(-1)
         groups_first, groups_late = [], []
         for ell in sorted(set(n_first.tolist())):
             ks = (n_first == ell).nonzero().view(-1)
-            groups_first.append(paths[ks, :ell])
+            groups_first.append(piece(ks, 0, ell))
         nl = n_late[late_rows]
         for ell in sorted(set(nl.tolist())):
             sel = (nl == ell).nonzero().view(-1)
             ks = late_rows[sel]
-            groups_late.append(torch.cat((entry[sel], paths[ks, L - ell:]), 1))
+            groups_late.append(torch.cat((entry[sel], piece(ks, L - ell, L)), 1))
         return sorted([*groups_first, *groups_late], key=lambda g: g.shape[1])
 
     def boundary(self, N_b):
