@@ -12,7 +12,8 @@
 //                (shared by the 4 waves of a block, two waves per SIMD), rows 48, 49 on the vector ALU; activations never
 //                leave the chain layout.  HBM traffic: x, t in, v, dv/dt out -- plus, on request, the record of layer
 //                inputs (500 doubles per point) that k_disc_rec reads instead of recomputing the forward.
-//   k_disc_rec : parameter gradient from that record: reverse chain + MFMA outer products, 78 KB of LDS, two blocks/CU.
+//   k_disc_rec : parameter gradient from that record: reverse chain + MFMA outer products (48 x 48 core on 16x16x4 tiles, the
+//                two edges of the 50 x 51 matrix on 4x4x4 blocks), 78 KB of LDS, two blocks/CU.
 //   k_disc_bwd : recomputes the forward for a tile of 16 points per wave (activations stay in registers), runs the
 //                reverse chain with Vh^T fragments from LDS, and accumulates  dVh += delta_{j+1} (x) relu(a_j)  as MFMA
 //                outer products over the points (LDS transpose; 4 waves of a block own one 16-row band of dVh each).
@@ -377,16 +378,32 @@ __global__ void __launch_bounds__(256, 2) k_disc_fwd(const double* __restrict__ 
       int ll = lane;                         // (the lane-offset part of those addresses is loop-invariant too: a copy of the
       asm volatile("" : "+v"(ll));           //  lane id the compiler cannot see through keeps it here as well)
       d4 (&dl)[D::MT] = a;
+      // (Gathering the A-fragments of Vh^T from the forward fragments in LDS -- element Vh[r][c] sits in fragment (r >> 4, c >> 2)
+      //  at lane (r & 15) + 16 (c & 3), so a fragment of the transpose is one ds_read with an immediate offset plus a fixed lane
+      //  part -- was built and is 8-way bank-conflicted: a lone gradient tile took 36 us more than a plain one, against 42 us
+      //  with the loads inside the k-step and 29 us with the L2 loads one k-step ahead as below; tools/gradtile.py.)
+      auto fragT = [&](int mt, int ks) -> double { return xw_fragAT_l(phg + o.Vh, W, W, W, 16 * mt, 4 * ks, ll); };
       for (int j = q - 1; j >= 0; --j) {
         d4 nd[D::MT];
 #pragma unroll
         for (int mt = 0; mt < D::MT; ++mt) nd[mt] = xw_zero4();
+        // (the fragments of k-step ks + 1 are requested before the matrix instructions of k-step ks)
+        double fn[D::MT];
+#pragma unroll
+        for (int mt = 0; mt < D::MT; ++mt) fn[mt] = fragT(mt, 0);
 #pragma unroll
         for (int ks = 0; ks < D::KS; ++ks) {
           const double b = dl[ks >> 2][ks & 3];
+          double fc[D::MT];
+#pragma unroll
+          for (int mt = 0; mt < D::MT; ++mt) fc[mt] = fn[mt];
+          if (ks + 1 < D::KS) {
+#pragma unroll
+            for (int mt = 0; mt < D::MT; ++mt) fn[mt] = fragT(mt, ks + 1);
+          }
           asm volatile("" ::: "memory");   // a few loads in flight, not all 52 (register pressure)
 #pragma unroll
-          for (int mt = 0; mt < D::MT; ++mt) nd[mt] = XW_MFMA(xw_fragAT_l(phg + o.Vh, W, W, W, 16 * mt, 4 * ks, ll), b, nd[mt]);
+          for (int mt = 0; mt < D::MT; ++mt) nd[mt] = XW_MFMA(fc[mt], b, nd[mt]);
         }
         const unsigned int mask = sMask[j][threadIdx.x];
 #pragma unroll
