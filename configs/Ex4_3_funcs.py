@@ -15,9 +15,13 @@ from utils.auxillary_funcs import rel_err
 
 def _sines(X, first):
     d = X.shape[-1] - 1
-    out = 1
-    for i in range(d):
-        out = out * torch.sin(math.pi / 2 * X[..., first + i] + math.pi / 2 * i)
+    # all d sines in three tensor operations, then the product in the upstream order (left to right: same bits as the
+    # coordinate-by-coordinate loop of upstream configs/Ex4_3_funcs.py:8-12, a third of its launches on a GPU tensor)
+    phase = ((math.pi / 2) * torch.arange(d, dtype=torch.float64)).to(device=X.device, dtype=X.dtype)   # (rounded once, like the scalars)
+    S = torch.sin(math.pi / 2 * X[..., first:first + d] + phase)
+    out = S[..., 0]
+    for i in range(1, d):
+        out = out * S[..., i]
     return out, (2 / math.pi) ** (-d)
 
 
