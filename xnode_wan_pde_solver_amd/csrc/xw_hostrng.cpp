@@ -50,7 +50,7 @@ __attribute__((target("avx2,fma"))) void emit_v3(const uint32_t* s, float* out, 
 }
 void regenerate_v1(uint32_t* s) { regenerate_body(s); }
 void emit_v1(const uint32_t* s, float* out, int k, float span, float from, int fused) { emit_body(s, out, k, span, from, fused); }
-const bool wide = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("fma");
+const bool wide = (__builtin_cpu_init(), __builtin_cpu_supports("avx2") && __builtin_cpu_supports("fma"));
 inline void regenerate(uint32_t* s) { wide ? regenerate_v3(s) : regenerate_v1(s); }
 inline void emit(const uint32_t* s, float* out, int k, float span, float from, int fused) {
   wide ? emit_v3(s, out, k, span, from, fused) : emit_v1(s, out, k, span, from, fused);
