@@ -500,9 +500,14 @@ if __name__ == '__main__':
     ap.add_argument('--round2', action='store_true', help='only the fixtures added in round 2 (BASELINE configs[2], configs[4])')
     ap.add_argument('--round3', action='store_true', help='only the fixtures added / regenerated in round 3 (natural group pairing on the '
                     'ball domains, d = 100, the cone trajectory)')
+    ap.add_argument('--traj-d20', action='store_true', help='only the d = 20 cube trajectory fixture (round 3)')
     ap.add_argument('--traj-hourglass', action='store_true', help='only the hourglass trajectory fixture (round 3, second ball domain)')
     args = ap.parse_args()
     torch.set_num_threads(4)
+    if args.traj_d20:
+        # trained-error parity at the headline dimension (BASELINE configs[1] family: d = 20; N small enough for the reference)
+        trajectory('ref_traj_d20_seed2_gpusem', 20, 128, 96, 12, 2, 150, True)
+        sys.exit(0)
     if args.traj_hourglass:
         sphere_trajectory('ref_traj_hourglass_ex43_d3_seed1', 'NSphere_THourglass', 3, 256, 128, 10, 1, 60)
         sys.exit(0)
@@ -517,6 +522,7 @@ if __name__ == '__main__':
         # trained error on a ball domain through the reference's own train()
         sphere_trajectory('ref_traj_cone_ex43_d3_seed0', 'NSphere_TCone', 3, 256, 128, 10, 0, 100)
         sphere_trajectory('ref_traj_hourglass_ex43_d3_seed1', 'NSphere_THourglass', 3, 256, 128, 10, 1, 60)
+        trajectory('ref_traj_d20_seed2_gpusem', 20, 128, 96, 12, 2, 150, True)
         sys.exit(0)
     if args.round2 or not args.only_traj:
         # BASELINE configs[2] shape family: d = 50, N_t = 64 (small N so that the reference runs in seconds)

@@ -239,11 +239,15 @@ def test_engine_against_oracle_general_coefficients(m, q, adjoint):
             close(g_, o['grad'][k_], 1e-5, 1e-6 * gmax, 'grad ' + k_)
 
 
-def test_trained_error_trajectory_matches_reference(golden_dir, tmp_path):
-    """BASELINE config 1 (d=5, N_r=256, N_b=64, N_t=16), seed 0, 400 outer iterations = 800 generator sub-steps through
-    train(): rel-L2 logged by the `stop` hook at every sub-step, compared with the reference's own run (fixture)."""
+@pytest.mark.parametrize('case,steps,windows,reached', [
+    ('ref_traj_plumb_seed0_gpusem', 800, ((100, 200), (400, 600), (600, 800)), 0.01),
+    ('ref_traj_d20_seed2_gpusem', 300, ((100, 200), (200, 300)), 0.02)])
+def test_trained_error_trajectory_matches_reference(golden_dir, tmp_path, case, steps, windows, reached):
+    """BASELINE config 1 (d=5, N_r=256, N_b=64, N_t=16; seed 0, 400 outer iterations = 800 generator sub-steps) and the
+    headline dimension (d=20, N_r=128, N_b=96, N_t=12; seed 2, 150 outer iterations) through train(): rel-L2 logged by the
+    `stop` hook at every sub-step, compared with the reference's own runs (fixtures)."""
     from utils.auxillary_funcs import rel_err
-    z, params = load(golden_dir, 'ref_traj_plumb_seed0_gpusem')
+    z, params = load(golden_dir, case)
     ref = z['rel_l2']
     log = []
 
@@ -259,15 +263,19 @@ def test_trained_error_trajectory_matches_reference(golden_dir, tmp_path):
     finally:
         os.chdir(cwd)
     got = np.array(log)
-    assert got.shape == ref.shape == (800,)
+    out = os.environ.get('XW_DUMP_TRAJ')
+    if out:
+        np.savez(out + '_' + case, got=got, ref=ref)
+    assert got.shape == ref.shape == (steps,)
     # same seeds, same arithmetic: the runs track each other closely before chaotic decorrelation sets in
     np.testing.assert_allclose(got[:50], ref[:50], rtol=2e-3)
     # north-star criterion: trained relative-L2 error within 1e-2 absolute of the reference's, on windowed statistics
-    for lo, hi in ((100, 200), (400, 600), (600, 800)):
+    for lo, hi in windows:
         assert abs(np.median(got[lo:hi]) - np.median(ref[lo:hi])) < 1e-2, (lo, hi, np.median(got[lo:hi]), np.median(ref[lo:hi]))
     assert abs(got[-1] - ref[-1]) < 1e-2
-    assert got[600:].min() < 0.01
-    for fn in ('losses_NODE_5.json', 'L2_NODE_5.json', 'Time_NODE_5.json', 'best_model_weights_NODE.pth'):
+    assert got[windows[-1][0]:].min() < reached and ref[windows[-1][0]:].min() < reached
+    d = params['dim']
+    for fn in ('losses_NODE_%d.json' % d, 'L2_NODE_%d.json' % d, 'Time_NODE_%d.json' % d, 'best_model_weights_NODE.pth'):
         assert (tmp_path / fn).exists(), fn
     sd = torch.load(tmp_path / 'best_model_weights_NODE.pth')
     assert 'module.ODE_rhs.net.14.weight' in sd and sd['module.final_linear.weight'].shape == (1, 20)
