@@ -255,6 +255,16 @@ template <int NR> __device__ __forceinline__ void xw_writeT_n(double* tile, d4 q
 #pragma unroll
   for (int r = 0; r < NR; ++r) tile[(g + 4 * r) * XW_TSTRIDE + n] = q[r];
 }
+// the same with the 16 columns stored at position 4 (n & 3) + (n >> 2): the tiles the duo sweep's chain wave posts for its
+// partner, whose 4x4x4 operand (lane i + 4 b + 16 k = row i, path 4 k + b) then reads position 4 b + k -- a half wave covers
+// positions {0,1,4,5,8,9,12,13} of four rows that sit 17 doubles apart: one bank conflict instead of twelve (read in path
+// order, rows i and i + 2 overlap in six of their eight banks: 5.4 M conflict cycles per launch)
+template <int NR> __device__ __forceinline__ void xw_writeT_pn(double* tile, d4 q) {
+  const int l = xw_lane();
+  const int g = l >> 4, n = l & 15, pn = ((n & 3) << 2) | (n >> 2);
+#pragma unroll
+  for (int r = 0; r < NR; ++r) tile[(g + 4 * r) * XW_TSTRIDE + pn] = q[r];
+}
 __device__ __forceinline__ double xw_readT(const double* tile, int ks) {
   const int l = xw_lane();
   return tile[(l & 15) * XW_TSTRIDE + 4 * ks + (l >> 4)];

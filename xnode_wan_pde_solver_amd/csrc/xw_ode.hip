@@ -350,8 +350,8 @@ __device__ __forceinline__ void field_vjp(const FieldW<H, K>& w, const FieldWT<H
   if (OUTER == 2) {
 #pragma unroll
     for (int ht = 0; ht < D::HT; ++ht) {
-      if (ht == 0) xw_writeT_n<D::HR(0)>(lds, ob[0]);
-      else xw_writeT_n<D::HR(D::HT - 1)>(lds + DuoPlan<H, K, M>::off(ht), ob[ht]);
+      if (ht == 0) xw_writeT_pn<D::HR(0)>(lds, ob[0]);
+      else xw_writeT_pn<D::HR(D::HT - 1)>(lds + DuoPlan<H, K, M>::off(ht), ob[ht]);
     }
   }
   if (PARAMS) {
@@ -382,7 +382,7 @@ __device__ __forceinline__ void field_vjp(const FieldW<H, K>& w, const FieldWT<H
       outer_post_ones<D::KSK, K>(zb, sv.z[j], lds);
       outer_fetch(o0, lds, rt1);
     }
-    if (OUTER == 2) xw_writeT_n<D::KSK>(lds + DuoPlan<H, K, M>::off(D::HT + (M - 2 - j)), zb);
+    if (OUTER == 2) xw_writeT_pn<D::KSK>(lds + DuoPlan<H, K, M>::off(D::HT + (M - 2 - j)), zb);
     d4 tt = xw_zero4();
 #pragma unroll
     for (int kb = 0; kb < D::KB; ++kb)
@@ -394,7 +394,7 @@ __device__ __forceinline__ void field_vjp(const FieldW<H, K>& w, const FieldWT<H
   }
 #pragma unroll
   for (int r = 0; r < D::KSK; ++r) xpb[r] += zb[r];
-  if (OUTER == 2) xw_writeT_n<D::KSK>(lds + DuoPlan<H, K, M>::off(D::HT + M - 1), zb);
+  if (OUTER == 2) xw_writeT_pn<D::KSK>(lds + DuoPlan<H, K, M>::off(D::HT + M - 1), zb);
   double rr[D::CT][4];
   if (PARAMS) {
     // one Q tile (the cotangent of z0) against the column tiles of [y ; t]: the time row makes column H collect the
@@ -1375,10 +1375,11 @@ __device__ __forceinline__ double duo_load_y(const DuoSrc<H, K, M, METHOD>& s, i
   const xw_gptr src = row < H ? (xw_gptr)(first ? src_y : src_a) : (xw_gptr)&xw_duo_const[0][0];
   return __builtin_nontemporal_load(src);
 }
-// A operand: rows 4 rb .. 4 rb + 3 of a transposed cotangent tile in LDS (tile[row * XW_TSTRIDE + path])
+// A operand: rows 4 rb .. 4 rb + 3 of a transposed cotangent tile in LDS, posted by xw_writeT_pn (tile[row * XW_TSTRIDE +
+// 4 (path & 3) + (path >> 2)]): lane i + 4 b + 16 k = (row i, path 4 k + b) sits at position 4 b + k
 __device__ __forceinline__ double duo_readA(const double* tile, int rb) {
   const int l = xw_lane();
-  return tile[(4 * rb + (l & 3)) * XW_TSTRIDE + (l >> 4) * 4 + ((l >> 2) & 3)];   // lane i + 4 b + 16 k = (row i, path 4 k + b)
+  return tile[(4 * rb + (l & 3)) * XW_TSTRIDE + ((l >> 2) & 3) * 4 + (l >> 4)];
 }
 // sum of an accumulator's four path-group partials (lane bits 2, 3), then element (row 4 rb + i, col 4 cb + j) from lane j + 16 i
 __device__ __forceinline__ double duo_fold(double x) {
