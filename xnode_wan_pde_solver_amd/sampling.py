@@ -25,10 +25,9 @@ from torch.utils.data import Dataset
 
 HIP_HOST_LOCK = threading.Lock()
 """Held by whoever allocates page-locked host memory or captures / launches a HIP graph.  The training loop stages the next
-sample on a helper thread while the main thread captures and replays sub-step graphs; a hipHostMalloc that coincides with a
-graph capture or launch in another thread was followed (once, in a test run of round 3, right after the draws had become
-three times faster) by a segmentation fault inside hipGraphLaunch.  The two are never concurrent now; the lock is
-uncontended except during a ring's first use."""
+sample on a helper thread while the main thread captures and replays sub-step graphs; nothing else orders a hipHostMalloc of
+the one against a capture or launch of the other.  A precaution (the one runtime fault met in round 3 turned out to be graph
+DESTRUCTION, engine._KEPT_GRAPHS): the lock is uncontended except during a ring's first use."""
 
 
 class _PinPool:
