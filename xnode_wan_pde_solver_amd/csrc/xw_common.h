@@ -227,11 +227,21 @@ __device__ __forceinline__ double xw_fold16(double a, double b) {
   return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
 }
 // sum over the 16 columns n (lanes within a 16-lane row)
+// sum over the 16 lanes of a row (lane & 15), every lane gets the total.  The xor butterfly 1, 2, 4, 8 on DPP row operations
+// instead of ds_bpermute (__shfl_xor): quad permutes for 1 and 2; once the quads are uniform, reversing a half row swaps its two
+// quads (= xor 4) and reversing the row swaps its halves (= xor 8) -- the same additions in the same association, without the
+// LDS crossbar's latency (4 x 2 dependent ds_bpermute per sum; the output layer of k_disc_rec takes 14 of these per tile).
+#define XW_DPP_ADD(x, CTRL)                                                                                                    \
+  {                                                                                                                            \
+    const int lo_ = __builtin_amdgcn_update_dpp(0, __double2loint(x), (CTRL), 0xf, 0xf, true);                                 \
+    const int hi_ = __builtin_amdgcn_update_dpp(0, __double2hiint(x), (CTRL), 0xf, 0xf, true);                                 \
+    x += __hiloint2double(hi_, lo_);                                                                                           \
+  }
 __device__ __forceinline__ double xw_sum_over_n(double x) {
-  x += __shfl_xor(x, 1);
-  x += __shfl_xor(x, 2);
-  x += __shfl_xor(x, 4);
-  x += __shfl_xor(x, 8);
+  XW_DPP_ADD(x, 0xB1)     // quad_perm [1, 0, 3, 2]
+  XW_DPP_ADD(x, 0x4E)     // quad_perm [2, 3, 0, 1]
+  XW_DPP_ADD(x, 0x141)    // row_half_mirror
+  XW_DPP_ADD(x, 0x140)    // row_mirror
   return x;
 }
 

@@ -13,11 +13,9 @@
 
 namespace {
 
-__device__ __forceinline__ double wave_sum(double x) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
-  return x;
-}
+// sum over the 64 lanes, every lane gets the total: rows of 16 on DPP row operations, the four rows on lane swaps
+// (xw_common.h) -- no ds_bpermute round trips (6 x 2 per value before; the reductions take five values per block)
+__device__ __forceinline__ double wave_sum(double x) { return xw_sum_over_g(xw_sum_over_n(x)); }
 // Deterministic grid-wide sum of NV per-thread partials: every block stores its partial sums to `work`, the block that
 // arrives last (agent-scope ticket) adds them up in block order and accumulates into dst[0..NV).  Float atomics would
 // be shorter but make two runs of the same step differ in the last bits; training must be bit-reproducible
