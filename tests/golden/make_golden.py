@@ -119,8 +119,15 @@ def npy(t):
     return t.detach().cpu().numpy().copy()
 
 
-def one_iteration(case, d, N_r, N_b, N_t, seed, solver_name, full_tensors, shape_param=None):
+def one_iteration(case, d, N_r, N_b, N_t, seed, solver_name, full_tensors, shape_param=None, slim=0):
+    """slim = s > 0 (round 4, the headline size N_r = 4096): per-path arrays keep every s-th path (`[::s]`; the dense
+    float32 `dphi` every 4s-th), the whole samples are pinned by their SHA-1 instead; scalars, gradients and parameters
+    are kept in full.  The consumer slices its own arrays the same way (`slim_stride` in the file)."""
+    import hashlib
     training, dataset, lossmod, F = load_reference()
+    sl = (lambda a: a[::slim].copy()) if slim else (lambda a: a)
+    sl4 = (lambda a: a[::4 * slim].copy()) if slim else (lambda a: a)
+    sha = lambda a: np.array(hashlib.sha1(np.ascontiguousarray(a).tobytes()).hexdigest())  # noqa: E731
     params = make_params(d, N_r, N_b, N_t, solver_name)
     if shape_param is not None:
         # d = 100: with the YAML's integer [-1, 1] the reference's own diagnostic raises OverflowError (V() is the Python
@@ -132,6 +139,8 @@ def one_iteration(case, d, N_r, N_b, N_t, seed, solver_name, full_tensors, shape
     S = training.NODE_WAN_solver(params, F.func_a, F.func_b, F.func_c, F.func_h, F.func_f, F.func_g, dev, './',
                                  func_u_sol=F.func_u_sol, p=2)
     out = {'params_json': np.array(json.dumps(params)), 'seed': np.array(seed)}
+    if slim:
+        out['slim_stride'] = np.array(slim)
     # initial parameters: unique tensors by canonical name + the full state_dict key list with its aliasing
     # (tied layers appear under several keys, src/model.py:38,127-131; `module.` prefix from DataParallel)
     for tag, net in (('u', S.u_net), ('v', S.v_net)):
@@ -147,15 +156,16 @@ def one_iteration(case, d, N_r, N_b, N_t, seed, solver_name, full_tensors, shape
     domain = S.domain(S.setup['shape_param'], d, S.setup['T0'], S.setup['T'], N_t)
     points = dataset.Comb_loader(N_r, N_b, domain, dev)
     out['times'] = npy(domain.times)
-    out['x_u'] = npy(points.interioru[:, 0, 1:])
-    out['x_v'] = npy(points.interiorv[:, 0, 1:])
-    out['x_b'] = npy(points.boundary[:, 0, 1:])
+    for key, arr in (('x_u', points.interioru), ('x_v', points.interiorv), ('x_b', points.boundary)):
+        out[key] = sl(npy(arr[:, 0, 1:]))
+        if slim:
+            out[key + '_sha1'] = sha(npy(arr[:, 0, 1:]))
     if full_tensors:
         out['X'] = npy(points.interioru)
         out['XV'] = npy(points.interiorv)
         out['BX'] = npy(points.boundary)
     out['V'] = np.array(float(domain.V()))
-    out['w_v'] = npy(domain.func_w(points.interiorv))
+    out['w_v'] = sl(npy(domain.func_w(points.interiorv)))
     out['L2_start'] = np.array(training.L_norm(points.interioru, S.u_net, S.p, S.func_u_sol, domain.V(), N_r).item())
     out['rel_start'] = np.array(training.rel_err(points.interioru, S.u_net, S.func_u_sol, S.p, domain.V(), N_r).item())
 
@@ -171,18 +181,18 @@ def one_iteration(case, d, N_r, N_b, N_t, seed, solver_name, full_tensors, shape
         G = torch.autograd.grad(pu.sum(), datau, retain_graph=True)[0]
         w = domain.func_w(datav).unsqueeze(2)
         dphi = torch.autograd.grad((pv * w).sum(), datav, retain_graph=True)[0]
-        out[tag + '/u'] = npy(pu.squeeze(2))
-        out[tag + '/v'] = npy(pv.squeeze(2))
-        out[tag + '/h'] = npy(h)
-        out[tag + '/f'] = npy(f)
-        out[tag + '/g'] = npy(g)
-        out[tag + '/Xgrad_l0'] = npy(G[:, 0, :])
+        out[tag + '/u'] = sl(npy(pu.squeeze(2)))
+        out[tag + '/v'] = sl(npy(pv.squeeze(2)))
+        out[tag + '/h'] = sl(npy(h))
+        out[tag + '/f'] = sl(npy(f))
+        out[tag + '/g'] = sl(npy(g))
+        out[tag + '/Xgrad_l0'] = sl(npy(G[:, 0, :]))
         out[tag + '/Xgrad_rest_absmax_x'] = np.array(float(G[:, 1:, 1:].abs().max()) if N_t > 1 else 0.0)
         out[tag + '/Xgrad_t_path0'] = npy(G[0, :, 0])
-        out[tag + '/dphi'] = npy(dphi)
+        out[tag + '/dphi'] = sl4(npy(dphi))
         if which == 'u':
             ub = S.u_net(bdata)
-            out[tag + '/u_b'] = npy(ub.squeeze(2))
+            out[tag + '/u_b'] = sl(npy(ub.squeeze(2)))
             out[tag + '/init'] = np.array(Lo.init(pu).item())
             out[tag + '/bdry'] = np.array(Lo.bdry(S.u_net, bdata).item())
             L = Lo.u(pu, pv, S.u_net, datau, datav, bdata)
@@ -223,12 +233,14 @@ def one_iteration(case, d, N_r, N_b, N_t, seed, solver_name, full_tensors, shape
     c = F.func_c(X5.clone().detach(), pu)
     Lo = lossmod.loss(S.config['alpha'], a, b, c, h, f, g, S.setup, domain, dev)
     out['final/int'] = np.array(Lo.int(pu, pv, X5, XV5).item())
-    out['final/u'] = npy(pu.squeeze(2))
-    out['final/v'] = npy(pv.squeeze(2))
+    out['final/u'] = sl(npy(pu.squeeze(2)))
+    out['final/v'] = sl(npy(pv.squeeze(2)))
 
     # second sample of the iteration + diagnostic (src/training.py:166-167) pins the RNG stream position
     points2 = dataset.Comb_loader(N_r, N_b, domain, dev)
-    out['x_u_second'] = npy(points2.interioru[:, 0, 1:])
+    out['x_u_second'] = sl(npy(points2.interioru[:, 0, 1:]))
+    if slim:
+        out['x_u_second_sha1'] = sha(npy(points2.interioru[:, 0, 1:]))
     out['L2_end'] = np.array(training.L_norm(points2.interioru, S.u_net, S.p, S.func_u_sol, domain.V(), N_r).item())
     path = os.path.join(HERE, case + '.npz')
     np.savez_compressed(path, **out)
@@ -501,12 +513,19 @@ if __name__ == '__main__':
     ap.add_argument('--round3', action='store_true', help='only the fixtures added / regenerated in round 3 (natural group pairing on the '
                     'ball domains, d = 100, the cone trajectory)')
     ap.add_argument('--traj-d20', action='store_true', help='only the d = 20 cube trajectory fixture (round 3)')
+    ap.add_argument('--round4', action='store_true', help='only the fixture added in round 4: one outer iteration of the reference at the '
+                    'BENCHMARKED size (BASELINE configs[1]: d = 20, N_r = N_b = 4096, N_t = 32), slim record (~4 min, 1 GB)')
     ap.add_argument('--traj-hourglass', action='store_true', help='only the hourglass trajectory fixture (round 3, second ball domain)')
     args = ap.parse_args()
     torch.set_num_threads(4)
     if args.traj_d20:
         # trained-error parity at the headline dimension (BASELINE configs[1] family: d = 20; N small enough for the reference)
         trajectory('ref_traj_d20_seed2_gpusem', 20, 128, 96, 12, 2, 150, True)
+        sys.exit(0)
+    if args.round4:
+        t0 = time.time()
+        one_iteration('ref_d20_headline', 20, 4096, 4096, 32, 11, 'midpoint', False, slim=64)
+        print('reference time %.0f s' % (time.time() - t0))
         sys.exit(0)
     if args.traj_hourglass:
         sphere_trajectory('ref_traj_hourglass_ex43_d3_seed1', 'NSphere_THourglass', 3, 256, 128, 10, 1, 60)
