@@ -2,7 +2,11 @@
 """bench.py -- WAN training-steps/sec on the BASELINE.json headline workload:
 d=20 time-independent cube (Ex4_1 functions), N_r = N_b = 4096 paths, N_t = 32, YAML hyper-parameters, float64.
 
-    python bench.py [--gpus N --steps K --warmup W]          (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py [--gpus N --steps K --warmup W]
+N > 1: one rank per GPU.  Started under torch.distributed.run (WORLD_SIZE set) this process IS a rank; started plainly,
+`python bench.py --gpus N` launches `python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>` itself as
+a child process (before anything touches the GPU), relays rank 0's JSON line and exits with the child's code -- the
+reference's nn.DataParallel needs no launcher either (src/training.py:93-97).
 
 A "step" is one optimiser sub-step of the adversarial loop (src/training.py:125-138 generator, :151-162 discriminator)
 on synthetic sampled paths already resident in HBM; the timed region cycles generator, generator, discriminator
@@ -53,6 +57,22 @@ def algorithmic_macs(p):
     return macs_F, path_u, macs_v
 
 
+def self_launch(argv, gpus):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD process (never exec: this process may not
+    be replaced once a GPU runtime is up, and here nothing has touched it yet), pass the output through, return its code."""
+    import socket
+    import subprocess
+    with socket.socket() as so:                     # a free rendezvous port on the loop-back interface
+        so.bind(('127.0.0.1', 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('MASTER_ADDR', '127.0.0.1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(gpus), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -72,6 +92,8 @@ def main():
     ap.add_argument('--no-solo', action='store_true', help='skip the extra full-grid launches of the dominant kernel '
                     '(roofline.solo_full_grid), so that a profiler run only sees production launches')
     args = ap.parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(self_launch(sys.argv[1:], args.gpus))
 
     import configs.Ex4_1_funcs as P
     from xnode_wan_pde_solver_amd import dist as xdist, kernels as KN
@@ -366,7 +388,10 @@ def main():
                                     % (s['dim'], n_glob, size, s['N_t'])) if strong else
                                    ('Ex4_1 cube d=%d N_r=%d N_b=%d N_t=%d per GPU, midpoint, n1=2 n2=1 (configs[1])'
                                     % (s['dim'], s['N_r'], s['N_b'], s['N_t'])), 'global_paths': n_glob,
-                       'parallelism': 'paths sharded x%d; 1 all-reduce per generator, 2 per discriminator sub-step' % size},
+                       'parallelism': ('%d global paths sharded x%d (strong scaling: value = global sub-steps/s)' % (n_glob, size)) if strong else
+                                      ('paths sharded x%d, %d paths per rank (weak scaling: value = sub-steps/s x ranks, i.e. %d-path '
+                                       'sub-steps per second over the job; the global batch grows with the rank count)' % (size, s['N_r'], s['N_r']))
+                                      + '; 1 all-reduce per generator, 2 per discriminator sub-step'},
             'roofline': roofline, 'cpu_baseline': cpu, 'whole_step': whole,
             'kernels': {k: {'ms': round(v['avg_ms'], 4), 'per_step': round(v['launches_per_step'], 2)} for k, v in sorted(kern.items())},
             'extras': extras,

@@ -147,3 +147,25 @@ def test_two_gpus_nccl_match_single_process(tmp_path):
         np.testing.assert_allclose(r['theta'].numpy(), one['theta'].numpy(), rtol=1e-8, atol=1e-10)
         np.testing.assert_allclose(r['phi'].numpy(), one['phi'].numpy(), rtol=1e-8, atol=1e-10)
     assert torch.equal(ranks[0]['theta'], ranks[1]['theta'])
+
+
+@pytest.mark.timeout(900)
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (the reference's nn.DataParallel needs none,
+    src/training.py:93-97): the script starts its ranks as a child process, rank 0's JSON line comes back.  Two gloo ranks
+    share the one GPU of the test box; on an 8-GPU node the same command runs one rank per GPU over RCCL."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, XW_DIST_BACKEND='gloo')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '6', '--warmup', '3', '--repeats', '2',
+                        '--no-cpu-baseline', '--train-iters', '0', '--n_r', '512', '--n_b', '512'],
+                       env=env, capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['scaling'] == 'weak' and out['value'] > 0 and out['extras']['finite']
+    assert 'paths per rank' in out['config']['parallelism']
