@@ -371,6 +371,34 @@ def sphere_groups(case, domain_name, d, N_r, N_b, N_t, seed, funcs_module='confi
           'boundary', [g.shape[0] for g in points.boundary], 'pairs', pairs)
 
 
+def sphere_sampling(case, domain_name, d, N_r, N_b, N_t, seed, radius):
+    """The groups a ball domain samples at a radius that is NOT a power of two (round 4): every other fixture uses
+    shape_param = 1.0, where `r * (float32 expression)` and `r * (float32 expression).double()` coincide -- the hourglass
+    bound of src/dataset.py:89-90 is the second form (`.double()` binds before `*`)."""
+    training, dataset, lossmod, F = load_reference()
+    params = make_params(d, N_r, N_b, N_t, 'midpoint')
+    params['domain'] = domain_name
+    params['shape_param'] = radius
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    S = training.NODE_WAN_solver(params, F.func_a, F.func_b, F.func_c, F.func_h, F.func_f, F.func_g, torch.device('cpu'), './',
+                                 func_u_sol=F.func_u_sol, p=2)
+    out = {'params_json': np.array(json.dumps(params)), 'seed': np.array(seed)}
+    domain = S.domain(S.setup['shape_param'], d, S.setup['T0'], S.setup['T'], N_t)
+    points = dataset.Comb_loader(N_r, N_b, domain, torch.device('cpu'))
+    out['times'] = npy(domain.times)
+    out['V'] = np.array(float(domain.V()))
+    out['n_interior'], out['n_boundary'] = np.array(len(points.interioru)), np.array(len(points.boundary))
+    for k, g in enumerate(points.interioru):
+        out['interior/%d' % k] = npy(g)
+        out['w/%d' % k] = npy(domain.func_w(g))
+    for k, g in enumerate(points.boundary):
+        out['boundary/%d' % k] = npy(g)
+    path = os.path.join(HERE, case + '.npz')
+    np.savez_compressed(path, **out)
+    print('wrote', path, '%.1f KB' % (os.path.getsize(path) / 1024), 'groups', len(points.interioru), len(points.boundary))
+
+
 def sphere_trajectory(case, domain_name, d, N_r, N_b, N_t, seed, outer_iters, funcs_module='configs.Ex4_3_funcs', alpha=100000000):
     """The reference's own train() on a time-varying ball domain (natural group loop incl. the single-slice groups),
     GPU loader semantics.  Its on-sample diagnostic is unusable on list domains (utils/auxillary_funcs.py:19 broadcasts
@@ -526,6 +554,8 @@ if __name__ == '__main__':
         t0 = time.time()
         one_iteration('ref_d20_headline', 20, 4096, 4096, 32, 11, 'midpoint', False, slim=64)
         print('reference time %.0f s' % (time.time() - t0))
+        sphere_sampling('ref_hourglass_r07_sampling', 'NSphere_THourglass', 3, 400, 64, 64, 5, 0.7)
+        sphere_sampling('ref_cone_r07_sampling', 'NSphere_TCone', 3, 400, 64, 64, 5, 0.7)
         sys.exit(0)
     if args.traj_hourglass:
         sphere_trajectory('ref_traj_hourglass_ex43_d3_seed1', 'NSphere_THourglass', 3, 256, 128, 10, 1, 60)

@@ -151,7 +151,9 @@ def test_product_never_imports_the_oracle():
 
 @pytest.mark.parametrize('case,name', [('ref_cone_groups', 'NSphere_TCone'), ('ref_hourglass_groups', 'NSphere_THourglass'),
                                        ('ref_cone_ex43_d10_groups', 'NSphere_TCone'),              # BASELINE configs[4]:
-                                       ('ref_hourglass_ex43_d10_groups', 'NSphere_THourglass')])   # d = 10, Ex4_3 functions
+                                       ('ref_hourglass_ex43_d10_groups', 'NSphere_THourglass'),    # d = 10, Ex4_3 functions
+                                       # a radius that is not a power of two: r * (float32 expr).double() != (r * float32 expr).double()
+                                       ('ref_hourglass_r07_sampling', 'NSphere_THourglass'), ('ref_cone_r07_sampling', 'NSphere_TCone')])
 def test_sphere_domains_sample_like_the_reference(golden_dir, case, name):
     z, params = load(golden_dir, case)
     params.pop('funcs', None)

@@ -348,7 +348,7 @@ class NSphere_THourglass(_NSphereBase):
         X = torch.from_numpy(pts).t().contiguous()                                        # [N, d] float64
         t32 = self.times
         early = torch.le(t32, self._half())
-        bound = torch.where(early, (self.r * ((self.T - self.T0) - t32)).double(), (self.r * t32).double())   # [L]
+        bound = torch.where(early, self.r * ((self.T - self.T0) - t32).double(), self.r * t32.double())   # [L]  (float32 difference, widened, THEN times r in float64: src/dataset.py:89-90 -- `.double()` binds before `*`)
         nrm = torch.sqrt(torch.sum(X ** 2, 1))
         inside = nrm.view(N_r, 1) < bound.view(1, L)
         t64 = t32.double()
