@@ -81,7 +81,12 @@ int xw_ode_bwd_slabs(int N);
  *   under  d/dt (y, a, theta-bar) = (f, -a^T df/dy, -a^T df/dtheta);  then a += flw * ubar[i-1].  The sample point x is
  *   not an input of that adjoint: gx is returned as zero, gs (through the lift) and the parameter gradients as usual.
  *   Differs from the discrete sweep by O(dt^p); the activation store is not used.  torchdiffeq is absent from the
- *   reference tree: restated from its published algorithm, parity unpinned. */
+ *   reference tree: restated from its published algorithm, parity unpinned.
+ * mode bit 4 (euler / midpoint with an activation store, not with bit 3): NARROW TILES -- the same sweep with the 16 paths of
+ *   a tile spread over four waves of 4 paths x 16 rows (csrc/xw_ode_n4.h): four times the instruction streams, each a
+ *   shorter dependent chain, ~1.8 x the matrix-pipe time per path.  Same inputs, outputs and slab count; results differ from
+ *   the 16-path form only by the summation order of the weight gradients.  For launches that leave SIMDs idle (fewer
+ *   16-path tiles than the chip has SIMDs and nothing else running beside them). */
 int xw_ode_bwd(const double* xT, const double* t, const double* start, const double* theta, const double* Y,
                const double* ubar, int method, int N, int L, int d, int H, int K, int m, int mode,
                double* gx, double* gs, double* gslab, void* stream);

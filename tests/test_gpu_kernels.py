@@ -304,6 +304,102 @@ def test_ode_sweep_with_residual_cotangents(solver):
         KN.ode_bwd_multi([dict(job, gslab=slab, ubar=ubar, res=res)], tc, blob, mid, H, K, 8, want_x=False, want_params=True)
 
 
+@pytest.mark.parametrize('solver', ['euler', 'midpoint'])
+@pytest.mark.parametrize('Hh,Kk,m,N,L,d', [(20, 10, 8, 37, 7, 5), (20, 10, 8, 64, 6, 20), (20, 10, 8, 16, 2, 3), (20, 10, 8, 1, 3, 1),
+                                           (20, 10, 3, 50, 5, 6), (20, 10, 1, 21, 4, 6), (20, 10, 8, 300, 4, 70),
+                                           (32, 12, 8, 37, 6, 5), (32, 12, 2, 19, 3, 21)])
+def test_ode_narrow_tile_sweeps(Hh, Kk, m, N, L, d, solver):
+    """xw_ode_bwd mode bit 4 (csrc/xw_ode_n4.h): the sweeps with a 16-path tile spread over four waves of 4 paths x 16 rows
+    -- x, start and every weight gradient against the oracle's autograd (1e-10), and against the 16-path sweeps of the same
+    store (1e-12: only the summation order of the weight gradients differs); x-only sweep from the reduced store; the fused
+    pollution + nabla_x u form; two jobs in one launch; residual cotangents"""
+    from oracle import refspec as R
+    from xnode_wan_pde_solver_amd import kernels as KN
+    cfg = dict(_cfg(m, solver), u_hidden_dim=Hh, u_hidden_hidden_dim=Kk)
+    torch.manual_seed(131)
+    theta, _ = R.init_parameters(cfg, _setup(d, 2))
+    for p in theta.values():
+        if p.dim() == 1:
+            p.copy_(0.3 * torch.randn(p.shape, dtype=torch.float64))
+    th = {k: v.clone().requires_grad_(True) for k, v in theta.items()}
+    x, t, X = _sample(N, L, d, 132)
+    g = torch.Generator().manual_seed(133)
+    start = torch.randn(N, dtype=torch.float64, generator=g).requires_grad_(True)
+    ubar = torch.randn(N, L, dtype=torch.float64, generator=g)
+    x64 = x.double().requires_grad_(True)
+    Xd = torch.cat((t.double().view(1, L, 1).expand(N, L, 1), x64.view(N, 1, d).expand(N, L, d)), 2)
+    u_ref = R.u_net(th, cfg, Xd, start)
+    order = [k for k in U_ORDER if k in theta]
+    grads = torch.autograd.grad((u_ref * ubar).sum(), [x64, start] + [th[k] for k in order], allow_unused=True)
+    grads = [g_ if g_ is not None else torch.zeros_like(p_) for g_, p_ in zip(grads, [x64, start] + [th[k] for k in order])]
+    blob = torch.cat([(theta[k] if k in theta else torch.zeros(Kk * Kk if k == 'Wh' else Kk, dtype=torch.float64)).reshape(-1)
+                      for k in U_ORDER]).cuda()
+    xT, tc, sc = x.double().t().contiguous().cuda(), t.double().cuda(), start.detach().cuda()
+    ub = ubar.t().contiguous().cuda()
+    mid = KN.method_id(solver)
+    rows = KN.ode_act_rows(mid, Hh, Kk, m)
+    new = lambda *shape: torch.full(shape, float('nan'), dtype=F64, device='cuda')      # noqa: E731
+    job = dict(xT=xT, start=sc, u=new(L, N), Y=new(L, Hh, N), act=new(L - 1, rows, KN.ode_act_cols(N)))
+    KN.ode_fwd_multi([job], tc, blob, mid, Hh, Kk, m)
+    nsl, P = KN.ode_bwd_slabs(N), blob.numel()
+
+    def sweep(narrow, want_x=True, want_params=True, j=job, **kw):
+        gx, gs, slab = new(d, N), new(N), new(nsl, P)
+        KN.ode_bwd_multi([dict(j, ubar=ub, gx=gx, gs=gs, gslab=slab)], tc, blob, mid, Hh, Kk, m, want_x=want_x, want_params=want_params,
+                         narrow=narrow, **kw)
+        return gx, gs, slab
+    gx, gs, slab = sweep(True)
+    gxw, gsw, slabw = sweep(False)
+    _close(gx.t(), grads[0], 1e-10, 'gx'); _close(gs, grads[1], 1e-10, 'gs')
+    _close(gx, gxw, 1e-12, 'gx vs the 16-path sweep'); _close(gs, gsw, 1e-12, 'gs vs the 16-path sweep')
+    assert torch.isfinite(slab).all()
+    flat, flatw, off = KN.slab_sum(slab).cpu(), KN.slab_sum(slabw).cpu(), 0
+    _close(flat, flatw, 1e-12, 'theta gradient vs the 16-path sweep')
+    for k in U_ORDER:
+        n = theta[k].numel() if k in theta else (Kk * Kk if k == 'Wh' else Kk)
+        if k in theta:
+            _close(flat[off:off + n].view(theta[k].shape), grads[2 + order.index(k)], 1e-10, 'grad ' + k)
+        off += n
+    # without weight gradients, from a store that only holds the tanh rows and the mask words
+    jx = dict(job, act=new(L - 1, rows, KN.ode_act_cols(N)))
+    KN.ode_fwd_multi([jx], tc, blob, mid, Hh, Kk, m, act_x_only=True)
+    gx1, gs1, _ = sweep(True, want_params=False, j=jx)
+    _close(gx1, gxw, 1e-12, 'gx (x-only, reduced store)'); _close(gs1, gsw, 1e-12, 'gs (x-only, reduced store)')
+    # weight gradients only
+    _, _, slab2 = sweep(True, want_x=False)
+    assert torch.equal(slab2, slab)
+    # the generator sub-step's fused form: x outputs for the all-ones cotangent, parameters for ubar (== 1 behind l = 0)
+    ub1 = torch.ones(L, N, dtype=F64, device='cuda')
+    ub1[0] = ub[0]
+    a = [new(d, N), new(N), new(nsl, P)]
+    b = [new(d, N), new(N), new(nsl, P)]
+    for out, narrow in ((a, True), (b, False)):
+        KN.ode_bwd_multi([dict(job, ubar=ub1, gx=out[0], gs=out[1], gslab=out[2])], tc, blob, mid, Hh, Kk, m, want_x=True,
+                         want_params=True, x_cot_ones=True, narrow=narrow)
+    for p_, q_, what in zip(a[:2], b[:2], ('gx (ones)', 'gs (ones)')):
+        _close(p_, q_, 1e-12, what)
+    _close(KN.slab_sum(a[2]), KN.slab_sum(b[2]), 1e-12, 'theta gradient (fused form)')
+    # two jobs in one launch (the second with its own paths), one of them with a residual cotangent formed in the sweep
+    N2 = max(N // 2, 1)
+    x2, _, _ = _sample(N2, L, d, 134)
+    job2 = dict(xT=x2.double().t().contiguous().cuda(), start=torch.randn(N2, dtype=F64, generator=g).cuda(), u=new(L, N2),
+                Y=new(L, Hh, N2), act=new(L - 1, rows, KN.ode_act_cols(N2)))
+    KN.ode_fwd_multi([job, job2], tc, blob, mid, Hh, Kk, m)
+    gref = torch.randn(L, N2, dtype=F64, generator=g).cuda()
+    res = dict(u=job2['u'], ref=gref, coef=-1.3, base=0.25, first_only=False)
+    outs = []
+    for narrow in (True, False):
+        s1, s2 = new(nsl, P), new(KN.ode_bwd_slabs(N2), P)
+        KN.ode_bwd_multi([dict(job, ubar=ub, gslab=s1), dict(job2, res=res, gslab=s2)], tc, blob, mid, Hh, Kk, m, want_x=False,
+                         want_params=True, narrow=narrow)
+        outs.append((KN.slab_sum(s1), KN.slab_sum(s2)))
+    assert torch.equal(outs[0][0].cpu(), flat)
+    _close(outs[0][1], outs[1][1], 1e-12, 'second job of the launch, residual cotangent')
+    with pytest.raises(Exception):                                  # no store, no narrow sweep
+        KN.ode_bwd_multi([dict(job, act=None, ubar=ub, gx=new(d, N), gs=new(N))], tc, blob, mid, Hh, Kk, m, want_x=True,
+                         want_params=False, narrow=True)
+
+
 def test_slab_sums_against_torch():
     """xw_slab_sum / xw_slab_sum2 (fixed-tree reductions of the per-wave gradient slabs) against torch.sum, at slab counts
     below, at and above the 64 groups of a block, with accumulation"""

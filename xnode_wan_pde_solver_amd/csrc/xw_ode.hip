@@ -856,6 +856,144 @@ __device__ __forceinline__ void load_stage(const double* __restrict__ Y, const d
   }
 }
 
+// ---- end of a sweep: everything behind the time loop, for ONE tile of 16 paths in the chain layout ------------------------
+// x-projection (cotangent of x, gradients of Win[:, :d] and Win.b), read-out layer gradients, the lift (initial layers):
+// lam = cotangent of y_0, xpb = sum of the cotangents of z_0 over all field evaluations, ub0 = cotangent of u at the first
+// time index, accFL / accFLb = sums of ubar y_l / ubar.  Shared by the 16-path sweeps (sweep_body) and by the narrow-tile
+// sweep (xw_ode_n4.h), whose four waves hand these registers to their first wave through LDS.  lds: XW_SWEEP_TILES tiles.
+template <int H, int K, bool PARAMS, bool ADJ>
+__device__ __forceinline__ void sweep_tail(const double* __restrict__ th, const UOff& o, int d, int N, int base, bool valid, int ncl,
+                                           const double* __restrict__ xT, double sv, bool x_ones, const d4 (&lam)[Dim<H, K>::HT],
+                                           d4 xpb, double ub0, const d4 (&accFL)[Dim<H, K>::HT], double accFLb,
+                                           const d4 (&flw)[Dim<H, K>::HT], double* __restrict__ gx, double* __restrict__ gs,
+                                           double* slab, double* lds) {
+  typedef Dim<H, K> D;
+  const int lane = xw_lane(), g = lane >> 4, n = lane & 15;
+  // ---- x-projection: cotangent of x, gradients of Win[:, :d] and Win.b -----------------------------------------
+  if (gx != nullptr) {
+    for (int rt = 0; rt < (d + 15) / 16; ++rt) {
+      d4 v = xw_zero4();
+      if (!ADJ) {                // (odeint_adjoint: x is not among the inputs the adjoint differentiates with respect to)
+#pragma unroll
+        for (int ks = 0; ks < D::KSK; ++ks) v = XW_MFMA(xw_fragAT(th + o.Win, o.ldin, K, d, 16 * rt, 4 * ks), xpb[ks], v);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 16 * rt + g + 4 * r;
+        if (i < d && valid) gx[(long)i * N + base + n] = v[r];
+      }
+    }
+  }
+  if (PARAMS) {
+    xw_writeT(lds, xpb);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int ct = 0; ct < (d + 15) / 16; ++ct) {
+      d4 acc = xw_zero4();
+      const int i = 16 * ct + (lane & 15);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int pn = base + 4 * ks + (lane >> 4);
+        const double b = (i < d && pn < N) ? xT[(long)i * N + pn] : 0.0;
+        acc = XW_MFMA(xw_readT(lds, ks), b, acc);
+      }
+      storeD(slab + o.Win, o.ldin, K, d, 0, 16 * ct, acc);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    storeRowSums(slab + o.Winb, K, 0, xpb);
+#pragma unroll
+    for (int ht = 0; ht < D::HT; ++ht) storeRowSums(slab + o.FLw, H, 16 * ht, accFL[ht]);
+    const double sb = xw_sum_over_n(accFLb);
+    if (lane == 0) slab[o.FLb] = sb;
+  }
+
+  // ---- initial layers: lam = cotangent of y_0 ----------------------------------------------------------------------
+  {
+    d4 a0[D::HT], a1[D::HT], y0[D::HT];
+    lift<H, K>(th, o, sv, a0, a1, y0);
+    d4 d1[D::HT], d0[D::HT];
+    if (PARAMS) {
+#pragma unroll
+      for (int rt = 0; rt < D::HT; ++rt) {
+#pragma unroll
+        for (int ct = 0; ct < D::HT; ++ct) {
+          d4 acc = xw_zero4();
+          outer_acc(acc, lam[rt], a1[ct], lds);
+          storeD(slab + o.IL4w, H, H, H, 16 * rt, 16 * ct, acc);
+        }
+        storeRowSums(slab + o.IL4b, H, 16 * rt, lam[rt]);
+      }
+    }
+#pragma unroll
+    for (int ht = 0; ht < D::HT; ++ht) {
+      d4 v = xw_zero4();
+#pragma unroll
+      for (int ks = 0; ks < D::KSH; ++ks) v = XW_MFMA(xw_fragAT(th + o.IL4w, H, H, H, 16 * ht, 4 * ks), lam[ks >> 2][ks & 3], v);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) d1[ht][r] = a1[ht][r] > 0.0 ? v[r] : 0.0;
+    }
+    if (PARAMS) {
+#pragma unroll
+      for (int rt = 0; rt < D::HT; ++rt) {
+#pragma unroll
+        for (int ct = 0; ct < D::HT; ++ct) {
+          d4 acc = xw_zero4();
+          outer_acc(acc, d1[rt], a0[ct], lds);
+          storeD(slab + o.IL2w, H, H, H, 16 * rt, 16 * ct, acc);
+        }
+        storeRowSums(slab + o.IL2b, H, 16 * rt, d1[rt]);
+      }
+    }
+    double gpart = 0.0;
+#pragma unroll
+    for (int ht = 0; ht < D::HT; ++ht) {
+      d4 v = xw_zero4();
+#pragma unroll
+      for (int ks = 0; ks < D::KSH; ++ks) v = XW_MFMA(xw_fragAT(th + o.IL2w, H, H, H, 16 * ht, 4 * ks), d1[ks >> 2][ks & 3], v);
+      const d4 w0 = xw_vecD(th + o.IL0w, H, 16 * ht);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        d0[ht][r] = a0[ht][r] > 0.0 ? v[r] : 0.0;
+        gpart += w0[r] * d0[ht][r];
+      }
+      if (PARAMS) {
+        storeRowSums(slab + o.IL0w, H, 16 * ht, d0[ht] * sv);
+        storeRowSums(slab + o.IL0b, H, 16 * ht, d0[ht]);
+      }
+    }
+    double gsn = xw_sum_over_g(gpart);
+    if (PARAMS && gs != nullptr && x_ones) {
+      // The x outputs of this launch stand for the helper backward u.backward(ones) (src/loss.py:55) while the
+      // parameter gradients use ubar, which differs from ones at the first time index only (the initial-value penalty).
+      // gx never sees that entry (no step is reversed after it), d/d start does, linearly through the lift:
+      // subtract the lift's response to flw * (ubar_0 - 1).
+      const double dub = ub0 - (valid ? 1.0 : 0.0);
+      d4 e1[D::HT];
+#pragma unroll
+      for (int ht = 0; ht < D::HT; ++ht) {
+        d4 v = xw_zero4();
+#pragma unroll
+        for (int ks = 0; ks < D::KSH; ++ks) v = XW_MFMA(xw_fragAT(th + o.IL4w, H, H, H, 16 * ht, 4 * ks), flw[ks >> 2][ks & 3], v);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) e1[ht][r] = a1[ht][r] > 0.0 ? v[r] : 0.0;
+      }
+      double cpart = 0.0;
+#pragma unroll
+      for (int ht = 0; ht < D::HT; ++ht) {
+        d4 v = xw_zero4();
+#pragma unroll
+        for (int ks = 0; ks < D::KSH; ++ks) v = XW_MFMA(xw_fragAT(th + o.IL2w, H, H, H, 16 * ht, 4 * ks), e1[ks >> 2][ks & 3], v);
+        const d4 w0 = xw_vecD(th + o.IL0w, H, 16 * ht);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cpart += a0[ht][r] > 0.0 ? w0[r] * v[r] : 0.0;
+      }
+      gsn -= dub * xw_sum_over_g(cpart);
+    }
+    if (gs != nullptr && g == 0 && valid) gs[base + n] = gsn;
+  }
+}
+
 // SAVED: the stage activations come from the forward pass's store (euler, midpoint); otherwise they are recomputed
 // ADJ: the reference's adjoint=True (src/model.py:103: torchdiffeq.odeint_adjoint) -- not the reverse of the steps that
 //   were taken but the continuous adjoint, integrated with the same fixed-grid method.  torchdiffeq 0.1.1 (absent here,
@@ -1176,132 +1314,10 @@ __device__ __forceinline__ void sweep_body(const BwdJobs& jobs, const double* __
   // (duo sweep: the three transpose tiles of the epilogue live in the Q buffer that is NOT in flight -- the partners are
   //  reading the one the last evaluation was posted into; they finished with the other one before the last barrier)
   if (DUO) lds = qbuf + qflip * DuoPlan<H, K, M>::BUF;
-  // ---- x-projection: cotangent of x, gradients of Win[:, :d] and Win.b -----------------------------------------
-  if (gx != nullptr) {
-    for (int rt = 0; rt < (d + 15) / 16; ++rt) {
-      d4 v = xw_zero4();
-      if (!ADJ) {                // (odeint_adjoint: x is not among the inputs the adjoint differentiates with respect to)
-#pragma unroll
-        for (int ks = 0; ks < D::KSK; ++ks) v = XW_MFMA(xw_fragAT(th + o.Win, o.ldin, K, d, 16 * rt, 4 * ks), xpb[ks], v);
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int i = 16 * rt + g + 4 * r;
-        if (i < d && valid) gx[(long)i * N + base + n] = v[r];
-      }
-    }
-  }
   double* slab = PARAMS ? gslab + (long)tile * o.total : nullptr;
-  if (PARAMS) {
-    xw_writeT(lds, xpb);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    for (int ct = 0; ct < (d + 15) / 16; ++ct) {
-      d4 acc = xw_zero4();
-      const int i = 16 * ct + (lane & 15);
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const int pn = base + 4 * ks + (lane >> 4);
-        const double b = (i < d && pn < N) ? xT[(long)i * N + pn] : 0.0;
-        acc = XW_MFMA(xw_readT(lds, ks), b, acc);
-      }
-      storeD(slab + o.Win, o.ldin, K, d, 0, 16 * ct, acc);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    storeRowSums(slab + o.Winb, K, 0, xpb);
-    if (!DUO) store_field_grads<H, K>(slab, o, d, G);      // (duo sweep: the partner wave holds and stores them)
-#pragma unroll
-    for (int ht = 0; ht < D::HT; ++ht) storeRowSums(slab + o.FLw, H, 16 * ht, accFL[ht]);
-    const double sb = xw_sum_over_n(accFLb);
-    if (lane == 0) slab[o.FLb] = sb;
-  }
-
-  // ---- initial layers: lam = cotangent of y_0 ----------------------------------------------------------------------
-  {
-    const double sv = start[ncl];
-    d4 a0[D::HT], a1[D::HT], y0[D::HT];
-    lift<H, K>(th, o, sv, a0, a1, y0);
-    d4 d1[D::HT], d0[D::HT];
-    if (PARAMS) {
-#pragma unroll
-      for (int rt = 0; rt < D::HT; ++rt) {
-#pragma unroll
-        for (int ct = 0; ct < D::HT; ++ct) {
-          d4 acc = xw_zero4();
-          outer_acc(acc, lam[rt], a1[ct], lds);
-          storeD(slab + o.IL4w, H, H, H, 16 * rt, 16 * ct, acc);
-        }
-        storeRowSums(slab + o.IL4b, H, 16 * rt, lam[rt]);
-      }
-    }
-#pragma unroll
-    for (int ht = 0; ht < D::HT; ++ht) {
-      d4 v = xw_zero4();
-#pragma unroll
-      for (int ks = 0; ks < D::KSH; ++ks) v = XW_MFMA(xw_fragAT(th + o.IL4w, H, H, H, 16 * ht, 4 * ks), lam[ks >> 2][ks & 3], v);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) d1[ht][r] = a1[ht][r] > 0.0 ? v[r] : 0.0;
-    }
-    if (PARAMS) {
-#pragma unroll
-      for (int rt = 0; rt < D::HT; ++rt) {
-#pragma unroll
-        for (int ct = 0; ct < D::HT; ++ct) {
-          d4 acc = xw_zero4();
-          outer_acc(acc, d1[rt], a0[ct], lds);
-          storeD(slab + o.IL2w, H, H, H, 16 * rt, 16 * ct, acc);
-        }
-        storeRowSums(slab + o.IL2b, H, 16 * rt, d1[rt]);
-      }
-    }
-    double gpart = 0.0;
-#pragma unroll
-    for (int ht = 0; ht < D::HT; ++ht) {
-      d4 v = xw_zero4();
-#pragma unroll
-      for (int ks = 0; ks < D::KSH; ++ks) v = XW_MFMA(xw_fragAT(th + o.IL2w, H, H, H, 16 * ht, 4 * ks), d1[ks >> 2][ks & 3], v);
-      const d4 w0 = xw_vecD(th + o.IL0w, H, 16 * ht);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        d0[ht][r] = a0[ht][r] > 0.0 ? v[r] : 0.0;
-        gpart += w0[r] * d0[ht][r];
-      }
-      if (PARAMS) {
-        storeRowSums(slab + o.IL0w, H, 16 * ht, d0[ht] * sv);
-        storeRowSums(slab + o.IL0b, H, 16 * ht, d0[ht]);
-      }
-    }
-    double gsn = xw_sum_over_g(gpart);
-    if (PARAMS && gs != nullptr && jobs.x_ones) {
-      // The x outputs of this launch stand for the helper backward u.backward(ones) (src/loss.py:55) while the
-      // parameter gradients use ubar, which differs from ones at the first time index only (the initial-value penalty).
-      // gx never sees that entry (no step is reversed after it), d/d start does, linearly through the lift:
-      // subtract the lift's response to flw * (ubar_0 - 1).
-      const double dub = ub0 - (valid ? 1.0 : 0.0);
-      d4 e1[D::HT];
-#pragma unroll
-      for (int ht = 0; ht < D::HT; ++ht) {
-        d4 v = xw_zero4();
-#pragma unroll
-        for (int ks = 0; ks < D::KSH; ++ks) v = XW_MFMA(xw_fragAT(th + o.IL4w, H, H, H, 16 * ht, 4 * ks), flw[ks >> 2][ks & 3], v);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) e1[ht][r] = a1[ht][r] > 0.0 ? v[r] : 0.0;
-      }
-      double cpart = 0.0;
-#pragma unroll
-      for (int ht = 0; ht < D::HT; ++ht) {
-        d4 v = xw_zero4();
-#pragma unroll
-        for (int ks = 0; ks < D::KSH; ++ks) v = XW_MFMA(xw_fragAT(th + o.IL2w, H, H, H, 16 * ht, 4 * ks), e1[ks >> 2][ks & 3], v);
-        const d4 w0 = xw_vecD(th + o.IL0w, H, 16 * ht);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) cpart += a0[ht][r] > 0.0 ? w0[r] * v[r] : 0.0;
-      }
-      gsn -= dub * xw_sum_over_g(cpart);
-    }
-    if (gs != nullptr && g == 0 && valid) gs[base + n] = gsn;
-  }
+  if (PARAMS && !DUO) store_field_grads<H, K>(slab, o, d, G);      // (duo sweep: the partner wave holds and stores them)
+  sweep_tail<H, K, PARAMS, ADJ>(th, o, d, N, base, valid, ncl, xT, start[ncl], jobs.x_ones != 0, lam, xpb, ub0, accFL, accFLb, flw,
+                                gx, gs, slab, lds);
 }
 
 // ---- the duo sweep's second wave: weight gradients of the field -------------------------------------------------------
@@ -1544,6 +1560,8 @@ __global__ void __launch_bounds__(XW_DUO_THREADS) k_ode_bwd_duo(const BwdJobs jo
   else duo_outer<H, K, M, METHOD>(jobs, tf, th, L, d, lds, (int)blockIdx.x);
 }
 
+#include "xw_ode_n4.h"
+
 template <int H, int K, int M>
 int launch_fwd(int method, const FwdJobs& jobs, const double* t, const double* theta, int L, int d, hipStream_t s) {
   const dim3 grid(jobs.tile0[jobs.n]), block(64);
@@ -1562,8 +1580,18 @@ int launch_fwd(int method, const FwdJobs& jobs, const double* t, const double* t
   return xw_launch_status();
 }
 template <int H, int K, int M, bool PARAMS>
-int launch_bwd(int method, const BwdJobs& jobs, const double* t, const double* theta, int L, int d, bool adj, hipStream_t s) {
+int launch_bwd(int method, const BwdJobs& jobs, const double* t, const double* theta, int L, int d, bool adj, bool narrow,
+               hipStream_t s) {
   const dim3 grid(jobs.tile0[jobs.n]), block(64);
+  if (narrow) {
+    // narrow tiles (xw_ode_n4.h): the same grid of 16-path tiles, four waves of 4 paths each; from the activation store only
+    if (adj || method > 1) return XW_E_ARG;
+    for (int i = 0; i < jobs.n; ++i)
+      if (jobs.act[i] == nullptr) return XW_E_ARG;
+    if (method == 0) hipLaunchKernelGGL((n4::k_ode_bwd_n4<H, K, M, 0, PARAMS>), grid, dim3(256), 0, s, jobs, t, theta, L, d);
+    else hipLaunchKernelGGL((n4::k_ode_bwd_n4<H, K, M, 1, PARAMS>), grid, dim3(256), 0, s, jobs, t, theta, L, d);
+    return xw_launch_status();
+  }
   if (adj) {
     switch (method) {
       case 0: hipLaunchKernelGGL((k_ode_bwd<H, K, M, 0, PARAMS, false, true>), grid, block, 0, s, jobs, t, theta, L, d); break;
@@ -1604,6 +1632,13 @@ int launch_bwd(int method, const BwdJobs& jobs, const double* t, const double* t
 #define XW_CAT4_(a, b, c, d) a##b##c##d
 #define XW_CAT4(a, b, c, d) XW_CAT4_(a, b, c, d)
 #define XW_ODE_FN(name) XW_CAT4(name, XW_ODE_H, _, XW_ODE_K)
+#ifdef XW_ODE_ONLY_M      /* development builds (ISA listings, A/B variants): one depth only */
+#define XW_ODE_DISPATCH(CALL)                                    \
+  switch (m) {                                                   \
+    case XW_ODE_ONLY_M: { CALL(XW_ODE_H, XW_ODE_K, XW_ODE_ONLY_M) } \
+    default: return XW_E_DIMS;                                   \
+  }
+#else
 #define XW_ODE_DISPATCH(CALL)                                    \
   switch (m) {                                                   \
     case 1: { CALL(XW_ODE_H, XW_ODE_K, 1) }                      \
@@ -1616,6 +1651,7 @@ int launch_bwd(int method, const BwdJobs& jobs, const double* t, const double* t
     case 8: { CALL(XW_ODE_H, XW_ODE_K, 8) }                      \
     default: return XW_E_DIMS;                                   \
   }
+#endif
 
 extern "C" int XW_ODE_FN(xw_ode_fwd_multi_w)(const XwOdeFwdJob* jobs, int njobs, const double* t, const double* theta, int method,
                                              int L, int d, int m, double* zero16, void* stream) {
@@ -1646,7 +1682,7 @@ extern "C" int XW_ODE_FN(xw_ode_fwd_multi_w)(const XwOdeFwdJob* jobs, int njobs,
 
 extern "C" int XW_ODE_FN(xw_ode_bwd_multi_w)(const XwOdeBwdJob* jobs, int njobs, const double* t, const double* theta, int method,
                                              int L, int d, int m, int mode, void* stream) {
-  if (!jobs || njobs < 1 || njobs > XW_MAXJOBS || !t || !theta || L <= 0 || d <= 0 || m < 1 || (mode & 3) == 0 || ((mode & 4) && (mode & 3) != 3) || ((mode & 8) && (mode & 4))) return XW_E_ARG;
+  if (!jobs || njobs < 1 || njobs > XW_MAXJOBS || !t || !theta || L <= 0 || d <= 0 || m < 1 || (mode & 3) == 0 || ((mode & 4) && (mode & 3) != 3) || ((mode & 8) && (mode & 4)) || ((mode & 16) && (mode & 8)) || (mode & ~31)) return XW_E_ARG;
   BwdJobs J;
   J.n = njobs;
   J.x_ones = (mode & 4) ? 1 : 0;
@@ -1686,8 +1722,8 @@ extern "C" int XW_ODE_FN(xw_ode_bwd_multi_w)(const XwOdeBwdJob* jobs, int njobs,
   }
   hipStream_t s = (hipStream_t)stream;
 #define CALL(HH, KK, MM)                                                             \
-  return (mode & 2) ? launch_bwd<HH, KK, MM, true>(method, J, t, theta, L, d, (mode & 8) != 0, s)     \
-                    : launch_bwd<HH, KK, MM, false>(method, J, t, theta, L, d, (mode & 8) != 0, s);
+  return (mode & 2) ? launch_bwd<HH, KK, MM, true>(method, J, t, theta, L, d, (mode & 8) != 0, (mode & 16) != 0, s)     \
+                    : launch_bwd<HH, KK, MM, false>(method, J, t, theta, L, d, (mode & 8) != 0, (mode & 16) != 0, s);
   XW_ODE_DISPATCH(CALL)
 #undef CALL
 }

@@ -168,6 +168,12 @@ class Engine:
         #  forward is 8 % shorter and the stepper's chain is what the sub-step waits for: 12/16 -- discriminator sub-step
         #  0.586 / 0.562 / 0.566 / 0.569 / 0.654 ms at 11..15 sixteenths, tools/sweep_caps.py)
         self.v_blocks_disc = int(os.environ.get('XW_V_BLOCKS_DISC', '0')) or (12 * 2 * cus) // 16
+        # Narrow tiles (csrc/xw_ode_n4.h, xw_ode_bwd mode bit 4): a 16-path tile of a sweep as four waves of 4 paths instead of one
+        # (+ a partner) -- four times the instruction streams, each a shorter chain, at ~1.8 x the matrix-pipe time per path.
+        # Used where a sweep runs with SIMDs to spare: sweep B of the generator sub-step (alone on the chip behind the test
+        # network), as long as its waves still find a SIMD each.  XW_NARROW: 0 off, 1 auto (default), 2 wherever possible.
+        self.narrow = os.environ.get('XW_NARROW', '1')
+        self.simds = 4 * cus
         self._phi_version = 0
         self.streams = [torch.cuda.Stream(device=device) for _ in range(4)]
         # several GPUs on RCCL: the exchanges are device-side calls on the current stream (dist.World.capturable), so a
@@ -561,6 +567,15 @@ class Engine:
             ck = 0.0
         G.ck = ck
 
+    def _narrow_ok(self, jobs, alone):
+        """narrow tiles for this sweep launch?  `alone`: nothing else of the sub-step runs beside it"""
+        if self.narrow == '0' or self.adjoint or self.method > 1 or any(j.get('act') is None for j in jobs):
+            return False
+        if self.narrow == '2':
+            return True
+        tiles = sum((j['xT'].shape[1] + 15) // 16 for j in jobs)
+        return 4 * tiles * (1 if alone else 4) <= self.simds // 2
+
     def _job(self, G, which, ubar=None, gslab=None, want_x=False):
         if which == 'i':
             j = dict(xT=G.xT, start=G.start, u=G.u, Y=G.Y, act=G.act, ubar=ubar, gslab=gslab)
@@ -640,9 +655,12 @@ class Engine:
             sweeps = [dict(self._job(G, 'i', None, G.slabA[:G.ns_u], want_x=fused_x), res=res_A)]
             if joint:
                 sweeps.append(dict(self._job(G, 'b', None, G.slabA[G.ns_u:]), res=res_b))
-            KN.ode_bwd_multi(sweeps, G.t, th, *M, want_x=fused_x, want_params=True, x_cot_ones=fused_x, adjoint=self.adjoint)
+            KN.ode_bwd_multi(sweeps, G.t, th, *M, want_x=fused_x, want_params=True, x_cot_ones=fused_x, adjoint=self.adjoint,
+                             narrow=self._narrow_ok(sweeps, alone=False))
             if G.Nb and not joint:
-                KN.ode_bwd_multi([dict(self._job(G, 'b', None, G.slabA[G.ns_u:]), res=res_b)], G.tb, th, *M, want_x=False, want_params=True, adjoint=self.adjoint)
+                sweep_b = [dict(self._job(G, 'b', None, G.slabA[G.ns_u:]), res=res_b)]
+                KN.ode_bwd_multi(sweep_b, G.tb, th, *M, want_x=False, want_params=True, adjoint=self.adjoint,
+                                 narrow=self._narrow_ok(sweep_b, alone=False))
             e_A = self._mark()
         e_v = self._mark()
         self._join(e_f)
@@ -651,8 +669,9 @@ class Engine:
         # test network -> sweep B -> Adam (0.5063 -> 0.5034 ms per generator sub-step in the same run)
         res_B = dict(u=G.u, ref=G.v, coef=G.Vol / G.Nglob / G.L * G.s3_scale, base=G.Vol / G.Nglob,
                      weak=dict(w=G.w, c=G.c, cp=G.cp, ckappa=G.ck))
-        KN.ode_bwd_multi([dict(self._job(G, 'i', None, G.slabB), res=res_B)], G.t, th, *M, want_x=False, want_params=True,
-                         adjoint=self.adjoint)
+        sweep_B = [dict(self._job(G, 'i', None, G.slabB), res=res_B)]
+        KN.ode_bwd_multi(sweep_B, G.t, th, *M, want_x=False, want_params=True, adjoint=self.adjoint,
+                         narrow=self._narrow_ok(sweep_B, alone=True))
         # the reduction needs nabla_x u (sweep A) and v, not sweep B: it runs behind sweep A on the side stream, next to
         # the tail of sweep B, instead of after it
         with self._side(3, e_A, e_v, *[e for e in (e_x, e_b) if e is not None]):   # (re-entering side 1 here crashes hipStreamEndCapture)
@@ -754,7 +773,9 @@ class Engine:
             # (the only sweep of this sub-step has no weight gradients: the forward stores a seventh of the record)
             KN.ode_fwd_multi([self._job(G, 'i')], G.t, th, *M, zero16=self.scal, act_x_only=True)
             self._reaction(G)
-            KN.ode_bwd_multi([self._job(G, 'i', want_x=True)], G.t, th, *M, want_x=True, want_params=False, adjoint=self.adjoint)
+            sweep_x = [self._job(G, 'i', want_x=True)]
+            KN.ode_bwd_multi(sweep_x, G.t, th, *M, want_x=True, want_params=False, adjoint=self.adjoint,
+                             narrow=self._narrow_ok(sweep_x, alone=False))
             e_x = self._mark()
         self._join(e_x)
         self._contract(G, self.adam_v)

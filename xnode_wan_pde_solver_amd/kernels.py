@@ -126,14 +126,16 @@ def ode_fwd_multi(jobs, t, theta, method, H, K, m, zero16=None, act_x_only=False
     check(lib.xw_ode_fwd_multi(arr, len(jobs), _p(t), _p(theta), method, L, d, H, K, m, _p(zero16), _stream()), 'xw_ode_fwd_multi')
 
 
-def ode_bwd_multi(jobs, t, theta, method, H, K, m, want_x, want_params, x_cot_ones=False, adjoint=False):
+def ode_bwd_multi(jobs, t, theta, method, H, K, m, want_x, want_params, x_cot_ones=False, adjoint=False, narrow=False):
     """jobs: list of dicts(xT, start, Y, ubar or None, gx, gs, gslab); ONE launch for all groups.
     res = dict(u[L,N], ref ([N] with first_only, else [L,N]), coef, base, first_only) instead of ubar: the cotangent
     base + coef (u - ref) (at l = 0 only with first_only) is formed inside the sweep.
     x_cot_ones (with want_x and want_params): gx, gs for the all-ones cotangent, parameter gradients for ubar, which must
     equal 1 at every time index >= 1; jobs without gx / gs produce no x outputs.
     adjoint: the continuous adjoint of torchdiffeq.odeint_adjoint (config['adjoint'] = True) instead of the reverse of
-    the steps taken; ignores the activation store."""
+    the steps taken; ignores the activation store.
+    narrow: narrow tiles (mode bit 4, csrc/xw_ode_n4.h): four waves of 4 paths per 16-path tile instead of one -- for
+    launches that leave SIMDs idle; needs every job's activation store (euler, midpoint)."""
     _need_gpu()
     L = t.shape[0]
     d = jobs[0]['xT'].shape[0]
@@ -177,7 +179,9 @@ def ode_bwd_multi(jobs, t, theta, method, H, K, m, want_x, want_params, x_cot_on
         raise XnwanError('x_cot_ones needs want_x and want_params')
     if x_cot_ones and adjoint:
         raise XnwanError('x_cot_ones is not available with the continuous adjoint')
-    mode = (1 if want_x else 0) | (2 if want_params else 0) | (4 if x_cot_ones else 0) | (8 if adjoint else 0)
+    if narrow and (adjoint or method > 1 or any(j.get('act') is None for j in jobs)):
+        raise XnwanError('narrow-tile sweeps run from the activation store of euler / midpoint (no adjoint=True, no rk4)')
+    mode = (1 if want_x else 0) | (2 if want_params else 0) | (4 if x_cot_ones else 0) | (8 if adjoint else 0) | (16 if narrow else 0)
     check(lib.xw_ode_bwd_multi(arr, len(jobs), _p(t), _p(theta), method, L, d, H, K, m, mode, _stream()), 'xw_ode_bwd_multi')
 
 
