@@ -56,6 +56,9 @@ int xw_ode_fwd(const double* xT, const double* t, const double* start, const dou
 typedef struct { const double* xT; const double* start; double* u; double* Y; double* act; int N;
                  int act_x_only;   /* != 0: store only what a sweep WITHOUT weight gradients (mode 1) reads back -- the tanh
                                       rows and the ReLU-mask words, 1/7 of the bytes; same for every job of a launch */
+                 int narrow;       /* != 0: NARROW TILES -- the 16 paths of a tile as four waves of 4 paths x 16 rows
+                                      (csrc/xw_ode_n4.h; see xw_ode_bwd mode bit 4): the same outputs and the same activation
+                                      store, for launches that leave SIMDs idle; same for every job of a launch */
                } XwOdeFwdJob;
 /* rows of the activation record per step (0: this method's sweeps recompute; negative: XW_E_*) */
 int xw_ode_act_rows(int method, int H, int K, int m);

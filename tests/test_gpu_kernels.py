@@ -360,6 +360,26 @@ def test_ode_narrow_tile_sweeps(Hh, Kk, m, N, L, d, solver):
         if k in theta:
             _close(flat[off:off + n].view(theta[k].shape), grads[2 + order.index(k)], 1e-10, 'grad ' + k)
         off += n
+    # the forward pass on narrow tiles (XwOdeFwdJob.narrow): same u, checkpoints and activation record (compared through the
+    # sweeps that read it: the 16-path sweep from the narrow store, the narrow sweep from the narrow store)
+    _close(job['u'].t(), u_ref.detach(), 1e-12, 'u (16-path forward)')
+    jn = dict(job, u=new(L, N), Y=new(L, Hh, N), act=new(L - 1, rows, KN.ode_act_cols(N)))
+    KN.ode_fwd_multi([jn], tc, blob, mid, Hh, Kk, m, narrow=True)
+    _close(jn['u'].t(), u_ref.detach(), 1e-12, 'u (narrow forward)')
+    _close(jn['Y'], job['Y'], 1e-12, 'checkpoints (narrow forward)')
+    ncol = KN.ode_act_cols(N)
+    written = torch.isfinite(job['act'])
+    assert torch.equal(torch.isfinite(jn['act']), written), 'the narrow forward fills the same slots of the record'
+    floats = jn['act'][:, :rows - 2 * (1 if solver == 'euler' else 2)]            # (the mask words behind them are not doubles)
+    _close(torch.nan_to_num(floats), torch.nan_to_num(job['act'][:, :floats.shape[1]]), 1e-12, 'activation record (narrow forward)')
+    for narrow in (False, True):
+        gxn, gsn, slabn = sweep(narrow, j=jn)
+        _close(gxn, gxw, 1e-12, 'gx from the narrow store'); _close(gsn, gsw, 1e-12, 'gs from the narrow store')
+        _close(KN.slab_sum(slabn).cpu(), flatw, 1e-12, 'theta gradient from the narrow store')
+    jnx = dict(jn, act=new(L - 1, rows, KN.ode_act_cols(N)))
+    KN.ode_fwd_multi([jnx], tc, blob, mid, Hh, Kk, m, act_x_only=True, narrow=True)
+    gxn, gsn, _ = sweep(True, want_params=False, j=jnx)
+    _close(gxn, gxw, 1e-12, 'gx (reduced narrow store)'); _close(gsn, gsw, 1e-12, 'gs (reduced narrow store)')
     # without weight gradients, from a store that only holds the tanh rows and the mask words
     jx = dict(job, act=new(L - 1, rows, KN.ode_act_cols(N)))
     KN.ode_fwd_multi([jx], tc, blob, mid, Hh, Kk, m, act_x_only=True)

@@ -482,6 +482,7 @@ struct FwdJobs {
   int tile0[XW_MAXJOBS + 1];   // first block of each job
   int n;
   int x_only;                  // the stores of this launch only serve x-only sweeps (XwOdeFwdJob.act_x_only)
+  int narrow;                  // narrow tiles (XwOdeFwdJob.narrow, xw_ode_n4.h)
   double* zero16;              // optional: 16 doubles cleared by block 0 (the sub-step's partial-sum slots)
 };
 struct BwdJobs {
@@ -1567,6 +1568,20 @@ int launch_fwd(int method, const FwdJobs& jobs, const double* t, const double* t
   const dim3 grid(jobs.tile0[jobs.n]), block(64);
   bool act = true;                                     // all jobs or none, all in the same mode (checked by the caller)
   for (int i = 0; i < jobs.n; ++i) act = act && jobs.act[i] != nullptr;
+  if (jobs.narrow) {
+    // narrow tiles (xw_ode_n4.h): the same grid of 16-path tiles, four waves of 4 paths each
+    switch (method * 3 + (act ? (jobs.x_only ? 2 : 1) : 0)) {
+      case 0: hipLaunchKernelGGL((n4::k_ode_fwd_n4<H, K, M, 0, 0>), grid, dim3(256), 0, s, jobs, t, theta, L, d); break;
+      case 1: hipLaunchKernelGGL((n4::k_ode_fwd_n4<H, K, M, 0, 1>), grid, dim3(256), 0, s, jobs, t, theta, L, d); break;
+      case 2: hipLaunchKernelGGL((n4::k_ode_fwd_n4<H, K, M, 0, 2>), grid, dim3(256), 0, s, jobs, t, theta, L, d); break;
+      case 3: hipLaunchKernelGGL((n4::k_ode_fwd_n4<H, K, M, 1, 0>), grid, dim3(256), 0, s, jobs, t, theta, L, d); break;
+      case 4: hipLaunchKernelGGL((n4::k_ode_fwd_n4<H, K, M, 1, 1>), grid, dim3(256), 0, s, jobs, t, theta, L, d); break;
+      case 5: hipLaunchKernelGGL((n4::k_ode_fwd_n4<H, K, M, 1, 2>), grid, dim3(256), 0, s, jobs, t, theta, L, d); break;
+      case 6: hipLaunchKernelGGL((n4::k_ode_fwd_n4<H, K, M, 2, 0>), grid, dim3(256), 0, s, jobs, t, theta, L, d); break;
+      default: return XW_E_ARG;
+    }
+    return xw_launch_status();
+  }
   switch (method * 3 + (act ? (jobs.x_only ? 2 : 1) : 0)) {
     case 0: hipLaunchKernelGGL((k_ode_fwd<H, K, M, 0, 0>), grid, block, 0, s, jobs, t, theta, L, d); break;
     case 1: hipLaunchKernelGGL((k_ode_fwd<H, K, M, 0, 1>), grid, block, 0, s, jobs, t, theta, L, d); break;
@@ -1660,11 +1675,13 @@ extern "C" int XW_ODE_FN(xw_ode_fwd_multi_w)(const XwOdeFwdJob* jobs, int njobs,
   J.n = njobs;
   J.zero16 = zero16;
   J.x_only = jobs[0].act_x_only ? 1 : 0;
+  J.narrow = jobs[0].narrow ? 1 : 0;
   J.tile0[0] = 0;
   for (int i = 0; i < XW_MAXJOBS; ++i) {
     const bool on = i < njobs;
     if (on && (!jobs[i].xT || !jobs[i].start || !jobs[i].u || jobs[i].N <= 0)) return XW_E_ARG;
     if (on && (jobs[i].act_x_only ? 1 : 0) != J.x_only) return XW_E_ARG;         // one store mode per launch
+    if (on && (jobs[i].narrow ? 1 : 0) != J.narrow) return XW_E_ARG;              // one layout per launch
     J.xT[i] = on ? jobs[i].xT : nullptr;
     J.start[i] = on ? jobs[i].start : nullptr;
     J.u[i] = on ? jobs[i].u : nullptr;

@@ -602,4 +602,230 @@ __global__ void __launch_bounds__(256, 2) k_ode_bwd_n4(const BwdJobs jobs, const
   sweep4<H, K, M, METHOD, PARAMS>(jobs, tf, th, L, d, lds, (int)blockIdx.x);
 }
 
+// ---- forward pass on narrow tiles -------------------------------------------------------------------------------------
+// The same outputs as k_ode_fwd (u, the checkpoints Y, the activation store in ActLayout -- so that either kind of sweep
+// can read what either kind of forward pass wrote), four waves of 4 paths per 16-path tile.  Per field evaluation 41 matrix
+// instructions (5 + 4 (m - 1) + 8 at (H, K) = (20, 10)), tanh once per 16 rows x 4 paths, one ReLU / mask push per layer.
+template <int H, int K> struct W4 {          // forward operands (rotation c): blocks (b, s_c(b)) of Wy, Wh, Wo
+  double Wy0[4], Wy1[4], Wh[4], Wo0[4], Wo1[4];
+  double wt, bh, bo[Dn<H, K>::NY];           // C layout: time column of Win, Wh.b, Wo.b
+};
+template <int H, int K>
+__device__ __forceinline__ void load_W4(const double* __restrict__ th, const UOff& o, int d, const Geo& g, W4<H, K>& w) {
+  typedef Dn<H, K> D;
+  const double* Wy = th + o.Win + d + 1;
+  constexpr int H0 = H < 16 ? H : 16;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    w.Wy0[c] = frag<false>(Wy, o.ldin, K, H0, 0, 0, g, c);
+    w.Wh[c] = frag<false>(th + o.Wh, K, K, K, 0, 0, g, c);
+    w.Wo0[c] = frag<false>(th + o.Wo, K, H0, K, 0, 0, g, c);
+    w.Wy1[c] = 0.0;
+    w.Wo1[c] = 0.0;
+    if (D::NY == 2) {
+      if (D::REP) {
+        if (c == 0) w.Wy1[0] = frag<false, false, true>(Wy, o.ldin, K, H, 0, 16, g, 0);
+        w.Wo1[c] = frag<false, true, false>(th + o.Wo, K, H, K, 16, 0, g, c);
+      } else {
+        w.Wy1[c] = frag<false>(Wy, o.ldin, K, H, 0, 16, g, c);
+        w.Wo1[c] = frag<false>(th + o.Wo, K, H, K, 16, 0, g, c);
+      }
+    }
+  }
+  const int rk = 4 * g.b + g.hi;
+  w.wt = rk < K ? xw_ld_g(th + o.Win + (long)rk * o.ldin + d) : 0.0;
+  w.bh = rk < K ? xw_ld_g(th + o.Whb + rk) : 0.0;
+#pragma unroll
+  for (int y = 0; y < D::NY; ++y) {
+    const int rh = y == 0 ? rk : (D::REP ? 16 + g.hi : 16 + rk);
+    w.bo[y] = rh < H ? xw_ld_g(th + o.Wob + rh) : 0.0;
+  }
+}
+// out[H] += Wm[H x H] in[H] in the C layout (the initial layers; operands straight from memory, used once)
+template <int H, int K>
+__device__ __forceinline__ void mat_hh(const double* __restrict__ Wm, const Geo& g, const double (&in)[Dn<H, K>::NY],
+                                       double (&out)[Dn<H, K>::NY]) {
+  typedef Dn<H, K> D;
+  constexpr int H0 = H < 16 ? H : 16;
+  const R4 r0 = rots(in[0]);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) out[0] = XW_MFMA4(frag<false>(Wm, H, H0, H0, 0, 0, g, c), r0.v[c], out[0]);
+  if (D::NY == 2) {
+    if (D::REP) {
+      out[0] = XW_MFMA4((frag<false, false, true>(Wm, H, H0, H, 0, 16, g, 0)), in[D::NY - 1], out[0]);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) out[D::NY - 1] = XW_MFMA4((frag<false, true, false>(Wm, H, H, H0, 16, 0, g, c)), r0.v[c], out[D::NY - 1]);
+      out[D::NY - 1] = XW_MFMA4((frag<false, true, true>(Wm, H, H, H, 16, 16, g, 0)), in[D::NY - 1], out[D::NY - 1]);
+    } else {
+      const R4 r1 = rots(in[D::NY - 1]);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        out[0] = XW_MFMA4(frag<false>(Wm, H, H0, H, 0, 16, g, c), r1.v[c], out[0]);
+        out[D::NY - 1] = XW_MFMA4(frag<false>(Wm, H, H, H0, 16, 0, g, c), r0.v[c], out[D::NY - 1]);
+        out[D::NY - 1] = XW_MFMA4(frag<false>(Wm, H, H, H, 16, 16, g, c), r1.v[c], out[D::NY - 1]);
+      }
+    }
+  }
+}
+// sum over the 16 rows a lane group (lo fixed) holds: the four blocks of a 16-lane row, then the four rows of lanes
+__device__ __forceinline__ double sum_rows(double x) {
+  x += rot<2>(x);
+  x += rot<1>(x);
+  return xw_sum_over_g(x);
+}
+
+template <int H, int K, int M, int METHOD, int ACT>
+__global__ void __launch_bounds__(256, 2) k_ode_fwd_n4(const FwdJobs jobs, const double* __restrict__ tf,
+                                                       const double* __restrict__ th, int L, int d) {
+  typedef Dn<H, K> D;
+  typedef RK<METHOD> T;
+  typedef ActLayout<H, K, M, T::S> AL;
+  static_assert(D::KB * (M - 1) + 3 <= 32, "mask word");
+  __builtin_amdgcn_s_setprio(XW_ODE_PRIO);
+  const Geo g = geo();
+  const int job = find_job(jobs, (int)blockIdx.x);
+  const double* __restrict__ xT = jobs.xT[job];
+  double* __restrict__ u = jobs.u[job];
+  double* __restrict__ Y = jobs.Y[job];
+  double* __restrict__ act = jobs.act[job];
+  const int N = jobs.N[job];
+  const int tile = (int)blockIdx.x - jobs.tile0[job];
+  const int col = tile * 16 + 4 * g.q + g.lo;
+  const bool valid = col < N;
+  const int ncl = valid ? col : N - 1;
+  if (blockIdx.x == 0 && jobs.zero16 != nullptr && threadIdx.x < 16) jobs.zero16[threadIdx.x] = 0.0;
+  const UOff o = u_offsets(d, H, K);
+  W4<H, K> w;
+  load_W4<H, K>(th, o, d, g, w);
+  int rowC[D::NY];
+  bool liveC[D::NY];                          // this lane holds a row of the hidden state that exists (and, REP: is block 0's copy)
+  double flw[D::NY];
+#pragma unroll
+  for (int y = 0; y < D::NY; ++y) {
+    rowC[y] = y == 0 ? 4 * g.b + g.hi : (D::REP ? 16 + g.hi : 16 + 4 * g.b + g.hi);
+    liveC[y] = rowC[y] < H && !(y == 1 && D::REP && g.b != 0);
+    flw[y] = liveC[y] ? xw_ld_g(th + o.FLw + rowC[y]) : 0.0;      // (a replicated row enters the read-out once)
+  }
+  const double flb = th[o.FLb];
+  // ---- lift: start scalar -> y_0 (initial_layers of src/model.py:78,97) ---------------------------------------------------
+  double y[D::NY];
+  {
+    const double sv = jobs.start[job][ncl];
+    double a0[D::NY], a1[D::NY];
+#pragma unroll
+    for (int q = 0; q < D::NY; ++q) {
+      const bool in = rowC[q] < H;
+      a0[q] = in ? xw_relu1(fma(xw_ld_g(th + o.IL0w + rowC[q]), sv, xw_ld_g(th + o.IL0b + rowC[q]))) : 0.0;
+      a1[q] = in ? xw_ld_g(th + o.IL2b + rowC[q]) : 0.0;
+      y[q] = in ? xw_ld_g(th + o.IL4b + rowC[q]) : 0.0;
+    }
+    mat_hh<H, K>(th + o.IL2w, g, a0, a1);
+#pragma unroll
+    for (int q = 0; q < D::NY; ++q) a1[q] = xw_relu1(a1[q]);
+    mat_hh<H, K>(th + o.IL4w, g, a1, y);
+  }
+  // ---- xp = Win.b + Win[:, :d] x  (time-invariant along a path) -------------------------------------------------------------
+  double xp;
+  {
+    const int rk = 4 * g.b + g.hi;
+    xp = rk < K ? xw_ld_g(th + o.Winb + rk) : 0.0;
+    for (int r = 0; r < (d + 15) / 16; ++r) {
+      const int dim = 16 * r + rk;
+      const R4 xr = rots(dim < d ? xw_ld_g(xT + (long)dim * N + ncl) : 0.0);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) xp = XW_MFMA4(frag<false>(th + o.Win, o.ldin, K, d, 0, 16 * r, g, c), xr.v[c], xp);
+    }
+  }
+  // lane offsets into the activation store's tile (C layout), store predicates
+  const int cK = koff<K>(g.b, g.hi, 4 * g.q + g.lo);
+  const bool liveK = 4 * g.b + g.hi < K;
+  int cY[D::NY];
+#pragma unroll
+  for (int q = 0; q < D::NY; ++q) cY[q] = 64 * (q == 0 ? g.b : (D::REP ? 4 : 4 + g.b)) + 4 * (4 * g.q + g.lo) + g.hi;
+  const long ntile = (N + 15) >> 4;
+
+  // one field evaluation: F([x, t, y]) of src/model.py:153-156; S: the stage's part of the activation record (or nullptr)
+  auto field = [&](double t, const double (&yi)[D::NY], double (&out)[D::NY], double* __restrict__ S, unsigned* __restrict__ mw) {
+    double z = fma(w.wt, t, xp);
+    {
+      const R4 r0 = rots(yi[0]);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) z = XW_MFMA4(w.Wy0[c], r0.v[c], z);
+      if (D::NY == 2) {
+        if (D::REP) z = XW_MFMA4(w.Wy1[0], yi[D::NY - 1], z);
+        else {
+          const R4 r1 = rots(yi[D::NY - 1]);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) z = XW_MFMA4(w.Wy1[c], r1.v[c], z);
+        }
+      }
+    }
+    unsigned bits = 0;
+#pragma unroll
+    for (int j = 0; j < M - 1; ++j) {
+      // (the bit is z > 0, not the sign: a dead layer feeds exact +0 to the next one and relu'(+0) = 0, xw_ode.hip SaveX)
+      bits = (bits << D::KB) | (z > 0.0 ? 1u : 0u);
+      const double r = xw_relu1(z);
+      if (ACT == 1 && liveK) xw_st_nt(r, S + j * K * 16 + cK);
+      const R4 rr = rots(r);
+      z = w.bh;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) z = XW_MFMA4(w.Wh[c], rr.v[c], z);
+    }
+    const double a = xw_tanh(z);
+    if (ACT && liveK) xw_st_nt(a, S + (M - 1) * K * 16 + cK);
+    if (ACT) {
+      // this lane pushed (layer j) at bit KB (M - 2 - j); the record wants (layer j, block b) at bit KB (M - 1) - 1 - KB j - b,
+      // all blocks of a lane row in ONE word: shift by the block, OR over the four blocks, block 0 stores
+      unsigned wd = bits << (D::KB - 1 - (g.b < D::KB ? g.b : D::KB - 1));
+      wd = g.b < D::KB ? wd : 0u;
+      wd |= (unsigned)rot_i<2>((int)wd);
+      wd |= (unsigned)rot_i<1>((int)wd);
+      if (g.b == 0) __builtin_nontemporal_store(wd, (unsigned __attribute__((address_space(1)))*)(mw + 16 * g.hi + 4 * g.q + g.lo));
+    }
+    const R4 ar = rots(a);
+#pragma unroll
+    for (int q = 0; q < D::NY; ++q) out[q] = w.bo[q];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      out[0] = XW_MFMA4(w.Wo0[c], ar.v[c], out[0]);
+      if (D::NY == 2) out[D::NY - 1] = XW_MFMA4(w.Wo1[c], ar.v[c], out[D::NY - 1]);
+    }
+  };
+
+  for (int l = 0; l < L; ++l) {
+    double part = 0.0;
+#pragma unroll
+    for (int q = 0; q < D::NY; ++q) {
+      part = fma(flw[q], y[q], part);
+      if (Y != nullptr && valid && liveC[q]) Y[((long)l * H + rowC[q]) * N + col] = y[q];
+    }
+    const double ul = sum_rows(part) + flb;               // final_linear, src/model.py:110
+    if (g.b == 0 && g.hi == 0 && valid) u[(long)l * N + col] = ul;
+    if (l == L - 1) break;
+    const double t0 = tf[l], dt = tf[l + 1] - t0;
+    double* __restrict__ A = ACT ? act + ((long)l * ntile + tile) * (AL::TOTAL * 16) : nullptr;
+    double k[T::S][D::NY];
+#pragma unroll
+    for (int i = 0; i < T::S; ++i) {
+      double yi[D::NY];
+#pragma unroll
+      for (int q = 0; q < D::NY; ++q) {
+        yi[q] = y[q];
+#pragma unroll
+        for (int j = 0; j < i; ++j)
+          if (T::a(i, j) != 0.0) yi[q] = fma(dt * T::a(i, j), k[j][q], yi[q]);
+        if (ACT == 1 && i > 0 && liveC[q]) xw_st_nt(yi[q], A + (long)(AL::YI + (i - 1) * H) * 16 + cY[q]);
+      }
+      field(t0 + T::c(i) * dt, yi, k[i], ACT ? A + (long)i * AL::STAGE * 16 : nullptr,
+            ACT ? reinterpret_cast<unsigned*>(A + (long)(AL::MASK + 2 * i) * 16) : nullptr);
+    }
+#pragma unroll
+    for (int i = 0; i < T::S; ++i)
+      if (T::b(i) != 0.0)
+#pragma unroll
+        for (int q = 0; q < D::NY; ++q) y[q] = fma(dt * T::b(i), k[i][q], y[q]);
+  }
+}
+
 }  // namespace n4

@@ -173,6 +173,12 @@ class Engine:
         # Used where a sweep runs with SIMDs to spare: sweep B of the generator sub-step (alone on the chip behind the test
         # network), as long as its waves still find a SIMD each.  XW_NARROW: 0 off, 1 auto (default), 2 wherever possible.
         self.narrow = os.environ.get('XW_NARROW', '1')
+        # Measured (profiles/r04_shard_sweep.md): forward and the sweep without weight gradients gain on shards up to ~2048
+        # paths (0.302 -> 0.272 ms per sub-step at 512 paths, 0.332 -> 0.294 at 1024, 0.375 -> 0.367 at 2048); the narrow sweep
+        # WITH weight gradients only ties the two-wave duo sweep (88 against 83 us alone) and is left to XW_NARROW_SET=fxp; at
+        # the headline size everything narrow LOSES (0.502 -> 0.586 ms): those phases are bound by the sum of SIMD time.
+        self.narrow_set = os.environ.get('XW_NARROW_SET', 'fx')
+        self.narrow_tiles = {'f': 192, 'x': 128, 'p': 64}    # largest launch (16-path tiles, all its jobs) that still gains
         self.simds = 4 * cus
         self._phi_version = 0
         self.streams = [torch.cuda.Stream(device=device) for _ in range(4)]
@@ -567,14 +573,18 @@ class Engine:
             ck = 0.0
         G.ck = ck
 
-    def _narrow_ok(self, jobs, alone):
-        """narrow tiles for this sweep launch?  `alone`: nothing else of the sub-step runs beside it"""
-        if self.narrow == '0' or self.adjoint or self.method > 1 or any(j.get('act') is None for j in jobs):
+    def _narrow_ok(self, jobs, alone, forward=False, params=True):
+        """narrow tiles (csrc/xw_ode_n4.h) for this stepper launch?  XW_NARROW: 0 never, 1 by size (default), 2 wherever the
+        kernels exist; XW_NARROW_SET: which launches may (f forward, x sweeps without weight gradients, p sweeps with them)"""
+        kind = 'f' if forward else ('p' if params else 'x')
+        if self.narrow == '0' or kind not in self.narrow_set:
+            return False
+        if not forward and (self.adjoint or self.method > 1 or any(j.get('act') is None for j in jobs)):
             return False
         if self.narrow == '2':
             return True
         tiles = sum((j['xT'].shape[1] + 15) // 16 for j in jobs)
-        return 4 * tiles * (1 if alone else 4) <= self.simds // 2
+        return tiles <= self.narrow_tiles[kind]
 
     def _job(self, G, which, ubar=None, gslab=None, want_x=False):
         if which == 'i':
@@ -627,9 +637,11 @@ class Engine:
         if not getattr(G, 'skip_v', False):
             self._launch_test_net_here(G)                        # enqueued first: its blocks must be resident before the
         with self._side(1, e0):                                  # stepper's waves spread over the CUs
-            KN.ode_fwd_multi([self._job(G, 'i')] + ([self._job(G, 'b')] if joint else []), G.t, th, *M, zero16=self.scal)
+            fwd = [self._job(G, 'i')] + ([self._job(G, 'b')] if joint else [])
+            KN.ode_fwd_multi(fwd, G.t, th, *M, zero16=self.scal, narrow=self._narrow_ok(fwd, alone=False, forward=True))
             if G.Nb and not joint:
-                KN.ode_fwd_multi([self._job(G, 'b')], G.tb, th, *M)
+                fwd_b = [self._job(G, 'b')]
+                KN.ode_fwd_multi(fwd_b, G.tb, th, *M, narrow=self._narrow_ok(fwd_b, alone=False, forward=True))
             self._reaction(G)
             e_f = self._mark()
             # Cotangent A (pollution + the initial-value penalty at t_0) and the boundary cotangent are residuals of what
@@ -650,7 +662,9 @@ class Engine:
             # backward u.backward(ones) are the same adjoint: one launch returns the parameter gradient of A and nabla_x u.
             if not fused_x:
                 with self._side(2, e_f):
-                    KN.ode_bwd_multi([self._job(G, 'i', want_x=True)], G.t, th, *M, want_x=True, want_params=False, adjoint=self.adjoint)
+                    sweep_x = [self._job(G, 'i', want_x=True)]
+                    KN.ode_bwd_multi(sweep_x, G.t, th, *M, want_x=True, want_params=False, adjoint=self.adjoint,
+                                     narrow=self._narrow_ok(sweep_x, alone=False, params=False))
                     e_x = self._mark()
             sweeps = [dict(self._job(G, 'i', None, G.slabA[:G.ns_u], want_x=fused_x), res=res_A)]
             if joint:
@@ -771,11 +785,12 @@ class Engine:
             self._launch_test_net_here(G, blocks=self.v_blocks_disc)
         with self._side(1, e0):
             # (the only sweep of this sub-step has no weight gradients: the forward stores a seventh of the record)
-            KN.ode_fwd_multi([self._job(G, 'i')], G.t, th, *M, zero16=self.scal, act_x_only=True)
+            fwd = [self._job(G, 'i')]
+            KN.ode_fwd_multi(fwd, G.t, th, *M, zero16=self.scal, act_x_only=True, narrow=self._narrow_ok(fwd, alone=False, forward=True))
             self._reaction(G)
             sweep_x = [self._job(G, 'i', want_x=True)]
             KN.ode_bwd_multi(sweep_x, G.t, th, *M, want_x=True, want_params=False, adjoint=self.adjoint,
-                             narrow=self._narrow_ok(sweep_x, alone=False))
+                             narrow=self._narrow_ok(sweep_x, alone=False, params=False))
             e_x = self._mark()
         self._join(e_x)
         self._contract(G, self.adam_v)

@@ -105,10 +105,12 @@ def ode_fwd(xT, t, start, theta, method, H, K, m, want_Y=True, u=None, Y=None):
     return u, Y
 
 
-def ode_fwd_multi(jobs, t, theta, method, H, K, m, zero16=None, act_x_only=False):
+def ode_fwd_multi(jobs, t, theta, method, H, K, m, zero16=None, act_x_only=False, narrow=False):
     """jobs: list of dicts(xT[d,N], start[N], u[L,N], Y[L,H,N] or None) -- all groups share t, theta; ONE launch.
     act_x_only: the activation stores of this launch will only be read by sweeps without weight gradients (the
-    discriminator sub-step): only the tanh rows and the ReLU-mask words are written."""
+    discriminator sub-step): only the tanh rows and the ReLU-mask words are written.
+    narrow: narrow tiles (XwOdeFwdJob.narrow, csrc/xw_ode_n4.h): four waves of 4 paths per 16-path tile -- same outputs, same
+    store; for launches that leave SIMDs idle."""
     _need_gpu()
     L = t.shape[0]
     d = jobs[0]['xT'].shape[0]
@@ -122,6 +124,7 @@ def ode_fwd_multi(jobs, t, theta, method, H, K, m, zero16=None, act_x_only=False
             _chk(j['act'], F64, (max(L - 1, 1), ode_act_rows(method, H, K, m), ode_act_cols(N)), 'act')
         a.xT, a.start, a.u, a.Y, a.act, a.N = _p(j['xT']), _p(j['start']), _p(j['u']), _p(j.get('Y')), _p(j.get('act')), N
         a.act_x_only = 1 if act_x_only else 0
+        a.narrow = 1 if narrow else 0
     _chk(zero16, F64, (16,), 'zero16')
     check(lib.xw_ode_fwd_multi(arr, len(jobs), _p(t), _p(theta), method, L, d, H, K, m, _p(zero16), _stream()), 'xw_ode_fwd_multi')
 
