@@ -14,7 +14,8 @@ pytestmark = pytest.mark.gpu
 
 F64 = torch.float64
 H, K, M, W, Q = 20, 10, 8, 50, 9
-SIZES = [(20, 4096, 32), (50, 2048, 64), (100, 8192, 32)]      # configs[1]; per-GPU shares of configs[2] and configs[3]
+SIZES = [(20, 4096, 32), (50, 2048, 64), (100, 8192, 32),      # configs[1]; per-GPU shares of configs[2] and configs[3]
+         (50, 16384, 64), (100, 65536, 32)]                      # configs[2] and configs[3] WHOLE (their stated global batch) on one GPU
 
 
 def _rel(a, b):
@@ -34,18 +35,26 @@ def _setup(d, N, L, seed):
     return KN, g, dev, th, ph, xT, t.to(dev), start
 
 
+@pytest.mark.parametrize('narrow', [False, True])
 @pytest.mark.parametrize('d,N,L', SIZES)
-def test_stepper_sweeps_at_full_size(d, N, L):
+def test_stepper_sweeps_at_full_size(d, N, L, narrow):
+    """narrow: the same properties for the narrow-tile kernels (four waves of 4 paths per tile, csrc/xw_ode_n4.h) -- the
+    forward pass that fills the store and every sweep that reads it"""
+    if narrow and N > 16384:
+        pytest.skip('narrow tiles are a small-launch layout; exercised up to 16384 paths')
     KN, g, dev, th, ph, xT, t, start = _setup(d, N, L, 1)
     Mth = (1, H, K, M)                                             # midpoint
     rows = KN.ode_act_rows(1, H, K, M)
     u, Y = torch.empty(L, N, dtype=F64, device=dev), torch.empty(L, H, N, dtype=F64, device=dev)
     act = torch.empty(L - 1, rows, KN.ode_act_cols(N), dtype=F64, device=dev)
     job = dict(xT=xT, start=start, u=u, Y=Y, act=act)
-    KN.ode_fwd_multi([job], t, th, *Mth)
+    KN.ode_fwd_multi([job], t, th, *Mth, narrow=narrow)
     assert torch.isfinite(u).all() and torch.isfinite(act).all()
     u_plain, Y_plain = KN.ode_fwd(xT, t, start, th, 1, H, K, M)
-    assert torch.equal(u, u_plain) and torch.equal(Y, Y_plain)     # storing the activations does not change the forward
+    if narrow:                                                     # (another summation order inside a layer)
+        assert _rel(u, u_plain) < 1e-12 and _rel(Y, Y_plain) < 1e-12
+    else:
+        assert torch.equal(u, u_plain) and torch.equal(Y, Y_plain)     # storing the activations does not change the forward
 
     def sweep(ubar, with_act=True, x_ones=False):
         gx, gs = torch.empty(d, N, dtype=F64, device=dev), torch.empty(N, dtype=F64, device=dev)
@@ -53,7 +62,7 @@ def test_stepper_sweeps_at_full_size(d, N, L):
         j = dict(job, ubar=ubar, gx=gx, gs=gs, gslab=slab)
         if not with_act:
             j['act'] = None
-        KN.ode_bwd_multi([j], t, th, *Mth, want_x=True, want_params=True, x_cot_ones=x_ones)
+        KN.ode_bwd_multi([j], t, th, *Mth, want_x=True, want_params=True, x_cot_ones=x_ones, narrow=narrow and with_act)
         return gx, gs, KN.slab_sum(slab)
 
     u1 = torch.randn(L, N, generator=g, dtype=F64).to(dev)
@@ -71,16 +80,20 @@ def test_stepper_sweeps_at_full_size(d, N, L):
     gx7, gs7, th7 = sweep(poll, x_ones=True)
     _, _, thp = sweep(poll)
     assert _rel(gx7, gx1) < 1e-12 and _rel(gs7, gs1) < 1e-10 and torch.equal(th7, thp)
+    if narrow:                                                     # the sweep WITHOUT weight gradients is a kernel of its own
+        gxo, gso = torch.empty(d, N, dtype=F64, device=dev), torch.empty(N, dtype=F64, device=dev)
+        KN.ode_bwd_multi([dict(job, ubar=u1, gx=gxo, gs=gso)], t, th, *Mth, want_x=True, want_params=False, narrow=True)
+        assert _rel(gxo, a[0]) < 1e-12 and _rel(gso, a[1]) < 1e-12
     # equivariance: permuting the paths permutes the per-path outputs and leaves the parameter gradient alone
     perm = torch.randperm(N, generator=g).to(dev)
     jobp = dict(xT=xT[:, perm].contiguous(), start=start[perm].contiguous(), u=torch.empty_like(u), Y=torch.empty_like(Y),
                 act=torch.empty_like(act))
-    KN.ode_fwd_multi([jobp], t, th, *Mth)
+    KN.ode_fwd_multi([jobp], t, th, *Mth, narrow=narrow)
     assert torch.equal(jobp['u'], u[:, perm])
     gxp, gsp = torch.empty(d, N, dtype=F64, device=dev), torch.empty(N, dtype=F64, device=dev)
     slabp = torch.empty(KN.ode_bwd_slabs(N), th.numel(), dtype=F64, device=dev)
     KN.ode_bwd_multi([dict(jobp, ubar=u1[:, perm].contiguous(), gx=gxp, gs=gsp, gslab=slabp)], t, th, *Mth, want_x=True,
-                     want_params=True)
+                     want_params=True, narrow=narrow)
     assert torch.equal(gxp, a[0][:, perm]) and torch.equal(gsp, a[1][perm])
     assert _rel(KN.slab_sum(slabp), a[2]) < 1e-11
 
