@@ -411,6 +411,32 @@ def test_ball_domain_training_trajectory_follows_reference(golden_dir, tmp_path,
     assert got[20:].min() > 1.0 and ref[20:].min() > 1.0          # (the run the reference produces here does not converge)
 
 
+def test_pipelined_loop_flushes_its_last_iteration_when_interrupted(golden_dir, tmp_path):
+    """the pipelined train() writes iteration k's files while the GPU works on k + 1: an exception inside the loop must still
+    leave every COMPUTED iteration on disk (losses, L2, best weights) -- the reference writes before it moves on"""
+    z, params = load(golden_dir, 'ref_plumb_midpoint')
+    S = make_solver(dict(params, iterations=6), int(z['seed']))
+    calls = {'n': 0}
+    real = S.engine.discriminator_step
+
+    def flaky(G):
+        calls['n'] += 1
+        if calls['n'] == 4:
+            raise KeyboardInterrupt()
+        return real(G)
+    S.engine.discriminator_step = flaky
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        with pytest.raises(KeyboardInterrupt):
+            S.train(report=False)
+        losses = json.load(open('losses_NODE_%d.json' % params['dim']))
+        assert len(losses) == 3 * params['n1'] and all(np.isfinite(losses))       # iterations 0, 1, 2 were complete
+        assert os.path.exists('best_model_weights_NODE.pth') and os.path.exists('L2_NODE_%d.json' % params['dim'])
+    finally:
+        os.chdir(cwd)
+
+
 def test_sphere_domain_trains_end_to_end(tmp_path):
     """train() over a list domain: group protocol, truncation, single-slice groups, per-group optimiser steps"""
     params = {'alpha': 1e4, 'u_layers': 8, 'u_hidden_dim': 20, 'u_hidden_hidden_dim': 10, 'v_layers': 9, 'v_hidden_dim': 50,

@@ -464,6 +464,26 @@ def test_disc_forward_and_time_tangent(N, L, d):
     _close(gtv, gX[:, 0, 0], 1e-11, 'fused dv/dt at t0')
 
 
+def test_disc_time_tangent_at_an_exact_zero_preactivation():
+    """relu'(0) = 0 as in torch: at (t, x) = (0, 0) with zero biases every first-layer pre-activation is exactly +0 while its
+    t-tangent Vin[:, 0] is not -- dv/dt there must be the gated one (0 through the dead units), not the right derivative"""
+    from oracle import refspec as R
+    from xnode_wan_pde_solver_amd import kernels as KN
+    d, N, L = 4, 16, 3
+    torch.manual_seed(5)
+    _, phi = R.init_parameters(_cfg(), _setup(d, 2))             # (biases are zero at initialisation, src/model.py:12-15)
+    x = torch.zeros(N, d)
+    x[1:] = torch.rand(N - 1, d) * 2 - 1
+    t = torch.tensor([0.0, 0.4, 1.0])
+    X = torch.cat((t.view(1, L, 1).expand(N, L, 1), x.view(N, 1, d).expand(N, L, d)), 2).contiguous().double().requires_grad_(True)
+    v_ref = R.v_net(phi, _cfg(), X)
+    dv = torch.autograd.grad(v_ref.sum(), X)[0][:, :, 0]
+    v, vt = KN.disc_fwd(x.double().t().contiguous().cuda(), t.double().cuda(), _blob(phi, V_ORDER), W, Q)
+    _close(v.t(), v_ref.detach(), 1e-12, 'v')
+    assert float(dv[0, 0]) == 0.0 and float(vt[0, 0]) == 0.0, (float(dv[0, 0]), float(vt[0, 0]))
+    _close(vt.t(), dv, 1e-11, 'dv/dt')
+
+
 @pytest.mark.parametrize('N,L,d,q', [(37, 7, 5, 9), (64, 6, 20, 4), (100, 3, 70, 1), (16, 2, 3, 12), (700, 9, 6, 9),
                                      (1100, 32, 6, 2)])     # (the last one: more 64-point groups than blocks -- grid-stride)
 def test_disc_kernels_at_width_64(N, L, d, q):

@@ -219,6 +219,18 @@ __global__ void __launch_bounds__(256, 2) k_disc_fwd(const double* __restrict__ 
     } else {
       input_layer<W>(pht, o, xT, N, d, pt, a, ad);
     }
+    // relu'(+0) = 0 (torch): the layers below gate the d/dt tangent by the SIGN bit of the pre-activation, which is open at an
+    // exact +0.  In a tied layer an exact +0 is a unit whose inputs are all dead -- its tangent is a sum of gated zeros -- but
+    // HERE it can come from the input itself (t = 0, x = 0 with the zero bias the network starts from) with a tangent Vin[:, 0]
+    // that is not zero: an exact zero leaves the input layer as -0, which every later test treats as "closed" (once per tile,
+    // 2 vector instructions per register).
+#pragma unroll
+    for (int mt = 0; mt < D::MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double x = a[mt][r];
+        a[mt][r] = __hiloint2double(x == 0.0 ? (int)0x80000000 : __double2hiint(x), __double2loint(x));
+      }
     if (DYN) {
       nxt = G + cur + (long)nq * (unsigned int)__builtin_amdgcn_readfirstlane((int)ticket);
       while (nxt >= ntiles && tries < XW_DISC_STEAL && tries + 1 < nq) {      // home queue dry: the neighbours' (rare, end of the launch)
@@ -265,7 +277,8 @@ __global__ void __launch_bounds__(256, 2) k_disc_fwd(const double* __restrict__ 
         // visible zero, or a visible sign test, it rewrites the bit operations into compare + v_cndmask_b32 again).
         // 1 + 4 instructions of 2.3 clocks per k-step where v_max_f64 x 2 (canonicalise + max), v_or, v_mov, v_cmp_ne_u64 and
         // two v_cndmask_b32 took ~31.  av >= +0 keeps both, av < 0 (or -0) clears both: at av == +0 exactly the gate stays
-        // open where torch's relu' is 0 -- that only happens where the tangent is zero as well (padding units, dead inputs).
+        // open where torch's relu' is 0 -- in a tied layer that only happens where the tangent is zero as well (padding units,
+        // dead inputs); the input layer's exact zeros arrive here as -0 (above).
         int sgn = __double2hiint(av) >> 31;
         asm volatile("" : "+v"(sgn));
         const double adv = adi[ks >> 2][ks & 3];

@@ -16,6 +16,44 @@
 #include "xw_common.h"
 #include "xnwan.h"
 
+// One object per stepper width (Makefile: -DXW_ODE_H=.. -DXW_ODE_K=..), every depth m = 1..8 in it; the public entry
+// points live in xw_ode_abi.hip and pick the object by (H, K).  Narrower networks run zero-padded inside the next larger
+// width (exact: padding units stay identically zero, nets.Blob).
+#if !defined(XW_ODE_H) || !defined(XW_ODE_K)
+#error "compile with -DXW_ODE_H=<u_hidden_dim> -DXW_ODE_K=<u_hidden_hidden_dim>"
+#endif
+#define XW_CAT4_(a, b, c, d) a##b##c##d
+#define XW_CAT4(a, b, c, d) XW_CAT4_(a, b, c, d)
+#define XW_ODE_FN(name) XW_CAT4(name, XW_ODE_H, _, XW_ODE_K)
+#ifdef XW_ODE_ONLY_M      /* development builds (ISA listings, A/B variants): one depth only */
+#define XW_ODE_DISPATCH(CALL)                                    \
+  switch (m) {                                                   \
+    case XW_ODE_ONLY_M: { CALL(XW_ODE_H, XW_ODE_K, XW_ODE_ONLY_M) } \
+    default: return XW_E_DIMS;                                   \
+  }
+#else
+#define XW_ODE_DISPATCH(CALL)                                    \
+  switch (m) {                                                   \
+    case 1: { CALL(XW_ODE_H, XW_ODE_K, 1) }                      \
+    case 2: { CALL(XW_ODE_H, XW_ODE_K, 2) }                      \
+    case 3: { CALL(XW_ODE_H, XW_ODE_K, 3) }                      \
+    case 4: { CALL(XW_ODE_H, XW_ODE_K, 4) }                      \
+    case 5: { CALL(XW_ODE_H, XW_ODE_K, 5) }                      \
+    case 6: { CALL(XW_ODE_H, XW_ODE_K, 6) }                      \
+    case 7: { CALL(XW_ODE_H, XW_ODE_K, 7) }                      \
+    case 8: { CALL(XW_ODE_H, XW_ODE_K, 8) }                      \
+    default: return XW_E_DIMS;                                   \
+  }
+#endif
+
+// The RECOMPUTING sweeps (no activation store: rk4, adjoint = True, XW_KEEP_ACT=0) are compiled into a second object per width
+// (-DXW_ODE_PART_RECOMP): at (32, 12) the largest of them (midpoint / rk4 with weight gradients, the continuous adjoint) crash
+// clang 22's 'AMDGPU Rewrite AGPR-Copy-MFMA' pass under -amdgpu-mfma-vgpr-form, which the kernels of the training path want
+// (forward, sweeps from the store, narrow tiles: without it the (32, 12) object spilled thousands of registers to scratch).
+// jobs: a BwdJobs, by address.
+extern "C" int XW_ODE_FN(xw_ode_bwd_recomp_w)(const void* jobs, const double* t, const double* theta, int method, int L, int d,
+                                              int m, int params, int adj, void* stream);
+
 namespace {
 
 // ---- explicit Runge-Kutta tableaux of the fixed-grid solvers (torchdiffeq fixed_grid: euler, midpoint, rk4 = 3/8 rule)
@@ -862,12 +900,12 @@ __device__ __forceinline__ void load_stage(const double* __restrict__ Y, const d
 // lam = cotangent of y_0, xpb = sum of the cotangents of z_0 over all field evaluations, ub0 = cotangent of u at the first
 // time index, accFL / accFLb = sums of ubar y_l / ubar.  Shared by the 16-path sweeps (sweep_body) and by the narrow-tile
 // sweep (xw_ode_n4.h), whose four waves hand these registers to their first wave through LDS.  lds: XW_SWEEP_TILES tiles.
-template <int H, int K, bool PARAMS, bool ADJ>
+template <int H, int K, bool PARAMS, bool ADJ, class StoreFieldGrads>
 __device__ __forceinline__ void sweep_tail(const double* __restrict__ th, const UOff& o, int d, int N, int base, bool valid, int ncl,
                                            const double* __restrict__ xT, double sv, bool x_ones, const d4 (&lam)[Dim<H, K>::HT],
                                            d4 xpb, double ub0, const d4 (&accFL)[Dim<H, K>::HT], double accFLb,
                                            const d4 (&flw)[Dim<H, K>::HT], double* __restrict__ gx, double* __restrict__ gs,
-                                           double* slab, double* lds) {
+                                           double* slab, double* lds, const StoreFieldGrads& store_field) {
   typedef Dim<H, K> D;
   const int lane = xw_lane(), g = lane >> 4, n = lane & 15;
   // ---- x-projection: cotangent of x, gradients of Win[:, :d] and Win.b -----------------------------------------
@@ -903,6 +941,7 @@ __device__ __forceinline__ void sweep_tail(const double* __restrict__ th, const 
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     storeRowSums(slab + o.Winb, K, 0, xpb);
+    store_field();                                         // (the field's own accumulators, where their owner keeps them)
 #pragma unroll
     for (int ht = 0; ht < D::HT; ++ht) storeRowSums(slab + o.FLw, H, 16 * ht, accFL[ht]);
     const double sb = xw_sum_over_n(accFLb);
@@ -1316,9 +1355,10 @@ __device__ __forceinline__ void sweep_body(const BwdJobs& jobs, const double* __
   //  reading the one the last evaluation was posted into; they finished with the other one before the last barrier)
   if (DUO) lds = qbuf + qflip * DuoPlan<H, K, M>::BUF;
   double* slab = PARAMS ? gslab + (long)tile * o.total : nullptr;
-  if (PARAMS && !DUO) store_field_grads<H, K>(slab, o, d, G);      // (duo sweep: the partner wave holds and stores them)
   sweep_tail<H, K, PARAMS, ADJ>(th, o, d, N, base, valid, ncl, xT, start[ncl], jobs.x_ones != 0, lam, xpb, ub0, accFL, accFLb, flw,
-                                gx, gs, slab, lds);
+                                gx, gs, slab, lds, [&]() {
+                                  if (PARAMS && !DUO) store_field_grads<H, K>(slab, o, d, G);   // (duo sweep: the partner wave stores them)
+                                });
 }
 
 // ---- the duo sweep's second wave: weight gradients of the field -------------------------------------------------------
@@ -1607,30 +1647,20 @@ int launch_bwd(int method, const BwdJobs& jobs, const double* t, const double* t
     else hipLaunchKernelGGL((n4::k_ode_bwd_n4<H, K, M, 1, PARAMS>), grid, dim3(256), 0, s, jobs, t, theta, L, d);
     return xw_launch_status();
   }
-  if (adj) {
-    switch (method) {
-      case 0: hipLaunchKernelGGL((k_ode_bwd<H, K, M, 0, PARAMS, false, true>), grid, block, 0, s, jobs, t, theta, L, d); break;
-      case 1: hipLaunchKernelGGL((k_ode_bwd<H, K, M, 1, PARAMS, false, true>), grid, block, 0, s, jobs, t, theta, L, d); break;
-      case 2: hipLaunchKernelGGL((k_ode_bwd<H, K, M, 2, PARAMS, false, true>), grid, block, 0, s, jobs, t, theta, L, d); break;
-      default: return XW_E_ARG;
-    }
-    return xw_launch_status();
-  }
   bool act = true;                                     // all jobs or none (checked by the caller)
   for (int i = 0; i < jobs.n; ++i) act = act && jobs.act[i] != nullptr;
+  if (adj || !act || method > 1)      // (the recomputing sweeps live in an object of their own: XW_ODE_PART_RECOMP below)
+    return XW_ODE_FN(xw_ode_bwd_recomp_w)(&jobs, t, theta, method, L, d, M, PARAMS ? 1 : 0, adj ? 1 : 0, (void*)s);
   const dim3 duo_grid(jobs.tile0[jobs.n]);
-  switch (method * 2 + (act ? 1 : 0)) {
-    case 0: hipLaunchKernelGGL((k_ode_bwd<H, K, M, 0, PARAMS, false>), grid, block, 0, s, jobs, t, theta, L, d); break;
-    case 1:
+  switch (method) {
+    case 0:
       if (PARAMS) hipLaunchKernelGGL((k_ode_bwd_duo<H, K, M, 0>), duo_grid, dim3(XW_DUO_THREADS), 0, s, jobs, t, theta, L, d);
       else hipLaunchKernelGGL((k_ode_bwd<H, K, M, 0, false, true>), grid, block, 0, s, jobs, t, theta, L, d);
       break;
-    case 2: hipLaunchKernelGGL((k_ode_bwd<H, K, M, 1, PARAMS, false>), grid, block, 0, s, jobs, t, theta, L, d); break;
-    case 3:
+    case 1:
       if (PARAMS) hipLaunchKernelGGL((k_ode_bwd_duo<H, K, M, 1>), duo_grid, dim3(XW_DUO_THREADS), 0, s, jobs, t, theta, L, d);
       else hipLaunchKernelGGL((k_ode_bwd<H, K, M, 1, false, true>), grid, block, 0, s, jobs, t, theta, L, d);
       break;
-    case 4: hipLaunchKernelGGL((k_ode_bwd<H, K, M, 2, PARAMS, false>), grid, block, 0, s, jobs, t, theta, L, d); break;
     default: return XW_E_ARG;
   }
   return xw_launch_status();
@@ -1638,36 +1668,7 @@ int launch_bwd(int method, const BwdJobs& jobs, const double* t, const double* t
 
 }  // namespace
 
-// One object per stepper width (Makefile: -DXW_ODE_H=.. -DXW_ODE_K=..), every depth m = 1..8 in it; the public entry
-// points live in xw_ode_abi.hip and pick the object by (H, K).  Narrower networks run zero-padded inside the next larger
-// width (exact: padding units stay identically zero, nets.Blob).
-#if !defined(XW_ODE_H) || !defined(XW_ODE_K)
-#error "compile with -DXW_ODE_H=<u_hidden_dim> -DXW_ODE_K=<u_hidden_hidden_dim>"
-#endif
-#define XW_CAT4_(a, b, c, d) a##b##c##d
-#define XW_CAT4(a, b, c, d) XW_CAT4_(a, b, c, d)
-#define XW_ODE_FN(name) XW_CAT4(name, XW_ODE_H, _, XW_ODE_K)
-#ifdef XW_ODE_ONLY_M      /* development builds (ISA listings, A/B variants): one depth only */
-#define XW_ODE_DISPATCH(CALL)                                    \
-  switch (m) {                                                   \
-    case XW_ODE_ONLY_M: { CALL(XW_ODE_H, XW_ODE_K, XW_ODE_ONLY_M) } \
-    default: return XW_E_DIMS;                                   \
-  }
-#else
-#define XW_ODE_DISPATCH(CALL)                                    \
-  switch (m) {                                                   \
-    case 1: { CALL(XW_ODE_H, XW_ODE_K, 1) }                      \
-    case 2: { CALL(XW_ODE_H, XW_ODE_K, 2) }                      \
-    case 3: { CALL(XW_ODE_H, XW_ODE_K, 3) }                      \
-    case 4: { CALL(XW_ODE_H, XW_ODE_K, 4) }                      \
-    case 5: { CALL(XW_ODE_H, XW_ODE_K, 5) }                      \
-    case 6: { CALL(XW_ODE_H, XW_ODE_K, 6) }                      \
-    case 7: { CALL(XW_ODE_H, XW_ODE_K, 7) }                      \
-    case 8: { CALL(XW_ODE_H, XW_ODE_K, 8) }                      \
-    default: return XW_E_DIMS;                                   \
-  }
-#endif
-
+#ifndef XW_ODE_PART_RECOMP
 extern "C" int XW_ODE_FN(xw_ode_fwd_multi_w)(const XwOdeFwdJob* jobs, int njobs, const double* t, const double* theta, int method,
                                              int L, int d, int m, double* zero16, void* stream) {
   if (!jobs || njobs < 1 || njobs > XW_MAXJOBS || !t || !theta || L <= 0 || d <= 0 || m < 1) return XW_E_ARG;
@@ -1744,3 +1745,27 @@ extern "C" int XW_ODE_FN(xw_ode_bwd_multi_w)(const XwOdeBwdJob* jobs, int njobs,
   XW_ODE_DISPATCH(CALL)
 #undef CALL
 }
+#else   // XW_ODE_PART_RECOMP: only the sweeps that re-evaluate the field (no activation store) and the continuous adjoint
+extern "C" int XW_ODE_FN(xw_ode_bwd_recomp_w)(const void* jobs_, const double* t, const double* theta, int method, int L, int d,
+                                              int m, int params, int adj, void* stream) {
+  const BwdJobs& jobs = *static_cast<const BwdJobs*>(jobs_);
+  const dim3 grid(jobs.tile0[jobs.n]), block(64);
+  hipStream_t s = (hipStream_t)stream;
+#define LAUNCH(HH, KK, MM, PP, AA)                                                                                                 \
+  switch (method) {                                                                                                                \
+    case 0: hipLaunchKernelGGL((k_ode_bwd<HH, KK, MM, 0, PP, false, AA>), grid, block, 0, s, jobs, t, theta, L, d); break;         \
+    case 1: hipLaunchKernelGGL((k_ode_bwd<HH, KK, MM, 1, PP, false, AA>), grid, block, 0, s, jobs, t, theta, L, d); break;         \
+    case 2: hipLaunchKernelGGL((k_ode_bwd<HH, KK, MM, 2, PP, false, AA>), grid, block, 0, s, jobs, t, theta, L, d); break;         \
+    default: return XW_E_ARG;                                                                                                      \
+  }                                                                                                                                \
+  return xw_launch_status();
+#define CALL(HH, KK, MM)                                                                                                           \
+  if (params && adj) { LAUNCH(HH, KK, MM, true, true) }                                                                            \
+  else if (params) { LAUNCH(HH, KK, MM, true, false) }                                                                             \
+  else if (adj) { LAUNCH(HH, KK, MM, false, true) }                                                                                \
+  else { LAUNCH(HH, KK, MM, false, false) }
+  XW_ODE_DISPATCH(CALL)
+#undef CALL
+#undef LAUNCH
+}
+#endif

@@ -591,7 +591,7 @@ __device__ __forceinline__ void sweep4(const BwdJobs& jobs, const double* __rest
       storeRowSumsStrided(slab + o.Win + d, o.ldin, K, 0, take_over(hand + (3 * D::NY + 2) * 256));
     }
     sweep_tail<H, K, PARAMS, false>(th, o, d, N, base, valid16, ncl16, xT, start[ncl16], jobs.x_ones != 0, lam16, xpb16, ub016, fl16,
-                                    flb16, flw16, jobs.gx[job], jobs.gs[job], slab, lds + P::TILES);
+                                    flb16, flw16, jobs.gx[job], jobs.gs[job], slab, lds + P::TILES, []() {});
   }
 }
 

@@ -32,13 +32,14 @@ DESTRUCTION, engine._KEPT_GRAPHS): the lock is uncontended except during a ring'
 
 class _PinPool:
     """page-locked staging buffers, a ring per (shape, dtype).  pin_memory() allocates (1 ms for the three tensors of a
-    cube sample); copying into a buffer that already exists is 30 us.  A buffer comes around again after RING uses -- four
-    outer iterations of the training loop, whose uploads are long done by then.  The whole ring of a shape is allocated at
-    its first use, under HIP_HOST_LOCK."""
+    cube sample); copying into a buffer that already exists is 30 us.  The whole ring of a shape is allocated at its first
+    use, under HIP_HOST_LOCK.  A slot is reused after RING stagings of its shape (at the headline shape xu, xv and xb share
+    one key: 6 stagings per outer iteration, i.e. after 2.7 iterations); what makes that safe is not the count but the
+    event `uploaded()` records behind the asynchronous copy out of the slot: `stage()` waits for it before overwriting."""
     RING = 16
 
     def __init__(self):
-        self.bufs, self.pos = {}, {}
+        self.bufs, self.pos, self.events = {}, {}, {}
 
     def stage(self, t):
         key = (tuple(t.shape), t.dtype)
@@ -49,8 +50,18 @@ class _PinPool:
         i = self.pos.get(key, 0)
         self.pos[key] = i + 1
         buf = ring[i % self.RING]
+        ev = self.events.pop(buf.data_ptr(), None)
+        if ev is not None:
+            ev.synchronize()            # (the upload that last read this slot; long done unless the pipeline got deeper)
         buf.copy_(t)
         return buf
+
+    def uploaded(self, buf):
+        """called right behind an asynchronous host -> device copy out of a staged buffer (solver._up)"""
+        if buf.is_pinned() and any(buf.data_ptr() == b.data_ptr() for b in self.bufs.get((tuple(buf.shape), buf.dtype), ())):
+            ev = torch.cuda.Event()
+            ev.record()
+            self.events[buf.data_ptr()] = ev
 
 
 _PIN_POOL = _PinPool()

@@ -222,7 +222,11 @@ class NODE_WAN_solver:
         """host -> device; asynchronous when the source is page-locked (Comb_loader.pin)"""
         if t.is_cuda:
             return t
-        return t.to(self.device, non_blocking=True) if t.is_pinned() else t.to(self.device)
+        if not t.is_pinned():
+            return t.to(self.device)
+        out = t.to(self.device, non_blocking=True)
+        sampling._PIN_POOL.uploaded(t)          # (the staging slot is not overwritten before this copy has read it)
+        return out
 
     def _shard(self, points):
         """this rank's contiguous share of every group (dist.py); identity on one GPU"""
@@ -335,7 +339,10 @@ class NODE_WAN_solver:
         keys = self._state_dict_layout()
 
         def process(k):
-            """host side of iteration k (its GPU work has finished or is finishing): files, best weights"""
+            """host side of iteration k (its GPU work has finished or is finishing): files, best weights.  Runs while the GPU
+            works on iteration k + 1, so Time_NODE_*.json holds the times the host WROTE an iteration's files (one iteration
+            behind the GPU, same spacing), and the loss / L2 / best-weights files trail the GPU by one iteration; all of them
+            are flushed before train() returns or raises (the `finally` below)."""
             r = k % R
             done[r].synchronize()
             row = host[r].tolist()
@@ -360,7 +367,9 @@ class NODE_WAN_solver:
                 times.write('Time_NODE_' + str(d) + '.json')
 
         nxt_domain = nxt_points = None
+        issued = processed = 0          # iterations whose ring row is on its way to the host / whose files have been written
         with torch.cuda.device(dev):
+          try:
             for k in range(self.iterations):
                 domain = nxt_domain if nxt_domain is not None else self._new_domain()
                 points = nxt_points if nxt_points is not None else self._loader(domain)
@@ -393,10 +402,16 @@ class NODE_WAN_solver:
                     rb.wait_event(filled[r])
                     host[r].copy_(ring[r], non_blocking=True)
                     done[r].record(rb)
+                issued = k + 1
                 if k > 0:
                     process(k - 1)
-            if self.iterations > 0:
-                process(self.iterations - 1)
+                    processed = k
+          finally:
+            # the host side runs one iteration behind the GPU: whatever has been computed is written out before train() returns
+            # OR raises (an exception / KeyboardInterrupt inside the loop must not lose the last iteration's losses and best weights)
+            while processed < issued:
+                process(processed)
+                processed += 1
         return past_losses
 
     def _state_dict_layout(self):
