@@ -234,6 +234,43 @@ int xw_slab_sum(const double* gslab, int nslab, int P, int accumulate, double* o
  * sub-step's exchange buffer on several GPUs) */
 int xw_slab_sum2(const double* gA, int nA, double* outA, const double* gB, int nB, double* outB, int P, void* stream);
 
+/* ---- one optimiser sub-step of ONE group of paths as ONE call (src/training.py:127-138 generator, :152-162 discriminator) ----
+ * The loops `for (datau, datav, bdata) in points:` of the reference visit 11-20 groups per sub-iteration on the time-varying
+ * domains, every group with new shapes every sample: nothing to replay, and a host language that issues the ~15 launches
+ * of a group sub-step one by one spends more time issuing than the GPU spends running them.  These two entry points enqueue
+ * the whole chain on ONE stream (program order is the dependency), from two plain structs the caller fills when a group is
+ * loaded: the kernels, their arguments and their order are exactly those of the separate calls above.
+ * Scope: one process (no exchange step inside), c(u,t,x) = ckappa u or tabulated c / cp already in the group (the caller
+ * refreshes them), any a / b (A0 / B0 tables), pairwise single-slice groups, carried gradients of a multi-group sub-iteration. */
+typedef struct {
+  int N, Nb, L, Lb, d;            /* interior paths, boundary paths, their sample times, dimensions */
+  int same_grid;                  /* boundary paths on the interior's time grid (one launch for both) */
+  int w_per_point, amode, pair_i, pair_b;
+  int ns_u, ns_b;                 /* slabs of the interior / boundary sweeps (xw_ode_bwd_slabs) */
+  int narrow;                     /* narrow-tile launches: bit 0 forward (generator), 1 boundary forward alone, 2 sweeps A (+ boundary),
+                                     3 boundary sweep alone, 4 sweep B, 5 x-only sweep (generator, unfused), 6 forward (discriminator),
+                                     7 x-only sweep (discriminator) */
+  double Vol, Nglob, Nbglob, s3_scale, init_off, bdry_off, ckappa;
+  const double *xT, *xvT, *xbT, *t, *tb, *tpp, *xvT_pts;
+  const double *start, *start_b, *h, *href, *f, *g, *w, *wt, *w0, *ghT, *gwx0T, *c, *cp, *A0, *B0;
+  double *u, *ub, *Y, *Yb, *act, *act_b, *v, *vt, *gxv, *gtv, *gx, *gs, *vbar, *s3x, *vact, *slabA, *slabB, *slab_v, *work_i, *work_b;
+} XwGroup;
+typedef struct {
+  int method, H, K, m, W, q, Pu, Pv, adjoint;
+  int v_blocks, v_blocks_disc;    /* grid caps of the test network's launch in the two sub-steps (0 = default) */
+  int lag_lo, lag_hi;             /* xw_adam: the field's range of theta keeps its own step count */
+  double alpha, pollution, lr_u, lr_v, beta1, beta2, eps;
+  double *theta, *phi, *scal, *grad_u, *grad_v, *m_u, *v_u, *m_v, *v_v;
+  long long *step_u, *step_v, *lag_u;
+} XwSolverState;
+/* skip_v: v, dv/dt, nabla_x v(t_0) of this group are still those of the current phi and sample (opt-in reuse);
+ * store_record: the test network's forward also stores its layer inputs (vact) for xw_disc_bwd;
+ * accum (may be NULL): gradient carried from the earlier groups of the sub-iteration (added in, then overwritten with the sum);
+ * adam_skip_field: no group of this sub-iteration has integrated the ODE yet (xw_adam skip) */
+int xw_substep_gen(const XwGroup* g, const XwSolverState* s, int skip_v, int store_record, double* accum, int adam_skip_field,
+                   void* stream);
+int xw_substep_disc(const XwGroup* g, const XwSolverState* s, int skip_v, int use_record, double* accum, void* stream);
+
 /* ---- the exchange step of the sharded path (replaces nn.DataParallel's scatter / gather / reduce-add around both nets,
  * src/training.py:93-97).  One process per GPU; every rank owns a contiguous share of the Monte-Carlo paths; per
  * generator sub-step ONE packed buffer [J^T ubarA | J^T ubarB | partial sums] is summed over the ranks, per

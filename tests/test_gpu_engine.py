@@ -437,6 +437,29 @@ def test_pipelined_loop_flushes_its_last_iteration_when_interrupted(golden_dir, 
         os.chdir(cwd)
 
 
+@pytest.mark.parametrize('name', ['NSphere_TCone', 'NSphere_THourglass'])
+def test_group_substep_runner_matches_the_launch_by_launch_path(tmp_path, name):
+    """xw_substep_gen / xw_substep_disc (one C-ABI call per group sub-step, csrc/xw_substep.hip) against the same chain issued
+    launch by launch from engine.py: bit-identical parameters after three outer iterations over all groups of a ball domain
+    (single-slice pairwise groups, boundary groups on their own grids, point-mode test network, carried gradients)"""
+    params = {'alpha': 1e4, 'u_layers': 8, 'u_hidden_dim': 20, 'u_hidden_hidden_dim': 10, 'v_layers': 9, 'v_hidden_dim': 50,
+              'n1': 2, 'n2': 1, 'u_rate': 0.015, 'v_rate': 0.04, 'min_steps': 5, 'adjoint': False, 'solver': 'midpoint',
+              'dim': 4, 'N_t': 8, 'N_r': 300, 'N_b': 200, 'T0': 0, 'T': 1, 'shape_param': 1.0, 'iterations': 3, 'domain': name}
+    out = []
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        for runner in (True, False):
+            S = make_solver(params, 3)
+            S.engine.use_runner = runner
+            losses = S.train(report=False)
+            out.append((S.engine.theta.data.clone(), S.engine.phi.data.clone(), list(losses)))
+    finally:
+        os.chdir(cwd)
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1]) and out[0][2] == out[1][2]
+    assert torch.isfinite(out[0][0]).all()
+
+
 def test_sphere_domain_trains_end_to_end(tmp_path):
     """train() over a list domain: group protocol, truncation, single-slice groups, per-group optimiser steps"""
     params = {'alpha': 1e4, 'u_layers': 8, 'u_hidden_dim': 20, 'u_hidden_hidden_dim': 10, 'v_layers': 9, 'v_hidden_dim': 50,

@@ -118,6 +118,13 @@ def test_cabi_exports_match_header():
         body = re.sub(r'/\*.*?\*/', '', body, flags=re.S)
         fields = [re.split(r'[\s\*]+', decl.strip())[-1] for decl in body.split(';') if decl.strip()]
         assert fields == [f[0] for f in ctype._fields_], (cname, fields)
+    # the sub-step runner's structs (several declarators per statement): every declared name, in order
+    for cname, ctype in (('XwGroup', _lib.XwGroup), ('XwSolverState', _lib.XwSolverState)):
+        body = re.search(r'typedef struct \{([^}]*)\}\s*' + cname + r'\s*;', hdr).group(1)
+        body = re.sub(r'/\*.*?\*/', '', body, flags=re.S)
+        fields = [re.sub(r'[\s\*]', '', name) for decl in body.split(';') if decl.strip()
+                  for name in re.sub(r'^\s*(const\s+)?(long\s+long|double|int)\b', '', decl.strip()).split(',')]
+        assert fields == [f[0] for f in ctype._fields_], (cname, fields)
     # host-side (no GPU) entry points are callable
     assert _lib.lib.xw_abi_version() == _lib.ABI_VERSION
     assert _lib.lib.xw_theta_size(20, 20, 10) == 1651 and _lib.lib.xw_phi_size(20, 50) == 3701

@@ -1,6 +1,6 @@
 """BASELINE config 5 (d=10 time-varying ball, N_r=N_b=8192, N_t=20, Ex4_3 functions): wall time per outer iteration"""
 import os, sys, time
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import configs.Ex4_3_funcs as P
 from src.training import NODE_WAN_solver

@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('XW_LIBRARY') or os.path.join(_HERE, 'libxnwan.so')   # (override: kernel experiments only)
-ABI_VERSION = 23
+ABI_VERSION = 24
 
 c_f32p = ctypes.c_void_p   # coordinates / time grid: const double* (device)   [name kept from the float32 era]
 c_f64p = ctypes.c_void_p   # double*       (device)
@@ -26,6 +26,24 @@ class XwOdeBwdJob(ctypes.Structure):
                 ('gslab', c_vp), ('N', c_int), ('res_first_only', c_int), ('res_u', c_vp), ('res_ref', c_vp),
                 ('res_coef', ctypes.c_double), ('res_base', ctypes.c_double), ('res_w_per_point', c_int), ('res_w', c_vp),
                 ('res_c', c_vp), ('res_cp', c_vp), ('res_kappa2', ctypes.c_double)]
+
+
+class XwGroup(ctypes.Structure):           # include/xnwan.h: one group of paths for xw_substep_gen / xw_substep_disc
+    _fields_ = ([(n, c_int) for n in ('N', 'Nb', 'L', 'Lb', 'd', 'same_grid', 'w_per_point', 'amode', 'pair_i', 'pair_b', 'ns_u', 'ns_b',
+                                      'narrow')]
+                + [(n, c_dbl) for n in ('Vol', 'Nglob', 'Nbglob', 's3_scale', 'init_off', 'bdry_off', 'ckappa')]
+                + [(n, c_vp) for n in ('xT', 'xvT', 'xbT', 't', 'tb', 'tpp', 'xvT_pts', 'start', 'start_b', 'h', 'href', 'f', 'g', 'w',
+                                       'wt', 'w0', 'ghT', 'gwx0T', 'c', 'cp', 'A0', 'B0', 'u', 'ub', 'Y', 'Yb', 'act', 'act_b', 'v',
+                                       'vt', 'gxv', 'gtv', 'gx', 'gs', 'vbar', 's3x', 'vact', 'slabA', 'slabB', 'slab_v', 'work_i',
+                                       'work_b')])
+
+
+class XwSolverState(ctypes.Structure):
+    _fields_ = ([(n, c_int) for n in ('method', 'H', 'K', 'm', 'W', 'q', 'Pu', 'Pv', 'adjoint', 'v_blocks', 'v_blocks_disc', 'lag_lo',
+                                      'lag_hi')]
+                + [(n, c_dbl) for n in ('alpha', 'pollution', 'lr_u', 'lr_v', 'beta1', 'beta2', 'eps')]
+                + [(n, c_vp) for n in ('theta', 'phi', 'scal', 'grad_u', 'grad_v', 'm_u', 'v_u', 'm_v', 'v_v', 'step_u', 'step_v',
+                                       'lag_u')])
 
 
 # name -> argument types (return type is always int); mirrors include/xnwan.h line by line
@@ -63,6 +81,8 @@ SIGNATURES = {
     'xw_losses': [c_f64p, c_int, c_int, c_dbl, c_dbl, c_dbl, c_dbl, c_dbl, c_dbl, c_i64p, c_vp],
     'xw_adam': [c_f64p, c_f64p, c_int, c_f64p, c_f64p, c_int, c_f64p, c_f64p, c_f64p, c_f64p, c_i64p, c_int, c_int, c_dbl,
                 c_dbl, c_dbl, c_dbl, c_f64p, c_int, c_int, c_int, c_i64p, c_vp],
+    'xw_substep_gen': [ctypes.POINTER(XwGroup), ctypes.POINTER(XwSolverState), c_int, c_int, c_f64p, c_int, c_vp],
+    'xw_substep_disc': [ctypes.POINTER(XwGroup), ctypes.POINTER(XwSolverState), c_int, c_int, c_f64p, c_vp],
     'xw_slab_sum': [c_f64p, c_int, c_int, c_int, c_f64p, c_vp],
     'xw_slab_sum2': [c_f64p, c_int, c_f64p, c_f64p, c_int, c_f64p, c_int, c_vp],
     'xw_comm_available': [],

@@ -173,6 +173,7 @@ class Engine:
         # Used where a sweep runs with SIMDs to spare: sweep B of the generator sub-step (alone on the chip behind the test
         # network), as long as its waves still find a SIMD each.  XW_NARROW: 0 off, 1 auto (default), 2 wherever possible.
         self.narrow = os.environ.get('XW_NARROW', '1')
+        self.use_runner = os.environ.get('XW_RUNNER', '1') == '1'      # one C call per eager group sub-step (xw_substep_*)
         # Measured (profiles/r04_shard_sweep.md): forward and the sweep without weight gradients gain on shards up to ~2048
         # paths (0.302 -> 0.272 ms per sub-step at 512 paths, 0.332 -> 0.294 at 1024, 0.375 -> 0.367 at 2048); the narrow sweep
         # WITH weight gradients only ties the two-wave duo sweep (88 against 83 us alone) and is left to XW_NARROW_SET=fxp; at
@@ -573,6 +574,69 @@ class Engine:
             ck = 0.0
         G.ck = ck
 
+    # ------------------------------------------------------------------------------------------------------------
+    # one C-ABI call per group sub-step (xw_substep_gen / xw_substep_disc, csrc/xw_substep.hip) for the groups that run
+    # eagerly -- the 11-20 groups per sample of the list domains, new shapes every sample: ~15 launches per group and
+    # sub-step issued from Python one by one cost more host time than the GPU needs to run them
+    # ------------------------------------------------------------------------------------------------------------
+    def _runner_state(self):
+        """XwSolverState of this engine (pointers to buffers that live as long as the engine)"""
+        from ._lib import XwSolverState
+        st = getattr(self, '_xw_state', None)
+        if st is None:
+            st = self._xw_state = XwSolverState()
+            st.method, st.H, st.K, st.m, st.W, st.q, st.Pu, st.Pv = self.method, self.H, self.K, self.m, self.W, self.q, self.Pu, self.Pv
+            st.adjoint = 1 if self.adjoint else 0
+            st.lag_lo, st.lag_hi = self.field_range
+            st.beta1, st.beta2, st.eps = 0.9, 0.999, 1e-8
+            st.theta, st.phi, st.scal = self.theta.data.data_ptr(), self.phi.data.data_ptr(), self.scal.data_ptr()
+            st.grad_u, st.grad_v = self.grad_u.data_ptr(), self.grad_v.data_ptr()
+            st.m_u, st.v_u, st.m_v, st.v_v = (self.adam_u['m'].data_ptr(), self.adam_u['v'].data_ptr(), self.adam_v['m'].data_ptr(),
+                                              self.adam_v['v'].data_ptr())
+            st.step_u, st.step_v, st.lag_u = self.adam_u['step'].data_ptr(), self.adam_v['step'].data_ptr(), self.adam_u['lag'].data_ptr()
+        st.v_blocks, st.v_blocks_disc = self.v_blocks, self.v_blocks_disc
+        st.alpha, st.pollution = float(self.alpha), float(self.pollution)
+        st.lr_u, st.lr_v = float(self.config['u_rate']), float(self.config['v_rate'])
+        return st
+
+    def _runner_group(self, G):
+        """XwGroup of a loaded group: pointers once per allocation, the per-sample scalars every time"""
+        from ._lib import XwGroup
+        xg = getattr(G, '_xw_group', None)
+        if xg is None:
+            xg = G._xw_group = XwGroup()
+            p = lambda t: 0 if t is None else t.data_ptr()  # noqa: E731
+            xg.N, xg.Nb, xg.L, xg.Lb, xg.d = G.N, G.Nb, G.L, G.Lb, self.d
+            xg.same_grid, xg.w_per_point, xg.amode = int(bool(G.same_grid)), int(G.w.dim() == 2), int(G.amode)
+            xg.ns_u, xg.ns_b = G.ns_u, G.ns_b
+            for k in ('xT', 'xvT', 'xbT', 't', 'tb', 'tpp', 'xvT_pts', 'start', 'start_b', 'h', 'href', 'f', 'g', 'w', 'wt', 'w0', 'ghT',
+                      'gwx0T', 'A0', 'B0', 'u', 'Y', 'act', 'act_b', 'v', 'vt', 'gxv', 'gtv', 'gx', 'gs', 'vbar', 's3x', 'vact',
+                      'slabA', 'slabB', 'slab_v', 'work_i', 'work_b'):
+                setattr(xg, k, p(getattr(G, k, None)))
+            xg.ub, xg.Yb = p(getattr(G, 'ub', None)), p(getattr(G, 'Yb', None))
+            nar = lambda jobs, **kw: self._narrow_ok(jobs, **kw)  # noqa: E731
+            ji, jb = self._job(G, 'i'), (self._job(G, 'b') if G.Nb else None)
+            joint = G.Nb and G.same_grid
+            bits = [nar([ji] + ([jb] if joint else []), alone=False, forward=True),
+                    bool(jb) and nar([jb], alone=False, forward=True),
+                    nar([ji] + ([jb] if joint else []), alone=False),
+                    bool(jb) and nar([jb], alone=False),
+                    nar([ji], alone=True),
+                    nar([ji], alone=False, params=False),
+                    nar([ji], alone=False, forward=True),
+                    nar([ji], alone=False, params=False)]
+            xg.narrow = sum(1 << i for i, b in enumerate(bits) if b)
+        xg.pair_i, xg.pair_b = int(bool(G.pair_i)), int(bool(G.pair_b))
+        xg.Vol, xg.Nglob, xg.Nbglob, xg.s3_scale = float(G.Vol), float(G.Nglob), float(G.Nbglob), float(G.s3_scale)
+        xg.init_off, xg.bdry_off, xg.ckappa = float(G.init_off), float(G.bdry_off), float(self.structure.c_kappa)
+        xg.href = 0 if G.href is None else G.href.data_ptr()
+        xg.c = xg.cp = 0
+        return xg
+
+    def _runner_ok(self, G):
+        return (self.use_runner and self.world is None and self.structure.c_kappa is not None and G.c is None
+                and not getattr(G, 'persistent', True))
+
     def _narrow_ok(self, jobs, alone, forward=False, params=True):
         """narrow tiles (csrc/xw_ode_n4.h) for this stepper launch?  XW_NARROW: 0 never, 1 by size (default), 2 wherever the
         kernels exist; XW_NARROW_SET: which launches may (f forward, x sweeps without weight gradients, p sweeps with them)"""
@@ -751,6 +815,16 @@ class Engine:
     def generator_step(self, G):
         """one pass of the generator sub-step body; loss_u is left in scal[4] (device)"""
         sfx = self._v_fresh(G)
+        if self._runner_ok(G):
+            from ._lib import lib, check
+            touched = G.L > 1 or (G.Nb > 0 and G.Lb > 1)
+            self._field_touched = touched or (self.accum_u is not None and self._field_touched)
+            skip = self.adam_skips_untouched and not self._field_touched
+            G.ck = self.structure.c_kappa
+            check(lib.xw_substep_gen(self._runner_group(G), self._runner_state(), int(bool(G.skip_v)),
+                                     int(bool(getattr(G, 'vact_valid', False))), KN._p(self.accum_u), int(skip), KN._stream()),
+                  'xw_substep_gen')
+            return
         if self.world is None:
             self._run(G, 'gen' + sfx, self._gen_all)
             return
@@ -847,6 +921,13 @@ class Engine:
         """one pass of the discriminator sub-step body; loss_v is left in scal[5] (device)"""
         sfx = self._v_fresh(G, store=True)
         self._phi_version += 1                                    # phi changes at the end of this sub-step
+        if self._runner_ok(G):
+            from ._lib import lib, check
+            G.ck = self.structure.c_kappa
+            check(lib.xw_substep_disc(self._runner_group(G), self._runner_state(), int(bool(G.skip_v)),
+                                      int(bool(getattr(G, 'vact_valid', False))), KN._p(self.accum_v), KN._stream()),
+                  'xw_substep_disc')
+            return
         if self.world is None:
             self._run(G, 'disc' + sfx, self._disc_all)
             return
