@@ -18,4 +18,8 @@ for _ in range(5):
     KN.ode_fwd_multi([job], t, th, *M)
     KN.ode_bwd_multi([dict(job, ubar=None, gx=gx, gs=gs)], t, th, *M, want_x=True, want_params=False)
     KN.ode_bwd_multi([dict(job, ubar=ubar, gslab=slab)], t, th, *M, want_x=False, want_params=True)
+    # the same three on narrow tiles (csrc/xw_ode_n4.h: k_ode_fwd_n4 / k_ode_bwd_n4)
+    KN.ode_fwd_multi([job], t, th, *M, narrow=True)
+    KN.ode_bwd_multi([dict(job, ubar=None, gx=gx, gs=gs)], t, th, *M, want_x=True, want_params=False, narrow=True)
+    KN.ode_bwd_multi([dict(job, ubar=ubar, gslab=slab)], t, th, *M, want_x=False, want_params=True, narrow=True)
 torch.cuda.synchronize()
