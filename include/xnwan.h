@@ -59,6 +59,9 @@ typedef struct { const double* xT; const double* start; double* u; double* Y; do
                  int narrow;       /* != 0: NARROW TILES -- the 16 paths of a tile as four waves of 4 paths x 16 rows
                                       (csrc/xw_ode_n4.h; see xw_ode_bwd mode bit 4): the same outputs and the same activation
                                       store, for launches that leave SIMDs idle; same for every job of a launch */
+                 int prio_drop;    /* 0..3: the launch's waves run at wave priority 3 - prio_drop (job 0 decides).  The stepper's
+                                      chains share their SIMDs with the throughput-bound test network and run at raised priority
+                                      by default; a launch that is NOT on the sub-step's critical path gives that up */
                } XwOdeFwdJob;
 /* rows of the activation record per step (0: this method's sweeps recompute; negative: XW_E_*) */
 int xw_ode_act_rows(int method, int H, int K, int m);
@@ -89,7 +92,9 @@ int xw_ode_bwd_slabs(int N);
  *   a tile spread over four waves of 4 paths x 16 rows (csrc/xw_ode_n4.h): four times the instruction streams, each a
  *   shorter dependent chain, ~1.8 x the matrix-pipe time per path.  Same inputs, outputs and slab count; results differ from
  *   the 16-path form only by the summation order of the weight gradients.  For launches that leave SIMDs idle (fewer
- *   16-path tiles than the chip has SIMDs and nothing else running beside them). */
+ *   16-path tiles than the chip has SIMDs and nothing else running beside them).
+ * mode bits 5..6: priority drop 0..3 -- the launch's waves run at wave priority 3 - drop (see XwOdeFwdJob.prio_drop): for sweeps
+ *   that are not on the sub-step's critical path (the generator's sweeps A + boundary: 0.5027 -> 0.4955 ms per sub-step). */
 int xw_ode_bwd(const double* xT, const double* t, const double* start, const double* theta, const double* Y,
                const double* ubar, int method, int N, int L, int d, int H, int K, int m, int mode,
                double* gx, double* gs, double* gslab, void* stream);

@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('XW_LIBRARY') or os.path.join(_HERE, 'libxnwan.so')   # (override: kernel experiments only)
-ABI_VERSION = 24
+ABI_VERSION = 25
 
 c_f32p = ctypes.c_void_p   # coordinates / time grid: const double* (device)   [name kept from the float32 era]
 c_f64p = ctypes.c_void_p   # double*       (device)
@@ -18,7 +18,7 @@ c_int, c_dbl, c_vp = ctypes.c_int, ctypes.c_double, ctypes.c_void_p
 
 class XwOdeFwdJob(ctypes.Structure):      # include/xnwan.h
     _fields_ = [('xT', c_vp), ('start', c_vp), ('u', c_vp), ('Y', c_vp), ('act', c_vp), ('N', c_int), ('act_x_only', c_int),
-                ('narrow', c_int)]
+                ('narrow', c_int), ('prio_drop', c_int)]
 
 
 class XwOdeBwdJob(ctypes.Structure):

@@ -521,6 +521,7 @@ struct FwdJobs {
   int n;
   int x_only;                  // the stores of this launch only serve x-only sweeps (XwOdeFwdJob.act_x_only)
   int narrow;                  // narrow tiles (XwOdeFwdJob.narrow, xw_ode_n4.h)
+  int prio;                    // wave priority (XW_ODE_PRIO - XwOdeFwdJob.prio_drop)
   double* zero16;              // optional: 16 doubles cleared by block 0 (the sub-step's partial-sum slots)
 };
 struct BwdJobs {
@@ -536,6 +537,7 @@ struct BwdJobs {
   int tile0[XW_MAXJOBS + 1];
   int n;
   int x_ones;                  // gx, gs are those of the all-ones cotangent (ubar == 1 at every time index >= 1)
+  int prio;                    // wave priority of this launch: XW_ODE_PRIO unless mode bits 5..6 lower it (XW_ODE_PRIO - bits)
   // cotangent from a residual (XwOdeBwdJob.res_*): ubar[l][n] = base + coef (res_u[l][n] - ref)
   const double* res_u[XW_MAXJOBS];
   const double* res_ref[XW_MAXJOBS];
@@ -586,6 +588,11 @@ template <typename J> __device__ __forceinline__ int find_job(const J& jobs, int
 // sub-step; raised wave priority lets them issue whenever they are ready (the throughput-bound neighbour fills the rest):
 // 0.832 -> 0.808 ms per discriminator sub-step, 0.574 -> 0.567 per generator sub-step.
 #define XW_ODE_PRIO 3
+__device__ __forceinline__ void xw_setprio(int p) {       // (s_setprio takes an immediate; p is uniform over the launch)
+  if (p >= 3) __builtin_amdgcn_s_setprio(3);
+  else if (p == 2) __builtin_amdgcn_s_setprio(2);
+  else if (p == 1) __builtin_amdgcn_s_setprio(1);
+}
 
 // ---- stage activations kept from the forward pass ---------------------------------------------------------------------
 // The sweeps need, for every stage of every step, the layer inputs relu(z_j), the tanh output and the stage input.
@@ -699,7 +706,7 @@ __global__ void __launch_bounds__(64, 2) k_ode_fwd(const FwdJobs jobs, const dou
   double* __restrict__ u = jobs.u[job];
   double* __restrict__ Y = jobs.Y[job];
   double* __restrict__ act = jobs.act[job];
-  __builtin_amdgcn_s_setprio(XW_ODE_PRIO);
+  xw_setprio(jobs.prio);
   typedef ActLayout<H, K, M, T::S> AL;
   const int N = jobs.N[job];
   const int lane = xw_lane(), g = lane >> 4, n = lane & 15;
@@ -1057,7 +1064,7 @@ __device__ __forceinline__ void sweep_body(const BwdJobs& jobs, const double* __
   typedef Dim<H, K> D;
   typedef RK<METHOD> T;
   constexpr int OUTER = DUO ? 2 : (PARAMS ? 1 : 0);
-  __builtin_amdgcn_s_setprio(XW_ODE_PRIO);
+  xw_setprio(jobs.prio);
   int qflip = 0;                                 // DUO: which of the two Q buffers the next field evaluation posts into
   if (PARAMS && !DUO) {
     if (xw_lane() < 16) lds[2 * XW_TTILE + K * XW_TSTRIDE + xw_lane()] = 1.0;
@@ -1453,7 +1460,7 @@ __device__ __forceinline__ void duo_outer(const BwdJobs& jobs, const double* __r
   typedef Duo4<H, K, M> Q;
   typedef DuoSrc<H, K, M, METHOD> Src;
   constexpr int NH = M > 1 ? M - 1 : 1;
-  __builtin_amdgcn_s_setprio(XW_ODE_PRIO);          // (a lower priority for this wave than for the chain: no difference)
+  xw_setprio(jobs.prio);          // (a lower priority for this wave than for the chain: no difference)
   const int job = find_job(jobs, vb);
   const double* __restrict__ Y = jobs.Y[job];
   const double* __restrict__ act = jobs.act[job];
@@ -1677,6 +1684,7 @@ extern "C" int XW_ODE_FN(xw_ode_fwd_multi_w)(const XwOdeFwdJob* jobs, int njobs,
   J.zero16 = zero16;
   J.x_only = jobs[0].act_x_only ? 1 : 0;
   J.narrow = jobs[0].narrow ? 1 : 0;
+  J.prio = XW_ODE_PRIO - (jobs[0].prio_drop < 0 ? 0 : jobs[0].prio_drop > 3 ? 3 : jobs[0].prio_drop);
   J.tile0[0] = 0;
   for (int i = 0; i < XW_MAXJOBS; ++i) {
     const bool on = i < njobs;
@@ -1700,10 +1708,11 @@ extern "C" int XW_ODE_FN(xw_ode_fwd_multi_w)(const XwOdeFwdJob* jobs, int njobs,
 
 extern "C" int XW_ODE_FN(xw_ode_bwd_multi_w)(const XwOdeBwdJob* jobs, int njobs, const double* t, const double* theta, int method,
                                              int L, int d, int m, int mode, void* stream) {
-  if (!jobs || njobs < 1 || njobs > XW_MAXJOBS || !t || !theta || L <= 0 || d <= 0 || m < 1 || (mode & 3) == 0 || ((mode & 4) && (mode & 3) != 3) || ((mode & 8) && (mode & 4)) || ((mode & 16) && (mode & 8)) || (mode & ~31)) return XW_E_ARG;
+  if (!jobs || njobs < 1 || njobs > XW_MAXJOBS || !t || !theta || L <= 0 || d <= 0 || m < 1 || (mode & 3) == 0 || ((mode & 4) && (mode & 3) != 3) || ((mode & 8) && (mode & 4)) || ((mode & 16) && (mode & 8)) || (mode & ~127)) return XW_E_ARG;
   BwdJobs J;
   J.n = njobs;
   J.x_ones = (mode & 4) ? 1 : 0;
+  J.prio = XW_ODE_PRIO - ((mode >> 5) & 3);
   J.tile0[0] = 0;
   for (int i = 0; i < XW_MAXJOBS; ++i) {
     const bool on = i < njobs;

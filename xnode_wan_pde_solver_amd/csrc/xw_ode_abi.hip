@@ -36,7 +36,7 @@ extern "C" int xw_ode_fwd_multi(const XwOdeFwdJob* jobs, int njobs, const double
 
 extern "C" int xw_ode_fwd(const double* xT, const double* t, const double* start, const double* theta, int method, int N,
                           int L, int d, int H, int K, int m, double* u, double* Y, void* stream) {
-  XwOdeFwdJob j = {xT, start, u, Y, nullptr, N, 0, 0};
+  XwOdeFwdJob j = {xT, start, u, Y, nullptr, N, 0, 0, 0};
   return xw_ode_fwd_multi(&j, 1, t, theta, method, L, d, H, K, m, nullptr, stream);
 }
 

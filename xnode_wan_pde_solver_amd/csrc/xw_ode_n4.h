@@ -381,7 +381,7 @@ __device__ __forceinline__ void sweep4(const BwdJobs& jobs, const double* __rest
   typedef Plan4<H, K> P;
   static_assert(T::S <= 2, "the activation store is used by euler and midpoint");
   static_assert(D::NY == DW::HT, "registers of the hidden state = row tiles of the 16-path layout");
-  __builtin_amdgcn_s_setprio(XW_ODE_PRIO);
+  xw_setprio(jobs.prio);
   const Geo g = geo();
   const int job = find_job(jobs, vb);
   const double* __restrict__ xT = jobs.xT[job];
@@ -681,7 +681,7 @@ __global__ void __launch_bounds__(256, 2) k_ode_fwd_n4(const FwdJobs jobs, const
   typedef RK<METHOD> T;
   typedef ActLayout<H, K, M, T::S> AL;
   static_assert(D::KB * (M - 1) + 3 <= 32, "mask word");
-  __builtin_amdgcn_s_setprio(XW_ODE_PRIO);
+  xw_setprio(jobs.prio);
   const Geo g = geo();
   const int job = find_job(jobs, (int)blockIdx.x);
   const double* __restrict__ xT = jobs.xT[job];

@@ -34,7 +34,7 @@ Side* side_of_current_device() {
 
 inline XwOdeFwdJob fwd_job(const double* xT, const double* start, double* u, double* Y, double* act, int N, int x_only, int narrow) {
   XwOdeFwdJob j;
-  j.xT = xT; j.start = start; j.u = u; j.Y = Y; j.act = act; j.N = N; j.act_x_only = x_only; j.narrow = narrow;
+  j.xT = xT; j.start = start; j.u = u; j.Y = Y; j.act = act; j.N = N; j.act_x_only = x_only; j.narrow = narrow; j.prio_drop = 0;
   return j;
 }
 inline XwOdeBwdJob bwd_job(const double* xT, const double* start, const double* Y, const double* act, int N) {

@@ -483,7 +483,7 @@ extern "C" int xw_slab_sum(const double* gslab, int nslab, int P, int accumulate
   return xw_launch_status();
 }
 
-extern "C" int xw_abi_version(void) { return 24; }
+extern "C" int xw_abi_version(void) { return 25; }
 extern "C" int xw_reduce_work_size(void) { return 5 * 1024 + 8; }
 
 extern "C" int xw_supported_dims(char* buf, int buflen) {

@@ -161,18 +161,26 @@ class Engine:
         # 1/2); the static split needed exactly 3/4 (0.5225 ms, 0.58 either side).  Round 3 (leaner test network and stepper
         # forward): 10/16 -- cycle 1.546 / 1.541 / 1.554 / 1.557 ms at 9/16, 10/16, 11/16, 12/16.
         cus = torch.cuda.get_device_properties(device).multi_processor_count
-        self.v_blocks = int(os.environ.get('XW_V_BLOCKS', '0')) or (10 * 2 * cus) // 16
+        # Round 4: with the generator's sweeps A + boundary at lowered wave priority (prio_drop below) the test network keeps more of
+        # the chip: generator sub-step 0.492 / 0.484 / 0.480 / 0.475 ms at 9, 10, 11, 12 sixteenths of the slots -- and 0.545 at 13 (a
+        # cliff: the stepper's forward pass no longer finds SIMDs); 12/16.
+        self.v_blocks = int(os.environ.get('XW_V_BLOCKS', '0')) or (12 * 2 * cus) // 16
         # (discriminator sub-step: only the stepper forward and the x-only sweep run beside it, 33 us of SIMD time: 7/8 of the
         #  slots -- 0.615 ms against 0.638 at 3/4, 0.681 at 15/16, 0.735 at all of them; round 3: 13/16 and 14/16 equal
         #  (cycle 1.537 / 1.538 ms), 15/16 1.626; with the record stored through global instead of flat instructions the
         #  forward is 8 % shorter and the stepper's chain is what the sub-step waits for: 12/16 -- discriminator sub-step
         #  0.586 / 0.562 / 0.566 / 0.569 / 0.654 ms at 11..15 sixteenths, tools/sweep_caps.py)
-        self.v_blocks_disc = int(os.environ.get('XW_V_BLOCKS_DISC', '0')) or (12 * 2 * cus) // 16
+        #  round 4: 0.583 / 0.566 / 0.563 / 0.566 ms at 11..14 sixteenths: 13/16)
+        self.v_blocks_disc = int(os.environ.get('XW_V_BLOCKS_DISC', '0')) or (13 * 2 * cus) // 16
         # Narrow tiles (csrc/xw_ode_n4.h, xw_ode_bwd mode bit 4): a 16-path tile of a sweep as four waves of 4 paths instead of one
         # (+ a partner) -- four times the instruction streams, each a shorter chain, at ~1.8 x the matrix-pipe time per path.
         # Used where a sweep runs with SIMDs to spare: sweep B of the generator sub-step (alone on the chip behind the test
         # network), as long as its waves still find a SIMD each.  XW_NARROW: 0 off, 1 auto (default), 2 wherever possible.
         self.narrow = os.environ.get('XW_NARROW', '1')
+        # wave-priority drops of the stepper launches that are not on a sub-step's critical path (include/xnwan.h: xw_ode_bwd mode
+        # bits 5..6, XwOdeFwdJob.prio_drop): A = the generator's sweeps A + boundary, X = the discriminator's x-only sweep,
+        # F = the discriminator's forward pass
+        self.prio_drop = {k: int(os.environ.get('XW_PRIO_DROP_' + k, dflt)) for k, dflt in (('A', 2), ('X', 0), ('F', 0), ('G', 0))}
         self.use_runner = os.environ.get('XW_RUNNER', '1') == '1'      # one C call per eager group sub-step (xw_substep_*)
         # Measured (profiles/r04_shard_sweep.md): forward and the sweep without weight gradients gain on shards up to ~2048
         # paths (0.302 -> 0.272 ms per sub-step at 512 paths, 0.332 -> 0.294 at 1024, 0.375 -> 0.367 at 2048); the narrow sweep
@@ -702,7 +710,8 @@ class Engine:
             self._launch_test_net_here(G)                        # enqueued first: its blocks must be resident before the
         with self._side(1, e0):                                  # stepper's waves spread over the CUs
             fwd = [self._job(G, 'i')] + ([self._job(G, 'b')] if joint else [])
-            KN.ode_fwd_multi(fwd, G.t, th, *M, zero16=self.scal, narrow=self._narrow_ok(fwd, alone=False, forward=True))
+            KN.ode_fwd_multi(fwd, G.t, th, *M, zero16=self.scal, narrow=self._narrow_ok(fwd, alone=False, forward=True),
+                             prio_drop=self.prio_drop['G'])
             if G.Nb and not joint:
                 fwd_b = [self._job(G, 'b')]
                 KN.ode_fwd_multi(fwd_b, G.tb, th, *M, narrow=self._narrow_ok(fwd_b, alone=False, forward=True))
@@ -734,7 +743,7 @@ class Engine:
             if joint:
                 sweeps.append(dict(self._job(G, 'b', None, G.slabA[G.ns_u:]), res=res_b))
             KN.ode_bwd_multi(sweeps, G.t, th, *M, want_x=fused_x, want_params=True, x_cot_ones=fused_x, adjoint=self.adjoint,
-                             narrow=self._narrow_ok(sweeps, alone=False))
+                             narrow=self._narrow_ok(sweeps, alone=False), prio_drop=self.prio_drop['A'])
             if G.Nb and not joint:
                 sweep_b = [dict(self._job(G, 'b', None, G.slabA[G.ns_u:]), res=res_b)]
                 KN.ode_bwd_multi(sweep_b, G.tb, th, *M, want_x=False, want_params=True, adjoint=self.adjoint,
@@ -860,11 +869,12 @@ class Engine:
         with self._side(1, e0):
             # (the only sweep of this sub-step has no weight gradients: the forward stores a seventh of the record)
             fwd = [self._job(G, 'i')]
-            KN.ode_fwd_multi(fwd, G.t, th, *M, zero16=self.scal, act_x_only=True, narrow=self._narrow_ok(fwd, alone=False, forward=True))
+            KN.ode_fwd_multi(fwd, G.t, th, *M, zero16=self.scal, act_x_only=True, narrow=self._narrow_ok(fwd, alone=False, forward=True),
+                             prio_drop=self.prio_drop['F'])
             self._reaction(G)
             sweep_x = [self._job(G, 'i', want_x=True)]
             KN.ode_bwd_multi(sweep_x, G.t, th, *M, want_x=True, want_params=False, adjoint=self.adjoint,
-                             narrow=self._narrow_ok(sweep_x, alone=False, params=False))
+                             narrow=self._narrow_ok(sweep_x, alone=False, params=False), prio_drop=self.prio_drop['X'])
             e_x = self._mark()
         self._join(e_x)
         self._contract(G, self.adam_v)

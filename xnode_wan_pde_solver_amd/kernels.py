@@ -105,7 +105,7 @@ def ode_fwd(xT, t, start, theta, method, H, K, m, want_Y=True, u=None, Y=None):
     return u, Y
 
 
-def ode_fwd_multi(jobs, t, theta, method, H, K, m, zero16=None, act_x_only=False, narrow=False):
+def ode_fwd_multi(jobs, t, theta, method, H, K, m, zero16=None, act_x_only=False, narrow=False, prio_drop=0):
     """jobs: list of dicts(xT[d,N], start[N], u[L,N], Y[L,H,N] or None) -- all groups share t, theta; ONE launch.
     act_x_only: the activation stores of this launch will only be read by sweeps without weight gradients (the
     discriminator sub-step): only the tanh rows and the ReLU-mask words are written.
@@ -125,11 +125,12 @@ def ode_fwd_multi(jobs, t, theta, method, H, K, m, zero16=None, act_x_only=False
         a.xT, a.start, a.u, a.Y, a.act, a.N = _p(j['xT']), _p(j['start']), _p(j['u']), _p(j.get('Y')), _p(j.get('act')), N
         a.act_x_only = 1 if act_x_only else 0
         a.narrow = 1 if narrow else 0
+        a.prio_drop = int(prio_drop)
     _chk(zero16, F64, (16,), 'zero16')
     check(lib.xw_ode_fwd_multi(arr, len(jobs), _p(t), _p(theta), method, L, d, H, K, m, _p(zero16), _stream()), 'xw_ode_fwd_multi')
 
 
-def ode_bwd_multi(jobs, t, theta, method, H, K, m, want_x, want_params, x_cot_ones=False, adjoint=False, narrow=False):
+def ode_bwd_multi(jobs, t, theta, method, H, K, m, want_x, want_params, x_cot_ones=False, adjoint=False, narrow=False, prio_drop=0):
     """jobs: list of dicts(xT, start, Y, ubar or None, gx, gs, gslab); ONE launch for all groups.
     res = dict(u[L,N], ref ([N] with first_only, else [L,N]), coef, base, first_only) instead of ubar: the cotangent
     base + coef (u - ref) (at l = 0 only with first_only) is formed inside the sweep.
@@ -184,7 +185,7 @@ def ode_bwd_multi(jobs, t, theta, method, H, K, m, want_x, want_params, x_cot_on
         raise XnwanError('x_cot_ones is not available with the continuous adjoint')
     if narrow and (adjoint or method > 1 or any(j.get('act') is None for j in jobs)):
         raise XnwanError('narrow-tile sweeps run from the activation store of euler / midpoint (no adjoint=True, no rk4)')
-    mode = (1 if want_x else 0) | (2 if want_params else 0) | (4 if x_cot_ones else 0) | (8 if adjoint else 0) | (16 if narrow else 0)
+    mode = (1 if want_x else 0) | (2 if want_params else 0) | (4 if x_cot_ones else 0) | (8 if adjoint else 0) | (16 if narrow else 0) | ((int(prio_drop) & 3) << 5)
     check(lib.xw_ode_bwd_multi(arr, len(jobs), _p(t), _p(theta), method, L, d, H, K, m, mode, _stream()), 'xw_ode_bwd_multi')
 
 
