@@ -1003,6 +1003,13 @@ class Engine:
                 return
             G.graphs[key] = g
             _KEPT_GRAPHS.append(g)                # (never destroyed: see _KEPT_GRAPHS)
+            if len(_KEPT_GRAPHS) in (256, 1024, 4096):
+                import warnings
+                # a process that builds many solvers (hyper-parameter sweeps) or whose group shapes keep changing: every graph
+                # and its private memory pool stay until exit
+                warnings.warn('%d captured HIP graphs are being kept alive (destroying one faults a later launch on this runtime, '
+                              'engine._KEPT_GRAPHS): a long-lived process that keeps building solvers should run them with '
+                              'XW_GRAPHS=0 or in child processes' % len(_KEPT_GRAPHS), RuntimeWarning, stacklevel=3)
             if ran_eager:
                 return                            # (the eager pass above was this call's step; the capture only recorded)
         with HIP_HOST_LOCK:
