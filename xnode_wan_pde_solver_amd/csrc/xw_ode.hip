@@ -575,6 +575,75 @@ __device__ __forceinline__ double cot_u(const BwdJobs& jobs, int job, const doub
   }
   return ubar != nullptr ? ubar[(long)l * N + col] : 1.0;
 }
+// ---- cotangent of u, one step ahead and without a branch around a load -------------------------------------------------
+// cot_u() above branches on the kind of cotangent, and a value loaded inside a branch is used inside it: the
+// wait in front of that use is vmcnt(0) -- it would drain the stage records this wave has just requested for the NEXT stage,
+// i.e. expose a full memory latency in every step of a chain that is only ~2 - 4 k clocks long.  Here every kind is the same
+// straight-line code: up to five loads from lane pointers prepared once (a pointer that a kind does not need aims at res_u /
+// Y, finite data; its value is dropped by a select, never multiplied in), issued a whole step before their use.
+//   affine kinds:  ub = cb + [st] + coef (ru - rf) [only at l = 0 when `first`]        (ones / stored / residual forms)
+//   weak kind   :  ub = coef d(c u)/du v w  (+ base v at l = L - 1),  d(c u)/du = c + u c' (tabulated) or kappa2 u
+struct Cot4 {
+  const double *p0, *p1, *p2, *p3, *p4;      // st | ru, rf | (weak) u, v, w, c, c'      lane pointers at time index 0
+  long s0, s1, s2;                           // strides (doubles) per time index of p0, (p1, p2 | p3, p4), p2 of the weak kind
+  double cb, coef, base, kappa2;
+  bool weak, use_st, use_res, first, tab, valid;
+};
+struct CotRaw { double a, b, c, d, e; };
+__device__ __forceinline__ Cot4 make_cot(const BwdJobs& jobs, int job, int N, int col, bool valid, const double* dummy) {
+  Cot4 c;
+  const double* ru = jobs.res_u[job];
+  const double* ubar = jobs.ubar[job];
+  c.valid = valid;
+  c.weak = ru != nullptr && jobs.res_first[job] == 2;
+  c.use_res = ru != nullptr && !c.weak;
+  c.use_st = ru == nullptr && ubar != nullptr;
+  c.first = c.use_res && jobs.res_first[job] != 0;
+  c.cb = ru != nullptr ? jobs.res_base[job] : (ubar != nullptr ? 0.0 : 1.0);
+  c.coef = jobs.res_coef[job];
+  c.base = jobs.res_base[job];
+  c.kappa2 = jobs.res_kappa2[job];
+  c.tab = c.weak && jobs.res_c[job] != nullptr;
+  if (c.weak) {
+    c.p0 = ru + col; c.p1 = jobs.res_ref[job] + col; c.p2 = jobs.res_w[job] + col;
+    c.p3 = (c.tab ? jobs.res_c[job] : ru) + col; c.p4 = (c.tab ? jobs.res_cp[job] : ru) + col;
+    c.s0 = N; c.s1 = N; c.s2 = jobs.res_wpp[job] ? N : 0;
+  } else {
+    c.p0 = (c.use_st ? ubar : dummy) + col; c.s0 = c.use_st ? N : 0;
+    c.p1 = (c.use_res ? ru : dummy) + col; c.p2 = (c.use_res ? jobs.res_ref[job] : dummy) + col;
+    c.s1 = (c.use_res && !c.first) ? N : 0; c.s2 = 0;
+    c.p3 = c.p4 = dummy;
+  }
+  return c;
+}
+template <bool WEAK> __device__ __forceinline__ CotRaw cot_issue(const Cot4& c, int l) {
+  CotRaw r;
+  r.a = xw_ld_g(c.p0 + l * c.s0);
+  r.b = xw_ld_g(c.p1 + l * c.s1);
+  if (WEAK) {
+    r.c = xw_ld_g(c.p2 + l * c.s2);
+    r.d = xw_ld_g(c.p3 + l * c.s1);
+    r.e = xw_ld_g(c.p4 + l * c.s1);
+  } else {
+    r.c = xw_ld_g(c.p2 + l * c.s1);
+    r.d = r.e = 0.0;
+  }
+  return r;
+}
+template <bool WEAK> __device__ __forceinline__ double cot_value(const Cot4& c, const CotRaw& r, int l, int L) {
+  double ub;
+  if (WEAK) {
+    const double dcu = c.tab ? fma(r.a, r.e, r.d) : c.kappa2 * r.a;        // (as cot_u: c + u c', or kappa2 u)
+    ub = c.coef * dcu * r.b * r.c;
+    if (l == L - 1) ub = fma(c.base, r.b, ub);
+  } else {
+    ub = c.cb;
+    if (c.use_st) ub += r.a;
+    if (c.use_res && (!c.first || l == 0)) ub = fma(c.coef, r.b - r.c, ub);
+  }
+  return c.valid ? ub : 0.0;
+}
+
 // vb: the 16-path tile of the launch this wave works on (= blockIdx.x in the one-tile-per-block kernels)
 template <typename J> __device__ __forceinline__ int find_job(const J& jobs, int vb) {
   int j = 0;
@@ -1219,15 +1288,9 @@ __device__ __forceinline__ void sweep_body(const BwdJobs& jobs, const double* __
       readout(l, yl, ub);
     }
   } else if constexpr (SAVED) {
-    {
-      d4 yl[D::HT];
-      load_ckpt<H, K>(Y, L - 1, N, ncl, yl);
-      readout(L - 1, yl, load_ub(L - 1));
-    }
     // (without weight gradients the sweep only needs tanh(z_{m-1}) and the ReLU masks of a stage)
     // (the duo sweep's chain wave neither: its partner reads the layer inputs)
     typedef typename std::conditional<PARAMS && !DUO, Save<M>, SaveX<M>>::type SV;
-    StageRec<H, K, M, SV> sa, sb;
     // y_l for the read-out layer's weight gradient: the stage-0 record carries it, except in the duo sweep
     auto y_of = [&](int l, const d4 (&rec)[D::HT], d4 (&yl)[D::HT]) {
       if (DUO) load_ckpt<H, K>(Y, l, N, ncl, yl);
@@ -1236,39 +1299,54 @@ __device__ __forceinline__ void sweep_body(const BwdJobs& jobs, const double* __
         for (int ht = 0; ht < D::HT; ++ht) yl[ht] = rec[ht];
       }
     };
-    if constexpr (T::S == 2) {
-      // stage 1 always lives in sa, stage 0 in sb: each is loaded while the other one is reversed
-      if (L > 1) load_stage<H, K, M, METHOD>(Y, act, L - 2, 1, N, ncl, sa);
-      for (int l = L - 2; l >= 0; --l) {
-        const double ub = load_ub(l);
-        d4 yl[D::HT];
-        load_stage<H, K, M, METHOD>(Y, act, l, 0, N, ncl, sb);
-        y_of(l, sb.yi, yl);
-        begin_step(l);
-        reverse_stage(l, 1, sa.yi, sa.sv);
-        load_stage<H, K, M, METHOD>(Y, act, l > 0 ? l - 1 : 0, 1, N, ncl, sa);
-        reverse_stage(l, 0, sb.yi, sb.sv);
-        end_step(l, yl, ub);                              // stage 0's input is y_l itself
+    // The cotangent of u is requested ONE STEP AHEAD by straight-line code (Cot4 above), in front of the stage record's
+    // requests: cot_u's branches wait for their loads where they stand (vmcnt(0)), which drained the record prefetched for the
+    // next stage -- one exposed memory latency per step in every sweep whose cotangent is formed from a residual (the
+    // boundary sweep, sweep B).
+    const Cot4 cot = make_cot(jobs, job, N, ncl, valid, Y);
+    auto run = [&](auto weak_tag) {
+      constexpr bool WEAK = decltype(weak_tag)::value;
+      StageRec<H, K, M, SV> sa, sb;
+      const CotRaw raw_last = cot_issue<WEAK>(cot, L - 1);
+      CotRaw raw = cot_issue<WEAK>(cot, L > 1 ? L - 2 : 0);
+      if constexpr (T::S == 2) {
+        // stage 1 always lives in sa, stage 0 in sb: each is loaded while the other one is reversed
+        if (L > 1) load_stage<H, K, M, METHOD>(Y, act, L - 2, 1, N, ncl, sa);
+      } else {
+        if (L > 1) load_stage<H, K, M, METHOD>(Y, act, L - 2, 0, N, ncl, sa);
       }
-    } else {
-      if (L > 1) load_stage<H, K, M, METHOD>(Y, act, L - 2, 0, N, ncl, sa);
-      int l = L - 2;
-      for (; l >= 1; l -= 2) {
-        const double ub1 = load_ub(l), ub2 = load_ub(l - 1);
+      {
         d4 yl[D::HT];
-        load_stage<H, K, M, METHOD>(Y, act, l - 1, 0, N, ncl, sb);
-        y_of(l, sa.yi, yl);
-        begin_step(l); reverse_stage(l, 0, sa.yi, sa.sv); end_step(l, yl, ub1);
-        load_stage<H, K, M, METHOD>(Y, act, l >= 2 ? l - 2 : 0, 0, N, ncl, sa);
-        y_of(l - 1, sb.yi, yl);
-        begin_step(l - 1); reverse_stage(l - 1, 0, sb.yi, sb.sv); end_step(l - 1, yl, ub2);
+        load_ckpt<H, K>(Y, L - 1, N, ncl, yl);
+        readout(L - 1, yl, cot_value<WEAK>(cot, raw_last, L - 1, L));
       }
-      if (l == 0) {
-        d4 yl[D::HT];
-        y_of(0, sa.yi, yl);
-        begin_step(0); reverse_stage(0, 0, sa.yi, sa.sv); end_step(0, yl, load_ub(0));
+      if constexpr (T::S == 2) {
+        for (int l = L - 2; l >= 0; --l) {
+          const double ub = cot_value<WEAK>(cot, raw, l, L);       // (requested a step ago)
+          d4 yl[D::HT];
+          load_stage<H, K, M, METHOD>(Y, act, l, 0, N, ncl, sb);
+          raw = cot_issue<WEAK>(cot, l > 0 ? l - 1 : 0);
+          y_of(l, sb.yi, yl);
+          begin_step(l);
+          reverse_stage(l, 1, sa.yi, sa.sv);
+          load_stage<H, K, M, METHOD>(Y, act, l > 0 ? l - 1 : 0, 1, N, ncl, sa);
+          reverse_stage(l, 0, sb.yi, sb.sv);
+          end_step(l, yl, ub);                              // stage 0's input is y_l itself
+        }
+      } else {
+        for (int l = L - 2; l >= 0; --l) {
+          const double ub = cot_value<WEAK>(cot, raw, l, L);
+          d4 yl[D::HT];
+          sb = sa;
+          raw = cot_issue<WEAK>(cot, l > 0 ? l - 1 : 0);
+          load_stage<H, K, M, METHOD>(Y, act, l > 0 ? l - 1 : 0, 0, N, ncl, sa);
+          y_of(l, sb.yi, yl);
+          begin_step(l); reverse_stage(l, 0, sb.yi, sb.sv); end_step(l, yl, ub);
+        }
       }
-    }
+    };
+    if (cot.weak) run(std::true_type{});
+    else run(std::false_type{});
   } else if constexpr (T::S <= 2) {
     load_field<H, K>(th, o, d, w);
     const d4 xp = project_x<H, K>(th, o, xT, N, d, ncl);

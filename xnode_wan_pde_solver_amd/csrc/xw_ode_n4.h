@@ -266,75 +266,6 @@ __device__ __forceinline__ void vjp4(const WT4<H, K>& w, double eye, int blk, do
   }
 }
 
-// ---- cotangent of u, one step ahead and without a branch around a load -------------------------------------------------
-// cot_u() (the 16-path sweeps) branches on the kind of cotangent, and a value loaded inside a branch is used inside it: the
-// wait in front of that use is vmcnt(0) -- it would drain the stage records this wave has just requested for the NEXT stage,
-// i.e. expose a full memory latency in every step of a chain that is only ~2 - 4 k clocks long.  Here every kind is the same
-// straight-line code: up to five loads from lane pointers prepared once (a pointer that a kind does not need aims at res_u /
-// Y, finite data; its value is dropped by a select, never multiplied in), issued a whole step before their use.
-//   affine kinds:  ub = cb + [st] + coef (ru - rf) [only at l = 0 when `first`]        (ones / stored / residual forms)
-//   weak kind   :  ub = coef d(c u)/du v w  (+ base v at l = L - 1),  d(c u)/du = c + u c' (tabulated) or kappa2 u
-struct Cot4 {
-  const double *p0, *p1, *p2, *p3, *p4;      // st | ru, rf | (weak) u, v, w, c, c'      lane pointers at time index 0
-  long s0, s1, s2;                           // strides (doubles) per time index of p0, (p1, p2 | p3, p4), p2 of the weak kind
-  double cb, coef, base, kappa2;
-  bool weak, use_st, use_res, first, tab, valid;
-};
-struct CotRaw { double a, b, c, d, e; };
-__device__ __forceinline__ Cot4 make_cot(const BwdJobs& jobs, int job, int N, int col, bool valid, const double* dummy) {
-  Cot4 c;
-  const double* ru = jobs.res_u[job];
-  const double* ubar = jobs.ubar[job];
-  c.valid = valid;
-  c.weak = ru != nullptr && jobs.res_first[job] == 2;
-  c.use_res = ru != nullptr && !c.weak;
-  c.use_st = ru == nullptr && ubar != nullptr;
-  c.first = c.use_res && jobs.res_first[job] != 0;
-  c.cb = ru != nullptr ? jobs.res_base[job] : (ubar != nullptr ? 0.0 : 1.0);
-  c.coef = jobs.res_coef[job];
-  c.base = jobs.res_base[job];
-  c.kappa2 = jobs.res_kappa2[job];
-  c.tab = c.weak && jobs.res_c[job] != nullptr;
-  if (c.weak) {
-    c.p0 = ru + col; c.p1 = jobs.res_ref[job] + col; c.p2 = jobs.res_w[job] + col;
-    c.p3 = (c.tab ? jobs.res_c[job] : ru) + col; c.p4 = (c.tab ? jobs.res_cp[job] : ru) + col;
-    c.s0 = N; c.s1 = N; c.s2 = jobs.res_wpp[job] ? N : 0;
-  } else {
-    c.p0 = (c.use_st ? ubar : dummy) + col; c.s0 = c.use_st ? N : 0;
-    c.p1 = (c.use_res ? ru : dummy) + col; c.p2 = (c.use_res ? jobs.res_ref[job] : dummy) + col;
-    c.s1 = (c.use_res && !c.first) ? N : 0; c.s2 = 0;
-    c.p3 = c.p4 = dummy;
-  }
-  return c;
-}
-template <bool WEAK> __device__ __forceinline__ CotRaw cot_issue(const Cot4& c, int l) {
-  CotRaw r;
-  r.a = xw_ld_g(c.p0 + l * c.s0);
-  r.b = xw_ld_g(c.p1 + l * c.s1);
-  if (WEAK) {
-    r.c = xw_ld_g(c.p2 + l * c.s2);
-    r.d = xw_ld_g(c.p3 + l * c.s1);
-    r.e = xw_ld_g(c.p4 + l * c.s1);
-  } else {
-    r.c = xw_ld_g(c.p2 + l * c.s1);
-    r.d = r.e = 0.0;
-  }
-  return r;
-}
-template <bool WEAK> __device__ __forceinline__ double cot_value(const Cot4& c, const CotRaw& r, int l, int L) {
-  double ub;
-  if (WEAK) {
-    const double dcu = c.tab ? fma(r.a, r.e, r.d) : c.kappa2 * r.a;        // (as cot_u: c + u c', or kappa2 u)
-    ub = c.coef * dcu * r.b * r.c;
-    if (l == L - 1) ub = fma(c.base, r.b, ub);
-  } else {
-    ub = c.cb;
-    if (c.use_st) ub += r.a;
-    if (c.use_res && (!c.first || l == 0)) ub = fma(c.coef, r.b - r.c, ub);
-  }
-  return c.valid ? ub : 0.0;
-}
-
 // LDS plan of a block (doubles)
 template <int H, int K> struct Plan4 {
   typedef Dn<H, K> D;
