@@ -73,7 +73,7 @@ class Blob:
     @staticmethod
     def _view(flat, shape, off, ld):
         if len(shape) == 2:
-            return flat.as_strided(tuple(shape), (ld, 1), off)
+            return flat.as_strided(tuple(shape), (ld, 1), flat.storage_offset() + off)     # (as_strided's offset is absolute)
         return flat[off:off + shape[0]]
 
     def split(self, flat):

@@ -332,7 +332,12 @@ class NODE_WAN_solver:
         snaps = torch.zeros(R, n1, eng.Pu, dtype=torch.float64, device=dev)     # theta after every generator sub-iteration
         with HIP_HOST_LOCK:
             host = torch.zeros(R, n1 + 2, dtype=torch.float64).pin_memory()
-            snap_host = torch.zeros(eng.Pu, dtype=torch.float64).pin_memory()
+            snaps_host = torch.zeros(R, n1, eng.Pu, dtype=torch.float64).pin_memory()   # (rides along with the ring row: 26 KB)
+        # best_model_weights_NODE.pth is written by ONE worker thread, in order (a later save overwrites an earlier one exactly as
+        # in the synchronous loop); the main thread only hands it the state dict -- torch.save was 0.65 ms of its 3 ms per iteration
+        from concurrent.futures import ThreadPoolExecutor
+        saver = ThreadPoolExecutor(max_workers=1) if self._is_main() else None
+        pending = []
         done = [torch.cuda.Event() for _ in range(R)]
         filled = [torch.cuda.Event() for _ in range(R)]
         rb = torch.cuda.Stream(device=dev)
@@ -354,10 +359,9 @@ class NODE_WAN_solver:
                     past_losses.write('losses_NODE_' + str(d) + '.json')
                 if self.av_l < self.best_l:
                     if self._is_main():
-                        with torch.cuda.stream(rb):
-                            snap_host.copy_(snaps[r, i], non_blocking=True)
-                        rb.synchronize()
-                        torch.save(self._state_dict_from(snap_host, keys), 'best_model_weights_NODE.pth')
+                        sd = self._state_dict_from(snaps_host[r, i].clone(), keys)   # (a copy of its own: Blob.split views the STORAGE from offset 0, and row r is reused R iterations later)
+                        pending[:] = [f for f in pending if not f.done()]
+                        pending.append(saver.submit(torch.save, sd, 'best_model_weights_NODE.pth'))
                     self.best_l = self.av_l
             self.last_loss_v = row[n1]
             times.append(time.time())
@@ -401,6 +405,7 @@ class NODE_WAN_solver:
                 with torch.cuda.stream(rb):
                     rb.wait_event(filled[r])
                     host[r].copy_(ring[r], non_blocking=True)
+                    snaps_host[r].copy_(snaps[r], non_blocking=True)
                     done[r].record(rb)
                 issued = k + 1
                 if k > 0:
@@ -412,6 +417,10 @@ class NODE_WAN_solver:
             while processed < issued:
                 process(processed)
                 processed += 1
+            if saver is not None:
+                saver.shutdown(wait=True)                 # every best-weights file is on disk before train() returns or raises
+                for f in pending:
+                    f.result()
         return past_losses
 
     def _state_dict_layout(self):
