@@ -39,7 +39,7 @@ class _PinPool:
     RING = 16
 
     def __init__(self):
-        self.bufs, self.pos, self.events = {}, {}, {}
+        self.bufs, self.pos, self.events, self.mine = {}, {}, {}, set()
 
     def stage(self, t):
         key = (tuple(t.shape), t.dtype)
@@ -47,6 +47,7 @@ class _PinPool:
         if ring is None:
             with HIP_HOST_LOCK:
                 ring = self.bufs[key] = [torch.empty(t.shape, dtype=t.dtype).pin_memory() for _ in range(self.RING)]
+                self.mine.update(b.data_ptr() for b in ring)
         i = self.pos.get(key, 0)
         self.pos[key] = i + 1
         buf = ring[i % self.RING]
@@ -58,7 +59,7 @@ class _PinPool:
 
     def uploaded(self, buf):
         """called right behind an asynchronous host -> device copy out of a staged buffer (solver._up)"""
-        if buf.is_pinned() and any(buf.data_ptr() == b.data_ptr() for b in self.bufs.get((tuple(buf.shape), buf.dtype), ())):
+        if buf.data_ptr() in self.mine:
             ev = torch.cuda.Event()
             ev.record()
             self.events[buf.data_ptr()] = ev

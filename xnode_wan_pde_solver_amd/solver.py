@@ -86,9 +86,17 @@ class _JsonList(list):
         self._text += (', ' if len(self) else '') + json.dumps(x)
         super().append(x)
 
+    def text(self):
+        return '[' + self._text + ']'
+
     def write(self, path):
-        with open(path, 'w') as fh:
-            fh.write('[' + self._text + ']')
+        _write_text(path, self.text())
+
+
+def _write_text(path, text):
+    with open(path, 'w') as fh:
+        fh.write(text)
+
 
 class FusedAdam:
     """Stands where the reference has torch.optim.Adam (attributes optimizer_u / optimizer_v).  step() applies the
@@ -333,8 +341,9 @@ class NODE_WAN_solver:
         with HIP_HOST_LOCK:
             host = torch.zeros(R, n1 + 2, dtype=torch.float64).pin_memory()
             snaps_host = torch.zeros(R, n1, eng.Pu, dtype=torch.float64).pin_memory()   # (rides along with the ring row: 26 KB)
-        # best_model_weights_NODE.pth is written by ONE worker thread, in order (a later save overwrites an earlier one exactly as
-        # in the synchronous loop); the main thread only hands it the state dict -- torch.save was 0.65 ms of its 3 ms per iteration
+        # The files of an iteration (loss list, L2, times, best weights) are written by ONE worker thread, in order (a later write
+        # of a file overwrites an earlier one exactly as in the synchronous loop); the main thread only hands it the finished text /
+        # state dict -- torch.save and four open() calls were 1 ms of its 3 ms per iteration
         from concurrent.futures import ThreadPoolExecutor
         saver = ThreadPoolExecutor(max_workers=1) if self._is_main() else None
         pending = []
@@ -356,7 +365,7 @@ class NODE_WAN_solver:
                 self.last_loss_u = row[i]
                 past_losses.append(self.av_l)
                 if self._is_main():
-                    past_losses.write('losses_NODE_' + str(d) + '.json')
+                    pending.append(saver.submit(_write_text, 'losses_NODE_' + str(d) + '.json', past_losses.text()))
                 if self.av_l < self.best_l:
                     if self._is_main():
                         sd = self._state_dict_from(snaps_host[r, i].clone(), keys)   # (a copy of its own: Blob.split views the STORAGE from offset 0, and row r is reused R iterations later)
@@ -366,9 +375,8 @@ class NODE_WAN_solver:
             self.last_loss_v = row[n1]
             times.append(time.time())
             if self._is_main():
-                with open('L2_NODE_' + str(d) + '.json', 'w') as fh:
-                    json.dump([row[n1 + 1]], fh)
-                times.write('Time_NODE_' + str(d) + '.json')
+                pending.append(saver.submit(_write_text, 'L2_NODE_' + str(d) + '.json', json.dumps([row[n1 + 1]])))
+                pending.append(saver.submit(_write_text, 'Time_NODE_' + str(d) + '.json', times.text()))
 
         nxt_domain = nxt_points = None
         issued = processed = 0          # iterations whose ring row is on its way to the host / whose files have been written
