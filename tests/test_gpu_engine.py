@@ -437,11 +437,26 @@ def test_pipelined_loop_flushes_its_last_iteration_when_interrupted(golden_dir, 
         os.chdir(cwd)
 
 
+@pytest.mark.parametrize('general', [False, True])
 @pytest.mark.parametrize('name', ['NSphere_TCone', 'NSphere_THourglass'])
-def test_group_substep_runner_matches_the_launch_by_launch_path(tmp_path, name):
+def test_group_substep_runner_matches_the_launch_by_launch_path(tmp_path, name, general):
     """xw_substep_gen / xw_substep_disc (one C-ABI call per group sub-step, csrc/xw_substep.hip) against the same chain issued
     launch by launch from engine.py: bit-identical parameters after three outer iterations over all groups of a ball domain
-    (single-slice pairwise groups, boundary groups on their own grids, point-mode test network, carried gradients)"""
+    (single-slice pairwise groups, boundary groups on their own grids, point-mode test network, carried gradients).
+    general: non-identity a_ij(t, x) and the linear reaction c = -0.7 u (the A0 table and xw_weak_contract_general inside the call;
+    XW_ELEMENTWISE_SINGLE_SLICE semantics are not involved: b = 0 keeps the pairwise groups allowed)"""
+    F = P
+    if general:
+        class F:      # noqa: N801
+            func_h, func_f, func_g, func_u_sol, func_b = P.func_h, P.func_f, P.func_g, P.func_u_sol, P.func_b
+
+            @staticmethod
+            def func_a(X, i, j):
+                return (1.0 + 0.5 * X[..., 1] ** 2) * (1.0 if i == j else 0.1 * torch.cos(X[..., 2]))
+
+            @staticmethod
+            def func_c(X, u):
+                return -0.7 * u
     params = {'alpha': 1e4, 'u_layers': 8, 'u_hidden_dim': 20, 'u_hidden_hidden_dim': 10, 'v_layers': 9, 'v_hidden_dim': 50,
               'n1': 2, 'n2': 1, 'u_rate': 0.015, 'v_rate': 0.04, 'min_steps': 5, 'adjoint': False, 'solver': 'midpoint',
               'dim': 4, 'N_t': 8, 'N_r': 300, 'N_b': 200, 'T0': 0, 'T': 1, 'shape_param': 1.0, 'iterations': 3, 'domain': name}
@@ -450,7 +465,8 @@ def test_group_substep_runner_matches_the_launch_by_launch_path(tmp_path, name):
     os.chdir(tmp_path)
     try:
         for runner in (True, False):
-            S = make_solver(params, 3)
+            S = make_solver(params, 3, F=F)
+            assert S.engine.structure.a_identity != general and S.engine.structure.c_kappa == (-0.7 if general else -1.0)
             S.engine.use_runner = runner
             losses = S.train(report=False)
             out.append((S.engine.theta.data.clone(), S.engine.phi.data.clone(), list(losses)))
