@@ -107,6 +107,10 @@ def _load():
         raise XnwanError(
             'libxnwan.so not found at %s -- build it with `python -c "import __graft_entry__ as g; g.build()"` '
             'or `make -C xnode_wan_pde_solver_amd/csrc`.  There is no CPU fallback.' % LIB_PATH)
+    # torch FIRST: its wheel ships its own ROCm runtime (torch/lib/libamdhip64.so); loaded before torch, this library would pull in
+    # the system's copy and the process would hold two HIP runtimes -- its kernels registered with one, torch's streams and memory
+    # living in the other (every launch then fails with hipErrorNoDevice: build() followed by smoke() in ONE process did)
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)           # AttributeError here = the .so does not export the declared ABI
