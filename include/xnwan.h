@@ -186,6 +186,14 @@ int xw_weak_partials(const double* u, const double* v, const double* vt, const d
  * once its two factors are global (several GPUs: after the all-reduce; one GPU: done by xw_weak_partials' finalisation) */
 int xw_pair_fold(double* scal, double Vol, double Nglob, void* stream);
 int xw_reduce_work_size(void);
+/* Distance weight of the hypercube domain and its x-gradient at N points (replaces Hypercube.func_w, src/dataset.py:278-282, and
+ * the autograd pass through it that the weak form takes, src/loss.py:51-63), in the sample's float32 arithmetic like the
+ * reference's tensors, widened to float64 on the way out:
+ *   x[N, d] float32 row-major;  w[n] = min(min_i |top - x_i|, min_i |bot - x_i|)  (also into w0 if not NULL);
+ *   gwT[d, N] = d w / d x as autograd returns it (first minimal index; an exact tie of the two distances splits half / half);
+ *   xT[d, N] (or NULL) = the points, transposed.  One launch where the tensor formulation takes ~25. */
+int xw_cube_weight(const float* x, int N, int d, double top, double bot, double* w, double* w0, double* gwT, double* xT,
+                   void* stream);
 /* The l = 0 gradient-contraction term for GENERAL coefficients (src/loss.py:66-69 with the a[d,d,N,L] / b[d,N,L] tables of
  * src/training.py:32-41 -- of which only time index 0 can ever contribute, so only that slice is tabulated):
  *   s3x[n] = sum_ij a_ij(t_0, x_n) d_i phi d_j u + phi sum_i b_i(t_0, x_n) d_i u,

@@ -899,3 +899,48 @@ def test_solvers_that_go_out_of_scope_do_not_take_live_graphs_with_them(golden_d
     assert len(E._KEPT_GRAPHS) > kept                            # the collected solvers' graphs are still there
     assert torch.equal(A.engine.theta.data, T.engine.theta.data) and torch.equal(A.engine.phi.data, T.engine.phi.data)
     assert torch.isfinite(A.engine.theta.data).all()
+
+
+@pytest.mark.parametrize('general', [False, True])
+def test_group_refilled_by_one_graph_replay_holds_what_load_group_writes(general):
+    """Engine.refill_compact (the training loop's refill of its group: static input buffers + ONE captured graph, with the
+    lean field-by-field body where the coefficient structure is the fused one) against load_group on the same samples, every
+    sample field bit for bit, on the capture pass and on plain replays; a general b_i takes load_group's own body (captured
+    when its tabulation allows it, eager with a warning otherwise) -- same fields."""
+    import warnings
+    from xnode_wan_pde_solver_amd import sampling
+    from xnode_wan_pde_solver_amd.engine import Group
+    params = {'alpha': 1e8, 'u_layers': 8, 'u_hidden_dim': 20, 'u_hidden_hidden_dim': 10, 'v_layers': 9, 'v_hidden_dim': 50,
+              'n1': 2, 'n2': 1, 'u_rate': 0.015, 'v_rate': 0.04, 'min_steps': 5, 'adjoint': False, 'solver': 'midpoint',
+              'dim': 5, 'N_t': 9, 'N_r': 300, 'N_b': 120, 'T0': 0, 'T': 1, 'shape_param': [-1, 1], 'iterations': 1,
+              'domain': 'Hypercube'}
+
+    class F(object):
+        pass
+    for k in ('func_a', 'func_c', 'func_h', 'func_f', 'func_g', 'func_u_sol'):
+        setattr(F, k, staticmethod(getattr(P, k)))
+    F.func_b = staticmethod((lambda X, i: 0.1 * (i + 1) * X[..., 1]) if general else P.func_b)
+    S = make_solver(params, 5, F=F)
+    eng, dev = S.engine, S.device
+    samples, refs = [], []
+    for _ in range(3):
+        dom, pts = first_sample(S)
+        comp = pts.compact()
+        td = comp[0].to(dev)
+        X, XV, BX = (sampling._paths(td, c.to(dev)) for c in comp[1:])
+        samples.append((dom, comp))
+        refs.append(eng.load_group(X, XV, BX, dom, shared_grid_t0=float(comp[0][0])))
+    G = refs.pop()                       # the group that gets refilled; the other two are what it must hold afterwards
+    samples.pop()
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore', RuntimeWarning)
+        for rep in range(4):
+            dom, comp = samples[rep % 2]
+            ver = G.sample_version
+            assert eng.refill_compact(G, comp, dom) is G and G.sample_version == ver + 1 and G.domain is dom
+            for k in Group.SAMPLE_FIELDS:
+                a, b = getattr(G, k), getattr(refs[rep % 2], k)
+                assert (a is None) == (b is None), k
+                assert a is None or torch.equal(a, b), (k, rep)
+    kinds = [type(v).__name__ for k, v in G.graphs.items() if k.startswith('refill')]
+    assert kinds in ((['bool'], ['CUDAGraph']) if general else (['CUDAGraph'],)), kinds

@@ -840,3 +840,39 @@ def test_ode_kernels_at_the_wide_instantiation(Hh, Kk, m, solver):
             if k in theta:
                 _close(flat[off:off + n].view(theta[k].shape), grads[2 + order.index(k)], 1e-10, 'grad %s act=%s' % (k, with_act))
             off += n
+
+
+@pytest.mark.parametrize('N,d', [(1, 1), (37, 2), (300, 5), (4096, 20), (1000, 100)])
+def test_cube_weight_kernel_is_the_tensor_formulation_bit_for_bit(N, d):
+    """xw_cube_weight against Hypercube.func_w_grad (itself checked against autograd through func_w, the reference's
+    src/dataset.py:278-282 + src/loss.py:51-63) on the device: w, the gradient and the transposed points, including points ON
+    faces, exact ties between the two distances (x_i = 0 on a symmetric cube), between coordinates, and the autograd result."""
+    from xnode_wan_pde_solver_amd import sampling
+    from xnode_wan_pde_solver_amd import kernels as KN
+    dev = torch.device('cuda')
+    g = torch.Generator().manual_seed(N * 131 + d)
+    for top_bot in ((-1.0, 1.0), (-0.3, 2.5)):
+        dom = sampling.Hypercube(top_bot, d, 0.0, 1.0, 4)
+        x = (torch.rand(N, d, generator=g) * (top_bot[1] - top_bot[0]) + top_bot[0])
+        if N > 8:
+            x[0, 0] = top_bot[1]                       # on the top face
+            x[1, d - 1] = top_bot[0]                   # on the bottom face
+            x[2] = 0.5 * (top_bot[0] + top_bot[1])     # centre: every coordinate ties, and top ties with bottom
+            x[3, :] = x[3, 0]                          # all coordinates equal
+            x[4, d // 2] = x[4, 0]
+        x = x.to(dev)
+        X = sampling._paths(torch.zeros(1, device=dev), x)                 # [N, 1, 1+d]
+        w_ref, g_ref = dom.func_w_grad(X)
+        Xa = X.clone().requires_grad_(True)
+        g_auto = torch.autograd.grad(dom.func_w(Xa).sum(), Xa)[0]
+        assert torch.equal(g_auto, g_ref)
+        w = torch.empty(N, dtype=torch.float64, device=dev)
+        w0 = torch.empty_like(w)
+        gwT = torch.empty(d, N, dtype=torch.float64, device=dev)
+        xT = torch.empty(d, N, dtype=torch.float64, device=dev)
+        KN.cube_weight(x, dom.top, dom.bot, w, gwT, w0=w0, xT=xT)
+        assert torch.equal(w, w_ref[:, 0].double()) and torch.equal(w0, w)
+        assert torch.equal(gwT, g_ref[:, 0, 1:].double().t())
+        assert torch.equal(xT, x.double().t())
+        KN.cube_weight(x, dom.top, dom.bot, w, gwT)                        # the optional outputs left out
+        assert torch.equal(gwT, g_ref[:, 0, 1:].double().t())

@@ -232,6 +232,39 @@ __global__ void k_pair_fold(double* __restrict__ scal, double cN) {
   if (blockIdx.x == 0 && threadIdx.x == 0) fold_pairs(scal, cN);
 }
 
+// Distance weight of the hypercube [bot, top]^d and its x-gradient at one point per thread (src/dataset.py:278-282 and the
+// autograd pass through it, src/loss.py:51-63): w = min(min_i |top - x_i|, min_i |bot - x_i|) in the sample's float32 arithmetic,
+// the gradient as autograd returns it -- min over a dimension sends it to the FIRST index that attains the minimum,
+// torch.minimum splits it half / half on equal operands, |.| has slope sign(.) (0 at 0) -- both widened to float64 on the
+// way out, into the layouts the weak form reads ([N], [d, N]); optionally the transposed float64 copy of the points.
+__global__ void __launch_bounds__(256) k_cube_weight(const float* __restrict__ x, int N, int d, float top, float bot,
+                                                     double* __restrict__ w, double* __restrict__ w0,
+                                                     double* __restrict__ gwT, double* __restrict__ xT) {
+  for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
+    const float* xn = x + (long)n * d;
+    float at = fabsf(top - xn[0]), ab = fabsf(bot - xn[0]);
+    int it = 0, ib = 0;
+    for (int i = 1; i < d; ++i) {
+      const float a = fabsf(top - xn[i]), b = fabsf(bot - xn[i]);
+      if (a < at) { at = a; it = i; }
+      if (b < ab) { ab = b; ib = i; }
+    }
+    const float wv = ab < at ? ab : at;
+    const float ct = (at < ab ? 1.0f : 0.0f) + (at == ab ? 0.5f : 0.0f), cb = (ab < at ? 1.0f : 0.0f) + (at == ab ? 0.5f : 0.0f);
+    const float dt = top - xn[it], db = bot - xn[ib];
+    const float gt = -(dt > 0.0f ? 1.0f : (dt < 0.0f ? -1.0f : 0.0f)) * ct, gb = -(db > 0.0f ? 1.0f : (db < 0.0f ? -1.0f : 0.0f)) * cb;
+    w[n] = (double)wv;
+    if (w0) w0[n] = (double)wv;
+    for (int i = 0; i < d; ++i) {
+      float g = 0.0f;
+      if (i == it) g += gt;
+      if (i == ib) g += gb;
+      gwT[(long)i * N + n] = (double)g;
+      if (xT) xT[(long)i * N + n] = (double)xn[i];
+    }
+  }
+}
+
 __global__ void __launch_bounds__(256) k_disc_cot(const double* __restrict__ u, const double* __restrict__ v,
                                                   const double* __restrict__ w, int w_per_point,
                                                   const double* __restrict__ c, double ckappa,
@@ -422,6 +455,14 @@ extern "C" int xw_pair_fold(double* scal, double Vol, double Nglob, void* stream
   return xw_launch_status();
 }
 
+extern "C" int xw_cube_weight(const float* x, int N, int d, double top, double bot, double* w, double* w0, double* gwT,
+                              double* xT, void* stream) {
+  if (!x || !w || !gwT || N <= 0 || d <= 0 || !(top > bot)) return XW_E_ARG;
+  hipLaunchKernelGGL(k_cube_weight, dim3(blocks_for(N, 256, 1024)), dim3(256), 0, (hipStream_t)stream, x, N, d, (float)top,
+                     (float)bot, w, w0, gwT, xT);
+  return xw_launch_status();
+}
+
 extern "C" int xw_disc_cotangent(const double* u, const double* v, const double* w, int w_per_point, const double* c,
                                  double ckappa, const double* f, const double* h, int N, int L, double Vol, double Nglob,
                                  double pollution, double s3_scale, const double* scal_in, double* vbar, void* stream) {
@@ -483,7 +524,7 @@ extern "C" int xw_slab_sum(const double* gslab, int nslab, int P, int accumulate
   return xw_launch_status();
 }
 
-extern "C" int xw_abi_version(void) { return 25; }
+extern "C" int xw_abi_version(void) { return 26; }
 extern "C" int xw_reduce_work_size(void) { return 5 * 1024 + 8; }
 
 extern "C" int xw_supported_dims(char* buf, int buflen) {

@@ -379,6 +379,21 @@ def pair_fold(scal, Vol, Nglob):
     check(lib.xw_pair_fold(_p(scal), float(Vol), float(Nglob), _stream()), 'xw_pair_fold')
 
 
+def cube_weight(x, top, bot, w, gwT, w0=None, xT=None):
+    """w[N], dw/dx as gwT[d, N] (float64) of the hypercube's distance weight at the float32 points x[N, d] -- the values and the
+    gradient Hypercube.func_w / autograd give in float32, widened; optionally w0 (a second copy of w) and xT = x^T as float64"""
+    _need_gpu()
+    N, d = x.shape
+    _chk(x, torch.float32, (N, d), 'x')
+    _chk(w, F64, (N,), 'w')
+    _chk(gwT, F64, (d, N), 'gwT')
+    if w0 is not None:
+        _chk(w0, F64, (N,), 'w0')
+    if xT is not None:
+        _chk(xT, F64, (d, N), 'xT')
+    check(lib.xw_cube_weight(_p(x), N, d, float(top), float(bot), _p(w), _p(w0), _p(gwT), _p(xT), _stream()), 'xw_cube_weight')
+
+
 def weak_contract_general(A0, amode, B0, gx, gs, ghT, gxv, w0, gwx0T, v0, s3x):
     """s3x[n] = sum_ij a_ij d_i(phi) d_j(u) + phi sum_i b_i d_i(u) at the first time index for general coefficients.
     amode says what A0 is (never inferred from its shape: [d,d] and [d,N] coincide when N == d):

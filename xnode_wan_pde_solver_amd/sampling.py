@@ -36,7 +36,7 @@ class _PinPool:
     use, under HIP_HOST_LOCK.  A slot is reused after RING stagings of its shape (at the headline shape xu, xv and xb share
     one key: 6 stagings per outer iteration, i.e. after 2.7 iterations); what makes that safe is not the count but the
     event `uploaded()` records behind the asynchronous copy out of the slot: `stage()` waits for it before overwriting."""
-    RING = 16
+    RING = 32
 
     def __init__(self):
         self.bufs, self.pos, self.events, self.mine = {}, {}, {}, set()
@@ -57,12 +57,19 @@ class _PinPool:
         buf.copy_(t)
         return buf
 
-    def uploaded(self, buf):
+    def uploaded(self, buf, stream=None):
         """called right behind an asynchronous host -> device copy out of a staged buffer (solver._up)"""
-        if buf.data_ptr() in self.mine:
+        self.uploaded_all((buf,), stream)
+
+    def uploaded_all(self, bufs, stream=None):
+        """the same for several buffers whose copies were issued on ONE stream: one event behind the last of them guards every
+        slot (an event per buffer was 6 x 40 us of an outer iteration: torch looks the current device up for each record)"""
+        ptrs = [b.data_ptr() for b in bufs if b.data_ptr() in self.mine]
+        if ptrs:
             ev = torch.cuda.Event()
-            ev.record()
-            self.events[buf.data_ptr()] = ev
+            ev.record(stream) if stream is not None else ev.record()
+            for p in ptrs:
+                self.events[p] = ev
 
 
 _PIN_POOL = _PinPool()

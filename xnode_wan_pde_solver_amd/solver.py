@@ -15,6 +15,7 @@ Differences, all deliberate:
   * `exit()` on the stop criterion can be turned into a normal return with `solver.exit_on_stop = False`
 """
 import json
+import os
 import time
 from itertools import product
 
@@ -93,6 +94,11 @@ class _JsonList(list):
         _write_text(path, self.text())
 
 
+def _run_all(jobs):
+    for fn, args in jobs:
+        fn(*args)
+
+
 def _write_text(path, text):
     with open(path, 'w') as fh:
         fh.write(text)
@@ -164,6 +170,11 @@ class NODE_WAN_solver:
                                           # written to the side-effect files and compared while iteration k + 1 runs (same
                                           # values, same files, one iteration later; everything is flushed before train()
                                           # returns).  False: every sub-iteration is synchronised like the reference's loop
+        self.capture_refill = os.environ.get('XW_CAPTURE_REFILL', '1') != '0'
+                                          # the pipelined loop refills its group (path tensors, h, f, g, w, transposes: ~110 small
+                                          # kernels) and evaluates the L^p diagnostic by replaying ONE captured graph each
+                                          # (Engine.refill_compact, _l_norm_replayed); same arithmetic, same fallback rule as the
+                                          # sub-step graphs.  False: eager launches
         self.reuse_test_net = True        # v, dv/dt, nabla_x v(t_0) are evaluated once per (phi, sample) and shared by the
                                           # sub-steps of an outer iteration -- bit-identical results (the reference
                                           # recomputes the same values); bench.py times the sub-steps WITHOUT it
@@ -233,7 +244,9 @@ class NODE_WAN_solver:
         if not t.is_pinned():
             return t.to(self.device)
         out = t.to(self.device, non_blocking=True)
-        sampling._PIN_POOL.uploaded(t)          # (the staging slot is not overwritten before this copy has read it)
+        # (the staging slot is not overwritten before this copy has read it; the stream is named WITH its device index: without
+        #  one torch asks whether CUDA is available on every call, 40 us)
+        sampling._PIN_POOL.uploaded(t, torch.cuda.current_stream(self.device))
         return out
 
     def _shard(self, points):
@@ -251,6 +264,35 @@ class NODE_WAN_solver:
             return (val if torch.is_tensor(val) else torch.tensor(val)).to(device=self.device, dtype=torch.float64).reshape(())
         val = self._l_norm_value(points, volume)
         return val.item() if torch.is_tensor(val) else val
+
+    def _l_norm_replayed(self, G, points, domain):
+        """_l_norm(points, V, as_tensor=True) for a compact cube sample, as ONE graph replay (held with the group's sub-step
+        graphs, same capture / fallback rule: Engine._run): the sample goes into two static buffers, the path tensor, the exact
+        solution, u_theta (the stepper's forward kernel) and the mean are replayed.  Anything else takes the ordinary way."""
+        comp = points.compact() if hasattr(points, 'compact') else None
+        eng = self.engine
+        if (comp is None or comp[0].is_cuda or self.func_u_sol is None or self.world is not None or not eng.use_graphs
+                or self.tabulate_on_host):
+            return self._l_norm(points, domain.V(), as_tensor=True)
+        from utils.auxillary_funcs import L_norm
+        times, xu = comp[0], comp[1]
+        st = G.__dict__.get('_diag_in')
+        if st is None or st[0].shape != times.shape or st[1].shape != xu.shape:
+            st = G._diag_in = [torch.empty(tuple(c.shape), dtype=c.dtype, device=self.device) for c in (times, xu)] + [
+                torch.zeros((), dtype=torch.float64, device=self.device)]
+            G.graphs = {k: v for k, v in G.graphs.items() if not k.startswith('diag')}
+        st[0].copy_(times, non_blocking=True)
+        st[1].copy_(xu, non_blocking=True)
+        sampling._PIN_POOL.uploaded_all((times, xu), torch.cuda.current_stream(self.device))
+        at_T0 = float(times[0]) == self.setup['T0']
+        volume, n_r, p = domain.V(), self.setup['N_r'], self.p
+
+        def body(_G):
+            X = sampling._paths(st[0], st[1])
+            val = L_norm(X, lambda x: self.u_net(x, starts_at_T0=at_T0), p, self.func_u_sol, volume, n_r)
+            st[2].copy_(val.to(torch.float64).reshape(()))
+        eng._run(G, 'diag_%r_%r_%r' % (at_T0, float(volume), p), body)
+        return st[2]
 
     def _l_norm_value(self, points, volume):
         from utils.auxillary_funcs import L_norm
@@ -360,41 +402,75 @@ class NODE_WAN_solver:
             r = k % R
             done[r].synchronize()
             row = host[r].tolist()
+            jobs = []                      # this iteration's files, in the order the synchronous loop writes them: ONE hand-over
             for i in range(n1):
                 self.av_l = row[i]
                 self.last_loss_u = row[i]
                 past_losses.append(self.av_l)
-                if self._is_main():
-                    pending.append(saver.submit(_write_text, 'losses_NODE_' + str(d) + '.json', past_losses.text()))
+                jobs.append((_write_text, ('losses_NODE_' + str(d) + '.json', past_losses.text())))
                 if self.av_l < self.best_l:
                     if self._is_main():
                         sd = self._state_dict_from(snaps_host[r, i].clone(), keys)   # (a copy of its own: Blob.split views the STORAGE from offset 0, and row r is reused R iterations later)
-                        pending[:] = [f for f in pending if not f.done()]
-                        pending.append(saver.submit(torch.save, sd, 'best_model_weights_NODE.pth'))
+                        jobs.append((torch.save, (sd, 'best_model_weights_NODE.pth')))
                     self.best_l = self.av_l
             self.last_loss_v = row[n1]
             times.append(time.time())
+            jobs.append((_write_text, ('L2_NODE_' + str(d) + '.json', json.dumps([row[n1 + 1]]))))
+            jobs.append((_write_text, ('Time_NODE_' + str(d) + '.json', times.text())))
             if self._is_main():
-                pending.append(saver.submit(_write_text, 'L2_NODE_' + str(d) + '.json', json.dumps([row[n1 + 1]])))
-                pending.append(saver.submit(_write_text, 'Time_NODE_' + str(d) + '.json', times.text()))
+                pending[:] = [f for f in pending if not f.done()]
+                pending.append(saver.submit(_run_all, jobs))
 
-        nxt_domain = nxt_points = None
+        # (Refilling a SECOND group for iteration k + 1 on a side stream beside the sub-steps of iteration k, and the diagnostic
+        #  beside the discriminator sub-step, was built and measured: with torch's side stream on a hardware queue of its own
+        #  (GPU_MAX_HW_QUEUES=8) an outer iteration takes 4.1-6.7 ms instead of 2.0-2.3 -- every one of the ~110 small dependent
+        #  kernels of a refill waits for a CU with free registers and LDS next to resident test-network and stepper blocks that
+        #  hold them for 0.2-0.3 ms; on the default four queues the side stream shares the main stream's queue and nothing
+        #  overlaps.  One group, one stream.)
+        main = torch.cuda.current_stream(dev)
+        group = self._group_cache[0] if len(self._group_cache) == 1 else None
+
+        def compact_of(pts):
+            comp = pts.compact() if hasattr(pts, 'compact') else None
+            return comp if (comp is not None and self.capture_refill and self.world is None and eng.use_graphs
+                            and not comp[0].is_cuda and not self.tabulate_on_host) else None
+
+        # (host seconds per phase of the loop body, summed over the run: tools/train_phases.py prints them)
+        phase = self._phase_seconds = dict.fromkeys(('fill', 'substeps', 'sampler_wait', 'diagnostic', 'ring', 'process'), 0.0)
+        clock = time.perf_counter
+
+        def lap(name, t):
+            now = clock()
+            phase[name] += now - t
+            return now
+
+        nxt_domain = nxt_points = ahead = None
         issued = processed = 0          # iterations whose ring row is on its way to the host / whose files have been written
+        last = self.iterations - 1
         with torch.cuda.device(dev):
           try:
             for k in range(self.iterations):
                 domain = nxt_domain if nxt_domain is not None else self._new_domain()
                 points = nxt_points if nxt_points is not None else self._loader(domain)
                 nxt_domain = nxt_points = None
-                ahead = pool.submit(draw_ahead, domain, k == self.iterations - 1) if pool is not None else None
-                (du, dv, bd, ng, nbg), = self._shard(self._groups(points))
-                old = self._group_cache[0] if len(self._group_cache) == 1 else None
-                G = eng.load_group(du, dv, bd, domain, ng, nbg, into=old, shared_grid_t0=self._grid_hint)
+                if ahead is None and pool is not None:     # (later ones are submitted the moment the previous result is taken)
+                    ahead = pool.submit(draw_ahead, domain, k == last)
+                tick = clock()
+                old = group
+                comp = compact_of(points)
+                if old is not None and comp is not None:
+                    # every iteration after the first: the sample into static buffers, ONE graph replay fills the group
+                    G = eng.refill_compact(old, comp, domain)
+                else:
+                    (du, dv, bd, ng, nbg), = self._shard(self._groups(points))
+                    G = eng.load_group(du, dv, bd, domain, ng, nbg, into=old, shared_grid_t0=self._grid_hint)
+                group = G
                 self._group_cache = [G]
                 G.persistent = True
                 r = k % R
                 if k >= R:
                     done[r].synchronize()                 # (row r was processed R - 1 iterations ago; its copy is long done)
+                tick = lap('fill', tick)
                 for i in range(n1):
                     eng.begin_substep('u', False)
                     eng.generator_step(G)
@@ -404,21 +480,32 @@ class NODE_WAN_solver:
                     eng.begin_substep('v', False)
                     eng.discriminator_step(G)
                 ring[r, n1].copy_(eng.loss_v())
+                tick = lap('substeps', tick)
                 if ahead is not None:
                     points_after, nxt_domain, nxt_points = ahead.result()
+                    ahead = pool.submit(draw_ahead, nxt_domain, k + 1 == last) if k < last else None
                 else:
                     points_after = self._loader(domain)
-                ring[r, n1 + 1].copy_(self._l_norm(points_after, domain.V(), as_tensor=True))
-                filled[r].record()
-                with torch.cuda.stream(rb):
+                tick = lap('sampler_wait', tick)
+                diag = (self._l_norm_replayed(G, points_after, domain) if self.capture_refill
+                        else self._l_norm(points_after, domain.V(), as_tensor=True))
+                tick = lap('diagnostic', tick)
+                ring[r, n1 + 1].copy_(diag)
+                filled[r].record(main)
+                torch.cuda.set_stream(rb)
+                try:
                     rb.wait_event(filled[r])
                     host[r].copy_(ring[r], non_blocking=True)
                     snaps_host[r].copy_(snaps[r], non_blocking=True)
                     done[r].record(rb)
+                finally:
+                    torch.cuda.set_stream(main)
                 issued = k + 1
+                tick = lap('ring', tick)
                 if k > 0:
                     process(k - 1)
                     processed = k
+                lap('process', tick)
           finally:
             # the host side runs one iteration behind the GPU: whatever has been computed is written out before train() returns
             # OR raises (an exception / KeyboardInterrupt inside the loop must not lose the last iteration's losses and best weights)
