@@ -833,6 +833,7 @@ def test_pipelined_training_loop_leaves_exactly_what_the_synchronous_one_does(tm
         try:
             S = make_solver(params, 3)
             S.pipeline = pipe
+            S.capture_refill = pipe        # (the synchronous run also refills by eager load_group calls and evaluates the diagnostic eagerly)
             losses = list(S.train(report=False))
             torch.cuda.synchronize()
             best = torch.load('best_model_weights_NODE.pth')

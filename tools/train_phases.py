@@ -12,6 +12,13 @@ S = NODE_WAN_solver(dict(workload_params(20, 4096, 4096, 32), iterations=5), P.f
 os.makedirs('/tmp/tt', exist_ok=True); os.chdir('/tmp/tt')
 S.train()
 n = S.iterations = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+if 'sync' in sys.argv:          # the synchronous loop (what a stop callback or report=True selects), with and without the captured refill
+    S.pipeline = False
+    for cap in (True, False, True, False):
+        S.capture_refill = cap
+        torch.cuda.synchronize(); t0 = time.perf_counter(); S.train(); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        print('synchronous loop, capture_refill=%-5s: %.3f ms per outer iteration' % (cap, 1e3 * dt / n))
+    sys.exit(0)
 for rep in range(2):
     torch.cuda.synchronize(); t0 = time.perf_counter(); S.train(); torch.cuda.synchronize(); dt = time.perf_counter() - t0
     print('%.3f ms per outer iteration; host ms per phase: %s' % (1e3 * dt / n, '  '.join('%s %.3f' % (k, 1e3 * v / n) for k, v in S._phase_seconds.items())))
