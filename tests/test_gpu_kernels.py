@@ -78,7 +78,7 @@ def test_ode_forward(N, L, d, solver):
     assert Y.shape == (L, H, N)
 
 
-@pytest.mark.parametrize('m', [8, 7, 6, 5, 4, 3, 2, 1])
+@pytest.mark.parametrize('m', [10, 9, 8, 7, 6, 5, 4, 3, 2, 1])
 def test_ode_forward_depths(m):
     from oracle import refspec as R
     from xnode_wan_pde_solver_amd import kernels as KN
@@ -307,7 +307,8 @@ def test_ode_sweep_with_residual_cotangents(solver):
 @pytest.mark.parametrize('solver', ['euler', 'midpoint'])
 @pytest.mark.parametrize('Hh,Kk,m,N,L,d', [(20, 10, 8, 37, 7, 5), (20, 10, 8, 64, 6, 20), (20, 10, 8, 16, 2, 3), (20, 10, 8, 1, 3, 1),
                                            (20, 10, 3, 50, 5, 6), (20, 10, 1, 21, 4, 6), (20, 10, 8, 300, 4, 70),
-                                           (32, 12, 8, 37, 6, 5), (32, 12, 2, 19, 3, 21)])
+                                           (32, 12, 8, 37, 6, 5), (32, 12, 2, 19, 3, 21),
+                                           (20, 10, 10, 37, 5, 5), (20, 10, 9, 20, 3, 4), (32, 12, 10, 19, 3, 6)])   # (deepest compiled fields)
 def test_ode_narrow_tile_sweeps(Hh, Kk, m, N, L, d, solver):
     """xw_ode_bwd mode bit 4 (csrc/xw_ode_n4.h): the sweeps with a 16-path tile spread over four waves of 4 paths x 16 rows
     -- x, start and every weight gradient against the oracle's autograd (1e-10), and against the 16-path sweeps of the same
@@ -791,7 +792,7 @@ def test_empty_and_malformed_inputs_are_refused_by_the_c_abi():
 
 # ---- widths other than the YAML's (src/model.py:62-85,130-138 accept any u_hidden_dim / u_hidden_hidden_dim) ----------------
 @pytest.mark.parametrize('solver', ['euler', 'midpoint', 'rk4'])
-@pytest.mark.parametrize('Hh,Kk,m', [(32, 12, 8), (32, 12, 3), (32, 12, 1)])
+@pytest.mark.parametrize('Hh,Kk,m', [(32, 12, 8), (32, 12, 3), (32, 12, 1), (32, 12, 10), (20, 10, 10)])
 def test_ode_kernels_at_the_wide_instantiation(Hh, Kk, m, solver):
     """the (32, 12) stepper object: H a multiple of 16 (the time row of [y ; t] is a tile of its own), K = 12 (no padding
     row inside the 4-row blocks) -- forward 1e-12, sweep (x, start, every weight gradient) 1e-10 against the oracle,

@@ -42,6 +42,8 @@
     case 6: { CALL(XW_ODE_H, XW_ODE_K, 6) }                      \
     case 7: { CALL(XW_ODE_H, XW_ODE_K, 7) }                      \
     case 8: { CALL(XW_ODE_H, XW_ODE_K, 8) }                      \
+    case 9: { CALL(XW_ODE_H, XW_ODE_K, 9) }                      \
+    case 10: { CALL(XW_ODE_H, XW_ODE_K, 10) }                    \
     default: return XW_E_DIMS;                                   \
   }
 #endif

@@ -21,7 +21,7 @@ static bool width_compiled(int H, int K) {
 }
 
 extern "C" int xw_ode_act_rows(int method, int H, int K, int m) {
-  if (!width_compiled(H, K) || m < 1 || m > 8) return XW_E_DIMS;
+  if (!width_compiled(H, K) || m < 1 || m > XW_ODE_MAX_LAYERS) return XW_E_DIMS;
   const int S = method == 0 ? 1 : method == 1 ? 2 : 0;           // rk4: the sweeps recompute
   return S == 0 ? 0 : S * m * K + (S - 1) * H + 2 * S;             // (+ the ReLU-mask words of every stage)
 }
