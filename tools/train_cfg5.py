@@ -16,7 +16,8 @@ os.makedirs('/tmp/c5', exist_ok=True); os.chdir('/tmp/c5')
 S.train()
 S.iterations = iters
 torch.cuda.synchronize(); t0 = time.time(); S.train(); torch.cuda.synchronize(); dt = time.time() - t0
-print('%s: %d outer iterations, %.1f ms each; groups per sample: %d' % (name, iters, 1e3 * dt / iters, len(S._group_cache)))
+print('%s: %d outer iterations, %.1f ms each; groups per sample: %d; the sampling thread drew for %.1f ms of each (two samples: the diagnostic\'s and the next iteration\'s)'
+      % (name, iters, 1e3 * dt / iters, len(S._group_cache), 1e3 * S._sampler_seconds / iters))
 if len(sys.argv) > 3:
     import cProfile, pstats, io
     pr = cProfile.Profile(); pr.enable(); S.iterations = 2; S.train(); torch.cuda.synchronize(); pr.disable()

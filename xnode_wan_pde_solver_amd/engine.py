@@ -568,7 +568,9 @@ class Engine:
                                   verify=False)
             if out is not G:
                 raise XnwanError('refill_compact: the sample does not have the shapes of the group it refills')
-        self._run(G, 'refill_%r_%s_%r' % (t0, type(domain).__name__, float(domain.V())), body)
+        # (what the captured body bakes in besides the buffers: the grid's first time, the domain's class and extent)
+        self._run(G, 'refill_%r_%s_%r_%r_%r' % (t0, type(domain).__name__, float(domain.V()), getattr(domain, 'top', None),
+                                                getattr(domain, 'bot', None)), body)
         # (host-side bookkeeping of load_group: done at capture time only, so it is set here on every path)
         G.domain, G.sample_version = domain, ver + 1
         return G

@@ -348,13 +348,19 @@ class NODE_WAN_solver:
             from concurrent.futures import ThreadPoolExecutor
             pool = ThreadPoolExecutor(max_workers=1, initializer=torch.set_num_threads, initargs=(torch.get_num_threads(),))
 
+        self._sampler_seconds = 0.0       # time the helper thread spent drawing (tools/train_cfg5.py: what bounds the ball domains)
+
         def draw_ahead(domain, last):
+            t_ = time.perf_counter()
             pin = lambda ld: ld.pin() if hasattr(ld, 'pin') else ld     # noqa: E731  (page-locked: asynchronous uploads)
             after = pin(self._loader(domain))
             if last:
+                self._sampler_seconds += time.perf_counter() - t_
                 return after, None, None
             nxt = self._new_domain()
-            return after, nxt, pin(self._loader(nxt))
+            out = after, nxt, pin(self._loader(nxt))
+            self._sampler_seconds += time.perf_counter() - t_
+            return out
 
         try:
             if self.pipeline and self.stop is None and not report and hasattr(self._new_domain_probe(), 'interior_x'):
@@ -536,13 +542,15 @@ class NODE_WAN_solver:
     def _iterate(self, report, report_it, show_plt, past_losses, times, pool, draw_ahead):
         d = self.setup['dim']
         eng = self.engine
-        nxt_domain = nxt_points = None
+        nxt_domain = nxt_points = ahead = None
+        last = self.iterations - 1
         with torch.cuda.device(self.device):
             for k in range(self.iterations):
                 domain = nxt_domain if nxt_domain is not None else self._new_domain()
                 points = nxt_points if nxt_points is not None else self._loader(domain)
                 nxt_domain = nxt_points = None
-                ahead = pool.submit(draw_ahead, domain, k == self.iterations - 1) if pool is not None else None
+                if ahead is None and pool is not None:     # (later ones are submitted the moment the previous result is taken: the
+                    ahead = pool.submit(draw_ahead, domain, k == last)   # draws of a ball-domain sample take as long as its sub-steps)
                 # (the reference also evaluates L_norm here, src/training.py:123, and overwrites the value unread at :167;
                 #  the call draws no random numbers and writes nothing, so it is not repeated)
                 comp = points.compact() if hasattr(points, 'compact') else None
@@ -599,6 +607,7 @@ class NODE_WAN_solver:
                     self.last_loss_v = eng.loss_v().item()
                 if ahead is not None:
                     points, nxt_domain, nxt_points = ahead.result()
+                    ahead = pool.submit(draw_ahead, nxt_domain, k + 1 == last) if k < last else None
                 else:
                     points = self._loader(domain)
                 L2 = (self._l_norm_replayed(groups[0], points, domain).item() if (self.capture_refill and not several)
