@@ -283,7 +283,7 @@ class Engine:
     # ------------------------------------------------------------------------------------------------------------
     # per-sample preparation (once per outer iteration; everything here is parameter-independent)
     # ------------------------------------------------------------------------------------------------------------
-    def tabulate_sample(self, triples, domain):
+    def tabulate_sample(self, triples, domain, hints=None):
         """List domains (src/dataset.py:48-229: 11-20 groups per sample): evaluate the user's callables h, f, g and the
         domain's weight w (with their input gradients) ONCE on the points of ALL groups instead of group by group, and
         hand every group its slices (load_group(tab=...)).  The callables are PDE data -- functions of the point (t, x) --
@@ -296,7 +296,10 @@ class Engine:
         Xs = [t_[0].detach() for t_ in triples]
         XVs = [t_[1].detach() for t_ in triples]
         BXs = [t_[2].detach() for t_ in triples]
-        first_t = torch.stack([x[0, 0, 0] for x in Xs] + [b[0, 0, 0] for b in BXs]).tolist()       # ONE host sync for all start times
+        if hints is not None and all(h is not None for h in hints):      # (the loader read them off its host copies: no read-back)
+            first_t = [h['t0'] for h in hints] + [h['tb0'] for h in hints]
+        else:
+            first_t = torch.stack([x[0, 0, 0] for x in Xs] + [b[0, 0, 0] for b in BXs]).tolist()   # ONE host sync for all start times
         at0 = [float(v) == T0 for v in first_t[:len(Xs)]]
         bat0 = [float(v) == T0 for v in first_t[len(Xs):]]
         pts = lambda ts: torch.cat([t_.reshape(-1, 1, d + 1) for t_ in ts], 0)                      # noqa: E731  [P, 1, d+1]
@@ -358,13 +361,17 @@ class Engine:
                 return [None] * len(triples)
         return tabs
 
-    def load_group(self, X, XV, BX, domain, n_glob=None, nb_glob=None, into=None, shared_grid_t0=None, tab=None, verify=True):
+    def load_group(self, X, XV, BX, domain, n_glob=None, nb_glob=None, into=None, shared_grid_t0=None, tab=None, verify=True,
+                   hints=None):
         """Prepare one group.  The user's callables (h, f, g, func_w, a, b) are evaluated on the device the given
         tensors live on and only their results are uploaded: pass the loader's host tensors to tabulate exactly like
         the reference's CPU path, or device tensors to tabulate on the GPU (float32 transcendental functions then
         differ from the host's in the last bit).  `into`: a Group of the same shapes to refill in place.
         `shared_grid_t0`: the caller built X, XV and BX from ONE time grid whose first time is this value (compact cube
-        samples): the checks that would otherwise read the device tensors back (four host syncs) are skipped."""
+        samples): the checks that would otherwise read the device tensors back (four host syncs) are skipped.
+        `hints` (list domains, sampling.Comb_loader.pack): the same facts per group, read off the loader's HOST copies --
+        `shared_times` (all paths of the group share one time column), `same_grid` (the boundary group sits on the
+        interior group's grid)."""
         dev, d = self.dev, self.d
         X, XV = X.detach(), XV.detach()
         BX = BX.detach() if BX is not None else None
@@ -379,7 +386,7 @@ class Engine:
         # the test network is pointwise on XV: when the paths of a group do not share one time column (late-entry groups
         # of the hourglass: every path has its own entry time at l = 0) it runs in point mode on all L*N points
         S['tpp'] = S['tpp0'] = S['xvT_pts'] = None
-        if shared_grid_t0 is None and not bool(torch.all(XV[:, :, 0] == XV[:1, :, 0])):
+        if shared_grid_t0 is None and not (hints['shared_times'] if hints is not None else bool(torch.all(XV[:, :, 0] == XV[:1, :, 0]))):
             S['tpp'] = _d64(XV[:, :, 0], dev).t().contiguous().reshape(-1)              # time-major: p = l*N + n
             S['tpp0'] = _d64(XV[:, 0, 0], dev).contiguous()
             S['xvT_pts'] = S['xvT'].unsqueeze(1).expand(d, L, N).reshape(d, L * N).contiguous()
@@ -426,7 +433,7 @@ class Engine:
         if BX is not None:
             Lb = BX.shape[1]
             S['tb'] = _d64(BX[0, :, 0], dev).contiguous()
-            same_grid = Lb == L and (shared_grid_t0 is not None or bool(torch.equal(S['tb'], S['t'])))
+            same_grid = Lb == L and (shared_grid_t0 is not None or (hints['same_grid'] if hints is not None else bool(torch.equal(S['tb'], S['t']))))
             S['xbT'] = _d64(BX[:, 0, 1:], dev).t().contiguous()
             if tab is not None:
                 b_T0 = bool(tab['b_T0'])

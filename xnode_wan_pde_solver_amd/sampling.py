@@ -75,6 +75,37 @@ class _PinPool:
 _PIN_POOL = _PinPool()
 
 
+class _ArenaPool:
+    """page-locked float64 arenas for the samples of the LIST domains (11-20 groups of new shapes every sample: a ring per
+    shape would never hit).  A sample's groups are packed into one arena (Comb_loader.pin, on the sampling thread) and travel
+    in ONE asynchronous copy instead of ~40 blocking copies out of pageable memory, each of which made the host wait for
+    everything queued on the device.  Same protocol as _PinPool: the consumer records an event behind its copy (`uploaded`),
+    `take` waits for it before the arena is packed again."""
+    RING = 6
+
+    def __init__(self):
+        self.bufs, self.events, self.pos = [None] * self.RING, [None] * self.RING, 0
+
+    def take(self, numel):
+        i = self.pos % self.RING
+        self.pos += 1
+        ev, self.events[i] = self.events[i], None
+        if ev is not None:
+            ev.synchronize()
+        if self.bufs[i] is None or self.bufs[i].numel() < numel:
+            with HIP_HOST_LOCK:
+                self.bufs[i] = torch.empty(max(numel * 5 // 4, 1 << 16), dtype=torch.float64).pin_memory()
+        return i, self.bufs[i]
+
+    def uploaded(self, i, stream):
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        self.events[i] = ev
+
+
+_ARENAS = _ArenaPool()
+
+
 class _UniformFill:
     """Tensor.uniform_(lo, hi) on torch's default CPU generator for float32 tensors, through the native fill of the C library
     (xw_mt19937_uniform_f32: the generator's state blob is advanced in vectorised loops, 8 x faster than torch's scalar walk --
@@ -491,11 +522,77 @@ class Comb_loader(Dataset):
 
     def pin(self):
         """page-lock the compact sample (same values): its upload can then be asynchronous.  A copy from pageable memory makes
-        the host wait for everything already queued on the device -- in the training loop that is a whole outer iteration."""
+        the host wait for everything already queued on the device -- in the training loop that is a whole outer iteration.
+        List domains: the groups are packed into one page-locked arena (pack)."""
         if self._lazy is not None and torch.cuda.is_available():
             self._lazy = {k: _PIN_POOL.stage(v) for k, v in self._lazy.items()}
             self._times_pinned = _PIN_POOL.stage(self.shape.times)
+        elif self._lazy is None and torch.cuda.is_available() and isinstance(self._cache.get('interioru'), list):
+            self.pack(pinned=True)
         return self
+
+    def pack(self, pinned=False):
+        """List domains: all interior groups (u; the v sample is a copy of it) and boundary groups of the sample in ONE flat
+        float64 buffer, with what the engine otherwise reads back from the device group by group, taken from the host copies
+        here: the first time of every group, whether its paths share one time column, whether a boundary group sits on its
+        interior group's grid.  Returns (buffer, layout) and keeps them; `device_groups` uploads the buffer in one copy."""
+        if getattr(self, '_packed', None) is not None:
+            return self._packed
+        gu, gb = self._cache['interioru'], self._cache['boundary']
+        n = min(len(gu), len(gb))                             # (iteration stops at the shorter list: __getitem__)
+        tensors = [g.detach() for g in gu] + [g.detach() for g in gb]
+        if any(t.dtype != torch.float64 for t in tensors):
+            self._packed = False
+            return False
+        total = sum(t.numel() for t in tensors)
+        slot, buf = _ARENAS.take(total) if pinned else (None, torch.empty(total, dtype=torch.float64))
+        offs, o = [], 0
+        for t in tensors:
+            buf[o:o + t.numel()].view(t.shape).copy_(t)
+            offs.append((o, tuple(t.shape)))
+            o += t.numel()
+        hints = []
+        for k in range(len(gu)):
+            x = tensors[k]
+            h = dict(t0=float(x[0, 0, 0]), shared_times=bool(torch.all(x[:, :, 0] == x[:1, :, 0])))
+            if k < n:
+                b = tensors[len(gu) + k]
+                h.update(tb0=float(b[0, 0, 0]), same_grid=b.shape[1] == x.shape[1] and bool(torch.equal(b[0, :, 0], x[0, :, 0])))
+            hints.append(h)
+        self._packed = (slot, buf, total, offs, hints, n, len(gu))
+        return self._packed
+
+    def _device_views(self, device):
+        if self._lazy is not None or not isinstance(self._cache.get('interioru'), list):
+            return None
+        packed = self.pack()
+        if not packed:
+            return None
+        if getattr(self, '_views', None) is None:
+            slot, buf, total, offs = packed[:4]
+            dev = buf[:total].to(device, non_blocking=True)
+            if slot is not None:
+                _ARENAS.uploaded(slot, torch.cuda.current_stream(device))
+            self._views = [dev[o:o + math.prod(shape)].view(shape) for o, shape in offs]
+        return self._views
+
+    def device_groups(self, device):
+        """[(X, XV, BX)] on the device -- views of one uploaded buffer (XV is X: the v sample of a list domain is a copy of the u
+        sample) -- and the per-group hints of pack(); None when the sample is not a packable list sample"""
+        views = self._device_views(device)
+        if views is None:
+            return None
+        hints, n, nu = self._packed[4:]
+        return [(views[k], views[k], views[nu + k]) for k in range(n)], hints[:n]
+
+    def device_interior(self, device):
+        """ALL interior groups on the device (the diagnostic integrates over every one of them, also where the boundary list
+        is shorter) with their hints; None as above"""
+        views = self._device_views(device)
+        if views is None:
+            return None
+        hints, n, nu = self._packed[4:]
+        return views[:nu], hints
 
     def __len__(self):
         return len(self.interioru) if isinstance(self.interioru, list) else 1

@@ -221,8 +221,13 @@ class NODE_WAN_solver:
         tensors, so that h, f, g, w are tabulated exactly like the reference's CPU path; False (default) builds the path tensors
         on the GPU from the compact sample and tabulates there."""
         self._grid_hint = None
+        self._group_hints = None          # list domains: per group, what the engine would otherwise read back from the device
         self._rank_local = isinstance(points, sampling.RankCubeLoader)
         if not self.tabulate_on_host or self.device_sampling:
+            packed = points.device_groups(self.device) if hasattr(points, 'device_groups') else None
+            if packed is not None:        # a list sample: ONE upload, the groups are views of it
+                groups, self._group_hints = packed
+                return groups
             comp = points.compact() if hasattr(points, 'compact') else None
             if comp is not None:
                 times, xu, xv, xb = comp
@@ -314,6 +319,9 @@ class NODE_WAN_solver:
                 u_fn = lambda x: self.u_net(x, starts_at_T0=at_T0)   # noqa: E731
                 return L_norm(X, u_fn, self.p, self.func_u_sol, volume, self.setup['N_r'])
             groups = points.interioru
+            lean = self._l_norm_groups(points, volume) if (isinstance(groups, list) and groups and self.world is None) else None
+            if lean is not None:
+                return lean
             if isinstance(groups, list) and groups and not groups[0].is_cuda:
                 # list domain: the groups go to the device, func_u_sol is evaluated ONCE on all their points, u_theta group by
                 # group with the start kind read from the host copy (no read-back between the launches)
@@ -324,6 +332,46 @@ class NODE_WAN_solver:
                 sols = iter([s_.view(x.shape[0], x.shape[1]) for s_, x in zip(sol.split([x.shape[0] * x.shape[1] for x in Xs]), Xs)])
                 return L_norm(Xs, lambda x: self.u_net(x, starts_at_T0=next(at0)), self.p, lambda x: next(sols), volume, self.setup['N_r'])
         return L_norm(points.interioru, self.u_net, self.p, self.func_u_sol, volume, self.setup['N_r'])
+
+    def _l_norm_groups(self, points, volume):
+        """L_norm over the groups of a list-domain sample with the per-group overheads taken out -- the sample arrives in one
+        upload (Comb_loader.device_groups), the exact solution and the start values h / g are evaluated ONCE on all groups'
+        points (the callables are functions of the point: the engine checks that on its first sample, Engine._batch_tab), and
+        u_theta is the stepper's forward kernel called directly per group (no module call, autograd Function or operator
+        dispatch: 20 groups x 0.3 ms were 5 of an hourglass iteration's 29 ms).  utils.L_norm itself -- the reference's
+        arithmetic, including its [N, N] table on a single-slice group -- is called as it is.  None: not applicable."""
+        from utils.auxillary_funcs import L_norm
+        from . import kernels as KN
+        eng, net = self.engine, self.u_net.module
+        packed = points.device_interior(self.device) if hasattr(points, 'device_interior') else None
+        if packed is None or getattr(eng, '_batch_tab', True) is False or getattr(eng, '_batch_tab_checked', False) is False:
+            return None
+        Xs, hints = packed
+        d1, T0 = self.setup['dim'] + 1, self.setup['T0']
+        at0 = [h['t0'] == T0 for h in hints]
+        with torch.no_grad():
+            sol = self.func_u_sol(torch.cat([x.reshape(-1, 1, d1) for x in Xs], 0)).reshape(-1)
+            sols = iter([s_.view(x.shape[0], x.shape[1]) for s_, x in zip(sol.split([x.shape[0] * x.shape[1] for x in Xs]), Xs)])
+            # start values: h on the first points of the groups that start at T0, g on those that start on the moving boundary
+            P0 = torch.cat([x[:, 0, :] for x in Xs], 0)
+            n = [x.shape[0] for x in Xs]
+            sel = torch.cat([torch.full((k,), a, dtype=torch.bool) for k, a in zip(n, at0)]).to(P0.device)
+            i_h, i_g = torch.nonzero(sel).reshape(-1), torch.nonzero(~sel).reshape(-1)
+            start = torch.zeros(P0.shape[0], dtype=torch.float64, device=P0.device)
+            if i_h.numel():
+                start = start.index_copy(0, i_h, self.func_h(P0.index_select(0, i_h)).reshape(-1).double())
+            if i_g.numel():
+                start = start.index_copy(0, i_g, self.func_g(P0.index_select(0, i_g).unsqueeze(1)).reshape(-1).double())
+            starts = iter(zip(start.split(n), at0))
+            net.blob.check_alias()
+
+            def u_fn(x):
+                s_k, a_k = next(starts)
+                u, _ = KN.ode_fwd(x[:, 0, 1:].t().contiguous(), x[0, :, 0].contiguous(), s_k.contiguous(), net.blob.data, net.method,
+                                  net.kdims[0], net.kdims[1], net.num_layers, want_Y=False)
+                out = u.t().unsqueeze(2).contiguous()               # [N, L, 1] like xnwan::xnode_forward
+                return out[:, 0, :] if (x.shape[1] == 1 and a_k) else out   # (src/model.py:89-91: [N, 1] on a single slice at T0)
+            return L_norm(Xs, u_fn, self.p, lambda x: next(sols), volume, self.setup['N_r'])
 
     def train(self, report=False, report_it=10, show_plt=False):
         threads = torch.get_num_threads()
@@ -566,10 +614,12 @@ class NODE_WAN_solver:
                 # list domains: the callables are evaluated once for all groups of the sample; the structure guard runs on the
                 # largest group of the sample (all groups are slices of the same draw)
                 if shards is not None:
-                    tabs = eng.tabulate_sample([sh[:3] for sh in shards], domain) if len(shards) > 1 else [None]
+                    hints = self._group_hints if (self._group_hints is not None and self.world is None) else [None] * len(shards)
+                    tabs = eng.tabulate_sample([sh[:3] for sh in shards], domain, hints=hints) if len(shards) > 1 else [None]
                     big = max(range(len(shards)), key=lambda i: shards[i][0].shape[0] * shards[i][0].shape[1])
-                    groups = [eng.load_group(du, dv, bd, domain, ng, nbg, into=old, shared_grid_t0=self._grid_hint, tab=tb, verify=(i == big))
-                              for i, ((du, dv, bd, ng, nbg), old, tb) in enumerate(zip(shards, self._group_cache, tabs))]
+                    groups = [eng.load_group(du, dv, bd, domain, ng, nbg, into=old, shared_grid_t0=self._grid_hint, tab=tb, verify=(i == big),
+                                             hints=hn)
+                              for i, ((du, dv, bd, ng, nbg), old, tb, hn) in enumerate(zip(shards, self._group_cache, tabs, hints))]
                 self._group_cache = groups
                 several = len(groups) > 1
                 for G in groups:
