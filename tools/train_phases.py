@@ -19,6 +19,14 @@ if 'sync' in sys.argv:          # the synchronous loop (what a stop callback or 
         torch.cuda.synchronize(); t0 = time.perf_counter(); S.train(); torch.cuda.synchronize(); dt = time.perf_counter() - t0
         print('synchronous loop, capture_refill=%-5s: %.3f ms per outer iteration' % (cap, 1e3 * dt / n))
     sys.exit(0)
+if 'calls' in sys.argv:         # bench.py's pattern: train() in 25-iteration calls (the fixed cost of a call)
+    S.iterations = 25
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(8):
+        S.train()
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    print('train() in calls of 25 outer iterations: %.3f ms per outer iteration' % (1e3 * dt / 200))
+    sys.exit(0)
 for rep in range(2):
     torch.cuda.synchronize(); t0 = time.perf_counter(); S.train(); torch.cuda.synchronize(); dt = time.perf_counter() - t0
     print('%.3f ms per outer iteration; host ms per phase: %s' % (1e3 * dt / n, '  '.join('%s %.3f' % (k, 1e3 * v / n) for k, v in S._phase_seconds.items())))

@@ -432,20 +432,25 @@ class NODE_WAN_solver:
     def _iterate_pipelined(self, past_losses, times, pool, draw_ahead):
         d, dev, eng = self.setup['dim'], self.device, self.engine
         R, n1, n2 = 4, self.n1, self.n2
-        ring = torch.zeros(R, n1 + 2, dtype=torch.float64, device=dev)          # loss_u x n1, loss_v, L2
-        snaps = torch.zeros(R, n1, eng.Pu, dtype=torch.float64, device=dev)     # theta after every generator sub-iteration
-        with HIP_HOST_LOCK:
-            host = torch.zeros(R, n1 + 2, dtype=torch.float64).pin_memory()
-            snaps_host = torch.zeros(R, n1, eng.Pu, dtype=torch.float64).pin_memory()   # (rides along with the ring row: 26 KB)
+        # (ring, page-locked mirrors, events and the read-back stream live as long as the solver: allocating them -- two
+        #  hipHostMalloc among them -- was 11 ms of every train() call, 0.45 ms per outer iteration of bench.py's 25-iteration calls)
+        keep = getattr(self, '_pipe_buffers', None)
+        if keep is None or keep[0] != (R, n1, eng.Pu, dev):
+            ring = torch.zeros(R, n1 + 2, dtype=torch.float64, device=dev)          # loss_u x n1, loss_v, L2
+            snaps = torch.zeros(R, n1, eng.Pu, dtype=torch.float64, device=dev)     # theta after every generator sub-iteration
+            with HIP_HOST_LOCK:
+                host = torch.zeros(R, n1 + 2, dtype=torch.float64).pin_memory()
+                snaps_host = torch.zeros(R, n1, eng.Pu, dtype=torch.float64).pin_memory()   # (rides along with the ring row: 26 KB)
+            keep = self._pipe_buffers = ((R, n1, eng.Pu, dev), ring, snaps, host, snaps_host,
+                                         [torch.cuda.Event() for _ in range(R)], [torch.cuda.Event() for _ in range(R)],
+                                         torch.cuda.Stream(device=dev))
+        _, ring, snaps, host, snaps_host, done, filled, rb = keep
         # The files of an iteration (loss list, L2, times, best weights) are written by ONE worker thread, in order (a later write
         # of a file overwrites an earlier one exactly as in the synchronous loop); the main thread only hands it the finished text /
         # state dict -- torch.save and four open() calls were 1 ms of its 3 ms per iteration
         from concurrent.futures import ThreadPoolExecutor
         saver = ThreadPoolExecutor(max_workers=1) if self._is_main() else None
         pending = []
-        done = [torch.cuda.Event() for _ in range(R)]
-        filled = [torch.cuda.Event() for _ in range(R)]
-        rb = torch.cuda.Stream(device=dev)
         keys = self._state_dict_layout()
 
         def process(k):
