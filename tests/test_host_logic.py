@@ -362,3 +362,32 @@ def test_boundary_face_table_is_shared_by_domain_objects_of_one_shape():
     c = sampling.Hypercube([-1, 2], 6, 0, 1, 5)._faces(100)
     e = sampling.Hypercube([-1, 1], 6, 0, 1, 5)._faces(101)
     assert c is not a and e is not a and float(c[2][0]) == 2.0 and e[0].shape[0] == 101
+
+
+@pytest.mark.parametrize('name', ['NSphere_TCone', 'NSphere_THourglass'])
+def test_packed_list_sample_is_the_sample_and_its_hints_are_what_the_engine_would_read_back(name):
+    """Comb_loader.pack (list domains): the groups as views of ONE flat buffer are the groups, bit for bit; the hints are the
+    facts Engine.tabulate_sample / load_group otherwise read back from the device group by group (first times, one shared
+    time column, boundary group on the interior group's grid); the triples stop at the shorter list like iteration does,
+    the interior views cover every interior group (the diagnostic integrates over all of them)."""
+    from xnode_wan_pde_solver_amd import sampling
+    torch.manual_seed(3)
+    np.random.seed(3)
+    dom = sampling.resolve_domain(name)(0.7, 3, 0.0, 1.0, 8)
+    ld = sampling.Comb_loader(300, 150, dom, 'cpu')
+    gu, gb = ld.interioru, ld.boundary
+    n = min(len(gu), len(gb))
+    triples, hints = ld.device_groups('cpu')
+    assert len(triples) == n == len(hints) == len(list(ld))          # (iterating the loader stops at the shorter list)
+    for k, ((x, xv, bx), h) in enumerate(zip(triples, hints)):
+        assert torch.equal(x, gu[k].detach()) and xv is x and torch.equal(x, ld.interiorv[k].detach())
+        assert torch.equal(bx, gb[k].detach())
+        assert h['t0'] == float(gu[k].detach()[0, 0, 0]) and h['tb0'] == float(gb[k].detach()[0, 0, 0])
+        assert h['shared_times'] == bool(torch.all(gu[k][:, :, 0] == gu[k][:1, :, 0]))
+        assert h['same_grid'] == (gb[k].shape[1] == gu[k].shape[1] and bool(torch.equal(gb[k][0, :, 0].double(), gu[k][0, :, 0].double())))
+    views, hall = ld.device_interior('cpu')
+    assert len(views) == len(gu) == len(hall) and all(torch.equal(a, b.detach()) for a, b in zip(views, gu))
+    if name == 'NSphere_THourglass':       # late-entry groups: every path has its own entry time
+        assert any(not h['shared_times'] for h in hall)
+    cube = sampling.Comb_loader(16, 16, sampling.Hypercube((-1.0, 1.0), 3, 0.0, 1.0, 4), 'cpu')
+    assert cube.device_groups('cpu') is None and cube.device_interior('cpu') is None
