@@ -155,6 +155,11 @@ class _UniformFill:
             self.mode = False
         finally:
             torch.set_rng_state(keep)
+        if self.mode is False:
+            import warnings
+            # (not silent: the draws of an outer iteration then take 8 x longer and bound train() again -- same numbers either way)
+            warnings.warn("the native uniform fill does not reproduce this torch build's CPU generator stream (torch %s): the samplers draw "
+                          'through torch.Tensor.uniform_ (same numbers, ~8 x slower draws)' % torch.__version__, RuntimeWarning)
 
     def __call__(self, t, lo, hi):
         if self.mode is None:
