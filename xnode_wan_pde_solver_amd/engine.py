@@ -43,6 +43,32 @@ _KEPT_GRAPHS = []
 
 _NOSTREAM = contextlib.nullcontext()      # Engine._side without side streams
 
+# One private memory pool for the captured graphs that ALLOCATE while they are recorded (the training loop's refill of its
+# group, its diagnostic: path tensors and the temporaries of the user's callables, ~100 MB at the headline size).  Their
+# results are copied into buffers of the group inside the graph, nothing in the pool is read after a replay has ended, and
+# replays are issued on one stream: the graphs of every group and solver of the process can reuse the same memory -- kept
+# graphs (above) then cost their nodes, not a pool each.
+_SCRATCH_POOL = []
+
+
+# The side streams and the capture stream are per DEVICE, shared by every engine of the process (engines are driven from one
+# host thread and never run concurrently): the allocator only reuses a block on the stream it was allocated on, so with
+# streams per engine the scratch pool above grew by what one refill allocates (54 MB at the headline size) per solver.
+_DEVICE_STREAMS = {}
+
+
+def _device_streams(device):
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    if key not in _DEVICE_STREAMS:
+        _DEVICE_STREAMS[key] = ([torch.cuda.Stream(device=device) for _ in range(4)], torch.cuda.Stream(device=device))
+    return _DEVICE_STREAMS[key]
+
+
+def _scratch_pool():
+    if not _SCRATCH_POOL:
+        _SCRATCH_POOL.append(torch.cuda.graph_pool_handle())
+    return _SCRATCH_POOL[0]
+
 F32, F64 = torch.float32, torch.float64
 
 
@@ -190,7 +216,7 @@ class Engine:
         self.narrow_tiles = {'f': 192, 'x': 128, 'p': 64}    # largest launch (16-path tiles, all its jobs) that still gains
         self.simds = 4 * cus
         self._phi_version = 0
-        self.streams = [torch.cuda.Stream(device=device) for _ in range(4)]
+        self.streams, self._cap = _device_streams(device)
         # several GPUs on RCCL: the exchanges are device-side calls on the current stream (dist.World.capturable), so a
         # sub-step and its exchange(s) are captured into ONE HIP graph instead of graph / host call / graph
         self.capture_exchange = (world is not None and getattr(world, 'capturable', False)
@@ -577,7 +603,7 @@ class Engine:
                 raise XnwanError('refill_compact: the sample does not have the shapes of the group it refills')
         # (what the captured body bakes in besides the buffers: the grid's first time, the domain's class and extent)
         self._run(G, 'refill_%r_%s_%r_%r_%r' % (t0, type(domain).__name__, float(domain.V()), getattr(domain, 'top', None),
-                                                getattr(domain, 'bot', None)), body)
+                                                getattr(domain, 'bot', None)), body, scratch=True)
         # (host-side bookkeeping of load_group: done at capture time only, so it is set here on every path)
         G.domain, G.sample_version = domain, ver + 1
         return G
@@ -1051,8 +1077,9 @@ class Engine:
         self._run(G, 'disc_back', self._disc_back)
 
     # ------------------------------------------------------------------------------------------------------------
-    def _run(self, G, key, fn):
-        """execute fn(G) eagerly, or capture it once into a HIP graph (per group and segment) and replay it"""
+    def _run(self, G, key, fn, scratch=False):
+        """execute fn(G) eagerly, or capture it once into a HIP graph (per group and segment) and replay it.
+        scratch: fn allocates while it runs and leaves nothing behind in what it allocated (_SCRATCH_POOL)"""
         # (a pairwise group carries per-sample host constants -- the variance offsets -- into its launches: never captured)
         capturable = (self.use_graphs and self.accum_u is None and self.accum_v is None and getattr(G, 'persistent', True)
                       and not (G.pair_i or G.pair_b))
@@ -1084,7 +1111,8 @@ class Engine:
             try:
                 # thread_local: other threads (the RCCL watchdog polls events) must not invalidate the capture
                 # (HIP_HOST_LOCK: no page-locked allocation of the sampling helper thread during a capture or a launch)
-                with HIP_HOST_LOCK, torch.cuda.graph(g, stream=self._capture_stream(), capture_error_mode='thread_local'):
+                with HIP_HOST_LOCK, torch.cuda.graph(g, pool=_scratch_pool() if scratch else None, stream=self._capture_stream(),
+                                                     capture_error_mode='thread_local'):
                     fn(G)
             except Exception as exc:
                 # Capture refused (typically a user callable that syncs with the host or builds CPU tensors): THIS segment
@@ -1116,8 +1144,6 @@ class Engine:
             g.replay()
 
     def _capture_stream(self):
-        if not hasattr(self, '_cap'):
-            self._cap = torch.cuda.Stream(device=self.dev)
         return self._cap
 
     def loss_u(self):

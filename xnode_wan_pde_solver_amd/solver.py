@@ -296,7 +296,7 @@ class NODE_WAN_solver:
             X = sampling._paths(st[0], st[1])
             val = L_norm(X, lambda x: self.u_net(x, starts_at_T0=at_T0), p, self.func_u_sol, volume, n_r)
             st[2].copy_(val.to(torch.float64).reshape(()))
-        eng._run(G, 'diag_%r_%r_%r' % (at_T0, float(volume), p), body)
+        eng._run(G, 'diag_%r_%r_%r' % (at_T0, float(volume), p), body, scratch=True)
         return st[2]
 
     def _l_norm_value(self, points, volume):
