@@ -74,6 +74,56 @@ def test_two_ranks_on_one_gpu_match_single_process(tmp_path):
     assert torch.equal(ranks[0]['theta'], ranks[1]['theta'])      # replicas stay bit-identical without broadcasts
 
 
+def _train_run(world, out_path, workdir):
+    """train() itself (the pipelined loop: the group refilled by graph replay from this rank's slice of the shared-seed sample)"""
+    import configs.Ex4_1_funcs as P
+    from src.training import NODE_WAN_solver
+    os.makedirs(workdir, exist_ok=True)
+    cwd = os.getcwd()
+    os.chdir(workdir)
+    try:
+        torch.manual_seed(11)
+        S = NODE_WAN_solver(dict(PARAMS, iterations=6), P.func_a, P.func_b, P.func_c, P.func_h, P.func_f, P.func_g, torch.device('cuda', 0),
+                            './', func_u_sol=P.func_u_sol, p=2, world=world)
+        losses = list(S.train())
+        torch.cuda.synchronize()
+        G = S._group_cache[0]
+        torch.save({'theta': S.engine.theta.data.cpu(), 'phi': S.engine.phi.data.cpu(), 'losses': losses, 'N': G.N,
+                    'refill_graphs': [k for k, v in G.graphs.items() if k.startswith('refill') and v is not False],
+                    'L2': json.load(open('L2_NODE_%d.json' % PARAMS['dim'])) if (world is None or world.rank == 0) else None}, out_path)
+    finally:
+        os.chdir(cwd)
+
+
+def _train_worker(rank, size, port, out_dir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(size), LOCAL_RANK='0')
+    from xnode_wan_pde_solver_amd import dist as xdist
+    world, _ = xdist.init_from_env('gloo')
+    torch.cuda.set_device(0)
+    _train_run(world, os.path.join(out_dir, 'train%d.pt' % rank), os.path.join(out_dir, 'wd%d' % rank))
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_two_ranks_train_like_one_process(tmp_path):
+    """six outer iterations of train() on two ranks (shared seed: every rank draws the global sample and keeps its slice; the
+    group is refilled by ONE graph replay from that slice, Engine.refill_compact) against the single-process run: the loss list,
+    the parameters and the diagnostic"""
+    size = 2
+    mp.spawn(_train_worker, args=(size, _free_port(), str(tmp_path)), nprocs=size, join=True)
+    _train_run(None, str(tmp_path / 'train_single.pt'), str(tmp_path / 'wd_single'))
+    one = torch.load(tmp_path / 'train_single.pt')
+    ranks = [torch.load(tmp_path / ('train%d.pt' % r)) for r in range(size)]
+    assert sum(r['N'] for r in ranks) == one['N'] == PARAMS['N_r'] and len(one['losses']) == 12
+    for r in ranks:
+        assert len(r['refill_graphs']) == 1                # the refill was captured on every rank
+        np.testing.assert_allclose(r['losses'], one['losses'], rtol=1e-7)
+        np.testing.assert_allclose(r['theta'].numpy(), one['theta'].numpy(), rtol=1e-6, atol=1e-9)
+        np.testing.assert_allclose(r['phi'].numpy(), one['phi'].numpy(), rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(ranks[0]['L2'], one['L2'], rtol=1e-7)
+    assert torch.equal(ranks[0]['theta'], ranks[1]['theta'])
+
+
 def _native_worker(rank, size, port, out_dir):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(size), LOCAL_RANK=str(rank),
                       HSA_ENABLE_IPC_MODE_LEGACY='0')

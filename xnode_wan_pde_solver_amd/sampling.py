@@ -47,11 +47,11 @@ class _PinPool:
         if ring is None:
             with HIP_HOST_LOCK:
                 ring = self.bufs[key] = [torch.empty(t.shape, dtype=t.dtype).pin_memory() for _ in range(self.RING)]
-                self.mine.update(b.data_ptr() for b in ring)
+                self.mine.update(b.untyped_storage().data_ptr() for b in ring)
         i = self.pos.get(key, 0)
         self.pos[key] = i + 1
         buf = ring[i % self.RING]
-        ev = self.events.pop(buf.data_ptr(), None)
+        ev = self.events.pop(buf.untyped_storage().data_ptr(), None)
         if ev is not None:
             ev.synchronize()            # (the upload that last read this slot; long done unless the pipeline got deeper)
         buf.copy_(t)
@@ -64,7 +64,8 @@ class _PinPool:
     def uploaded_all(self, bufs, stream=None):
         """the same for several buffers whose copies were issued on ONE stream: one event behind the last of them guards every
         slot (an event per buffer was 6 x 40 us of an outer iteration: torch looks the current device up for each record)"""
-        ptrs = [b.data_ptr() for b in bufs if b.data_ptr() in self.mine]
+        # (by storage: a rank's share of a staged sample is a slice of the slot)
+        ptrs = [b.untyped_storage().data_ptr() for b in bufs if not b.is_cuda and b.untyped_storage().data_ptr() in self.mine]
         if ptrs:
             ev = torch.cuda.Event()
             ev.record(stream) if stream is not None else ev.record()

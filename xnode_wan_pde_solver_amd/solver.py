@@ -276,8 +276,9 @@ class NODE_WAN_solver:
         solution, u_theta (the stepper's forward kernel) and the mean are replayed.  Anything else takes the ordinary way."""
         comp = points.compact() if hasattr(points, 'compact') else None
         eng = self.engine
-        if (comp is None or comp[0].is_cuda or self.func_u_sol is None or self.world is not None or not eng.use_graphs
-                or self.tabulate_on_host):
+        if (comp is None or comp[0].is_cuda or self.func_u_sol is None or isinstance(points, sampling.RankCubeLoader)
+                or not eng.use_graphs or self.tabulate_on_host):
+            # (several GPUs with the shared seed: every rank evaluates the diagnostic on the global sample, like _l_norm_value)
             return self._l_norm(points, domain.V(), as_tensor=True)
         from utils.auxillary_funcs import L_norm
         times, xu = comp[0], comp[1]
@@ -490,9 +491,19 @@ class NODE_WAN_solver:
         group = self._group_cache[0] if len(self._group_cache) == 1 else None
 
         def compact_of(pts):
+            """(compact sample of THIS rank, global path counts) when the group can be refilled by graph replay, else None"""
             comp = pts.compact() if hasattr(pts, 'compact') else None
-            return comp if (comp is not None and self.capture_refill and self.world is None and eng.use_graphs
-                            and not comp[0].is_cuda and not self.tabulate_on_host) else None
+            if comp is None or not self.capture_refill or not eng.use_graphs or comp[0].is_cuda or self.tabulate_on_host:
+                return None
+            if self.world is None:
+                return comp, None, None
+            if isinstance(pts, sampling.RankCubeLoader):            # the loader already drew this rank's share only
+                return comp, self.setup['N_r'], self.setup['N_b']
+            times, xu, xv, xb = comp                                  # every rank drew the global sample: its contiguous slice
+            (lo, hi), (blo, bhi) = self.world.bounds(xu.shape[0]), self.world.bounds(xb.shape[0])
+            if hi - lo == 0 or bhi - blo == 0:
+                return None
+            return (times, xu[lo:hi], xv[lo:hi], xb[blo:bhi]), xu.shape[0], xb.shape[0]
 
         # (host seconds per phase of the loop body, summed over the run: tools/train_phases.py prints them)
         phase = self._phase_seconds = dict.fromkeys(('fill', 'substeps', 'sampler_wait', 'diagnostic', 'ring', 'process'), 0.0)
@@ -519,7 +530,7 @@ class NODE_WAN_solver:
                 comp = compact_of(points)
                 if old is not None and comp is not None:
                     # every iteration after the first: the sample into static buffers, ONE graph replay fills the group
-                    G = eng.refill_compact(old, comp, domain)
+                    G = eng.refill_compact(old, comp[0], domain, comp[1], comp[2])
                 else:
                     (du, dv, bd, ng, nbg), = self._shard(self._groups(points))
                     G = eng.load_group(du, dv, bd, domain, ng, nbg, into=old, shared_grid_t0=self._grid_hint)
