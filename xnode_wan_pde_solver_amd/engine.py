@@ -205,8 +205,10 @@ class Engine:
         self.narrow = os.environ.get('XW_NARROW', '1')
         # wave-priority drops of the stepper launches that are not on a sub-step's critical path (include/xnwan.h: xw_ode_bwd mode
         # bits 5..6, XwOdeFwdJob.prio_drop): A = the generator's sweeps A + boundary, X = the discriminator's x-only sweep,
-        # F = the discriminator's forward pass
-        self.prio_drop = {k: int(os.environ.get('XW_PRIO_DROP_' + k, dflt)) for k, dflt in (('A', 2), ('X', 0), ('F', 0), ('G', 0))}
+        # F = the discriminator's forward pass, G = the generator's.  A = 3 puts sweeps A + boundary at the test network's own
+        # priority (0): 0.4764 against 0.4838 ms per sub-step at 2 (tools/cap_sweep.sh, three alternating runs each; found at the end
+        # of round 4: the first sweep stopped at 2); G = 1..2 and X, F = 1 are within the noise of that, G = 3 loses 7 %.
+        self.prio_drop = {k: int(os.environ.get('XW_PRIO_DROP_' + k, dflt)) for k, dflt in (('A', 3), ('X', 0), ('F', 0), ('G', 0))}
         self.use_runner = os.environ.get('XW_RUNNER', '1') == '1'      # one C call per eager group sub-step (xw_substep_*)
         # Measured (profiles/r04_shard_sweep.md): forward and the sweep without weight gradients gain on shards up to ~2048
         # paths (0.302 -> 0.272 ms per sub-step at 512 paths, 0.332 -> 0.294 at 1024, 0.375 -> 0.367 at 2048); the narrow sweep
