@@ -544,8 +544,13 @@ if __name__ == '__main__':
     ap.add_argument('--round4', action='store_true', help='only the fixture added in round 4: one outer iteration of the reference at the '
                     'BENCHMARKED size (BASELINE configs[1]: d = 20, N_r = N_b = 4096, N_t = 32), slim record (~4 min, 1 GB)')
     ap.add_argument('--traj-hourglass', action='store_true', help='only the hourglass trajectory fixture (round 3, second ball domain)')
+    ap.add_argument('--traj-headline', action='store_true', help='round 4: 60 outer iterations of the reference\'s own train() at the '
+                    'BENCHMARKED size (d = 20, N_r = N_b = 4096, N_t = 32), rel-L2 at every generator sub-step (~10 min, 1 GB)')
     args = ap.parse_args()
     torch.set_num_threads(4)
+    if args.traj_headline:
+        trajectory('ref_traj_d20_headline_seed4', 20, 4096, 4096, 32, 4, 60, True)
+        sys.exit(0)
     if args.traj_d20:
         # trained-error parity at the headline dimension (BASELINE configs[1] family: d = 20; N small enough for the reference)
         trajectory('ref_traj_d20_seed2_gpusem', 20, 128, 96, 12, 2, 150, True)
