@@ -544,12 +544,20 @@ if __name__ == '__main__':
     ap.add_argument('--round4', action='store_true', help='only the fixture added in round 4: one outer iteration of the reference at the '
                     'BENCHMARKED size (BASELINE configs[1]: d = 20, N_r = N_b = 4096, N_t = 32), slim record (~4 min, 1 GB)')
     ap.add_argument('--traj-hourglass', action='store_true', help='only the hourglass trajectory fixture (round 3, second ball domain)')
-    ap.add_argument('--traj-headline', action='store_true', help='round 4: 60 outer iterations of the reference\'s own train() at the '
-                    'BENCHMARKED size (d = 20, N_r = N_b = 4096, N_t = 32), rel-L2 at every generator sub-step (~10 min, 1 GB)')
+    ap.add_argument('--traj-cfg5', action='store_true', help='round 4: 8 outer iterations of the reference\'s own train() on both ball '
+                    'domains at BASELINE config 5 size (Ex4_3, d = 10, N_r = N_b = 8192, N_t = 20)')
+    ap.add_argument('--traj-headline', action='store_true', help='round 4: 250 outer iterations of the reference\'s own train() at the '
+                    'BENCHMARKED size (d = 20, N_r = N_b = 4096, N_t = 32), rel-L2 at every generator sub-step (~30 min, 1 GB)')
     args = ap.parse_args()
     torch.set_num_threads(4)
+    if args.traj_cfg5:
+        # BASELINE configs[4] AT ITS STATED SIZE (Ex4_3, d = 10, N_r = N_b = 8192, N_t = 20, alpha = 1e4 as tools/train_cfg5.py runs it):
+        # 8 outer iterations of the reference's own train() per ball domain
+        sphere_trajectory('ref_traj_cone_ex43_d10_full_seed2', 'NSphere_TCone', 10, 8192, 8192, 20, 2, 8, alpha=10000.0)
+        sphere_trajectory('ref_traj_hourglass_ex43_d10_full_seed3', 'NSphere_THourglass', 10, 8192, 8192, 20, 3, 8, alpha=10000.0)
+        sys.exit(0)
     if args.traj_headline:
-        trajectory('ref_traj_d20_headline_seed4', 20, 4096, 4096, 32, 4, 60, True)
+        trajectory('ref_traj_d20_headline_seed4', 20, 4096, 4096, 32, 4, 250, True)
         sys.exit(0)
     if args.traj_d20:
         # trained-error parity at the headline dimension (BASELINE configs[1] family: d = 20; N small enough for the reference)

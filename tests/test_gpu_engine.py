@@ -262,11 +262,12 @@ def test_engine_against_oracle_general_coefficients(m, q, adjoint):
 @pytest.mark.parametrize('case,steps,windows,reached', [
     ('ref_traj_plumb_seed0_gpusem', 800, ((100, 200), (400, 600), (600, 800)), 0.01),
     ('ref_traj_d20_seed2_gpusem', 300, ((100, 200), (200, 300)), 0.02),
-    ('ref_traj_d20_headline_seed4', 120, ((40, 80), (80, 120)), 0.04)])
+    ('ref_traj_d20_headline_seed4', 500, ((300, 400), (400, 500)), 0.015)])
 def test_trained_error_trajectory_matches_reference(golden_dir, tmp_path, case, steps, windows, reached):
     """BASELINE config 1 (d=5, N_r=256, N_b=64, N_t=16; seed 0, 400 outer iterations = 800 generator sub-steps), the
     headline dimension (d=20, N_r=128, N_b=96, N_t=12; seed 2, 150 outer iterations) and -- round 4 -- BASELINE configs[1] AT THE
-    BENCHMARKED SIZE (d=20, N_r=N_b=4096, N_t=32; seed 4, 60 outer iterations of the reference's own train(): rel-L2 0.78 -> 0.031)
+    BENCHMARKED SIZE (d=20, N_r=N_b=4096, N_t=32; seed 4, 250 outer iterations of the reference's own train(), 25 min of its CPU time:
+    rel-L2 0.78 -> 0.0069, under its own acceptance rule of 0.01)
     through train(): rel-L2 logged by the `stop` hook at every sub-step, compared with the reference's own runs (fixtures)."""
     from utils.auxillary_funcs import rel_err
     z, params = load(golden_dir, case)
@@ -292,12 +293,17 @@ def test_trained_error_trajectory_matches_reference(golden_dir, tmp_path, case, 
     # same seeds, same arithmetic: the runs track each other closely before chaotic decorrelation sets in
     np.testing.assert_allclose(got[:50], ref[:50], rtol=2e-3)
     if case == 'ref_traj_d20_headline_seed4':
-        # 4096 paths per sample: the two runs stay together over all 60 outer iterations (measured: 2e-6 at worst)
-        np.testing.assert_allclose(got, ref, rtol=1e-4)
+        # 4096 paths per sample: the two runs stay together for the first 60 outer iterations (measured: 2e-6 at worst over the
+        # first 120 logged values, 1e-5 at 140, 8e-4 at 160, then the usual exponential decorrelation of two adversarial runs: a
+        # loss spike falls on step 287 here and on step ~360 there); after 250 outer iterations 0.0101 against the reference's 0.0069
+        np.testing.assert_allclose(got[:120], ref[:120], rtol=1e-4)
     # north-star criterion: trained relative-L2 error within 1e-2 absolute of the reference's, on windowed statistics
     for lo, hi in windows:
         assert abs(np.median(got[lo:hi]) - np.median(ref[lo:hi])) < 1e-2, (lo, hi, np.median(got[lo:hi]), np.median(ref[lo:hi]))
-    assert abs(got[-1] - ref[-1]) < 1e-2
+    # (the long run at the benchmarked size: its last VALUE can sit on one of the loss spikes of adversarial training -- the
+    #  reference's own run has one at step ~360 --, so the end of the run is compared on the median of its last 20 values)
+    tail = 20 if case == 'ref_traj_d20_headline_seed4' else 1
+    assert abs(np.median(got[-tail:]) - np.median(ref[-tail:])) < 1e-2
     assert got[windows[-1][0]:].min() < reached and ref[windows[-1][0]:].min() < reached
     d = params['dim']
     for fn in ('losses_NODE_%d.json' % d, 'L2_NODE_%d.json' % d, 'Time_NODE_%d.json' % d, 'best_model_weights_NODE.pth'):
