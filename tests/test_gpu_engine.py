@@ -380,10 +380,13 @@ def test_sphere_domain_groups_against_reference_vectors(golden_dir, case, name):
     assert step == int(z['n_steps'])
 
 
-@pytest.mark.parametrize('case,steps', [('ref_traj_cone_ex43_d3_seed0', 200), ('ref_traj_hourglass_ex43_d3_seed1', 120)])
+@pytest.mark.parametrize('case,steps', [('ref_traj_cone_ex43_d3_seed0', 200), ('ref_traj_hourglass_ex43_d3_seed1', 120),
+                                        ('ref_traj_cone_ex43_d10_full_seed2', 16), ('ref_traj_hourglass_ex43_d10_full_seed3', 16)])
 def test_ball_domain_training_trajectory_follows_reference(golden_dir, tmp_path, case, steps):
     """BASELINE configs[4] family, through train(): NSphere_TCone (seed 0, 100 outer iterations) and NSphere_THourglass (seed 1,
-    60), Ex4_3, d = 3, N_r = 256, N_b = 128, N_t = 10: the natural group loop (single-slice T0 groups with the reference's pairwise terms, Adam
+    60), Ex4_3, d = 3, N_r = 256, N_b = 128, N_t = 10 -- and, round 4, both domains AT THE CONFIG'S STATED SIZE (d = 10,
+    N_r = N_b = 8192, N_t = 20, alpha = 1e4; 8 outer iterations of the reference's own train(), 2 min of its CPU time each:
+    11-12 and 18-20 groups per sample, single-slice groups of ~3600 paths with their [N, N] pairwise terms): the natural group loop (single-slice T0 groups with the reference's pairwise terms, Adam
     skipping the field's parameters there).  The `stop` hook evaluates u_theta on the fixture's fixed multi-slice probe
     group (the reference's own L_norm is all-pairs on list domains).  The REFERENCE DOES NOT CONVERGE on the ball domains
     (as run on this software stack its probe error grows from 1.4 to > 100, for alpha = 1e2 .. 1e8, both domains, Ex4_1
@@ -419,7 +422,8 @@ def test_ball_domain_training_trajectory_follows_reference(golden_dir, tmp_path,
     # same seeds): holds at EVERY logged sub-iteration, not only at the end.
     np.testing.assert_allclose(got, ref, rtol=1e-6)
     assert np.abs(got - ref).max() < 1e-2
-    assert got[20:].min() > 1.0 and ref[20:].min() > 1.0          # (the run the reference produces here does not converge)
+    late = min(20, steps // 2)
+    assert got[late:].min() > 1.0 and ref[late:].min() > 1.0      # (the run the reference produces here does not converge)
 
 
 def test_pipelined_loop_flushes_its_last_iteration_when_interrupted(golden_dir, tmp_path):
