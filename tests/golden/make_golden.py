@@ -119,16 +119,26 @@ def npy(t):
     return t.detach().cpu().numpy().copy()
 
 
-def one_iteration(case, d, N_r, N_b, N_t, seed, solver_name, full_tensors, shape_param=None, slim=0):
+def one_iteration(case, d, N_r, N_b, N_t, seed, solver_name, full_tensors, shape_param=None, slim=0, general=False, alpha=None):
     """slim = s > 0 (round 4, the headline size N_r = 4096): per-path arrays keep every s-th path (`[::s]`; the dense
     float32 `dphi` every 4s-th), the whole samples are pinned by their SHA-1 instead; scalars, gradients and parameters
     are kept in full.  The consumer slices its own arrays the same way (`slim_stride` in the file)."""
     import hashlib
     training, dataset, lossmod, F = load_reference()
+    if general:
+        # round 4: the reference's own classes with GENERAL coefficient callables (tests/golden/general_funcs.py) in place of
+        # Ex4_1's identity a, zero b, c = -u: pins src/training.py:32-41 (the a[d,d,N,L] / b[d,N,L] tables) and src/loss.py:66-69
+        import types
+        sys.path.insert(0, HERE)
+        import general_funcs as GF
+        F = types.SimpleNamespace(func_a=GF.func_a, func_b=GF.func_b, func_c=GF.func_c, func_h=F.func_h, func_f=F.func_f,
+                                  func_g=F.func_g, func_u_sol=F.func_u_sol)
     sl = (lambda a: a[::slim].copy()) if slim else (lambda a: a)
     sl4 = (lambda a: a[::4 * slim].copy()) if slim else (lambda a: a)
     sha = lambda a: np.array(hashlib.sha1(np.ascontiguousarray(a).tobytes()).hexdigest())  # noqa: E731
-    params = make_params(d, N_r, N_b, N_t, solver_name)
+    params = make_params(d, N_r, N_b, N_t, solver_name) if alpha is None else make_params(d, N_r, N_b, N_t, solver_name, alpha=alpha)
+    if general:
+        params['funcs'] = 'general_v1'
     if shape_param is not None:
         # d = 100: with the YAML's integer [-1, 1] the reference's own diagnostic raises OverflowError (V() is the Python
         # int 2**100, utils/auxillary_funcs.py:15 multiplies a tensor by it); float bounds are what lets it run at all
@@ -544,12 +554,16 @@ if __name__ == '__main__':
     ap.add_argument('--round4', action='store_true', help='only the fixture added in round 4: one outer iteration of the reference at the '
                     'BENCHMARKED size (BASELINE configs[1]: d = 20, N_r = N_b = 4096, N_t = 32), slim record (~4 min, 1 GB)')
     ap.add_argument('--traj-hourglass', action='store_true', help='only the hourglass trajectory fixture (round 3, second ball domain)')
+    ap.add_argument('--general', action='store_true', help='round 4: one outer iteration of the reference with general a_ij, b_i, c(u,t,x)')
     ap.add_argument('--traj-cfg5', action='store_true', help='round 4: 8 outer iterations of the reference\'s own train() on both ball '
                     'domains at BASELINE config 5 size (Ex4_3, d = 10, N_r = N_b = 8192, N_t = 20)')
     ap.add_argument('--traj-headline', action='store_true', help='round 4: 250 outer iterations of the reference\'s own train() at the '
                     'BENCHMARKED size (d = 20, N_r = N_b = 4096, N_t = 32), rel-L2 at every generator sub-step (~30 min, 1 GB)')
     args = ap.parse_args()
     torch.set_num_threads(4)
+    if args.general:
+        one_iteration('ref_general_d4_midpoint', 4, 83, 45, 9, 5, 'midpoint', True, general=True, alpha=1000.0)
+        sys.exit(0)
     if args.traj_cfg5:
         # BASELINE configs[4] AT ITS STATED SIZE (Ex4_3, d = 10, N_r = N_b = 8192, N_t = 20, alpha = 1e4 as tools/train_cfg5.py runs it):
         # 8 outer iterations of the reference's own train() per ball domain

@@ -25,8 +25,9 @@ import configs.Ex4_1_funcs as P  # noqa: E402
 CASES = ['ref_tiny_midpoint', 'ref_tiny_euler', 'ref_tiny_rk4', 'ref_plumb_midpoint', 'ref_d20_small_midpoint',
          'ref_d50_nt64_small_midpoint',       # BASELINE configs[2] family (d = 50, N_t = 64)
          'ref_d100_small_midpoint',           # BASELINE configs[3] family (d = 100, N_t = 32)
-         'ref_d20_headline']                  # BASELINE configs[1] AT THE BENCHMARKED SIZE (N_r = N_b = 4096, N_t = 32; slim
+         'ref_d20_headline',                  # BASELINE configs[1] AT THE BENCHMARKED SIZE (N_r = N_b = 4096, N_t = 32; slim
                                               # record of the reference's own run: graphs, side streams, ticket queues on)
+         'ref_general_d4_midpoint']           # the reference run with GENERAL a_ij, b_i, c(u, t, x) (tests/golden/general_funcs.py)
 FUNCS = dict(h=P.func_h, f=P.func_f, g=P.func_g, a=P.func_a, b=P.func_b, c=P.func_c)
 
 
@@ -82,7 +83,17 @@ def first_sample(S):
 def test_first_iteration_against_reference_vectors(golden_dir, case):
     from utils.auxillary_funcs import L_norm, rel_err
     z, params = load(golden_dir, case)
-    S = make_solver(params, int(z['seed']))
+    general = params.pop('funcs', None) == 'general_v1'
+    F = P
+    if general:       # the callables the fixture was recorded with (the reference's own classes ran them)
+        import importlib.util
+        import types
+        spec = importlib.util.spec_from_file_location('general_funcs', os.path.join(golden_dir, 'general_funcs.py'))
+        GF = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(GF)
+        F = types.SimpleNamespace(func_a=GF.func_a, func_b=GF.func_b, func_c=GF.func_c, func_h=P.func_h, func_f=P.func_f, func_g=P.func_g,
+                                  func_u_sol=P.func_u_sol)
+    S = make_solver(params, int(z['seed']), F=F)
     for tag, net in (('u', S.u_net), ('v', S.v_net)):
         sd = net.state_dict()
         assert list(sd.keys()) == [str(k) for k in z[tag + '_sd_keys']]
@@ -95,7 +106,10 @@ def test_first_iteration_against_reference_vectors(golden_dir, case):
     close(L_norm(pts.interioru, S.u_net, 2, P.func_u_sol, domain.V(), S.setup['N_r']), float(z['L2_start']), F32TOL)
     close(rel_err(pts.interioru, S.u_net, P.func_u_sol, 2, domain.V(), S.setup['N_r']), float(z['rel_start']), F32TOL)
     eng = S.engine
-    assert eng.structure.a_identity and eng.structure.b_zero and eng.structure.c_kappa == -1.0
+    if general:       # every fused fast path is off: tabulated a_ij, b_i at t_0, c(u, t, x) through autograd, all inside the graphs
+        assert not eng.structure.a_identity and not eng.structure.b_zero and eng.structure.c_kappa is None
+    else:
+        assert eng.structure.a_identity and eng.structure.b_zero and eng.structure.c_kappa == -1.0
     G = eng.load_group(pts.interioru, pts.interiorv, pts.boundary, domain)   # host tensors: tabulated like the reference
     unames = [n for n, _ in S.u_net.named_parameters()]
     vnames = [n for n, _ in S.v_net.named_parameters()]
