@@ -132,7 +132,10 @@ V_NAME_MAP = [('module.input.weight', 'Vin'), ('module.input.bias', 'Vin_b'),
 
 def u_names(m):
     last = 2 * m  # index of the output Linear inside _ODEField.net (src/model.py:131-135)
-    return [(a % last if '%d' in a else a, b) for a, b in U_NAME_MAP]
+    names = [(a % last if '%d' in a else a, b) for a, b in U_NAME_MAP]
+    # u_layers = 1: no tied hidden Linear exists (src/model.py:127-130, `additional_layers = ... if num_layers > 1 else []`) and
+    # net.2 IS the output layer; the oracle's Wh / Wh_b stay zero and have no counterpart in the reference's state_dict
+    return [nb for nb in names if not (m == 1 and nb[1] in ('Wh', 'Wh_b'))]
 
 
 # --------------------------------------------------------------------------------------

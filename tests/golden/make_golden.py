@@ -119,7 +119,8 @@ def npy(t):
     return t.detach().cpu().numpy().copy()
 
 
-def one_iteration(case, d, N_r, N_b, N_t, seed, solver_name, full_tensors, shape_param=None, slim=0, general=False, alpha=None):
+def one_iteration(case, d, N_r, N_b, N_t, seed, solver_name, full_tensors, shape_param=None, slim=0, general=False, alpha=None,
+                  net=None):
     """slim = s > 0 (round 4, the headline size N_r = 4096): per-path arrays keep every s-th path (`[::s]`; the dense
     float32 `dphi` every 4s-th), the whole samples are pinned by their SHA-1 instead; scalars, gradients and parameters
     are kept in full.  The consumer slices its own arrays the same way (`slim_stride` in the file)."""
@@ -139,6 +140,8 @@ def one_iteration(case, d, N_r, N_b, N_t, seed, solver_name, full_tensors, shape
     params = make_params(d, N_r, N_b, N_t, solver_name) if alpha is None else make_params(d, N_r, N_b, N_t, solver_name, alpha=alpha)
     if general:
         params['funcs'] = 'general_v1'
+    if net is not None:           # network shapes other than the YAML's (src/model.py:30-43,62-85,130-138 accept any)
+        params.update(net)
     if shape_param is not None:
         # d = 100: with the YAML's integer [-1, 1] the reference's own diagnostic raises OverflowError (V() is the Python
         # int 2**100, utils/auxillary_funcs.py:15 multiplies a tensor by it); float bounds are what lets it run at all
@@ -554,6 +557,7 @@ if __name__ == '__main__':
     ap.add_argument('--round4', action='store_true', help='only the fixture added in round 4: one outer iteration of the reference at the '
                     'BENCHMARKED size (BASELINE configs[1]: d = 20, N_r = N_b = 4096, N_t = 32), slim record (~4 min, 1 GB)')
     ap.add_argument('--traj-hourglass', action='store_true', help='only the hourglass trajectory fixture (round 3, second ball domain)')
+    ap.add_argument('--shapes', action='store_true', help='round 4: one outer iteration of the reference at three other network shapes')
     ap.add_argument('--general', action='store_true', help='round 4: one outer iteration of the reference with general a_ij, b_i, c(u,t,x)')
     ap.add_argument('--traj-cfg5', action='store_true', help='round 4: 8 outer iterations of the reference\'s own train() on both ball '
                     'domains at BASELINE config 5 size (Ex4_3, d = 10, N_r = N_b = 8192, N_t = 20)')
@@ -563,6 +567,16 @@ if __name__ == '__main__':
     torch.set_num_threads(4)
     if args.general:
         one_iteration('ref_general_d4_midpoint', 4, 83, 45, 9, 5, 'midpoint', True, general=True, alpha=1000.0)
+        sys.exit(0)
+    if args.shapes:
+        # the widest / deepest networks the engine compiles (stepper container (32, 12), depth 10; test network width 64), a
+        # narrow odd-sized pair that runs zero-padded inside the (20, 10) / 50 containers, and a field without hidden layer
+        one_iteration('ref_wide_d6_midpoint', 6, 70, 40, 7, 8, 'midpoint', True,
+                      net=dict(u_hidden_dim=32, u_hidden_hidden_dim=12, u_layers=10, v_hidden_dim=64, v_layers=4))
+        one_iteration('ref_narrow_d3_euler', 3, 50, 30, 6, 9, 'euler', True,
+                      net=dict(u_hidden_dim=7, u_hidden_hidden_dim=3, u_layers=2, v_hidden_dim=11, v_layers=2))
+        one_iteration('ref_m1_d4_rk4', 4, 40, 24, 5, 10, 'rk4', True,
+                      net=dict(u_hidden_dim=16, u_hidden_hidden_dim=8, u_layers=1, v_hidden_dim=57, v_layers=12))
         sys.exit(0)
     if args.traj_cfg5:
         # BASELINE configs[4] AT ITS STATED SIZE (Ex4_3, d = 10, N_r = N_b = 8192, N_t = 20, alpha = 1e4 as tools/train_cfg5.py runs it):

@@ -27,7 +27,11 @@ CASES = ['ref_tiny_midpoint', 'ref_tiny_euler', 'ref_tiny_rk4', 'ref_plumb_midpo
          'ref_d100_small_midpoint',           # BASELINE configs[3] family (d = 100, N_t = 32)
          'ref_d20_headline',                  # BASELINE configs[1] AT THE BENCHMARKED SIZE (N_r = N_b = 4096, N_t = 32; slim
                                               # record of the reference's own run: graphs, side streams, ticket queues on)
-         'ref_general_d4_midpoint']           # the reference run with GENERAL a_ij, b_i, c(u, t, x) (tests/golden/general_funcs.py)
+         'ref_general_d4_midpoint',           # the reference run with GENERAL a_ij, b_i, c(u, t, x) (tests/golden/general_funcs.py)
+         # other network shapes, run by the reference itself (round 4): the widest / deepest the engine compiles -- (32, 12) field of
+         # depth 10, test network 64 wide --, an odd narrow pair (7, 3) / 11 zero-padded inside the (20, 10) / 50 containers (euler),
+         # and a field without hidden layer (u_layers = 1) with a 57-wide, 12-deep test network (rk4)
+         'ref_wide_d6_midpoint', 'ref_narrow_d3_euler', 'ref_m1_d4_rk4']
 FUNCS = dict(h=P.func_h, f=P.func_f, g=P.func_g, a=P.func_a, b=P.func_b, c=P.func_c)
 
 
