@@ -208,6 +208,7 @@ class Engine:
         # F = the discriminator's forward pass, G = the generator's.  A = 3 puts sweeps A + boundary at the test network's own
         # priority (0): 0.4764 against 0.4838 ms per sub-step at 2 (tools/cap_sweep.sh, three alternating runs each; found at the end
         # of round 4: the first sweep stopped at 2); G = 1..2 and X, F = 1 are within the noise of that, G = 3 loses 7 %.
+        self.early_slab_sum = os.environ.get('XW_EARLY_SLAB_SUM', '1') == '1'
         self.prio_drop = {k: int(os.environ.get('XW_PRIO_DROP_' + k, dflt)) for k, dflt in (('A', 3), ('X', 0), ('F', 0), ('G', 0))}
         self.use_runner = os.environ.get('XW_RUNNER', '1') == '1'      # one C call per eager group sub-step (xw_substep_*)
         # Measured (profiles/r04_shard_sweep.md): forward and the sweep without weight gradients gain on shards up to ~2048
@@ -877,6 +878,15 @@ class Engine:
                 KN.ode_bwd_multi(sweep_b, G.tb, th, *M, want_x=False, want_params=True, adjoint=self.adjoint,
                                  narrow=self._narrow_ok(sweep_b, alone=False))
             e_A = self._mark()
+            # The slabs of sweeps A + boundary are summed HERE, beside the tail of sweep B, so that the update at the end of the sub-step
+            # only has sweep B's slabs left to read (k_slab_sum is the A half of k_adam's own summation tree: the same bits).
+            G.sumA_ready = self.early_slab_sum and self.world is None and self.accum_u is None and self.use_streams
+            e_S = None
+            if G.sumA_ready:
+                if getattr(G, 'sumA', None) is None:
+                    G.sumA = torch.empty(self.Pu, dtype=F64, device=self.dev)
+                KN.slab_sum(G.slabA, out=G.sumA)
+                e_S = self._mark()
         e_v = self._mark()
         self._join(e_f)
         # cotangent B = dI/du is a pointwise product of what the two forward passes wrote: sweep B forms it on the fly too
@@ -892,7 +902,7 @@ class Engine:
         with self._side(3, e_A, e_v, *[e for e in (e_x, e_b) if e is not None]):   # (re-entering side 1 here crashes hipStreamEndCapture)
             self._contract(G, self.adam_u)                       # -> scal[0..2], loss values
             e_C = self._mark()
-        self._join(e_C)
+        self._join(e_C, e_S)
 
     def begin_substep(self, which, accumulate):
         """start of a generator ('u') / discriminator ('v') sub-iteration over several groups: zero the carried gradient"""
@@ -919,7 +929,10 @@ class Engine:
                 KN.pair_fold(self.scal, G.Vol, G.Nglob)
             KN.losses(self.scal, G.L, G.Lb, G.Vol, G.Nglob, G.Nbglob, self.alpha, step=st['step'], init_off=G.init_off,
                       bdry_off=G.bdry_off)
-        if self.world is None:
+        if self.world is None and getattr(G, 'sumA_ready', False) and acc is None:
+            KN.adam(self.theta.data, None, st['m'], st['v'], st['step'], lr, gslabB=G.slabB, scal=self.scal,
+                    gextraA=G.sumA, gsum_out=self.grad_u, bump_step=-1, **lag)
+        elif self.world is None:
             KN.adam(self.theta.data, G.slabA, st['m'], st['v'], st['step'], lr, gslabB=G.slabB, scal=self.scal,
                     gextraA=acc, gsum_out=self.grad_u, bump_step=-1, **lag)
         else:
