@@ -208,8 +208,13 @@ class Engine:
         # F = the discriminator's forward pass, G = the generator's.  A = 3 puts sweeps A + boundary at the test network's own
         # priority (0): 0.4764 against 0.4838 ms per sub-step at 2 (tools/cap_sweep.sh, three alternating runs each; found at the end
         # of round 4: the first sweep stopped at 2); G = 1..2 and X, F = 1 are within the noise of that, G = 3 loses 7 %.
+        # At larger d the test network's launch is longer relative to the stepper's chains (its input layer and the fused
+        # nabla_x v grow with d, the stepper's x-projection is hoisted) and sweeps that never get ahead of it end AFTER sweep B:
+        # tools/ab_cfg_prio.sh, priority 1 against 0 -- d = 20: -1.4 % / -1.1 % at 4096 / 8192 paths, equal at 2048; d = 50: equal
+        # at 2048 x 64, +0.8 % at 16384 x 64; d = 100: +1.2 % at 8192, +1.3 % at 65536.  Default: 3 up to d = 32, 2 above.
         self.early_slab_sum = os.environ.get('XW_EARLY_SLAB_SUM', '1') == '1'
-        self.prio_drop = {k: int(os.environ.get('XW_PRIO_DROP_' + k, dflt)) for k, dflt in (('A', 3), ('X', 0), ('F', 0), ('G', 0))}
+        self.prio_drop = {k: int(os.environ.get('XW_PRIO_DROP_' + k, dflt))
+                          for k, dflt in (('A', 3 if self.d <= 32 else 2), ('X', 0), ('F', 0), ('G', 0))}
         self.use_runner = os.environ.get('XW_RUNNER', '1') == '1'      # one C call per eager group sub-step (xw_substep_*)
         # Measured (profiles/r04_shard_sweep.md): forward and the sweep without weight gradients gain on shards up to ~2048
         # paths (0.302 -> 0.272 ms per sub-step at 512 paths, 0.332 -> 0.294 at 1024, 0.375 -> 0.367 at 2048); the narrow sweep
