@@ -5,10 +5,12 @@ t(shipped) - t(variant) is an upper bound on what ANY rewrite of that kernel can
 elsewhere: "one sweep, two cotangents" (sweep A's chain carried by sweep B behind the test network) can gain at most what
 dropping sweep A's interior job gains, since the merged sweep costs at least what sweep B costs now.
 
-    python tools/what_if.py [variant ...]        variants: none sweepA sweepA+bdry sweepB fwd_gen xsweep fwd_disc rec testnet_gen"""
+    python tools/what_if.py [variant ...]        variants: none sweepA sweepA+bdry sweepB fwd_gen xsweep fwd_disc rec testnet_gen
+                                                           contract (k_weak_partials, all three sub-steps) cot_disc adam (all three) bdry"""
 import json, os, subprocess, sys
 HERE = os.path.dirname(os.path.abspath(__file__))
-VARIANTS = ['none', 'sweepA', 'sweepA+bdry', 'sweepB', 'fwd_gen', 'xsweep', 'fwd_disc', 'rec', 'testnet_gen', 'none']
+VARIANTS = ['none', 'sweepA', 'sweepA+bdry', 'sweepB', 'fwd_gen', 'xsweep', 'fwd_disc', 'rec', 'testnet_gen', 'contract', 'cot_disc', 'adam',
+            'bdry', 'none']
 
 if os.environ.get('XW_WHAT_IF') is None:
     rows = []
@@ -66,6 +68,9 @@ def disc_fwd(*a, **kw):
 
 
 KN.ode_bwd_multi, KN.ode_fwd_multi, KN.disc_bwd, KN.disc_fwd = ode_bwd_multi, ode_fwd_multi, disc_bwd, disc_fwd
+for name, key in (('weak_partials', 'contract'), ('disc_cotangent', 'cot_disc'), ('adam', 'adam'), ('bdry_partials', 'bdry')):
+    if what == key:
+        setattr(KN, name, lambda *a, **kw: None)
 import bench
 sys.argv = ['bench.py', '--no-cpu-baseline', '--train-iters', '0', '--no-solo', '--steps', '90', '--warmup', '12']
 bench.main()
