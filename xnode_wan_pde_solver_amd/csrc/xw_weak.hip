@@ -25,7 +25,7 @@ __device__ __forceinline__ double wave_sum(double x) { return xw_sum_over_g(xw_s
 // NV > 3: values 3, 4, ... go to dst[7], dst[8], ... (scal[3..6] are the boundary sum and the loss values)
 template <int NV>
 __device__ __forceinline__ bool grid_sum(double (&val)[NV], double* __restrict__ work, double* __restrict__ dst) {
-  __shared__ double red[NV][4];
+  __shared__ double red[NV][16];                        // (blocks of up to 16 waves)
   __shared__ int is_last;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
@@ -95,7 +95,7 @@ __device__ __forceinline__ void loss_values(double* scal, int L, int Lb, double 
   scal[5] = -in_;                                                                                          // src/loss.py:96
 }
 
-__global__ void __launch_bounds__(256) k_weak_partials(const double* __restrict__ u, const double* __restrict__ v,
+__global__ void __launch_bounds__(1024) k_weak_partials(const double* __restrict__ u, const double* __restrict__ v,
                                                        const double* __restrict__ vt, const double* __restrict__ w,
                                                        int w_per_point, const double* __restrict__ wt,
                                                        const double* __restrict__ s3x, const double* __restrict__ gx,
@@ -173,7 +173,7 @@ __global__ void __launch_bounds__(256) k_weak_partials(const double* __restrict_
   }
 }
 
-__global__ void __launch_bounds__(256) k_bdry(const double* __restrict__ ub, const double* __restrict__ gb, long P,
+__global__ void __launch_bounds__(1024) k_bdry(const double* __restrict__ ub, const double* __restrict__ gb, long P,
                                               double coef, double* __restrict__ ubar_b, double* __restrict__ work,
                                               double* __restrict__ scal) {
   double acc[1] = {0.0};
@@ -360,6 +360,20 @@ __global__ void __launch_bounds__(1024) k_slab_sum(const double* __restrict__ gs
   out[i] = g;
 }
 
+// Launch shape of the deterministic grid sums (k_weak_partials, k_bdry).  Every block ends with one atomic on ONE ticket word, and
+// the blocks of such a launch finish together: 512 blocks of 256 threads queued for ~6 us on that word (one word serves ~88
+// atomics per us) in a kernel that is on the critical path of every sub-step.  128 blocks of 1024 threads: 17.2 -> 11.3 us
+// for the 131,072 points of the headline group, 0.4794 -> 0.4717 ms per sub-step (tools/cap_sweep.sh; 256 x 512: 12.4 us, 64 x 1024: 12.5,
+// 32 x 1024: 15).  XW_REDUCE_BLOCKS / XW_REDUCE_THREADS override (measurements).
+inline int reduce_cap(long points) {
+  static const int v = [] { const char* e = getenv("XW_REDUCE_BLOCKS"); const int x = e ? atoi(e) : 0; return x > 0 && x <= 1024 ? x : 0; }();
+  // (a million points and more -- BASELINE configs[2], [3] whole on one GPU -- stream through 256 blocks faster: 62 against 85 us at 2 M)
+  return v ? v : (points > (1L << 18) ? 256 : 128);
+}
+inline int reduce_threads() {
+  static const int v = [] { const char* e = getenv("XW_REDUCE_THREADS"); const int x = e ? atoi(e) : 0; return (x == 256 || x == 512) ? x : 1024; }();
+  return v;
+}
 inline int blocks_for(long n, int per, int cap) {
   long b = (n + per - 1) / per;
   if (b < 1) b = 1;
@@ -414,7 +428,7 @@ extern "C" int xw_weak_partials(const double* u, const double* v, const double* 
   if (!u || !v || !vt || !w || !f || !h || !work || !scal || N <= 0 || L <= 0 || (finalize && Lb <= 0)) return XW_E_ARG;
   if (!s3x && (!gx || !gs || !ghT || !gxv || !w0 || !gwx0T || d <= 0)) return XW_E_ARG;
   if (pairwise && L != 1) return XW_E_ARG;
-  hipLaunchKernelGGL(k_weak_partials, dim3(blocks_for((long)N * L, 256, 1024)), dim3(256), 0, (hipStream_t)stream, u, v, vt, w,
+  hipLaunchKernelGGL(k_weak_partials, dim3(blocks_for((long)N * L, reduce_threads(), reduce_cap((long)N * L))), dim3(reduce_threads()), 0, (hipStream_t)stream, u, v, vt, w,
                      w_per_point, wt, s3x, gx, gs, ghT, gxv, w0, gwx0T, d, c, ckappa, f, h, href, pairwise, s3_scale, N, L, Vol,
                      Nglob, work, scal, finalize, Lb, Nbglob, alpha, init_off, bdry_off, step);
   return xw_launch_status();
@@ -425,7 +439,7 @@ extern "C" int xw_bdry_partials(const double* ub, const double* g, int Nb, int L
   if (!ub || !g || !work || !scal || Nb <= 0 || L <= 0) return XW_E_ARG;
   const long P = (long)Nb * L;
   const double coef = alpha * 2.0 / (Nbglob * (double)L);
-  hipLaunchKernelGGL(k_bdry, dim3(blocks_for(P, 256, 1024)), dim3(256), 0, (hipStream_t)stream, ub, g, P, coef, ubar_b, work, scal);
+  hipLaunchKernelGGL(k_bdry, dim3(blocks_for(P, reduce_threads(), reduce_cap(P))), dim3(reduce_threads()), 0, (hipStream_t)stream, ub, g, P, coef, ubar_b, work, scal);
   return xw_launch_status();
 }
 
