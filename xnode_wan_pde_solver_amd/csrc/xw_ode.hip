@@ -16,7 +16,7 @@
 #include "xw_common.h"
 #include "xnwan.h"
 
-// One object per stepper width (Makefile: -DXW_ODE_H=.. -DXW_ODE_K=..), every depth m = 1..8 in it; the public entry
+// One object per stepper width (Makefile: -DXW_ODE_H=.. -DXW_ODE_K=..), every depth m = 1..10 in it; the public entry
 // points live in xw_ode_abi.hip and pick the object by (H, K).  Narrower networks run zero-padded inside the next larger
 // width (exact: padding units stay identically zero, nets.Blob).
 #if !defined(XW_ODE_H) || !defined(XW_ODE_K)
