@@ -260,10 +260,10 @@ def one_iteration(case, d, N_r, N_b, N_t, seed, solver_name, full_tensors, shape
     print('wrote', path, '%.1f KB' % (os.path.getsize(path) / 1024))
 
 
-def trajectory(case, d, N_r, N_b, N_t, seed, outer_iters, gpu_loader_semantics):
+def trajectory(case, d, N_r, N_b, N_t, seed, outer_iters, gpu_loader_semantics, solver_name='midpoint'):
     """rel-L2 at every generator sub-step through the reference's own train() loop (stop hook = logging point)."""
     training, dataset, lossmod, F = load_reference()
-    params = make_params(d, N_r, N_b, N_t, 'midpoint', iterations=outer_iters)
+    params = make_params(d, N_r, N_b, N_t, solver_name, iterations=outer_iters)
     if gpu_loader_semantics:
         orig = dataset.Comb_loader.__getitem__
 
@@ -561,6 +561,8 @@ if __name__ == '__main__':
     ap.add_argument('--general', action='store_true', help='round 4: one outer iteration of the reference with general a_ij, b_i, c(u,t,x)')
     ap.add_argument('--traj-cfg5', action='store_true', help='round 4: 8 outer iterations of the reference\'s own train() on both ball '
                     'domains at BASELINE config 5 size (Ex4_3, d = 10, N_r = N_b = 8192, N_t = 20)')
+    ap.add_argument('--traj-headline-solvers', action='store_true', help='round 4: 30 outer iterations of the reference at the benchmarked '
+                    'size with solver euler and rk4 (~5 + ~12 min)')
     ap.add_argument('--traj-headline', action='store_true', help='round 4: 250 outer iterations of the reference\'s own train() at the '
                     'BENCHMARKED size (d = 20, N_r = N_b = 4096, N_t = 32), rel-L2 at every generator sub-step (~30 min, 1 GB)')
     args = ap.parse_args()
@@ -583,6 +585,11 @@ if __name__ == '__main__':
         # 8 outer iterations of the reference's own train() per ball domain
         sphere_trajectory('ref_traj_cone_ex43_d10_full_seed2', 'NSphere_TCone', 10, 8192, 8192, 20, 2, 8, alpha=10000.0)
         sphere_trajectory('ref_traj_hourglass_ex43_d10_full_seed3', 'NSphere_THourglass', 10, 8192, 8192, 20, 3, 8, alpha=10000.0)
+        sys.exit(0)
+    if args.traj_headline_solvers:
+        # the other two fixed-grid schemes at the benchmarked size: 30 outer iterations of the reference's own train() each
+        trajectory('ref_traj_d20_headline_euler_seed5', 20, 4096, 4096, 32, 5, 30, True, solver_name='euler')
+        trajectory('ref_traj_d20_headline_rk4_seed6', 20, 4096, 4096, 32, 6, 30, True, solver_name='rk4')
         sys.exit(0)
     if args.traj_headline:
         trajectory('ref_traj_d20_headline_seed4', 20, 4096, 4096, 32, 4, 250, True)
