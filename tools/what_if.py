@@ -72,5 +72,6 @@ for name, key in (('weak_partials', 'contract'), ('disc_cotangent', 'cot_disc'),
     if what == key:
         setattr(KN, name, lambda *a, **kw: None)
 import bench
-sys.argv = ['bench.py', '--no-cpu-baseline', '--train-iters', '0', '--no-solo', '--steps', '90', '--warmup', '12']
+sys.argv = ['bench.py', '--no-cpu-baseline', '--train-iters', '0', '--no-solo', '--steps', '90', '--warmup', '12'] + os.environ.get(
+    'XW_WHAT_IF_ARGS', '').split()          # (e.g. XW_WHAT_IF_ARGS="--global-paths 512": a strong-scaling shard)
 bench.main()
