@@ -175,13 +175,16 @@ int xw_disc_bwd(const double* xT, const double* t, const double* tpp, const doub
  *   Vol = domain volume; Nglob = global number of interior paths (the 1/N, 1/(N L) factors of src/loss.py:64-71)
  *   finalize != 0 (single-GPU path): the sums of this launch are the global ones, so the block that completes them also
  *   does what xw_losses does (loss values into scal[4..6] from scal[0..3], optimiser counter *step += 1 if step != NULL);
- *   Lb, Nbglob, alpha as in xw_losses.  With several GPUs call xw_losses after the all-reduce instead. */
+ *   Lb, Nbglob, alpha as in xw_losses.  With several GPUs call xw_losses after the all-reduce instead.
+ *   ub, gb [Pb] (or NULL, NULL, 0): the boundary forward u_b and the boundary data g at the Pb = N_b L_b boundary points -- the
+ *   launch then also adds sum (u_b - g)^2 to scal[3] (what xw_bdry_partials does in a launch of its own, src/loss.py:84). */
 int xw_weak_partials(const double* u, const double* v, const double* vt, const double* w, int w_per_point,
                      const double* wt, const double* s3x, const double* gx, const double* gs, const double* ghT,
                      const double* gxv, const double* w0, const double* gwx0T, int d, const double* c, double ckappa,
                      const double* f, const double* h, const double* href, int pairwise, double s3_scale, int N, int L,
                      double Vol, double Nglob, double* work, double* scal, int finalize, int Lb, double Nbglob, double alpha,
-                     double init_off, double bdry_off, long long* step, void* stream);
+                     double init_off, double bdry_off, long long* step, const double* ub, const double* gb, long Pb,
+                     void* stream);
 /* scal[0] -= (Vol / Nglob) scal[7] scal[8]; scal[7] = scal[8] = 0: the pairwise d(phi)/dt term of a single-slice T0 group,
  * once its two factors are global (several GPUs: after the all-reduce; one GPU: done by xw_weak_partials' finalisation) */
 int xw_pair_fold(double* scal, double Vol, double Nglob, void* stream);

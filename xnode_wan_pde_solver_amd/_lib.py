@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('XW_LIBRARY') or os.path.join(_HERE, 'libxnwan.so')   # (override: kernel experiments only)
-ABI_VERSION = 26
+ABI_VERSION = 27
 
 c_f32p = ctypes.c_void_p   # coordinates / time grid: const double* (device)   [name kept from the float32 era]
 c_f64p = ctypes.c_void_p   # double*       (device)
@@ -69,7 +69,7 @@ SIGNATURES = {
     'xw_mt19937_uniform_f32': [c_vp, ctypes.c_long, c_vp, ctypes.c_long, ctypes.c_float, ctypes.c_float, c_int],
     'xw_weak_partials': [c_f64p, c_f64p, c_f64p, c_f64p, c_int, c_f64p, c_f64p, c_f64p, c_f64p, c_f64p, c_f64p, c_f64p,
                          c_f64p, c_int, c_f64p, c_dbl, c_f64p, c_f64p, c_f64p, c_int, c_dbl, c_int, c_int, c_dbl, c_dbl, c_f64p, c_f64p,
-                         c_int, c_int, c_dbl, c_dbl, c_dbl, c_dbl, c_i64p, c_vp],
+                         c_int, c_int, c_dbl, c_dbl, c_dbl, c_dbl, c_i64p, c_f64p, c_f64p, ctypes.c_long, c_vp],
     'xw_pair_fold': [c_f64p, c_dbl, c_dbl, c_vp],
     'xw_cube_weight': [c_vp, c_int, c_int, c_dbl, c_dbl, c_f64p, c_f64p, c_f64p, c_f64p, c_vp],
     'xw_bdry_partials': [c_f64p, c_f64p, c_int, c_int, c_dbl, c_dbl, c_f64p, c_f64p, c_f64p, c_vp],

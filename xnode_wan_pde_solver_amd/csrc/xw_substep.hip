@@ -55,7 +55,7 @@ int test_net(const XwGroup* g, const XwSolverState* s, int blocks, double* recor
                      stream);
 }
 // I, sum v^2, SSE_init (+ loss values and the optimiser's counter: one process, the sums are global)
-int contract(const XwGroup* g, const XwSolverState* s, long long* step, void* stream) {
+int contract(const XwGroup* g, const XwSolverState* s, long long* step, bool with_bdry, void* stream) {
   const double* s3x = nullptr;
   if (g->A0 != nullptr || g->B0 != nullptr) {
     XW_TRY(xw_weak_contract_general(g->A0, g->amode, g->B0, g->gx, g->gs, g->ghT, g->gxv, g->w0, g->gwx0T, g->v, g->d, g->N, g->s3x,
@@ -67,7 +67,8 @@ int contract(const XwGroup* g, const XwSolverState* s, long long* step, void* st
                           fused ? g->ghT : nullptr, fused ? g->gxv : nullptr, fused ? g->w0 : nullptr, fused ? g->gwx0T : nullptr,
                           fused ? g->d : 0, g->c, g->ckappa, g->f, g->h, g->pair_i ? g->href : nullptr, g->pair_i ? 1 : 0,
                           g->pair_i ? g->s3_scale : 1.0, g->N, g->L, g->Vol, g->Nglob, g->work_i, s->scal, 1, g->Lb > 0 ? g->Lb : 1,
-                          g->Nbglob, s->alpha, g->init_off, g->bdry_off, step, stream);
+                          g->Nbglob, s->alpha, g->init_off, g->bdry_off, step, with_bdry && g->Nb > 0 ? g->ub : nullptr,
+                          with_bdry && g->Nb > 0 ? g->g : nullptr, with_bdry && g->Nb > 0 ? (long)g->Nb * g->Lb : 0, stream);
 }
 }  // namespace
 
@@ -95,7 +96,7 @@ extern "C" int xw_substep_gen(const XwGroup* g, const XwSolverState* s, int skip
     }
   }
   XW_HIP(hipEventRecord(sd->fwd, sd->s));
-  if (g->Nb > 0) XW_TRY(xw_bdry_partials(g->ub, g->g, g->Nb, g->Lb, s->alpha, g->Nbglob, nullptr, g->work_b, s->scal, stream));
+  // (the boundary sum of squares, a loss value only, is formed by the reduction at the end: contract(..., with_bdry))
   if (!fused_x) {     // the helper backward u.backward(ones) as a sweep of its own
     XwOdeBwdJob jx = bwd_job(g->xT, g->start, g->Y, g->act, g->N);
     jx.gx = g->gx; jx.gs = g->gs;
@@ -137,7 +138,7 @@ extern "C" int xw_substep_gen(const XwGroup* g, const XwSolverState* s, int skip
                             stream));
   }
   XW_HIP(hipStreamWaitEvent((hipStream_t)main_stream, sd->done, 0));
-  XW_TRY(contract(g, s, s->step_u, stream));
+  XW_TRY(contract(g, s, s->step_u, true, stream));
   XW_TRY(xw_adam(s->theta, g->slabA, g->ns_u + g->ns_b, accum, g->slabB, g->ns_u, nullptr, s->scal, s->m_u, s->v_u, s->step_u, -1, s->Pu,
                  s->lr_u, s->beta1, s->beta2, s->eps, s->grad_u, s->lag_lo, s->lag_hi, adam_skip_field, s->lag_u, stream));
   if (accum != nullptr) {
@@ -170,7 +171,7 @@ extern "C" int xw_substep_disc(const XwGroup* g, const XwSolverState* s, int ski
   XW_HIP(hipEventRecord(sd->done, sd->s));
   stream = main_stream;
   XW_HIP(hipStreamWaitEvent((hipStream_t)main_stream, sd->done, 0));
-  XW_TRY(contract(g, s, s->step_v, stream));
+  XW_TRY(contract(g, s, s->step_v, false, stream));
   XW_TRY(xw_disc_cotangent(g->u, g->v, g->w, g->w_per_point, g->c, g->ckappa, g->f, g->h, g->N, g->L, g->Vol, g->Nglob, s->pollution,
                            g->s3_scale, s->scal, g->vbar, stream));
   if (g->tpp != nullptr) {

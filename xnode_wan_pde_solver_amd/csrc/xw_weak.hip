@@ -22,7 +22,7 @@ __device__ __forceinline__ double wave_sum(double x) { return xw_sum_over_g(xw_s
 // (checkpoint/resume, test_test_net_reuse_is_exact).  work: NV * gridDim.x doubles + 1 ticket word (kept at zero
 // between launches: the last block resets it).  Hand-off follows cdna_hip_programming.md Guideline 16: stores ->
 // s_waitcnt vmcnt(0) -> barrier -> lane-0 release fence -> ticket; consumer: ticket -> acquire fence -> barrier -> loads.
-// NV > 3: values 3, 4, ... go to dst[7], dst[8], ... (scal[3..6] are the boundary sum and the loss values)
+// NV > 3: values 3, 4 go to dst[7], dst[8] (scal[4..6] are the loss values), value 5 to dst[3] (the boundary sum of squares)
 template <int NV>
 __device__ __forceinline__ bool grid_sum(double (&val)[NV], double* __restrict__ work, double* __restrict__ dst) {
   __shared__ double red[NV][16];                        // (blocks of up to 16 waves)
@@ -66,7 +66,7 @@ __device__ __forceinline__ bool grid_sum(double (&val)[NV], double* __restrict__
   if (threadIdx.x < NV) {
     double tot = 0.0;
     for (int w = 0; w < (int)(blockDim.x >> 6); ++w) tot += red[threadIdx.x][w];
-    dst[threadIdx.x < 3 ? threadIdx.x : threadIdx.x + 4] += tot;
+    dst[threadIdx.x < 3 ? threadIdx.x : (threadIdx.x < 5 ? threadIdx.x + 4 : threadIdx.x - 2)] += tot;   // 0..2 | 7, 8 | 3
   }
   if (threadIdx.x == 0) *ticket = 0u;
   return true;                                          // this block completed the sum
@@ -108,11 +108,12 @@ __global__ void __launch_bounds__(1024) k_weak_partials(const double* __restrict
                                                        int N, int L, double Vol, double Nglob, double* __restrict__ work,
                                                        double* __restrict__ scal, int finalize, int Lb, double Nbglob,
                                                        double alpha, double init_off, double bdry_off,
-                                                       long long* __restrict__ step) {
+                                                       long long* __restrict__ step, const double* __restrict__ ub,
+                                                       const double* __restrict__ gb, long Pb) {
   // one lane per sample point (time-major: consecutive lanes = consecutive paths of one time index, coalesced)
   // pairwise (single-slice T0 group, L == 1): the s2 term is (sum u)(sum dphi0) -- factors in acc[3], acc[4] -- and the
   // caller passes s3_scale = N with f := mean f, href := mean h (the [N,N] sums of src/loss.py:70,79 factorised)
-  double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};  // I, sum v^2, SSE_init, sum u, sum dphi/dt
+  double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};  // I, sum v^2, SSE_init, sum u, sum dphi/dt, SSE_bdry
   const double cN = Vol / Nglob, cNL = Vol / Nglob / (double)L;
   const long P = (long)N * L;
   for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (long)gridDim.x * blockDim.x) {
@@ -160,10 +161,18 @@ __global__ void __launch_bounds__(1024) k_weak_partials(const double* __restrict
     acc[0] += I;
     acc[1] += vl * vl;
   }
-  const bool last = grid_sum<5>(acc, work, scal);
+  // boundary penalty sum (u_b - g)^2 (src/loss.py:84) over the boundary paths of the group, when the caller hands them over: what
+  // xw_bdry_partials does in a launch of its own -- one launch and one ticket round less per generator sub-step (4 % of the
+  // sub-step of a 512-path shard, profiles/r04_what_if_shard512.txt)
+  if (ub != nullptr)
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < Pb; p += (long)gridDim.x * blockDim.x) {
+      const double r = ub[p] - gb[p];
+      acc[5] += r * r;
+    }
+  const bool last = grid_sum<6>(acc, work, scal);
   if (finalize && last) {
     // the block that completed the sums also turns them into the loss values (what xw_losses does) -- one launch and
-    // one dependency edge less per sub-step; scal[3] (boundary SSE) was completed by an earlier launch on this stream
+    // one dependency edge less per sub-step; scal[3] (boundary SSE) is complete too: summed above, or by an earlier launch
     __syncthreads();
     if (threadIdx.x == 0) {
       if (step != nullptr) *step += 1;
@@ -424,13 +433,14 @@ extern "C" int xw_weak_partials(const double* u, const double* v, const double* 
                                 double ckappa, const double* f, const double* h, const double* href, int pairwise,
                                 double s3_scale, int N, int L, double Vol, double Nglob, double* work, double* scal,
                                 int finalize, int Lb, double Nbglob, double alpha, double init_off, double bdry_off,
-                                long long* step, void* stream) {
+                                long long* step, const double* ub, const double* gb, long Pb, void* stream) {
   if (!u || !v || !vt || !w || !f || !h || !work || !scal || N <= 0 || L <= 0 || (finalize && Lb <= 0)) return XW_E_ARG;
+  if ((ub == nullptr) != (gb == nullptr) || (ub != nullptr && Pb <= 0)) return XW_E_ARG;
   if (!s3x && (!gx || !gs || !ghT || !gxv || !w0 || !gwx0T || d <= 0)) return XW_E_ARG;
   if (pairwise && L != 1) return XW_E_ARG;
   hipLaunchKernelGGL(k_weak_partials, dim3(blocks_for((long)N * L, reduce_threads(), reduce_cap((long)N * L))), dim3(reduce_threads()), 0, (hipStream_t)stream, u, v, vt, w,
                      w_per_point, wt, s3x, gx, gs, ghT, gxv, w0, gwx0T, d, c, ckappa, f, h, href, pairwise, s3_scale, N, L, Vol,
-                     Nglob, work, scal, finalize, Lb, Nbglob, alpha, init_off, bdry_off, step);
+                     Nglob, work, scal, finalize, Lb, Nbglob, alpha, init_off, bdry_off, step, ub, gb, Pb);
   return xw_launch_status();
 }
 
@@ -538,8 +548,8 @@ extern "C" int xw_slab_sum(const double* gslab, int nslab, int P, int accumulate
   return xw_launch_status();
 }
 
-extern "C" int xw_abi_version(void) { return 26; }
-extern "C" int xw_reduce_work_size(void) { return 5 * 1024 + 8; }
+extern "C" int xw_abi_version(void) { return 27; }
+extern "C" int xw_reduce_work_size(void) { return 6 * 1024 + 8; }
 
 extern "C" int xw_supported_dims(char* buf, int buflen) {
   static const char s[] = "ode (H,K)=(20,10),(32,12), m=1..10; disc_fwd W=50,64 any q; disc_bwd W=50 (q=9 unrolled, any q from the record), W=64 (from the record), d<=126";

@@ -801,7 +801,7 @@ class Engine:
             j = dict(xT=G.xbT, start=G.start_b, u=G.ub, Y=G.Yb, act=G.act_b, ubar=ubar, gslab=gslab)
         return j
 
-    def _contract(self, G, adam_state=None):
+    def _contract(self, G, adam_state=None, with_bdry=False):
         """I, sum v^2, SSE_init from u, v, dv/dt and the two helper-backward gradients (src/loss.py:46-76).
         Single GPU: the sums are global, so the same launch also forms the loss values and advances the optimiser's
         counter (`adam_state`); with several GPUs that is done by KN.losses after the all-reduce."""
@@ -809,14 +809,17 @@ class Engine:
         if self.world is None and adam_state is not None:
             fin = dict(Lb=G.Lb, Nbglob=G.Nbglob, alpha=self.alpha, step=adam_state['step'], init_off=G.init_off, bdry_off=G.bdry_off)
         pair = dict(href=G.href, s3_scale=G.s3_scale) if G.pair_i else None
+        # generator sub-step: the boundary penalty's sum of squares (a loss value; the sweeps form its cotangent themselves) rides along
+        bdry = dict(ub=G.ub, g=G.g) if (with_bdry and G.Nb) else None
         if G.A0 is None and G.B0 is None:
             KN.weak_partials(G.u, G.v, G.vt, G.w, G.f, G.h, G.Vol, G.Nglob, self.scal, G.work_i, c=G.c, ckappa=G.ck, wt=G.wt,
-                             contract=dict(gx=G.gx, gs=G.gs, ghT=G.ghT, gxv=G.gxv, w0=G.w0, gwx0T=G.gwx0T), finalize=fin, pair=pair)
+                             contract=dict(gx=G.gx, gs=G.gs, ghT=G.ghT, gxv=G.gxv, w0=G.w0, gwx0T=G.gwx0T), finalize=fin, pair=pair,
+                             bdry=bdry)
             return
         # general a_ij / b_i: the l = 0 contraction as one streaming kernel over the tabulated slice (graph-capturable)
         KN.weak_contract_general(G.A0, G.amode, G.B0, G.gx, G.gs, G.ghT, G.gxv, G.w0, G.gwx0T, G.v[0], G.s3x)
         KN.weak_partials(G.u, G.v, G.vt, G.w, G.f, G.h, G.Vol, G.Nglob, self.scal, G.work_i, s3x=G.s3x, c=G.c, ckappa=G.ck,
-                         wt=G.wt, finalize=fin, pair=pair)
+                         wt=G.wt, finalize=fin, pair=pair, bdry=bdry)
 
     # ------------------------------------------------------------------------------------------------------------
     # generator sub-step (src/training.py:127-138)
@@ -860,11 +863,7 @@ class Engine:
             # (pairwise group: the initial penalty is the mean over all PAIRS (u_n - h_m)^2, whose u-gradient is 2 (u_n - mean h) / N)
             res_A = dict(u=G.u, ref=G.href if G.pair_i else G.h, coef=2.0 * self.alpha / G.Nglob, base=self.pollution, first_only=True)
             res_b = dict(u=G.ub, ref=G.g, coef=2.0 * self.alpha / (G.Nbglob * G.Lb), base=0.0, first_only=False) if G.Nb else None
-            e_b = None
-            if G.Nb:
-                with self._side(2, e_f):
-                    KN.bdry_partials(G.ub, G.g, self.alpha, G.Nbglob, self.scal, G.work_b)
-                    e_b = self._mark()
+            e_b = None       # (the boundary sum of squares, a loss value only, is formed by the reduction at the end: _contract(with_bdry))
             # With the reference's pollution (cotangent A = ones + the initial-value term at t_0) sweep A and the helper
             # backward u.backward(ones) are the same adjoint: one launch returns the parameter gradient of A and nabla_x u.
             if not fused_x:
@@ -905,7 +904,7 @@ class Engine:
         # the reduction needs nabla_x u (sweep A) and v, not sweep B: it runs behind sweep A on the side stream, next to
         # the tail of sweep B, instead of after it
         with self._side(3, e_A, e_v, *[e for e in (e_x, e_b) if e is not None]):   # (re-entering side 1 here crashes hipStreamEndCapture)
-            self._contract(G, self.adam_u)                       # -> scal[0..2], loss values
+            self._contract(G, self.adam_u, with_bdry=True)       # -> scal[0..3], loss values
             e_C = self._mark()
         self._join(e_C, e_S)
 

@@ -334,13 +334,14 @@ def reduce_work_size():
 
 
 def weak_partials(u, v, vt, w, f, h, Vol, Nglob, scal, work, s3x=None, contract=None, c=None, ckappa=0.0, wt=None,
-                  finalize=None, pair=None):
+                  finalize=None, pair=None, bdry=None):
     """partial sums of I, sum v^2, SSE_init.  Either s3x[N] (pre-contracted gradient term) or contract = dict(gx, gs, ghT,
     gxv, w0, gwx0T) for the in-kernel contraction with a = identity, b = 0.
     finalize = dict(Lb, Nbglob, alpha, step[, init_off, bdry_off]) (single GPU): also turn the sums into the loss values
     and advance `step`, exactly what losses() does.
     pair = dict(href[N], s3_scale) (L == 1 only): the reference's [N,N] broadcast on a single-slice T0 group, factorised
-    (include/xnwan.h); f must then hold mean(f) in every entry."""
+    (include/xnwan.h); f must then hold mean(f) in every entry.
+    bdry = dict(ub[Lb, Nb], g[Lb, Nb]): also add the boundary sum of squares sum (u_b - g)^2 to scal[3] (bdry_partials' sum, same launch)."""
     _need_gpu()
     L, N = u.shape
     for name, a in (('u', u), ('v', v), ('vt', vt), ('f', f)):
@@ -351,6 +352,10 @@ def weak_partials(u, v, vt, w, f, h, Vol, Nglob, scal, work, s3x=None, contract=
     _chk(work, F64, (reduce_work_size(),), 'work')
     fz = finalize or {}
     _chk(fz.get('step'), torch.int64, (1,), 'step')
+    bd, Pb = bdry or {}, 0
+    if bdry is not None:
+        Pb = bdry['ub'].numel()
+        _chk(bdry['ub'], F64, tuple(bdry['ub'].shape), 'ub'); _chk(bdry['g'], F64, tuple(bdry['ub'].shape), 'g')
     pr = pair or {}
     _chk(pr.get('href'), F64, (N,), 'href')
     if pair is not None and L != 1:
@@ -368,7 +373,7 @@ def weak_partials(u, v, vt, w, f, h, Vol, Nglob, scal, work, s3x=None, contract=
                                float(pr.get('s3_scale', 1.0)), N, L, float(Vol), float(Nglob), _p(work), _p(scal),
                                0 if finalize is None else 1, max(int(fz.get('Lb', 1)), 1), float(fz.get('Nbglob', 1.0)),
                                float(fz.get('alpha', 0.0)), float(fz.get('init_off', 0.0)), float(fz.get('bdry_off', 0.0)),
-                               _p(fz.get('step')), _stream()),
+                               _p(fz.get('step')), _p(bd.get('ub')), _p(bd.get('g')), Pb, _stream()),
           'xw_weak_partials')
 
 
