@@ -96,6 +96,12 @@ extern "C" int xw_substep_gen(const XwGroup* g, const XwSolverState* s, int skip
     }
   }
   XW_HIP(hipEventRecord(sd->fwd, sd->s));
+  // ---- main chain again, behind the test network AND the forward pass: every sweep of the sub-step in ONE launch (three jobs),
+  // the reduction and the update behind it on the same stream.  The groups this runner serves are small (a few tiles): their
+  // sub-step is a chain of dependent launches, and each cross-queue dependency edge costs ~12 us -- this order has one (the
+  // forward pass), the wide schedule of engine.py three (Engine._gen_front_compact is the same order for captured groups).
+  stream = main_stream;
+  XW_HIP(hipStreamWaitEvent((hipStream_t)main_stream, sd->fwd, 0));
   // (the boundary sum of squares, a loss value only, is formed by the reduction at the end: contract(..., with_bdry))
   if (!fused_x) {     // the helper backward u.backward(ones) as a sweep of its own
     XwOdeBwdJob jx = bwd_job(g->xT, g->start, g->Y, g->act, g->N);
@@ -103,41 +109,36 @@ extern "C" int xw_substep_gen(const XwGroup* g, const XwSolverState* s, int skip
     XW_TRY(xw_ode_bwd_multi(&jx, 1, g->t, s->theta, s->method, g->L, g->d, s->H, s->K, s->m, 1 | adj | (((g->narrow >> 5) & 1) ? 16 : 0),
                             stream));
   }
-  // sweeps with cotangent A (pollution + initial penalty, formed from the residual u - h at t_0) and the boundary penalty
   {
-    XwOdeBwdJob jobs[2];
-    jobs[0] = bwd_job(g->xT, g->start, g->Y, g->act, g->N);
-    jobs[0].gslab = g->slabA;
-    if (fused_x) { jobs[0].gx = g->gx; jobs[0].gs = g->gs; }
-    jobs[0].res_u = g->u; jobs[0].res_ref = g->pair_i ? g->href : g->h; jobs[0].res_first_only = 1;
-    jobs[0].res_coef = 2.0 * s->alpha / g->Nglob; jobs[0].res_base = s->pollution;
+    // cotangent A (pollution + initial penalty, formed from the residual u - h at t_0), the boundary penalty, cotangent B = dI/du
+    // (formed inside the sweep from u, v, w and c, c')
+    XwOdeBwdJob jobs[3];
+    int nj = 0;
+    jobs[nj] = bwd_job(g->xT, g->start, g->Y, g->act, g->N);
+    jobs[nj].gslab = g->slabA;
+    if (fused_x) { jobs[nj].gx = g->gx; jobs[nj].gs = g->gs; }
+    jobs[nj].res_u = g->u; jobs[nj].res_ref = g->pair_i ? g->href : g->h; jobs[nj].res_first_only = 1;
+    jobs[nj].res_coef = 2.0 * s->alpha / g->Nglob; jobs[nj].res_base = s->pollution;
+    ++nj;
     XwOdeBwdJob jb = bwd_job(g->xbT, g->start_b, g->Yb, g->act_b, g->Nb);
     if (g->Nb > 0) {
       jb.gslab = g->slabA + (long)g->ns_u * s->Pu;
       jb.res_u = g->ub; jb.res_ref = g->g; jb.res_first_only = 0;
       jb.res_coef = 2.0 * s->alpha / (g->Nbglob * g->Lb); jb.res_base = 0.0;
     }
-    jobs[1] = jb;
-    const int modeA = (fused_x ? (1 | 2 | 4) : 2) | adj | (((g->narrow >> 2) & 1) ? 16 : 0);
-    XW_TRY(xw_ode_bwd_multi(jobs, joint ? 2 : 1, g->t, s->theta, s->method, g->L, g->d, s->H, s->K, s->m, modeA, stream));
-    if (g->Nb > 0 && !joint)
-      XW_TRY(xw_ode_bwd_multi(&jb, 1, g->tb, s->theta, s->method, g->Lb, g->d, s->H, s->K, s->m, 2 | adj | (((g->narrow >> 3) & 1) ? 16 : 0),
-                              stream));
-  }
-  XW_HIP(hipEventRecord(sd->done, sd->s));
-  stream = main_stream;              // ---- main chain again: sweep B behind the test network AND the forward pass
-  XW_HIP(hipStreamWaitEvent((hipStream_t)main_stream, sd->fwd, 0));
-  // sweep B: cotangent dI/du formed inside the sweep from u, v, w (and c, c')
-  {
+    if (joint) jobs[nj++] = jb;
     XwOdeBwdJob jB = bwd_job(g->xT, g->start, g->Y, g->act, g->N);
     jB.gslab = g->slabB;
     jB.res_first_only = 2; jB.res_u = g->u; jB.res_ref = g->v;
     jB.res_coef = g->Vol / g->Nglob / g->L * g->s3_scale; jB.res_base = g->Vol / g->Nglob;
     jB.res_w_per_point = g->w_per_point; jB.res_w = g->w; jB.res_c = g->c; jB.res_cp = g->cp; jB.res_kappa2 = 2.0 * g->ckappa;
-    XW_TRY(xw_ode_bwd_multi(&jB, 1, g->t, s->theta, s->method, g->L, g->d, s->H, s->K, s->m, 2 | adj | (((g->narrow >> 4) & 1) ? 16 : 0),
-                            stream));
+    jobs[nj++] = jB;
+    const int modeA = (fused_x ? (1 | 2 | 4) : 2) | adj | (((g->narrow >> 2) & 1) ? 16 : 0);
+    XW_TRY(xw_ode_bwd_multi(jobs, nj, g->t, s->theta, s->method, g->L, g->d, s->H, s->K, s->m, modeA, stream));
+    if (g->Nb > 0 && !joint)
+      XW_TRY(xw_ode_bwd_multi(&jb, 1, g->tb, s->theta, s->method, g->Lb, g->d, s->H, s->K, s->m, 2 | adj | (((g->narrow >> 3) & 1) ? 16 : 0),
+                              stream));
   }
-  XW_HIP(hipStreamWaitEvent((hipStream_t)main_stream, sd->done, 0));
   XW_TRY(contract(g, s, s->step_u, true, stream));
   XW_TRY(xw_adam(s->theta, g->slabA, g->ns_u + g->ns_b, accum, g->slabB, g->ns_u, nullptr, s->scal, s->m_u, s->v_u, s->step_u, -1, s->Pu,
                  s->lr_u, s->beta1, s->beta2, s->eps, s->grad_u, s->lag_lo, s->lag_hi, adam_skip_field, s->lag_u, stream));

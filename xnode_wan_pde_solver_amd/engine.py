@@ -213,6 +213,10 @@ class Engine:
         # tools/ab_cfg_prio.sh, priority 1 against 0 -- d = 20: -1.4 % / -1.1 % at 4096 / 8192 paths, equal at 2048; d = 50: equal
         # at 2048 x 64, +0.8 % at 16384 x 64; d = 100: +1.2 % at 8192, +1.3 % at 65536.  Default: 3 up to d = 32, 2 above.
         self.early_slab_sum = os.environ.get('XW_EARLY_SLAB_SUM', '1') == '1'
+        # groups of at most this many 16-path tiles (interior + boundary) take the compact schedule of _gen_front_compact (0: never).
+        # tools/shard_streams.sh, ms per sub-step wide / compact: 256 paths (+ 256 boundary paths) 0.2489 / 0.2183, 512 0.2609 / 0.2244,
+        # 1024 0.2829 / 0.2487, 1536 0.3190 / 0.3108, 2048 0.3490 / 0.3432, 2560 0.3931 / 0.3791, 3072 0.4173 / 0.4272, 4096 0.4698 / 0.4919
+        self.compact_tiles = int(os.environ.get('XW_COMPACT_TILES', '320'))
         self.prio_drop = {k: int(os.environ.get('XW_PRIO_DROP_' + k, dflt))
                           for k, dflt in (('A', 3 if self.d <= 32 else 2), ('X', 0), ('F', 0), ('G', 0))}
         self.use_runner = os.environ.get('XW_RUNNER', '1') == '1'      # one C call per eager group sub-step (xw_substep_*)
@@ -843,6 +847,8 @@ class Engine:
         fused_x = self.pollution == 1.0 and not self.adjoint
         joint = G.Nb and G.same_grid           # boundary paths on the interior's time grid: one launch for both
         e_x = None
+        if self._compact(G, fused_x, joint):
+            return self._gen_front_compact(G)
         if not getattr(G, 'skip_v', False):
             self._launch_test_net_here(G)                        # enqueued first: its blocks must be resident before the
         with self._side(1, e0):                                  # stepper's waves spread over the CUs
@@ -907,6 +913,41 @@ class Engine:
             self._contract(G, self.adam_u, with_bdry=True)       # -> scal[0..3], loss values
             e_C = self._mark()
         self._join(e_C, e_S)
+
+    def _compact(self, G, fused_x, joint):
+        """small groups (shards of a strong-scaling job, small problems): the sub-step is a chain of dependent launches whose
+        every cross-queue dependency edge costs ~12 us -- the compact schedule below has one instead of three"""
+        tiles = (G.N + 15) // 16 + ((G.Nb + 15) // 16 if G.Nb else 0)
+        return self.compact_tiles > 0 and tiles <= self.compact_tiles and self.use_streams and fused_x and joint
+
+    def _gen_front_compact(self, G):
+        """_gen_front for a group that leaves the chip mostly idle: test network (main) || forward pass (side 1), then ON THE MAIN
+        STREAM one launch with all three sweep jobs (A with nabla_x u, boundary, B), the reduction and (in _gen_back) the update --
+        same kernels, same arguments, same results as the wide schedule; dependent launches of one stream follow each other without
+        the cross-queue hop."""
+        th = self.theta.data
+        M = (self.method, self.H, self.K, self.m)
+        e0 = self._mark()
+        if not getattr(G, 'skip_v', False):
+            self._launch_test_net_here(G)
+        with self._side(1, e0):
+            fwd = [self._job(G, 'i'), self._job(G, 'b')]
+            KN.ode_fwd_multi(fwd, G.t, th, *M, zero16=self.scal, narrow=self._narrow_ok(fwd, alone=False, forward=True),
+                             prio_drop=self.prio_drop['G'])
+            self._reaction(G)
+            e_f = self._mark()
+        self._join(e_f)
+        res_A = dict(u=G.u, ref=G.href if G.pair_i else G.h, coef=2.0 * self.alpha / G.Nglob, base=self.pollution, first_only=True)
+        res_b = dict(u=G.ub, ref=G.g, coef=2.0 * self.alpha / (G.Nbglob * G.Lb), base=0.0, first_only=False)
+        res_B = dict(u=G.u, ref=G.v, coef=G.Vol / G.Nglob / G.L * G.s3_scale, base=G.Vol / G.Nglob,
+                     weak=dict(w=G.w, c=G.c, cp=G.cp, ckappa=G.ck))
+        sweeps = [dict(self._job(G, 'i', None, G.slabA[:G.ns_u], want_x=True), res=res_A),
+                  dict(self._job(G, 'b', None, G.slabA[G.ns_u:]), res=res_b),
+                  dict(self._job(G, 'i', None, G.slabB), res=res_B)]
+        KN.ode_bwd_multi(sweeps, G.t, th, *M, want_x=True, want_params=True, x_cot_ones=True, adjoint=self.adjoint,
+                         narrow=self._narrow_ok(sweeps, alone=False))
+        G.sumA_ready = False
+        self._contract(G, self.adam_u, with_bdry=True)
 
     def begin_substep(self, which, accumulate):
         """start of a generator ('u') / discriminator ('v') sub-iteration over several groups: zero the carried gradient"""
