@@ -224,6 +224,15 @@ def test_reductions_against_torch_at_full_size():
     KN.weak_partials(u, v, vt, w, f, h, Vol, float(N), scal2, work, ckappa=kappa,
                      contract=dict(gx=gx, gs=gs, ghT=ghT, gxv=gxv, w0=w0, gwx0T=gwx0T))
     assert torch.equal(scal2[:3], scal[:3])
+    # the boundary sum of squares formed by the SAME launch (what the generator sub-step does since round 4: xw_weak_partials(ub, gb, Pb)),
+    # also with a boundary sample of another size than the interior's
+    for ubx, gbx in ((ub, gb), (ub[:7, :1000].contiguous(), gb[:7, :1000].contiguous())):
+        scal3 = torch.zeros(16, dtype=F64, device=dev)
+        KN.weak_partials(u, v, vt, w, f, h, Vol, float(N), scal3, work, ckappa=kappa,
+                         contract=dict(gx=gx, gs=gs, ghT=ghT, gxv=gxv, w0=w0, gwx0T=gwx0T), bdry=dict(ub=ubx, g=gbx))
+        assert torch.equal(scal3[:3], scal[:3])
+        np.testing.assert_allclose(float(scal3[3]), float(((ubx - gbx) ** 2).sum()), rtol=1e-12)
+        assert float(scal3[4:].abs().max()) == 0.0
 
 
 def test_headline_substeps_are_bit_reproducible():
