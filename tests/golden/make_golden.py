@@ -2,6 +2,14 @@
 """Generate golden vectors by running the upstream reference IN THIS CONTAINER ONLY.
 
 Usage:  python tests/golden/make_golden.py [--traj]          (needs /root/reference; CPU; ~1 min, --traj ~10 min)
+Round-4 fixtures, one option each (reference CPU time on this container's 8 cores):
+        --round4                  ref_d20_headline (one outer iteration at the benchmarked size, slim record) + the r = 0.7 samplers   4 min
+        --traj-headline           ref_traj_d20_headline_seed4: 250 outer iterations of the reference's train() at the benchmarked size  25 min
+        --traj-headline-solvers   ref_traj_d20_headline_{euler_seed5, rk4_seed6}: 30 outer iterations each                              8 min
+        --traj-cfg5               ref_traj_{cone, hourglass}_ex43_d10_full_*: 8 outer iterations at config 5's stated size              4 min
+        --general                 ref_general_d4_midpoint: general a_ij, b_i, c(u,t,x) (general_funcs.py)                               seconds
+        --shapes                  ref_wide_d6_midpoint, ref_narrow_d3_euler, ref_m1_d4_rk4: other network shapes                        seconds
+(general b_i: the reference's `np.sum(list of tensors)` goes through shim 2 below, i.e. Python's sum over the list.)
 
 What this is: test infrastructure.  It imports the reference implementation from
 /root/reference (never copied into this repo, never shipped to the GPU box) and
