@@ -325,9 +325,16 @@ def main():
                 torch.set_rng_state(rng)
                 if traj[-1] < 0.01:
                     break
+            # ... and one long call (no held-out evaluation in between): what an outer iteration costs once the loop's pipeline is full
+            S2.iterations = 200
+            torch.cuda.synchronize()
+            tt0 = time.time()
+            S2.train(report=False)
+            torch.cuda.synchronize()
+            steady = 1e3 * (time.time() - tt0) / 200
         finally:
             os.chdir(cwd)
-        extras['train'] = {'outer_iterations': done, 'stopped_by': 'rel-L2 < 0.01 (reference stopping rule)' if traj[-1] < 0.01 else 'iteration cap',
+        extras['train'] = {'outer_iterations': done, 'ms_per_outer_iteration_one_call_of_200': round(steady, 2), 'stopped_by': 'rel-L2 < 0.01 (reference stopping rule)' if traj[-1] < 0.01 else 'iteration cap',
                            'wall_s': round(wall, 2), 'ms_per_outer_iteration_incl_resampling_diagnostics_io': round(1e3 * wall / done, 2),
                            # (the first 25-iteration call carries the library load and the graph captures)
                            'ms_per_outer_iteration_after_the_first_call': round(1e3 * sum(calls[1:]) / (25 * len(calls[1:])), 2) if len(calls) > 1 else None,
