@@ -587,6 +587,28 @@ def test_activation_stores_do_not_change_the_step(golden_dir):
     close(outs[0][2][:6], outs[1][2][:6], 1e-10, 0.0, 'sums and losses')
 
 
+@pytest.mark.parametrize('case', ['ref_plumb_midpoint', 'ref_d20_small_midpoint'])
+def test_compact_and_wide_generator_schedules_give_the_same_bits(golden_dir, case):
+    """Engine._gen_front_compact (groups of at most `compact_tiles` tiles: all three sweep jobs in ONE launch on the main stream, the
+    slabs summed by the update) against the wide schedule (sweeps A + boundary on a side stream, sweep B behind the test network, the
+    slabs of the former summed early): the same kernels on the same arguments, the same summation trees -- bit-identical parameters,
+    gradients and sums after g, g, d, g"""
+    z, params = load(golden_dir, case)
+    outs = []
+    for tiles in (10 ** 6, 0):
+        S = make_solver(params, 0)
+        domain, pts = first_sample(S)
+        eng = S.engine
+        eng.compact_tiles = tiles
+        G = eng.load_group(pts.interioru, pts.interiorv, pts.boundary, domain)
+        assert eng._compact(G, True, True) == (tiles > 0)
+        for kind in 'ggdg':
+            (eng.generator_step if kind == 'g' else eng.discriminator_step)(G)
+        outs.append((eng.theta.data.clone(), eng.phi.data.clone(), eng.scal.clone(), eng.grad_u.clone(), sorted(G.graphs)))
+    a, b = outs
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3]) and a[4] == b[4]
+
+
 def test_evaluation_off_the_boundary_matches_reference(golden_dir):
     """u_net on paths that start neither at T0 nor on the boundary: bound_pad / fillt densified grid (src/model.py:92-106)"""
     z, params = load(golden_dir, 'ref_boundpad')
