@@ -212,6 +212,15 @@ class Engine:
         # nabla_x v grow with d, the stepper's x-projection is hoisted) and sweeps that never get ahead of it end AFTER sweep B:
         # tools/ab_cfg_prio.sh, priority 1 against 0 -- d = 20: -1.4 % / -1.1 % at 4096 / 8192 paths, equal at 2048; d = 50: equal
         # at 2048 x 64, +0.8 % at 16384 x 64; d = 100: +1.2 % at 8192, +1.3 % at 65536.  Default: 3 up to d = 32, 2 above.
+        # The sub-step graphs' four chains are laid out for the HIP runtime's default of FOUR hardware queues: with 5, 6 or 8
+        # (GPU_MAX_HW_QUEUES) the headline sub-step takes 0.69 instead of 0.47 ms (tools/hwq.sh; 2 and 3 are as good as 4).
+        try:
+            if int(os.environ.get('GPU_MAX_HW_QUEUES', '4')) > 4:
+                import warnings
+                warnings.warn('GPU_MAX_HW_QUEUES=%s: the sub-step schedule is tuned for the runtime default of 4 hardware queues and '
+                              'measures ~45 %% slower with more' % os.environ['GPU_MAX_HW_QUEUES'], RuntimeWarning, stacklevel=2)
+        except ValueError:
+            pass
         self.early_slab_sum = os.environ.get('XW_EARLY_SLAB_SUM', '1') == '1'
         # groups of at most this many 16-path tiles (interior + boundary) take the compact schedule of _gen_front_compact (0: never).
         # tools/shard_streams.sh, ms per sub-step wide / compact: 256 paths (+ 256 boundary paths) 0.2489 / 0.2183, 512 0.2609 / 0.2244,
