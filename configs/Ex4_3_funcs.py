@@ -13,11 +13,17 @@ import torch
 from utils.auxillary_funcs import rel_err
 
 
+_PHASES = {}
+
+
 def _sines(X, first):
     d = X.shape[-1] - 1
     # all d sines in three tensor operations, then the product in the upstream order (left to right: same bits as the
     # coordinate-by-coordinate loop of upstream configs/Ex4_3_funcs.py:8-12, a third of its launches on a GPU tensor)
-    phase = ((math.pi / 2) * torch.arange(d, dtype=torch.float64)).to(device=X.device, dtype=X.dtype)   # (rounded once, like the scalars)
+    key = (d, X.device, X.dtype)
+    phase = _PHASES.get(key)
+    if phase is None:          # (kept per device: an upload out of pageable memory waits for everything queued on the stream)
+        phase = _PHASES[key] = ((math.pi / 2) * torch.arange(d, dtype=torch.float64)).to(device=X.device, dtype=X.dtype)   # (rounded once, like the scalars)
     S = torch.sin(math.pi / 2 * X[..., first:first + d] + phase)
     out = S[..., 0]
     for i in range(1, d):

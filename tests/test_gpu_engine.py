@@ -908,6 +908,49 @@ def test_pipelined_training_loop_leaves_exactly_what_the_synchronous_one_does(tm
     assert a[3] == b[3] and a[4] == b[4] and a[5] == b[5] and a[6] == b[6] and a[7] == b[7]
 
 
+@pytest.mark.parametrize('domain,seed', [('NSphere_THourglass', 5), ('NSphere_TCone', 6)])
+def test_list_domain_loop_with_one_read_back_leaves_exactly_what_the_synchronous_one_does(tmp_path, domain, seed):
+    """solver.defer_list_readback (ball domains, 11-20 groups per sample): all sub-steps of an outer iteration queued without a
+    read-back, the next sample's groups loaded behind them, losses / theta snapshots / diagnostic read back once -- with the
+    samples drawn by the forked sampling process (solver.sampler_process, sampler_proc.py) or by the helper thread.  The
+    parameters, the loss list, the files, the best weights and the generator streams after train() must be those of the loop
+    that synchronises after every sub-iteration (the one the reference-trajectory fixtures run through), bit for bit."""
+    import hashlib
+    import configs.Ex4_3_funcs as F
+    params = {'alpha': 1e4, 'u_layers': 8, 'u_hidden_dim': 20, 'u_hidden_hidden_dim': 10, 'v_layers': 9, 'v_hidden_dim': 50,
+              'n1': 2, 'n2': 1, 'u_rate': 0.015, 'v_rate': 0.04, 'min_steps': 5, 'adjoint': False, 'solver': 'midpoint',
+              'dim': 4, 'N_t': 9, 'N_r': 600, 'N_b': 400, 'T0': 0, 'T': 1, 'shape_param': 1.0, 'iterations': 7, 'domain': domain}
+    out = []
+    cwd = os.getcwd()
+    for mode, (defer, proc) in enumerate(((True, True), (True, False), (False, False))):
+        wd = tmp_path / ('mode%d' % mode)
+        wd.mkdir()
+        os.chdir(wd)
+        try:
+            S = make_solver(params, seed, F=F)
+            S.defer_list_readback, S.sampler_process = defer, proc
+            losses = list(S.train(report=False))
+            S.iterations = 3
+            losses += list(S.train(report=False))          # (a second call: the sampling process is handed the streams again)
+            torch.cuda.synchronize()
+            assert len(S._group_cache) > 1
+            assert (getattr(S, '_sampler_proc', None) is not None) == proc
+            best = torch.load('best_model_weights_NODE.pth')
+            out.append((losses, S.engine.theta.data.cpu(), S.engine.phi.data.cpu(), open('losses_NODE_4.json').read(),
+                        open('L2_NODE_4.json').read(), hashlib.sha1(b''.join(v.cpu().numpy().tobytes() for v in best.values())).hexdigest(),
+                        list(best.keys()), S.best_l, S.last_loss_u, S.last_loss_v, len(json.load(open('Time_NODE_4.json'))),
+                        torch.rand(4).tolist(), np.random.rand(4).tolist(), np.random.normal(size=3).tolist()))
+            if proc:
+                S._sampler_proc[1].close()
+        finally:
+            os.chdir(cwd)
+    a, b, c = out
+    assert len(a[0]) == 20
+    for other in (b, c):
+        assert a[0] == other[0] and torch.equal(a[1], other[1]) and torch.equal(a[2], other[2])
+        assert a[3:] == other[3:]
+
+
 def test_poisoned_work_buffers_change_nothing(golden_dir, monkeypatch):
     """XW_POISON=1 starts every work buffer as NaN: no kernel may read a slot that nobody wrote (a stale but plausible value
     from the allocator is how such a read hides), and nothing may depend on timing -- the same three sub-steps, bit for bit"""

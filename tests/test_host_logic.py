@@ -333,6 +333,123 @@ def test_native_uniform_fill_is_torchs_stream():
     assert lib.xw_mt19937_uniform_f32(s0.data_ptr(), 100, torch.empty(4).data_ptr(), 4, 0.0, 1.0, 1) < 0
 
 
+def test_native_normal_fill_is_numpys_legacy_stream():
+    """xw_mt19937_legacy_normal_f64 (csrc/xw_hostrng.cpp) behind sampling._legacy_normal: values, order and the state left behind
+    (key, position, cached second value of a pair) are those of np.random.normal on numpy's global generator -- across state
+    blocks, from any position, with and without a cached value going in and coming out; the ball domains' samples follow"""
+    import ctypes
+    import numpy as np
+    from xnode_wan_pde_solver_amd import sampling
+    draw = sampling._LegacyNormal()
+    draw((2, 2))
+    assert draw.ok is True, 'the native fill did not reproduce numpy on this machine (it would fall back, with a warning)'
+    keep = np.random.get_state()
+    try:
+        rs = np.random.RandomState(5)
+        sizes = [(10, 8192), 1025, 1, 2048, (3, 1001), 4096, 7, (10, 3), 100001, 1024, 2, 2047 + 1024] + [int(n) for n in rs.randint(1024, 9000, 40)]
+        for seed in (0, 31337):
+            np.random.seed(seed)
+            np.random.rand(211)                               # somewhere inside a state block
+            a = [np.random.normal(size=n) for n in sizes]
+            ra, sa = np.random.rand(5), np.random.get_state()
+            np.random.seed(seed)
+            np.random.rand(211)
+            b = [draw(n) for n in sizes]
+            rb, sb = np.random.rand(5), np.random.get_state()
+            assert all(x.shape == y.shape and np.array_equal(x, y) for x, y in zip(a, b))
+            assert np.array_equal(ra, rb) and np.array_equal(sa[1], sb[1]) and sa[2:] == sb[2:]
+        # the samplers built on it: same groups either way
+        for cls, args in ((sampling.NSphere_THourglass, (0.7, 5, 0.0, 1.0, 9)), (sampling.NSphere_TCone, (1.0, 4, 0.0, 1.0, 7))):
+            out = []
+            for native in (True, False):
+                sampling._legacy_normal.ok = None if native else False
+                torch.manual_seed(3)
+                np.random.seed(3)
+                dom = cls(*args)
+                out.append((dom.interior(3000), dom.boundary(2000)))
+            sampling._legacy_normal.ok = None
+            for ga, gb in zip(out[0], out[1]):
+                assert len(ga) == len(gb) and all(torch.equal(x, y) for x, y in zip(ga, gb))
+        # the diagnostic's sample (interior only): same interior groups, both generators end where the full sample leaves them
+        for cls, args in ((sampling.NSphere_THourglass, (1.0, 5, 0.0, 1.0, 9)), (sampling.NSphere_TCone, (0.7, 4, 0.0, 1.0, 7))):
+            out = []
+            for slim in (False, True):
+                torch.manual_seed(11)
+                np.random.seed(11)
+                dom = cls(*args)
+                ld = sampling.Comb_loader(3000, 2000, dom, 'cpu', interior_only=slim)
+                out.append((ld.interioru, ld.interiorv, ld.boundary, torch.rand(3), np.random.rand(3), np.random.normal(size=3)))
+            full, slim = out
+            assert len(full[0]) == len(slim[0]) and all(torch.equal(x, y) for x, y in zip(full[0], slim[0]))
+            assert all(torch.equal(x, y) for x, y in zip(full[1], slim[1])) and len(full[2]) > 0 and slim[2] == []
+            assert torch.equal(full[3], slim[3]) and np.array_equal(full[4], slim[4]) and np.array_equal(full[5], slim[5])
+        # a position outside the state is refused
+        from xnode_wan_pde_solver_amd._lib import lib
+        key = np.zeros(624, dtype=np.uint32)
+        p, h, c = ctypes.c_int(700), ctypes.c_int(0), ctypes.c_double(0.0)
+        buf = np.empty(4)
+        assert lib.xw_mt19937_legacy_normal_f64(key.ctypes.data, ctypes.byref(p), ctypes.byref(h), ctypes.byref(c), buf.ctypes.data, 4) < 0
+    finally:
+        np.random.set_state(keep)
+
+
+@pytest.mark.parametrize('name', ['NSphere_THourglass', 'NSphere_TCone'])
+def test_sampling_process_draws_what_the_sampling_thread_draws(name):
+    """sampler_proc.SamplerProcess (a forked child that owns both generator streams while train() runs): the first sample, then
+    per outer iteration the diagnostic's sample (interior only) and the next domain + sample, in solver._train.draw_ahead's
+    order -- groups, per-group hints and the domains' time grids equal to in-process draws from the same seeds, and the streams
+    handed back at the end stand where the in-process ones stand; a second begin / shutdown round works on the same child"""
+    import numpy as np
+    from xnode_wan_pde_solver_amd import sampling, sampler_proc
+    cls = sampling.DOMAINS[name]
+    setup = dict(shape_param=1.0, dim=5, T0=0.0, T=1.0, N_t=9)
+    N_r, N_b, rounds = 3000, 2000, 3
+    make = lambda: cls(setup['shape_param'], setup['dim'], setup['T0'], setup['T'], setup['N_t'])   # noqa: E731
+    eq = lambda A, B: len(A) == len(B) and all(torch.equal(a.detach(), b.detach()) for a, b in zip(A, B))   # noqa: E731
+    keep_t, keep_n = torch.get_rng_state(), np.random.get_state()
+    sp = None
+    try:
+        for seed in (4, 5):                                   # (two rounds on one child)
+            torch.manual_seed(seed)
+            np.random.seed(seed)
+            dom = make()
+            ref = [(dom, sampling.Comb_loader(N_r, N_b, dom, 'cpu'))]
+            for k in range(rounds):
+                after = sampling.Comb_loader(N_r, N_b, dom, 'cpu', interior_only=True)
+                if k == rounds - 1:
+                    ref.append((after, None, None))
+                else:
+                    dom = make()
+                    ref.append((after, dom, sampling.Comb_loader(N_r, N_b, dom, 'cpu')))
+            end_ref = (torch.rand(3), np.random.rand(3), np.random.normal(size=3))
+            torch.manual_seed(seed)
+            np.random.seed(seed)
+            sp = sp or sampler_proc.SamplerProcess(cls, setup, N_r, N_b)
+            sp.begin()
+            d0, s0 = sp.first()
+            assert eq(s0.interioru, ref[0][1].interioru) and eq(s0.boundary, ref[0][1].boundary) and torch.equal(d0.times, ref[0][0].times)
+            assert s0._hints == ref[0][1].pack()[4] and len(s0.interioru) > 1
+            cur = d0
+            for k in range(rounds):
+                after, nd, nxt = sp.submit(None, cur, k == rounds - 1).result()
+                r = ref[1 + k]
+                assert eq(after.interioru, r[0].interioru) and after.boundary == []
+                assert (nd is None) == (r[1] is None)
+                if nd is not None:
+                    assert torch.equal(nd.times, r[1].times) and eq(nxt.interioru, r[2].interioru) and eq(nxt.boundary, r[2].boundary)
+                    assert nxt._hints == r[2].pack()[4] and nd.V() == r[1].V()
+                cur = nd
+            sp.shutdown()
+            end = (torch.rand(3), np.random.rand(3), np.random.normal(size=3))
+            assert torch.equal(end[0], end_ref[0]) and np.array_equal(end[1], end_ref[1]) and np.array_equal(end[2], end_ref[2])
+    finally:
+        if sp is not None:
+            sp.close()
+            assert not sp.proc.is_alive()
+        torch.set_rng_state(keep_t)
+        np.random.set_state(keep_n)
+
+
 def test_ex43_sines_keep_the_upstream_product_order():
     """configs/Ex4_3_funcs._sines takes the d sines in three tensor operations; the product must stay the coordinate-by-coordinate
     loop of the upstream file (configs/Ex4_3_funcs.py:8-12) bit for bit -- the ball-domain trajectory fixtures hang on it"""

@@ -84,3 +84,80 @@ extern "C" int xw_mt19937_uniform_f32(void* state_blob, long blob_bytes, float* 
   for (int j = 0; j < N; ++j) { w = s[j]; std::memcpy(blob + 24 + 8 * j, &w, 8); }
   return 0;
 }
+
+// ---- numpy's legacy normal stream ------------------------------------------------------------------------------------------
+// The ball domains draw their points with np.random.normal on numpy's GLOBAL RandomState (src/dataset.py:29-34, 160-166:
+// "same seeds" = this stream too): legacy_gauss of numpy/random/src/legacy/legacy-distributions.c, the polar method on pairs of
+// 53-bit doubles of the mt19937 words, the second value of a pair cached in the state.  numpy walks it value by value, 18.6 ns
+// each, 0.3 M per hourglass sample -- what bounded the ball domains' train().  Here the words of a state block are
+// tempered and turned into candidate pairs in vectorisable loops, the rejection scan only compacts (branch-free), and the log /
+// sqrt of the accepted pairs -- libm's scalar log, the function numpy calls: same bits -- run back to back over a block: 4.5 ns
+// per value.  Same values, same order, same state left behind (key, pos, has_gauss, cached value); the caller verifies that
+// against numpy once per process.
+namespace {
+inline uint32_t temper(uint32_t y) {
+  y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
+  return y;
+}
+static inline __attribute__((always_inline)) void candidates_body(const uint32_t* s, int attempts, double* x1, double* x2, double* r2) {
+  for (int i = 0; i < attempts; ++i) {
+    const uint32_t a1 = temper(s[4 * i]) >> 5, b1 = temper(s[4 * i + 1]) >> 6, a2 = temper(s[4 * i + 2]) >> 5, b2 = temper(s[4 * i + 3]) >> 6;
+    const double u1 = ((double)a1 * 67108864.0 + (double)b1) / 9007199254740992.0;      // mt19937_next_double
+    const double u2 = ((double)a2 * 67108864.0 + (double)b2) / 9007199254740992.0;
+    const double p = 2.0 * u1 - 1.0, q = 2.0 * u2 - 1.0;
+    x1[i] = p; x2[i] = q; r2[i] = p * p + q * q;
+  }
+}
+__attribute__((target("avx2"))) void candidates_v3(const uint32_t* s, int n, double* x1, double* x2, double* r2) { candidates_body(s, n, x1, x2, r2); }
+void candidates_v1(const uint32_t* s, int n, double* x1, double* x2, double* r2) { candidates_body(s, n, x1, x2, r2); }
+
+}  // namespace
+
+extern "C" int xw_mt19937_legacy_normal_f64(uint32_t* key, int* pos_io, int* has_gauss_io, double* cached_io, double* out, long n) {
+  if (!key || !pos_io || !has_gauss_io || !cached_io || (!out && n > 0) || n < 0) return -2;
+  int pos = *pos_io;
+  if (pos < 0 || pos > N) return -2;
+  long done = 0;
+  if (n > 0 && *has_gauss_io) { out[done++] = 0.0 + 1.0 * *cached_io; *has_gauss_io = 0; *cached_io = 0.0; }
+  const long want = (n - done + 1) / 2;                 // pairs still to accept
+  // words of the current state block that have not been handed out, behind up to three words left over from the block before
+  constexpr int A = N / 4 + 2;
+  uint32_t w[N + 4];
+  double x1[A], x2[A], r2[A], a1[A], a2[A], ar[A], vals[2 * A];
+  int carry = 0;
+  long got = 0;
+  while (got < want) {
+    if (pos == N) { regenerate(key); pos = 0; }
+    const int fresh = N - pos;
+    std::memcpy(w + carry, key + pos, sizeof(uint32_t) * (size_t)fresh);
+    const int have = carry + fresh, attempts = have / 4;
+    wide ? candidates_v3(w, attempts, x1, x2, r2) : candidates_v1(w, attempts, x1, x2, r2);
+    int i = 0, k = 0;
+    if (want - got >= attempts) {                        // the whole block is needed: compact without branches
+      for (; i < attempts; ++i) {
+        a1[k] = x1[i]; a2[k] = x2[i]; ar[k] = r2[i];
+        k += !(r2[i] >= 1.0 || r2[i] == 0.0);
+      }
+    } else {
+      for (; i < attempts && got + k < want; ++i)
+        if (!(r2[i] >= 1.0 || r2[i] == 0.0)) { a1[k] = x1[i]; a2[k] = x2[i]; ar[k] = r2[i]; ++k; }
+    }
+    for (int j = 0; j < k; ++j) {
+      const double f = std::sqrt(-2.0 * std::log(ar[j]) / ar[j]);
+      vals[2 * j] = 0.0 + 1.0 * (f * a2[j]);             // legacy_normal: loc + scale * gauss, loc = 0, scale = 1
+      vals[2 * j + 1] = 0.0 + 1.0 * (f * a1[j]);         // (the value legacy_gauss caches and hands out next)
+    }
+    got += k;
+    const long room = n - done, m = 2L * k < room ? 2L * k : room;
+    std::memcpy(out + done, vals, sizeof(double) * (size_t)m);
+    done += m;
+    if (m < 2L * k) { *has_gauss_io = 1; *cached_io = vals[2 * k - 1]; }     // (only the very last pair can be cut)
+    const int used = 4 * i;                              // words consumed, the carried ones first
+    if (got == want) { pos = N - (have - used); break; }  // (the unused words all belong to this block: carry < 4 <= used)
+    carry = have - used;
+    std::memmove(w, w + used, sizeof(uint32_t) * (size_t)carry);
+    pos = N;
+  }
+  *pos_io = pos;
+  return 0;
+}

@@ -364,16 +364,18 @@ class Engine:
         def starts(ts, flags):
             P0 = torch.cat([x[:, 0, :] for x in ts], 0).clone().requires_grad_(True)
             n = [x.shape[0] for x in ts]
-            sel = torch.cat([torch.full((k,), a, dtype=torch.bool) for k, a in zip(n, flags)]).to(P0.device)
-            i_h, i_g = torch.nonzero(sel).reshape(-1), torch.nonzero(~sel).reshape(-1)
-            hval = self.funcs['h'](P0.index_select(0, i_h)).reshape(-1) if i_h.numel() else None
-            gval = self.funcs['g'](P0.index_select(0, i_g).unsqueeze(1)).reshape(-1) if i_g.numel() else None
+            # (the groups are contiguous row ranges of P0: the rows of the groups that start at T0 / on the boundary are taken and
+            #  put back as slices -- an index tensor would have to be uploaded or found on the device, both of which wait for
+            #  everything queued on the stream, i.e. for the previous iteration's sub-steps when this runs beside them)
+            rows = P0.split(n)
+            pick = lambda want: [r for r, a in zip(rows, flags) if a == want]                 # noqa: E731
+            rows_h, rows_g = pick(True), pick(False)
+            hval = self.funcs['h'](torch.cat(rows_h, 0)).reshape(-1) if rows_h else None
+            gval = self.funcs['g'](torch.cat(rows_g, 0).unsqueeze(1)).reshape(-1) if rows_g else None
             ref = hval if hval is not None else gval
-            val = torch.zeros(P0.shape[0], dtype=ref.dtype, device=P0.device)
-            if hval is not None:
-                val = val.index_copy(0, i_h, hval)
-            if gval is not None:
-                val = val.index_copy(0, i_g, gval.to(val.dtype))
+            it_h = iter(hval.split([r.shape[0] for r in rows_h])) if hval is not None else None
+            it_g = iter(gval.to(ref.dtype).split([r.shape[0] for r in rows_g])) if gval is not None else None
+            val = torch.cat([next(it_h) if a else next(it_g) for a in flags], 0)
             return P0, n, val
         X0, n0, start = starts(Xs, at0)
         gh = torch.autograd.grad(start.sum(), X0)[0][:, 1:] if start.requires_grad else torch.zeros(X0.shape[0], d, device=X0.device, dtype=X0.dtype)
@@ -383,11 +385,12 @@ class Engine:
         _, nb0, sb = starts(BXs, bat0)
         sb = sb.detach()
         tabs = []
+        start_k, gh_k, hv_k, sb_k = start.detach().split(n0), gh.split(n0), hv.detach().split(n0), sb.split(nb0)   # (once: a split is 20 new tensors)
         for k, (x, xv, bx) in enumerate(zip(Xs, XVs, BXs)):
             N, L = x.shape[0], x.shape[1]
-            tabs.append(dict(starts_T0=at0[k], start=start.detach().split(n0)[k], gh=gh.split(n0)[k], h=hv.detach().split(n0)[k],
+            tabs.append(dict(starts_T0=at0[k], start=start_k[k], gh=gh_k[k], h=hv_k[k],
                              f=f_all[k].view(N, L), w=w_all[k].view(N, L), gw=gw_all[k].view(N, L, d + 1),
-                             b_T0=bat0[k], start_b=sb.split(nb0)[k], g=g_all[k].view(bx.shape[0], bx.shape[1])))
+                             b_T0=bat0[k], start_b=sb_k[k], g=g_all[k].view(bx.shape[0], bx.shape[1])))
         if not getattr(self, '_batch_tab_checked', False):
             self._batch_tab_checked = True
             # bitwise against the per-group calls: f, h, w on the first group, and g, the start values with their gradient and the
@@ -582,7 +585,9 @@ class Engine:
         G.work_i = torch.zeros(KN.reduce_work_size(), dtype=F64, device=dev)   # scratch of the deterministic grid sums
         G.work_b = torch.zeros(KN.reduce_work_size(), dtype=F64, device=dev)   # (interior / boundary run concurrently)
         G.graphs = {}
-        G.sample_version = 0
+        # (a group of a list domain changes shape with every sample and is built anew each time: the count of samples it has seen
+        #  is carried over, or the periodic structure guard above -- two read-backs -- would run on EVERY sample)
+        G.sample_version = into.sample_version + 1 if into is not None else 0
         return G
 
     def refill_compact(self, G, comp, domain, n_glob=None, nb_glob=None):

@@ -172,6 +172,107 @@ class _UniformFill:
 
 
 _uniform_fill = _UniformFill()
+
+
+class _LegacyNormal:
+    """np.random.normal(size=shape) on numpy's GLOBAL legacy generator through the native fill of the C library
+    (xw_mt19937_legacy_normal_f64: numpy walks legacy_gauss value by value, 16-18 ns each, and a ball-domain sample draws 0.1-0.3 M
+    of them -- the draws were what bounded train() on those domains).  The FIRST use compares the native stream with numpy's,
+    values and the state left behind (key, position, cached second value), over sizes that cross state blocks and leave /
+    consume a cached value; if anything differs, or the library is absent, every draw goes through numpy: the numbers a seed
+    produces never depend on which way they were drawn.  XW_NATIVE_RNG=0 turns the native fill off."""
+    MIN = 4096          # below this numpy's own call is as fast as the state round trip (get_state + set_state: 80 us)
+
+    def __init__(self):
+        import threading
+        self.ok = None
+        self._local = threading.local()
+
+    def _fill(self, st, shape):
+        import ctypes
+        out = np.empty(shape)
+        p, h, c = ctypes.c_int(st[2]), ctypes.c_int(st[3]), ctypes.c_double(st[4])
+        rc = self.fn(st[1].ctypes.data, ctypes.byref(p), ctypes.byref(h), ctypes.byref(c), out.ctypes.data, out.size)
+        if rc != 0:
+            raise RuntimeError("xw_mt19937_legacy_normal_f64 refused numpy's generator state (%d)" % rc)
+        st[2:] = p.value, h.value, c.value
+        return out
+
+    def _native(self, shape):
+        st = list(np.random.get_state())
+        if st[0] != 'MT19937' or st[1].dtype != np.uint32 or not st[1].flags.c_contiguous:
+            return np.random.normal(size=shape)
+        out = self._fill(st, shape)
+        np.random.set_state(tuple(st))
+        return out
+
+    def hold(self):
+        """context: numpy's global state is taken ONCE, every draw inside goes through the native fill on that copy whatever its
+        size, and the state goes back at the end (a boundary sample is 20 draws; the round trip would be a third of their time).
+        Nothing else may draw from numpy's global generator inside."""
+        from contextlib import contextmanager
+
+        @contextmanager
+        def held():
+            if self.ok is None:
+                self._probe()
+            st = list(np.random.get_state()) if self.ok else None
+            if st is None or st[0] != 'MT19937' or st[1].dtype != np.uint32 or not st[1].flags.c_contiguous:
+                yield
+                return
+            self._local.state = st
+            try:
+                yield
+            finally:
+                self._local.state = None
+                np.random.set_state(tuple(st))
+        return held()
+
+    def _probe(self):
+        import os
+        self.ok = False
+        if os.environ.get('XW_NATIVE_RNG', '1') != '1':
+            return
+        try:
+            from ._lib import lib
+            self.fn = lib.xw_mt19937_legacy_normal_f64
+        except Exception:
+            return
+        keep = np.random.get_state()
+        try:
+            same = True
+            for seed in (20240229, 7):
+                sizes = (5, 1, 700, 155, 156, 157, 312, 313, (10, 4099), 3, 2, 40001, 1)
+                np.random.seed(seed)
+                a = [np.random.normal(size=n) for n in sizes]
+                sa = np.random.get_state()
+                np.random.seed(seed)
+                b = [self._native(n) for n in sizes]
+                sb = np.random.get_state()
+                same = (same and all(x.shape == y.shape and np.array_equal(x, y) for x, y in zip(a, b))
+                        and np.array_equal(sa[1], sb[1]) and sa[2:] == sb[2:])
+            self.ok = bool(same)
+        except Exception:
+            self.ok = False
+        finally:
+            np.random.set_state(keep)
+        if not self.ok:
+            import warnings
+            warnings.warn("the native normal fill does not reproduce this numpy build's legacy generator stream (numpy %s): the ball "
+                          'domains draw through np.random.normal (same numbers, ~2 x slower draws)' % np.__version__, RuntimeWarning)
+
+    def __call__(self, shape):
+        st = getattr(self._local, 'state', None)
+        if st is not None:
+            return self._fill(st, shape)
+        if self.ok is None:
+            self._probe()
+        if not self.ok or int(np.prod(shape)) < self.MIN:
+            return np.random.normal(size=shape)
+        return self._native(shape)
+
+
+_legacy_normal = _LegacyNormal()
 _FACE_TABLES = {}
 
 
@@ -323,7 +424,7 @@ class _NSphereBase:
 
     def surf(self, N):
         """N points uniform on the sphere of radius r, as a [dim, N] array"""
-        z = np.random.normal(size=(self.dim, N))
+        z = _legacy_normal((self.dim, N))
         return self.r * z / np.sqrt((z ** 2).sum(axis=0))
 
     def _ball(self, N):
@@ -335,13 +436,22 @@ class _NSphereBase:
         """one boundary group per sample time: int(N_b * factor(t)^dim) points on the sphere of radius factor(t)
         (the reference scales the unit-r surface by factor(t) only, src/dataset.py:103,196)"""
         out = []
-        for t in self.times.numpy():
-            fac = radius_factor(t)
-            n = int(N_b * fac ** self.dim)
-            pts = torch.from_numpy(self.surf(n) * fac).t().unsqueeze(1)
-            if n != 0:
-                out.append(torch.cat((t * torch.ones(n, 1, 1), pts), 2).requires_grad_(True))
+        with _legacy_normal.hold():
+            for t in self.times.numpy():
+                fac = radius_factor(t)
+                n = int(N_b * fac ** self.dim)
+                pts = torch.from_numpy(self.surf(n) * fac).t().unsqueeze(1)
+                if n != 0:
+                    out.append(torch.cat((t * torch.ones(n, 1, 1), pts), 2).requires_grad_(True))
         return out
+
+
+    def skip_boundary(self, N_b):
+        """the draws of boundary(N_b) -- numpy's stream ends where it would -- without the points: the post-step diagnostic
+        sample (src/training.py:166-167) is drawn in full by the reference but only its interior is ever read"""
+        with _legacy_normal.hold():
+            for t in self.times.numpy():
+                _legacy_normal((self.dim, int(N_b * self._radius_factor(t) ** self.dim)))
 
 
 class NSphere_TCone(_NSphereBase):
@@ -366,8 +476,11 @@ class NSphere_TCone(_NSphereBase):
             k -= 1
         return groups[::-1]
 
+    def _radius_factor(self, t):
+        return 1 - t
+
     def boundary(self, N_b):
-        return self._shell_groups(N_b, lambda t: 1 - t)
+        return self._shell_groups(N_b, self._radius_factor)
 
     def func_w(self, x):
         return self.r * (1 - x[:, :, 0]) - torch.sqrt(torch.sum(x[:, :, 1:] ** 2, 2))
@@ -436,18 +549,19 @@ class NSphere_THourglass(_NSphereBase):
             groups_late.append(torch.cat((entry[sel], piece(ks, L - ell, L)), 1))
         return sorted([*groups_first, *groups_late], key=lambda g: g.shape[1])
 
+    def _radius_factor(self, t):
+        return (self.T - self.T0 - t) if t < self._half() else t
+
     def boundary(self, N_b):
-        span, half = self.T - self.T0, self._half()
-        return self._shell_groups(N_b, lambda t: (span - t) if t < half else t)
+        return self._shell_groups(N_b, self._radius_factor)
 
     def func_w(self, x):
         t = x[:, :, 0]
         dist = torch.sqrt(torch.sum(x[:, :, 1:] ** 2, 2))
-        res = torch.ones_like(t)
         early = torch.le(t, self._half())
-        res[early] = self.r * ((self.T - self.T0) - t[early]) - dist[early]
-        res[~early] = self.r * t[~early] - dist[~early]
-        return res
+        # (a select, not two masked assignments: same value and same gradient per point, and nothing waits for the device -- a
+        #  boolean-mask index is a nonzero() whose size the host has to read back)
+        return torch.where(early, self.r * ((self.T - self.T0) - t) - dist, self.r * t - dist)
 
     def bound_pad(self, x):
         """Per-path densified grids for the evaluation of paths that start neither at T0 nor on the boundary
@@ -495,7 +609,10 @@ class Comb_loader(Dataset):
     [N, d] points are drawn here -- same RNG consumption -- and the [N, L, 1+d] tensors `interioru`, `interiorv`,
     `boundary` are materialised on first access; the engine works from the compact form (`compact()`)."""
 
-    def __init__(self, N_r, N_b, shape, device):
+    def __init__(self, N_r, N_b, shape, device, interior_only=False):
+        """interior_only: the sample is drawn in full -- every generator ends where it would -- but a list domain that can
+        consume its boundary draws without building the points (skip_boundary) does so, and `boundary` is empty: the post-step
+        diagnostic sample, of which only the interior is read."""
         self.N_r, self.N_b, self.shape, self.device = N_r, N_b, shape, device
         self._lazy, self._cache = None, {}
         if hasattr(shape, 'interior_x') and hasattr(shape, 'boundary_x'):
@@ -503,8 +620,11 @@ class Comb_loader(Dataset):
             return
         inner = shape.interior(N_r)
         if isinstance(inner, list):
-            self._cache['interioru'] = [g.requires_grad_(True) for g in inner]
-            self._cache['interiorv'] = [g.clone().detach().requires_grad_(True) for g in self._cache['interioru']]
+            self._cache['interioru'] = [g.requires_grad_(True) for g in inner]       # (interiorv: a copy, made when first asked for)
+            if interior_only and hasattr(shape, 'skip_boundary'):
+                shape.skip_boundary(N_b)
+                self._cache['boundary'] = []
+                return
         else:
             self._cache['interioru'] = inner.requires_grad_(True)
             self._cache['interiorv'] = shape.interior(N_r).clone().detach().requires_grad_(True)
@@ -513,7 +633,10 @@ class Comb_loader(Dataset):
 
     def _get(self, name):
         if name not in self._cache:
-            self._cache[name] = _paths(self.shape.times, self._lazy[name]).requires_grad_(True)
+            if self._lazy is None:        # list domains: the v sample is a copy of the u sample (14 MB at config-5 size; the engine reads the u sample for both)
+                self._cache[name] = [g.clone().detach().requires_grad_(True) for g in self._cache['interioru']]
+            else:
+                self._cache[name] = _paths(self.shape.times, self._lazy[name]).requires_grad_(True)
         return self._cache[name]
 
     interioru = property(lambda self: self._get('interioru'))
@@ -537,7 +660,7 @@ class Comb_loader(Dataset):
             self.pack(pinned=True)
         return self
 
-    def pack(self, pinned=False):
+    def pack(self, pinned=False, into=None):
         """List domains: all interior groups (u; the v sample is a copy of it) and boundary groups of the sample in ONE flat
         float64 buffer, with what the engine otherwise reads back from the device group by group, taken from the host copies
         here: the first time of every group, whether its paths share one time column, whether a boundary group sits on its
@@ -551,7 +674,10 @@ class Comb_loader(Dataset):
             self._packed = False
             return False
         total = sum(t.numel() for t in tensors)
-        slot, buf = _ARENAS.take(total) if pinned else (None, torch.empty(total, dtype=torch.float64))
+        if into is not None:              # (a caller's buffer: the sampling process packs into shared memory, sampler_proc.py)
+            slot, buf = None, into
+        else:
+            slot, buf = _ARENAS.take(total) if pinned else (None, torch.empty(total, dtype=torch.float64))
         offs, o = [], 0
         for t in tensors:
             buf[o:o + t.numel()].view(t.shape).copy_(t)

@@ -175,6 +175,16 @@ class NODE_WAN_solver:
                                           # kernels) and evaluates the L^p diagnostic by replaying ONE captured graph each
                                           # (Engine.refill_compact, _l_norm_replayed); same arithmetic, same fallback rule as the
                                           # sub-step graphs.  False: eager launches
+        self.defer_list_readback = os.environ.get('XW_DEFER_LIST', '1') != '0'
+                                          # list domains (11-20 groups per sample) with the sampling thread: an outer iteration's
+                                          # sub-steps are queued without a read-back and the NEXT sample's groups are loaded while
+                                          # the GPU walks them; one read-back per outer iteration (_list_iteration_deferred).
+                                          # False: every sub-iteration is synchronised like the reference's loop
+        self.sampler_process = os.environ.get('XW_SAMPLER_PROCESS', '1') != '0'
+                                          # the time-varying ball domains: the samples are drawn by a forked child process instead
+                                          # of a helper thread (sampler_proc.py: the two sides of an outer iteration are ~2000 small
+                                          # host operations each and two threads share the interpreter lock); same draws, the
+                                          # generator states come back when train() ends
         self.reuse_test_net = True        # v, dv/dt, nabla_x v(t_0) are evaluated once per (phi, sample) and shared by the
                                           # sub-steps of an outer iteration -- bit-identical results (the reference
                                           # recomputes the same values); bench.py times the sub-steps WITHOUT it
@@ -209,7 +219,9 @@ class NODE_WAN_solver:
         s = self.setup
         return self.domain(s['shape_param'], s['dim'], s['T0'], s['T'], s['N_t'])
 
-    def _loader(self, domain):
+    def _loader(self, domain, interior_only=False):
+        if interior_only and self.world is None and not self.device_sampling and not self.tabulate_on_host:
+            return sampling.Comb_loader(self.setup['N_r'], self.setup['N_b'], domain, self.device, interior_only=True)
         if self.world is not None and self.rank_local_sampling and hasattr(domain, 'interior_x'):
             return sampling.RankCubeLoader(self.setup['N_r'], self.setup['N_b'], domain, self.device, self.world.rank, self.world.size)
         if self.device_sampling and hasattr(domain, 'device_sample'):
@@ -356,13 +368,14 @@ class NODE_WAN_solver:
             # start values: h on the first points of the groups that start at T0, g on those that start on the moving boundary
             P0 = torch.cat([x[:, 0, :] for x in Xs], 0)
             n = [x.shape[0] for x in Xs]
-            sel = torch.cat([torch.full((k,), a, dtype=torch.bool) for k, a in zip(n, at0)]).to(P0.device)
-            i_h, i_g = torch.nonzero(sel).reshape(-1), torch.nonzero(~sel).reshape(-1)
-            start = torch.zeros(P0.shape[0], dtype=torch.float64, device=P0.device)
-            if i_h.numel():
-                start = start.index_copy(0, i_h, self.func_h(P0.index_select(0, i_h)).reshape(-1).double())
-            if i_g.numel():
-                start = start.index_copy(0, i_g, self.func_g(P0.index_select(0, i_g).unsqueeze(1)).reshape(-1).double())
+            # (groups are contiguous row ranges of P0: slices, not an index tensor -- see Engine.tabulate_sample)
+            rows = P0.split(n)
+            rows_h, rows_g = [r for r, a in zip(rows, at0) if a], [r for r, a in zip(rows, at0) if not a]
+            hval = self.func_h(torch.cat(rows_h, 0)).reshape(-1).double() if rows_h else None
+            gval = self.func_g(torch.cat(rows_g, 0).unsqueeze(1)).reshape(-1).double() if rows_g else None
+            it_h = iter(hval.split([r.shape[0] for r in rows_h])) if hval is not None else None
+            it_g = iter(gval.split([r.shape[0] for r in rows_g])) if gval is not None else None
+            start = torch.cat([next(it_h) if a else next(it_g) for a in at0], 0)
             starts = iter(zip(start.split(n), at0))
             net.blob.check_alias()
 
@@ -392,8 +405,10 @@ class NODE_WAN_solver:
         # iteration and the domain + sample of the next one WHILE the main thread waits for the GPU -- in the reference's
         # order, and nothing beyond the last iteration, so the generator ends where the reference's does.  A user stop
         # callback may draw random numbers itself between those calls: then everything stays in line.
-        pool = None
-        if self.overlap_sampling and self.stop is None and not self.device_sampling:
+        pool = self._sampling_process()
+        if pool is not None:
+            pool.begin()
+        elif self.overlap_sampling and self.stop is None and not self.device_sampling:
             from concurrent.futures import ThreadPoolExecutor
             pool = ThreadPoolExecutor(max_workers=1, initializer=torch.set_num_threads, initargs=(torch.get_num_threads(),))
 
@@ -402,7 +417,7 @@ class NODE_WAN_solver:
         def draw_ahead(domain, last):
             t_ = time.perf_counter()
             pin = lambda ld: ld.pin() if hasattr(ld, 'pin') else ld     # noqa: E731  (page-locked: asynchronous uploads)
-            after = pin(self._loader(domain))
+            after = pin(self._loader(domain, interior_only=True))     # (the diagnostic's sample: only its interior is read)
             if last:
                 self._sampler_seconds += time.perf_counter() - t_
                 return after, None, None
@@ -418,6 +433,30 @@ class NODE_WAN_solver:
         finally:
             if pool is not None:
                 pool.shutdown(wait=True)
+
+    def _sampling_process(self):
+        """the forked sampler of sampler_proc.py when this run can use it, else None (the helper thread, or no overlap at all)"""
+        if not (self.sampler_process and self.overlap_sampling and self.defer_list_readback and self.stop is None and self.world is None
+                and not self.device_sampling and not self.tabulate_on_host and isinstance(self.domain, type)
+                and issubclass(self.domain, sampling._NSphereBase) and hasattr(os, 'fork')):
+            return None
+        s = self.setup
+        key = (self.domain, s['N_r'], s['N_b'], s['dim'], s['N_t'], s['T0'], s['T'], repr(s['shape_param']))
+        held = getattr(self, '_sampler_proc', None)
+        if held is not None and held[0] == key and held[1].proc.is_alive():
+            return held[1]
+        if held is not None:
+            held[1].close()
+        try:
+            from .sampler_proc import SamplerProcess
+            sp = SamplerProcess(self.domain, dict(s), s['N_r'], s['N_b'])
+        except Exception as e:          # (no shared memory, no fork: the helper thread draws the same numbers)
+            import warnings
+            warnings.warn('the sampling process could not be started (%s): drawing on a helper thread' % e, RuntimeWarning)
+            self.sampler_process = False
+            return None
+        self._sampler_proc = (key, sp)
+        return sp
 
     def _new_domain_probe(self):
         """the domain CLASS's compact-draw capability, without constructing an instance (construction draws random numbers)"""
@@ -603,11 +642,108 @@ class NODE_WAN_solver:
             sd[k_] = parts[i].clone()
         return sd
 
+    def _prepare_groups(self, points, domain, pairs_last=False):
+        """the groups of a sample, loaded into the engine (the cached Group objects are refilled)"""
+        eng = self.engine
+        comp = points.compact() if hasattr(points, 'compact') else None
+        if (comp is not None and len(self._group_cache) == 1 and self._group_cache[0] is not None and self.capture_refill
+                and self.world is None and eng.use_graphs and not comp[0].is_cuda and not self.tabulate_on_host):
+            # the cube after its first sample: static inputs + one graph replay (Engine.refill_compact)
+            return [eng.refill_compact(self._group_cache[0], comp, domain)]
+        shards = self._shard(self._groups(points))
+        if len(self._group_cache) != len(shards):     # (the number of groups varies from sample to sample: keep the ones that stay)
+            self._group_cache = self._group_cache[:len(shards)] + [None] * (len(shards) - len(self._group_cache))
+        # list domains: the callables are evaluated once for all groups of the sample; the structure guard runs on the
+        # largest group of the sample (all groups are slices of the same draw)
+        hints = self._group_hints if (self._group_hints is not None and self.world is None) else [None] * len(shards)
+        tabs = eng.tabulate_sample([sh[:3] for sh in shards], domain, hints=hints) if len(shards) > 1 else [None]
+        big = max(range(len(shards)), key=lambda i: shards[i][0].shape[0] * shards[i][0].shape[1])
+        order = list(range(len(shards)))
+        if pairs_last:
+            # (a single-slice group at T0 reads five sums back, Engine.load_group: behind queued sub-steps that read-back waits for
+            #  all of them, so those groups are loaded after everything that does not wait)
+            T0 = self.setup['T0']
+            waits = lambda i: (shards[i][0].shape[1] == 1 or shards[i][2].shape[1] == 1) and hints[i] is not None and (  # noqa: E731
+                hints[i]['t0'] == T0 or hints[i]['tb0'] == T0)
+            order.sort(key=lambda i: bool(waits(i)) or hints[i] is None)
+        groups = [None] * len(shards)
+        for i in order:
+            du, dv, bd, ng, nbg = shards[i]
+            groups[i] = eng.load_group(du, dv, bd, domain, ng, nbg, into=self._group_cache[i], shared_grid_t0=self._grid_hint, tab=tabs[i],
+                                       verify=(i == big), hints=hints[i])
+        return groups
+
+    def _list_iteration_deferred(self, groups, domain, ahead, pool, draw_ahead, k, last, past_losses, times):
+        """One outer iteration on a list domain (11-20 groups per sample) whose host work runs BESIDE its GPU work: the sub-steps
+        of all groups are queued without a read-back (per-group losses and theta after every generator sub-iteration stay on the
+        device), then -- while the GPU walks that chain of ~60 dependent sub-steps -- the host takes the sampling thread's
+        result, queues the diagnostic and loads the NEXT sample's groups (callables tabulated, Group objects refilled: same
+        stream, so behind the sub-steps that still read the old contents), and only then reads everything back at once.  The
+        synchronous order (_iterate) has the GPU idle during the 10 ms of loading and the host idle during the 13 ms of sub-steps.
+        Same values, same files, same order of writes; needs the sampling thread (no stop hook) and one GPU."""
+        eng, d, n1, n2 = self.engine, self.setup['dim'], self.n1, self.n2
+        # (host seconds per phase, summed over the run: tools/train_cfg5.py prints them)
+        phase = self.__dict__.setdefault('_list_phase_seconds', dict.fromkeys(('substeps', 'sampler_wait', 'diagnostic', 'load_next', 'read_back', 'files'), 0.0))
+        clock = time.perf_counter
+
+        def lap(name, t):
+            now = clock()
+            phase[name] += now - t
+            return now
+        tick = clock()
+        lu, snaps = [], []
+        for _ in range(n1):
+            eng.begin_substep('u', True)
+            for G in groups:
+                eng.generator_step(G)
+                lu.append(eng.loss_u().clone())
+            snaps.append(eng.theta.data.clone())
+        for _ in range(n2):
+            eng.begin_substep('v', True)
+            for G in groups:
+                eng.discriminator_step(G)
+        lv = eng.loss_v().clone()
+        tick = lap('substeps', tick)
+        points_after, nxt_domain, nxt_points = ahead.result()
+        ahead = pool.submit(draw_ahead, nxt_domain, k + 1 == last) if k < last else None
+        tick = lap('sampler_wait', tick)
+        L2 = self._l_norm(points_after, domain.V(), as_tensor=True)
+        tick = lap('diagnostic', tick)
+        prepared = None
+        if nxt_points is not None:
+            prepared = self._prepare_groups(nxt_points, nxt_domain, pairs_last=True)
+            self._group_cache = prepared
+        tick = lap('load_next', tick)
+        row = torch.cat([torch.stack(lu).reshape(-1).double(), lv.reshape(1).double(), L2.reshape(1)]).tolist()   # the ONE read-back
+        tick = lap('read_back', tick)
+        ng, keys = len(groups), None
+        for i in range(n1):
+            vals = row[i * ng:(i + 1) * ng]
+            self.last_loss_u = vals[-1]
+            self.av_l = 0
+            for x_ in vals:
+                self.av_l += x_                   # (summed in group order, like the reference's running sum)
+            past_losses.append(self.av_l)
+            past_losses.write('losses_NODE_' + str(d) + '.json')
+            if self.av_l < self.best_l:
+                keys = keys or self._state_dict_layout()
+                torch.save(self._state_dict_from(snaps[i], keys), 'best_model_weights_NODE.pth')   # u_net as it was after sub-iteration i
+                self.best_l = self.av_l
+        self.last_loss_v, self._last_L2 = row[n1 * ng], row[n1 * ng + 1]
+        times.append(time.time())
+        with open('L2_NODE_' + str(d) + '.json', 'w') as fh:
+            json.dump([self._last_L2], fh)
+        times.write('Time_NODE_' + str(d) + '.json')
+        lap('files', tick)
+        return prepared, nxt_domain, nxt_points, ahead
+
     def _iterate(self, report, report_it, show_plt, past_losses, times, pool, draw_ahead):
         d = self.setup['dim']
         eng = self.engine
-        nxt_domain = nxt_points = ahead = None
+        nxt_domain = nxt_points = ahead = prepared = None
         last = self.iterations - 1
+        if hasattr(pool, 'first') and self.iterations > 0:        # (the sampling process owns the generators while train() runs)
+            nxt_domain, nxt_points = pool.first()
         with torch.cuda.device(self.device):
             for k in range(self.iterations):
                 domain = nxt_domain if nxt_domain is not None else self._new_domain()
@@ -617,29 +753,25 @@ class NODE_WAN_solver:
                     ahead = pool.submit(draw_ahead, domain, k == last)   # draws of a ball-domain sample take as long as its sub-steps)
                 # (the reference also evaluates L_norm here, src/training.py:123, and overwrites the value unread at :167;
                 #  the call draws no random numbers and writes nothing, so it is not repeated)
-                comp = points.compact() if hasattr(points, 'compact') else None
-                if (comp is not None and len(self._group_cache) == 1 and self._group_cache[0] is not None and self.capture_refill
-                        and self.world is None and eng.use_graphs and not comp[0].is_cuda and not self.tabulate_on_host):
-                    # the cube after its first sample: static inputs + one graph replay (Engine.refill_compact)
-                    shards = None
-                    groups = [eng.refill_compact(self._group_cache[0], comp, domain)]
+                if prepared is not None:                   # (list domains: loaded behind the previous iteration's sub-steps)
+                    groups, prepared = prepared, None
                 else:
-                    shards = self._shard(self._groups(points))
-                if shards is not None and len(self._group_cache) != len(shards):
-                    self._group_cache = [None] * len(shards)
-                # list domains: the callables are evaluated once for all groups of the sample; the structure guard runs on the
-                # largest group of the sample (all groups are slices of the same draw)
-                if shards is not None:
-                    hints = self._group_hints if (self._group_hints is not None and self.world is None) else [None] * len(shards)
-                    tabs = eng.tabulate_sample([sh[:3] for sh in shards], domain, hints=hints) if len(shards) > 1 else [None]
-                    big = max(range(len(shards)), key=lambda i: shards[i][0].shape[0] * shards[i][0].shape[1])
-                    groups = [eng.load_group(du, dv, bd, domain, ng, nbg, into=old, shared_grid_t0=self._grid_hint, tab=tb, verify=(i == big),
-                                             hints=hn)
-                              for i, ((du, dv, bd, ng, nbg), old, tb, hn) in enumerate(zip(shards, self._group_cache, tabs, hints))]
+                    groups = self._prepare_groups(points, domain)
                 self._group_cache = groups
                 several = len(groups) > 1
                 for G in groups:
                     G.persistent = not several        # list domains: group shapes change every sample -> no graph capture
+                if several and ahead is not None and self.world is None and self.defer_list_readback:
+                    prepared, nxt_domain, nxt_points, ahead = self._list_iteration_deferred(groups, domain, ahead, pool, draw_ahead, k, last,
+                                                                                            past_losses, times)
+                    if report and k % report_it == 0:
+                        print('iteration: ' + str(k), 'Loss u: ' + str(self.last_loss_u), 'Loss v: ' + str(self.last_loss_v))
+                        if self.func_u_sol is not None:
+                            print('L^2 norm error: ' + str(self._last_L2))
+                            from utils.auxillary_funcs import proj
+                            proj(self.u_net, self.setup, k, self.device, axes=[0, 1], resolution=200, colours=20, save=True,
+                                 show=show_plt, func_u_sol=self.func_u_sol)
+                    continue
                 for _ in range(self.n1):
                     self.av_l = 0
                     eng.begin_substep('u', several)
