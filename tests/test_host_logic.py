@@ -442,10 +442,20 @@ def test_sampling_process_draws_what_the_sampling_thread_draws(name):
             sp.shutdown()
             end = (torch.rand(3), np.random.rand(3), np.random.normal(size=3))
             assert torch.equal(end[0], end_ref[0]) and np.array_equal(end[1], end_ref[1]) and np.array_equal(end[2], end_ref[2])
+        # the child belongs to the process: a second handle (another solver) talks to the same one; it ends with the server
+        other = sampler_proc.SamplerProcess(cls, setup, 2 * N_r, N_b)
+        assert other.proc.pid == sp.proc.pid and other.proc.is_alive()
+        other.begin()
+        d1, s1 = other.first()
+        other.shutdown()
+        assert sum(g.shape[0] for g in s1.interioru if g[0, 0, 0] == 0.0) <= 2 * N_r and len(s1.interioru) > 1
     finally:
         if sp is not None:
             sp.close()
-            assert not sp.proc.is_alive()
+        srv = sampler_proc._SERVER
+        if srv is not None:
+            srv.close()
+            assert not srv.proc.is_alive() and not srv.pools
         torch.set_rng_state(keep_t)
         np.random.set_state(keep_n)
 

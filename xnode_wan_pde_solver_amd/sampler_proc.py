@@ -10,6 +10,11 @@ the start of train() and takes them back at the end, so the streams end exactly 
 sample into a slot of shared memory that the parent has page-locked: the upload is one asynchronous copy straight from the slot.
 
 Same draws, same order, same values as the sampling thread (solver._train.draw_ahead); tests/test_host_logic.py compares them.
+
+ONE child per process, forked at the first train() that uses it and shared by every solver after that: a fork write-protects the
+parent's pages, the GPU driver re-validates the process's memory on the next submission, and that next submission takes 0.15-0.35 s
+in a small process and seconds in one that holds many allocations (measured: tools/sampler_proc_cost.py).  Sample slots are
+attached by name, so a solver with larger samples gets larger slots without another fork.
 """
 import math
 import os
@@ -24,13 +29,13 @@ from . import sampling
 import atexit
 import weakref
 
-_LIVE = weakref.WeakSet()
+_SERVER = None
 
 
 @atexit.register
 def _close_all():
-    for sp in list(_LIVE):
-        sp.close()
+    if _SERVER is not None:
+        _SERVER.close()
 
 
 SLOTS = 4          # two per request (diagnostic sample, next sample); a request reuses the slots of the one before the last
@@ -85,9 +90,10 @@ def _pack(loader, slot):
     return (total, offs, hints, n, nu), (None if fits else buf[:total].clone())
 
 
-def _child(conn, slots, solver_bits):
+def _child(conn):
     """the sampling process: draws what solver._train.draw_ahead draws, in its order"""
-    domain_cls, setup, N_r, N_b = solver_bits
+    import _posixshmem
+    import mmap
     try:
         import ctypes
         import signal
@@ -95,9 +101,9 @@ def _child(conn, slots, solver_bits):
     except Exception:
         pass
     torch.set_num_threads(1)          # (a forked child must not enter an OpenMP region of the parent's thread pool)
-    new_domain = lambda: domain_cls(setup['shape_param'], setup['dim'], setup['T0'], setup['T'], setup['N_t'])   # noqa: E731
     send = lambda obj: conn.send_bytes(pickle.dumps(obj, protocol=pickle.HIGHEST_PROTOCOL))                      # noqa: E731
-    domain = None
+    attached = {}
+    domain = new_domain = slots = N_r = N_b = None
     try:
         while True:
             try:
@@ -106,8 +112,21 @@ def _child(conn, slots, solver_bits):
                 break
             try:
                 if msg[0] == 'begin':
-                    torch.set_rng_state(msg[1])
-                    np.random.set_state(msg[2])
+                    _, (domain_cls, setup, N_r, N_b), names, elems, t_state, n_state = msg
+                    for name in names:
+                        if name not in attached:
+                            # (mapped by hand: multiprocessing's SharedMemory would start a resource tracker of this child's own,
+                            #  which "cleans up" -- unlinks -- the parent's blocks when the child ends)
+                            fd = _posixshmem.shm_open('/' + name, os.O_RDWR, mode=0o600)
+                            try:
+                                shm = mmap.mmap(fd, 8 * elems)
+                            finally:
+                                os.close(fd)
+                            attached[name] = (shm, torch.frombuffer(shm, dtype=torch.float64, count=elems))
+                    slots = [attached[name][1] for name in names]
+                    new_domain = lambda: domain_cls(setup['shape_param'], setup['dim'], setup['T0'], setup['T'], setup['N_t'])   # noqa: E731
+                    torch.set_rng_state(t_state)
+                    np.random.set_state(n_state)
                     domain = None
                     send(('ok',))
                 elif msg[0] == 'first':
@@ -124,12 +143,115 @@ def _child(conn, slots, solver_bits):
                         send(('ok', after, domain, _pack(sampling.Comb_loader(N_r, N_b, domain, 'cpu'), slots[slot_b])))
                 elif msg[0] == 'finish':
                     send(('ok', torch.get_rng_state(), np.random.get_state()))
+                elif msg[0] == 'drop':
+                    for name in msg[1]:
+                        ent = attached.pop(name, None)
+                        if ent is not None:
+                            slots = None
+                            shm, t = ent
+                            del t, ent
+                            try:
+                                shm.close()
+                            except Exception:
+                                pass
+                    send(('ok',))
                 elif msg[0] == 'quit':
                     break
             except Exception:
                 send(('error', traceback.format_exc()))
     finally:
         os._exit(0)                   # (no interpreter shutdown: the parent's GPU runtime was copied into this process by the fork)
+
+
+class _Server:
+    """the one sampling child of this process and the shared, page-locked sample slots (kept per size)"""
+
+    def __init__(self):
+        import multiprocessing
+        ctx = multiprocessing.get_context('fork')
+        self.conn, child_conn = ctx.Pipe()
+        self.proc = ctx.Process(target=_child, args=(child_conn,), daemon=True)
+        self.proc.start()
+        child_conn.close()
+        self.pools = {}               # elems -> (shared memory blocks, tensors over them, page-locked addresses)
+        self.user = None              # the SamplerProcess that holds the streams right now
+
+    def send(self, *msg):
+        self.conn.send_bytes(pickle.dumps(msg, protocol=pickle.HIGHEST_PROTOCOL))
+
+    def recv(self):
+        try:
+            out = pickle.loads(self.conn.recv_bytes())
+        except EOFError:
+            raise RuntimeError('the sampling process ended unexpectedly (exit code %r)' % self.proc.exitcode)
+        if out[0] == 'error':
+            raise RuntimeError('the sampling process failed:\n' + out[1])
+        return out[1:]
+
+    def slots(self, elems):
+        from multiprocessing import shared_memory
+        if elems not in self.pools:
+            st = os.statvfs('/dev/shm')
+            if st.f_bavail * st.f_frsize < SLOTS * 8 * elems + (64 << 20):
+                raise RuntimeError('not enough shared memory for %d sample slots of %d MB' % (SLOTS, 8 * elems >> 20))
+            for old in [e for e in self.pools if e < elems]:      # (one pool is in use at a time: smaller ones go)
+                self.drop(old)
+            shm = [shared_memory.SharedMemory(create=True, size=8 * elems) for _ in range(SLOTS)]
+            tens = [torch.frombuffer(s.buf, dtype=torch.float64, count=elems) for s in shm]
+            locked = []
+            if torch.cuda.is_available():
+                rt = torch.cuda.cudart()
+                for t in tens:
+                    if int(rt.cudaHostRegister(t.data_ptr(), t.numel() * 8, 0)) == 0:
+                        locked.append(t.data_ptr())
+            self.pools[elems] = (shm, tens, locked)
+        usable = min(e for e in self.pools if e >= elems)
+        shm, tens, _ = self.pools[usable]
+        return [s.name for s in shm], tens, usable
+
+    def drop(self, elems):
+        shm, tens, locked = self.pools.pop(elems)
+        try:
+            if self.proc.is_alive():
+                self.send('drop', [s.name for s in shm])
+                self.recv()
+        except Exception:
+            pass
+        if locked and torch.cuda.is_available():
+            rt = torch.cuda.cudart()
+            for p in locked:
+                rt.cudaHostUnregister(p)
+        del tens
+        for s in shm:
+            try:
+                s.unlink()
+            except Exception:
+                pass
+            try:
+                s.close()             # (refused while a sample still views the slot: the mapping then goes with its last view)
+            except Exception:
+                pass
+
+    def close(self):
+        try:
+            if self.proc.is_alive():
+                self.send('quit')
+                self.proc.join(timeout=5)
+                if self.proc.is_alive():
+                    self.proc.terminate()
+        except Exception:
+            pass
+        for elems in list(self.pools):
+            self.drop(elems)
+
+
+def _server():
+    global _SERVER
+    if _SERVER is None or not _SERVER.proc.is_alive():
+        if _SERVER is not None:
+            _SERVER.close()
+        _SERVER = _Server()
+    return _SERVER
 
 
 class _Future:
@@ -141,47 +263,21 @@ class _Future:
 
 
 class SamplerProcess:
-    """Stands where solver._train puts its one-thread pool: submit(draw_ahead, domain, last) -> future with result()."""
+    """A solver's handle on the sampling child.  Stands where solver._train puts its one-thread pool:
+    submit(draw_ahead, domain, last) -> future with result()."""
 
     def __init__(self, domain_cls, setup, N_r, N_b):
-        import multiprocessing
-        from multiprocessing import shared_memory
         d, L = setup['dim'], setup['N_t']
-        elems = (N_r * (L + 1) + N_b * L) * (1 + d)       # every path at full length plus an entry point, a full shell per sample time
-        self.N_r, self.N_b = N_r, N_b
-        st = os.statvfs('/dev/shm')
-        if st.f_bavail * st.f_frsize < SLOTS * 8 * elems + (64 << 20):
-            raise RuntimeError('not enough shared memory for %d sample slots of %d MB' % (SLOTS, 8 * elems >> 20))
-        self.shm = [shared_memory.SharedMemory(create=True, size=8 * elems) for _ in range(SLOTS)]
-        self.slots = [torch.frombuffer(s.buf, dtype=torch.float64, count=elems) for s in self.shm]
-        ctx = multiprocessing.get_context('fork')
-        self.conn, child_conn = ctx.Pipe()
-        self.proc = ctx.Process(target=_child, args=(child_conn, self.slots, (domain_cls, setup, N_r, N_b)), daemon=True)
-        self.proc.start()
-        child_conn.close()
-        self.registered = []
-        if torch.cuda.is_available():                      # (after the fork: the child maps the plain shared pages)
-            rt = torch.cuda.cudart()
-            for t in self.slots:
-                if int(rt.cudaHostRegister(t.data_ptr(), t.numel() * 8, 0)) == 0:
-                    self.registered.append(t.data_ptr())
+        self.elems = (N_r * (L + 1) + N_b * L) * (1 + d)   # every path at full length plus an entry point, a full shell per sample time
+        self.config = (domain_cls, dict(setup), N_r, N_b)
+        self.server = _server()
+        self.server.slots(self.elems)                       # (fails here, not in train(), when there is no room for the slots)
         self.request = 0
         self.outstanding = None
         self.active = False
-        _LIVE.add(self)
+        self.slots = None
 
-    # -- protocol ------------------------------------------------------------------------------------------------------
-    def _send(self, *msg):
-        self.conn.send_bytes(pickle.dumps(msg, protocol=pickle.HIGHEST_PROTOCOL))
-
-    def _recv(self):
-        try:
-            out = pickle.loads(self.conn.recv_bytes())
-        except EOFError:
-            raise RuntimeError('the sampling process ended unexpectedly (exit code %r)' % self.proc.exitcode)
-        if out[0] == 'error':
-            raise RuntimeError('the sampling process failed:\n' + out[1])
-        return out[1:]
+    proc = property(lambda self: self.server.proc)
 
     def _sample(self, slot, packed):
         meta, inline = packed
@@ -189,28 +285,33 @@ class SamplerProcess:
 
     def begin(self):
         """hand the generator streams over (they come back in shutdown)"""
-        self._send('begin', torch.get_rng_state(), np.random.get_state())
-        self._recv()
+        sv = self.server
+        if sv.user is not None and sv.user is not self:
+            raise RuntimeError('the sampling process is held by another solver that is training right now')
+        names, self.slots, elems = sv.slots(self.elems)
+        sv.send('begin', self.config, names, elems, torch.get_rng_state(), np.random.get_state())
+        sv.recv()
+        sv.user = self
         self.active, self.outstanding = True, None
 
     def first(self):
         slot = (2 * self.request) % SLOTS
         self.request += 1
-        self._send('first', slot)
-        domain, packed = self._recv()
+        self.server.send('first', slot)
+        domain, packed = self.server.recv()
         return domain, self._sample(slot, packed)
 
     def submit(self, _fn, _domain, last):
         a = (2 * self.request) % SLOTS
         self.request += 1
-        self._send('draw', a, a + 1, bool(last))
+        self.server.send('draw', a, a + 1, bool(last))
         self.outstanding = (a, a + 1)
         return _Future(self)
 
     def _take(self):
         a, b = self.outstanding
         self.outstanding = None
-        after, domain, nxt = self._recv()
+        after, domain, nxt = self.server.recv()
         return self._sample(a, after), domain, (self._sample(b, nxt) if nxt is not None else None)
 
     def shutdown(self, wait=True):
@@ -218,40 +319,18 @@ class SamplerProcess:
         if not self.active:
             return
         self.active = False
-        if self.outstanding is not None:      # (train() left early: the request in flight is drained first)
-            self._take()
-        self._send('finish')
-        t_state, n_state = self._recv()
-        torch.set_rng_state(t_state)
-        np.random.set_state(n_state)
+        try:
+            if self.outstanding is not None:      # (train() left early: the request in flight is drained first)
+                self._take()
+            self.server.send('finish')
+            t_state, n_state = self.server.recv()
+            torch.set_rng_state(t_state)
+            np.random.set_state(n_state)
+        finally:
+            self.server.user = None
 
     def close(self):
-        try:
-            if self.proc.is_alive():
-                self._send('quit')
-                self.proc.join(timeout=5)
-                if self.proc.is_alive():
-                    self.proc.terminate()
-        except Exception:
-            pass
-        if self.registered and torch.cuda.is_available():
-            rt = torch.cuda.cudart()
-            for p in self.registered:
-                rt.cudaHostUnregister(p)
-        self.registered, self.slots = [], []
-        for s in self.shm:
-            try:
-                s.unlink()
-            except Exception:
-                pass
-            try:
-                s.close()             # (refused while a sample still views the slot: the mapping then goes with its last view)
-            except Exception:
-                pass
-        self.shm = []
-
-    def __del__(self):
-        try:
-            self.close()
-        except Exception:
-            pass
+        """(the child and the slots belong to the process and stay for the next solver)"""
+        if self.active:
+            self.shutdown()
+        self.slots = None

@@ -407,7 +407,14 @@ class NODE_WAN_solver:
         # callback may draw random numbers itself between those calls: then everything stays in line.
         pool = self._sampling_process()
         if pool is not None:
-            pool.begin()
+            try:
+                pool.begin()
+            except Exception as e:       # (held by another solver that is training, or the child is gone: the helper thread draws the same numbers)
+                import warnings
+                warnings.warn('the sampling process is not available (%s): drawing on a helper thread' % e, RuntimeWarning)
+                pool = None
+        if pool is not None:
+            pass
         elif self.overlap_sampling and self.stop is None and not self.device_sampling:
             from concurrent.futures import ThreadPoolExecutor
             pool = ThreadPoolExecutor(max_workers=1, initializer=torch.set_num_threads, initargs=(torch.get_num_threads(),))
