@@ -316,7 +316,7 @@ int xw_mt19937_uniform_f32(void* state_blob, long blob_bytes, float* out, long n
 /* float64 standard normals from numpy's GLOBAL legacy generator state (np.random.get_state(): key[624], pos, has_gauss,
  * cached_gaussian -- the four are updated in place and go back with np.random.set_state): the numbers, their order and the
  * state left behind are those of np.random.normal(size = n) (legacy_gauss, polar method; the ball domains draw their points
- * that way, src/dataset.py:29-34: "same seeds" = this stream), 2.3 x faster than numpy's value-by-value walk.  The caller
+ * that way, src/dataset.py:65, 180: "same seeds" = this stream), 2.3 x faster than numpy's value-by-value walk.  The caller
  * verifies against numpy once and falls back to numpy otherwise.  Returns 0, or XW_E_ARG for pos outside 0..624 / null pointers. */
 int xw_mt19937_legacy_normal_f64(unsigned int* key, int* pos, int* has_gauss, double* cached_gaussian, double* out, long n);
 

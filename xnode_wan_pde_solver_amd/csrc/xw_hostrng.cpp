@@ -86,7 +86,7 @@ extern "C" int xw_mt19937_uniform_f32(void* state_blob, long blob_bytes, float* 
 }
 
 // ---- numpy's legacy normal stream ------------------------------------------------------------------------------------------
-// The ball domains draw their points with np.random.normal on numpy's GLOBAL RandomState (src/dataset.py:29-34, 160-166:
+// The ball domains draw their points with np.random.normal on numpy's GLOBAL RandomState (src/dataset.py:65, 180:
 // "same seeds" = this stream too): legacy_gauss of numpy/random/src/legacy/legacy-distributions.c, the polar method on pairs of
 // 53-bit doubles of the mt19937 words, the second value of a pair cached in the state.  numpy walks it value by value, 18.6 ns
 // each, 0.3 M per hourglass sample -- what bounded the ball domains' train().  Here the words of a state block are
