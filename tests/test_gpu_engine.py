@@ -908,6 +908,40 @@ def test_pipelined_training_loop_leaves_exactly_what_the_synchronous_one_does(tm
     assert a[3] == b[3] and a[4] == b[4] and a[5] == b[5] and a[6] == b[6] and a[7] == b[7]
 
 
+@pytest.mark.parametrize('case', ['ref_traj_cone_ex43_d3_seed0', 'ref_traj_hourglass_ex43_d3_seed1',
+                                  'ref_traj_cone_ex43_d10_full_seed2', 'ref_traj_hourglass_ex43_d10_full_seed3'])
+def test_ball_domain_fast_loop_ends_where_the_reference_ends(golden_dir, tmp_path, case):
+    """The same reference runs as above through the loop a hook-free train() takes on the ball domains -- one read-back per outer
+    iteration, the next sample loaded behind the queued sub-steps, the samples drawn by the forked sampling process, h / f / g
+    tabulated on the GPU -- compared where that loop can be compared without a hook: u_theta on the fixture's probe after the
+    last outer iteration against the reference's last logged value (theta does not change after the last generator
+    sub-iteration), and the loss list's length.  The d = 3 cases are 100 / 60 outer iterations of ~12 groups each."""
+    import configs.Ex4_3_funcs as F
+    z, params = load(golden_dir, case)
+    params.pop('funcs')
+    ref = z['rel_l2']
+    probe, sol = torch.from_numpy(z['probe']), torch.from_numpy(z['probe_sol'])
+    S = make_solver(params, int(z['seed']), F=F)
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        losses = S.train(report=False)
+    finally:
+        os.chdir(cwd)
+    assert getattr(S, '_sampler_proc', None) is not None and '_list_phase_seconds' in S.__dict__      # (the loop under test ran)
+    assert len(losses) == len(ref)
+    with torch.no_grad():
+        up = S.u_net(probe).squeeze(2).cpu()
+    got = float(torch.sqrt(torch.mean((up - sol) ** 2) / torch.mean(sol ** 2)))
+    out = os.environ.get('XW_DUMP_TRAJ')
+    if out:
+        print('%s: probe error after the last outer iteration %.12g, reference %.12g (relative difference %.2e)'
+              % (case, got, float(ref[-1]), abs(got - float(ref[-1])) / float(ref[-1])))
+    # (float64 samples end to end; measured on the MI355X: 1.5e-10 relative after 100 outer iterations on the cone, 7e-14 at full size)
+    np.testing.assert_allclose(got, float(ref[-1]), rtol=1e-7)
+    assert abs(got - float(ref[-1])) < 1e-2
+
+
 @pytest.mark.parametrize('domain,seed', [('NSphere_THourglass', 5), ('NSphere_TCone', 6)])
 def test_list_domain_loop_with_one_read_back_leaves_exactly_what_the_synchronous_one_does(tmp_path, domain, seed):
     """solver.defer_list_readback (ball domains, 11-20 groups per sample): all sub-steps of an outer iteration queued without a
