@@ -19,6 +19,18 @@ if 'sync' in sys.argv:          # the synchronous loop (what a stop callback or 
         torch.cuda.synchronize(); t0 = time.perf_counter(); S.train(); torch.cuda.synchronize(); dt = time.perf_counter() - t0
         print('synchronous loop, capture_refill=%-5s: %.3f ms per outer iteration' % (cap, 1e3 * dt / n))
     sys.exit(0)
+if 'stop' in sys.argv:          # what main.py of the reference runs: a stop hook (configs' acceptance rule) after every generator sub-iteration
+    never = lambda solver, points, domain: P.stop(solver, points, domain) and False     # noqa: E731  (evaluated, never taken)
+    for hook, name in ((None, 'no hook (pipelined loop)'), (never, "configs' stop rule evaluated after every generator sub-iteration")):
+        S.stop = hook
+        S.train()
+        torch.cuda.synchronize(); t0 = time.perf_counter(); S.train(); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        print('%-70s %.3f ms per outer iteration' % (name, 1e3 * dt / n))
+    import cProfile, pstats, io
+    S.iterations = 50
+    pr = cProfile.Profile(); pr.enable(); S.train(); torch.cuda.synchronize(); pr.disable()
+    st = io.StringIO(); pstats.Stats(pr, stream=st).sort_stats('cumulative').print_stats(28); print(st.getvalue()[:7000])
+    sys.exit(0)
 if 'calls' in sys.argv:         # bench.py's pattern: train() in 25-iteration calls (the fixed cost of a call)
     S.iterations = 25
     torch.cuda.synchronize(); t0 = time.perf_counter()
