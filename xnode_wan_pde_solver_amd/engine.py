@@ -24,6 +24,7 @@ Data layout in HBM (per group of N equal-length paths, L sample times, d dimensi
   slabs         float64 [n_slab, P]  per-wave partial parameter gradients, summed inside the Adam kernel
 """
 import contextlib
+import math
 import os
 
 import torch
@@ -124,6 +125,28 @@ class Group:
 
     def signature(self):
         return tuple((k, tuple(getattr(self, k).shape)) for k in self.SAMPLE_FIELDS if getattr(self, k, None) is not None)
+
+    # The work buffers are regions of ONE allocation (`_arena`), described by `_lazy` = {name: (offset, shape)}; the tensor
+    # view of a region is made when somebody reads the attribute.  The sub-step runner only needs addresses (ptr): the groups
+    # of a list domain are rebuilt with every sample, 19 groups x 22 buffers, and a torch.empty or a view costs the host 4 us each.
+    def __getattr__(self, name):          # (only reached when the attribute is not set)
+        lazy = self.__dict__.get('_lazy')
+        if lazy is not None and name in lazy:
+            off, shape = lazy[name]
+            t = self.__dict__['_arena'][off:off + math.prod(shape)].view(shape)
+            self.__dict__[name] = t
+            return t
+        raise AttributeError(name)
+
+    def ptr(self, name):
+        """device address of a buffer (0: the group has none)"""
+        t = self.__dict__.get(name)
+        if t is not None:
+            return t.data_ptr()
+        lazy = self.__dict__.get('_lazy')
+        if lazy is not None and name in lazy:
+            return self.__dict__['_arena'].data_ptr() + 8 * lazy[name][0]
+        return 0
 
 
 class Engine:
@@ -560,30 +583,45 @@ class Engine:
         # XW_POISON=1 (debugging): work buffers start as NaN instead of whatever the allocator hands out, so that a kernel
         # reading a slot nobody wrote shows up as NaN in the results instead of as a stale, plausible number
         poison = os.environ.get('XW_POISON', '0') == '1'
-        e = (lambda *s_: torch.full(s_, float('nan'), dtype=F64, device=dev)) if poison else (lambda *s_: torch.empty(*s_, dtype=F64, device=dev))  # noqa: E731
         H = self.H
-        G.u, G.Y, G.v, G.vt = e(L, N), e(L, H, N), e(L, N), e(L, N)
-        G.gxv, G.gtv, G.gx, G.gs = e(d, N), e(N), e(d, N), e(N)
-        G.vbar, G.s3x = e(L, N), e(N)
-        G.c = G.cp = None
         # stage activations of every step, written by the forward, read back by the sweeps (183 MB at N = 4096, L = 32)
         ar = KN.ode_act_rows(self.method, H, self.K, self.m) if self.keep_activations and not self.adjoint else 0
-        G.act = e(max(L - 1, 1), ar, KN.ode_act_cols(N)) if ar else None
-        G.act_b = e(max(Lb - 1, 1), ar, KN.ode_act_cols(Nb)) if (ar and Nb) else None
         # layer inputs of the test network at every point, stored by its forward in the discriminator sub-step and read
         # back by its backward (524 MB at 131072 points)
         # (only the reference's width and depth have a recomputing reverse kernel: everything else always runs from the record)
         keep_v = self.keep_activations or not KN.disc_recompute(self.W, self.q)
-        G.vact = e(KN.disc_act_rows(self.W, self.q), KN.disc_act_cols(L * N)) if keep_v else None
         G.ns_u = KN.ode_bwd_slabs(N)
         G.ns_b = KN.ode_bwd_slabs(Nb) if Nb else 0
-        G.slabA = e(G.ns_u + G.ns_b, self.Pu)          # sweep with cotangent A (interior) + the boundary sweep
-        G.slabB = e(G.ns_u, self.Pu)                   # sweep with cotangent B = dI/du
-        G.slab_v = e(KN.disc_bwd_slabs(N, L), self.Pv)
+        nw = KN.reduce_work_size()
+        plan = [('u', (L, N)), ('Y', (L, H, N)), ('v', (L, N)), ('vt', (L, N)), ('gxv', (d, N)), ('gtv', (N,)), ('gx', (d, N)), ('gs', (N,)),
+                ('vbar', (L, N)), ('s3x', (N,)),
+                ('slabA', (G.ns_u + G.ns_b, self.Pu)),         # sweep with cotangent A (interior) + the boundary sweep
+                ('slabB', (G.ns_u, self.Pu)),                  # sweep with cotangent B = dI/du
+                ('slab_v', (KN.disc_bwd_slabs(N, L), self.Pv)),
+                ('work_i', (nw,)), ('work_b', (nw,))]          # scratch of the deterministic grid sums (interior / boundary run concurrently): zeroed below
+        if ar:
+            plan.append(('act', (max(L - 1, 1), ar, KN.ode_act_cols(N))))
+            if Nb:
+                plan.append(('act_b', (max(Lb - 1, 1), ar, KN.ode_act_cols(Nb))))
+        if keep_v:
+            plan.append(('vact', (KN.disc_act_rows(self.W, self.q), KN.disc_act_cols(L * N))))
         if Nb:
-            G.ub, G.Yb = e(Lb, Nb), e(Lb, H, Nb)
-        G.work_i = torch.zeros(KN.reduce_work_size(), dtype=F64, device=dev)   # scratch of the deterministic grid sums
-        G.work_b = torch.zeros(KN.reduce_work_size(), dtype=F64, device=dev)   # (interior / boundary run concurrently)
+            plan += [('ub', (Lb, Nb)), ('Yb', (Lb, H, Nb))]
+        lazy, off = {}, 0
+        for name, shape in plan:
+            lazy[name] = (off, shape)
+            off += -(-math.prod(shape) // 64) * 64           # (regions start on 512-byte boundaries, like allocations of their own)
+        G._arena = torch.full((off,), float('nan'), dtype=F64, device=dev) if poison else torch.empty(off, dtype=F64, device=dev)
+        G._lazy = lazy
+        w0 = lazy['work_i'][0]
+        G._arena[w0:lazy['work_b'][0] + nw].zero_()
+        G.c = G.cp = None
+        if not ar:
+            G.act = G.act_b = None
+        elif not Nb:
+            G.act_b = None
+        if not keep_v:
+            G.vact = None
         G.graphs = {}
         # (a group of a list domain changes shape with every sample and is built anew each time: the count of samples it has seen
         #  is carried over, or the periodic structure guard above -- two read-backs -- would run on EVERY sample)
@@ -771,9 +809,8 @@ class Engine:
             xg.ns_u, xg.ns_b = G.ns_u, G.ns_b
             for k in ('xT', 'xvT', 'xbT', 't', 'tb', 'tpp', 'xvT_pts', 'start', 'start_b', 'h', 'href', 'f', 'g', 'w', 'wt', 'w0', 'ghT',
                       'gwx0T', 'A0', 'B0', 'u', 'Y', 'act', 'act_b', 'v', 'vt', 'gxv', 'gtv', 'gx', 'gs', 'vbar', 's3x', 'vact',
-                      'slabA', 'slabB', 'slab_v', 'work_i', 'work_b'):
-                setattr(xg, k, p(getattr(G, k, None)))
-            xg.ub, xg.Yb = p(getattr(G, 'ub', None)), p(getattr(G, 'Yb', None))
+                      'slabA', 'slabB', 'slab_v', 'work_i', 'work_b', 'ub', 'Yb'):
+                setattr(xg, k, G.ptr(k))         # (addresses only: the work buffers' tensor views are made when Python reads them)
             nar = lambda jobs, **kw: self._narrow_ok(jobs, **kw)  # noqa: E731
             ji, jb = self._job(G, 'i'), (self._job(G, 'b') if G.Nb else None)
             joint = G.Nb and G.same_grid
