@@ -7,6 +7,7 @@ Round-4 fixtures, one option each (reference CPU time on this container's 8 core
         --traj-headline           ref_traj_d20_headline_seed4: 250 outer iterations of the reference's train() at the benchmarked size  25 min
         --traj-headline-solvers   ref_traj_d20_headline_{euler_seed5, rk4_seed6}: 30 outer iterations each                              8 min
         --traj-cfg5               ref_traj_{cone, hourglass}_ex43_d10_full_*: 8 outer iterations at config 5's stated size              4 min
+        --traj-ball-solvers       ref_traj_hourglass_ex43_d3_euler_seed7, ref_traj_cone_ex43_d3_rk4_seed8: 40 outer iterations each    2 min
         --general                 ref_general_d4_midpoint: general a_ij, b_i, c(u,t,x) (general_funcs.py)                               seconds
         --shapes                  ref_wide_d6_midpoint, ref_narrow_d3_euler, ref_m1_d4_rk4: other network shapes                        seconds
 (general b_i: the reference's `np.sum(list of tensors)` goes through shim 2 below, i.e. Python's sum over the list.)
@@ -420,14 +421,15 @@ def sphere_sampling(case, domain_name, d, N_r, N_b, N_t, seed, radius):
     print('wrote', path, '%.1f KB' % (os.path.getsize(path) / 1024), 'groups', len(points.interioru), len(points.boundary))
 
 
-def sphere_trajectory(case, domain_name, d, N_r, N_b, N_t, seed, outer_iters, funcs_module='configs.Ex4_3_funcs', alpha=100000000):
+def sphere_trajectory(case, domain_name, d, N_r, N_b, N_t, seed, outer_iters, funcs_module='configs.Ex4_3_funcs', alpha=100000000,
+                      solver_name='midpoint'):
     """The reference's own train() on a time-varying ball domain (natural group loop incl. the single-slice groups),
     GPU loader semantics.  Its on-sample diagnostic is unusable on list domains (utils/auxillary_funcs.py:19 broadcasts
     [N,1] - [N] to [N,N] on single-slice groups), so the `stop` hook -- called once per generator sub-iteration,
     src/training.py:142 -- evaluates u_net on a FIXED multi-slice probe group that starts at T0 and stays strictly
     inside the domain, against func_u_sol: relative L2 error over the probe points."""
     training, dataset, lossmod, F = load_reference(funcs_module, d)
-    params = make_params(d, N_r, N_b, N_t, 'midpoint', iterations=outer_iters, alpha=alpha)
+    params = make_params(d, N_r, N_b, N_t, solver_name, iterations=outer_iters, alpha=alpha)
     params['domain'] = domain_name
     params['shape_param'] = 1.0
     if not funcs_module.endswith('Ex4_1_funcs'):
@@ -569,6 +571,8 @@ if __name__ == '__main__':
     ap.add_argument('--general', action='store_true', help='round 4: one outer iteration of the reference with general a_ij, b_i, c(u,t,x)')
     ap.add_argument('--traj-cfg5', action='store_true', help='round 4: 8 outer iterations of the reference\'s own train() on both ball '
                     'domains at BASELINE config 5 size (Ex4_3, d = 10, N_r = N_b = 8192, N_t = 20)')
+    ap.add_argument('--traj-ball-solvers', action='store_true', help='round 4: 40 outer iterations of the reference\'s own train() on the ball '
+                    'domains with the other two fixed-grid schemes (euler on the hourglass, rk4 on the cone; d = 3)')
     ap.add_argument('--traj-headline-solvers', action='store_true', help='round 4: 30 outer iterations of the reference at the benchmarked '
                     'size with solver euler and rk4 (~5 + ~12 min)')
     ap.add_argument('--traj-headline', action='store_true', help='round 4: 250 outer iterations of the reference\'s own train() at the '
@@ -593,6 +597,10 @@ if __name__ == '__main__':
         # 8 outer iterations of the reference's own train() per ball domain
         sphere_trajectory('ref_traj_cone_ex43_d10_full_seed2', 'NSphere_TCone', 10, 8192, 8192, 20, 2, 8, alpha=10000.0)
         sphere_trajectory('ref_traj_hourglass_ex43_d10_full_seed3', 'NSphere_THourglass', 10, 8192, 8192, 20, 3, 8, alpha=10000.0)
+        sys.exit(0)
+    if args.traj_ball_solvers:
+        sphere_trajectory('ref_traj_hourglass_ex43_d3_euler_seed7', 'NSphere_THourglass', 3, 256, 128, 10, 7, 40, solver_name='euler')
+        sphere_trajectory('ref_traj_cone_ex43_d3_rk4_seed8', 'NSphere_TCone', 3, 256, 128, 10, 8, 40, solver_name='rk4')
         sys.exit(0)
     if args.traj_headline_solvers:
         # the other two fixed-grid schemes at the benchmarked size: 30 outer iterations of the reference's own train() each

@@ -404,11 +404,12 @@ def test_sphere_domain_groups_against_reference_vectors(golden_dir, case, name):
 
 
 @pytest.mark.parametrize('case,steps', [('ref_traj_cone_ex43_d3_seed0', 200), ('ref_traj_hourglass_ex43_d3_seed1', 120),
-                                        ('ref_traj_cone_ex43_d10_full_seed2', 16), ('ref_traj_hourglass_ex43_d10_full_seed3', 16)])
+                                        ('ref_traj_cone_ex43_d10_full_seed2', 16), ('ref_traj_hourglass_ex43_d10_full_seed3', 16),
+                                        ('ref_traj_hourglass_ex43_d3_euler_seed7', 80), ('ref_traj_cone_ex43_d3_rk4_seed8', 80)])
 def test_ball_domain_training_trajectory_follows_reference(golden_dir, tmp_path, case, steps):
     """BASELINE configs[4] family, through train(): NSphere_TCone (seed 0, 100 outer iterations) and NSphere_THourglass (seed 1,
     60), Ex4_3, d = 3, N_r = 256, N_b = 128, N_t = 10 -- and, round 4, both domains AT THE CONFIG'S STATED SIZE (d = 10,
-    N_r = N_b = 8192, N_t = 20, alpha = 1e4; 8 outer iterations of the reference's own train(), 2 min of its CPU time each:
+    N_r = N_b = 8192, N_t = 20, alpha = 1e4; 8 outer iterations of the reference's own train(), 2 min of its CPU time each; and the other two fixed-grid schemes on list domains: euler on the hourglass, rk4 on the cone, 40 outer iterations each:
     11-12 and 18-20 groups per sample, single-slice groups of ~3600 paths with their [N, N] pairwise terms): the natural group loop (single-slice T0 groups with the reference's pairwise terms, Adam
     skipping the field's parameters there).  The `stop` hook evaluates u_theta on the fixture's fixed multi-slice probe
     group (the reference's own L_norm is all-pairs on list domains).  The REFERENCE DOES NOT CONVERGE on the ball domains
@@ -909,7 +910,8 @@ def test_pipelined_training_loop_leaves_exactly_what_the_synchronous_one_does(tm
 
 
 @pytest.mark.parametrize('case', ['ref_traj_cone_ex43_d3_seed0', 'ref_traj_hourglass_ex43_d3_seed1',
-                                  'ref_traj_cone_ex43_d10_full_seed2', 'ref_traj_hourglass_ex43_d10_full_seed3'])
+                                  'ref_traj_cone_ex43_d10_full_seed2', 'ref_traj_hourglass_ex43_d10_full_seed3',
+                                  'ref_traj_hourglass_ex43_d3_euler_seed7', 'ref_traj_cone_ex43_d3_rk4_seed8'])
 def test_ball_domain_fast_loop_ends_where_the_reference_ends(golden_dir, tmp_path, case):
     """The same reference runs as above through the loop a hook-free train() takes on the ball domains -- one read-back per outer
     iteration, the next sample loaded behind the queued sub-steps, the samples drawn by the forked sampling process, h / f / g
