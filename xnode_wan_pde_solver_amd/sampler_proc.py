@@ -173,7 +173,8 @@ class _Server:
         self.proc = ctx.Process(target=_child, args=(child_conn,), daemon=True)
         self.proc.start()
         child_conn.close()
-        self.pools = {}               # elems -> (shared memory blocks, tensors over them, page-locked addresses)
+        self.pools = {}               # capacity in doubles -> the pool of SLOTS shared blocks (slots)
+        self.serial = 0
         self.user = None              # the SamplerProcess that holds the streams right now
 
     def send(self, *msg):
@@ -189,46 +190,73 @@ class _Server:
         return out[1:]
 
     def slots(self, elems):
-        from multiprocessing import shared_memory
-        if elems not in self.pools:
+        """-> (names, tensors, capacity) of the slot pool for samples of `elems` doubles.  The blocks are POSIX shared memory made
+        and mapped by hand (multiprocessing.shared_memory would start its resource-tracker helper: an exec out of a process that
+        holds the GPU) and unlinked as soon as the child has mapped them (unlink_attached): nothing is left in /dev/shm however
+        this process ends."""
+        import _posixshmem
+        import mmap
+        if not any(e >= elems for e in self.pools):
             st = os.statvfs('/dev/shm')
             if st.f_bavail * st.f_frsize < SLOTS * 8 * elems + (64 << 20):
                 raise RuntimeError('not enough shared memory for %d sample slots of %d MB' % (SLOTS, 8 * elems >> 20))
-            for old in [e for e in self.pools if e < elems]:      # (one pool is in use at a time: smaller ones go)
+            for old in list(self.pools):                          # (one pool is in use at a time: smaller ones go)
                 self.drop(old)
-            shm = [shared_memory.SharedMemory(create=True, size=8 * elems) for _ in range(SLOTS)]
-            tens = [torch.frombuffer(s.buf, dtype=torch.float64, count=elems) for s in shm]
+            names, maps = [], []
+            for k in range(SLOTS):
+                name = 'xw_samples_%d_%d_%d' % (os.getpid(), self.serial, k)
+                fd = _posixshmem.shm_open('/' + name, os.O_CREAT | os.O_EXCL | os.O_RDWR, mode=0o600)
+                try:
+                    os.ftruncate(fd, 8 * elems)
+                    maps.append(mmap.mmap(fd, 8 * elems))
+                finally:
+                    os.close(fd)
+                names.append(name)
+            self.serial += 1
+            tens = [torch.frombuffer(m, dtype=torch.float64, count=elems) for m in maps]
             locked = []
             if torch.cuda.is_available():
                 rt = torch.cuda.cudart()
                 for t in tens:
                     if int(rt.cudaHostRegister(t.data_ptr(), t.numel() * 8, 0)) == 0:
                         locked.append(t.data_ptr())
-            self.pools[elems] = (shm, tens, locked)
+            self.pools[elems] = dict(names=names, maps=maps, tensors=tens, locked=locked, linked=True)
         usable = min(e for e in self.pools if e >= elems)
-        shm, tens, _ = self.pools[usable]
-        return [s.name for s in shm], tens, usable
+        pool = self.pools[usable]
+        return pool['names'], pool['tensors'], usable
+
+    def unlink_attached(self, elems):
+        """the child has mapped the pool's blocks: their names can go (the mappings on both sides stay)"""
+        import _posixshmem
+        pool = self.pools.get(elems)
+        if pool is not None and pool['linked']:
+            pool['linked'] = False
+            for name in pool['names']:
+                try:
+                    _posixshmem.shm_unlink('/' + name)
+                except OSError:
+                    pass
 
     def drop(self, elems):
-        shm, tens, locked = self.pools.pop(elems)
+        pool = self.pools.pop(elems)
         try:
             if self.proc.is_alive():
-                self.send('drop', [s.name for s in shm])
+                self.send('drop', pool['names'])
                 self.recv()
         except Exception:
             pass
-        if locked and torch.cuda.is_available():
+        if pool['locked'] and torch.cuda.is_available():
             rt = torch.cuda.cudart()
-            for p in locked:
+            for p in pool['locked']:
                 rt.cudaHostUnregister(p)
-        del tens
-        for s in shm:
+        if pool['linked']:
+            self.pools[elems] = pool
+            self.unlink_attached(elems)
+            self.pools.pop(elems)
+        pool['tensors'] = None
+        for m in pool['maps']:
             try:
-                s.unlink()
-            except Exception:
-                pass
-            try:
-                s.close()             # (refused while a sample still views the slot: the mapping then goes with its last view)
+                m.close()             # (refused while a sample still views the slot: the mapping then goes with its last view)
             except Exception:
                 pass
 
@@ -291,6 +319,7 @@ class SamplerProcess:
         names, self.slots, elems = sv.slots(self.elems)
         sv.send('begin', self.config, names, elems, torch.get_rng_state(), np.random.get_state())
         sv.recv()
+        sv.unlink_attached(elems)
         sv.user = self
         self.active, self.outstanding = True, None
 
