@@ -716,10 +716,13 @@ class NODE_WAN_solver:
         tick = lap('sampler_wait', tick)
         L2 = self._l_norm(points_after, domain.V(), as_tensor=True)
         tick = lap('diagnostic', tick)
-        prepared = None
+        prepared = failed = None
         if nxt_points is not None:
-            prepared = self._prepare_groups(nxt_points, nxt_domain, pairs_last=True)
-            self._group_cache = prepared
+            try:
+                prepared = self._prepare_groups(nxt_points, nxt_domain, pairs_last=True)
+                self._group_cache = prepared
+            except Exception as e:        # (e.g. the structure guard on the NEXT sample: this iteration's results are written out first)
+                failed = e
         tick = lap('load_next', tick)
         row = torch.cat([torch.stack(lu).reshape(-1).double(), lv.reshape(1).double(), L2.reshape(1)]).tolist()   # the ONE read-back
         tick = lap('read_back', tick)
@@ -742,6 +745,8 @@ class NODE_WAN_solver:
             json.dump([self._last_L2], fh)
         times.write('Time_NODE_' + str(d) + '.json')
         lap('files', tick)
+        if failed is not None:
+            raise failed
         return prepared, nxt_domain, nxt_points, ahead
 
     def _iterate(self, report, report_it, show_plt, past_losses, times, pool, draw_ahead):
