@@ -305,6 +305,20 @@ int xw_comm_init(const unsigned char* id128, int nranks, int rank, void** comm);
 int xw_allreduce(double* buf, int count, void* comm, void* stream);
 int xw_comm_destroy(void* comm);
 
+/* ---- sample fields of a list-domain sample (callers' side of the path: src/training.py:13-43 func_eval + the per-group
+ * tensor plumbing of src/loss.py:36-60) ----------------------------------------------------------------------------------
+ * One row per output array: dst[i][j][k] = src[i*s0 + j*s1 + k*s2] for i < n0, j < n1, k < n2 (dst contiguous, float64);
+ * `before` = number of elements of all rows in front of this one (the rows partition [0, total)).  The table lives in
+ * device memory; count <= 1024. */
+typedef struct XwGather {
+  const double* src;
+  double* dst;
+  long n0, n1, n2;
+  long s0, s1, s2;
+  long before;
+} XwGather;
+int xw_gather_fields(const XwGather* table_dev, int count, long total, void* stream);
+
 /* ---- host-side helper of the samplers (no GPU involved) ---------------------------------------------------------------
  * float32 uniform fill straight from torch's CPU generator state (torch.get_rng_state(), 5056 bytes: at::mt19937, legacy state
  * layout): the numbers, their order and the state left behind are those of Tensor.uniform_(from, to) on the default

@@ -944,6 +944,56 @@ def test_ball_domain_fast_loop_ends_where_the_reference_ends(golden_dir, tmp_pat
     assert abs(got - float(ref[-1])) < 1e-2
 
 
+@pytest.mark.parametrize('domain,seed', [('NSphere_THourglass', 8), ('NSphere_TCone', 9)])
+def test_all_groups_of_a_list_sample_loaded_by_one_gather_launch_hold_what_load_group_writes(domain, seed):
+    """Engine.load_groups_packed (the sample fields of every group as regions of the group's one allocation, filled by ONE
+    xw_gather_fields launch from the uploaded sample and the whole-sample tables of tabulate_sample) against load_group, group by
+    group: every sample field bit for bit, the same shapes, flags and pair terms -- late-entry groups of the hourglass (per-point
+    times), single-slice groups at T0 (the factorised [N, N] terms) and boundary groups included -- and one outer iteration on
+    top gives the same parameters either way"""
+    import configs.Ex4_3_funcs as F
+    from xnode_wan_pde_solver_amd.engine import Group
+    params = {'alpha': 1e4, 'u_layers': 8, 'u_hidden_dim': 20, 'u_hidden_hidden_dim': 10, 'v_layers': 9, 'v_hidden_dim': 50,
+              'n1': 2, 'n2': 1, 'u_rate': 0.015, 'v_rate': 0.04, 'min_steps': 5, 'adjoint': False, 'solver': 'midpoint',
+              'dim': 5, 'N_t': 9, 'N_r': 1500, 'N_b': 700, 'T0': 0, 'T': 1, 'shape_param': 1.0, 'iterations': 1, 'domain': domain}
+    out = []
+    for packed in (True, False):
+        S = make_solver(params, seed, F=F)
+        S.engine.packed_load = packed
+        dom = S._new_domain()
+        pts = S._loader(dom).pin()
+        groups = S._prepare_groups(pts, dom)
+        assert len(groups) > 3 and (('_tab_cat' in S.engine.__dict__) and all('xT' in G._lazy for G in groups)) == packed
+        fields = []
+        for G in groups:
+            rec = {k: (None if getattr(G, k, None) is None else getattr(G, k).clone()) for k in Group.SAMPLE_FIELDS}
+            rec['meta'] = (G.N, G.L, G.Nb, G.Lb, G.same_grid, G.Vol, G.Nglob, G.Nbglob, G.pair_i, G.pair_b, G.init_off, G.bdry_off, G.s3_scale, G.amode)
+            fields.append(rec)
+        for G in groups:
+            G.persistent = False
+        S.engine.begin_substep('u', True)
+        for G in groups:
+            S.engine.generator_step(G)
+        S.engine.begin_substep('v', True)
+        for G in groups:
+            S.engine.discriminator_step(G)
+        out.append((fields, S.engine.theta.data.clone(), S.engine.phi.data.clone()))
+    a, b = out
+    assert len(a[0]) == len(b[0])
+    kinds = set()
+    for ra, rb in zip(a[0], b[0]):
+        assert ra['meta'] == rb['meta']
+        kinds.add((ra['tpp'] is not None, ra['meta'][8], ra['meta'][9]))
+        for k in Group.SAMPLE_FIELDS:
+            assert (ra[k] is None) == (rb[k] is None), k
+            if ra[k] is not None:
+                assert ra[k].shape == rb[k].shape and ra[k].dtype == rb[k].dtype and torch.equal(ra[k], rb[k]), k
+    assert (False, False, True) in kinds or (False, True, True) in kinds          # a single-slice boundary group at T0
+    if domain == 'NSphere_THourglass':
+        assert any(k_[0] for k_ in kinds)                                         # late-entry groups with per-point times
+    assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+
+
 @pytest.mark.parametrize('domain,seed', [('NSphere_THourglass', 5), ('NSphere_TCone', 6)])
 def test_list_domain_loop_with_one_read_back_leaves_exactly_what_the_synchronous_one_does(tmp_path, domain, seed):
     """solver.defer_list_readback (ball domains, 11-20 groups per sample): all sub-steps of an outer iteration queued without a

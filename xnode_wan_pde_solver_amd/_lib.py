@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('XW_LIBRARY') or os.path.join(_HERE, 'libxnwan.so')   # (override: kernel experiments only)
-ABI_VERSION = 28
+ABI_VERSION = 29
 
 c_f32p = ctypes.c_void_p   # coordinates / time grid: const double* (device)   [name kept from the float32 era]
 c_f64p = ctypes.c_void_p   # double*       (device)
@@ -67,6 +67,7 @@ SIGNATURES = {
     'xw_disc_bwd_slabs': [c_int, c_int],
     'xw_disc_bwd': [c_f32p, c_f32p, c_f32p, c_f64p, c_f64p, c_int, c_int, c_int, c_int, c_int, c_f64p, c_f64p, c_vp],
     'xw_mt19937_uniform_f32': [c_vp, ctypes.c_long, c_vp, ctypes.c_long, ctypes.c_float, ctypes.c_float, c_int],
+    'xw_gather_fields': [c_vp, c_int, ctypes.c_long, c_vp],
     'xw_mt19937_legacy_normal_f64': [c_vp, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_dbl), c_vp, ctypes.c_long],
     'xw_weak_partials': [c_f64p, c_f64p, c_f64p, c_f64p, c_int, c_f64p, c_f64p, c_f64p, c_f64p, c_f64p, c_f64p, c_f64p,
                          c_f64p, c_int, c_f64p, c_dbl, c_f64p, c_f64p, c_f64p, c_int, c_dbl, c_int, c_int, c_dbl, c_dbl, c_f64p, c_f64p,

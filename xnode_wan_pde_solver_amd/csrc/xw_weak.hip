@@ -10,6 +10,7 @@
 // nabla_x u only exists at the first time index (Q3), so the a_ij d_i phi d_j u contraction arrives pre-contracted
 // per path in s3x[N].
 #include "xw_common.h"
+#include "xnwan.h"
 
 namespace {
 
@@ -487,6 +488,37 @@ extern "C" int xw_cube_weight(const float* x, int N, int d, double top, double b
   return xw_launch_status();
 }
 
+// ---- sample fields of the groups of a list-domain sample in one launch ------------------------------------------------------
+// A sample of a time-varying ball domain is 11-20 groups; per group the engine needs ~18 device arrays that are all STRIDED
+// VIEWS of what the sampler uploaded and the callables returned for the whole sample (the time grid, transposed coordinates,
+// [N, L] tables as [L, N], one component of a gradient, ...).  Taken one by one through tensor operations that was ~45 host
+// operations per group -- the largest item of an outer iteration's host time once nothing else waited.  Here
+// every output array is one row of a table {src, dst, n0 x n1 x n2, strides of src}: dst[i][j][k] = src[i s0 + j s1 + k s2],
+// dst contiguous; the table of the whole sample (~350 rows) is uploaded once and ONE launch walks all elements.
+__global__ __launch_bounds__(256) void k_gather_fields(const XwGather* __restrict__ tab, int count, long total) {
+  __shared__ long first[1025];                    // first[r] = elements before row r; first[count] = total
+  for (int r = threadIdx.x; r <= count; r += blockDim.x) first[r] = r < count ? tab[r].before : total;
+  __syncthreads();
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+    int lo = 0, hi = count;                       // the row with first[lo] <= e < first[lo + 1]
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (first[mid] <= e) lo = mid; else hi = mid;
+    }
+    const XwGather g = tab[lo];
+    const long local = e - g.before;
+    const long k = local % g.n2, ij = local / g.n2, j = ij % g.n1, i = ij / g.n1;
+    g.dst[local] = g.src[i * g.s0 + j * g.s1 + k * g.s2];
+  }
+}
+
+extern "C" int xw_gather_fields(const XwGather* table_dev, int count, long total, void* stream) {
+  if (!table_dev || count <= 0 || count > 1024 || total <= 0) return XW_E_ARG;
+  hipLaunchKernelGGL(k_gather_fields, dim3(blocks_for(total, 256, 2048)), dim3(256), 0, (hipStream_t)stream, table_dev, count, total);
+  return xw_launch_status();
+}
+
 extern "C" int xw_disc_cotangent(const double* u, const double* v, const double* w, int w_per_point, const double* c,
                                  double ckappa, const double* f, const double* h, int N, int L, double Vol, double Nglob,
                                  double pollution, double s3_scale, const double* scal_in, double* vbar, void* stream) {
@@ -548,7 +580,7 @@ extern "C" int xw_slab_sum(const double* gslab, int nslab, int P, int accumulate
   return xw_launch_status();
 }
 
-extern "C" int xw_abi_version(void) { return 28; }
+extern "C" int xw_abi_version(void) { return 29; }
 extern "C" int xw_reduce_work_size(void) { return 6 * 1024 + 8; }
 
 extern "C" int xw_supported_dims(char* buf, int buflen) {

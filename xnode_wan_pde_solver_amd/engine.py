@@ -160,6 +160,7 @@ class Engine:
         self.alpha = float(config['alpha'])
         self.pollution = 1.0
         self.verify_structure = os.environ.get('XW_VERIFY_STRUCTURE', '1') == '1'    # (_check_structure)
+        self.packed_load = os.environ.get('XW_PACKED_LOAD', '1') != '0'     # list domains: load_groups_packed
         self.verify_every = 16          # ~3 d + 1 callable evaluations per check: ~1 ms at d = 20, a fifth of an outer iteration
         sp = setup.get('shape_param', [-1, 1])
         lo, hi = (sp[0], sp[1]) if isinstance(sp, (list, tuple)) else (-sp, sp)
@@ -374,12 +375,14 @@ class Engine:
         bat0 = [float(v) == T0 for v in first_t[len(Xs):]]
         pts = lambda ts: torch.cat([t_.reshape(-1, 1, d + 1) for t_ in ts], 0)                      # noqa: E731  [P, 1, d+1]
         cuts = lambda ts: [t_.shape[0] * t_.shape[1] for t_ in ts]                                  # noqa: E731
-        f_all = self.funcs['f'](pts(Xs)).detach().reshape(-1).split(cuts(Xs))
-        g_all = self.funcs['g'](pts(BXs)).detach().reshape(-1).split(cuts(BXs))
+        f_cat = self.funcs['f'](pts(Xs)).detach().reshape(-1)
+        g_cat = self.funcs['g'](pts(BXs)).detach().reshape(-1)
+        f_all, g_all = f_cat.split(cuts(Xs)), g_cat.split(cuts(BXs))
         XVp = pts(XVs).clone().requires_grad_(True)
         w_all = domain.func_w(XVp)
         gw_all = torch.autograd.grad(w_all.sum(), XVp)[0] if w_all.requires_grad else torch.zeros_like(XVp)
-        w_all, gw_all = w_all.detach().reshape(-1).split(cuts(XVs)), gw_all.reshape(-1, d + 1).split(cuts(XVs))
+        w_cat, gw_cat = w_all.detach().reshape(-1), gw_all.reshape(-1, d + 1)
+        w_all, gw_all = w_cat.split(cuts(XVs)), gw_cat.split(cuts(XVs))
         # start values with their x-gradient: h for groups that start at T0, g for groups that start on the boundary
         # (h is evaluated ONLY on the start points of the groups that start at T0 and g ONLY on those that start on the
         #  boundary -- the combinations the per-group path evaluates: a callable that is not finite, or has no finite
@@ -408,6 +411,8 @@ class Engine:
         _, nb0, sb = starts(BXs, bat0)
         sb = sb.detach()
         tabs = []
+        # (the unsplit tables, for load_groups_packed: one gather launch takes every group's fields out of them)
+        self._tab_cat = dict(f=f_cat, g=g_cat, w=w_cat, gw=gw_cat, start=start.detach(), gh=gh, h=hv.detach(), start_b=sb, at0=at0, bat0=bat0)
         start_k, gh_k, hv_k, sb_k = start.detach().split(n0), gh.split(n0), hv.detach().split(n0), sb.split(nb0)   # (once: a split is 20 new tensors)
         for k, (x, xv, bx) in enumerate(zip(Xs, XVs, BXs)):
             N, L = x.shape[0], x.shape[1]
@@ -582,6 +587,118 @@ class Engine:
         # work buffers
         # XW_POISON=1 (debugging): work buffers start as NaN instead of whatever the allocator hands out, so that a kernel
         # reading a slot nobody wrote shows up as NaN in the results instead of as a stale, plausible number
+        self._work_buffers(G, [])
+        G.graphs = {}
+        # (a group of a list domain changes shape with every sample and is built anew each time: the count of samples it has seen
+        #  is carried over, or the periodic structure guard above -- two read-backs -- would run on EVERY sample)
+        G.sample_version = into.sample_version + 1 if into is not None else 0
+        return G
+
+    def load_groups_packed(self, shards, hints, domain, cache, big):
+        """load_group for ALL groups of a list-domain sample at once (time-varying balls: 11-20 groups): every sample field of
+        every group is a strided view of the uploaded sample or of a table tabulate_sample has just filled for the whole
+        sample, so the fields are regions of each group's one allocation (Group._arena) and ONE gather launch
+        (kernels.gather_fields, a ~350-row table uploaded once) fills them -- instead of ~45 tensor operations per group.
+        Same values bit for bit (copies), same Group attributes.  Returns None when the sample is not of that kind (anything
+        but float64 device tensors, general a / b / c, several GPUs, no batched tabulation): the caller goes group by group."""
+        tc = getattr(self, '_tab_cat', None)
+        st = self.structure
+        if (tc is None or self.world is not None or not (st.a_identity and st.b_zero and st.c_kappa is not None)
+                or getattr(domain, 'time_independent', False) or any(h is None for h in hints)):
+            return None
+        srcs = [tc[k] for k in ('f', 'g', 'w', 'gw', 'start', 'gh', 'h', 'start_b')]
+        if any(t.dtype != F64 or not t.is_cuda for t in srcs) or any(t.dtype != F64 or not t.is_cuda or t_[0] is not t_[1]
+                                                                       for t_ in shards for t in t_[:3]):
+            return None
+        d, dev, T0 = self.d, self.dev, self.setup['T0']
+        f_cat, g_cat, w_cat, gw_cat, start, gh, hv, sb = srcs
+        if f_cat.stride(0) != 1 or g_cat.stride(0) != 1 or w_cat.stride(0) != 1:
+            return None
+        g0, g1 = gw_cat.stride()
+        h0, h1 = gh.stride()
+        rows, groups, total = [], [], 0
+        oN = oNL = oNb = oNbL = 0
+        vol = float(domain.V())
+        for k, ((X, XV, BX, n_glob, nb_glob), hn) in enumerate(zip(shards, hints)):
+            N, L, Nb, Lb = X.shape[0], X.shape[1], BX.shape[0], BX.shape[1]
+            shared = bool(hn['shared_times'])
+            same_grid = Lb == L and bool(hn['same_grid'])
+            starts_T0, b_T0 = bool(tc['at0'][k]), bool(tc['bat0'][k])
+            G = Group()
+            G.domain, G.N, G.L, G.Nb, G.Vol, G.Nglob, G.Nbglob = domain, N, L, Nb, vol, float(N), float(max(Nb, 1))
+            G.Lb, G.same_grid, G.amode = Lb, same_grid, 0
+            fields = [('t', (L,)), ('xT', (d, N))]
+            if not shared:
+                fields += [('tpp', (L * N,)), ('tpp0', (N,)), ('xvT_pts', (d, L * N))]
+            fields += [('start', (N,)), ('ghT', (d, N)), ('h', (N,)), ('f', (L, N)), ('w', (L, N)), ('wt', (L, N)), ('w0', (N,)), ('gwx0T', (d, N)),
+                       ('tb', (Lb,)), ('xbT', (d, Nb)), ('start_b', (Nb,)), ('g', (Lb, Nb))]
+            self._work_buffers(G, fields)
+            G._lazy['xvT'] = G._lazy['xT']           # (the v sample of a list domain is the u sample)
+            if shared:
+                G.tpp = G.tpp0 = G.xvT_pts = None
+            G.href = G.X = G.A0 = G.B0 = None
+            base = G._arena.data_ptr()
+            x0, x1, x2 = X.stride()
+            b0, b1, b2 = BX.stride()
+            xp, bp = X.data_ptr(), BX.data_ptr()
+            src = {'t': (xp, 1, 1, L, 0, 0, x1), 'xT': (xp + 8 * x2, 1, d, N, 0, x2, x0),
+                   'tpp': (xp, 1, L, N, 0, x1, x0), 'tpp0': (xp, 1, 1, N, 0, 0, x0), 'xvT_pts': (xp + 8 * x2, d, L, N, x2, 0, x0),
+                   'start': (start.data_ptr() + 8 * oN * start.stride(0), 1, 1, N, 0, 0, start.stride(0)),
+                   'ghT': (gh.data_ptr() + 8 * oN * h0, 1, d, N, 0, h1, h0),
+                   'h': (hv.data_ptr() + 8 * oN * hv.stride(0), 1, 1, N, 0, 0, hv.stride(0)),
+                   'f': (f_cat.data_ptr() + 8 * oNL, 1, L, N, 0, 1, L),
+                   'w': (w_cat.data_ptr() + 8 * oNL, 1, L, N, 0, 1, L),
+                   'wt': (gw_cat.data_ptr() + 8 * oNL * g0, 1, L, N, 0, g0, L * g0),
+                   'w0': (w_cat.data_ptr() + 8 * oNL, 1, 1, N, 0, 0, L),
+                   'gwx0T': (gw_cat.data_ptr() + 8 * (oNL * g0 + g1), 1, d, N, 0, g1, L * g0),
+                   'tb': (bp, 1, 1, Lb, 0, 0, b1), 'xbT': (bp + 8 * b2, 1, d, Nb, 0, b2, b0),
+                   'start_b': (sb.data_ptr() + 8 * oNb * sb.stride(0), 1, 1, Nb, 0, 0, sb.stride(0)),
+                   'g': (g_cat.data_ptr() + 8 * oNbL, 1, Lb, Nb, 0, 1, Lb)}
+            for name, shape in fields:
+                a, n0_, n1_, n2_, s0_, s1_, s2_ = src[name]
+                rows.append((a, base + 8 * G._lazy[name][0], n0_, n1_, n2_, s0_, s1_, s2_, total))
+                total += n0_ * n1_ * n2_
+            pair_i = self.pairwise_single_slice and L == 1 and starts_T0
+            pair_b = self.pairwise_single_slice and Nb > 0 and Lb == 1 and b_T0
+            G.__dict__.update(dict(pair_i=pair_i, pair_b=pair_b, init_off=0.0, bdry_off=0.0, s3_scale=float(N) if pair_i else 1.0))
+            old = cache[k] if k < len(cache) else None
+            G.graphs = {}
+            ver = old.sample_version if old is not None else 0
+            G.sample_version = ver + 1 if old is not None else 0
+            if self.verify_structure and k == big and ver % self.verify_every == 0:      # (as load_group: the first sample and every 16th)
+                self._check_structure(X, ver // self.verify_every)
+            groups.append(G)
+            oN, oNL, oNb, oNbL = oN + N, oNL + N * L, oNb + Nb, oNbL + Nb * Lb
+        if len(rows) > KN.GATHER_ROWS:
+            return None
+        table = torch.zeros(KN.GATHER_ROWS, 9, dtype=torch.int64)
+        table[:len(rows)] = torch.tensor(rows, dtype=torch.int64)
+        from .sampling import _PIN_POOL
+        pinned = _PIN_POOL.stage(table)
+        tdev = pinned.to(dev, non_blocking=True)
+        _PIN_POOL.uploaded(pinned, torch.cuda.current_stream(dev))
+        KN.gather_fields(tdev, len(rows), total)
+        # single-slice groups at T0: the reference's [N, N] broadcasts in factorised form (load_group); these read five sums back
+        for G in groups:
+            if G.pair_i and not st.b_zero:
+                raise XnwanError('func_b != 0 on a single-slice group at T0 (see load_group)')
+            if G.pair_i or G.pair_b:
+                zero = torch.zeros((), dtype=F64, device=dev)
+                gsum, gsq = (G.g.sum(), (G.g ** 2).sum()) if G.pair_b else (zero, zero)
+                sh, shh, sf, sg, sgg = torch.stack([G.h.sum(), (G.h ** 2).sum(), G.f.sum(), gsum, gsq]).tolist()
+                if G.pair_i:
+                    G.href = torch.full((G.N,), sh / G.Nglob, dtype=F64, device=dev)
+                    G.f.fill_(sf / G.Nglob)
+                    G.init_off = shh / G.Nglob - (sh / G.Nglob) ** 2
+                if G.pair_b:
+                    G.g.fill_(sg / G.Nbglob)
+                    G.bdry_off = sgg / G.Nbglob - (sg / G.Nbglob) ** 2
+        return groups
+
+    def _work_buffers(self, G, fields):
+        """every buffer the sub-steps of G need, as regions of ONE allocation (Group._arena / _lazy), behind the regions `fields`
+        = [(name, shape)] the caller fills itself (load_groups_packed: the sample fields)"""
+        dev, d, N, L, Nb, Lb = self.dev, self.d, G.N, G.L, G.Nb, G.Lb
         poison = os.environ.get('XW_POISON', '0') == '1'
         H = self.H
         # stage activations of every step, written by the forward, read back by the sweeps (183 MB at N = 4096, L = 32)
@@ -593,7 +710,7 @@ class Engine:
         G.ns_u = KN.ode_bwd_slabs(N)
         G.ns_b = KN.ode_bwd_slabs(Nb) if Nb else 0
         nw = KN.reduce_work_size()
-        plan = [('u', (L, N)), ('Y', (L, H, N)), ('v', (L, N)), ('vt', (L, N)), ('gxv', (d, N)), ('gtv', (N,)), ('gx', (d, N)), ('gs', (N,)),
+        plan = list(fields) + [('u', (L, N)), ('Y', (L, H, N)), ('v', (L, N)), ('vt', (L, N)), ('gxv', (d, N)), ('gtv', (N,)), ('gx', (d, N)), ('gs', (N,)),
                 ('vbar', (L, N)), ('s3x', (N,)),
                 ('slabA', (G.ns_u + G.ns_b, self.Pu)),         # sweep with cotangent A (interior) + the boundary sweep
                 ('slabB', (G.ns_u, self.Pu)),                  # sweep with cotangent B = dI/du
@@ -622,11 +739,6 @@ class Engine:
             G.act_b = None
         if not keep_v:
             G.vact = None
-        G.graphs = {}
-        # (a group of a list domain changes shape with every sample and is built anew each time: the count of samples it has seen
-        #  is carried over, or the periodic structure guard above -- two read-backs -- would run on EVERY sample)
-        G.sample_version = into.sample_version + 1 if into is not None else 0
-        return G
 
     def refill_compact(self, G, comp, domain, n_glob=None, nb_glob=None):
         """load_group(..., into=G) for a COMPACT sample of a domain whose paths are vertical lines over one shared grid

@@ -399,6 +399,19 @@ def cube_weight(x, top, bot, w, gwT, w0=None, xT=None):
     check(lib.xw_cube_weight(_p(x), N, d, float(top), float(bot), _p(w), _p(w0), _p(gwT), _p(xT), _stream()), 'xw_cube_weight')
 
 
+GATHER_ROWS = 1024        # rows of one xw_gather_fields table (include/xnwan.h)
+
+
+def gather_fields(table, count, total):
+    """dst[i][j][k] = src[i s0 + j s1 + k s2] for every row (src, dst, n0, n1, n2, s0, s1, s2, before) of the int64 device table
+    [>= count, 9] (addresses as integers; float64 arrays; dst contiguous): the sample fields of all groups of a list-domain
+    sample in one launch (Engine.load_groups_packed)"""
+    _need_gpu()
+    if table.dtype != torch.int64 or table.dim() != 2 or table.shape[1] != 9 or not table.is_contiguous() or table.shape[0] < count:
+        raise XnwanError('gather table: need a contiguous int64 [>= count, 9] device tensor')
+    check(lib.xw_gather_fields(_p(table), int(count), int(total), _stream()), 'xw_gather_fields')
+
+
 def weak_contract_general(A0, amode, B0, gx, gs, ghT, gxv, w0, gwx0T, v0, s3x):
     """s3x[n] = sum_ij a_ij d_i(phi) d_j(u) + phi sum_i b_i d_i(u) at the first time index for general coefficients.
     amode says what A0 is (never inferred from its shape: [d,d] and [d,N] coincide when N == d):

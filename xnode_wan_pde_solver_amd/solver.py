@@ -673,6 +673,10 @@ class NODE_WAN_solver:
             waits = lambda i: (shards[i][0].shape[1] == 1 or shards[i][2].shape[1] == 1) and hints[i] is not None and (  # noqa: E731
                 hints[i]['t0'] == T0 or hints[i]['tb0'] == T0)
             order.sort(key=lambda i: bool(waits(i)) or hints[i] is None)
+        if len(shards) > 1 and eng.packed_load and tabs[0] is not None and self.world is None:
+            packed = eng.load_groups_packed(shards, hints, domain, self._group_cache, big)      # (one gather launch for all groups)
+            if packed is not None:
+                return packed
         groups = [None] * len(shards)
         for i in order:
             du, dv, bd, ng, nbg = shards[i]
