@@ -16,6 +16,7 @@ parent's pages, the GPU driver re-validates the process's memory on the next sub
 in a small process and seconds in one that holds many allocations (measured: tools/sampler_proc_cost.py).  Sample slots are
 attached by name, so a solver with larger samples gets larger slots without another fork.
 """
+import atexit
 import math
 import os
 import pickle
@@ -25,9 +26,6 @@ import numpy as np
 import torch
 
 from . import sampling
-
-import atexit
-import weakref
 
 _SERVER = None
 
