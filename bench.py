@@ -340,6 +340,34 @@ def main():
                            'ms_per_outer_iteration_after_the_first_call': round(1e3 * sum(calls[1:]) / (25 * len(calls[1:])), 2) if len(calls) > 1 else None,
                            'rel_l2_heldout_16384': traj[-1], 'rel_l2_heldout_every_25_iterations': traj}
 
+        # BASELINE configs[4] (time-varying balls, Ex4_3, d = 10, N_r = N_b = 8192, N_t = 20) through the same train(): 11-20 groups
+        # per sample, ~60 dependent sub-steps of ~400 paths per outer iteration -- host-bound by construction; reported
+        # beside the headline, never part of `value`
+        try:
+            import numpy as np
+            import configs.Ex4_3_funcs as P3
+            c5 = {}
+            os.chdir('/tmp/xnwan_bench')
+            for name in ('NSphere_TCone', 'NSphere_THourglass'):
+                p5 = dict(params, dim=10, N_t=20, N_r=8192, N_b=8192, T0=0, T=1, shape_param=1.0, alpha=1e4, domain=name, iterations=3)
+                torch.manual_seed(0)
+                np.random.seed(0)
+                S5 = NODE_WAN_solver(p5, P3.func_a, P3.func_b, P3.func_c, P3.func_h, P3.func_f, P3.func_g, dev, './',
+                                     func_u_sol=P3.func_u_sol, p=2)
+                S5.train(report=False)
+                S5.iterations = 30
+                torch.cuda.synchronize()
+                tt0 = time.time()
+                S5.train(report=False)
+                torch.cuda.synchronize()
+                c5[name] = round(1e3 * (time.time() - tt0) / 30, 2)
+                del S5
+            extras['train_config5_ms_per_outer_iteration'] = c5
+        except Exception as e:       # (never at the expense of the headline line)
+            extras['train_config5_ms_per_outer_iteration'] = {'error': repr(e)[:200]}
+        finally:
+            os.chdir(cwd)
+
     # ---- CPU baseline: the oracle (port of the reference's CPU/PyTorch path), bounded sample ---------------------------
     cpu = None
     if rank == 0 and size == 1 and not args.no_cpu_baseline:
