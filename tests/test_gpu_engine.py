@@ -930,7 +930,8 @@ def test_ball_domain_fast_loop_ends_where_the_reference_ends(golden_dir, tmp_pat
         losses = S.train(report=False)
     finally:
         os.chdir(cwd)
-    assert getattr(S, '_sampler_proc', None) is not None and '_list_phase_seconds' in S.__dict__      # (the loop under test ran)
+    assert '_list_phase_seconds' in S.__dict__                                     # (the loop under test ran ...
+    assert getattr(S, '_sampler_proc', None) is not None or not S.sampler_process   #  ... with the sampling process, unless this machine cannot start one: then it said so and drew on the helper thread)
     assert len(losses) == len(ref)
     with torch.no_grad():
         up = S.u_net(probe).squeeze(2).cpu()
@@ -1020,13 +1021,13 @@ def test_list_domain_loop_with_one_read_back_leaves_exactly_what_the_synchronous
             losses += list(S.train(report=False))          # (a second call: the sampling process is handed the streams again)
             torch.cuda.synchronize()
             assert len(S._group_cache) > 1
-            assert (getattr(S, '_sampler_proc', None) is not None) == proc
+            assert (getattr(S, '_sampler_proc', None) is not None) == (proc and S.sampler_process)   # (sampler_process goes False, with a warning, where no child can be started)
             best = torch.load('best_model_weights_NODE.pth')
             out.append((losses, S.engine.theta.data.cpu(), S.engine.phi.data.cpu(), open('losses_NODE_4.json').read(),
                         open('L2_NODE_4.json').read(), hashlib.sha1(b''.join(v.cpu().numpy().tobytes() for v in best.values())).hexdigest(),
                         list(best.keys()), S.best_l, S.last_loss_u, S.last_loss_v, len(json.load(open('Time_NODE_4.json'))),
                         torch.rand(4).tolist(), np.random.rand(4).tolist(), np.random.normal(size=3).tolist()))
-            if proc:
+            if getattr(S, '_sampler_proc', None) is not None:
                 S._sampler_proc[1].close()
         finally:
             os.chdir(cwd)
