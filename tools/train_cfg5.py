@@ -17,8 +17,9 @@ S.train()
 S.iterations = iters
 S.__dict__.pop('_list_phase_seconds', None)
 torch.cuda.synchronize(); t0 = time.time(); S.train(); torch.cuda.synchronize(); dt = time.time() - t0
-print('%s: %d outer iterations, %.1f ms each; groups per sample: %d; the sampling thread drew for %.1f ms of each (two samples: the diagnostic\'s and the next iteration\'s)'
-      % (name, iters, 1e3 * dt / iters, len(S._group_cache), 1e3 * S._sampler_seconds / iters))
+drew = ('samples drawn by the sampling process (XW_SAMPLER_PROCESS=0: the helper thread)' if getattr(S, '_sampler_proc', None) is not None
+        else 'the sampling thread drew for %.1f ms of each (two samples: the diagnostic\'s and the next iteration\'s)' % (1e3 * S._sampler_seconds / iters))
+print('%s: %d outer iterations, %.1f ms each; groups per sample: %d; %s' % (name, iters, 1e3 * dt / iters, len(S._group_cache), drew))
 ph = getattr(S, '_list_phase_seconds', None)
 if ph:
     print('  host ms per outer iteration by phase: ' + ', '.join('%s %.2f' % (k_, 1e3 * v / iters) for k_, v in ph.items()))
