@@ -1016,6 +1016,7 @@ def test_list_domain_loop_with_one_read_back_leaves_exactly_what_the_synchronous
         try:
             S = make_solver(params, seed, F=F)
             S.defer_list_readback, S.sampler_process = defer, proc
+            S.engine.packed_load = proc          # (... and the groups' fields from one gather launch / group by group)
             losses = list(S.train(report=False))
             S.iterations = 3
             losses += list(S.train(report=False))          # (a second call: the sampling process is handed the streams again)
