@@ -256,21 +256,30 @@ int xw_slab_sum2(const double* gA, int nA, double* outA, const double* gB, int n
  * of a group sub-step one by one spends more time issuing than the GPU spends running them.  These two entry points enqueue
  * the whole chain on ONE stream (program order is the dependency), from two plain structs the caller fills when a group is
  * loaded: the kernels, their arguments and their order are exactly those of the separate calls above.
- * Scope: one process (no exchange step inside), c(u,t,x) = ckappa u or tabulated c / cp already in the group (the caller
- * refreshes them), any a / b (A0 / B0 tables), pairwise single-slice groups, carried gradients of a multi-group sub-iteration. */
+ * Scope: c(u,t,x) = ckappa u or tabulated c / cp already in the group (the caller refreshes them), any a / b (A0 / B0 tables),
+ * pairwise single-slice groups, carried gradients of a multi-group sub-iteration; one process, or -- XwGroup.sharded with
+ * XwSolverState.exchange -- one rank of several that hold contiguous shares of the group's paths: the same chain with the
+ * exchange steps of dist.py between its launches (generator: ONE sum of pack_u = [J^T ubarA | J^T ubarB | scal] over the ranks;
+ * discriminator: scal[0..8], then the packed gradient grad_v), every rank applying the identical update.  A share may be EMPTY
+ * (N == 0 and / or Nb == 0: a group with fewer paths than ranks): nothing is launched for what the rank does not hold, zeros go
+ * into every exchange, the update is the same (nn.DataParallel scatters a batch of any size, src/training.py:93-97). */
 typedef struct {
   int N, Nb, L, Lb, d;            /* interior paths, boundary paths, their sample times, dimensions */
   int same_grid;                  /* boundary paths on the interior's time grid (one launch for both) */
   int w_per_point, amode, pair_i, pair_b;
   int ns_u, ns_b;                 /* slabs of the interior / boundary sweeps (xw_ode_bwd_slabs) */
-  int narrow;                     /* narrow-tile launches: bit 0 forward (generator), 1 boundary forward alone, 2 sweeps A (+ boundary),
-                                     3 boundary sweep alone, 4 sweep B, 5 x-only sweep (generator, unfused), 6 forward (discriminator),
-                                     7 x-only sweep (discriminator) */
+  int narrow;                     /* narrow-tile launches: bit 0 forward (generator), 1 boundary forward alone, 2 the sweeps launch of the
+                                     generator sub-step (A, boundary on the same grid, B: one launch), 3 boundary sweep alone, 4 unused,
+                                     5 x-only sweep (generator, unfused), 6 forward (discriminator), 7 x-only sweep (discriminator) */
+  int sharded;                    /* != 0: N / Nb are this rank's SHARE of a group of Nglob / Nbglob paths (either may be 0); the
+                                     sub-step runs XwSolverState.exchange between its launches */
   double Vol, Nglob, Nbglob, s3_scale, init_off, bdry_off, ckappa;
   const double *xT, *xvT, *xbT, *t, *tb, *tpp, *xvT_pts;
   const double *start, *start_b, *h, *href, *f, *g, *w, *wt, *w0, *ghT, *gwx0T, *c, *cp, *A0, *B0;
   double *u, *ub, *Y, *Yb, *act, *act_b, *v, *vt, *gxv, *gtv, *gx, *gs, *vbar, *s3x, *vact, *slabA, *slabB, *slab_v, *work_i, *work_b;
 } XwGroup;
+/* in-place float64 sum of buf[count] over the ranks, enqueued on `stream`: xw_allreduce's own signature */
+typedef int (*XwExchangeFn)(double* buf, int count, void* ctx, void* stream);
 typedef struct {
   int method, H, K, m, W, q, Pu, Pv, adjoint;
   int v_blocks, v_blocks_disc;    /* grid caps of the test network's launch in the two sub-steps (0 = default) */
@@ -278,6 +287,12 @@ typedef struct {
   double alpha, pollution, lr_u, lr_v, beta1, beta2, eps;
   double *theta, *phi, *scal, *grad_u, *grad_v, *m_u, *v_u, *m_v, *v_v;
   long long *step_u, *step_v, *lag_u;
+  /* several ranks (NULL / unused in one process): the in-place float64 sum over the ranks -- xw_allreduce itself with
+   * exchange_ctx = the communicator, or a host-side stand-in with the same contract (rehearsals without RCCL) -- and the
+   * generator sub-step's exchange buffer pack_u[2 Pu + 16] = [sum A | sum B | scal], i.e. scal == pack_u + 2 Pu */
+  XwExchangeFn exchange;
+  void* exchange_ctx;
+  double* pack_u;
 } XwSolverState;
 /* skip_v: v, dv/dt, nabla_x v(t_0) of this group are still those of the current phi and sample (opt-in reuse);
  * store_record: the test network's forward also stores its layer inputs (vact) for xw_disc_bwd;

@@ -123,7 +123,7 @@ def test_cabi_exports_match_header():
         body = re.search(r'typedef struct \{([^}]*)\}\s*' + cname + r'\s*;', hdr).group(1)
         body = re.sub(r'/\*.*?\*/', '', body, flags=re.S)
         fields = [re.sub(r'[\s\*]', '', name) for decl in body.split(';') if decl.strip()
-                  for name in re.sub(r'^\s*(const\s+)?(long\s+long|double|int)\b', '', decl.strip()).split(',')]
+                  for name in re.sub(r'^\s*(const\s+)?(long\s+long|double|int|void|XwExchangeFn)\b', '', decl.strip()).split(',')]
         assert fields == [f[0] for f in ctype._fields_], (cname, fields)
     # host-side (no GPU) entry points are callable
     assert _lib.lib.xw_abi_version() == _lib.ABI_VERSION

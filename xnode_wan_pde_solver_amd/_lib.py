@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('XW_LIBRARY') or os.path.join(_HERE, 'libxnwan.so')   # (override: kernel experiments only)
-ABI_VERSION = 29
+ABI_VERSION = 30
 
 c_f32p = ctypes.c_void_p   # coordinates / time grid: const double* (device)   [name kept from the float32 era]
 c_f64p = ctypes.c_void_p   # double*       (device)
@@ -30,7 +30,7 @@ class XwOdeBwdJob(ctypes.Structure):
 
 class XwGroup(ctypes.Structure):           # include/xnwan.h: one group of paths for xw_substep_gen / xw_substep_disc
     _fields_ = ([(n, c_int) for n in ('N', 'Nb', 'L', 'Lb', 'd', 'same_grid', 'w_per_point', 'amode', 'pair_i', 'pair_b', 'ns_u', 'ns_b',
-                                      'narrow')]
+                                      'narrow', 'sharded')]
                 + [(n, c_dbl) for n in ('Vol', 'Nglob', 'Nbglob', 's3_scale', 'init_off', 'bdry_off', 'ckappa')]
                 + [(n, c_vp) for n in ('xT', 'xvT', 'xbT', 't', 'tb', 'tpp', 'xvT_pts', 'start', 'start_b', 'h', 'href', 'f', 'g', 'w',
                                        'wt', 'w0', 'ghT', 'gwx0T', 'c', 'cp', 'A0', 'B0', 'u', 'ub', 'Y', 'Yb', 'act', 'act_b', 'v',
@@ -43,7 +43,11 @@ class XwSolverState(ctypes.Structure):
                                       'lag_hi')]
                 + [(n, c_dbl) for n in ('alpha', 'pollution', 'lr_u', 'lr_v', 'beta1', 'beta2', 'eps')]
                 + [(n, c_vp) for n in ('theta', 'phi', 'scal', 'grad_u', 'grad_v', 'm_u', 'v_u', 'm_v', 'v_v', 'step_u', 'step_v',
-                                       'lag_u')])
+                                       'lag_u', 'exchange', 'exchange_ctx', 'pack_u')])
+
+
+# XwSolverState.exchange: int (*)(double* buf, int count, void* ctx, void* stream) -- xw_allreduce's own signature
+EXCHANGE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p)
 
 
 # name -> argument types (return type is always int); mirrors include/xnwan.h line by line

@@ -110,14 +110,30 @@ class World:
             lib.xw_comm_destroy(self.comm)
             self.comm = None
 
+    def replicated(self, n, nb):
+        """A group this small is not sharded at all: every rank computes ALL of it, with the single-process arithmetic and
+        no exchange (identical inputs, deterministic kernels: the replicas stay bit-identical as they do through the
+        replicated Adam update).  A 16-path tile is the stepper's unit of work and the groups in question are latency-
+        bound, so a shard of less than a tile per rank does not shorten any launch -- it only adds the two or three
+        exchanges of a sub-step.  The time-varying ball domains produce such groups in every sample (config 5, hourglass:
+        interior groups of 5, 3, 3, 4, 2 paths next to one of 4991).  XW_REPLICATE_BELOW paths per rank (default 16; 0: never --
+        every group is sharded, ranks whose share is empty stay in step through shard_group / the engine's empty shares)."""
+        lim = self.replicate_below * self.size
+        return n < lim and nb < lim
+
+    replicate_below = int(os.environ.get('XW_REPLICATE_BELOW', '16'))
+
     def shard_group(self, du, dv, bd):
-        """this rank's slice of a group (every rank sampled the same global group from the same seed)"""
+        """this rank's slice of a group (every rank sampled the same global group from the same seed).  TOTAL: a group with
+        fewer paths than ranks leaves some ranks with an empty slice (shape [0, L, d+1]) of the interior sample, of the boundary
+        sample or of both -- such a rank launches nothing for what it does not hold but joins every exchange of the group's
+        sub-step with zeros and applies the same update (engine.Engine; the reference's nn.DataParallel scatters a batch of any
+        size, src/training.py:93-97)."""
         n, nb = du.shape[0], bd.shape[0]
         lo, hi = self.bounds(n)
         blo, bhi = self.bounds(nb)
-        if hi - lo == 0 or bhi - blo == 0:
-            raise RuntimeError('group of %d/%d paths is too small for %d ranks' % (n, nb, self.size))
-        return du[lo:hi], dv[lo:hi], bd[blo:bhi], n, nb
+        us = du[lo:hi]
+        return us, (us if dv is du else dv[lo:hi]), bd[blo:bhi], n, nb
 
 
 def init_from_env(backend=None):

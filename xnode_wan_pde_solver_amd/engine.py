@@ -33,6 +33,12 @@ from . import kernels as KN
 from ._lib import XnwanError
 from .sampling import HIP_HOST_LOCK, _PIN_POOL, Hypercube, _paths
 
+
+def ctypes_addr(fn):
+    """address of a ctypes callback object (kept alive by the caller)"""
+    import ctypes
+    return ctypes.cast(fn, ctypes.c_void_p).value
+
 # Every captured sub-step graph of the process, kept alive until it exits.  On this stack (ROCm 7.2 runtime inside the
 # PyTorch 2.10 wheel) destroying the executable of a multi-branch graph -- which is what Python's garbage collector does to
 # the graphs of a solver that went out of scope -- leaves the runtime's per-graph stream bookkeeping in a state in which a
@@ -363,6 +369,8 @@ class Engine:
         Per outer iteration this removes ~140 of ~150 callable evaluations, each a dozen tiny kernel launches."""
         if getattr(self, '_batch_tab', True) is False or len(triples) < 2:
             return [None] * len(triples)
+        if sum(t_[0].shape[0] for t_ in triples) == 0 or sum(t_[2].shape[0] for t_ in triples) == 0:
+            return [None] * len(triples)      # (a rank whose shares of this sample hold no interior / no boundary path at all: group by group)
         d, T0 = self.d, self.setup['T0']
         Xs = [t_[0].detach() for t_ in triples]
         XVs = [t_[1].detach() for t_ in triples]
@@ -370,6 +378,8 @@ class Engine:
         if hints is not None and all(h is not None for h in hints):      # (the loader read them off its host copies: no read-back)
             first_t = [h['t0'] for h in hints] + [h['tb0'] for h in hints]
         else:
+            if any(x.shape[0] == 0 for x in Xs + BXs):
+                raise XnwanError('tabulate_sample: an empty share needs the hints of the whole group (its first time)')
             first_t = torch.stack([x[0, 0, 0] for x in Xs] + [b[0, 0, 0] for b in BXs]).tolist()   # ONE host sync for all start times
         at0 = [float(v) == T0 for v in first_t[:len(Xs)]]
         bat0 = [float(v) == T0 for v in first_t[len(Xs):]]
@@ -396,11 +406,13 @@ class Engine:
             rows = P0.split(n)
             pick = lambda want: [r for r, a in zip(rows, flags) if a == want]                 # noqa: E731
             rows_h, rows_g = pick(True), pick(False)
-            hval = self.funcs['h'](torch.cat(rows_h, 0)).reshape(-1) if rows_h else None
-            gval = self.funcs['g'](torch.cat(rows_g, 0).unsqueeze(1)).reshape(-1) if rows_g else None
+            some = lambda rows: sum(r.shape[0] for r in rows) > 0          # noqa: E731  (a rank's shares may hold none of them)
+            hval = self.funcs['h'](torch.cat(rows_h, 0)).reshape(-1) if some(rows_h) else None
+            gval = self.funcs['g'](torch.cat(rows_g, 0).unsqueeze(1)).reshape(-1) if some(rows_g) else None
             ref = hval if hval is not None else gval
-            it_h = iter(hval.split([r.shape[0] for r in rows_h])) if hval is not None else None
-            it_g = iter(gval.to(ref.dtype).split([r.shape[0] for r in rows_g])) if gval is not None else None
+            none = ref.new_zeros(0)
+            it_h = iter(hval.split([r.shape[0] for r in rows_h])) if hval is not None else iter([none] * len(rows_h))
+            it_g = iter(gval.to(ref.dtype).split([r.shape[0] for r in rows_g])) if gval is not None else iter([none] * len(rows_g))
             val = torch.cat([next(it_h) if a else next(it_g) for a in flags], 0)
             return P0, n, val
         X0, n0, start = starts(Xs, at0)
@@ -423,14 +435,17 @@ class Engine:
             self._batch_tab_checked = True
             # bitwise against the per-group calls: f, h, w on the first group, and g, the start values with their gradient and the
             # boundary start values on the LAST triple (a late group: boundary-type starts on the hourglass)
-            x, t0, kl = Xs[0], tabs[0], len(Xs) - 1
+            # (the first and the last group of which this rank holds interior AND boundary paths: an empty share has nothing to compare)
+            full = [k for k in range(len(Xs)) if Xs[k].shape[0] > 0 and BXs[k].shape[0] > 0] or [0]
+            k0, kl = full[0], full[-1]
+            x, t0 = Xs[k0], tabs[k0]
             xl, bl, tl = Xs[kl], BXs[kl], tabs[kl]
             eq = lambda a, b: torch.equal(a.detach().reshape(-1), b.detach().reshape(-1))      # noqa: E731
             xl0 = xl[:, 0, :].clone().requires_grad_(True)
             s_l = self.funcs['h'](xl0) if at0[kl] else self.funcs['g'](xl0.unsqueeze(1)).reshape(-1)
             g_l = torch.autograd.grad(s_l.sum(), xl0)[0][:, 1:] if s_l.requires_grad else torch.zeros_like(xl0[:, 1:])
             sb_l = self.funcs['h'](bl[:, 0, :]) if bat0[kl] else self.funcs['g'](bl[:, 0, :].unsqueeze(1))
-            if not (eq(self.funcs['f'](x), t0['f']) and eq(self.funcs['h'](x[:, 0, :]), t0['h']) and eq(domain.func_w(XVs[0]), t0['w'])
+            if not (eq(self.funcs['f'](x), t0['f']) and eq(self.funcs['h'](x[:, 0, :]), t0['h']) and eq(domain.func_w(XVs[k0]), t0['w'])
                     and eq(self.funcs['g'](bl), tl['g']) and eq(s_l, tl['start']) and eq(g_l, tl['gh']) and eq(sb_l, tl['start_b'])):
                 import warnings
                 warnings.warn('the PDE callables give different values on a concatenation of groups than group by group (not pointwise?): '
@@ -440,7 +455,7 @@ class Engine:
         return tabs
 
     def load_group(self, X, XV, BX, domain, n_glob=None, nb_glob=None, into=None, shared_grid_t0=None, tab=None, verify=True,
-                   hints=None):
+                   hints=None, grids=None):
         """Prepare one group.  The user's callables (h, f, g, func_w, a, b) are evaluated on the device the given
         tensors live on and only their results are uploaded: pass the loader's host tensors to tabulate exactly like
         the reference's CPU path, or device tensors to tabulate on the GPU (float32 transcendental functions then
@@ -449,16 +464,25 @@ class Engine:
         samples): the checks that would otherwise read the device tensors back (four host syncs) are skipped.
         `hints` (list domains, sampling.Comb_loader.pack): the same facts per group, read off the loader's HOST copies --
         `shared_times` (all paths of the group share one time column), `same_grid` (the boundary group sits on the
-        interior group's grid)."""
+        interior group's grid).
+        `n_glob`, `nb_glob` (several ranks): X, XV, BX are this rank's SHARE of a group of that many interior / boundary paths --
+        the sub-steps of the group then run the exchange steps of dist.py; None: the whole group is here (one process, or a
+        group every rank computes in full, dist.World.replicated).  A share may be empty ([0, L, d+1]: a group with fewer paths
+        than ranks); `grids` = (time column of the WHOLE group's first interior path, of its first boundary path): the reference
+        integrates every path of a group on its first path's grid (src/model.py:92: inputs[0, :, 0]), which an empty share does
+        not hold and a later share holds a different one of where the paths of a group enter at their own times."""
         dev, d = self.dev, self.d
+        sharded = n_glob is not None and self.world is not None
         X, XV = X.detach(), XV.detach()
         BX = BX.detach() if BX is not None else None
         N, L = X.shape[0], X.shape[1]
         Nb = BX.shape[0] if BX is not None else 0
         if XV.shape[1] != L or XV.shape[0] != N:
             raise XnwanError('u- and v-samples of a group must have the same shape')
+        if (N == 0 or (BX is not None and Nb == 0)) and not (sharded and grids is not None):
+            raise XnwanError("a group without interior or boundary paths only exists as a rank's share of a sharded group (n_glob, grids)")
         S = {}
-        S['t'] = _d64(X[0, :, 0], dev).contiguous()
+        S['t'] = _d64(grids[0] if grids is not None else X[0, :, 0], dev).contiguous()
         S['xT'] = _d64(X[:, 0, 1:], dev).t().contiguous()
         S['xvT'] = _d64(XV[:, 0, 1:], dev).t().contiguous()
         # the test network is pointwise on XV: when the paths of a group do not share one time column (late-entry groups
@@ -476,9 +500,17 @@ class Engine:
             S['h'] = _d64(tab['h'], dev).reshape(-1).contiguous()
             S['f'] = _to_LN(tab['f'], dev)
             w, gw = tab['w'], tab['gw']
+        elif N == 0:
+            # an empty share: the user's callables are not asked about no points (max(), indexing ... of an empty tensor)
+            starts_T0 = float(hints['t0'] if hints is not None else (shared_grid_t0 if shared_grid_t0 is not None else grids[0][0])) == self.setup['T0']
+            z = lambda *shape: torch.zeros(*shape, dtype=F64, device=dev)  # noqa: E731
+            S['start'], S['ghT'], S['h'], S['f'] = z(0), z(d, 0), z(0), z(L, 0)
+            Lw = 1 if getattr(domain, 'time_independent', False) else L
+            w, gw = z(0, Lw), z(0, Lw, d + 1)
         else:
             X0 = X[:, 0, :].clone().requires_grad_(True)
-            starts_T0 = (float(X[0, 0, 0]) if shared_grid_t0 is None else float(shared_grid_t0)) == self.setup['T0']
+            t_first = grids[0][0] if grids is not None else X[0, 0, 0]
+            starts_T0 = (float(t_first) if shared_grid_t0 is None else float(shared_grid_t0)) == self.setup['T0']
             s = self.funcs['h'](X0) if starts_T0 else self.funcs['g'](X0.unsqueeze(1)).reshape(-1)
             S['start'] = _d64(s.detach(), dev).reshape(-1).contiguous()
             if s.requires_grad:
@@ -510,15 +542,19 @@ class Engine:
         Lb, same_grid, b_T0 = 0, True, False
         if BX is not None:
             Lb = BX.shape[1]
-            S['tb'] = _d64(BX[0, :, 0], dev).contiguous()
+            S['tb'] = _d64(grids[1] if grids is not None else BX[0, :, 0], dev).contiguous()
             same_grid = Lb == L and (shared_grid_t0 is not None or (hints['same_grid'] if hints is not None else bool(torch.equal(S['tb'], S['t']))))
             S['xbT'] = _d64(BX[:, 0, 1:], dev).t().contiguous()
             if tab is not None:
                 b_T0 = bool(tab['b_T0'])
                 S['start_b'] = _d64(tab['start_b'], dev).reshape(-1).contiguous()
                 S['g'] = _to_LN(tab['g'], dev)
+            elif Nb == 0:
+                b_T0 = float(hints['tb0'] if hints is not None else (shared_grid_t0 if shared_grid_t0 is not None else grids[1][0])) == self.setup['T0']
+                S['start_b'], S['g'] = torch.zeros(0, dtype=F64, device=dev), torch.zeros(Lb, 0, dtype=F64, device=dev)
             else:
-                b_T0 = (float(BX[0, 0, 0]) if shared_grid_t0 is None else float(shared_grid_t0)) == self.setup['T0']
+                tb_first = grids[1][0] if grids is not None else BX[0, 0, 0]
+                b_T0 = (float(tb_first) if shared_grid_t0 is None else float(shared_grid_t0)) == self.setup['T0']
                 sb = self.funcs['h'](BX[:, 0, :]) if b_T0 else self.funcs['g'](BX[:, 0, :].unsqueeze(1)).reshape(-1)
                 S['start_b'] = _d64(sb.detach(), dev).reshape(-1).contiguous()
                 S['g'] = _to_LN(self.funcs['g'](BX), dev)
@@ -526,13 +562,13 @@ class Engine:
         S['X'] = X.to(dev) if st.c_kappa is None else None      # only read by a general reaction callable c(u, t, x)
         S['A0'] = S['B0'] = None
         amode = 0
-        if not st.a_identity:
+        if not st.a_identity and N > 0:
             S['A0'], amode = self._tabulate_a(X[:, :1, :])     # [d,d,N] / [d,N] (diagonal) / [d,d] (constant) at time index 0
-        if not st.b_zero:
+        if not st.b_zero and N > 0:
             S['B0'] = self._tabulate_b(X[:, :1, :])            # [d, N]
         if self.verify_structure and verify:
             ver = getattr(into, 'sample_version', 0) if into is not None else 0
-            if ver % self.verify_every == 0:       # the first sample of a group and every verify_every-th refill after it
+            if ver % self.verify_every == 0 and N > 0:   # the first sample of a group and every verify_every-th refill after it
                 self._check_structure(X, ver // self.verify_every)
         vol = float(domain.V())
         nglob = float(n_glob if n_glob is not None else N)
@@ -542,7 +578,7 @@ class Engine:
         #   mean_nm (u_n - h_m)^2 = mean_n (u_n - mean h)^2 + var h          (src/loss.py:79; :84 likewise with g)
         #   sum_mn f_m phi_n      = N sum_n mean(f) phi_n                    (src/loss.py:70)
         pair_i = self.pairwise_single_slice and L == 1 and starts_T0
-        pair_b = self.pairwise_single_slice and Nb > 0 and Lb == 1 and b_T0
+        pair_b = self.pairwise_single_slice and (nb_glob if sharded else Nb) > 0 and Lb == 1 and b_T0
         S['href'] = None
         init_off = bdry_off = 0.0
         if pair_i and not st.b_zero:
@@ -553,7 +589,7 @@ class Engine:
             zero = torch.zeros((), dtype=F64, device=dev)
             gsum, gsq = (S['g'].sum(), (S['g'] ** 2).sum()) if pair_b else (zero, zero)
             stats = torch.stack([S['h'].sum(), (S['h'] ** 2).sum(), S['f'].sum(), gsum, gsq]).contiguous()
-            if self.world is not None:
+            if sharded:
                 self.world.all_reduce(stats)                 # the means are over ALL paths of the group, not this rank's share
             sh, shh, sf, sg, sgg = stats.tolist()
             if pair_i:
@@ -563,11 +599,14 @@ class Engine:
             if pair_b:
                 S['g'] = torch.full_like(S['g'], sg / nbglob)
                 bdry_off = sgg / nbglob - (sg / nbglob) ** 2
-        pair_state = dict(pair_i=pair_i, pair_b=pair_b, init_off=init_off, bdry_off=bdry_off, s3_scale=nglob if pair_i else 1.0)
+        # `sharded`: the sums of this group are partial sums (exchange steps in its sub-steps); `has_bdry`: the GROUP has boundary
+        # paths, whether or not this rank holds any (which parameters Adam skips must not depend on the rank, _gen_back)
+        pair_state = dict(pair_i=pair_i, pair_b=pair_b, init_off=init_off, bdry_off=bdry_off, s3_scale=nglob if pair_i else 1.0,
+                          sharded=sharded, has_bdry=BX is not None and (nb_glob if sharded else Nb) > 0)
         if into is not None:
             G = into
-            same = (G.N, G.L, G.Nb, G.Lb, G.same_grid, G.Vol, G.Nglob, G.Nbglob, G.pair_i, G.pair_b, G.amode) == (
-                N, L, Nb, Lb, same_grid, vol, nglob, nbglob, pair_i, pair_b, amode) and all(
+            same = (G.N, G.L, G.Nb, G.Lb, G.same_grid, G.Vol, G.Nglob, G.Nbglob, G.pair_i, G.pair_b, G.amode, G.sharded) == (
+                N, L, Nb, Lb, same_grid, vol, nglob, nbglob, pair_i, pair_b, amode, sharded) and all(
                 (getattr(G, k) is None) == (S[k] is None) and (S[k] is None or getattr(G, k).shape == S[k].shape)
                 for k in Group.SAMPLE_FIELDS)
             if same:
@@ -600,10 +639,12 @@ class Engine:
         sample, so the fields are regions of each group's one allocation (Group._arena) and ONE gather launch
         (kernels.gather_fields, a ~350-row table uploaded once) fills them -- instead of ~45 tensor operations per group.
         Same values bit for bit (copies), same Group attributes.  Returns None when the sample is not of that kind (anything
-        but float64 device tensors, general a / b / c, several GPUs, no batched tabulation): the caller goes group by group."""
+        but float64 device tensors, general a / b / c, no batched tabulation): the caller goes group by group.
+        `shards`: (X, XV, BX, n_glob, nb_glob, grids) per group as in load_group -- with several ranks this rank's shares (possibly
+        empty) of the groups that are sharded, the whole of those that are replicated."""
         tc = getattr(self, '_tab_cat', None)
         st = self.structure
-        if (tc is None or self.world is not None or not (st.a_identity and st.b_zero and st.c_kappa is not None)
+        if (tc is None or not (st.a_identity and st.b_zero and st.c_kappa is not None)
                 or getattr(domain, 'time_independent', False) or any(h is None for h in hints)):
             return None
         srcs = [tc[k] for k in ('f', 'g', 'w', 'gw', 'start', 'gh', 'h', 'start_b')]
@@ -619,13 +660,15 @@ class Engine:
         rows, groups, total = [], [], 0
         oN = oNL = oNb = oNbL = 0
         vol = float(domain.V())
-        for k, ((X, XV, BX, n_glob, nb_glob), hn) in enumerate(zip(shards, hints)):
+        for k, ((X, XV, BX, n_glob, nb_glob, grids), hn) in enumerate(zip(shards, hints)):
             N, L, Nb, Lb = X.shape[0], X.shape[1], BX.shape[0], BX.shape[1]
+            sharded = n_glob is not None and self.world is not None
             shared = bool(hn['shared_times'])
             same_grid = Lb == L and bool(hn['same_grid'])
             starts_T0, b_T0 = bool(tc['at0'][k]), bool(tc['bat0'][k])
             G = Group()
-            G.domain, G.N, G.L, G.Nb, G.Vol, G.Nglob, G.Nbglob = domain, N, L, Nb, vol, float(N), float(max(Nb, 1))
+            G.domain, G.N, G.L, G.Nb, G.Vol = domain, N, L, Nb, vol
+            G.Nglob, G.Nbglob = float(n_glob if n_glob is not None else N), float(nb_glob if nb_glob is not None else max(Nb, 1))
             G.Lb, G.same_grid, G.amode = Lb, same_grid, 0
             fields = [('t', (L,)), ('xT', (d, N))]
             if not shared:
@@ -641,7 +684,10 @@ class Engine:
             x0, x1, x2 = X.stride()
             b0, b1, b2 = BX.stride()
             xp, bp = X.data_ptr(), BX.data_ptr()
-            src = {'t': (xp, 1, 1, L, 0, 0, x1), 'xT': (xp + 8 * x2, 1, d, N, 0, x2, x0),
+            # (the grids are those of the WHOLE group's first paths: load_group)
+            t_src = (xp, x1) if grids is None else (grids[0].data_ptr(), grids[0].stride(0))
+            tb_src = (bp, b1) if grids is None else (grids[1].data_ptr(), grids[1].stride(0))
+            src = {'t': (t_src[0], 1, 1, L, 0, 0, t_src[1]), 'xT': (xp + 8 * x2, 1, d, N, 0, x2, x0),
                    'tpp': (xp, 1, L, N, 0, x1, x0), 'tpp0': (xp, 1, 1, N, 0, 0, x0), 'xvT_pts': (xp + 8 * x2, d, L, N, x2, 0, x0),
                    'start': (start.data_ptr() + 8 * oN * start.stride(0), 1, 1, N, 0, 0, start.stride(0)),
                    'ghT': (gh.data_ptr() + 8 * oN * h0, 1, d, N, 0, h1, h0),
@@ -651,16 +697,20 @@ class Engine:
                    'wt': (gw_cat.data_ptr() + 8 * oNL * g0, 1, L, N, 0, g0, L * g0),
                    'w0': (w_cat.data_ptr() + 8 * oNL, 1, 1, N, 0, 0, L),
                    'gwx0T': (gw_cat.data_ptr() + 8 * (oNL * g0 + g1), 1, d, N, 0, g1, L * g0),
-                   'tb': (bp, 1, 1, Lb, 0, 0, b1), 'xbT': (bp + 8 * b2, 1, d, Nb, 0, b2, b0),
+                   'tb': (tb_src[0], 1, 1, Lb, 0, 0, tb_src[1]), 'xbT': (bp + 8 * b2, 1, d, Nb, 0, b2, b0),
                    'start_b': (sb.data_ptr() + 8 * oNb * sb.stride(0), 1, 1, Nb, 0, 0, sb.stride(0)),
                    'g': (g_cat.data_ptr() + 8 * oNbL, 1, Lb, Nb, 0, 1, Lb)}
             for name, shape in fields:
                 a, n0_, n1_, n2_, s0_, s1_, s2_ = src[name]
+                if n0_ * n1_ * n2_ == 0:        # (an empty share: nothing to gather)
+                    continue
                 rows.append((a, base + 8 * G._lazy[name][0], n0_, n1_, n2_, s0_, s1_, s2_, total))
                 total += n0_ * n1_ * n2_
+            has_bdry = (nb_glob if sharded else Nb) > 0
             pair_i = self.pairwise_single_slice and L == 1 and starts_T0
-            pair_b = self.pairwise_single_slice and Nb > 0 and Lb == 1 and b_T0
-            G.__dict__.update(dict(pair_i=pair_i, pair_b=pair_b, init_off=0.0, bdry_off=0.0, s3_scale=float(N) if pair_i else 1.0))
+            pair_b = self.pairwise_single_slice and has_bdry and Lb == 1 and b_T0
+            G.__dict__.update(dict(pair_i=pair_i, pair_b=pair_b, init_off=0.0, bdry_off=0.0, s3_scale=G.Nglob if pair_i else 1.0,
+                                   sharded=sharded, has_bdry=has_bdry))
             old = cache[k] if k < len(cache) else None
             G.graphs = {}
             ver = old.sample_version if old is not None else 0
@@ -685,7 +735,10 @@ class Engine:
             if G.pair_i or G.pair_b:
                 zero = torch.zeros((), dtype=F64, device=dev)
                 gsum, gsq = (G.g.sum(), (G.g ** 2).sum()) if G.pair_b else (zero, zero)
-                sh, shh, sf, sg, sgg = torch.stack([G.h.sum(), (G.h ** 2).sum(), G.f.sum(), gsum, gsq]).tolist()
+                stats = torch.stack([G.h.sum(), (G.h ** 2).sum(), G.f.sum(), gsum, gsq]).contiguous()
+                if G.sharded:
+                    self.world.all_reduce(stats)             # (the means are over ALL paths of the group: load_group)
+                sh, shh, sf, sg, sgg = stats.tolist()
                 if G.pair_i:
                     G.href = torch.full((G.N,), sh / G.Nglob, dtype=F64, device=dev)
                     G.f.fill_(sf / G.Nglob)
@@ -904,10 +957,37 @@ class Engine:
             st.m_u, st.v_u, st.m_v, st.v_v = (self.adam_u['m'].data_ptr(), self.adam_u['v'].data_ptr(), self.adam_v['m'].data_ptr(),
                                               self.adam_v['v'].data_ptr())
             st.step_u, st.step_v, st.lag_u = self.adam_u['step'].data_ptr(), self.adam_v['step'].data_ptr(), self.adam_u['lag'].data_ptr()
+            st.exchange = st.exchange_ctx = st.pack_u = None
+            if self.world is not None:
+                st.pack_u = self.pack_u.data_ptr()
+                if self.world.comm is not None:            # RCCL: the library's own entry point, enqueued on the stream like the kernels
+                    from ._lib import lib
+                    import ctypes
+                    st.exchange = ctypes.cast(lib.xw_allreduce, ctypes.c_void_p).value
+                    st.exchange_ctx = self.world.comm.value if hasattr(self.world.comm, 'value') else self.world.comm
+                else:                                      # rehearsal (gloo): a host-side stand-in with the same contract
+                    self._exchange_cb = self._host_exchange()
+                    st.exchange = ctypes_addr(self._exchange_cb)
         st.v_blocks, st.v_blocks_disc = self.v_blocks, self.v_blocks_disc
         st.alpha, st.pollution = float(self.alpha), float(self.pollution)
         st.lr_u, st.lr_v = float(self.config['u_rate']), float(self.config['v_rate'])
         return st
+
+    def _host_exchange(self):
+        """XwSolverState.exchange without RCCL (the `gloo` rehearsal: several ranks on one GPU, tests): the same contract as
+        xw_allreduce -- in-place float64 sum of buf[count] over the ranks, in stream order -- through torch.distributed with the
+        buffer staged on the host.  The runner only ever passes the engine's own exchange buffers."""
+        from ._lib import EXCHANGE_FN
+        bufs = {t.data_ptr(): t for t in (self.pack_u, self.scal, self.grad_v)}
+
+        def exchange(buf, count, _ctx, _stream):
+            try:
+                self.world.all_reduce(bufs[buf][:count])
+                return 0
+            except BaseException as e:          # (an exception cannot cross the C frames: kept for the caller, reported as XW_E_COMM)
+                self._exchange_error = e
+                return -4
+        return EXCHANGE_FN(exchange)
 
     def _runner_group(self, G):
         """XwGroup of a loaded group: pointers once per allocation, the per-sample scalars every time"""
@@ -926,15 +1006,18 @@ class Engine:
             nar = lambda jobs, **kw: self._narrow_ok(jobs, **kw)  # noqa: E731
             ji, jb = self._job(G, 'i'), (self._job(G, 'b') if G.Nb else None)
             joint = G.Nb and G.same_grid
+            # (bit 2: the runner launches sweep A, the boundary sweep on the same grid and sweep B as ONE launch -- the tile count
+            #  that decides is that launch's, as in _gen_front_compact; bit 4 is unused)
             bits = [nar([ji] + ([jb] if joint else []), alone=False, forward=True),
                     bool(jb) and nar([jb], alone=False, forward=True),
-                    nar([ji] + ([jb] if joint else []), alone=False),
+                    nar([ji] + ([jb] if joint else []) + [ji], alone=False),
                     bool(jb) and nar([jb], alone=False),
-                    nar([ji], alone=True),
+                    False,
                     nar([ji], alone=False, params=False),
                     nar([ji], alone=False, forward=True),
                     nar([ji], alone=False, params=False)]
             xg.narrow = sum(1 << i for i, b in enumerate(bits) if b)
+        xg.sharded = int(bool(getattr(G, 'sharded', False)))
         xg.pair_i, xg.pair_b = int(bool(G.pair_i)), int(bool(G.pair_b))
         xg.Vol, xg.Nglob, xg.Nbglob, xg.s3_scale = float(G.Vol), float(G.Nglob), float(G.Nbglob), float(G.s3_scale)
         xg.init_off, xg.bdry_off, xg.ckappa = float(G.init_off), float(G.bdry_off), float(self.structure.c_kappa)
@@ -943,8 +1026,19 @@ class Engine:
         return xg
 
     def _runner_ok(self, G):
-        return (self.use_runner and self.world is None and self.structure.c_kappa is not None and G.c is None
-                and not getattr(G, 'persistent', True))
+        return (self.use_runner and self.structure.c_kappa is not None and G.c is None and not getattr(G, 'persistent', True))
+
+    def _world_of(self, G):
+        """the ranks that hold shares of G: None when the whole group is here (one process, or a group every rank computes in
+        full -- dist.World.replicated -- with the single-process arithmetic and no exchange)"""
+        return self.world if getattr(G, 'sharded', self.world is not None) else None
+
+    def _field_seen(self, G):
+        """has a group of this sub-iteration integrated the ODE yet?  (no: the field's parameters have no gradient, Adam skips
+        them -- Engine.__init__.)  From facts every rank shares: `has_bdry` is the GROUP's, not this rank's possibly empty share"""
+        touched = G.L > 1 or (getattr(G, 'has_bdry', G.Nb > 0) and G.Lb > 1)
+        self._field_touched = touched or (self.accum_u is not None and self._field_touched)
+        return self._field_touched
 
     def _narrow_ok(self, jobs, alone, forward=False, params=True):
         """narrow tiles (csrc/xw_ode_n4.h) for this stepper launch?  XW_NARROW: 0 never, 1 by size (default), 2 wherever the
@@ -973,7 +1067,7 @@ class Engine:
         Single GPU: the sums are global, so the same launch also forms the loss values and advances the optimiser's
         counter (`adam_state`); with several GPUs that is done by KN.losses after the all-reduce."""
         fin = None
-        if self.world is None and adam_state is not None:
+        if self._world_of(G) is None and adam_state is not None:
             fin = dict(Lb=G.Lb, Nbglob=G.Nbglob, alpha=self.alpha, step=adam_state['step'], init_off=G.init_off, bdry_off=G.bdry_off)
         pair = dict(href=G.href, s3_scale=G.s3_scale) if G.pair_i else None
         # generator sub-step: the boundary penalty's sum of squares (a loss value; the sweeps form its cotangent themselves) rides along
@@ -1053,7 +1147,7 @@ class Engine:
             e_A = self._mark()
             # The slabs of sweeps A + boundary are summed HERE, beside the tail of sweep B, so that the update at the end of the sub-step
             # only has sweep B's slabs left to read (k_slab_sum is the A half of k_adam's own summation tree: the same bits).
-            G.sumA_ready = self.early_slab_sum and self.world is None and self.accum_u is None and self.use_streams
+            G.sumA_ready = self.early_slab_sum and self._world_of(G) is None and self.accum_u is None and self.use_streams
             e_S = None
             if G.sumA_ready:
                 if getattr(G, 'sumA', None) is None:
@@ -1127,20 +1221,17 @@ class Engine:
     def _gen_back(self, G):
         lr, st = self.config['u_rate'], self.adam_u
         acc = self.accum_u
-        # has any group of this sub-iteration integrated the ODE yet?  (no: the field's parameters have no gradient, Adam
-        # skips them -- Engine.__init__)
-        touched = G.L > 1 or (G.Nb > 0 and G.Lb > 1)
-        self._field_touched = touched or (acc is not None and self._field_touched)
-        lag = dict(lag=st['lag'], lag_range=self.field_range, skip=self.adam_skips_untouched and not self._field_touched)
-        if self.world is not None:     # (single GPU: loss values and counter were done by the reduction launch, _contract)
+        world = self._world_of(G)
+        lag = dict(lag=st['lag'], lag_range=self.field_range, skip=self.adam_skips_untouched and not self._field_seen(G))
+        if world is not None:     # (the whole group here: loss values and counter were done by the reduction launch, _contract)
             if G.pair_i:
                 KN.pair_fold(self.scal, G.Vol, G.Nglob)
             KN.losses(self.scal, G.L, G.Lb, G.Vol, G.Nglob, G.Nbglob, self.alpha, step=st['step'], init_off=G.init_off,
                       bdry_off=G.bdry_off)
-        if self.world is None and getattr(G, 'sumA_ready', False) and acc is None:
+        if world is None and getattr(G, 'sumA_ready', False) and acc is None:
             KN.adam(self.theta.data, None, st['m'], st['v'], st['step'], lr, gslabB=G.slabB, scal=self.scal,
                     gextraA=G.sumA, gsum_out=self.grad_u, bump_step=-1, **lag)
-        elif self.world is None:
+        elif world is None:
             KN.adam(self.theta.data, G.slabA, st['m'], st['v'], st['step'], lr, gslabB=G.slabB, scal=self.scal,
                     gextraA=acc, gsum_out=self.grad_u, bump_step=-1, **lag)
         else:
@@ -1170,27 +1261,34 @@ class Engine:
         """phi was changed from outside the engine (optimizer_v.step(), load_state_dict, ...)"""
         self._phi_version += 1
 
+    def _run_runner(self, fn, *args):
+        from ._lib import check
+        self._exchange_error = None
+        rc = fn(*args)
+        if getattr(self, '_exchange_error', None) is not None:      # (raised inside the host-side exchange stand-in)
+            err, self._exchange_error = self._exchange_error, None
+            raise err
+        check(rc, fn.__name__)
+
     def generator_step(self, G):
         """one pass of the generator sub-step body; loss_u is left in scal[4] (device)"""
         sfx = self._v_fresh(G)
+        world = self._world_of(G)
         if self._runner_ok(G):
-            from ._lib import lib, check
-            touched = G.L > 1 or (G.Nb > 0 and G.Lb > 1)
-            self._field_touched = touched or (self.accum_u is not None and self._field_touched)
-            skip = self.adam_skips_untouched and not self._field_touched
+            from ._lib import lib
+            skip = self.adam_skips_untouched and not self._field_seen(G)
             G.ck = self.structure.c_kappa
-            check(lib.xw_substep_gen(self._runner_group(G), self._runner_state(), int(bool(G.skip_v)),
-                                     int(bool(getattr(G, 'vact_valid', False))), KN._p(self.accum_u), int(skip), KN._stream()),
-                  'xw_substep_gen')
+            self._run_runner(lib.xw_substep_gen, self._runner_group(G), self._runner_state(), int(bool(G.skip_v)),
+                             int(bool(getattr(G, 'vact_valid', False))), KN._p(self.accum_u), int(skip), KN._stream())
             return
-        if self.world is None:
+        if world is None:
             self._run(G, 'gen' + sfx, self._gen_all)
             return
         if self.capture_exchange:
             self._run(G, 'gen_dist' + sfx, self._gen_all_dist)
             return
         self._run(G, 'gen_front' + sfx, self._gen_front_packed)   # ... -> pack_u = [sum A | sum B | scal]
-        self.world.all_reduce(self.pack_u)                        # the ONE exchange of the generator sub-step
+        world.all_reduce(self.pack_u)                             # the ONE exchange of the generator sub-step
         self._run(G, 'gen_back', self._gen_back)
 
     def _gen_all_dist(self, G):
@@ -1201,9 +1299,29 @@ class Engine:
 
     def _gen_front_packed(self, G):
         """several GPUs: the front segment ends with the slab sums into the exchange buffer (same captured graph)"""
-        self._gen_front(G)
         P = self.Pu
+        if G.N == 0:
+            return self._gen_front_empty(G)
+        self._gen_front(G)
         KN.slab_sum2(G.slabA, self.pack_u[:P], G.slabB, self.pack_u[P:2 * P])
+
+    def _gen_front_empty(self, G):
+        """_gen_front_packed on a rank whose share of the group holds no interior path (fewer paths than ranks): nothing of the
+        weak form lives here -- zeros go into the exchange -- but the boundary paths the rank holds, if any, take their forward
+        pass and their sweep as usual (csrc/xw_substep.hip does the same for the runner's groups)"""
+        P, th = self.Pu, self.theta.data
+        M = (self.method, self.H, self.K, self.m)
+        self.pack_u.zero_()
+        if not G.Nb:
+            return
+        fwd_b = [self._job(G, 'b')]
+        KN.ode_fwd_multi(fwd_b, G.tb, th, *M, narrow=self._narrow_ok(fwd_b, alone=False, forward=True))
+        res_b = dict(u=G.ub, ref=G.g, coef=2.0 * self.alpha / (G.Nbglob * G.Lb), base=0.0, first_only=False)
+        sweep_b = [dict(self._job(G, 'b', None, G.slabA[G.ns_u:]), res=res_b)]
+        KN.ode_bwd_multi(sweep_b, G.tb, th, *M, want_x=False, want_params=True, adjoint=self.adjoint,
+                         narrow=self._narrow_ok(sweep_b, alone=False))
+        KN.bdry_partials(G.ub, G.g, self.alpha, G.Nbglob, self.scal, G.work_b)
+        KN.slab_sum(G.slabA[G.ns_u:], out=self.pack_u[:P])
 
     # ------------------------------------------------------------------------------------------------------------
     # discriminator sub-step (src/training.py:152-162)
@@ -1212,6 +1330,9 @@ class Engine:
         """main: test network (+ its record) -> [join] -> I, sum v^2, loss values;  side 1: u-forward -> x-sweep"""
         th = self.theta.data
         M = (self.method, self.H, self.K, self.m)
+        if G.N == 0:                     # an empty share of a sharded group: zeros into both exchanges
+            self.scal.zero_()
+            return
         e0 = self._mark()
         if not getattr(G, 'skip_v', False):
             self._launch_test_net_here(G, blocks=self.v_blocks_disc)
@@ -1238,15 +1359,19 @@ class Engine:
             KN.disc_bwd(G.xvT_pts, None, self.phi.data, G.vbar.view(1, -1), self.W, self.q, tpp=G.tpp, gslab=G.slab_v, act=act)
 
     def _disc_mid_packed(self, G):
+        if G.N == 0:
+            self.grad_v.zero_()
+            return
         self._disc_mid(G)
         KN.slab_sum(G.slab_v, out=self.grad_v)
 
     def _disc_back(self, G):
         lr, st = self.config['v_rate'], self.adam_v
         acc = self.accum_v
-        if self.world is not None:
+        world = self._world_of(G)
+        if world is not None:
             KN.losses(self.scal, G.L, G.Lb, G.Vol, G.Nglob, G.Nbglob, self.alpha, step=st['step'])
-        if self.world is None:
+        if world is None:
             KN.adam(self.phi.data, G.slab_v, st['m'], st['v'], st['step'], lr, gextraA=acc, gsum_out=self.grad_v,
                     bump_step=-1)
         else:
@@ -1280,14 +1405,14 @@ class Engine:
         """one pass of the discriminator sub-step body; loss_v is left in scal[5] (device)"""
         sfx = self._v_fresh(G, store=True)
         self._phi_version += 1                                    # phi changes at the end of this sub-step
+        world = self._world_of(G)
         if self._runner_ok(G):
-            from ._lib import lib, check
+            from ._lib import lib
             G.ck = self.structure.c_kappa
-            check(lib.xw_substep_disc(self._runner_group(G), self._runner_state(), int(bool(G.skip_v)),
-                                      int(bool(getattr(G, 'vact_valid', False))), KN._p(self.accum_v), KN._stream()),
-                  'xw_substep_disc')
+            self._run_runner(lib.xw_substep_disc, self._runner_group(G), self._runner_state(), int(bool(G.skip_v)),
+                             int(bool(getattr(G, 'vact_valid', False))), KN._p(self.accum_v), KN._stream())
             return
-        if self.world is None:
+        if world is None:
             self._run(G, 'disc' + sfx, self._disc_all)
             return
         if self.capture_exchange:
@@ -1296,7 +1421,7 @@ class Engine:
         self._run(G, 'disc_front' + sfx, self._disc_front)
         self._reduce_sums(G)                                      # I and sum v^2 must be global before the cotangent
         self._run(G, 'disc_mid' + ('_act' if getattr(G, 'vact_valid', False) else ''), self._disc_mid_packed)
-        self.world.all_reduce(self.grad_v)
+        world.all_reduce(self.grad_v)
         self._run(G, 'disc_back', self._disc_back)
 
     # ------------------------------------------------------------------------------------------------------------

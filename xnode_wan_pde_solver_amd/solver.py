@@ -220,7 +220,7 @@ class NODE_WAN_solver:
         return self.domain(s['shape_param'], s['dim'], s['T0'], s['T'], s['N_t'])
 
     def _loader(self, domain, interior_only=False):
-        if interior_only and self.world is None and not self.device_sampling and not self.tabulate_on_host:
+        if interior_only and not self.device_sampling and not self.tabulate_on_host:
             return sampling.Comb_loader(self.setup['N_r'], self.setup['N_b'], domain, self.device, interior_only=True)
         if self.world is not None and self.rank_local_sampling and hasattr(domain, 'interior_x'):
             return sampling.RankCubeLoader(self.setup['N_r'], self.setup['N_b'], domain, self.device, self.world.rank, self.world.size)
@@ -267,12 +267,20 @@ class NODE_WAN_solver:
         return out
 
     def _shard(self, points):
-        """this rank's contiguous share of every group (dist.py); identity on one GPU"""
+        """(X, XV, BX, n_glob, nb_glob, grids) per group: this rank's contiguous share of every group (dist.py) with the path counts
+        of the whole group and the time columns of its first interior / boundary path (Engine.load_group); identity -- the
+        counts and grids None -- on one GPU and for the groups every rank computes in full (dist.World.replicated)"""
         if self.world is None:
-            return [(du, dv, bd, None, None) for (du, dv, bd) in points]
+            return [(du, dv, bd, None, None, None) for (du, dv, bd) in points]
         if self._rank_local:                       # the loader already drew this rank's share only
-            return [(du, dv, bd, self.setup['N_r'], self.setup['N_b']) for (du, dv, bd) in points]
-        return [self.world.shard_group(du, dv, bd) for (du, dv, bd) in points]
+            return [(du, dv, bd, self.setup['N_r'], self.setup['N_b'], None) for (du, dv, bd) in points]
+        out = []
+        for du, dv, bd in points:
+            if len(points) > 1 and self.world.replicated(du.shape[0], bd.shape[0]):
+                out.append((du, dv, bd, None, None, None))
+            else:
+                out.append(self.world.shard_group(du, dv, bd) + ((du[0, :, 0], bd[0, :, 0]),))
+        return out
 
     def _l_norm(self, points, volume, as_tensor=False):
         """the L^p diagnostic of src/training.py:167; as_tensor: a 0-dim float64 device tensor, nothing read back"""
@@ -332,7 +340,8 @@ class NODE_WAN_solver:
                 u_fn = lambda x: self.u_net(x, starts_at_T0=at_T0)   # noqa: E731
                 return L_norm(X, u_fn, self.p, self.func_u_sol, volume, self.setup['N_r'])
             groups = points.interioru
-            lean = self._l_norm_groups(points, volume) if (isinstance(groups, list) and groups and self.world is None) else None
+            # (several ranks: every rank evaluates the diagnostic on the whole sample, as _l_norm_value does for the cube)
+            lean = self._l_norm_groups(points, volume) if (isinstance(groups, list) and groups) else None
             if lean is not None:
                 return lean
             if isinstance(groups, list) and groups and not groups[0].is_cuda:
@@ -443,7 +452,7 @@ class NODE_WAN_solver:
 
     def _sampling_process(self):
         """the forked sampler of sampler_proc.py when this run can use it, else None (the helper thread, or no overlap at all)"""
-        if not (self.sampler_process and self.overlap_sampling and self.defer_list_readback and self.stop is None and self.world is None
+        if not (self.sampler_process and self.overlap_sampling and self.defer_list_readback and self.stop is None
                 and not self.device_sampling and not self.tabulate_on_host and isinstance(self.domain, type)
                 and issubclass(self.domain, sampling._NSphereBase) and hasattr(os, 'fork')):
             return None
@@ -578,8 +587,8 @@ class NODE_WAN_solver:
                     # every iteration after the first: the sample into static buffers, ONE graph replay fills the group
                     G = eng.refill_compact(old, comp[0], domain, comp[1], comp[2])
                 else:
-                    (du, dv, bd, ng, nbg), = self._shard(self._groups(points))
-                    G = eng.load_group(du, dv, bd, domain, ng, nbg, into=old, shared_grid_t0=self._grid_hint)
+                    (du, dv, bd, ng, nbg, grids), = self._shard(self._groups(points))
+                    G = eng.load_group(du, dv, bd, domain, ng, nbg, into=old, shared_grid_t0=self._grid_hint, grids=grids)
                 group = G
                 self._group_cache = [G]
                 G.persistent = True
@@ -662,7 +671,8 @@ class NODE_WAN_solver:
             self._group_cache = self._group_cache[:len(shards)] + [None] * (len(shards) - len(self._group_cache))
         # list domains: the callables are evaluated once for all groups of the sample; the structure guard runs on the
         # largest group of the sample (all groups are slices of the same draw)
-        hints = self._group_hints if (self._group_hints is not None and self.world is None) else [None] * len(shards)
+        # (the loader's facts about a group -- first times, shared time column, same grid -- hold for every rank's share of it)
+        hints = self._group_hints if self._group_hints is not None else [None] * len(shards)
         tabs = eng.tabulate_sample([sh[:3] for sh in shards], domain, hints=hints) if len(shards) > 1 else [None]
         big = max(range(len(shards)), key=lambda i: shards[i][0].shape[0] * shards[i][0].shape[1])
         order = list(range(len(shards)))
@@ -673,15 +683,15 @@ class NODE_WAN_solver:
             waits = lambda i: (shards[i][0].shape[1] == 1 or shards[i][2].shape[1] == 1) and hints[i] is not None and (  # noqa: E731
                 hints[i]['t0'] == T0 or hints[i]['tb0'] == T0)
             order.sort(key=lambda i: bool(waits(i)) or hints[i] is None)
-        if len(shards) > 1 and eng.packed_load and tabs[0] is not None and self.world is None:
+        if len(shards) > 1 and eng.packed_load and tabs[0] is not None:
             packed = eng.load_groups_packed(shards, hints, domain, self._group_cache, big)      # (one gather launch for all groups)
             if packed is not None:
                 return packed
         groups = [None] * len(shards)
         for i in order:
-            du, dv, bd, ng, nbg = shards[i]
+            du, dv, bd, ng, nbg, grids = shards[i]
             groups[i] = eng.load_group(du, dv, bd, domain, ng, nbg, into=self._group_cache[i], shared_grid_t0=self._grid_hint, tab=tabs[i],
-                                       verify=(i == big), hints=hints[i])
+                                       verify=(i == big), hints=hints[i], grids=grids)
         return groups
 
     def _list_iteration_deferred(self, groups, domain, ahead, pool, draw_ahead, k, last, past_losses, times):
@@ -691,7 +701,8 @@ class NODE_WAN_solver:
         result, queues the diagnostic and loads the NEXT sample's groups (callables tabulated, Group objects refilled: same
         stream, so behind the sub-steps that still read the old contents), and only then reads everything back at once.  The
         synchronous order (_iterate) has the GPU idle during the 10 ms of loading and the host idle during the 13 ms of sub-steps.
-        Same values, same files, same order of writes; needs the sampling thread (no stop hook) and one GPU."""
+        Same values, same files, same order of writes; needs the sampling thread or process (no stop hook).  Several ranks walk
+        it in lockstep: every exchange of a sub-step is a call on the stream (RCCL) or staged through the host (gloo rehearsal)."""
         eng, d, n1, n2 = self.engine, self.setup['dim'], self.n1, self.n2
         # (host seconds per phase, summed over the run: tools/train_cfg5.py prints them)
         phase = self.__dict__.setdefault('_list_phase_seconds', dict.fromkeys(('substeps', 'sampler_wait', 'diagnostic', 'load_next', 'read_back', 'files'), 0.0))
@@ -738,16 +749,20 @@ class NODE_WAN_solver:
             for x_ in vals:
                 self.av_l += x_                   # (summed in group order, like the reference's running sum)
             past_losses.append(self.av_l)
-            past_losses.write('losses_NODE_' + str(d) + '.json')
+            main = self._is_main()            # (several ranks: identical values everywhere, rank 0 writes the files)
+            if main:
+                past_losses.write('losses_NODE_' + str(d) + '.json')
             if self.av_l < self.best_l:
-                keys = keys or self._state_dict_layout()
-                torch.save(self._state_dict_from(snaps[i], keys), 'best_model_weights_NODE.pth')   # u_net as it was after sub-iteration i
+                if main:
+                    keys = keys or self._state_dict_layout()
+                    torch.save(self._state_dict_from(snaps[i], keys), 'best_model_weights_NODE.pth')   # u_net as it was after sub-iteration i
                 self.best_l = self.av_l
         self.last_loss_v, self._last_L2 = row[n1 * ng], row[n1 * ng + 1]
         times.append(time.time())
-        with open('L2_NODE_' + str(d) + '.json', 'w') as fh:
-            json.dump([self._last_L2], fh)
-        times.write('Time_NODE_' + str(d) + '.json')
+        if self._is_main():
+            with open('L2_NODE_' + str(d) + '.json', 'w') as fh:
+                json.dump([self._last_L2], fh)
+            times.write('Time_NODE_' + str(d) + '.json')
         lap('files', tick)
         if failed is not None:
             raise failed
@@ -777,7 +792,7 @@ class NODE_WAN_solver:
                 several = len(groups) > 1
                 for G in groups:
                     G.persistent = not several        # list domains: group shapes change every sample -> no graph capture
-                if several and ahead is not None and self.world is None and self.defer_list_readback:
+                if several and ahead is not None and self.defer_list_readback:
                     prepared, nxt_domain, nxt_points, ahead = self._list_iteration_deferred(groups, domain, ahead, pool, draw_ahead, k, last,
                                                                                             past_losses, times)
                     if report and k % report_it == 0:
