@@ -332,5 +332,35 @@ def test_config5_hourglass_on_two_ranks_matches_one_process(tmp_path):
     params = dict(LIST_PARAMS, domain='NSphere_THourglass', dim=10, N_t=20, N_r=8192, N_b=8192, iterations=1)
     # (phi: 20 Adam updates of 3201 parameters; Adam divides by the gradient's running magnitude, so an entry whose gradient
     #  is rounding noise of the 8192-path sums moves by lr x O(1) whichever way the noise points -- 3e-6 observed)
-    one, ranks = _check_list_ranks(tmp_path, 2, params, 0, dict(replicate_below=0), rtol=1e-7, rtol_phi=2e-5)
+    one, ranks = _check_list_ranks(tmp_path, 2, params, 4, dict(replicate_below=0), rtol=1e-7, rtol_phi=2e-5)      # (seed 4: two groups of ONE interior path)
     assert min(sh[0] for r in ranks for sample in r['shares'] for sh in sample) == 0
+
+
+def _list_native_worker(rank, size, port, out_dir, params, seed, opts):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(size), LOCAL_RANK=str(rank),
+                      HSA_ENABLE_IPC_MODE_LEGACY='0')
+    from xnode_wan_pde_solver_amd import dist as xdist
+    torch.cuda.set_device(rank)
+    torch.distributed.init_process_group('nccl', rank=rank, world_size=size, device_id=torch.device('cuda', rank))
+    world = xdist.World()
+    assert world.capturable
+    _list_train(world, os.path.join(out_dir, 'list%d.pt' % rank), os.path.join(out_dir, 'wd%d' % rank), params, seed, opts)
+    world.close()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_list_domain_group_runner_calls_rccl_between_its_launches(tmp_path):
+    """a 1-rank RCCL communicator on the test box's GPU: the sharded groups of a ball domain go through xw_substep_gen / _disc with
+    XwSolverState.exchange = xw_allreduce itself (device-side calls on the stream, between the runner's launches), the small ones
+    are replicated, the samples come from the sampling process forked AFTER RCCL has started its threads -- and train() leaves
+    what the plain single-process run leaves"""
+    params = dict(LIST_PARAMS, domain='NSphere_THourglass')
+    mp.spawn(_list_native_worker, args=(1, _free_port(), str(tmp_path), params, 5, dict()), nprocs=1, join=True)
+    _list_train(None, str(tmp_path / 'list_single.pt'), str(tmp_path / 'wd_single'), params, 5, dict(sampler_process=False))
+    one, nat = torch.load(tmp_path / 'list_single.pt'), torch.load(tmp_path / 'list0.pt')
+    assert nat['proc'] and any(sh[2] is not None for s_ in nat['shares'] for sh in s_) and any(sh[2] is None for s_ in nat['shares'] for sh in s_)
+    np.testing.assert_allclose(nat['losses'], one['losses'], rtol=2e-7)
+    np.testing.assert_allclose(nat['theta'].numpy(), one['theta'].numpy(), rtol=2e-7, atol=2e-7 * float(one['theta'].abs().max()))
+    np.testing.assert_allclose(nat['phi'].numpy(), one['phi'].numpy(), rtol=2e-7, atol=2e-7 * float(one['phi'].abs().max()))
+    assert nat['steps'] == one['steps'] and nat['rng'] == one['rng']
