@@ -19,6 +19,11 @@ sub-steps/s x n_gpus, i.e. 4096-path sub-steps per second over the whole job.
 `--global-paths N` switches to STRONG scaling, the way BASELINE configs[2] / configs[3] are stated (a FIXED global batch
 sharded over the GPUs, the reference's scatter along dim 0, src/training.py:93-97): every rank takes its contiguous
 share of N interior + N boundary paths (dist.World.bounds) and `value` is the plain rate of global sub-steps.
+ONE command answers both questions: without --global-paths the run also times two FIXED global batches after the headline
+-- the headline batch itself (4096 global paths) and BASELINE configs[2] (d = 50, N_t = 64, 16384 global paths) -- sharded
+over the same ranks, and reports them under `extras.strong` (steps_per_s of a fixed batch at --gpus 1, 2, 4, 8 is the
+strong-scaling curve; `value` stays the weak product); `extras.rccl` records how many ranks the exchange saw and whether it
+ran inside the captured sub-step graphs.
 
 Timed region: `--steps` sub-steps cycling g, g, d (rounded UP to whole cycles so that every region holds the same mix),
 repeated `--repeats` times back to back, each repeat bracketed by barrier + synchronize; the reported figure is the MEDIAN
@@ -89,6 +94,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--train-iters', type=int, default=600, help='outer iterations of real training (with resampling) for '
                     'the rel-L2 figure, outside the timed region; 0 disables')
+    ap.add_argument('--no-strong', action='store_true', help='N > 1 without --global-paths: skip the two strong-scaling workloads '
+                    'that are timed after the weak-scaling headline (extras.strong)')
     ap.add_argument('--no-solo', action='store_true', help='skip the extra full-grid launches of the dominant kernel '
                     '(roofline.solo_full_grid), so that a profiler run only sees production launches')
     args = ap.parse_args()
@@ -133,6 +140,41 @@ def main():
 
     schedule = ['g', 'g', 'd']
 
+    def barrier():
+        if world is not None:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    def timed_regions(eng_, G_, steps, warmup, repeats):
+        """`repeats` timed regions of `steps` sub-steps (whole g, g, d cycles) of group G_, each bracketed by barrier +
+        synchronize, every one as long as its slowest rank; returns (seconds per region, untimed extra warm-up sub-steps)"""
+        def run_(n, offset=0):
+            for i in range(n):
+                if schedule[(offset + i) % 3] == 'g':
+                    eng_.generator_step(G_)
+                else:
+                    eng_.discriminator_step(G_)
+        run_(warmup)
+        # The shader clock needs ~30 ms of load to settle (repeats of a 3 ms region: 3.48, 3.44, 3.32, 3.25, 3.20 ms): when the
+        # requested warm-up is shorter than 54 sub-steps, whole untimed cycles are added up to that (extras.extra_warmup_steps)
+        # (a fixed count, not a timed loop: every rank must run the same number of sub-steps -- they contain collectives)
+        extra = max(0, 54 - warmup)
+        run_(extra)
+        region_ = []
+        for _ in range(max(repeats, 1)):
+            barrier()
+            t0 = time.perf_counter()
+            run_(steps)                                   # (steps and warmup are whole cycles: every region starts at g)
+            torch.cuda.synchronize()
+            barrier()
+            region_.append(time.perf_counter() - t0)
+        if world is not None:                                 # a region is as long as its slowest rank
+            on_host = torch.distributed.get_backend() == 'gloo'
+            te = torch.tensor(region_, dtype=torch.float64, device='cpu' if on_host else dev)
+            torch.distributed.all_reduce(te, op=torch.distributed.ReduceOp.MAX)
+            region_ = [float(x) for x in te.tolist()]
+        return region_, extra
+
     def run(n, offset=0):
         for i in range(n):
             if schedule[(offset + i) % 3] == 'g':
@@ -140,30 +182,7 @@ def main():
             else:
                 eng.discriminator_step(G)
 
-    def barrier():
-        if world is not None:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
-
-    run(args.warmup)
-    # The shader clock needs ~30 ms of load to settle (repeats of a 3 ms region: 3.48, 3.44, 3.32, 3.25, 3.20 ms): when the
-    # requested warm-up is shorter than 54 sub-steps, whole untimed cycles are added up to that (extras.extra_warmup_steps)
-    # (a fixed count, not a timed loop: every rank must run the same number of sub-steps -- they contain collectives)
-    extra_warmup = max(0, 54 - args.warmup)
-    run(extra_warmup)
-    region = []
-    for _ in range(max(args.repeats, 1)):
-        barrier()
-        t0 = time.perf_counter()
-        run(args.steps)                                   # (steps and warmup are whole cycles: every region starts at g)
-        torch.cuda.synchronize()
-        barrier()
-        region.append(time.perf_counter() - t0)
-    if world is not None:                                 # a region is as long as its slowest rank
-        on_host = torch.distributed.get_backend() == 'gloo'
-        te = torch.tensor(region, dtype=torch.float64, device='cpu' if on_host else dev)
-        torch.distributed.all_reduce(te, op=torch.distributed.ReduceOp.MAX)
-        region = [float(x) for x in te.tolist()]
+    region, extra_warmup = timed_regions(eng, G, args.steps, args.warmup, args.repeats)
     elapsed = sorted(region)[len(region) // 2]            # median repeat
     steps_per_s = args.steps / elapsed
     finite = bool(torch.isfinite(eng.scal[4]).item() and torch.isfinite(eng.theta.data).all().item())
@@ -171,50 +190,66 @@ def main():
     # ---- per-kernel timing with events on the launch stream (instrumented pass, outside the timed region) ------------
     names = ['disc_fwd', 'disc_gradx', 'ode_fwd_multi', 'ode_bwd_multi', 'weak_partials', 'bdry_partials', 'gen_cotangents',
              'disc_cotangent', 'disc_bwd', 'adam', 'slab_sum', 'losses']
-    graphs_on, streams_on = eng.use_graphs, eng.use_streams
-    eng.use_graphs = eng.use_streams = False             # serial, eager: one event pair per kernel launch
-    records, originals = {}, {}
 
-    def wrap(name, fn):
-        def inner(*a, **kw):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            r = fn(*a, **kw)
-            e1.record()
-            key = name
-            if name == 'ode_bwd_multi':
-                key = ('ode_bwd_params' if kw.get('want_params') else 'ode_bwd_x') + '_%djob' % len(a[0])
-            if name == 'ode_fwd_multi':
-                key = 'ode_fwd_%djob' % len(a[0])
-            records.setdefault(key, []).append((e0, e1))
-            return r
-        return inner
-    for n_ in names:
-        originals[n_] = getattr(KN, n_)
-        setattr(KN, n_, wrap(n_, originals[n_]))
-    prof_steps = 9
-    run(prof_steps)
-    torch.cuda.synchronize()
-    for n_ in names:
-        setattr(KN, n_, originals[n_])
-    eng.use_graphs, eng.use_streams = graphs_on, streams_on
-    kern = {k: {'launches_per_step': len(v) / prof_steps, 'avg_ms': sum(a.elapsed_time(b) for a, b in v) / len(v)}
-            for k, v in records.items()}
-    for k in kern:
-        kern[k]['ms_per_step'] = kern[k]['avg_ms'] * kern[k]['launches_per_step']
+    def kernel_pass(eng_, G_, params_, n_paths, nb_paths):
+        """every kernel launch of 9 sub-steps (3 cycles) bracketed by an event pair on the launch stream, serial and eager;
+        returns (per-kernel times, algorithmic FLOP per launch, the dominant kernel, its achieved TFLOP/s)"""
+        graphs_, streams_ = eng_.use_graphs, eng_.use_streams
+        eng_.use_graphs = eng_.use_streams = False             # serial, eager: one event pair per kernel launch
+        records, originals = {}, {}
+
+        def wrap(name, fn):
+            def inner(*a, **kw):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                r = fn(*a, **kw)
+                e1.record()
+                key = name
+                if name == 'ode_bwd_multi':
+                    key = ('ode_bwd_params' if kw.get('want_params') else 'ode_bwd_x') + '_%djob' % len(a[0])
+                if name == 'ode_fwd_multi':
+                    key = 'ode_fwd_%djob' % len(a[0])
+                records.setdefault(key, []).append((e0, e1))
+                return r
+            return inner
+        for n_ in names:
+            originals[n_] = getattr(KN, n_)
+            setattr(KN, n_, wrap(n_, originals[n_]))
+        prof_steps = 9
+        try:
+            for i in range(prof_steps):
+                if schedule[i % 3] == 'g':
+                    eng_.generator_step(G_)
+                else:
+                    eng_.discriminator_step(G_)
+            torch.cuda.synchronize()
+        finally:
+            for n_ in names:
+                setattr(KN, n_, originals[n_])
+            eng_.use_graphs, eng_.use_streams = graphs_, streams_
+        kern_ = {k: {'launches_per_step': len(v) / prof_steps, 'avg_ms': sum(a.elapsed_time(b) for a, b in v) / len(v)}
+                 for k, v in records.items()}
+        for k in kern_:
+            kern_[k]['ms_per_step'] = kern_[k]['avg_ms'] * kern_[k]['launches_per_step']
+        _, path_u_, macs_v_ = algorithmic_macs(params_)
+        Pn_ = n_paths * params_['N_t']
+        flops_ = {                                             # algorithmic FLOP (2 x MAC) per launch, SURVEY section 8(d)
+            'disc_fwd': 2.0 * (2 * Pn_ + n_paths) * macs_v_,   # value + d/dt tangent at all points, reverse pass at the N points of t_0
+            'disc_bwd': 2.0 * 2 * Pn_ * macs_v_,               # reverse chain + weight-gradient contraction (recompute not counted)
+            'ode_fwd_1job': 2.0 * n_paths * path_u_,
+            'ode_fwd_2job': 2.0 * (n_paths + nb_paths) * path_u_,
+            'ode_bwd_x_1job': 2.0 * n_paths * path_u_,         # adjoint chain (recompute not counted)
+            'ode_bwd_params_1job': 2.0 * 2 * n_paths * path_u_,   # adjoint chain + weight-gradient contraction
+            'ode_bwd_params_2job': 2.0 * 2 * (n_paths + nb_paths) * path_u_,
+            'ode_bwd_params_3job': 2.0 * 2 * (2 * n_paths + nb_paths) * path_u_,   # (compact schedule: sweeps A, boundary, B in one launch)
+        }
+        dom_ = max((k for k in kern_ if k in flops_), key=lambda k: kern_[k]['ms_per_step'])
+        return kern_, flops_, dom_, flops_[dom_] / (kern_[dom_]['avg_ms'] * 1e-3) / 1e12
+
+    graphs_on, streams_on = eng.use_graphs, eng.use_streams
+    kern, alg_flops, dominant, ach = kernel_pass(eng, G, params, s['N_r'], s['N_b'])
     macs_F, path_u, macs_v = algorithmic_macs(params)
     Pn, N, Nb = s['N_r'] * s['N_t'], s['N_r'], s['N_b']
-    alg_flops = {                                          # algorithmic FLOP (2 x MAC) per launch, SURVEY section 8(d)
-        'disc_fwd': 2.0 * (2 * Pn + N) * macs_v,           # value + d/dt tangent at all points, reverse pass at the N points of t_0
-        'disc_bwd': 2.0 * 2 * Pn * macs_v,                 # reverse chain + weight-gradient contraction (recompute not counted)
-        'ode_fwd_1job': 2.0 * N * path_u,
-        'ode_fwd_2job': 2.0 * (N + Nb) * path_u,
-        'ode_bwd_x_1job': 2.0 * N * path_u,                # adjoint chain (recompute not counted)
-        'ode_bwd_params_1job': 2.0 * 2 * N * path_u,       # adjoint chain + weight-gradient contraction
-        'ode_bwd_params_2job': 2.0 * 2 * (N + Nb) * path_u,
-    }
-    dominant = max((k for k in kern if k in alg_flops), key=lambda k: kern[k]['ms_per_step'])
-    ach = alg_flops[dominant] / (kern[dominant]['avg_ms'] * 1e-3) / 1e12
     # HBM bytes per launch: NOT measurable inside this process (rocprofv3 --pmc passes, separate runs); taken from the
     # newest committed counter summary and labelled as such (roofline.traffic_source); null when there is none for the workload
     traffic, traffic_by_variant, traffic_source = None, None, None
@@ -295,6 +330,54 @@ def main():
               'repeat_ms': [round(1e3 * x, 3) for x in region], 'reported_repeat': 'median',
               'exchange': None if world is None else ('xw_allreduce (RCCL), captured in the sub-step graphs' if eng.capture_exchange
                                                       else 'torch.distributed between graph segments')}
+    if world is not None:
+        # RCCL as the job sees it: one sum of ones through the library's own entry point (the exchange of the sub-steps), and
+        # whether that exchange sits inside the captured sub-step graphs
+        ones = torch.ones(1, dtype=torch.float64, device=dev)
+        world.all_reduce(ones)
+        extras['rccl'] = {'ranks_seen': int(round(float(ones[0]))), 'native_communicator': world.comm is not None,
+                          'in_graph': bool(eng.capture_exchange and any(k.startswith('gen_dist') for k in G.graphs)
+                                           and any(k.startswith('disc_dist') for k in G.graphs)),
+                          'backend': torch.distributed.get_backend()}
+    if not strong and not args.no_strong:
+        # ---- the same command also answers the STRONG-scaling question (a FIXED global batch over the ranks, the way
+        # BASELINE configs[2] / configs[3] are stated and the way the reference's nn.DataParallel scatters, src/training.py:93-97):
+        # the headline batch (4096 global paths) and configs[2] (d = 50, N_t = 64, 16384 global paths), each as its own solver
+        # on this rank's contiguous share; `value` above stays the weak product.  Compare extras.strong[*].steps_per_s of runs
+        # with different --gpus (and profiles/r04_other_configs_1gpu.md for one GPU) for the 1 -> 8 speed-up of a fixed batch.
+        def strong_workload(dim, n_t, gpaths, tag, steps=30, warmup=6, repeats=3):
+            base_, rem_ = divmod(gpaths, size)
+            n_loc = base_ + (1 if rank < rem_ else 0)
+            p_ = workload_params(dim, n_loc, n_loc, n_t)
+            torch.manual_seed(0)
+            S_ = NODE_WAN_solver(p_, P.func_a, P.func_b, P.func_c, P.func_h, P.func_f, P.func_g, dev, './', func_u_sol=P.func_u_sol,
+                                 p=2, world=world)
+            e_, s_ = S_.engine, S_.setup
+            dom_ = S_.domain(s_['shape_param'], s_['dim'], s_['T0'], s_['T'], s_['N_t'])
+            torch.manual_seed(1000 + rank)
+            du_, dv_, bd_ = Comb_loader(n_loc, n_loc, dom_, dev)[0]
+            G_ = e_.load_group(du_, dv_, bd_, dom_, n_glob=gpaths, nb_glob=gpaths)
+            reg_, _ = timed_regions(e_, G_, steps, warmup, repeats)
+            el_ = sorted(reg_)[len(reg_) // 2]
+            k_, f_, d_k, a_ = kernel_pass(e_, G_, p_, n_loc, n_loc)
+            fused_x = e_.pollution == 1.0 and not e_.adjoint
+            out_ = {'workload': tag, 'scaling': 'strong', 'global_paths': gpaths, 'paths_per_rank': [base_, base_ + (1 if rem_ else 0)],
+                    'steps': steps, 'repeats': repeats, 'steps_per_s': round(steps / el_, 2), 'ms_per_step': round(1e3 * el_ / steps, 4),
+                    'finite': bool(torch.isfinite(e_.scal[4]).item() and torch.isfinite(e_.theta.data).all().item()),
+                    'exchange': None if world is None else ('xw_allreduce (RCCL), captured in the sub-step graphs' if e_.capture_exchange else 'torch.distributed between graph segments'),
+                    'schedule_rank0': {'generator': 'compact' if e_._compact(G_, fused_x, bool(G_.Nb and G_.same_grid)) else 'wide',
+                                       'narrow_tiles_forward': bool(e_._narrow_ok([e_._job(G_, 'i'), e_._job(G_, 'b')], alone=False, forward=True))},
+                    'roofline_rank0': {'bound': 'mfma', 'kernel': d_k, 'achieved': round(a_, 3), 'peak': PEAK_FP64_MATRIX_TFLOPS, 'unit': 'TFLOP/s',
+                                       'frac': round(a_ / PEAK_FP64_MATRIX_TFLOPS, 4), 'avg_launch_ms': round(k_[d_k]['avg_ms'], 4),
+                                       'alg_flop_per_launch': f_[d_k]}}
+            del S_, G_
+            torch.cuda.empty_cache()
+            return out_
+        try:
+            extras['strong'] = [strong_workload(20, 32, 4096, 'headline batch: Ex4_1 cube d=20, 4096 global paths, N_t=32 (configs[1] sharded)'),
+                                strong_workload(50, 64, 16384, 'configs[2]: Ex4_1 cube d=50, 16384 global paths, N_t=64')]
+        except Exception as e:        # (never at the expense of the headline line -- but every rank must get here or none: a collective)
+            extras['strong'] = {'error': repr(e)[:300]}
     if args.train_iters > 0 and world is None:
         # The reference's own acceptance rule is a stopping rule: train until the relative L2 error drops below 0.01
         # (configs/Ex4_1_funcs.py:36-37).  Same rule here, on the fixed held-out sample (16,384 paths, seed 12345), checked
@@ -382,14 +465,12 @@ def main():
         c_el = time.perf_counter() - c0
         cpu = {'value': round(2 / c_el, 5), 'unit': 'steps/s', 'cores': torch.get_num_threads(), 'kind': 'port',
                'sample': '1 generator + 1 discriminator sub-step at the full workload size (%.1f s)' % c_el}
-        # one thread, bounded: the same two sub-steps on a quarter of the paths (the port's cost is linear in the paths:
-        # d^2 coefficient loop + per-path stepper), scaled by 4
+        # one thread, the same two sub-steps at the FULL workload size (measured, not extrapolated: ~4 s on the driver box's host)
         nthr = torch.get_num_threads()
         torch.set_num_threads(1)
         try:
-            q = max(s['N_r'] // 4, 1)
             torch.manual_seed(0)
-            O1 = R.Solver(dict(params, N_r=q, N_b=q), funcs, u_sol=P.func_u_sol, p=2)
+            O1 = R.Solver(params, funcs, u_sol=P.func_u_sol, p=2)
             O1.new_sample()
             c1 = time.perf_counter()
             O1.generator_step()
@@ -397,8 +478,8 @@ def main():
             c1_el = time.perf_counter() - c1
         finally:
             torch.set_num_threads(nthr)
-        one = {'value': round(2 / (c1_el * s['N_r'] / q), 5), 'unit': 'steps/s', 'cores': 1,
-               'sample': '1 generator + 1 discriminator sub-step on N_r = N_b = %d paths (%.1f s), scaled x%d to the workload' % (q, c1_el, s['N_r'] // q)}
+        one = {'value': round(2 / c1_el, 5), 'unit': 'steps/s', 'cores': 1,
+               'sample': '1 generator + 1 discriminator sub-step at the full workload size, one thread (%.1f s)' % c1_el}
         allthr = dict(cpu)
         # `value` is the BETTER of the two runs (the port's small tensor ops thrash on a many-core host: one thread is usually
         # faster than all of them); both are kept
@@ -425,7 +506,8 @@ def main():
                                     % (s['dim'], s['N_r'], s['N_b'], s['N_t'])), 'global_paths': n_glob,
                        'parallelism': ('%d global paths sharded x%d (strong scaling: value = global sub-steps/s)' % (n_glob, size)) if strong else
                                       ('paths sharded x%d, %d paths per rank (weak scaling: value = sub-steps/s x ranks, i.e. %d-path '
-                                       'sub-steps per second over the job; the global batch grows with the rank count)' % (size, s['N_r'], s['N_r']))
+                                       'sub-steps per second over the job; the global batch grows with the rank count; the same run '
+                                       'times FIXED global batches too: extras.strong)' % (size, s['N_r'], s['N_r']))
                                       + '; 1 all-reduce per generator, 2 per discriminator sub-step'},
             'roofline': roofline, 'cpu_baseline': cpu, 'whole_step': whole,
             'kernels': {k: {'ms': round(v['avg_ms'], 4), 'per_step': round(v['launches_per_step'], 2)} for k, v in sorted(kern.items())},

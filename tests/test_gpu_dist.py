@@ -219,6 +219,12 @@ def test_bench_launches_its_own_ranks():
     out = json.loads(lines[0])
     assert out['n_gpus'] == 2 and out['scaling'] == 'weak' and out['value'] > 0 and out['extras']['finite']
     assert 'paths per rank' in out['config']['parallelism']
+    # the same command times two FIXED global batches over the same ranks (strong scaling) and records what the exchange saw
+    strong = out['extras']['strong']
+    assert [w['global_paths'] for w in strong] == [4096, 16384] and [w['paths_per_rank'] for w in strong] == [[2048, 2048], [8192, 8192]]
+    for w in strong:
+        assert w['scaling'] == 'strong' and w['steps_per_s'] > 0 and w['finite'] and w['exchange'] and 0 < w['roofline_rank0']['frac'] < 1
+    assert out['extras']['rccl'] == {'ranks_seen': 2, 'native_communicator': False, 'in_graph': False, 'backend': 'gloo'}
 
 
 # ---- list domains (time-varying balls) under a world: groups smaller than the rank count ------------------------------------

@@ -45,7 +45,7 @@ def timeit(fn, n=20):
 
 
 cases = [('full512', 512, 0, True), ('cap352', 352, 0, True), ('one256', 256, 0, True), ('rec448', 448, vact.data_ptr(), True),
-         ('nograd512', 512, 0, False)]
+         ('nograd512', 512, 0, False), ('full768', 768, 0, True), ('full640', 640, 0, True)]
 res = {(i, c[0]): [] for i in range(len(H)) for c in cases}
 for r in range(rounds):
     for i, h in enumerate(H):

@@ -106,8 +106,11 @@ __device__ unsigned int xw_disc_queue[XW_DISC_SLOTS][(XW_DISC_NQ + 1) * XW_DISC_
 #ifdef XW_CLOCK_PROBE   // diagnostic build only (tools/probe_disc_clock.py): shader clocks / 100 MHz ticks of every wave's tile loop
 __device__ unsigned long long xw_clock_buf[2 * 4096];
 #endif
+#ifndef XW_DISC_FWD_WAVES
+#define XW_DISC_FWD_WAVES 2     // waves per SIMD the register allocation leaves room for (2: 256 registers, 3: 168)
+#endif
 template <int W, bool ACT, bool DYN, int VKS>      // VKS: k-steps of the input layer kept in LDS (0: none)
-__global__ void __launch_bounds__(256, 2) k_disc_fwd(const double* __restrict__ xT, const double* __restrict__ tf,
+__global__ void __launch_bounds__(256, XW_DISC_FWD_WAVES) k_disc_fwd(const double* __restrict__ xT, const double* __restrict__ tf,
                                                      const double* __restrict__ tpp, const double* __restrict__ ph, int N,
                                                      int L, int d, int q, double* __restrict__ v, double* __restrict__ vt,
                                                      double* __restrict__ gxv, double* __restrict__ gtv, int ngrad,
