@@ -888,14 +888,27 @@ def test_pipelined_training_loop_leaves_exactly_what_the_synchronous_one_does(tm
               'domain': 'Hypercube'}
     out = []
     cwd = os.getcwd()
-    for pipe in (True, False):
-        wd = tmp_path / ('pipe%d' % pipe)
+    seen = []
+
+    def never(solver, pts, domain):
+        """the configs' acceptance rule (what the reference's main.py passes as `stop`), evaluated after every generator
+        sub-iteration and never taken: the hook is handed ONE device tensor per sample and u_net(that tensor) is served from the
+        loaded group (solver._stop_agreed) -- the same error the module path computes on the loader's own path tensor"""
+        from utils.auxillary_funcs import rel_err
+        err = float(rel_err(pts, solver.u_net, solver.func_u_sol, solver.p, domain.V(), solver.params['N_r']))
+        seen.append((err, pts.is_cuda, pts))
+        return err < 0.0
+
+    for pipe in (True, False, 'hook'):
+        wd = tmp_path / ('pipe_%s' % pipe)
         wd.mkdir()
         os.chdir(wd)
         try:
             S = make_solver(params, 3)
-            S.pipeline = pipe
-            S.capture_refill = pipe        # (the synchronous run also refills by eager load_group calls and evaluates the diagnostic eagerly)
+            S.pipeline = pipe is True
+            S.capture_refill = pipe is not False   # (the plain synchronous run also refills by eager load_group calls and evaluates the diagnostic eagerly)
+            if pipe == 'hook':
+                S.stop = never
             losses = list(S.train(report=False))
             torch.cuda.synchronize()
             best = torch.load('best_model_weights_NODE.pth')
@@ -904,9 +917,17 @@ def test_pipelined_training_loop_leaves_exactly_what_the_synchronous_one_does(tm
                         list(best.keys()), S.best_l))
         finally:
             os.chdir(cwd)
-    a, b = out
-    assert len(a[0]) >= 12 and a[0] == b[0] and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
-    assert a[3] == b[3] and a[4] == b[4] and a[5] == b[5] and a[6] == b[6] and a[7] == b[7]
+    a, b, c = out
+    for other in (b, c):
+        assert len(a[0]) >= 12 and a[0] == other[0] and torch.equal(a[1], other[1]) and torch.equal(a[2], other[2])
+        assert a[3] == other[3] and a[4] == other[4] and a[5] == other[5] and a[6] == other[6] and a[7] == other[7]
+    # the hook ran after every generator sub-iteration, on one device tensor per sample, and saw the error of the module path
+    assert len(seen) == 24 and all(s_[1] for s_ in seen) and all(seen[2 * k][2] is seen[2 * k + 1][2] for k in range(12))
+    assert all(seen[2 * k][2] is not seen[2 * k + 2][2] for k in range(11))
+    X_last = seen[-1][2]
+    from utils.auxillary_funcs import rel_err
+    np.testing.assert_allclose(seen[-1][0], float(rel_err(X_last.clone(), S.u_net, S.func_u_sol, S.p, S._new_domain().V(), 200)),
+                               rtol=1e-9)
 
 
 @pytest.mark.parametrize('case', ['ref_traj_cone_ex43_d3_seed0', 'ref_traj_hourglass_ex43_d3_seed1',

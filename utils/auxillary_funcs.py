@@ -8,8 +8,27 @@ import numpy as np
 import torch
 
 
+# func_u_sol on the last few samples it was asked about.  The exact solution is PDE data -- a function of the points -- and the
+# reference's acceptance rule (configs/Ex4_1_funcs.py:36-37: rel_err after every generator sub-iteration) evaluates it FOUR times
+# per outer iteration on the same [N, L, d+1] tensor (error and norm, twice): one evaluation per sample here.  Keyed by the tensor
+# OBJECT and its version counter (an in-place change is a miss); the entries hold their tensors, so an id is never reused.
+_EXACT = []
+
+
+def _exact(func_u_sol, x):
+    if not torch.is_tensor(x) or (x.is_cuda and torch.cuda.is_current_stream_capturing()):
+        return func_u_sol(x)                       # (inside a graph capture the value lives in the capture's pool: never kept)
+    for ent in _EXACT:
+        if ent[0] is x and ent[1] == x._version and ent[2] is func_u_sol:
+            return ent[3]
+    val = func_u_sol(x)
+    _EXACT.insert(0, (x, x._version, func_u_sol, val))
+    del _EXACT[2:]
+    return val
+
+
 def _group_mean_p(x, u_net, p, func_u_sol, error):
-    target = func_u_sol(x)
+    target = _exact(func_u_sol, x)
     if error:
         # `.squeeze()` as in the reference (:14,20): it drops EVERY unit axis, so on a single-slice group the prediction [N]
         # meets func_u_sol's [N,1] and the difference is the [N,N] table over all pairs -- reproduced, not "fixed"

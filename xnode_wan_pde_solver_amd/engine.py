@@ -1500,6 +1500,12 @@ class Engine:
     def loss_v(self):
         return self.scal[5]
 
+    def predict_group(self, G):
+        """u_theta on the interior paths of a loaded group as the module returns it, [N, L, 1] -- no path tensor, no callables:
+        the group already holds the transposed points, the grid and the start values"""
+        u, _ = KN.ode_fwd(G.xT, G.t, G.start, self.theta.data, self.method, self.H, self.K, self.m, want_Y=False)
+        return u.t().unsqueeze(2)
+
     def predict(self, X):
         """u_theta on a group [N, L, d+1] -> [L, N] (diagnostics; no checkpoints kept)"""
         Xd = X.detach()

@@ -104,6 +104,37 @@ def _write_text(path, text):
         fh.write(text)
 
 
+class _Saver:
+    """The side-effect files of train() (loss list, L2, times, best weights) written by ONE worker thread, in order -- a later
+    write of a file overwrites an earlier one exactly as in a loop that writes them itself.  The main thread only hands over the
+    finished text / host state dict: torch.save and the open() calls were a third of an outer iteration's host time, spent
+    while the GPU had nothing queued.  A failed write (disk full, ...) surfaces at the next hand-over, not at the end."""
+
+    def __init__(self, active=True):
+        from concurrent.futures import ThreadPoolExecutor
+        self.pool = ThreadPoolExecutor(max_workers=1) if active else None
+        self.pending = []
+
+    def submit(self, jobs):
+        if self.pool is None or not jobs:
+            return
+        done = [f for f in self.pending if f.done()]
+        self.pending = [f for f in self.pending if not f.done()]
+        for f in done:
+            f.result()                         # (raises here what the worker raised)
+        self.pending.append(self.pool.submit(_run_all, jobs))
+
+    def close(self, raising=True):
+        """everything handed over is on disk when this returns; raising=False (another exception is on its way): best effort"""
+        if self.pool is None:
+            return
+        self.pool.shutdown(wait=True)
+        for f in self.pending:
+            if raising:
+                f.result()
+        self.pending = []
+
+
 class FusedAdam:
     """Stands where the reference has torch.optim.Adam (attributes optimizer_u / optimizer_v).  step() applies the
     fused HIP Adam kernel to the blob using the .grad of the parameters (for user code that went through autograd);
@@ -504,9 +535,7 @@ class NODE_WAN_solver:
         # The files of an iteration (loss list, L2, times, best weights) are written by ONE worker thread, in order (a later write
         # of a file overwrites an earlier one exactly as in the synchronous loop); the main thread only hands it the finished text /
         # state dict -- torch.save and four open() calls were 1 ms of its 3 ms per iteration
-        from concurrent.futures import ThreadPoolExecutor
-        saver = ThreadPoolExecutor(max_workers=1) if self._is_main() else None
-        pending = []
+        saver = _Saver(self._is_main())
         keys = self._state_dict_layout()
 
         def process(k):
@@ -532,9 +561,7 @@ class NODE_WAN_solver:
             times.append(time.time())
             jobs.append((_write_text, ('L2_NODE_' + str(d) + '.json', json.dumps([row[n1 + 1]]))))
             jobs.append((_write_text, ('Time_NODE_' + str(d) + '.json', times.text())))
-            if self._is_main():
-                pending[:] = [f for f in pending if not f.done()]
-                pending.append(saver.submit(_run_all, jobs))
+            saver.submit(jobs)
 
         # (Refilling a SECOND group for iteration k + 1 on a side stream beside the sub-steps of iteration k, and the diagnostic
         #  beside the discriminator sub-step, was built and measured: with torch's side stream on a hardware queue of its own
@@ -570,6 +597,7 @@ class NODE_WAN_solver:
             return now
 
         nxt_domain = nxt_points = ahead = None
+        failing = False
         issued = processed = 0          # iterations whose ring row is on its way to the host / whose files have been written
         last = self.iterations - 1
         with torch.cuda.device(dev):
@@ -628,19 +656,21 @@ class NODE_WAN_solver:
                 issued = k + 1
                 tick = lap('ring', tick)
                 if k > 0:
+                    processed = k                         # (before the call: see the flush below)
                     process(k - 1)
-                    processed = k
                 lap('process', tick)
+          except BaseException:
+            failing = True
+            raise
           finally:
             # the host side runs one iteration behind the GPU: whatever has been computed is written out before train() returns
             # OR raises (an exception / KeyboardInterrupt inside the loop must not lose the last iteration's losses and best weights)
-            while processed < issued:
-                process(processed)
-                processed += 1
-            if saver is not None:
-                saver.shutdown(wait=True)                 # every best-weights file is on disk before train() returns or raises
-                for f in pending:
-                    f.result()
+            try:
+                while processed < issued:
+                    processed += 1                        # (advanced first: an iteration whose processing raised is not processed twice)
+                    process(processed - 1)
+            finally:
+                saver.close(raising=not failing)          # every best-weights file is on disk before train() returns or raises
         return past_losses
 
     def _state_dict_layout(self):
@@ -665,7 +695,9 @@ class NODE_WAN_solver:
         if (comp is not None and len(self._group_cache) == 1 and self._group_cache[0] is not None and self.capture_refill
                 and self.world is None and eng.use_graphs and not comp[0].is_cuda and not self.tabulate_on_host):
             # the cube after its first sample: static inputs + one graph replay (Engine.refill_compact)
-            return [eng.refill_compact(self._group_cache[0], comp, domain)]
+            G = eng.refill_compact(self._group_cache[0], comp, domain)
+            G._refill_points = points            # (whose sample the group's static input buffers hold: _stop_agreed)
+            return [G]
         shards = self._shard(self._groups(points))
         if len(self._group_cache) != len(shards):     # (the number of groups varies from sample to sample: keep the ones that stay)
             self._group_cache = self._group_cache[:len(shards)] + [None] * (len(shards) - len(self._group_cache))
@@ -769,16 +801,41 @@ class NODE_WAN_solver:
         return prepared, nxt_domain, nxt_points, ahead
 
     def _iterate(self, report, report_it, show_plt, past_losses, times, pool, draw_ahead):
+        """the loop that synchronises after every sub-iteration like the reference's (a `stop` hook, report=True, list domains
+        without the sampling thread).  Its side-effect files go through the ordered writer thread (_Saver): same files, same
+        order, same final contents, written while the GPU already works on the next sub-iteration."""
+        saver = _Saver(self._is_main())
+        failing = False
+        try:
+            return self._iterate_body(report, report_it, show_plt, past_losses, times, pool, draw_ahead, saver)
+        except BaseException:
+            failing = True
+            raise
+        finally:
+            saver.close(raising=not failing)
+
+    @staticmethod
+    def _pinned(loader):
+        """page-locked staging of a compact sample (same values): its uploads are asynchronous -- a copy from pageable memory
+        makes the host wait for everything queued on the device"""
+        return loader.pin() if hasattr(loader, 'pin') else loader
+
+    def _host_state_dict(self, keys):
+        """u_net.state_dict() as host tensors, from one small read-back of the parameter blob"""
+        return self._state_dict_from(self.engine.theta.data.cpu(), keys)
+
+    def _iterate_body(self, report, report_it, show_plt, past_losses, times, pool, draw_ahead, saver):
         d = self.setup['dim']
         eng = self.engine
         nxt_domain = nxt_points = ahead = prepared = None
         last = self.iterations - 1
+        keys = None
         if hasattr(pool, 'first') and self.iterations > 0:        # (the sampling process owns the generators while train() runs)
             nxt_domain, nxt_points = pool.first()
         with torch.cuda.device(self.device):
             for k in range(self.iterations):
                 domain = nxt_domain if nxt_domain is not None else self._new_domain()
-                points = nxt_points if nxt_points is not None else self._loader(domain)
+                points = nxt_points if nxt_points is not None else self._pinned(self._loader(domain))
                 nxt_domain = nxt_points = None
                 if ahead is None and pool is not None:     # (later ones are submitted the moment the previous result is taken: the
                     ahead = pool.submit(draw_ahead, domain, k == last)   # draws of a ball-domain sample take as long as its sub-steps)
@@ -816,36 +873,48 @@ class NODE_WAN_solver:
                     for x_ in lu:
                         self.av_l += x_                   # (summed in group order, like the reference's running sum)
                     past_losses.append(self.av_l)
-                    if self._is_main():
-                        past_losses.write('losses_NODE_' + str(d) + '.json')
-                    if self.stop is not None and self._stop_agreed(points, domain):
+                    saver.submit([(_write_text, ('losses_NODE_' + str(d) + '.json', past_losses.text()))])
+                    if self.stop is not None and self._stop_agreed(points, domain, None if several else groups[0]):
                         if self._is_main():
-                            torch.save(self.u_net.state_dict(), self.path + 'best_model_weights_NODE.pth')
+                            keys = keys or self._state_dict_layout()
+                            saver.submit([(torch.save, (self._host_state_dict(keys), self.path + 'best_model_weights_NODE.pth'))])
+                        saver.close()                     # (everything is on disk before the process may end)
                         print('Stopping Criterion Reached')
                         if self.exit_on_stop:
                             exit()
                         return past_losses
                     if self.av_l < self.best_l:
                         if self._is_main():
-                            torch.save(self.u_net.state_dict(), 'best_model_weights_NODE.pth')
+                            keys = keys or self._state_dict_layout()
+                            saver.submit([(torch.save, (self._host_state_dict(keys), 'best_model_weights_NODE.pth'))])
                         self.best_l = self.av_l
-                for _ in range(self.n2):
+                # (no sampling thread -- a `stop` hook may draw random numbers of its own between the sub-iterations --: the host
+                #  draws of this point of the loop, the diagnostic's sample and then the next iteration's domain and sample, are
+                #  made in the reference's order but BEFORE the read-backs that would wait for the GPU: behind the queued
+                #  discriminator sub-step and behind the queued diagnostic, 0.6 ms per outer iteration at the headline size)
+                for i_ in range(self.n2):
                     eng.begin_substep('v', several)
                     for G in groups:
                         eng.discriminator_step(G)
+                    if ahead is None and i_ == self.n2 - 1:
+                        points = self._pinned(self._loader(domain, interior_only=True))
                     self.last_loss_v = eng.loss_v().item()
                 if ahead is not None:
                     points, nxt_domain, nxt_points = ahead.result()
                     ahead = pool.submit(draw_ahead, nxt_domain, k + 1 == last) if k < last else None
+                elif self.n2 == 0:
+                    points = self._pinned(self._loader(domain, interior_only=True))
+                if self.capture_refill and not several:
+                    L2 = self._l_norm_replayed(groups[0], points, domain)
+                    if pool is None and k < last:
+                        nxt_domain = self._new_domain()
+                        nxt_points = self._pinned(self._loader(nxt_domain))
+                    L2 = L2.item()
                 else:
-                    points = self._loader(domain)
-                L2 = (self._l_norm_replayed(groups[0], points, domain).item() if (self.capture_refill and not several)
-                      else self._l_norm(points, domain.V()))
+                    L2 = self._l_norm(points, domain.V())
                 times.append(time.time())
-                if self._is_main():
-                    with open('L2_NODE_' + str(d) + '.json', 'w') as fh:
-                        json.dump([L2], fh)
-                    times.write('Time_NODE_' + str(d) + '.json')
+                saver.submit([(_write_text, ('L2_NODE_' + str(d) + '.json', json.dumps([L2]))),
+                              (_write_text, ('Time_NODE_' + str(d) + '.json', times.text()))])
                 if report and k % report_it == 0 and self._is_main():
                     print('iteration: ' + str(k), 'Loss u: ' + str(self.last_loss_u), 'Loss v: ' + str(self.last_loss_v))
                     if self.func_u_sol is not None:
@@ -879,12 +948,33 @@ class NODE_WAN_solver:
         np.random.set_state(ck['numpy_rng'])
         self.engine.invalidate_test_net()                # cached / prefetched test-network outputs are stale now
 
-    def _stop_agreed(self, points, domain):
+    def _stop_agreed(self, points, domain, G=None):
         """the user's stop hook (src/training.py:142).  With several ranks every rank calls it (it may run u_net, which
         every rank can do), but the ranks must leave the loop TOGETHER -- one that returned while the others entered the next
         captured all-reduce would deadlock them -- so rank 0's verdict is the one all of them follow (with rank-local
-        sampling the hook sees different paths on every rank and the verdicts can differ)."""
-        verdict = bool(self.stop(self, points.interioru, domain))
+        sampling the hook sees different paths on every rank and the verdicts can differ).
+
+        What the hook is handed as `interior_points`: the reference's loader keeps its sample on the training device
+        (src/dataset.py:300-310), so the hook gets device tensors there too.  For a compact cube sample that is the path tensor
+        built on the device from the [N, d] points (328 KB uploaded instead of 11 MB of paths at the headline size), ONE object
+        per sample -- so that the exact solution is evaluated once per sample (utils._exact) -- and while the hook runs
+        `u_net(that tensor)` is the stepper's forward kernel on the loaded group's own buffers (nets.XNODE._served)."""
+        X, mod = None, self.u_net.module
+        comp = points.compact() if hasattr(points, 'compact') else None
+        if (G is not None and comp is not None and not comp[0].is_cuda and not self.tabulate_on_host and self.world is None
+                and G.L > 1 and G.tpp is None):
+            held = self.__dict__.get('_hook_sample')
+            if held is None or held[0] is not points:
+                st = G.__dict__.get('_refill_in')
+                fresh = st is not None and getattr(G, '_refill_points', None) is points
+                td, du = (st[0], st[1]) if fresh else (self._up(comp[0]), self._up(comp[1]))
+                held = self._hook_sample = (points, sampling._paths(td, du))
+            X = held[1]
+            mod._served = (X, lambda: self.engine.predict_group(G))
+        try:
+            verdict = bool(self.stop(self, X if X is not None else points.interioru, domain))
+        finally:
+            mod._served = None
         if self.world is None:
             return verdict
         flag = torch.tensor([1.0 if (verdict and self.world.rank == 0) else 0.0], dtype=torch.float64, device=self.device)
