@@ -83,17 +83,21 @@ def _worker(rank, size, port, out_dir):
 
 
 @pytest.mark.timeout(600)
-def test_two_rank_gloo_exchange_reproduces_unsharded_step(tmp_path):
-    size = 2
+@pytest.mark.parametrize('size', [2, 8])
+def test_two_rank_gloo_exchange_reproduces_unsharded_step(tmp_path, size):
+    """(also at 8 ranks, the node size the job is stated for: shards of 4-5 interior and 2-3 boundary paths)"""
     mp.spawn(_worker, args=(size, _free_port(), str(tmp_path)), nprocs=size, join=True)
     res = [torch.load(tmp_path / ('rank%d.pt' % r)) for r in range(size)]
-    assert res[0]['bounds'] == (0, 19) and res[1]['bounds'] == (19, 37)
+    if size == 2:
+        assert res[0]['bounds'] == (0, 19) and res[1]['bounds'] == (19, 37)
+    else:
+        assert [r['bounds'][1] - r['bounds'][0] for r in res] == [5, 5, 5, 5, 5, 4, 4, 4] and res[-1]['bounds'][1] == 37
     for r in res:
         for which in ('u', 'v'):
             loss, ref_loss, err, scale = r[which]
             np.testing.assert_allclose(loss, ref_loss, rtol=1e-6 if which == 'v' else 1e-9)
             assert err <= 2e-5 * scale, (which, err, scale)
-    assert res[0]['u'][0] == res[1]['u'][0]               # every rank sees the same global loss
+    assert all(r['u'][0] == res[0]['u'][0] for r in res)  # every rank sees the same global loss
 
 
 def test_bounds_cover_everything_once():
@@ -102,6 +106,11 @@ def test_bounds_cover_everything_once():
     class W(World):
         def __init__(self, rank, size):
             self.rank, self.size, self.group = rank, size, None
+    # the headline batch on a node: eight shards of 512 paths; an uneven batch: the first ranks take the extra paths
+    assert [W(r, 8).bounds(4096) for r in (0, 7)] == [(0, 512), (3584, 4096)]
+    assert [b - a for a, b in (W(r, 8).bounds(4099) for r in range(8))] == [513, 513, 513, 512, 512, 512, 512, 512]
+    # fewer paths than ranks: empty shares, never an error (list domains: groups of 1-5 paths)
+    assert [W(r, 8).bounds(3) for r in range(8)] == [(0, 1), (1, 2), (2, 3)] + [(3, 3)] * 5
     for n in (1, 7, 8, 4096, 4097):
         for size in (1, 2, 3, 8):
             spans = [W(r, size).bounds(n) for r in range(size)]
@@ -129,25 +138,31 @@ def _sampling_worker(rank, size, port, out_dir):
 
 
 @pytest.mark.timeout(600)
-def test_rank_local_sampling_draws_only_the_shard(tmp_path):
+@pytest.mark.parametrize('size', [2, 8])
+def test_rank_local_sampling_draws_only_the_shard(tmp_path, size):
     """sampling.RankCubeLoader (solver.rank_local_sampling): every rank draws its share only; shares add up to the global
     counts, the time grids and the shared RNG stream stay common, the points are different draws on every rank, interior
-    points are uniform in the cube and boundary points sit on faces in the global proportions"""
-    size = 2
+    points are uniform in the cube and boundary points sit on faces in the global proportions (2 ranks and a node's 8)"""
     mp.spawn(_sampling_worker, args=(size, _free_port(), str(tmp_path)), nprocs=size, join=True)
-    r0, r1 = (torch.load(tmp_path / ('samp%d.pt' % r)) for r in range(size))
-    assert torch.equal(r0[2]['after'], r1[2]['after'])
-    for a, b in zip(r0[:2], r1[:2]):
-        assert a['n'] + b['n'] == 1001 and a['nb'] + b['nb'] == 403 and abs(a['n'] - b['n']) <= 1
-        assert torch.equal(a['t'], b['t'])
-        assert a['xu'].shape == (a['n'], 5) and a['xb'].shape == (a['nb'], 5)
-        assert not torch.equal(a['xu'][:100], b['xu'][:100]) and not torch.equal(a['xu'], a['xv'])
-        for r in (a, b):
-            assert float(r['xu'].abs().max()) <= 1.0 and abs(float(r['xu'].mean())) < 0.1
-            on_face = (r['xb'].abs() == 1.0)
+    rs = [torch.load(tmp_path / ('samp%d.pt' % r)) for r in range(size)]
+    r0 = rs[0]
+    assert all(torch.equal(r0[2]['after'], r[2]['after']) for r in rs)
+    for it in range(2):
+        shares = [r[it] for r in rs]
+        assert sum(a['n'] for a in shares) == 1001 and sum(a['nb'] for a in shares) == 403
+        assert max(a['n'] for a in shares) - min(a['n'] for a in shares) <= 1
+        faces = torch.zeros(5, dtype=torch.float64)
+        for a in shares:
+            assert torch.equal(a['t'], shares[0]['t'])
+            assert a['xu'].shape == (a['n'], 5) and a['xb'].shape == (a['nb'], 5)
+            assert not torch.equal(a['xu'], a['xv'])
+            assert float(a['xu'].abs().max()) <= 1.0 and abs(float(a['xu'].mean())) < (0.1 if size == 2 else 0.2)
+            on_face = (a['xb'].abs() == 1.0)
             assert bool(torch.all(on_face.sum(1) >= 1))
-            per_axis = on_face.sum(0).double() / r['nb']
-            assert float(per_axis.min()) > 0.08 and float(per_axis.max()) < 0.35      # ~ 1 / d each
+            faces += on_face.sum(0).double()
+        per_axis = faces / 403
+        assert float(per_axis.min()) > 0.08 and float(per_axis.max()) < 0.35      # ~ 1 / d each, over the whole job
+        assert not torch.equal(shares[0]['xu'][:50], shares[1]['xu'][:50])      # different draws on different ranks
     assert not torch.equal(r0[0]['xu'], r0[1]['xu'])       # a new draw every iteration
 
 
@@ -441,3 +456,40 @@ def test_list_groups_smaller_than_the_world_keep_every_rank_in_step(tmp_path, go
                 np.testing.assert_allclose(e['loss'][0], e['loss'][1], rtol=1e-8 if e['which'] == 'u' else 1e-6, err_msg=str(e))
                 assert e['gerr'] <= 1e-6 * e['gscale'], e
         assert [e['loss'][0] for e in r if 'loss' in e] == [e['loss'][0] for e in ranks[0] if 'loss' in e]   # the same numbers on every rank
+
+
+def test_schedule_selection_on_a_node_of_eight():
+    """Which schedule a rank's shard takes is decided from its size alone (engine.Engine._compact / _narrow_ok: policy, no
+    kernels): the headline batch over 8 ranks is 512 interior + 512 boundary paths per rank = 64 tiles -- the compact generator
+    schedule with narrow-tile forward and x-only launches --, the unsharded batch keeps the wide schedule with 16-path waves;
+    configs[2] over 8 ranks (2048 paths) is compact with 16-path waves."""
+    from xnode_wan_pde_solver_amd.engine import Engine
+    from xnode_wan_pde_solver_amd.dist import World
+
+    class W(World):
+        def __init__(self, rank, size):
+            self.rank, self.size, self.group, self.comm = rank, size, None, None
+    eng = Engine.__new__(Engine)
+    eng.compact_tiles, eng.use_streams, eng.narrow, eng.narrow_set = 320, True, '1', 'fx'
+    eng.narrow_tiles, eng.adjoint, eng.method = {'f': 192, 'x': 128, 'p': 64}, False, 1
+
+    class G:
+        pass
+
+    def shard(n_glob, rank=0, size=8, d=20):
+        lo, hi = W(rank, size).bounds(n_glob)
+        g = G()
+        g.N = g.Nb = hi - lo
+        job = dict(xT=torch.empty(d, g.N), act=torch.empty(1))
+        return g, job
+    for rank in (0, 7):
+        g, job = shard(4096, rank)
+        assert g.N == 512 and eng._compact(g, True, True)
+        assert eng._narrow_ok([job, job], alone=False, forward=True) and eng._narrow_ok([job], alone=False, params=False)
+        assert not eng._narrow_ok([job, job, job], alone=False)              # sweeps with weight gradients stay on the duo waves
+    g, job = shard(4096, 0, size=1)
+    assert g.N == 4096 and not eng._compact(g, True, True) and not eng._narrow_ok([job, job], alone=False, forward=True)
+    g, job = shard(16384, 3)
+    assert g.N == 2048 and eng._compact(g, True, True) and not eng._narrow_ok([job, job], alone=False, forward=True)
+    g, job = shard(4099, 0)
+    assert g.N == 513 and eng._compact(g, True, True)
