@@ -495,6 +495,7 @@ extern "C" int xw_cube_weight(const float* x, int N, int d, double top, double b
 // operations per group -- the largest item of an outer iteration's host time once nothing else waited.  Here
 // every output array is one row of a table {src, dst, n0 x n1 x n2, strides of src}: dst[i][j][k] = src[i s0 + j s1 + k s2],
 // dst contiguous; the table of the whole sample (~350 rows) is uploaded once and ONE launch walks all elements.
+namespace {
 __global__ __launch_bounds__(256) void k_gather_fields(const XwGather* __restrict__ tab, int count, long total) {
   __shared__ long first[1025];                    // first[r] = elements before row r; first[count] = total
   for (int r = threadIdx.x; r <= count; r += blockDim.x) first[r] = r < count ? tab[r].before : total;
@@ -512,6 +513,7 @@ __global__ __launch_bounds__(256) void k_gather_fields(const XwGather* __restric
     g.dst[local] = g.src[i * g.s0 + j * g.s1 + k * g.s2];
   }
 }
+}  // namespace
 
 extern "C" int xw_gather_fields(const XwGather* table_dev, int count, long total, void* stream) {
   if (!table_dev || count <= 0 || count > 1024 || total <= 0) return XW_E_ARG;
@@ -547,6 +549,7 @@ extern "C" int xw_adam(double* param, const double* gslabA, int nA, const double
 }
 
 // two slab sets in one launch (blockIdx.y picks the set): the generator sub-step's [sum A | sum B] exchange buffer
+namespace {
 __global__ void __launch_bounds__(1024) k_slab_sum2(const double* __restrict__ gA, int nA, double* __restrict__ outA,
                                                     const double* __restrict__ gB, int nB, double* __restrict__ outB, int P) {
   __shared__ double red[XW_ADAM_GROUPS][XW_ADAM_PARAMS];
@@ -566,6 +569,7 @@ __global__ void __launch_bounds__(1024) k_slab_sum2(const double* __restrict__ g
   for (int k = 0; k < XW_ADAM_GROUPS; ++k) g += red[k][tx];
   out[i] = g;
 }
+}  // namespace
 extern "C" int xw_slab_sum2(const double* gA, int nA, double* outA, const double* gB, int nB, double* outB, int P, void* stream) {
   if (!gA || !gB || !outA || !outB || P <= 0 || nA <= 0 || nB <= 0) return XW_E_ARG;
   hipLaunchKernelGGL(k_slab_sum2, dim3((P + XW_ADAM_PARAMS - 1) / XW_ADAM_PARAMS, 2), dim3(XW_ADAM_PARAMS * XW_ADAM_GROUPS), 0,
