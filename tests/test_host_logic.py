@@ -107,6 +107,8 @@ def test_cabi_exports_match_header():
     out = subprocess.run(['nm', '-D', '--defined-only', _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
     exported = set(re.findall(r'\bT\s+(xw_\w+)', out))
     assert declared <= exported, declared - exported
+    # ... and nothing else: no kernel launch stub or helper leaks into the dynamic symbol table
+    assert set(re.findall(r'\bT\s+(\S+)', out)) <= exported | {'_init', '_fini'}, set(re.findall(r'\bT\s+(\S+)', out)) - exported
     # argument counts of the ctypes signatures agree with the header
     for name, args in _lib.SIGNATURES.items():
         m = re.search(r'int\s+' + name + r'\s*\((.*?)\)\s*;', hdr, flags=re.S)

@@ -167,6 +167,7 @@ class Engine:
         self.pollution = 1.0
         self.verify_structure = os.environ.get('XW_VERIFY_STRUCTURE', '1') == '1'    # (_check_structure)
         self.packed_load = os.environ.get('XW_PACKED_LOAD', '1') != '0'     # list domains: load_groups_packed
+        self.refill_variants = 8        # captured variants of a group's refill / diagnostic graph before further ones run eagerly
         self.verify_every = 16          # ~3 d + 1 callable evaluations per check: ~1 ms at d = 20, a fifth of an outer iteration
         sp = setup.get('shape_param', [-1, 1])
         lo, hi = (sp[0], sp[1]) if isinstance(sp, (list, tuple)) else (-sp, sp)
@@ -830,9 +831,20 @@ class Engine:
                                   verify=False)
             if out is not G:
                 raise XnwanError('refill_compact: the sample does not have the shapes of the group it refills')
-        # (what the captured body bakes in besides the buffers: the grid's first time, the domain's class and extent)
-        self._run(G, 'refill_%r_%s_%r_%r_%r' % (t0, type(domain).__name__, float(domain.V()), getattr(domain, 'top', None),
-                                                getattr(domain, 'bot', None)), body, scratch=True)
+        # (what the captured body bakes in besides the buffers: the grid's first time, the domain's class and extent, which of
+        #  the two bodies it is and the global path counts)
+        key = 'refill_%r_%s_%r_%r_%r_%d_%r_%r' % (t0, type(domain).__name__, float(domain.V()), getattr(domain, 'top', None),
+                                                  getattr(domain, 'bot', None), int(lean), n_glob, nb_glob)
+        if key not in G.graphs and sum(1 for k in G.graphs if k.startswith('refill')) >= self.refill_variants:
+            # a domain whose first time or extent changes with every sample would capture a graph per outer iteration (graphs are
+            # never destroyed, _KEPT_GRAPHS): beyond a few variants per group the refill runs eagerly
+            if not G.__dict__.get('_refill_cap_warned'):
+                import warnings
+                G._refill_cap_warned = True
+                warnings.warn('more than %d variants of the refill graph for one group (first time / extent / path counts change from '
+                              'sample to sample): further variants run as eager launches' % self.refill_variants, RuntimeWarning, stacklevel=2)
+            G.graphs[key] = False
+        self._run(G, key, body, scratch=True)
         # (host-side bookkeeping of load_group: done at capture time only, so it is set here on every path)
         G.domain, G.sample_version = domain, ver + 1
         return G

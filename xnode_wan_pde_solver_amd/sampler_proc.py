@@ -42,10 +42,11 @@ SLOTS = 4          # two per request (diagnostic sample, next sample); a request
 class PackedSample:
     """what the training loop reads of a sampling.Comb_loader, over a sample the child packed into a shared slot"""
 
-    def __init__(self, buf, meta):
+    def __init__(self, buf, meta, guard=None):
         self._buf = buf
         self._total, self._offs, self._hints, self._n, self._nu = meta
         self._views = None
+        self._guard = guard            # (slot events of the owning SamplerProcess: the upload below records one)
 
     def compact(self):
         return None
@@ -66,6 +67,11 @@ class PackedSample:
     def _device_views(self, device):
         if self._views is None:
             dev = self._buf[:self._total].to(device, non_blocking=True)
+            if self._guard is not None:
+                # the copy reads the shared slot asynchronously: the child may only overwrite the slot once this event has passed
+                # (SamplerProcess.submit waits for it before it hands the slot out again)
+                owner, slot = self._guard
+                owner._slot_events[slot] = torch.cuda.current_stream(device).record_event()
             self._views = [dev[o:o + math.prod(shape)].view(shape) for o, shape in self._offs]
         return self._views
 
@@ -178,8 +184,17 @@ class _Server:
     def send(self, *msg):
         self.conn.send_bytes(pickle.dumps(msg, protocol=pickle.HIGHEST_PROTOCOL))
 
-    def recv(self):
+    def recv(self, timeout=600.0):
+        """the child's answer.  The pipe is polled, not waited on blindly: a child that died (or hung -- it is a fork of a
+        multi-threaded process) makes train() raise instead of waiting forever"""
+        import time as _time
+        t_end = _time.monotonic() + timeout
         try:
+            while not self.conn.poll(0.25):
+                if not self.proc.is_alive():
+                    raise RuntimeError('the sampling process ended unexpectedly (exit code %r)' % self.proc.exitcode)
+                if _time.monotonic() > t_end:
+                    raise RuntimeError('the sampling process did not answer within %.0f s' % timeout)
             out = pickle.loads(self.conn.recv_bytes())
         except EOFError:
             raise RuntimeError('the sampling process ended unexpectedly (exit code %r)' % self.proc.exitcode)
@@ -302,12 +317,22 @@ class SamplerProcess:
         self.outstanding = None
         self.active = False
         self.slots = None
+        self._slot_events = {}          # slot -> event of the last upload out of it (PackedSample._device_views)
 
     proc = property(lambda self: self.server.proc)
 
     def _sample(self, slot, packed):
         meta, inline = packed
-        return PackedSample(self.slots[slot] if inline is None else inline, meta)
+        if inline is not None:
+            return PackedSample(inline, meta)
+        return PackedSample(self.slots[slot], meta, guard=(self, slot))
+
+    def _release(self, *slots):
+        """before the child is told to write into these slots: every upload that still reads them has finished"""
+        for sl in slots:
+            ev = self._slot_events.pop(sl, None)
+            if ev is not None:
+                ev.synchronize()
 
     def begin(self):
         """hand the generator streams over (they come back in shutdown)"""
@@ -324,6 +349,7 @@ class SamplerProcess:
     def first(self):
         slot = (2 * self.request) % SLOTS
         self.request += 1
+        self._release(slot)
         self.server.send('first', slot)
         domain, packed = self.server.recv()
         return domain, self._sample(slot, packed)
@@ -331,6 +357,7 @@ class SamplerProcess:
     def submit(self, _fn, _domain, last):
         a = (2 * self.request) % SLOTS
         self.request += 1
+        self._release(a, a + 1)
         self.server.send('draw', a, a + 1, bool(last))
         self.outstanding = (a, a + 1)
         return _Future(self)
@@ -346,6 +373,9 @@ class SamplerProcess:
         if not self.active:
             return
         self.active = False
+        import sys
+        import warnings
+        failing = sys.exc_info()[0] is not None       # (called from a `finally` while train()'s own exception propagates)
         try:
             if self.outstanding is not None:      # (train() left early: the request in flight is drained first)
                 self._take()
@@ -353,6 +383,13 @@ class SamplerProcess:
             t_state, n_state = self.server.recv()
             torch.set_rng_state(t_state)
             np.random.set_state(n_state)
+        except Exception as e:
+            # the generator streams the child held are lost: torch's and numpy's global generators stay where they were when
+            # train() began.  Never at the expense of the exception that is already on its way
+            if not failing:
+                raise
+            warnings.warn('the sampling process could not hand the generator streams back (%s): torch / numpy global RNG states are '
+                          'those from before train()' % e, RuntimeWarning)
         finally:
             self.server.user = None
 

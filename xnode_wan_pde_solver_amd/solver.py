@@ -348,7 +348,10 @@ class NODE_WAN_solver:
             X = sampling._paths(st[0], st[1])
             val = L_norm(X, lambda x: self.u_net(x, starts_at_T0=at_T0), p, self.func_u_sol, volume, n_r)
             st[2].copy_(val.to(torch.float64).reshape(()))
-        eng._run(G, 'diag_%r_%r_%r' % (at_T0, float(volume), p), body, scratch=True)
+        key = 'diag_%r_%r_%r' % (at_T0, float(volume), p)
+        if key not in G.graphs and sum(1 for k_ in G.graphs if k_.startswith('diag')) >= eng.refill_variants:
+            G.graphs[key] = False        # (as Engine.refill_compact: a volume that changes every sample must not capture a graph per iteration)
+        eng._run(G, key, body, scratch=True)
         return st[2]
 
     def _l_norm_value(self, points, volume):
