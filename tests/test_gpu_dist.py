@@ -362,7 +362,7 @@ def test_list_domain_group_runner_calls_rccl_between_its_launches(tmp_path):
     are replicated, the samples come from the sampling process forked AFTER RCCL has started its threads -- and train() leaves
     what the plain single-process run leaves"""
     params = dict(LIST_PARAMS, domain='NSphere_THourglass')
-    mp.spawn(_list_native_worker, args=(1, _free_port(), str(tmp_path), params, 5, dict()), nprocs=1, join=True)
+    mp.spawn(_list_native_worker, args=(1, _free_port(), str(tmp_path), params, 5, dict(replicate_below=64)), nprocs=1, join=True)
     _list_train(None, str(tmp_path / 'list_single.pt'), str(tmp_path / 'wd_single'), params, 5, dict(sampler_process=False))
     one, nat = torch.load(tmp_path / 'list_single.pt'), torch.load(tmp_path / 'list0.pt')
     assert nat['proc'] and any(sh[2] is not None for s_ in nat['shares'] for sh in s_) and any(sh[2] is None for s_ in nat['shares'] for sh in s_)
