@@ -1158,3 +1158,26 @@ def test_group_refilled_by_one_graph_replay_holds_what_load_group_writes(general
                 assert a is None or torch.equal(a, b), (k, rep)
     kinds = [type(v).__name__ for k, v in G.graphs.items() if k.startswith('refill')]
     assert kinds in ((['bool'], ['CUDAGraph']) if general else (['CUDAGraph'],)), kinds
+
+
+def test_plan_names_the_loop_a_solver_takes():
+    """NODE_WAN_solver.plan(): the default-path matrix (domain x stop hook x report x switches) made explicit"""
+    params = {'alpha': 1e4, 'u_layers': 8, 'u_hidden_dim': 20, 'u_hidden_hidden_dim': 10, 'v_layers': 9, 'v_hidden_dim': 50,
+              'n1': 2, 'n2': 1, 'u_rate': 0.015, 'v_rate': 0.04, 'min_steps': 5, 'adjoint': False, 'solver': 'midpoint',
+              'dim': 4, 'N_t': 8, 'N_r': 64, 'N_b': 32, 'T0': 0, 'T': 1, 'shape_param': [-1, 1], 'iterations': 1, 'domain': 'Hypercube'}
+    S = make_solver(params, 0)
+    p = S.plan()
+    assert p['loop'].startswith('pipelined') and p['sampling'] == 'helper thread' and p['refill'].startswith('one graph replay')
+    assert p['sub_steps'] == 'captured HIP graphs' and p['ranks'] == 1 and p['exchange'] is None and p['coefficients'].startswith('a=identity')
+    assert S.plan(report=True)['loop'].startswith('synchronous')
+    S.stop = lambda *a: False
+    p = S.plan()
+    assert p['loop'].startswith('synchronous') and p['sampling'].startswith('in the loop')
+    C = make_solver(dict(params, domain='NSphere_TCone', shape_param=1.0), 0)
+    p = C.plan()
+    assert p['loop'].startswith('list domain, one read-back') and p['sampling'] == 'forked sampling process'
+    assert p['refill'].startswith('one packed upload') and p['sub_steps'].startswith('one C call per group sub-step')
+    C.sampler_process = False
+    assert C.plan()['sampling'] == 'helper thread'
+    C.defer_list_readback = False
+    assert C.plan()['loop'].startswith('synchronous')

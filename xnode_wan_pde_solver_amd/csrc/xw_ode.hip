@@ -14,6 +14,9 @@
 // stays on chip.  At the headline size this kernel is bound by the FP64 matrix pipe, not by HBM.
 #include <type_traits>
 #include "xw_common.h"
+#ifndef XW_ODE_FWD_WAVES
+#define XW_ODE_FWD_WAVES 2     // waves per SIMD the forward pass's register allocation leaves room for (2: <= 256 registers; 3: <= 168)
+#endif
 #include "xnwan.h"
 
 // One object per stepper width (Makefile: -DXW_ODE_H=.. -DXW_ODE_K=..), every depth m = 1..10 in it; the public entry
@@ -767,7 +770,7 @@ template <int K, int M, bool FULL = true> struct SinkAct {
 
 // ACT: 0 = no activation store, 1 = the full store, 2 = only what an x-only sweep reads (tanh rows + ReLU mask words)
 template <int H, int K, int M, int METHOD, int ACT>
-__global__ void __launch_bounds__(64, 2) k_ode_fwd(const FwdJobs jobs, const double* __restrict__ tf,
+__global__ void __launch_bounds__(64, XW_ODE_FWD_WAVES) k_ode_fwd(const FwdJobs jobs, const double* __restrict__ tf,
                                                 const double* __restrict__ th, int L, int d) {
   typedef Dim<H, K> D;
   typedef RK<METHOD> T;

@@ -430,7 +430,43 @@ class NODE_WAN_solver:
                 return out[:, 0, :] if (x.shape[1] == 1 and a_k) else out   # (src/model.py:89-91: [N, 1] on a single slice at T0)
             return L_norm(Xs, u_fn, self.p, lambda x: next(sols), volume, self.setup['N_r'])
 
+    def plan(self, report=False):
+        """Which of train()'s loops and helpers THIS solver would take, as a dict -- the choice depends on the domain, a `stop`
+        hook, `report`, several ranks and a handful of attributes / XW_* switches, and the loops differ by a factor of three
+        in host time (same results: tests/test_gpu_engine.py compares them bit for bit).  XW_SHOW_PLAN=1 prints it once per
+        train() call."""
+        eng = self.engine
+        cube = hasattr(self._new_domain_probe(), 'interior_x')
+        listy = isinstance(self.domain, type) and issubclass(self.domain, sampling._NSphereBase)
+        overlap = self.overlap_sampling and self.stop is None and not self.device_sampling
+        proc = bool(self.sampler_process and overlap and self.defer_list_readback and not self.tabulate_on_host and listy and hasattr(os, 'fork'))
+        if self.pipeline and self.stop is None and not report and cube:
+            loop = 'pipelined (nothing in an outer iteration waits for the GPU; files one iteration behind, flushed at the end)'
+        elif not cube and overlap and self.defer_list_readback:
+            loop = 'list domain, one read-back per outer iteration (next sample loaded behind the queued sub-steps)'
+        else:
+            loop = 'synchronous (a read-back after every sub-iteration, like the reference)'
+        return {
+            'loop': loop,
+            'sampling': 'device RNG' if self.device_sampling else ('forked sampling process' if proc else 'helper thread' if overlap else
+                                                                  'in the loop (a stop hook may draw random numbers itself)'),
+            'tabulation': 'host (bitwise the reference\'s CPU values)' if self.tabulate_on_host else 'device',
+            'refill': 'one graph replay per sample' if (cube and self.capture_refill and eng.use_graphs and not self.tabulate_on_host) else
+                      ('one packed upload + one gather launch per sample' if (not cube and eng.packed_load and not self.tabulate_on_host) else 'group by group'),
+            'sub_steps': 'captured HIP graphs' if (cube and eng.use_graphs) else ('one C call per group sub-step (xw_substep_*)' if eng.use_runner and
+                                                                                 eng.structure.c_kappa is not None else 'launch by launch'),
+            'ranks': 1 if self.world is None else self.world.size,
+            'exchange': None if self.world is None else ('xw_allreduce (RCCL) on the stream: inside the sub-step graphs / the group runner'
+                                                         if self.world.capturable else 'torch.distributed, staged through the host'),
+            'small_groups': None if (self.world is None or cube) else ('replicated below %d paths per rank' % self.world.replicate_below
+                                                                       if self.world.replicate_below > 0 else 'sharded (empty shares)'),
+            'test_net_reuse_inside_an_outer_iteration': bool(self.reuse_test_net),
+            'coefficients': eng.structure.describe(),
+        }
+
     def train(self, report=False, report_it=10, show_plt=False):
+        if os.environ.get('XW_SHOW_PLAN', '0') == '1' and self._is_main():
+            print('train() plan: ' + json.dumps(self.plan(report)))
         threads = torch.get_num_threads()
         if self.host_threads:
             torch.set_num_threads(min(threads, int(self.host_threads)))
