@@ -485,15 +485,17 @@ def test_disc_time_tangent_at_an_exact_zero_preactivation():
     _close(vt.t(), dv, 1e-11, 'dv/dt')
 
 
+@pytest.mark.parametrize('Ww', [64, 100, 128, 51 + 64])          # (64: the MFMA container; the others: the generic path)
 @pytest.mark.parametrize('N,L,d,q', [(37, 7, 5, 9), (64, 6, 20, 4), (100, 3, 70, 1), (16, 2, 3, 12), (700, 9, 6, 9),
                                      (1100, 32, 6, 2)])     # (the last one: more 64-point groups than blocks -- grid-stride)
-def test_disc_kernels_at_width_64(N, L, d, q):
+def test_disc_kernels_at_width_64(N, L, d, q, Ww):
     """the second compiled test-network width (64 = four full MFMA row tiles, container of v_hidden_dim 51..64): forward,
     d/dt tangent, fused input gradient, record and the reverse from the record (dVh.b summed on the vector ALU: no padding
     row left for the ones-row trick) against the oracle at v_hidden_dim = 64.  No recomputing reverse kernels at this width."""
     from oracle import refspec as R
     from xnode_wan_pde_solver_amd import kernels as KN
-    Ww = 64
+    if Ww != 64 and N * L > 1000:
+        pytest.skip('the generic path is slow: small cases only')
     cfg = dict(_cfg(), v_hidden_dim=Ww, v_layers=q)
     torch.manual_seed(61)
     _, phi = R.init_parameters(cfg, _setup(d, 2))
@@ -508,7 +510,7 @@ def test_disc_kernels_at_width_64(N, L, d, q):
     gX = torch.autograd.grad(v_ref.sum(), Xd, retain_graph=True)[0]
     grads = torch.autograd.grad((v_ref * vbar).sum(), [ph[k] for k in V_ORDER])
     xT, tc, blob = x.double().t().contiguous().cuda(), t.double().cuda(), _blob(phi, V_ORDER)
-    assert blob.numel() == KN.phi_size(d, Ww) and KN.disc_container(51) == 64 and KN.disc_container(64) == 64
+    assert blob.numel() == KN.phi_size(d, Ww) and KN.disc_container(51) == 64 and KN.disc_container(64) == 64 and KN.disc_container(Ww) == Ww
     gxv, gtv = torch.empty(d, N, dtype=torch.float64).cuda(), torch.empty(N, dtype=torch.float64).cuda()
     rec = torch.empty(KN.disc_act_rows(Ww, q), KN.disc_act_cols(L * N), dtype=torch.float64).cuda()
     v, vt = KN.disc_fwd(xT, tc, blob, Ww, q, gxv=gxv, gtv=gtv, ngrad=N, act=rec, max_blocks=5)
@@ -528,6 +530,11 @@ def test_disc_kernels_at_width_64(N, L, d, q):
     _close(gx2.t(), gX[:, 0, 1:], 1e-11, 'disc_gradx'); _close(gt2, gX[:, 0, 0], 1e-11, 'disc_gradx dt')
     from xnode_wan_pde_solver_amd._lib import lib
     assert lib.xw_disc_gradx(xT.data_ptr(), tc.data_ptr(), None, blob.data_ptr(), None, N, d, Ww, 9, gxv.data_ptr(), gtv.data_ptr(), None) == -1   # XW_E_DIMS
+    # point mode (every point its own time) gives the same values at the same points
+    tpp = tc.view(L, 1).expand(L, N).reshape(-1).contiguous()
+    xp = xT.unsqueeze(1).expand(d, L, N).reshape(d, L * N).contiguous()
+    vp, vtp = KN.disc_fwd(xp, None, blob, Ww, q, tpp=tpp)
+    _close(vp.view(L, N), v, 1e-13, 'point mode v'); _close(vtp.view(L, N), vt, 1e-13, 'point mode dv/dt')
 
 
 def test_disc_forward_ticket_queue_matches_static_split_over_many_launches():
@@ -745,9 +752,16 @@ def test_dims_outside_the_compiled_set_fail_loudly():
     from xnode_wan_pde_solver_amd._lib import XnwanError
     x = torch.zeros(3, 16, dtype=torch.float64).cuda()
     t = torch.linspace(0, 1, 4, dtype=torch.float64).cuda()
+    # (widths between the MFMA containers -- (24, 12) here -- are served at their own widths by the generic path; beyond ITS
+    #  limits, u_hidden_dim 64 / u_hidden_hidden_dim 16 / v_hidden_dim 128, the refusal is loud)
+    KN.ode_fwd(x, t, torch.zeros(16, dtype=torch.float64).cuda(), torch.zeros(KN.theta_size(3, 24, 12), dtype=torch.float64).cuda(), 1, 24, 12, 8)
     with pytest.raises(XnwanError):
         KN.ode_fwd(x, t, torch.zeros(16, dtype=torch.float64).cuda(),
-                   torch.zeros(KN.theta_size(3, 24, 12), dtype=torch.float64).cuda(), 1, 24, 12, 8)
+                   torch.zeros(KN.theta_size(3, 65, 12), dtype=torch.float64).cuda(), 1, 65, 12, 8)
+    with pytest.raises(XnwanError):
+        KN.ode_container(20, 17)
+    with pytest.raises(XnwanError):
+        KN.disc_container(129)
     with pytest.raises(XnwanError):
         KN.ode_fwd(x.cpu(), t, torch.zeros(16, dtype=torch.float64).cuda(),
                    torch.zeros(KN.theta_size(3, 20, 10), dtype=torch.float64).cuda(), 1, 20, 10, 8)
@@ -792,7 +806,8 @@ def test_empty_and_malformed_inputs_are_refused_by_the_c_abi():
 
 # ---- widths other than the YAML's (src/model.py:62-85,130-138 accept any u_hidden_dim / u_hidden_hidden_dim) ----------------
 @pytest.mark.parametrize('solver', ['euler', 'midpoint', 'rk4'])
-@pytest.mark.parametrize('Hh,Kk,m', [(32, 12, 8), (32, 12, 3), (32, 12, 1), (32, 12, 10), (20, 10, 10)])
+@pytest.mark.parametrize('Hh,Kk,m', [(32, 12, 8), (32, 12, 3), (32, 12, 1), (32, 12, 10), (20, 10, 10),
+                                     (48, 16, 8), (64, 16, 3), (33, 9, 1), (24, 13, 10)])       # (the last four: the generic path)
 def test_ode_kernels_at_the_wide_instantiation(Hh, Kk, m, solver):
     """the (32, 12) stepper object: H a multiple of 16 (the time row of [y ; t] is a tile of its own), K = 12 (no padding
     row inside the 4-row blocks) -- forward 1e-12, sweep (x, start, every weight gradient) 1e-10 against the oracle,

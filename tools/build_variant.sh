@@ -20,7 +20,7 @@ while [ $# -gt 0 ]; do
     repl="$repl $base.o"
   fi
 done
-for o in xw_ode_abi.o xw_disc.o xw_weak.o xw_comm.o xw_substep.o xw_ode_20_10.o xw_ode_20_10_recomp.o xw_ode_32_12.o xw_ode_32_12_recomp.o xw_hostrng.o; do
+for o in xw_ode_abi.o xw_disc.o xw_weak.o xw_comm.o xw_substep.o xw_generic.o xw_ode_20_10.o xw_ode_20_10_recomp.o xw_ode_32_12.o xw_ode_32_12_recomp.o xw_hostrng.o; do
   if echo "$repl" | grep -qw "$o"; then objs="$objs ../../_var/obj_$name/$o"; else objs="$objs $o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../_var/libxnwan_$name.so $objs -ldl

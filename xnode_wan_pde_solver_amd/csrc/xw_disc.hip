@@ -19,6 +19,7 @@
 //                outer products over the points (LDS transpose; 4 waves of a block own one 16-row band of dVh each).
 //                Optionally also returns the input gradient (nabla_x v, dv/dt) -- used for nabla phi at t0.
 #include "xw_common.h"
+#include "xw_generic.h"
 #include <atomic>
 #include <cstdlib>
 
@@ -1178,7 +1179,8 @@ int bwd_blocks(long P) {
 // compiled widths: 50 (the reference's YAML; all kernels) and 64 (container of the widths above 50: forward with the
 // fused input gradient + reverse from the record, any depth; no recomputing reverse kernels)
 static bool disc_width_ok(int W) { return W == 50 || W == 64; }
-extern "C" int xw_disc_act_rows(int W, int q) { return (disc_width_ok(W) && q >= 0) ? (q + 1) * W : XW_E_DIMS; }
+// (other widths up to 128: the generic path of xw_generic.hip, always from a record -- row-major there, [rows][columns])
+extern "C" int xw_disc_act_rows(int W, int q) { return ((disc_width_ok(W) && q >= 0) || xwg_disc_ok(1, W, q)) ? (q + 1) * W : XW_E_DIMS; }
 
 extern "C" int xw_disc_fwd(const double* xT, const double* t, const double* tpp, const double* phi, int N, int L, int d,
                            int W, int q, double* v, double* vt, double* gxv, double* gtv, int ngrad, int max_blocks,
@@ -1187,7 +1189,7 @@ extern "C" int xw_disc_fwd(const double* xT, const double* t, const double* tpp,
   if (!tpp && !t) return XW_E_ARG;
   if (tpp && L != 1) return XW_E_ARG;
   if (gxv && (ngrad <= 0 || (long)ngrad > (long)N * L || q > XW_QMAX)) return XW_E_ARG;
-  if (!disc_width_ok(W)) return XW_E_DIMS;
+  if (!disc_width_ok(W)) return xwg_disc_fwd(xT, t, tpp, phi, N, L, d, W, q, v, vt, gxv, gtv, ngrad, act, stream);
   const long ntiles = ((long)N * L + 15) / 16;
   long blocks = (ntiles + 3) / 4;
   long cap = max_blocks > 0 ? max_blocks : 512;   // default: 2 blocks per CU resident (launch bounds), grid-stride over tiles
@@ -1255,9 +1257,10 @@ extern "C" int xw_disc_bwd(const double* xT, const double* t, const double* tpp,
   if (!xT || !phi || !gslab || N <= 0 || L <= 0 || d <= 0) return XW_E_ARG;
   if (!tpp && !t) return XW_E_ARG;
   if (tpp && L != 1) return XW_E_ARG;
+  if (!disc_width_ok(W)) return xwg_disc_bwd(xT, t, tpp, phi, vbar, N, L, d, W, q, act, gslab, bwd_blocks((long)N * L), stream);
   // from the record: any depth (the layer loop is rolled -- unrolled for q = 9 it spilled and was 2 % slower); without a
   // record only the recomputing kernel of depth 9 (the reference's YAML) exists
-  if (!disc_width_ok(W) || q < 0 || d + 2 > 128 || ((q != 9 || W != 50) && act == nullptr)) return XW_E_DIMS;
+  if (q < 0 || d + 2 > 128 || ((q != 9 || W != 50) && act == nullptr)) return XW_E_DIMS;
   if ((long)N * L * 4 >= (1L << 31)) return XW_E_ARG;
   hipStream_t s = (hipStream_t)stream;
   const int blocks = bwd_blocks((long)N * L);

@@ -2,6 +2,7 @@
 // width, and the choice of the object compiled for (H, K) (xw_ode.hip, one object per width).
 #include "xw_common.h"
 #include "xnwan.h"
+#include "xw_generic.h"
 
 #define XW_ODE_WIDTHS(X) X(20, 10) X(32, 12)      /* keep in step with the Makefile and kernels.ODE_WIDTHS */
 
@@ -21,6 +22,7 @@ static bool width_compiled(int H, int K) {
 }
 
 extern "C" int xw_ode_act_rows(int method, int H, int K, int m) {
+  if (!width_compiled(H, K) && xwg_ode_ok(1, H, K, m)) return 0;      // generic widths (xw_generic.hip): the sweeps recompute
   if (!width_compiled(H, K) || m < 1 || m > XW_ODE_MAX_LAYERS) return XW_E_DIMS;
   const int S = method == 0 ? 1 : method == 1 ? 2 : 0;           // rk4: the sweeps recompute
   return S == 0 ? 0 : S * m * K + (S - 1) * H + 2 * S;             // (+ the ReLU-mask words of every stage)
@@ -31,7 +33,7 @@ extern "C" int xw_ode_fwd_multi(const XwOdeFwdJob* jobs, int njobs, const double
 #define CALL(HH, KK) if (H == HH && K == KK) return xw_ode_fwd_multi_w##HH##_##KK(jobs, njobs, t, theta, method, L, d, m, zero16, stream);
   XW_ODE_WIDTHS(CALL)
 #undef CALL
-  return XW_E_DIMS;
+  return xwg_ode_fwd_multi(jobs, njobs, t, theta, method, L, d, H, K, m, zero16, stream);    // any other width: the generic path
 }
 
 extern "C" int xw_ode_fwd(const double* xT, const double* t, const double* start, const double* theta, int method, int N,
@@ -45,7 +47,7 @@ extern "C" int xw_ode_bwd_multi(const XwOdeBwdJob* jobs, int njobs, const double
 #define CALL(HH, KK) if (H == HH && K == KK) return xw_ode_bwd_multi_w##HH##_##KK(jobs, njobs, t, theta, method, L, d, m, mode, stream);
   XW_ODE_WIDTHS(CALL)
 #undef CALL
-  return XW_E_DIMS;
+  return xwg_ode_bwd_multi(jobs, njobs, t, theta, method, L, d, H, K, m, mode, stream);
 }
 
 extern "C" int xw_ode_bwd(const double* xT, const double* t, const double* start, const double* theta, const double* Y,

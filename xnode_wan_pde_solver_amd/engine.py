@@ -178,6 +178,19 @@ class Engine:
         # network exactly, zero-padded, in the next larger instantiation)
         (self.H, self.K), self.m = u_mod.kdims, config['u_layers']
         self.W, self.q = v_mod.kwidth, config['v_layers']
+        # widths beyond the MFMA containers run on the generic path (csrc/xw_generic.hip): correct, deterministic, and two to three
+        # orders of magnitude slower -- said once, loudly
+        self.generic = (KN.ode_generic(self.H, self.K), KN.disc_generic(self.W))
+        if any(self.generic):
+            import warnings
+            which = ' and '.join(n_ for n_, g_ in zip(('u_theta (u_hidden_dim %d, u_hidden_hidden_dim %d)' % (self.H, self.K),
+                                                       'v_phi (v_hidden_dim %d)' % self.W), self.generic) if g_)
+            warnings.warn('%s is wider than the MFMA kernel instantiations %s / %s: running on the generic vector-ALU path, expect a step '
+                          'rate lower by two to three orders of magnitude' % (which, KN.ODE_WIDTHS, KN.DISC_WIDTHS), RuntimeWarning, stacklevel=3)
+        if self.generic[0] and self.adjoint:
+            raise XnwanError('adjoint=True (the continuous adjoint) exists for the MFMA stepper instantiations %s only; u_hidden_dim = %d, '
+                             'u_hidden_hidden_dim = %d run on the generic path, which reverses the steps taken (adjoint=False)'
+                             % (KN.ODE_WIDTHS, self.H, self.K))
         self.theta, self.phi = u_mod.blob, v_mod.blob
         self.Pu, self.Pv = self.theta.data.numel(), self.phi.data.numel()
         z = lambda n: torch.zeros(n, dtype=F64, device=device)  # noqa: E731

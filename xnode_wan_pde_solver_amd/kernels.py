@@ -58,27 +58,45 @@ def method_id(name):
     return METHODS[name]
 
 
-# Kernel instantiations (csrc/xw_ode.hip XW_ODE_DISPATCH, csrc/xw_disc.hip): widths the kernels are compiled for.  Any
+# Kernel instantiations (csrc/xw_ode.hip XW_ODE_DISPATCH, csrc/xw_disc.hip): widths the MFMA kernels are compiled for.  Any
 # smaller network runs EXACTLY inside the next larger instantiation: its parameters are embedded in a zero-padded blob
 # (nets.Blob) -- padding units have zero in- and outgoing weights and zero bias, so they stay identically zero through
 # relu / tanh, contribute exact zeros to every sum, and receive exactly zero gradients (Adam leaves them at zero).
+# Anything wider runs, at its own widths, on the GENERIC path (csrc/xw_generic.hip: per-path / per-point code on the vector ALU,
+# two to three orders of magnitude slower -- there so that every legal configuration of the reference trains).
 ODE_WIDTHS = [(20, 10), (32, 12)]          # (u_hidden_dim, u_hidden_hidden_dim) containers, smallest first
 DISC_WIDTHS = [50, 64]                     # v_hidden_dim containers (W = 50: 3 MFMA row tiles + a 2-row vector tail; 64: 4 tiles)
+GENERIC_ODE_MAX = (64, 16)                 # csrc/xw_generic.h
+GENERIC_DISC_MAX = 128
 
 
 def ode_container(H, K):
     for Hc, Kc in ODE_WIDTHS:
         if H <= Hc and K <= Kc and lib.xw_theta_size(1, Hc, Kc) > 0 and lib.xw_ode_act_rows(0, Hc, Kc, 1) >= 0:
             return Hc, Kc
-    raise XnwanError('u_hidden_dim = %d, u_hidden_hidden_dim = %d: the stepper kernels are compiled for widths up to %s'
-                     % (H, K, ODE_WIDTHS[-1]))
+    if H <= GENERIC_ODE_MAX[0] and K <= GENERIC_ODE_MAX[1] and lib.xw_ode_act_rows(0, H, K, 1) >= 0:
+        return H, K                        # the generic path, at the network's own widths
+    raise XnwanError('u_hidden_dim = %d, u_hidden_hidden_dim = %d: the stepper kernels serve widths up to %s (MFMA) / %s (generic path)'
+                     % (H, K, ODE_WIDTHS[-1], GENERIC_ODE_MAX))
+
+
+def ode_generic(H, K):
+    """True when (H, K) is served by the generic (slow) path rather than by an MFMA instantiation"""
+    return (H, K) not in ODE_WIDTHS
 
 
 def disc_container(W):
     for Wc in DISC_WIDTHS:
         if W <= Wc and lib.xw_disc_act_rows(Wc, 1) >= 0:
             return Wc
-    raise XnwanError('v_hidden_dim = %d: the test-network kernels are compiled for widths up to %d' % (W, DISC_WIDTHS[-1]))
+    if W <= GENERIC_DISC_MAX and lib.xw_disc_act_rows(W, 1) >= 0:
+        return W
+    raise XnwanError('v_hidden_dim = %d: the test-network kernels serve widths up to %d (MFMA) / %d (generic path)'
+                     % (W, DISC_WIDTHS[-1], GENERIC_DISC_MAX))
+
+
+def disc_generic(W):
+    return W not in DISC_WIDTHS
 
 
 def theta_size(d, H, K):
