@@ -793,7 +793,8 @@ def test_empty_and_malformed_inputs_are_refused_by_the_c_abi():
     assert lib.xw_disc_fwd(p(x), p(t), null, p(ph), 0, L, d, W, Q, p(v), null, null, null, 0, 0, null, null) < 0
     assert lib.xw_disc_fwd(p(x), null, null, p(ph), N, L, d, W, Q, p(v), null, null, null, 0, 0, null, null) < 0       # no times
     assert lib.xw_disc_fwd(p(x), p(t), p(s), p(ph), N, L, d, W, Q, p(v), null, null, null, 0, 0, null, null) < 0       # tpp with L > 1
-    assert lib.xw_disc_fwd(p(x), p(t), null, p(ph), N, L, d, 48, Q, p(v), null, null, null, 0, 0, null, null) < 0      # width
+    assert lib.xw_disc_fwd(p(x), p(t), null, p(ph), N, L, d, 129, Q, p(v), null, null, null, 0, 0, null, null) == -1   # width beyond the generic path's 128: XW_E_DIMS
+    assert lib.xw_ode_fwd(p(x), p(t), p(s), p(th), 1, N, L, d, 65, K, 8, p(u), null, null) == -1                          # u_hidden_dim beyond its 64
     # and the Python layer turns shape / dtype mismatches into XnwanError before anything reaches the device
     with pytest.raises(XnwanError):
         KN.disc_fwd(x, t, ph[:-1].contiguous(), W, Q)
