@@ -415,9 +415,21 @@ def main():
             S2.train(report=False)
             torch.cuda.synchronize()
             steady = 1e3 * (time.time() - tt0) / 200
+            # ... and the loop the reference's own CLI selects (main.py:51 passes the configs' acceptance rule as `stop`): the
+            # hook is evaluated after every generator sub-iteration (and never taken here), every sub-iteration is synchronised
+            S2.stop = lambda solver, pts, dom: P.stop(solver, pts, dom) and False
+            S2.iterations = 100
+            S2.train(report=False)
+            torch.cuda.synchronize()
+            tt0 = time.time()
+            S2.train(report=False)
+            torch.cuda.synchronize()
+            hooked = 1e3 * (time.time() - tt0) / 100
+            S2.stop = None
         finally:
             os.chdir(cwd)
-        extras['train'] = {'outer_iterations': done, 'ms_per_outer_iteration_one_call_of_200': round(steady, 2), 'stopped_by': 'rel-L2 < 0.01 (reference stopping rule)' if traj[-1] < 0.01 else 'iteration cap',
+        extras['train'] = {'outer_iterations': done, 'ms_per_outer_iteration_one_call_of_200': round(steady, 2),
+                           'ms_per_outer_iteration_with_the_reference_stop_hook': round(hooked, 2), 'stopped_by': 'rel-L2 < 0.01 (reference stopping rule)' if traj[-1] < 0.01 else 'iteration cap',
                            'wall_s': round(wall, 2), 'ms_per_outer_iteration_incl_resampling_diagnostics_io': round(1e3 * wall / done, 2),
                            # (the first 25-iteration call carries the library load and the graph captures)
                            'ms_per_outer_iteration_after_the_first_call': round(1e3 * sum(calls[1:]) / (25 * len(calls[1:])), 2) if len(calls) > 1 else None,
@@ -456,15 +468,19 @@ def main():
     if rank == 0 and size == 1 and not args.no_cpu_baseline:
         from oracle import refspec as R
         funcs = dict(h=P.func_h, f=P.func_f, g=P.func_g, a=P.func_a, b=P.func_b, c=P.func_c)
+        # all host threads: the port's small tensor operations thrash on a many-core host (42 s for the two sub-steps at full size on
+        # 128 threads against 4 s on one), so this leg is bounded to a quarter of the paths and scaled; `value` comes from the
+        # full-size one-thread run below unless this one is faster
+        qn = max(s['N_r'] // 4, 1)
         torch.manual_seed(0)
-        O = R.Solver(params, funcs, u_sol=P.func_u_sol, p=2)
+        O = R.Solver(dict(params, N_r=qn, N_b=qn), funcs, u_sol=P.func_u_sol, p=2)
         O.new_sample()
         c0 = time.perf_counter()
         O.generator_step()
         O.discriminator_step()
         c_el = time.perf_counter() - c0
-        cpu = {'value': round(2 / c_el, 5), 'unit': 'steps/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-               'sample': '1 generator + 1 discriminator sub-step at the full workload size (%.1f s)' % c_el}
+        cpu = {'value': round(2 / (c_el * s['N_r'] / qn), 5), 'unit': 'steps/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+               'sample': '1 generator + 1 discriminator sub-step on N_r = N_b = %d paths (%.1f s), scaled x%d to the workload' % (qn, c_el, s['N_r'] // qn)}
         # one thread, the same two sub-steps at the FULL workload size (measured, not extrapolated: ~4 s on the driver box's host)
         nthr = torch.get_num_threads()
         torch.set_num_threads(1)
