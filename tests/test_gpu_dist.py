@@ -248,6 +248,7 @@ def _list_train(world, out_path, workdir, params, seed, opts):
         S.engine.use_runner = opts.get('runner', True)
         S.sampler_process = opts.get('sampler_process', True)
         S.defer_list_readback = opts.get('defer', True)
+        S.tabulate_on_host = opts.get('tabulate_on_host', False)
         shares = []
         if world is not None:
             world.replicate_below = opts.get('replicate_below', 16)
@@ -308,6 +309,7 @@ def _check_list_ranks(tmp_path, size, params, seed, opts, rtol, rtol_phi=None):
     ('NSphere_TCone', 6, 4, dict(replicate_below=0, runner=False, defer=False)),   # ... launch by launch from engine.py, synchronous loop
     ('NSphere_THourglass', 5, 2, dict(replicate_below=64)),                    # small groups replicated (the default policy, wider)
     ('NSphere_TCone', 6, 3, dict(replicate_below=4, sampler_process=False)),   # uneven split, mixed policy, sampling thread
+    ('NSphere_THourglass', 5, 4, dict(replicate_below=0, tabulate_on_host=True)),   # callables on the host like the reference's CPU path: no loader hints
 ])
 def test_list_domain_ranks_with_empty_shares_train_like_one_process(tmp_path, domain, seed, size, opts):
     """BASELINE configs[4] is stated on 4 GPUs and a ball-domain sample holds groups of 1-5 paths next to one of thousands
@@ -328,7 +330,7 @@ def test_list_domain_ranks_with_empty_shares_train_like_one_process(tmp_path, do
         assert any(sh[0] == 0 for sh in sharded)
         assert 'N_b' not in opts or any(sh[1] == 0 and sh[0] > 0 for sh in sharded)
     for r in ranks:
-        assert r['proc'] == (opts.get('sampler_process', True) and opts.get('defer', True))
+        assert r['proc'] == (opts.get('sampler_process', True) and opts.get('defer', True) and not opts.get('tabulate_on_host', False))
 
 
 @pytest.mark.timeout(1500)

@@ -374,7 +374,7 @@ class Engine:
     # ------------------------------------------------------------------------------------------------------------
     # per-sample preparation (once per outer iteration; everything here is parameter-independent)
     # ------------------------------------------------------------------------------------------------------------
-    def tabulate_sample(self, triples, domain, hints=None):
+    def tabulate_sample(self, triples, domain, hints=None, grids=None):
         """List domains (src/dataset.py:48-229: 11-20 groups per sample): evaluate the user's callables h, f, g and the
         domain's weight w (with their input gradients) ONCE on the points of ALL groups instead of group by group, and
         hand every group its slices (load_group(tab=...)).  The callables are PDE data -- functions of the point (t, x) --
@@ -392,9 +392,13 @@ class Engine:
         if hints is not None and all(h is not None for h in hints):      # (the loader read them off its host copies: no read-back)
             first_t = [h['t0'] for h in hints] + [h['tb0'] for h in hints]
         else:
-            if any(x.shape[0] == 0 for x in Xs + BXs):
-                raise XnwanError('tabulate_sample: an empty share needs the hints of the whole group (its first time)')
-            first_t = torch.stack([x[0, 0, 0] for x in Xs] + [b[0, 0, 0] for b in BXs]).tolist()   # ONE host sync for all start times
+            # ONE host sync for all start times; a share of a sharded group reads the WHOLE group's first paths (`grids`: it may be
+            # empty, or start at another path's entry time)
+            gr = grids if grids is not None else [None] * len(Xs)
+            if any(g_ is None and (x.shape[0] == 0 or b.shape[0] == 0) for g_, x, b in zip(gr, Xs, BXs)):
+                raise XnwanError('tabulate_sample: an empty share needs the first times of the whole group (hints or grids)')
+            first_t = torch.stack([(g_[0][0] if g_ is not None else x[0, 0, 0]).to(Xs[0].device) for g_, x in zip(gr, Xs)] +
+                                  [(g_[1][0] if g_ is not None else b[0, 0, 0]).to(Xs[0].device) for g_, b in zip(gr, BXs)]).tolist()
         at0 = [float(v) == T0 for v in first_t[:len(Xs)]]
         bat0 = [float(v) == T0 for v in first_t[len(Xs):]]
         pts = lambda ts: torch.cat([t_.reshape(-1, 1, d + 1) for t_ in ts], 0)                      # noqa: E731  [P, 1, d+1]
@@ -502,7 +506,9 @@ class Engine:
         # the test network is pointwise on XV: when the paths of a group do not share one time column (late-entry groups
         # of the hourglass: every path has its own entry time at l = 0) it runs in point mode on all L*N points
         S['tpp'] = S['tpp0'] = S['xvT_pts'] = None
-        if shared_grid_t0 is None and not (hints['shared_times'] if hints is not None else bool(torch.all(XV[:, :, 0] == XV[:1, :, 0]))):
+        # (a share of a sharded group is compared with the WHOLE group's first path, whose grid G.t is: `grids`)
+        col0 = XV[:1, :, 0] if grids is None else grids[0].to(XV.device).view(1, -1)
+        if shared_grid_t0 is None and not (hints['shared_times'] if hints is not None else bool(torch.all(XV[:, :, 0] == col0))):
             S['tpp'] = _d64(XV[:, :, 0], dev).t().contiguous().reshape(-1)              # time-major: p = l*N + n
             S['tpp0'] = _d64(XV[:, 0, 0], dev).contiguous()
             S['xvT_pts'] = S['xvT'].unsqueeze(1).expand(d, L, N).reshape(d, L * N).contiguous()

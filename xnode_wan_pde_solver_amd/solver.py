@@ -744,7 +744,9 @@ class NODE_WAN_solver:
         # largest group of the sample (all groups are slices of the same draw)
         # (the loader's facts about a group -- first times, shared time column, same grid -- hold for every rank's share of it)
         hints = self._group_hints if self._group_hints is not None else [None] * len(shards)
-        tabs = eng.tabulate_sample([sh[:3] for sh in shards], domain, hints=hints) if len(shards) > 1 else [None]
+        # (several ranks: a sample is tabulated on this rank's shares; the start kinds come from the whole groups' first paths)
+        grids = [sh[5] for sh in shards]
+        tabs = eng.tabulate_sample([sh[:3] for sh in shards], domain, hints=hints, grids=grids) if len(shards) > 1 else [None]
         big = max(range(len(shards)), key=lambda i: shards[i][0].shape[0] * shards[i][0].shape[1])
         order = list(range(len(shards)))
         if pairs_last:
