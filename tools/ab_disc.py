@@ -44,7 +44,7 @@ def timeit(fn, n=20):
     return e0.elapsed_time(e1) / n * 1e3
 
 
-cases = [('full512', 512, 0, True), ('cap352', 352, 0, True), ('one256', 256, 0, True), ('rec448', 448, vact.data_ptr(), True),
+cases = [('full512', 512, 0, True), ('cap384', 384, 0, True), ('cap416', 416, 0, True), ('cap352', 352, 0, True), ('one256', 256, 0, True), ('rec448', 448, vact.data_ptr(), True),
          ('nograd512', 512, 0, False), ('full768', 768, 0, True), ('full640', 640, 0, True)]
 res = {(i, c[0]): [] for i in range(len(H)) for c in cases}
 for r in range(rounds):
