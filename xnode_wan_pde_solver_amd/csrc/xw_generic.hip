@@ -10,7 +10,8 @@
 // whose job is that a legal reference configuration trains instead of raising.
 //
 // Determinism: parameter gradients are reduced over the 16 paths of a slab (stepper) / the 64 points of a wave (test network) by
-// a fixed butterfly of lane exchanges, and one lane adds the sum to the slab: no float atomics, same bits on every run and rank.
+// a fixed butterfly of lane exchanges, entry by entry, and added to the slab 16 / 64 entries at a time by the lanes that hold them
+// (an entry always by the same lane, in program order): no float atomics, same bits on every run and rank.
 //
 // Not here: the continuous adjoint (mode bit 3), the activation store (the sweeps recompute from the checkpoints Y), narrow tiles,
 // priorities -- accepted and ignored where they are hints, XW_E_DIMS where they change the result.
@@ -42,48 +43,94 @@ struct Net {
   int d, H, K, m;
 };
 
+// out[r] = init[r] + sum_c Wm[r ldw + c] x(c), r < rows -- four rows at a time (four independent chains, every x(c) used four times)
+template <class FX>
+__device__ __forceinline__ void matvec(const double* Wm, int ldw, int rows, int cols, FX x, const double* init, double* out) {
+  for (int r = 0; r < rows; r += 4) {
+    const int r1 = r + 1 < rows ? r + 1 : rows - 1, r2 = r + 2 < rows ? r + 2 : rows - 1, r3 = r + 3 < rows ? r + 3 : rows - 1;
+    const double* w0 = Wm + (long)r * ldw;
+    const double* w1 = Wm + (long)r1 * ldw;
+    const double* w2 = Wm + (long)r2 * ldw;
+    const double* w3 = Wm + (long)r3 * ldw;
+    double a0 = init ? init[r] : 0.0, a1 = init ? init[r1] : 0.0, a2 = init ? init[r2] : 0.0, a3 = init ? init[r3] : 0.0;
+#pragma unroll 4
+    for (int c = 0; c < cols; ++c) {
+      const double xc = x(c);
+      a0 = fma(w0[c], xc, a0);
+      a1 = fma(w1[c], xc, a1);
+      a2 = fma(w2[c], xc, a2);
+      a3 = fma(w3[c], xc, a3);
+    }
+    out[r] = a0;
+    if (r + 1 < rows) out[r + 1] = a1;
+    if (r + 2 < rows) out[r + 2] = a2;
+    if (r + 3 < rows) out[r + 3] = a3;
+  }
+}
+// out[c] = sum_r Wm[r ldw + c] x[r], c < cols (the transposed product) -- four adjacent columns at a time
+__device__ __forceinline__ void matvecT(const double* Wm, int ldw, int rows, int cols, const double* x, double* out) {
+  for (int c = 0; c < cols; c += 4) {
+    const int c1 = c + 1 < cols ? c + 1 : cols - 1, c2 = c + 2 < cols ? c + 2 : cols - 1, c3 = c + 3 < cols ? c + 3 : cols - 1;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll 4
+    for (int r = 0; r < rows; ++r) {
+      const double xr = x[r];
+      const double* w = Wm + (long)r * ldw;
+      a0 = fma(w[c], xr, a0);
+      a1 = fma(w[c1], xr, a1);
+      a2 = fma(w[c2], xr, a2);
+      a3 = fma(w[c3], xr, a3);
+    }
+    out[c] = a0;
+    if (c + 1 < cols) out[c + 1] = a1;
+    if (c + 2 < cols) out[c + 2] = a2;
+    if (c + 3 < cols) out[c + 3] = a3;
+  }
+}
+
 // F([x, t, y]) (src/model.py:153-156, 130-141); xproj[k] = Win[k, 0..d) x + Win.b[k] is hoisted (x does not move along a path)
 // zs (or null): pre-activations of every layer, [m][GK], for the vector-Jacobian product
 __device__ void field_eval(const Net& n, const double* xproj, double t, const double* y, double* out, double* zs) {
   const double* Win = n.th + n.o.Win;
-  const int ld = n.o.ldin;
+  const int ld = n.o.ldin, K = n.K;
   double z[GK], z2[GK];
-  for (int k = 0; k < n.K; ++k) {
-    double acc = fma(Win[k * ld + n.d], t, xproj[k]);
-    for (int j = 0; j < n.H; ++j) acc = fma(Win[k * ld + n.d + 1 + j], y[j], acc);
-    z[k] = acc;
-    if (zs) zs[k] = acc;
-  }
-  const double* Wh = n.th + n.o.Wh;
-  const double* Whb = n.th + n.o.Whb;
+  for (int k = 0; k < K; ++k) z2[k] = fma(Win[k * ld + n.d], t, xproj[k]);
+  matvec(Win + n.d + 1, ld, K, n.H, [&](int j) { return y[j]; }, z2, z);
+  if (zs)
+    for (int k = 0; k < K; ++k) zs[k] = z[k];
   for (int l = 1; l < n.m; ++l) {
-    for (int k = 0; k < n.K; ++k) {
-      double acc = Whb[k];
-      for (int kk = 0; kk < n.K; ++kk) acc = fma(Wh[k * n.K + kk], z[kk] > 0.0 ? z[kk] : 0.0, acc);
-      z2[k] = acc;
-    }
-    for (int k = 0; k < n.K; ++k) {
+    matvec(n.th + n.o.Wh, K, K, K, [&](int kk) { return z[kk] > 0.0 ? z[kk] : 0.0; }, n.th + n.o.Whb, z2);
+    for (int k = 0; k < K; ++k) {
       z[k] = z2[k];
       if (zs) zs[l * GK + k] = z2[k];
     }
   }
-  const double* Wo = n.th + n.o.Wo;
-  const double* Wob = n.th + n.o.Wob;
-  for (int k = 0; k < n.K; ++k) z[k] = xw_tanh(z[k]);
-  for (int h = 0; h < n.H; ++h) {
-    double acc = Wob[h];
-    for (int k = 0; k < n.K; ++k) acc = fma(Wo[h * n.K + k], z[k], acc);
-    out[h] = acc;
-  }
+  for (int k = 0; k < K; ++k) z[k] = xw_tanh(z[k]);
+  matvec(n.th + n.o.Wo, K, n.H, K, [&](int k) { return z[k]; }, n.th + n.o.Wob, out);
 }
 
-// slab[e] += sum over the 16 paths of the group of `term` (zero on lanes past the end): fixed butterfly, one writer
-#define XWG_ADD(e, term) { const double s_ = gsum16(active ? (term) : 0.0); if (lead) slab[e] += s_; }
+// slab[e0 + i] += sum over the 16 paths of the group of term(i), i < n.  Sixteen entries at a time: every lane of the group ends
+// up holding the total of ONE entry (a fixed butterfly of lane exchanges per entry) and the group adds them with one coalesced
+// read-modify-write -- an entry is always touched by the same lane, in program order: deterministic, no atomics, and the memory
+// round trip is paid once per 16 entries (per entry it was 0.5 us: 120 of the 150 ms of a sweep at (64, 16)).
+template <class F>
+__device__ __forceinline__ void gadd_run(double* slab, int e0, int n, bool active, F term) {
+  const int l16 = threadIdx.x & 15;
+  for (int c = 0; c < n; c += 16) {
+    double mine = 0.0;
+    for (int i = 0; i < 16; ++i) {
+      if (c + i >= n) break;
+      const double s_ = gsum16(active ? term(c + i) : 0.0);
+      if (l16 == i) mine = s_;
+    }
+    if (c + l16 < n) slab[e0 + c + l16] += mine;
+  }
+}
 
 // a^T dF/d(y, theta) at (t, yin): gy[H] (overwritten), Sx[K] += cotangent of the input layer's pre-activation (the x columns and
 // the bias of Win are contracted once per sweep from it), parameter gradients into the group's slab (or none: slab == null)
 __device__ void field_vjp(const Net& n, const double* xproj, double t, const double* yin, const double* a, double* gy, double* Sx,
-                          double* slab, bool active, bool lead) {
+                          double* slab, bool active) {
   double zs[GM * GK], out[GH];
   field_eval(n, xproj, t, yin, out, zs);
   const int K = n.K, H = n.H, ld = n.o.ldin;
@@ -92,60 +139,44 @@ __device__ void field_vjp(const Net& n, const double* xproj, double t, const dou
   const double* Win = n.th + n.o.Win;
   double dz[GK], dzp[GK], th[GK];
   for (int k = 0; k < K; ++k) th[k] = xw_tanh(zs[(n.m - 1) * GK + k]);
-  for (int k = 0; k < K; ++k) {
-    double acc = 0.0;
-    for (int h = 0; h < H; ++h) acc = fma(Wo[h * K + k], a[h], acc);
-    dz[k] = acc * (1.0 - th[k] * th[k]);
-  }
+  matvecT(Wo, K, H, K, a, dz);
+  for (int k = 0; k < K; ++k) dz[k] *= 1.0 - th[k] * th[k];
   if (slab) {
     for (int h = 0; h < H; ++h) {
-      for (int k = 0; k < K; ++k) XWG_ADD(n.o.Wo + h * K + k, a[h] * th[k])
-      XWG_ADD(n.o.Wob + h, a[h])
+      const double ah = a[h];
+      gadd_run(slab, n.o.Wo + h * K, K, active, [&](int k) { return ah * th[k]; });
     }
+    gadd_run(slab, n.o.Wob, H, active, [&](int h) { return a[h]; });
   }
   for (int l = n.m - 1; l >= 1; --l) {
     const double* zp = zs + (l - 1) * GK;
     if (slab) {
       for (int k = 0; k < K; ++k) {
-        for (int kk = 0; kk < K; ++kk) XWG_ADD(n.o.Wh + k * K + kk, dz[k] * (zp[kk] > 0.0 ? zp[kk] : 0.0))
-        XWG_ADD(n.o.Whb + k, dz[k])
+        const double dk = dz[k];
+        gadd_run(slab, n.o.Wh + k * K, K, active, [&](int kk) { return dk * (zp[kk] > 0.0 ? zp[kk] : 0.0); });
       }
+      gadd_run(slab, n.o.Whb, K, active, [&](int k) { return dz[k]; });
     }
-    for (int kk = 0; kk < K; ++kk) {
-      double acc = 0.0;
-      for (int k = 0; k < K; ++k) acc = fma(Wh[k * K + kk], dz[k], acc);
-      dzp[kk] = zp[kk] > 0.0 ? acc : 0.0;
-    }
-    for (int k = 0; k < K; ++k) dz[k] = dzp[k];
+    matvecT(Wh, K, K, K, dz, dzp);
+    for (int k = 0; k < K; ++k) dz[k] = zp[k] > 0.0 ? dzp[k] : 0.0;
   }
   if (slab) {
     for (int k = 0; k < K; ++k) {
-      XWG_ADD(n.o.Win + k * ld + n.d, dz[k] * t)
-      for (int j = 0; j < H; ++j) XWG_ADD(n.o.Win + k * ld + n.d + 1 + j, dz[k] * yin[j])
+      const double dk = dz[k];
+      // columns d (the time) and d + 1 .. d + H (the state) of row k are contiguous
+      gadd_run(slab, n.o.Win + k * ld + n.d, 1 + H, active, [&](int c) { return dk * (c == 0 ? t : yin[c - 1]); });
     }
   }
   for (int k = 0; k < K; ++k) Sx[k] += dz[k];
-  for (int j = 0; j < H; ++j) {
-    double acc = 0.0;
-    for (int k = 0; k < K; ++k) acc = fma(Win[k * ld + n.d + 1 + j], dz[k], acc);
-    gy[j] = acc;
-  }
+  matvecT(Win + n.d + 1, ld, K, H, dz, gy);
 }
 
 __device__ void lift(const Net& n, double s, double* pre0, double* pre2, double* y) {   // y0 = IL(start), src/model.py:78,97
   const double* th = n.th;
   const int H = n.H;
   for (int i = 0; i < H; ++i) pre0[i] = fma(th[n.o.IL0w + i], s, th[n.o.IL0b + i]);
-  for (int i = 0; i < H; ++i) {
-    double acc = th[n.o.IL2b + i];
-    for (int j = 0; j < H; ++j) acc = fma(th[n.o.IL2w + i * H + j], pre0[j] > 0.0 ? pre0[j] : 0.0, acc);
-    pre2[i] = acc;
-  }
-  for (int i = 0; i < H; ++i) {
-    double acc = th[n.o.IL4b + i];
-    for (int j = 0; j < H; ++j) acc = fma(th[n.o.IL4w + i * H + j], pre2[j] > 0.0 ? pre2[j] : 0.0, acc);
-    y[i] = acc;
-  }
+  matvec(th + n.o.IL2w, H, H, H, [&](int j) { return pre0[j] > 0.0 ? pre0[j] : 0.0; }, th + n.o.IL2b, pre2);
+  matvec(th + n.o.IL4w, H, H, H, [&](int j) { return pre2[j] > 0.0 ? pre2[j] : 0.0; }, th + n.o.IL4b, y);
 }
 
 __device__ void x_projection(const Net& n, const double* xT, int N, int path, double* xproj) {
@@ -223,7 +254,6 @@ __global__ void __launch_bounds__(64) kg_ode_bwd(XwOdeBwdJob job, const double* 
   const int raw = blockIdx.x * 64 + threadIdx.x;
   const bool active = raw < N;
   const int path = active ? raw : N - 1;                       // (lanes past the end walk along with the last path, adding zeros)
-  const bool lead = (threadIdx.x & 15) == 0;
   const bool want_x = (mode & 1) != 0, ones_x = (mode & 4) != 0;
   double* slab = (mode & 2) ? job.gslab + (long)(raw >> 4) * u_offsets(d, H, K).total : nullptr;
   if (slab != nullptr && (raw >> 4) * 16 >= N) slab = nullptr;  // (a group entirely past the end owns no slab)
@@ -240,15 +270,15 @@ __global__ void __launch_bounds__(64) kg_ode_bwd(XwOdeBwdJob job, const double* 
       lam[j] = fma(flw[j], ub, lam[j]);
     }
     if (slab) {
-      for (int j = 0; j < H; ++j) XWG_ADD(n.o.FLw + j, ub * y[j])
-      XWG_ADD(n.o.FLb, ub)
+      gadd_run(slab, n.o.FLw, H, active, [&](int j) { return ub * y[j]; });
+      gadd_run(slab, n.o.FLb, 1, active, [&](int) { return ub; });
     }
     // y_l = step(y_{l-1}): lam becomes the cotangent of y_{l-1}
     const double t0 = tf[l - 1], dt = tf[l] - tf[l - 1];
     for (int j = 0; j < H; ++j) y[j] = job.Y[((long)(l - 1) * H + j) * N + path];
     if (method == 0) {
       for (int j = 0; j < H; ++j) a[j] = dt * lam[j];
-      field_vjp(n, xproj, t0, y, a, gy, Sx, slab, active, lead);
+      field_vjp(n, xproj, t0, y, a, gy, Sx, slab, active);
       for (int j = 0; j < H; ++j) lam[j] += gy[j];
     } else if (method == 1) {
       double k1[GH], ym[GH];
@@ -257,12 +287,12 @@ __global__ void __launch_bounds__(64) kg_ode_bwd(XwOdeBwdJob job, const double* 
         ym[j] = fma(k1[j], dt / 2, y[j]);
         a[j] = dt * lam[j];
       }
-      field_vjp(n, xproj, t0 + dt / 2, ym, a, gy, Sx, slab, active, lead);
+      field_vjp(n, xproj, t0 + dt / 2, ym, a, gy, Sx, slab, active);
       for (int j = 0; j < H; ++j) {
         lam[j] += gy[j];
         a[j] = (dt / 2) * gy[j];
       }
-      field_vjp(n, xproj, t0, y, a, gy, Sx, slab, active, lead);
+      field_vjp(n, xproj, t0, y, a, gy, Sx, slab, active);
       for (int j = 0; j < H; ++j) lam[j] += gy[j];
     } else {
       double k1[GH], k2[GH], k3[GH], Y2[GH], Y3[GH], Y4[GH], g4[GH], g3[GH], g2[GH];
@@ -273,13 +303,13 @@ __global__ void __launch_bounds__(64) kg_ode_bwd(XwOdeBwdJob job, const double* 
       field_eval(n, xproj, t0 + 2 * dt / 3, Y3, k3, nullptr);
       for (int j = 0; j < H; ++j) Y4[j] = y[j] + dt * (k1[j] - k2[j] + k3[j]);
       for (int j = 0; j < H; ++j) a[j] = (dt / 8) * lam[j];
-      field_vjp(n, xproj, t0 + dt, Y4, a, g4, Sx, slab, active, lead);
+      field_vjp(n, xproj, t0 + dt, Y4, a, g4, Sx, slab, active);
       for (int j = 0; j < H; ++j) a[j] = (3 * dt / 8) * lam[j] + dt * g4[j];
-      field_vjp(n, xproj, t0 + 2 * dt / 3, Y3, a, g3, Sx, slab, active, lead);
+      field_vjp(n, xproj, t0 + 2 * dt / 3, Y3, a, g3, Sx, slab, active);
       for (int j = 0; j < H; ++j) a[j] = (3 * dt / 8) * lam[j] - dt * g4[j] + dt * g3[j];
-      field_vjp(n, xproj, t0 + dt / 3, Y2, a, g2, Sx, slab, active, lead);
+      field_vjp(n, xproj, t0 + dt / 3, Y2, a, g2, Sx, slab, active);
       for (int j = 0; j < H; ++j) a[j] = (dt / 8) * lam[j] + dt * g4[j] - (dt / 3) * g3[j] + (dt / 3) * g2[j];
-      field_vjp(n, xproj, t0, y, a, gy, Sx, slab, active, lead);
+      field_vjp(n, xproj, t0, y, a, gy, Sx, slab, active);
       for (int j = 0; j < H; ++j) lam[j] += g4[j] + g3[j] + g2[j] + gy[j];
     }
   }
@@ -289,8 +319,8 @@ __global__ void __launch_bounds__(64) kg_ode_bwd(XwOdeBwdJob job, const double* 
   double p0[GH], p2[GH];
   lift(n, job.start[path], p0, p2, y);
   if (slab) {
-    for (int j = 0; j < H; ++j) XWG_ADD(n.o.FLw + j, ub0 * y[j])
-    XWG_ADD(n.o.FLb, ub0)
+    gadd_run(slab, n.o.FLw, H, active, [&](int j) { return ub0 * y[j]; });
+    gadd_run(slab, n.o.FLb, 1, active, [&](int) { return ub0; });
   }
   const double s = job.start[path];
   for (int pass = 0; pass < 2; ++pass) {
@@ -300,29 +330,20 @@ __global__ void __launch_bounds__(64) kg_ode_bwd(XwOdeBwdJob job, const double* 
     const double ub = pass == 1 && ones_x ? 1.0 : ub0;
     double l0[GH], dh2[GH], dh1[GH];
     for (int j = 0; j < H; ++j) l0[j] = fma(flw[j], ub, lam[j]);
-    for (int j = 0; j < H; ++j) {
-      double acc = 0.0;
-      for (int i = 0; i < H; ++i) acc = fma(theta[n.o.IL4w + i * H + j], l0[i], acc);
-      dh2[j] = p2[j] > 0.0 ? acc : 0.0;
-    }
-    for (int j = 0; j < H; ++j) {
-      double acc = 0.0;
-      for (int i = 0; i < H; ++i) acc = fma(theta[n.o.IL2w + i * H + j], dh2[i], acc);
-      dh1[j] = p0[j] > 0.0 ? acc : 0.0;
-    }
+    matvecT(theta + n.o.IL4w, H, H, H, l0, dh2);
+    for (int j = 0; j < H; ++j) dh2[j] = p2[j] > 0.0 ? dh2[j] : 0.0;
+    matvecT(theta + n.o.IL2w, H, H, H, dh2, dh1);
+    for (int j = 0; j < H; ++j) dh1[j] = p0[j] > 0.0 ? dh1[j] : 0.0;
     if (pass == 0) {
       for (int i = 0; i < H; ++i) {
-        for (int j = 0; j < H; ++j) XWG_ADD(n.o.IL4w + i * H + j, l0[i] * (p2[j] > 0.0 ? p2[j] : 0.0))
-        XWG_ADD(n.o.IL4b + i, l0[i])
+        const double li = l0[i], di = dh2[i];
+        gadd_run(slab, n.o.IL4w + i * H, H, active, [&](int j) { return li * (p2[j] > 0.0 ? p2[j] : 0.0); });
+        gadd_run(slab, n.o.IL2w + i * H, H, active, [&](int j) { return di * (p0[j] > 0.0 ? p0[j] : 0.0); });
       }
-      for (int i = 0; i < H; ++i) {
-        for (int j = 0; j < H; ++j) XWG_ADD(n.o.IL2w + i * H + j, dh2[i] * (p0[j] > 0.0 ? p0[j] : 0.0))
-        XWG_ADD(n.o.IL2b + i, dh2[i])
-      }
-      for (int i = 0; i < H; ++i) {
-        XWG_ADD(n.o.IL0w + i, dh1[i] * s)
-        XWG_ADD(n.o.IL0b + i, dh1[i])
-      }
+      gadd_run(slab, n.o.IL4b, H, active, [&](int i) { return l0[i]; });
+      gadd_run(slab, n.o.IL2b, H, active, [&](int i) { return dh2[i]; });
+      gadd_run(slab, n.o.IL0w, H, active, [&](int i) { return dh1[i] * s; });
+      gadd_run(slab, n.o.IL0b, H, active, [&](int i) { return dh1[i]; });
     } else if (active) {
       double acc = 0.0;
       for (int i = 0; i < H; ++i) acc = fma(theta[n.o.IL0w + i], dh1[i], acc);
@@ -332,9 +353,10 @@ __global__ void __launch_bounds__(64) kg_ode_bwd(XwOdeBwdJob job, const double* 
   // the x columns and the bias of the input layer, from the summed cotangent of its pre-activation
   const double* Win = theta + n.o.Win;
   if (slab) {
+    gadd_run(slab, n.o.Winb, K, active, [&](int k) { return Sx[k]; });
     for (int k = 0; k < K; ++k) {
-      XWG_ADD(n.o.Winb + k, Sx[k])
-      for (int i = 0; i < d; ++i) XWG_ADD(n.o.Win + k * n.o.ldin + i, Sx[k] * job.xT[(long)i * N + path])
+      const double sk = Sx[k];
+      gadd_run(slab, n.o.Win + k * n.o.ldin, d, active, [&](int i) { return sk * job.xT[(long)i * N + path]; });
     }
   }
   if (want_x && job.gx != nullptr && active)
@@ -344,7 +366,6 @@ __global__ void __launch_bounds__(64) kg_ode_bwd(XwOdeBwdJob job, const double* 
       job.gx[(long)i * N + path] = acc;
     }
 }
-#undef XWG_ADD
 
 // ---- v_phi ---------------------------------------------------------------------------------------------------------------------
 // point -> (time, path): path mode p = l N + n, point mode (tpp) p = n
@@ -390,15 +411,26 @@ __global__ void __launch_bounds__(64) kg_disc_fwd(const double* __restrict__ xT,
       if (grad && open) mk[j][k >> 6] |= 1ull << (k & 63);
       if (act) act[((long)j * W + k) * cols + p] = a[k];
     }
-    for (int k = 0; k < W; ++k) {
-      double s0 = ph[o.Vhb + k], s1 = 0.0;
+    for (int k = 0; k < W; k += 4) {                // four output rows at a time: a loaded activation feeds 8 multiply-adds
+      const int k1 = k + 1 < W ? k + 1 : W - 1, k2 = k + 2 < W ? k + 2 : W - 1, k3 = k + 3 < W ? k + 3 : W - 1;
+      const double* w0 = ph + o.Vh + k * W;
+      const double* w1 = ph + o.Vh + k1 * W;
+      const double* w2 = ph + o.Vh + k2 * W;
+      const double* w3 = ph + o.Vh + k3 * W;
+      double s0 = ph[o.Vhb + k], s1 = ph[o.Vhb + k1], s2 = ph[o.Vhb + k2], s3 = ph[o.Vhb + k3];
+      double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+#pragma unroll 4
       for (int kk = 0; kk < W; ++kk) {
-        const double w_ = ph[o.Vh + k * W + kk];
-        s0 = fma(w_, a[kk], s0);
-        s1 = fma(w_, ad[kk], s1);
+        const double av = a[kk], adv = ad[kk];
+        s0 = fma(w0[kk], av, s0); t0 = fma(w0[kk], adv, t0);
+        s1 = fma(w1[kk], av, s1); t1 = fma(w1[kk], adv, t1);
+        s2 = fma(w2[kk], av, s2); t2 = fma(w2[kk], adv, t2);
+        s3 = fma(w3[kk], av, s3); t3 = fma(w3[kk], adv, t3);
       }
-      nw[k] = s0;
-      nd[k] = s1;
+      nw[k] = s0; nd[k] = t0;
+      if (k + 1 < W) { nw[k + 1] = s1; nd[k + 1] = t1; }
+      if (k + 2 < W) { nw[k + 2] = s2; nd[k + 2] = t2; }
+      if (k + 3 < W) { nw[k + 3] = s3; nd[k + 3] = t3; }
     }
     for (int k = 0; k < W; ++k) {
       a[k] = nw[k];
@@ -437,7 +469,25 @@ __global__ void __launch_bounds__(64) kg_disc_fwd(const double* __restrict__ xT,
   }
 }
 
-// parameter gradient of <vbar, v> from the record of kg_disc_fwd; one wave per block, one slab per block, 64 points per pass
+// slab[e0 + i] += sum over the 64 points of the wave of term(i), i < n: as gadd_run, 64 entries per coalesced read-modify-write
+template <class F>
+__device__ __forceinline__ void wadd_run(double* slab, int e0, int n, F term) {
+  const int lane = threadIdx.x;
+  for (int c = 0; c < n; c += 64) {
+    double mine = 0.0;
+    for (int i = 0; i < 64; ++i) {
+      if (c + i >= n) break;
+      const double s_ = gsum64(term(c + i));
+      if (lane == i) mine = s_;
+    }
+    if (c + lane < n) slab[e0 + c + lane] += mine;
+  }
+}
+
+// parameter gradient of <vbar, v> from the record of kg_disc_fwd; one wave per block, one slab per block, 64 points per pass.
+// The reverse chain runs first and keeps the cotangent of every layer (per lane, scratch); dVh is then formed entry by entry over
+// ALL layers at once -- sum_j delta_{j+1}[k] r_j[kk] per lane, one butterfly over the 64 points, one coalesced slab update per
+// 64 entries -- instead of a memory round trip per entry and layer (387 -> ~10 ms at W = 128, headline sample).
 __global__ void __launch_bounds__(64) kg_disc_bwd(const double* __restrict__ xT, const double* __restrict__ tf,
                                                    const double* __restrict__ tpp, const double* __restrict__ ph,
                                                    const double* __restrict__ vbar, int N, int L, int d, int W, int q,
@@ -446,8 +496,6 @@ __global__ void __launch_bounds__(64) kg_disc_bwd(const double* __restrict__ xT,
   const long nsuper = (P + 63) / 64;
   const VOff o = v_offsets(d, W);
   double* slab = gslab + (long)blockIdx.x * o.total;
-  const bool lead = threadIdx.x == 0;
-#define XWG_ADDW(e, term) { const double s_ = gsum64(term); if (lead) slab[e] += s_; }
   for (long st = blockIdx.x; st < nsuper; st += gridDim.x) {
     const long raw = st * 64 + threadIdx.x;
     const bool valid = raw < P;
@@ -456,34 +504,58 @@ __global__ void __launch_bounds__(64) kg_disc_bwd(const double* __restrict__ xT,
     int nidx;
     locate_pt(p, N, tf, tpp, t, nidx);
     const double vb = valid ? (vbar ? vbar[p] : 1.0) : 0.0;
-    double dl[GW], nx[GW];
+    double dls[(GQ + 1) * GW];                                   // dls[j * GW + k]: cotangent of a_j[k] (j = q: of the last pre-activation)
+    double* dq = dls + q * GW;
     for (int k = 0; k < W; ++k) {
       const double th = act[((long)q * W + k) * cols + p];
-      dl[k] = ph[o.Vo + k] * (1.0 - th * th) * vb;
-      XWG_ADDW(o.Vo + k, vb * th)
+      dq[k] = ph[o.Vo + k] * (1.0 - th * th) * vb;
     }
-    XWG_ADDW(o.Vob, vb)
+    wadd_run(slab, o.Vo, W, [&](int k) { return vb * act[((long)q * W + k) * cols + p]; });
+    wadd_run(slab, o.Vob, 1, [&](int) { return vb; });
     for (int j = q - 1; j >= 0; --j) {
-      const double* r = act + (long)j * W * cols + p;           // r[kk * cols]: input kk of tied layer j at this point
-      for (int k = 0; k < W; ++k) {
-        const double dk = dl[k];
-        for (int kk = 0; kk < W; ++kk) XWG_ADDW(o.Vh + k * W + kk, dk * r[(long)kk * cols])
-        XWG_ADDW(o.Vhb + k, dk)
+      const double* r = act + (long)j * W * cols + p;            // r[kk * cols]: input kk of tied layer j at this point
+      const double* dn = dls + (j + 1) * GW;
+      double* dj = dls + j * GW;
+      for (int kk = 0; kk < W; kk += 4) {
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        const int c1 = kk + 1 < W ? kk + 1 : W - 1, c2 = kk + 2 < W ? kk + 2 : W - 1, c3 = kk + 3 < W ? kk + 3 : W - 1;
+#pragma unroll 4
+        for (int k = 0; k < W; ++k) {
+          const double dk = dn[k];
+          const double* row = ph + o.Vh + k * W;
+          a0 = fma(row[kk], dk, a0);
+          a1 = fma(row[c1], dk, a1);
+          a2 = fma(row[c2], dk, a2);
+          a3 = fma(row[c3], dk, a3);
+        }
+        dj[kk] = r[(long)kk * cols] > 0.0 ? a0 : 0.0;
+        if (kk + 1 < W) dj[kk + 1] = r[(long)(kk + 1) * cols] > 0.0 ? a1 : 0.0;
+        if (kk + 2 < W) dj[kk + 2] = r[(long)(kk + 2) * cols] > 0.0 ? a2 : 0.0;
+        if (kk + 3 < W) dj[kk + 3] = r[(long)(kk + 3) * cols] > 0.0 ? a3 : 0.0;
       }
-      for (int kk = 0; kk < W; ++kk) {
-        double acc = 0.0;
-        for (int k = 0; k < W; ++k) acc = fma(ph[o.Vh + k * W + kk], dl[k], acc);
-        nx[kk] = r[(long)kk * cols] > 0.0 ? acc : 0.0;
-      }
-      for (int k = 0; k < W; ++k) dl[k] = nx[k];
     }
+    // dVh[k][kk] += sum_j delta_{j+1}[k] r_j[kk];  dVh.b[k] += sum_j delta_{j+1}[k]
     for (int k = 0; k < W; ++k) {
-      XWG_ADDW(o.Vinb + k, dl[k])
-      XWG_ADDW(o.Vin + k * o.ldin, dl[k] * t)
-      for (int i = 0; i < d; ++i) XWG_ADDW(o.Vin + k * o.ldin + 1 + i, dl[k] * xT[(long)i * N + nidx])
+      double dk[GQ];
+      for (int j = 0; j < q; ++j) dk[j] = dls[(j + 1) * GW + k];
+      wadd_run(slab, o.Vh + k * W, W, [&](int kk) {
+        double acc = 0.0;
+        for (int j = 0; j < q; ++j) acc = fma(dk[j], act[((long)j * W + kk) * cols + p], acc);
+        return acc;
+      });
+    }
+    wadd_run(slab, o.Vhb, W, [&](int k) {
+      double acc = 0.0;
+      for (int j = 0; j < q; ++j) acc += dls[(j + 1) * GW + k];
+      return acc;
+    });
+    // input layer: row k of dVin = delta_0[k] [t, x], contiguous; dVin.b = delta_0
+    wadd_run(slab, o.Vinb, W, [&](int k) { return dls[k]; });
+    for (int k = 0; k < W; ++k) {
+      const double d0 = dls[k];
+      wadd_run(slab, o.Vin + k * o.ldin, 1 + d, [&](int c) { return d0 * (c == 0 ? t : xT[(long)(c - 1) * N + nidx]); });
     }
   }
-#undef XWG_ADDW
 }
 
 }  // namespace
