@@ -487,7 +487,8 @@ __device__ __forceinline__ void wadd_run(double* slab, int e0, int n, F term) {
 // parameter gradient of <vbar, v> from the record of kg_disc_fwd; one wave per block, one slab per block, 64 points per pass.
 // The reverse chain runs first and keeps the cotangent of every layer (per lane, scratch); dVh is then formed entry by entry over
 // ALL layers at once -- sum_j delta_{j+1}[k] r_j[kk] per lane, one butterfly over the 64 points, one coalesced slab update per
-// 64 entries -- instead of a memory round trip per entry and layer (387 -> ~10 ms at W = 128, headline sample).
+// 64 entries, four rows of dVh per pass over the record -- instead of a memory round trip per entry and layer (387 -> 82 ms at W = 128,
+// headline sample).
 __global__ void __launch_bounds__(64) kg_disc_bwd(const double* __restrict__ xT, const double* __restrict__ tf,
                                                    const double* __restrict__ tpp, const double* __restrict__ ph,
                                                    const double* __restrict__ vbar, int N, int L, int d, int W, int q,
@@ -534,15 +535,40 @@ __global__ void __launch_bounds__(64) kg_disc_bwd(const double* __restrict__ xT,
         if (kk + 3 < W) dj[kk + 3] = r[(long)(kk + 3) * cols] > 0.0 ? a3 : 0.0;
       }
     }
-    // dVh[k][kk] += sum_j delta_{j+1}[k] r_j[kk];  dVh.b[k] += sum_j delta_{j+1}[k]
-    for (int k = 0; k < W; ++k) {
-      double dk[GQ];
-      for (int j = 0; j < q; ++j) dk[j] = dls[(j + 1) * GW + k];
-      wadd_run(slab, o.Vh + k * W, W, [&](int kk) {
-        double acc = 0.0;
-        for (int j = 0; j < q; ++j) acc = fma(dk[j], act[((long)j * W + kk) * cols + p], acc);
-        return acc;
-      });
+    // dVh[k][kk] += sum_j delta_{j+1}[k] r_j[kk];  dVh.b[k] += sum_j delta_{j+1}[k].  FOUR rows k at a time: the q record values
+    // r_j[kk] of an input kk are loaded once per four rows (the record of a 64-point pass, 0.6 MB at W = 128, does not stay in
+    // cache across the passes of all the waves of an XCD: row by row it was re-read W times from HBM)
+    for (int k = 0; k < W; k += 4) {
+      double dk[4][GQ];
+#pragma unroll
+      for (int j = 0; j < GQ; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dk[i][j] = (j < q && k + i < W) ? dls[(j + 1) * GW + k + i] : 0.0;
+      const int lane = threadIdx.x;
+      for (int c = 0; c < W; c += 64) {
+        double mine[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int i = 0; i < 64; ++i) {
+          if (c + i >= W) break;
+          double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+          for (int j = 0; j < GQ; ++j) {
+            if (j < q) {
+              const double rj = act[((long)j * W + c + i) * cols + p];
+              a0 = fma(dk[0][j], rj, a0);
+              a1 = fma(dk[1][j], rj, a1);
+              a2 = fma(dk[2][j], rj, a2);
+              a3 = fma(dk[3][j], rj, a3);
+            }
+          }
+          a0 = gsum64(a0); a1 = gsum64(a1); a2 = gsum64(a2); a3 = gsum64(a3);
+          if (lane == i) { mine[0] = a0; mine[1] = a1; mine[2] = a2; mine[3] = a3; }
+        }
+        if (c + lane < W) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (k + i < W) slab[o.Vh + (k + i) * W + c + lane] += mine[i];
+        }
+      }
     }
     wadd_run(slab, o.Vhb, W, [&](int k) {
       double acc = 0.0;
