@@ -234,7 +234,10 @@ def main():
         _, path_u_, macs_v_ = algorithmic_macs(params_)
         Pn_ = n_paths * params_['N_t']
         flops_ = {                                             # algorithmic FLOP (2 x MAC) per launch, SURVEY section 8(d)
-            'disc_fwd': 2.0 * (2 * Pn_ + n_paths) * macs_v_,   # value + d/dt tangent at all points, reverse pass at the N points of t_0
+            # value + d/dt tangent at all points, reverse pass at the N points of t_0; with the input layer's spatial columns applied
+            # once per path (engine: from d = XW_XPROJ_MIN_D on) the d W multiply-adds per point it no longer does are not counted
+            'disc_fwd': 2.0 * ((2 * Pn_ + n_paths) * macs_v_ - ((Pn_ - n_paths) * params_['dim'] * params_['v_hidden_dim']
+                                                                if G_.ptr('xproj') else 0)),
             'disc_bwd': 2.0 * 2 * Pn_ * macs_v_,               # reverse chain + weight-gradient contraction (recompute not counted)
             'ode_fwd_1job': 2.0 * n_paths * path_u_,
             'ode_fwd_2job': 2.0 * (n_paths + nb_paths) * path_u_,

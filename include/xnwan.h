@@ -129,6 +129,15 @@ int xw_ode_bwd_multi(const XwOdeBwdJob* jobs, int njobs, const double* t, const 
 int xw_disc_fwd(const double* xT, const double* t, const double* tpp, const double* phi,
                 int N, int L, int d, int W, int q, double* v, double* vt, double* gxv, double* gtv, int ngrad,
                 int max_blocks, double* act, void* stream);
+/* The same with the x-projection of the input layer HOISTED out of the points (path mode only, tpp == NULL): on vertical paths the d
+ * spatial columns of the input layer do not move along a path, so Vin[:, 1..d] x_n + Vin.b is formed once per path by xw_disc_xproj
+ * (xproj[64][N], rows >= W zero) and a point's input layer is one load and one multiply-add per row -- instead of ceil(d/4) x 4
+ * matrix instructions and as many loads of x per 16-point tile, L times per path (12 % of the launch at d = 100).  xproj == NULL: as
+ * xw_disc_fwd.  The widths of the MFMA kernels only (50, 64). */
+int xw_disc_xproj(const double* xT, const double* phi, int N, int d, int W, double* xproj, void* stream);
+int xw_disc_fwd_xproj(const double* xT, const double* t, const double* tpp, const double* phi,
+                      int N, int L, int d, int W, int q, double* v, double* vt, double* gxv, double* gtv, int ngrad,
+                      int max_blocks, double* act, const double* xproj, void* stream);
 /* act (may be NULL): activation record of xw_disc_act_rows(W, q) x (N L rounded up to a multiple of 16) doubles = the
  * inputs relu(a_j) of the q tied layers and tanh(a_q).  Its layout is the kernels' own (tile-major: [tile of 16 points]
  * [row j W + k][16], so that a wave's accesses are contiguous); callers only size it.  Given to xw_disc_bwd it replaces that kernel's forward recompute (500 doubles per point =
@@ -277,6 +286,7 @@ typedef struct {
   const double *xT, *xvT, *xbT, *t, *tb, *tpp, *xvT_pts;
   const double *start, *start_b, *h, *href, *f, *g, *w, *wt, *w0, *ghT, *gwx0T, *c, *cp, *A0, *B0;
   double *u, *ub, *Y, *Yb, *act, *act_b, *v, *vt, *gxv, *gtv, *gx, *gs, *vbar, *s3x, *vact, *slabA, *slabB, *slab_v, *work_i, *work_b;
+  double *xproj;                  /* [64][N] or NULL: table of xw_disc_xproj -- the test network then runs as xw_disc_fwd_xproj (path mode) */
 } XwGroup;
 /* in-place float64 sum of buf[count] over the ranks, enqueued on `stream`: xw_allreduce's own signature */
 typedef int (*XwExchangeFn)(double* buf, int count, void* ctx, void* stream);

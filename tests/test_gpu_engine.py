@@ -85,6 +85,20 @@ def first_sample(S):
 
 @pytest.mark.parametrize('case', CASES)
 def test_first_iteration_against_reference_vectors(golden_dir, case):
+    _first_iteration(golden_dir, case)
+
+
+@pytest.mark.parametrize('case', ['ref_plumb_midpoint', 'ref_d50_nt64_small_midpoint', 'ref_d100_small_midpoint', 'ref_wide_d6_midpoint',
+                                  'ref_m1_d4_rk4'])
+def test_first_iteration_with_the_hoisted_x_projection_against_reference_vectors(golden_dir, case, monkeypatch):
+    """the same comparison with the test network's input layer split into xw_disc_xproj (spatial columns, once per path) and
+    xw_disc_fwd_xproj -- on by itself from d = 45 (engine.xproj_min_d), forced here for the smaller ones"""
+    monkeypatch.setenv('XW_XPROJ_MIN_D', '1')
+    G = _first_iteration(golden_dir, case)
+    assert G.ptr('xproj') != 0 and float(G.xproj.abs().sum()) > 0
+
+
+def _first_iteration(golden_dir, case):
     from utils.auxillary_funcs import L_norm, rel_err
     z, params = load(golden_dir, case)
     general = params.pop('funcs', None) == 'general_v1'
@@ -164,6 +178,7 @@ def test_first_iteration_against_reference_vectors(golden_dir, case):
     pts2 = Comb_loader(S.setup['N_r'], S.setup['N_b'], domain, S.device)
     same_sample(z, 'x_u_second', pts2.interioru[:, 0, 1:])
     close(L_norm(pts2.interioru, S.u_net, 2, P.func_u_sol, domain.V(), S.setup['N_r']), float(z['L2_end']), 1e-6)
+    return G
 
 
 def test_module_autograd_path_reproduces_reference_gradients(golden_dir):
@@ -476,14 +491,18 @@ def test_pipelined_loop_flushes_its_last_iteration_when_interrupted(golden_dir, 
         os.chdir(cwd)
 
 
-@pytest.mark.parametrize('general', [False, True])
-@pytest.mark.parametrize('name', ['NSphere_TCone', 'NSphere_THourglass'])
-def test_group_substep_runner_matches_the_launch_by_launch_path(tmp_path, name, general):
+@pytest.mark.parametrize('name,general,hoist', [('NSphere_TCone', False, False), ('NSphere_THourglass', False, False),
+                                                ('NSphere_TCone', True, False), ('NSphere_THourglass', True, False),
+                                                ('NSphere_THourglass', False, True)])
+def test_group_substep_runner_matches_the_launch_by_launch_path(tmp_path, name, general, hoist, monkeypatch):
     """xw_substep_gen / xw_substep_disc (one C-ABI call per group sub-step, csrc/xw_substep.hip) against the same chain issued
     launch by launch from engine.py: bit-identical parameters after three outer iterations over all groups of a ball domain
     (single-slice pairwise groups, boundary groups on their own grids, point-mode test network, carried gradients).
     general: non-identity a_ij(t, x) and the linear reaction c = -0.7 u (the A0 table and xw_weak_contract_general inside the call;
-    XW_ELEMENTWISE_SINGLE_SLICE semantics are not involved: b = 0 keeps the pairwise groups allowed)"""
+    XW_ELEMENTWISE_SINGLE_SLICE semantics are not involved: b = 0 keeps the pairwise groups allowed)
+    hoist: every path-mode group with the x-projection table in front of its test network (XwGroup.xproj), in both forms"""
+    if hoist:
+        monkeypatch.setenv('XW_XPROJ_MIN_D', '1')
     F = P
     if general:
         class F:      # noqa: N801

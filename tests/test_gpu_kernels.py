@@ -537,6 +537,48 @@ def test_disc_kernels_at_width_64(N, L, d, q, Ww):
     _close(vp.view(L, N), v, 1e-13, 'point mode v'); _close(vtp.view(L, N), vt, 1e-13, 'point mode dv/dt')
 
 
+@pytest.mark.parametrize('Ww,q', [(50, 9), (64, 4)])
+@pytest.mark.parametrize('N,L,d', [(37, 7, 5), (64, 6, 20), (100, 3, 70), (300, 5, 100), (1100, 32, 50)])
+def test_disc_forward_with_the_hoisted_x_projection(N, L, d, Ww, q):
+    """xw_disc_xproj + xw_disc_fwd_xproj (the input layer's spatial columns applied once per path instead of once per point)
+    against the oracle and against the plain launch: values, d/dt, fused input gradient, and the gradient from its record"""
+    from oracle import refspec as R
+    from xnode_wan_pde_solver_amd import kernels as KN
+    from xnode_wan_pde_solver_amd._lib import XnwanError
+    cfg = dict(_cfg(), v_hidden_dim=Ww, v_layers=q)
+    torch.manual_seed(71)
+    _, phi = R.init_parameters(cfg, _setup(d, 2))
+    for p_ in phi.values():
+        if p_.dim() == 1:
+            p_.copy_(0.3 * torch.randn_like(p_))
+    x, t, X = _sample(N, L, d, 72)
+    xT, tc, blob = x.double().t().contiguous().cuda(), t.double().cuda(), _blob(phi, V_ORDER)
+    xp = KN.disc_xproj(xT, blob, Ww)
+    Vin, b = phi['Vin'].double(), phi['Vin_b'].double()
+    ref_p = x.double() @ Vin[:, 1:].t() + b
+    _close(xp[:Ww].t(), ref_p, 1e-13, 'x projection')
+    assert float(xp[Ww:].abs().sum()) == 0.0
+    outs = []
+    for table in (None, xp):
+        gxv, gtv = torch.empty(d, N, dtype=torch.float64).cuda(), torch.empty(N, dtype=torch.float64).cuda()
+        rec = torch.empty(KN.disc_act_rows(Ww, q), KN.disc_act_cols(L * N), dtype=torch.float64).cuda()
+        v, vt = KN.disc_fwd(xT, tc, blob, Ww, q, gxv=gxv, gtv=gtv, ngrad=N, act=rec, max_blocks=7, xproj=table)
+        vbar = torch.randn(L, N, dtype=torch.float64, generator=torch.Generator().manual_seed(73)).cuda()
+        g = KN.slab_sum(KN.disc_bwd(xT, tc, blob, vbar, Ww, q, act=rec))
+        v3, vt3 = KN.disc_fwd(xT, tc, blob, Ww, q, xproj=table)                  # (no record, no gradient, static split)
+        _close(v3, v, 1e-14, 'v without the extras'); _close(vt3, vt, 1e-14, 'dv/dt without the extras')
+        outs.append((v, vt, gxv, gtv, g))
+    Xd = X.double().requires_grad_(True)
+    v_ref = R.v_net(phi, cfg, Xd)
+    gX = torch.autograd.grad(v_ref.sum(), Xd)[0]
+    _close(outs[1][0].t(), v_ref, 1e-12, 'v'); _close(outs[1][1].t(), gX[:, :, 0], 1e-11, 'dv/dt')
+    _close(outs[1][2].t(), gX[:, 0, 1:], 1e-11, 'fused nabla_x v'); _close(outs[1][3], gX[:, 0, 0], 1e-11, 'fused dv/dt')
+    for a, b_, what in zip(outs[0], outs[1], ('v', 'vt', 'gxv', 'gtv', 'gradient')):
+        _close(b_, a, 1e-12, what + ' hoisted vs plain')
+    with pytest.raises(XnwanError):                                              # point mode has no per-path table
+        KN.disc_fwd(xT, None, blob, Ww, q, tpp=torch.rand(N, dtype=torch.float64).cuda(), xproj=xp)
+
+
 def test_disc_forward_ticket_queue_matches_static_split_over_many_launches():
     """more tiles than waves: the tiles after a wave's first one come from ticket counters (k_disc_fwd DYN) that the last wave
     of a launch zeroes again.  Which wave computes a tile cannot change its result: every launch -- more of them than there are

@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('XW_LIBRARY') or os.path.join(_HERE, 'libxnwan.so')   # (override: kernel experiments only)
-ABI_VERSION = 30
+ABI_VERSION = 31
 
 c_f32p = ctypes.c_void_p   # coordinates / time grid: const double* (device)   [name kept from the float32 era]
 c_f64p = ctypes.c_void_p   # double*       (device)
@@ -35,7 +35,7 @@ class XwGroup(ctypes.Structure):           # include/xnwan.h: one group of paths
                 + [(n, c_vp) for n in ('xT', 'xvT', 'xbT', 't', 'tb', 'tpp', 'xvT_pts', 'start', 'start_b', 'h', 'href', 'f', 'g', 'w',
                                        'wt', 'w0', 'ghT', 'gwx0T', 'c', 'cp', 'A0', 'B0', 'u', 'ub', 'Y', 'Yb', 'act', 'act_b', 'v',
                                        'vt', 'gxv', 'gtv', 'gx', 'gs', 'vbar', 's3x', 'vact', 'slabA', 'slabB', 'slab_v', 'work_i',
-                                       'work_b')])
+                                       'work_b', 'xproj')])
 
 
 class XwSolverState(ctypes.Structure):
@@ -66,6 +66,9 @@ SIGNATURES = {
                    c_f64p, c_f64p, c_f64p, c_vp],
     'xw_disc_fwd': [c_f32p, c_f32p, c_f32p, c_f64p, c_int, c_int, c_int, c_int, c_int, c_f64p, c_f64p, c_f64p, c_f64p, c_int,
                     c_int, c_f64p, c_vp],
+    'xw_disc_xproj': [c_f32p, c_f64p, c_int, c_int, c_int, c_f64p, c_vp],
+    'xw_disc_fwd_xproj': [c_f32p, c_f32p, c_f32p, c_f64p, c_int, c_int, c_int, c_int, c_int, c_f64p, c_f64p, c_f64p, c_f64p, c_int,
+                          c_int, c_f64p, c_f64p, c_vp],
     'xw_disc_act_rows': [c_int, c_int],
     'xw_disc_gradx': [c_f32p, c_f32p, c_f32p, c_f64p, c_f64p, c_int, c_int, c_int, c_int, c_f64p, c_f64p, c_vp],
     'xw_disc_bwd_slabs': [c_int, c_int],

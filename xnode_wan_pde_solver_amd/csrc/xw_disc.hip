@@ -110,12 +110,17 @@ __device__ unsigned long long xw_clock_buf[2 * 4096];
 #ifndef XW_DISC_FWD_WAVES
 #define XW_DISC_FWD_WAVES 2     // waves per SIMD the register allocation leaves room for (2: 256 registers, 3: 168)
 #endif
-template <int W, bool ACT, bool DYN, int VKS>      // VKS: k-steps of the input layer kept in LDS (0: none)
+// VKS: k-steps of the input layer kept in LDS (0: none; -1: the x-projection Vin[:, 1..d] x + Vin.b of every PATH is handed in,
+// `xproj`, and the input layer of a point is one load and one multiply-add per row: on vertical paths the d columns of the input
+// layer do not move along a path -- L = 32..64 times the same d W multiply-adds per path, 12 % of the launch's matrix
+// instructions at d = 100 and 25 + 48 loads per tile)
+template <int W, bool ACT, bool DYN, int VKS>
 __global__ void __launch_bounds__(256, XW_DISC_FWD_WAVES) k_disc_fwd(const double* __restrict__ xT, const double* __restrict__ tf,
                                                      const double* __restrict__ tpp, const double* __restrict__ ph, int N,
                                                      int L, int d, int q, double* __restrict__ v, double* __restrict__ vt,
                                                      double* __restrict__ gxv, double* __restrict__ gtv, int ngrad,
-                                                     double* __restrict__ act, unsigned int* __restrict__ queue) {
+                                                     double* __restrict__ act, unsigned int* __restrict__ queue,
+                                                     const double* __restrict__ xproj) {
   typedef VDim<W> D;
   // Vh as MFMA A-fragments in LDS (26.6 KB), shared by the 4 waves of the block: one ds_read_b64 feeds two 64-cycle MFMAs
   // (value and d/dt tangent), and keeping them out of the register file lets two waves share a SIMD so that one wave's
@@ -128,8 +133,9 @@ __global__ void __launch_bounds__(256, XW_DISC_FWD_WAVES) k_disc_fwd(const doubl
   // tile (the fragment loads put the four lanes of a quad into four rows) and their address arithmetic, re-formed for
   // every tile to keep them out of the spilled loop-invariant set
   constexpr bool VINLDS = VKS > 0;
+  constexpr bool XPROJ = VKS < 0;
   __shared__ double sVin[VINLDS ? VKS * D::MT * 64 : 1];
-  __shared__ double sIn[VINLDS ? 2 * 16 * D::MT : 1];
+  __shared__ double sIn[(VINLDS || XPROJ) ? 2 * 16 * D::MT : 1];
   __shared__ unsigned int sDone;
   if (DYN && threadIdx.x == 0) sDone = 0;
   // (s_setprio for this kernel's waves: no gain at 1, -5 % at 3 -- the sub-step's SIMD time is conserved)
@@ -147,7 +153,7 @@ __global__ void __launch_bounds__(256, XW_DISC_FWD_WAVES) k_disc_fwd(const doubl
   if (threadIdx.x < 16 * D::MT) {
     sB[threadIdx.x] = (int)threadIdx.x < W ? ph[o.Vhb + threadIdx.x] : 0.0;
     sB[16 * D::MT + threadIdx.x] = (int)threadIdx.x < W ? ph[o.Vo + threadIdx.x] : 0.0;
-    if (VINLDS) {
+    if (VINLDS || XPROJ) {
       sIn[threadIdx.x] = (int)threadIdx.x < W ? ph[o.Vin + (long)threadIdx.x * o.ldin] : 0.0;
       sIn[16 * D::MT + threadIdx.x] = (int)threadIdx.x < W ? ph[o.Vinb + threadIdx.x] : 0.0;
     }
@@ -200,7 +206,17 @@ __global__ void __launch_bounds__(256, XW_DISC_FWD_WAVES) k_disc_fwd(const doubl
     const int aoff = lane;                                              // (g, n) -> row offset g, point n
     const double* pht = ph;                                             // laundered: keeps the input-layer fragment
     asm volatile("" : "+s"(pht));                                       // addresses out of the loop-invariant (spilled) set
-    if (VINLDS) {
+    if (XPROJ) {
+      // input layer from the path's x-projection (rows >= W of it are zero): a_0 = (Vin[:, 1..d] x + Vin.b) + Vin[:, 0] t
+      const double* xp = xproj + pt.n;
+#pragma unroll
+      for (int mt = 0; mt < D::MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          ad[mt][r] = sIn[16 * mt + g + 4 * r];
+          a[mt][r] = (16 * mt + 4 * r < W) ? fma(ad[mt][r], pt.t, xw_ld_g(xp + (long)(16 * mt + 4 * r + g) * N)) : 0.0;
+        }
+    } else if (VINLDS) {
 #pragma unroll
       for (int mt = 0; mt < D::MT; ++mt)
 #pragma unroll
@@ -1182,14 +1198,58 @@ static bool disc_width_ok(int W) { return W == 50 || W == 64; }
 // (other widths up to 128: the generic path of xw_generic.hip, always from a record -- row-major there, [rows][columns])
 extern "C" int xw_disc_act_rows(int W, int q) { return ((disc_width_ok(W) && q >= 0) || xwg_disc_ok(1, W, q)) ? (q + 1) * W : XW_E_DIMS; }
 
+// x-projection of the input layer for the N paths of a group: xproj[r][n] = Vin[r, 1..d] x_n + Vin.b[r] for r < W, zero for the
+// padding rows up to 64.  One thread per (path, four rows); 41 MFLOP at d = 100, N = 8192: a few microseconds.
+namespace {
+__global__ void __launch_bounds__(256) k_disc_xproj(const double* __restrict__ xT, const double* __restrict__ ph, int N, int d, int W,
+                                                     double* __restrict__ xproj) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  const int r0 = blockIdx.y * 4;
+  if (n >= N) return;
+  const VOff o = v_offsets(d, W);
+  const int r1 = r0 + 1 < W ? r0 + 1 : W - 1, r2 = r0 + 2 < W ? r0 + 2 : W - 1, r3 = r0 + 3 < W ? r0 + 3 : W - 1, rr = r0 < W ? r0 : W - 1;
+  const double* w0 = ph + o.Vin + (long)rr * o.ldin + 1;
+  const double* w1 = ph + o.Vin + (long)r1 * o.ldin + 1;
+  const double* w2 = ph + o.Vin + (long)r2 * o.ldin + 1;
+  const double* w3 = ph + o.Vin + (long)r3 * o.ldin + 1;
+  double a0 = ph[o.Vinb + rr], a1 = ph[o.Vinb + r1], a2 = ph[o.Vinb + r2], a3 = ph[o.Vinb + r3];
+#pragma unroll 4
+  for (int i = 0; i < d; ++i) {
+    const double x = xT[(long)i * N + n];
+    a0 = fma(w0[i], x, a0);
+    a1 = fma(w1[i], x, a1);
+    a2 = fma(w2[i], x, a2);
+    a3 = fma(w3[i], x, a3);
+  }
+  xproj[(long)r0 * N + n] = r0 < W ? a0 : 0.0;
+  xproj[(long)(r0 + 1) * N + n] = r0 + 1 < W ? a1 : 0.0;
+  xproj[(long)(r0 + 2) * N + n] = r0 + 2 < W ? a2 : 0.0;
+  xproj[(long)(r0 + 3) * N + n] = r0 + 3 < W ? a3 : 0.0;
+}
+}  // namespace
+
+extern "C" int xw_disc_xproj(const double* xT, const double* phi, int N, int d, int W, double* xproj, void* stream) {
+  if (!xT || !phi || !xproj || N <= 0 || d <= 0) return XW_E_ARG;
+  if (!disc_width_ok(W)) return XW_E_DIMS;
+  hipLaunchKernelGGL(k_disc_xproj, dim3((N + 255) / 256, 16), dim3(256), 0, (hipStream_t)stream, xT, phi, N, d, W, xproj);
+  return xw_launch_status();
+}
+
 extern "C" int xw_disc_fwd(const double* xT, const double* t, const double* tpp, const double* phi, int N, int L, int d,
                            int W, int q, double* v, double* vt, double* gxv, double* gtv, int ngrad, int max_blocks,
                            double* act, void* stream) {
+  return xw_disc_fwd_xproj(xT, t, tpp, phi, N, L, d, W, q, v, vt, gxv, gtv, ngrad, max_blocks, act, nullptr, stream);
+}
+
+extern "C" int xw_disc_fwd_xproj(const double* xT, const double* t, const double* tpp, const double* phi, int N, int L, int d,
+                                 int W, int q, double* v, double* vt, double* gxv, double* gtv, int ngrad, int max_blocks,
+                                 double* act, const double* xproj, void* stream) {
   if (!xT || !phi || !v || N <= 0 || L <= 0 || d <= 0 || q < 0) return XW_E_ARG;
   if (!tpp && !t) return XW_E_ARG;
   if (tpp && L != 1) return XW_E_ARG;
   if (gxv && (ngrad <= 0 || (long)ngrad > (long)N * L || q > XW_QMAX)) return XW_E_ARG;
   if (!disc_width_ok(W)) return xwg_disc_fwd(xT, t, tpp, phi, N, L, d, W, q, v, vt, gxv, gtv, ngrad, act, stream);
+  if (xproj != nullptr && tpp != nullptr) return XW_E_ARG;             // (point mode: every point has its own x)
   const long ntiles = ((long)N * L + 15) / 16;
   long blocks = (ntiles + 3) / 4;
   long cap = max_blocks > 0 ? max_blocks : 512;   // default: 2 blocks per CU resident (launch bounds), grid-stride over tiles
@@ -1212,11 +1272,11 @@ extern "C" int xw_disc_fwd(const double* xT, const double* t, const double* tpp,
     queue = qbase + (size_t)slot * ((XW_DISC_NQ + 1) * XW_DISC_QSTRIDE);
   }
   static const bool vin_on = [] { const char* e = getenv("XW_DISC_VIN_LDS"); return !(e && e[0] == '0'); }();
-  const int vks = !vin_on ? 0 : ((d + 3) / 4 <= XW_VIN_KS ? XW_VIN_KS : XW_VIN_KS_WIDE);
+  const int vks = xproj != nullptr ? -1 : !vin_on ? 0 : ((d + 3) / 4 <= XW_VIN_KS ? XW_VIN_KS : XW_VIN_KS_WIDE);
 #define XW_DISC_FWD2(W_, ACT_, DYN_, VIN_)                                                                                \
   hipLaunchKernelGGL((k_disc_fwd<W_, ACT_, DYN_, VIN_>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, xT, t,  \
-                     tpp, phi, N, L, d, q, v, vt, gxv, gtv, ngrad, act, queue)
-#define XW_DISC_FWD(W_, ACT_, DYN_) do { if (vks == XW_VIN_KS) XW_DISC_FWD2(W_, ACT_, DYN_, XW_VIN_KS); else if (vks) XW_DISC_FWD2(W_, ACT_, DYN_, XW_VIN_KS_WIDE); else XW_DISC_FWD2(W_, ACT_, DYN_, 0); } while (0)
+                     tpp, phi, N, L, d, q, v, vt, gxv, gtv, ngrad, act, queue, xproj)
+#define XW_DISC_FWD(W_, ACT_, DYN_) do { if (vks < 0) XW_DISC_FWD2(W_, ACT_, DYN_, -1); else if (vks == XW_VIN_KS) XW_DISC_FWD2(W_, ACT_, DYN_, XW_VIN_KS); else if (vks) XW_DISC_FWD2(W_, ACT_, DYN_, XW_VIN_KS_WIDE); else XW_DISC_FWD2(W_, ACT_, DYN_, 0); } while (0)
 #define XW_DISC_FWD_W(W_)                                                                                                 \
   if (act != nullptr) {                                                                                                   \
     if (dyn) XW_DISC_FWD(W_, true, true); else XW_DISC_FWD(W_, true, false);                                              \

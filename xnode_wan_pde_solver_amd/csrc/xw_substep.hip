@@ -51,8 +51,9 @@ int test_net(const XwGroup* g, const XwSolverState* s, int blocks, double* recor
   if (g->tpp != nullptr)
     return xw_disc_fwd(g->xvT_pts, nullptr, g->tpp, s->phi, g->N * g->L, 1, g->d, s->W, s->q, g->v, g->vt, g->gxv, g->gtv, g->N, blocks,
                        record, stream);
-  return xw_disc_fwd(g->xvT, g->t, nullptr, s->phi, g->N, g->L, g->d, s->W, s->q, g->v, g->vt, g->gxv, g->gtv, g->N, blocks, record,
-                     stream);
+  if (g->xproj != nullptr) XW_TRY(xw_disc_xproj(g->xvT, s->phi, g->N, g->d, s->W, g->xproj, stream));
+  return xw_disc_fwd_xproj(g->xvT, g->t, nullptr, s->phi, g->N, g->L, g->d, s->W, s->q, g->v, g->vt, g->gxv, g->gtv, g->N, blocks, record,
+                           g->xproj, stream);
 }
 // I, sum v^2, SSE_init (+ finalize: loss values and the optimiser's counter -- one process, the sums are global)
 int contract(const XwGroup* g, const XwSolverState* s, long long* step, bool with_bdry, bool finalize, void* stream) {

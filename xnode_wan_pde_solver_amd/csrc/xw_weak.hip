@@ -584,7 +584,7 @@ extern "C" int xw_slab_sum(const double* gslab, int nslab, int P, int accumulate
   return xw_launch_status();
 }
 
-extern "C" int xw_abi_version(void) { return 30; }
+extern "C" int xw_abi_version(void) { return 31; }
 extern "C" int xw_reduce_work_size(void) { return 6 * 1024 + 8; }
 
 extern "C" int xw_supported_dims(char* buf, int buflen) {

@@ -187,6 +187,11 @@ class Engine:
                                                        'v_phi (v_hidden_dim %d)' % self.W), self.generic) if g_)
             warnings.warn('%s is wider than the MFMA kernel instantiations %s / %s: running on the generic vector-ALU path, expect a step '
                           'rate lower by two to three orders of magnitude' % (which, KN.ODE_WIDTHS, KN.DISC_WIDTHS), RuntimeWarning, stacklevel=3)
+        # the test network's input layer: spatial columns once per path (xw_disc_xproj) -- the MFMA widths, paths over a shared grid
+        # XW_XPROJ_MIN_D: from which d on.  In the sub-step cycle the split form wins from d ~ 45 on and not below, at 131072 points as at
+        # a million (profiles/r05_xproj.txt: headline d = 20 0.488 against 0.473 ms per sub-step -- the small launch is one more dependent
+        # node on the critical chain --, d = 20 at 16384 x 64 3.41 against 3.38; d = 50 -1.3 %, BASELINE configs[2] -2.7 %, [3] -6.5 %).
+        self.xproj_min_d = 1 << 30 if self.generic[1] else int(os.environ.get('XW_XPROJ_MIN_D', '45'))
         if self.generic[0] and self.adjoint:
             raise XnwanError('adjoint=True (the continuous adjoint) exists for the MFMA stepper instantiations %s only; u_hidden_dim = %d, '
                              'u_hidden_hidden_dim = %d run on the generic path, which reverses the steps taken (adjoint=False)'
@@ -795,6 +800,8 @@ class Engine:
                 plan.append(('act_b', (max(Lb - 1, 1), ar, KN.ode_act_cols(Nb))))
         if keep_v:
             plan.append(('vact', (KN.disc_act_rows(self.W, self.q), KN.disc_act_cols(L * N))))
+        if N and d >= self.xproj_min_d:
+            plan.append(('xproj', (64, N)))                    # Vin[:, 1..d] x + Vin.b per path (_launch_test_net_here)
         if Nb:
             plan += [('ub', (Lb, Nb)), ('Yb', (Lb, H, Nb))]
         lazy, off = {}, 0
@@ -950,8 +957,11 @@ class Engine:
             KN.disc_fwd(G.xvT_pts, None, ph, self.W, self.q, tpp=G.tpp, v=G.v.view(1, -1), vt=G.vt.view(1, -1),
                         gxv=G.gxv, gtv=G.gtv, ngrad=G.N, max_blocks=blocks, act=act)
         else:
+            # (the input layer's spatial columns do not move along a vertical path: applied once per path by a small launch in
+            #  front, csrc/xw_disc.hip k_disc_xproj -- the main launch then loads its row of that table instead of x)
+            xp = KN.disc_xproj(G.xvT, ph, self.W, out=G.xproj) if 'xproj' in G._lazy else None
             KN.disc_fwd(G.xvT, G.t, ph, self.W, self.q, v=G.v, vt=G.vt, gxv=G.gxv, gtv=G.gtv, ngrad=G.N,
-                        max_blocks=blocks, act=act)
+                        max_blocks=blocks, act=act, xproj=xp)
 
     def _reaction(self, G):
         """c(u, t, x): linear fast path, or the user's callable differentiated by autograd (not graph-capturable)"""
@@ -1032,7 +1042,7 @@ class Engine:
             xg.ns_u, xg.ns_b = G.ns_u, G.ns_b
             for k in ('xT', 'xvT', 'xbT', 't', 'tb', 'tpp', 'xvT_pts', 'start', 'start_b', 'h', 'href', 'f', 'g', 'w', 'wt', 'w0', 'ghT',
                       'gwx0T', 'A0', 'B0', 'u', 'Y', 'act', 'act_b', 'v', 'vt', 'gxv', 'gtv', 'gx', 'gs', 'vbar', 's3x', 'vact',
-                      'slabA', 'slabB', 'slab_v', 'work_i', 'work_b', 'ub', 'Yb'):
+                      'xproj', 'slabA', 'slabB', 'slab_v', 'work_i', 'work_b', 'ub', 'Yb'):
                 setattr(xg, k, G.ptr(k))         # (addresses only: the work buffers' tensor views are made when Python reads them)
             nar = lambda jobs, **kw: self._narrow_ok(jobs, **kw)  # noqa: E731
             ji, jb = self._job(G, 'i'), (self._job(G, 'b') if G.Nb else None)

@@ -275,10 +275,23 @@ def disc_act_cols(P):
     return (P + 15) // 16 * 16
 
 
-def disc_fwd(xT, t, phi, W, q, tpp=None, want_vt=True, v=None, vt=None, gxv=None, gtv=None, ngrad=0, max_blocks=0, act=None):
+def disc_xproj(xT, phi, W, out=None):
+    """the input layer's x-projection per path, [64, N] (rows >= W zero): Vin[:, 1..d] x_n + Vin.b -- for disc_fwd(xproj=...)."""
+    _need_gpu()
+    d, N = xT.shape
+    _chk(xT, F64, (d, N), 'xT'); _chk(phi, F64, (phi_size(d, W),), 'phi')
+    out = torch.empty(64, N, dtype=F64, device=xT.device) if out is None else out
+    _chk(out, F64, (64, N), 'xproj')
+    check(lib.xw_disc_xproj(_p(xT), _p(phi), N, d, W, _p(out), _stream()), 'xw_disc_xproj')
+    return out
+
+
+def disc_fwd(xT, t, phi, W, q, tpp=None, want_vt=True, v=None, vt=None, gxv=None, gtv=None, ngrad=0, max_blocks=0, act=None,
+             xproj=None):
     """v_phi and dv/dt.  Path mode: points (t[l], x_n) -> [L,N].  Point mode (tpp[N]): points (tpp[n], x_n) -> [1,N].
     gxv[d,ngrad] / gtv[ngrad]: also return the input gradient of v at the leading ngrad points (time-major order).
-    act[disc_act_rows(W, q), disc_act_cols(L*N)]: also store the layer inputs, for disc_bwd(act=...)."""
+    act[disc_act_rows(W, q), disc_act_cols(L*N)]: also store the layer inputs, for disc_bwd(act=...).
+    xproj[64,N] (path mode, widths 50 / 64): disc_xproj's table -- the input layer then costs one load per row and point."""
     _need_gpu()
     d, N = xT.shape
     L = 1 if tpp is not None else t.shape[0]
@@ -292,8 +305,10 @@ def disc_fwd(xT, t, phi, W, q, tpp=None, want_vt=True, v=None, vt=None, gxv=None
         _chk(gxv, F64, (d, ngrad), 'gxv'); _chk(gtv, F64, (ngrad,), 'gtv')
     if act is not None:
         _chk(act, F64, (disc_act_rows(W, q), disc_act_cols(L * N)), 'act')
-    check(lib.xw_disc_fwd(_p(xT), _p(t), _p(tpp), _p(phi), N, L, d, W, q, _p(v), _p(vt if want_vt else None), _p(gxv), _p(gtv),
-                          int(ngrad), int(max_blocks), _p(act), _stream()), 'xw_disc_fwd')
+    if xproj is not None:
+        _chk(xproj, F64, (64, N), 'xproj')
+    check(lib.xw_disc_fwd_xproj(_p(xT), _p(t), _p(tpp), _p(phi), N, L, d, W, q, _p(v), _p(vt if want_vt else None), _p(gxv),
+                                _p(gtv), int(ngrad), int(max_blocks), _p(act), _p(xproj), _stream()), 'xw_disc_fwd')
     return v, (vt if want_vt else None)
 
 
