@@ -1,6 +1,6 @@
 # configs[2] and configs[3] of BASELINE.json at their STATED global batch on ONE GPU, and their 1/8 shares (profiles/r04_lines/)
 set -e
-O=gpurun_out/r04_lines; mkdir -p $O
+O=gpurun_out/${XW_ROUND:-r04}_lines; mkdir -p $O
 B="python bench.py --no-cpu-baseline --train-iters 0 --gpus 1"
 $B --dim 50 --n_t 64 --global-paths 16384  > $O/cfg2_d50_16384x64_1gpu.json   2> $O/cfg2.log
 $B --dim 100 --global-paths 65536          > $O/cfg3_d100_65536x32_1gpu.json  2> $O/cfg3.log
