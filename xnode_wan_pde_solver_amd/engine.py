@@ -284,6 +284,8 @@ class Engine:
         # the headline size everything narrow LOSES (0.502 -> 0.586 ms): those phases are bound by the sum of SIMD time.
         self.narrow_set = os.environ.get('XW_NARROW_SET', 'fx')
         self.narrow_tiles = {'f': 192, 'x': 128, 'p': 64}    # largest launch (16-path tiles, all its jobs) that still gains
+        if os.environ.get('XW_NARROW_TILES'):                # (measurements: "f:x:p")
+            self.narrow_tiles = dict(zip('fxp', (int(v_) for v_ in os.environ['XW_NARROW_TILES'].split(':'))))
         self.simds = 4 * cus
         self._phi_version = 0
         self.streams, self._cap = _device_streams(device)
