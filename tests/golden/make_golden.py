@@ -10,6 +10,7 @@ Round-4 fixtures, one option each (reference CPU time on this container's 8 core
         --traj-ball-solvers       ref_traj_hourglass_ex43_d3_euler_seed7, ref_traj_cone_ex43_d3_rk4_seed8: 40 outer iterations each    2 min
         --general                 ref_general_d4_midpoint: general a_ij, b_i, c(u,t,x) (general_funcs.py)                               seconds
         --shapes                  ref_wide_d6_midpoint, ref_narrow_d3_euler, ref_m1_d4_rk4: other network shapes                        seconds
+        --generic                 ref_generic_d5_midpoint, ref_generic_d3_rk4, ref_generic_mixed_d4_euler: widths of the generic path   seconds
 (general b_i: the reference's `np.sum(list of tensors)` goes through shim 2 below, i.e. Python's sum over the list.)
 
 What this is: test infrastructure.  It imports the reference implementation from
@@ -569,6 +570,8 @@ if __name__ == '__main__':
     ap.add_argument('--traj-hourglass', action='store_true', help='only the hourglass trajectory fixture (round 3, second ball domain)')
     ap.add_argument('--shapes', action='store_true', help='round 4: one outer iteration of the reference at three other network shapes')
     ap.add_argument('--general', action='store_true', help='round 4: one outer iteration of the reference with general a_ij, b_i, c(u,t,x)')
+    ap.add_argument('--generic', action='store_true', help='round 5: one outer iteration of the reference at network widths beyond the '
+                    'MFMA kernel instantiations (the generic path of csrc/xw_generic.hip)')
     ap.add_argument('--traj-cfg5', action='store_true', help='round 4: 8 outer iterations of the reference\'s own train() on both ball '
                     'domains at BASELINE config 5 size (Ex4_3, d = 10, N_r = N_b = 8192, N_t = 20)')
     ap.add_argument('--traj-ball-solvers', action='store_true', help='round 4: 40 outer iterations of the reference\'s own train() on the ball '
@@ -581,6 +584,15 @@ if __name__ == '__main__':
     torch.set_num_threads(4)
     if args.general:
         one_iteration('ref_general_d4_midpoint', 4, 83, 45, 9, 5, 'midpoint', True, general=True, alpha=1000.0)
+        sys.exit(0)
+    if args.generic:
+        # wider than the stepper's (32, 12) and the test network's 64: what csrc/xw_generic.hip serves (up to (64, 16) / 128)
+        one_iteration('ref_generic_d5_midpoint', 5, 48, 28, 6, 11, 'midpoint', True,
+                      net=dict(u_hidden_dim=48, u_hidden_hidden_dim=16, u_layers=4, v_hidden_dim=100, v_layers=3))
+        one_iteration('ref_generic_d3_rk4', 3, 36, 20, 5, 12, 'rk4', True,
+                      net=dict(u_hidden_dim=64, u_hidden_hidden_dim=16, u_layers=2, v_hidden_dim=128, v_layers=2))
+        one_iteration('ref_generic_mixed_d4_euler', 4, 40, 24, 5, 13, 'euler', True,
+                      net=dict(u_hidden_dim=20, u_hidden_hidden_dim=10, u_layers=8, v_hidden_dim=70, v_layers=9))
         sys.exit(0)
     if args.shapes:
         # the widest / deepest networks the engine compiles (stepper container (32, 12), depth 10; test network width 64), a

@@ -31,7 +31,10 @@ CASES = ['ref_tiny_midpoint', 'ref_tiny_euler', 'ref_tiny_rk4', 'ref_plumb_midpo
          # other network shapes, run by the reference itself (round 4): the widest / deepest the engine compiles -- (32, 12) field of
          # depth 10, test network 64 wide --, an odd narrow pair (7, 3) / 11 zero-padded inside the (20, 10) / 50 containers (euler),
          # and a field without hidden layer (u_layers = 1) with a 57-wide, 12-deep test network (rk4)
-         'ref_wide_d6_midpoint', 'ref_narrow_d3_euler', 'ref_m1_d4_rk4']
+         'ref_wide_d6_midpoint', 'ref_narrow_d3_euler', 'ref_m1_d4_rk4',
+         # round 5: widths beyond the MFMA kernel instantiations, run by the reference itself -- (48, 16) / 100, (64, 16) / 128 (the
+         # limits of csrc/xw_generic.hip) and the reference's own field next to a 70-wide test network (MFMA stepper + generic test net)
+         'ref_generic_d5_midpoint', 'ref_generic_d3_rk4', 'ref_generic_mixed_d4_euler']
 FUNCS = dict(h=P.func_h, f=P.func_f, g=P.func_g, a=P.func_a, b=P.func_b, c=P.func_c)
 
 
