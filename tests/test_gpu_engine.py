@@ -955,6 +955,56 @@ def test_pipelined_training_loop_leaves_exactly_what_the_synchronous_one_does(tm
                                rtol=1e-9)
 
 
+@pytest.mark.parametrize('domain', ['Hypercube', 'NSphere_TCone'])
+def test_stop_hook_taken_saves_the_weights_of_that_moment_and_leaves(tmp_path, domain):
+    """src/training.py:142-146: the moment `stop` returns True the generator's weights go to <path>best_model_weights_NODE.pth
+    and the process exits (solver.exit_on_stop = False: train() returns instead).  Cube (captured sub-steps, served hook
+    tensor) and a ball domain (group runner): the loss list ends with the sub-iteration whose hook fired, the file holds the
+    parameters of that moment -- one generator sub-iteration after the previous one, no discriminator sub-step in between --
+    and nothing of the interrupted outer iteration's later files exists."""
+    params = {'alpha': 1e6, 'u_layers': 8, 'u_hidden_dim': 20, 'u_hidden_hidden_dim': 10, 'v_layers': 9, 'v_hidden_dim': 50,
+              'n1': 2, 'n2': 1, 'u_rate': 0.015, 'v_rate': 0.04, 'min_steps': 5, 'adjoint': False, 'solver': 'midpoint',
+              'dim': 3, 'N_t': 7, 'N_r': 150, 'N_b': 90, 'T0': 0, 'T': 1, 'iterations': 6, 'domain': domain,
+              'shape_param': [-1, 1] if domain == 'Hypercube' else 1.0}
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        calls = []
+
+        def fifth(solver, pts, dom):
+            calls.append(solver.engine.theta.data.clone())
+            return len(calls) == 5                      # (outer iteration 2, first generator sub-iteration)
+
+        out = str(tmp_path) + os.sep + 'run_'
+        from src.training import NODE_WAN_solver
+        torch.manual_seed(2)
+        np.random.seed(2)
+        S = NODE_WAN_solver(params, P.func_a, P.func_b, P.func_c, P.func_h, P.func_f, P.func_g, torch.device('cuda'), out,
+                            stop=fifth, func_u_sol=P.func_u_sol, p=2)
+        S.exit_on_stop = False
+        losses = list(S.train(report=False))
+        torch.cuda.synchronize()
+        assert len(calls) == 5 and len(losses) == 5 and all(np.isfinite(losses))
+        saved = torch.load(out + 'best_model_weights_NODE.pth')
+        assert list(saved.keys()) == list(S.u_net.state_dict().keys())
+        for k_, v_ in S.u_net.state_dict().items():
+            assert torch.equal(saved[k_].cpu(), v_.cpu()), k_
+        assert torch.equal(S.engine.theta.data, calls[4]) and not torch.equal(calls[4], calls[3])
+        assert json.load(open('losses_NODE_3.json')) == losses
+        assert len(json.load(open('Time_NODE_3.json'))) == 3         # (start + two complete outer iterations before the one that stopped)
+        # the reference leaves the process: the default does too
+        calls.clear()
+        torch.manual_seed(2)
+        np.random.seed(2)
+        S2 = NODE_WAN_solver(params, P.func_a, P.func_b, P.func_c, P.func_h, P.func_f, P.func_g, torch.device('cuda'), out,
+                             stop=fifth, func_u_sol=P.func_u_sol, p=2)
+        with pytest.raises(SystemExit):
+            S2.train(report=False)
+        assert len(calls) == 5 and torch.equal(calls[4], S.engine.theta.data)
+    finally:
+        os.chdir(cwd)
+
+
 @pytest.mark.parametrize('case', ['ref_traj_cone_ex43_d3_seed0', 'ref_traj_hourglass_ex43_d3_seed1',
                                   'ref_traj_cone_ex43_d10_full_seed2', 'ref_traj_hourglass_ex43_d10_full_seed3',
                                   'ref_traj_hourglass_ex43_d3_euler_seed7', 'ref_traj_cone_ex43_d3_rk4_seed8'])
