@@ -10,6 +10,7 @@ Round-4 fixtures, one option each (reference CPU time on this container's 8 core
         --traj-ball-solvers       ref_traj_hourglass_ex43_d3_euler_seed7, ref_traj_cone_ex43_d3_rk4_seed8: 40 outer iterations each    2 min
         --general                 ref_general_d4_midpoint: general a_ij, b_i, c(u,t,x) (general_funcs.py)                               seconds
         --shapes                  ref_wide_d6_midpoint, ref_narrow_d3_euler, ref_m1_d4_rk4: other network shapes                        seconds
+        --proj                    ref_proj: what the reference's proj() saves (three slices)                                            seconds
         --generic                 ref_generic_d5_midpoint, ref_generic_d3_rk4, ref_generic_mixed_d4_euler: widths of the generic path   seconds
 (general b_i: the reference's `np.sum(list of tensors)` goes through shim 2 below, i.e. Python's sum over the list.)
 
@@ -540,6 +541,37 @@ def bound_pad_hourglass_vectors():
     print('wrote ref_boundpad_hourglass.npz', k, 'cases', [tuple(out['%d/u' % i].shape) for i in range(k)])
 
 
+def proj_vectors():
+    """round 5: the reference's own plotting helper (utils/auxillary_funcs.py:34-98) on a freshly initialised solver: the two arrays
+    it saves (guess_cn.npy, error_cn.npy) for a (t, x_1) slice -- a path tensor over the plot's own time grid -- and for an
+    (x_1, x_2) slice at the fixed time T, where every row starts off T0 (bound_pad / fillt inside u_net)."""
+    training, dataset, lossmod, F = load_reference()
+    aux = sys.modules['utils.auxillary_funcs']
+    d = 3
+    params = make_params(d, 8, 12, 6, 'midpoint')
+    torch.manual_seed(9)
+    np.random.seed(9)
+    S = training.NODE_WAN_solver(params, F.func_a, F.func_b, F.func_c, F.func_h, F.func_f, F.func_g, torch.device('cpu'), './',
+                                 func_u_sol=F.func_u_sol, p=2)
+    out = {'params_json': np.array(json.dumps(params)), 'seed': np.array(9)}
+    cwd = os.getcwd()
+    tmp = tempfile.mkdtemp(prefix='proj_')
+    os.chdir(tmp)
+    try:
+        for k, axes in enumerate(([0, 1], [1, 2], [0, 3])):
+            aux.proj(S.u_net, S.setup, 7, torch.device('cpu'), axes=list(axes), resolution=12, colours=6, save=True, show=False,
+                     func_u_sol=F.func_u_sol)
+            out['%d/axes' % k] = np.array(axes)
+            out['%d/guess' % k] = np.load('guess_cn.npy')
+            out['%d/error' % k] = np.load('error_cn.npy')
+            assert os.path.exists('plot_at_7_along_' + str(list(axes)) + '.png')
+        out['n'] = np.array(3)
+    finally:
+        os.chdir(cwd)
+    np.savez_compressed(os.path.join(HERE, 'ref_proj.npz'), **out)
+    print('wrote ref_proj.npz', [tuple(out['%d/guess' % i].shape) for i in range(3)])
+
+
 def fillt_vectors():
     """src/dataset.py:13-32 on a few hand-picked time vectors (the helper has surprising edge behaviour that the
     product reproduces verbatim: it can drop a sample and return indices past the filled vector)."""
@@ -570,6 +602,7 @@ if __name__ == '__main__':
     ap.add_argument('--traj-hourglass', action='store_true', help='only the hourglass trajectory fixture (round 3, second ball domain)')
     ap.add_argument('--shapes', action='store_true', help='round 4: one outer iteration of the reference at three other network shapes')
     ap.add_argument('--general', action='store_true', help='round 4: one outer iteration of the reference with general a_ij, b_i, c(u,t,x)')
+    ap.add_argument('--proj', action='store_true', help='round 5: the arrays the reference\'s proj() saves on a freshly initialised solver')
     ap.add_argument('--generic', action='store_true', help='round 5: one outer iteration of the reference at network widths beyond the '
                     'MFMA kernel instantiations (the generic path of csrc/xw_generic.hip)')
     ap.add_argument('--traj-cfg5', action='store_true', help='round 4: 8 outer iterations of the reference\'s own train() on both ball '
@@ -584,6 +617,9 @@ if __name__ == '__main__':
     torch.set_num_threads(4)
     if args.general:
         one_iteration('ref_general_d4_midpoint', 4, 83, 45, 9, 5, 'midpoint', True, general=True, alpha=1000.0)
+        sys.exit(0)
+    if args.proj:
+        proj_vectors()
         sys.exit(0)
     if args.generic:
         # wider than the stepper's (32, 12) and the test network's 64: what csrc/xw_generic.hip serves (up to (64, 16) / 128)

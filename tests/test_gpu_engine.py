@@ -644,6 +644,26 @@ def test_evaluation_off_the_boundary_matches_reference(golden_dir):
         close(u, z['%d/u' % k], F32TOL, F32TOL, 'case %d' % k)
 
 
+def test_proj_saves_what_the_reference_saves(golden_dir, tmp_path):
+    """utils.auxillary_funcs.proj (reference :34-98, the evaluation path's plotting helper): guess_cn.npy / error_cn.npy and the
+    picture for a (t, x_1) slice, an (x_1, x_2) slice at the fixed time T (every row starts off T0: bound_pad / fillt inside
+    u_net) and a (t, x_3) slice -- against the arrays the reference's own proj() saved for the same initial weights"""
+    from utils.auxillary_funcs import proj
+    z, params = load(golden_dir, 'ref_proj')
+    S = make_solver(params, int(z['seed']))
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        for k in range(int(z['n'])):
+            axes = [int(a) for a in z['%d/axes' % k]]
+            proj(S.u_net, S.setup, 7, S.device, axes=axes, resolution=12, colours=6, save=True, show=False, func_u_sol=P.func_u_sol)
+            close(np.load('guess_cn.npy'), z['%d/guess' % k], F32TOL, F32TOL, 'guess along %s' % axes)
+            close(np.load('error_cn.npy'), z['%d/error' % k], F32TOL, 10 * F32TOL, 'error along %s' % axes)
+            assert os.path.getsize('plot_at_7_along_' + str(axes) + '.png') > 1000
+    finally:
+        os.chdir(cwd)
+
+
 def test_evaluation_off_the_boundary_on_the_hourglass_matches_reference(golden_dir):
     """the per-path padded grids of NSphere_THourglass.bound_pad (src/dataset.py:127-152): buckets by grid length, every
     bucket on the grid of its first path, results ordered bucket by bucket -- on the inputs the reference survives"""
