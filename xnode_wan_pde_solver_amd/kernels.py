@@ -22,6 +22,7 @@ def _need_gpu():
 # Everything reachable from user code -- the module call surface, the custom operators, the first launch of every captured
 # graph -- stays checked.
 TRUSTED = False
+LONE_NARROW = __import__('os').environ.get('XW_LONE_NARROW', '1') == '1'     # (ode_fwd below)
 
 
 def _chk(t, dtype, shape, name):
@@ -119,6 +120,15 @@ def ode_fwd(xT, t, start, theta, method, H, K, m, want_Y=True, u=None, Y=None):
     if Y is None and want_Y:
         Y = torch.empty(L, H, N, dtype=F64, device=xT.device)
     _chk(u, F64, (L, N), 'u'); _chk(Y, F64, (L, H, N), 'Y')
+    if Y is None and LONE_NARROW and (N + 15) // 16 <= 256 and (H, K) in ODE_WIDTHS:
+        # an evaluation on its own (the diagnostic, a stop hook, Engine.predict) has the chip to itself: up to 256 tiles the narrow
+        # layout -- four waves of 4 paths per tile, every SIMD busy -- ends sooner (57 against 73 us at 4096 paths x 32 times,
+        # 109 against 143 at 64 times; beyond 256 tiles it loses: tools/lone_forward.py).  Same values to the last bit or two.
+        arr = (XwOdeFwdJob * 1)()
+        a = arr[0]
+        a.xT, a.start, a.u, a.Y, a.act, a.N, a.act_x_only, a.narrow, a.prio_drop = _p(xT), _p(start), _p(u), 0, 0, N, 0, 1, 0
+        check(lib.xw_ode_fwd_multi(arr, 1, _p(t), _p(theta), method, L, d, H, K, m, 0, _stream()), 'xw_ode_fwd_multi')
+        return u, None
     check(lib.xw_ode_fwd(_p(xT), _p(t), _p(start), _p(theta), method, N, L, d, H, K, m, _p(u), _p(Y), _stream()), 'xw_ode_fwd')
     return u, Y
 
