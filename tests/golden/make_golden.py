@@ -271,10 +271,12 @@ def one_iteration(case, d, N_r, N_b, N_t, seed, solver_name, full_tensors, shape
     print('wrote', path, '%.1f KB' % (os.path.getsize(path) / 1024))
 
 
-def trajectory(case, d, N_r, N_b, N_t, seed, outer_iters, gpu_loader_semantics, solver_name='midpoint'):
+def trajectory(case, d, N_r, N_b, N_t, seed, outer_iters, gpu_loader_semantics, solver_name='midpoint', net=None):
     """rel-L2 at every generator sub-step through the reference's own train() loop (stop hook = logging point)."""
     training, dataset, lossmod, F = load_reference()
     params = make_params(d, N_r, N_b, N_t, solver_name, iterations=outer_iters)
+    if net is not None:
+        params.update(net)
     if gpu_loader_semantics:
         orig = dataset.Comb_loader.__getitem__
 
@@ -629,6 +631,9 @@ if __name__ == '__main__':
                       net=dict(u_hidden_dim=64, u_hidden_hidden_dim=16, u_layers=2, v_hidden_dim=128, v_layers=2))
         one_iteration('ref_generic_mixed_d4_euler', 4, 40, 24, 5, 13, 'euler', True,
                       net=dict(u_hidden_dim=20, u_hidden_hidden_dim=10, u_layers=8, v_hidden_dim=70, v_layers=9))
+        # and 25 outer iterations of the reference's own train() at (48, 16) / 100
+        trajectory('ref_traj_generic_d3_seed14', 3, 64, 40, 8, 14, 25, True,
+                   net=dict(u_hidden_dim=48, u_hidden_hidden_dim=16, u_layers=4, v_hidden_dim=100, v_layers=3))
         sys.exit(0)
     if args.shapes:
         # the widest / deepest networks the engine compiles (stepper container (32, 12), depth 10; test network width 64), a

@@ -301,7 +301,9 @@ def test_engine_against_oracle_general_coefficients(m, q, adjoint):
     ('ref_traj_d20_headline_seed4', 500, ((300, 400), (400, 500)), 0.015),
     # the other two fixed-grid schemes at the benchmarked size (30 outer iterations of the reference's own train() each)
     ('ref_traj_d20_headline_euler_seed5', 60, ((20, 40), (40, 60)), 0.4),
-    ('ref_traj_d20_headline_rk4_seed6', 60, ((20, 40), (40, 60)), 0.1)])
+    ('ref_traj_d20_headline_rk4_seed6', 60, ((20, 40), (40, 60)), 0.1),
+    # round 5: 25 outer iterations of the reference's own train() at widths of the generic path -- (48, 16) field, 100-wide test network
+    ('ref_traj_generic_d3_seed14', 50, ((10, 30), (30, 50)), 0.06)])
 def test_trained_error_trajectory_matches_reference(golden_dir, tmp_path, case, steps, windows, reached):
     """BASELINE config 1 (d=5, N_r=256, N_b=64, N_t=16; seed 0, 400 outer iterations = 800 generator sub-steps), the
     headline dimension (d=20, N_r=128, N_b=96, N_t=12; seed 2, 150 outer iterations) and -- round 4 -- BASELINE configs[1] AT THE
@@ -331,7 +333,7 @@ def test_trained_error_trajectory_matches_reference(golden_dir, tmp_path, case, 
     assert got.shape == ref.shape == (steps,)
     # same seeds, same arithmetic: the runs track each other closely before chaotic decorrelation sets in
     np.testing.assert_allclose(got[:50], ref[:50], rtol=2e-3)
-    if case in ('ref_traj_d20_headline_euler_seed5', 'ref_traj_d20_headline_rk4_seed6'):
+    if case in ('ref_traj_d20_headline_euler_seed5', 'ref_traj_d20_headline_rk4_seed6', 'ref_traj_generic_d3_seed14'):
         np.testing.assert_allclose(got, ref, rtol=1e-4)               # (60 logged values: before the decorrelation sets in)
     if case == 'ref_traj_d20_headline_seed4':
         # 4096 paths per sample: the two runs stay together for the first 60 outer iterations (measured: 2e-6 at worst over the
@@ -350,7 +352,8 @@ def test_trained_error_trajectory_matches_reference(golden_dir, tmp_path, case, 
     for fn in ('losses_NODE_%d.json' % d, 'L2_NODE_%d.json' % d, 'Time_NODE_%d.json' % d, 'best_model_weights_NODE.pth'):
         assert (tmp_path / fn).exists(), fn
     sd = torch.load(tmp_path / 'best_model_weights_NODE.pth')
-    assert 'module.ODE_rhs.net.14.weight' in sd and sd['module.final_linear.weight'].shape == (1, 20)
+    assert ('module.ODE_rhs.net.%d.weight' % (2 * (params['u_layers'] - 1))) in sd
+    assert sd['module.final_linear.weight'].shape == (1, params['u_hidden_dim'])
 
 
 @pytest.mark.parametrize('case,name', [('ref_cone_groups', 'NSphere_TCone'), ('ref_hourglass_groups', 'NSphere_THourglass'),
