@@ -10,7 +10,7 @@ Round-4 fixtures, one option each (reference CPU time on this container's 8 core
         --traj-ball-solvers       ref_traj_hourglass_ex43_d3_euler_seed7, ref_traj_cone_ex43_d3_rk4_seed8: 40 outer iterations each    2 min
         --general                 ref_general_d4_midpoint: general a_ij, b_i, c(u,t,x) (general_funcs.py)                               seconds
         --shapes                  ref_wide_d6_midpoint, ref_narrow_d3_euler, ref_m1_d4_rk4: other network shapes                        seconds
-        --proj                    ref_proj: what the reference's proj() saves (three slices)                                            seconds
+        --proj                    ref_proj: what the reference's proj() saves (three slices); ref_stop_taken_d3_seed15: a stop hook that fires                                           seconds
         --generic                 ref_generic_d5_midpoint, ref_generic_d3_rk4, ref_generic_mixed_d4_euler: widths of the generic path   seconds
 (general b_i: the reference's `np.sum(list of tensors)` goes through shim 2 below, i.e. Python's sum over the list.)
 
@@ -543,6 +543,50 @@ def bound_pad_hourglass_vectors():
     print('wrote ref_boundpad_hourglass.npz', k, 'cases', [tuple(out['%d/u' % i].shape) for i in range(k)])
 
 
+def stop_taken(case, d, N_r, N_b, N_t, seed, fire_at):
+    """round 5: the reference's own train() with a `stop` hook that returns True at its `fire_at`-th call (src/training.py:142-146:
+    save the generator's weights under <path>, print, exit()): the loss list it leaves, the weights it saved, the files that exist."""
+    training, dataset, lossmod, F = load_reference()
+    params = make_params(d, N_r, N_b, N_t, 'midpoint', iterations=6)
+    orig = dataset.Comb_loader.__getitem__
+    dataset.Comb_loader.__getitem__ = lambda self, idx: tuple(t.clone() for t in orig(self, idx))   # (.to(device) on a GPU copies)
+    calls = []
+
+    def hook(self, pts, domain):
+        calls.append(1)
+        return len(calls) == fire_at
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    cwd = os.getcwd()
+    scratch = tempfile.mkdtemp(prefix='ref_stop_')
+    os.chdir(scratch)
+    out = {'params_json': np.array(json.dumps(params)), 'seed': np.array(seed), 'fire_at': np.array(fire_at)}
+    try:
+        S = training.NODE_WAN_solver(params, F.func_a, F.func_b, F.func_c, F.func_h, F.func_f, F.func_g, torch.device('cpu'),
+                                     scratch + os.sep + 'run_', func_u_sol=F.func_u_sol, p=2, stop=hook)
+        left = False
+        try:
+            S.train(report=False)
+        except SystemExit:
+            left = True
+        assert left and len(calls) == fire_at
+        out['losses'] = np.array(json.load(open('losses_NODE_%d.json' % d)))
+        out['n_times'] = np.array(len(json.load(open('Time_NODE_%d.json' % d))))
+        out['n_L2'] = np.array(len(json.load(open('L2_NODE_%d.json' % d))))
+        sd = torch.load(scratch + os.sep + 'run_best_model_weights_NODE.pth')
+        out['saved_keys'] = np.array(list(sd.keys()))
+        for k_, v_ in sd.items():
+            out['saved/' + k_] = npy(v_)
+        best = torch.load('best_model_weights_NODE.pth')
+        for k_, v_ in best.items():
+            out['best/' + k_] = npy(v_)
+    finally:
+        os.chdir(cwd)
+        dataset.Comb_loader.__getitem__ = orig
+    np.savez_compressed(os.path.join(HERE, case + '.npz'), **out)
+    print('wrote', case, 'losses', out['losses'])
+
+
 def proj_vectors():
     """round 5: the reference's own plotting helper (utils/auxillary_funcs.py:34-98) on a freshly initialised solver: the two arrays
     it saves (guess_cn.npy, error_cn.npy) for a (t, x_1) slice -- a path tensor over the plot's own time grid -- and for an
@@ -622,6 +666,7 @@ if __name__ == '__main__':
         sys.exit(0)
     if args.proj:
         proj_vectors()
+        stop_taken('ref_stop_taken_d3_seed15', 3, 64, 40, 8, 15, 5)
         sys.exit(0)
     if args.generic:
         # wider than the stepper's (32, 12) and the test network's 64: what csrc/xw_generic.hip serves (up to (64, 16) / 128)

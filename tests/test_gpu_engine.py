@@ -978,6 +978,41 @@ def test_pipelined_training_loop_leaves_exactly_what_the_synchronous_one_does(tm
                                rtol=1e-9)
 
 
+def test_stop_hook_taken_leaves_what_the_reference_leaves(golden_dir, tmp_path):
+    """the reference's own train() with a hook that fires at its fifth call (tests/golden/make_golden.py stop_taken): the loss
+    list on disk, the number of diagnostics / times written before it left, the weights it saved under <path> and the best
+    weights in the working directory -- against this engine's run with the same seed"""
+    z, params = load(golden_dir, 'ref_stop_taken_d3_seed15')
+    fire_at, calls = int(z['fire_at']), []
+
+    def hook(solver, pts, dom):
+        calls.append(1)
+        return len(calls) == fire_at
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        out = str(tmp_path) + os.sep + 'run_'
+        from src.training import NODE_WAN_solver
+        torch.manual_seed(int(z['seed']))
+        np.random.seed(int(z['seed']))
+        S = NODE_WAN_solver(params, P.func_a, P.func_b, P.func_c, P.func_h, P.func_f, P.func_g, torch.device('cuda'), out,
+                            stop=hook, func_u_sol=P.func_u_sol, p=2)
+        S.tabulate_on_host = True
+        with pytest.raises(SystemExit):
+            S.train(report=False)
+        d = params['dim']
+        losses = json.load(open('losses_NODE_%d.json' % d))
+        close(losses, z['losses'], 2e-5, what='loss list')
+        assert len(json.load(open('Time_NODE_%d.json' % d))) == int(z['n_times']) and len(json.load(open('L2_NODE_%d.json' % d))) == int(z['n_L2'])
+        saved, best = torch.load(out + 'best_model_weights_NODE.pth'), torch.load('best_model_weights_NODE.pth')
+        assert list(saved.keys()) == [str(k) for k in z['saved_keys']] == list(best.keys())
+        for k_ in saved:
+            close(saved[k_], z['saved/' + k_], 2e-5, 2e-6, 'saved ' + k_)
+            close(best[k_], z['best/' + k_], 2e-5, 2e-6, 'best ' + k_)
+    finally:
+        os.chdir(cwd)
+
+
 @pytest.mark.parametrize('domain', ['Hypercube', 'NSphere_TCone'])
 def test_stop_hook_taken_saves_the_weights_of_that_moment_and_leaves(tmp_path, domain):
     """src/training.py:142-146: the moment `stop` returns True the generator's weights go to <path>best_model_weights_NODE.pth
