@@ -614,6 +614,16 @@ def proj_vectors():
         out['n'] = np.array(3)
     finally:
         os.chdir(cwd)
+    # the error norms the loop and the configs' stop rule use (utils/auxillary_funcs.py:7-30) at p = 1, 2, 3, on a cube sample
+    # (one tensor) and on a cone sample (a list of groups, weighted by their share of N_r)
+    for tag, shape in (('cube', dataset.Hypercube(params['shape_param'], d, 0, 1, params['N_t'])), ('cone', dataset.NSphere_TCone(1.0, d, 0, 1, params['N_t']))):
+        torch.manual_seed(21)
+        np.random.seed(21)
+        pts = dataset.Comb_loader(40, 24, shape, torch.device('cpu'))
+        for p_ in (1, 2, 3):
+            with torch.no_grad():
+                out['%s/L%d' % (tag, p_)] = npy(aux.L_norm(pts.interioru, S.u_net, p_, F.func_u_sol, shape.V(), 40))
+                out['%s/rel%d' % (tag, p_)] = npy(aux.rel_err(pts.interioru, S.u_net, F.func_u_sol, p_, shape.V(), 40))
     np.savez_compressed(os.path.join(HERE, 'ref_proj.npz'), **out)
     print('wrote ref_proj.npz', [tuple(out['%d/guess' % i].shape) for i in range(3)])
 

@@ -665,6 +665,18 @@ def test_proj_saves_what_the_reference_saves(golden_dir, tmp_path):
             assert os.path.getsize('plot_at_7_along_' + str(axes) + '.png') > 1000
     finally:
         os.chdir(cwd)
+    # L_norm / rel_err (reference utils/auxillary_funcs.py:7-30) at p = 1, 2, 3: one tensor (cube) and a list of groups (cone)
+    from utils.auxillary_funcs import L_norm, rel_err
+    from src.dataset import Comb_loader, Hypercube, NSphere_TCone
+    s_ = S.setup
+    for tag, shape in (('cube', Hypercube(params['shape_param'], s_['dim'], 0, 1, s_['N_t'])), ('cone', NSphere_TCone(1.0, s_['dim'], 0, 1, s_['N_t']))):
+        torch.manual_seed(21)
+        np.random.seed(21)
+        pts = Comb_loader(40, 24, shape, S.device)
+        for p_ in (1, 2, 3):
+            with torch.no_grad():
+                close(L_norm(pts.interioru, S.u_net, p_, P.func_u_sol, shape.V(), 40), float(z['%s/L%d' % (tag, p_)]), 2e-6, what='%s L%d' % (tag, p_))
+                close(rel_err(pts.interioru, S.u_net, P.func_u_sol, p_, shape.V(), 40), float(z['%s/rel%d' % (tag, p_)]), 2e-6, what='%s rel%d' % (tag, p_))
 
 
 def test_evaluation_off_the_boundary_on_the_hourglass_matches_reference(golden_dir):
