@@ -11,6 +11,7 @@ Round-4 fixtures, one option each (reference CPU time on this container's 8 core
         --general                 ref_general_d4_midpoint: general a_ij, b_i, c(u,t,x) (general_funcs.py)                               seconds
         --shapes                  ref_wide_d6_midpoint, ref_narrow_d3_euler, ref_m1_d4_rk4: other network shapes                        seconds
         --proj                    ref_proj: what the reference's proj() saves (three slices); ref_stop_taken_d3_seed15: a stop hook that fires                                           seconds
+        --loops                   ref_traj_n1_3_n2_2_d3_seed16, ref_traj_n1_1_n2_3_d3_seed17, ref_traj_cone_n1_3_n2_2_d3_seed18: other (n1, n2)         seconds
         --generic                 ref_generic_d5_midpoint, ref_generic_d3_rk4, ref_generic_mixed_d4_euler: widths of the generic path   seconds
 (general b_i: the reference's `np.sum(list of tensors)` goes through shim 2 below, i.e. Python's sum over the list.)
 
@@ -426,7 +427,7 @@ def sphere_sampling(case, domain_name, d, N_r, N_b, N_t, seed, radius):
 
 
 def sphere_trajectory(case, domain_name, d, N_r, N_b, N_t, seed, outer_iters, funcs_module='configs.Ex4_3_funcs', alpha=100000000,
-                      solver_name='midpoint'):
+                      solver_name='midpoint', net=None):
     """The reference's own train() on a time-varying ball domain (natural group loop incl. the single-slice groups),
     GPU loader semantics.  Its on-sample diagnostic is unusable on list domains (utils/auxillary_funcs.py:19 broadcasts
     [N,1] - [N] to [N,N] on single-slice groups), so the `stop` hook -- called once per generator sub-iteration,
@@ -436,6 +437,8 @@ def sphere_trajectory(case, domain_name, d, N_r, N_b, N_t, seed, outer_iters, fu
     params = make_params(d, N_r, N_b, N_t, solver_name, iterations=outer_iters, alpha=alpha)
     params['domain'] = domain_name
     params['shape_param'] = 1.0
+    if net is not None:
+        params.update(net)
     if not funcs_module.endswith('Ex4_1_funcs'):
         params['funcs'] = funcs_module.split('.')[-1]
     orig = dataset.Comb_loader.__getitem__
@@ -658,6 +661,7 @@ if __name__ == '__main__':
     ap.add_argument('--traj-hourglass', action='store_true', help='only the hourglass trajectory fixture (round 3, second ball domain)')
     ap.add_argument('--shapes', action='store_true', help='round 4: one outer iteration of the reference at three other network shapes')
     ap.add_argument('--general', action='store_true', help='round 4: one outer iteration of the reference with general a_ij, b_i, c(u,t,x)')
+    ap.add_argument('--loops', action='store_true', help='round 5: the reference\'s train() with other sub-iteration counts (n1, n2) = (3, 2), (1, 3)')
     ap.add_argument('--proj', action='store_true', help='round 5: the arrays the reference\'s proj() saves on a freshly initialised solver')
     ap.add_argument('--generic', action='store_true', help='round 5: one outer iteration of the reference at network widths beyond the '
                     'MFMA kernel instantiations (the generic path of csrc/xw_generic.hip)')
@@ -673,6 +677,13 @@ if __name__ == '__main__':
     torch.set_num_threads(4)
     if args.general:
         one_iteration('ref_general_d4_midpoint', 4, 83, 45, 9, 5, 'midpoint', True, general=True, alpha=1000.0)
+        sys.exit(0)
+    if args.loops:
+        # other sub-iteration counts than the YAML's n1 = 2, n2 = 1 (src/training.py:125,151): several discriminator sub-steps per outer
+        # iteration move phi between them, several generator sub-steps see the same phi
+        trajectory('ref_traj_n1_3_n2_2_d3_seed16', 3, 64, 40, 8, 16, 20, True, net=dict(n1=3, n2=2))
+        trajectory('ref_traj_n1_1_n2_3_d3_seed17', 3, 64, 40, 8, 17, 30, True, net=dict(n1=1, n2=3))
+        sphere_trajectory('ref_traj_cone_n1_3_n2_2_d3_seed18', 'NSphere_TCone', 3, 128, 64, 8, 18, 12, alpha=10000.0, net=dict(n1=3, n2=2))
         sys.exit(0)
     if args.proj:
         proj_vectors()

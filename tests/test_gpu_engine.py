@@ -303,7 +303,10 @@ def test_engine_against_oracle_general_coefficients(m, q, adjoint):
     ('ref_traj_d20_headline_euler_seed5', 60, ((20, 40), (40, 60)), 0.4),
     ('ref_traj_d20_headline_rk4_seed6', 60, ((20, 40), (40, 60)), 0.1),
     # round 5: 25 outer iterations of the reference's own train() at widths of the generic path -- (48, 16) field, 100-wide test network
-    ('ref_traj_generic_d3_seed14', 50, ((10, 30), (30, 50)), 0.06)])
+    ('ref_traj_generic_d3_seed14', 50, ((10, 30), (30, 50)), 0.06),
+    # round 5: other sub-iteration counts than the YAML's (n1, n2) = (2, 1): (3, 2) over 20 outer iterations, (1, 3) over 30
+    ('ref_traj_n1_3_n2_2_d3_seed16', 60, ((20, 40), (40, 60)), 0.08),
+    ('ref_traj_n1_1_n2_3_d3_seed17', 30, ((10, 20), (20, 30)), 0.45)])
 def test_trained_error_trajectory_matches_reference(golden_dir, tmp_path, case, steps, windows, reached):
     """BASELINE config 1 (d=5, N_r=256, N_b=64, N_t=16; seed 0, 400 outer iterations = 800 generator sub-steps), the
     headline dimension (d=20, N_r=128, N_b=96, N_t=12; seed 2, 150 outer iterations) and -- round 4 -- BASELINE configs[1] AT THE
@@ -333,7 +336,8 @@ def test_trained_error_trajectory_matches_reference(golden_dir, tmp_path, case, 
     assert got.shape == ref.shape == (steps,)
     # same seeds, same arithmetic: the runs track each other closely before chaotic decorrelation sets in
     np.testing.assert_allclose(got[:50], ref[:50], rtol=2e-3)
-    if case in ('ref_traj_d20_headline_euler_seed5', 'ref_traj_d20_headline_rk4_seed6', 'ref_traj_generic_d3_seed14'):
+    if case in ('ref_traj_d20_headline_euler_seed5', 'ref_traj_d20_headline_rk4_seed6', 'ref_traj_generic_d3_seed14',
+                'ref_traj_n1_3_n2_2_d3_seed16', 'ref_traj_n1_1_n2_3_d3_seed17'):
         np.testing.assert_allclose(got, ref, rtol=1e-4)               # (60 logged values: before the decorrelation sets in)
     if case == 'ref_traj_d20_headline_seed4':
         # 4096 paths per sample: the two runs stay together for the first 60 outer iterations (measured: 2e-6 at worst over the
@@ -426,7 +430,10 @@ def test_sphere_domain_groups_against_reference_vectors(golden_dir, case, name):
 
 @pytest.mark.parametrize('case,steps', [('ref_traj_cone_ex43_d3_seed0', 200), ('ref_traj_hourglass_ex43_d3_seed1', 120),
                                         ('ref_traj_cone_ex43_d10_full_seed2', 16), ('ref_traj_hourglass_ex43_d10_full_seed3', 16),
-                                        ('ref_traj_hourglass_ex43_d3_euler_seed7', 80), ('ref_traj_cone_ex43_d3_rk4_seed8', 80)])
+                                        ('ref_traj_hourglass_ex43_d3_euler_seed7', 80), ('ref_traj_cone_ex43_d3_rk4_seed8', 80),
+                                        # round 5: n1 = 3, n2 = 2 (12 outer iterations): several discriminator sub-iterations move phi
+                                        # between them, three generator sub-iterations see the same phi
+                                        ('ref_traj_cone_n1_3_n2_2_d3_seed18', 36)])
 def test_ball_domain_training_trajectory_follows_reference(golden_dir, tmp_path, case, steps):
     """BASELINE configs[4] family, through train(): NSphere_TCone (seed 0, 100 outer iterations) and NSphere_THourglass (seed 1,
     60), Ex4_3, d = 3, N_r = 256, N_b = 128, N_t = 10 -- and, round 4, both domains AT THE CONFIG'S STATED SIZE (d = 10,
