@@ -11,6 +11,7 @@ Round-4 fixtures, one option each (reference CPU time on this container's 8 core
         --general                 ref_general_d4_midpoint: general a_ij, b_i, c(u,t,x) (general_funcs.py)                               seconds
         --shapes                  ref_wide_d6_midpoint, ref_narrow_d3_euler, ref_m1_d4_rk4: other network shapes                        seconds
         --proj                    ref_proj: what the reference's proj() saves (three slices); ref_stop_taken_d3_seed15: a stop hook that fires                                           seconds
+        --intervals               ref_interval_d4_midpoint, ref_interval_d3_rk4: other time intervals and cubes                              seconds
         --loops                   ref_traj_n1_3_n2_2_d3_seed16, ref_traj_n1_1_n2_3_d3_seed17, ref_traj_cone_n1_3_n2_2_d3_seed18: other (n1, n2)         seconds
         --generic                 ref_generic_d5_midpoint, ref_generic_d3_rk4, ref_generic_mixed_d4_euler: widths of the generic path   seconds
 (general b_i: the reference's `np.sum(list of tensors)` goes through shim 2 below, i.e. Python's sum over the list.)
@@ -305,8 +306,12 @@ def trajectory(case, d, N_r, N_b, N_t, seed, outer_iters, gpu_loader_semantics, 
         wall = time.time() - t0
         # fixed probe set for the trained u
         g = torch.Generator().manual_seed(12345)
+        bot, top = params['shape_param']
         xp = torch.rand(64, 1, d, generator=g) * 2 - 1
         tp = torch.linspace(0, 1, N_t).view(1, N_t, 1).repeat(64, 1, 1)
+        if (bot, top, params['T0'], params['T']) != (-1, 1, 0, 1):          # (round 5: the probe lives on the run's own interval and cube)
+            xp = bot + (top - bot) * (xp + 1) / 2
+            tp = params['T0'] + (params['T'] - params['T0']) * tp
         probe = torch.cat((tp, xp.repeat(1, N_t, 1)), 2)
         with torch.no_grad():
             up = S.u_net(probe).squeeze(2)
@@ -662,6 +667,7 @@ if __name__ == '__main__':
     ap.add_argument('--shapes', action='store_true', help='round 4: one outer iteration of the reference at three other network shapes')
     ap.add_argument('--general', action='store_true', help='round 4: one outer iteration of the reference with general a_ij, b_i, c(u,t,x)')
     ap.add_argument('--loops', action='store_true', help='round 5: the reference\'s train() with other sub-iteration counts (n1, n2) = (3, 2), (1, 3)')
+    ap.add_argument('--intervals', action='store_true', help='round 5: one outer iteration of the reference on a time interval and a cube other than [0, 1] x [-1, 1]^d')
     ap.add_argument('--proj', action='store_true', help='round 5: the arrays the reference\'s proj() saves on a freshly initialised solver')
     ap.add_argument('--generic', action='store_true', help='round 5: one outer iteration of the reference at network widths beyond the '
                     'MFMA kernel instantiations (the generic path of csrc/xw_generic.hip)')
@@ -677,6 +683,13 @@ if __name__ == '__main__':
     torch.set_num_threads(4)
     if args.general:
         one_iteration('ref_general_d4_midpoint', 4, 83, 45, 9, 5, 'midpoint', True, general=True, alpha=1000.0)
+        sys.exit(0)
+    if args.intervals:
+        # T0 = 0.25, T = 1.5 and the asymmetric cube [-0.5, 1.5]^d (midpoint); T0 = -1, T = 0 on [0, 2]^d (rk4)
+        one_iteration('ref_interval_d4_midpoint', 4, 48, 28, 6, 19, 'midpoint', True, shape_param=[-0.5, 1.5], net=dict(T0=0.25, T=1.5))
+        one_iteration('ref_interval_d3_rk4', 3, 40, 24, 5, 20, 'rk4', True, shape_param=[0.0, 2.0], net=dict(T0=-1.0, T=0.0))
+        # and 15 outer iterations of the reference's own train() there (the compact cube sample, its weight kernel, the refill graph)
+        trajectory('ref_traj_interval_d3_seed21', 3, 64, 40, 8, 21, 15, True, net=dict(T0=0.25, T=1.5, shape_param=[-0.5, 1.5]))
         sys.exit(0)
     if args.loops:
         # other sub-iteration counts than the YAML's n1 = 2, n2 = 1 (src/training.py:125,151): several discriminator sub-steps per outer

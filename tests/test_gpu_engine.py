@@ -34,7 +34,9 @@ CASES = ['ref_tiny_midpoint', 'ref_tiny_euler', 'ref_tiny_rk4', 'ref_plumb_midpo
          'ref_wide_d6_midpoint', 'ref_narrow_d3_euler', 'ref_m1_d4_rk4',
          # round 5: widths beyond the MFMA kernel instantiations, run by the reference itself -- (48, 16) / 100, (64, 16) / 128 (the
          # limits of csrc/xw_generic.hip) and the reference's own field next to a 70-wide test network (MFMA stepper + generic test net)
-         'ref_generic_d5_midpoint', 'ref_generic_d3_rk4', 'ref_generic_mixed_d4_euler']
+         'ref_generic_d5_midpoint', 'ref_generic_d3_rk4', 'ref_generic_mixed_d4_euler',
+         # round 5: other time intervals and cubes -- [0.25, 1.5] x [-0.5, 1.5]^4 (midpoint), [-1, 0] x [0, 2]^3 (rk4)
+         'ref_interval_d4_midpoint', 'ref_interval_d3_rk4']
 FUNCS = dict(h=P.func_h, f=P.func_f, g=P.func_g, a=P.func_a, b=P.func_b, c=P.func_c)
 
 
@@ -306,7 +308,9 @@ def test_engine_against_oracle_general_coefficients(m, q, adjoint):
     ('ref_traj_generic_d3_seed14', 50, ((10, 30), (30, 50)), 0.06),
     # round 5: other sub-iteration counts than the YAML's (n1, n2) = (2, 1): (3, 2) over 20 outer iterations, (1, 3) over 30
     ('ref_traj_n1_3_n2_2_d3_seed16', 60, ((20, 40), (40, 60)), 0.08),
-    ('ref_traj_n1_1_n2_3_d3_seed17', 30, ((10, 20), (20, 30)), 0.45)])
+    ('ref_traj_n1_1_n2_3_d3_seed17', 30, ((10, 20), (20, 30)), 0.45),
+    # round 5: [0.25, 1.5] x [-0.5, 1.5]^3, 15 outer iterations
+    ('ref_traj_interval_d3_seed21', 30, ((10, 20), (20, 30)), 0.2)])
 def test_trained_error_trajectory_matches_reference(golden_dir, tmp_path, case, steps, windows, reached):
     """BASELINE config 1 (d=5, N_r=256, N_b=64, N_t=16; seed 0, 400 outer iterations = 800 generator sub-steps), the
     headline dimension (d=20, N_r=128, N_b=96, N_t=12; seed 2, 150 outer iterations) and -- round 4 -- BASELINE configs[1] AT THE
@@ -337,7 +341,7 @@ def test_trained_error_trajectory_matches_reference(golden_dir, tmp_path, case, 
     # same seeds, same arithmetic: the runs track each other closely before chaotic decorrelation sets in
     np.testing.assert_allclose(got[:50], ref[:50], rtol=2e-3)
     if case in ('ref_traj_d20_headline_euler_seed5', 'ref_traj_d20_headline_rk4_seed6', 'ref_traj_generic_d3_seed14',
-                'ref_traj_n1_3_n2_2_d3_seed16', 'ref_traj_n1_1_n2_3_d3_seed17'):
+                'ref_traj_n1_3_n2_2_d3_seed16', 'ref_traj_n1_1_n2_3_d3_seed17', 'ref_traj_interval_d3_seed21'):
         np.testing.assert_allclose(got, ref, rtol=1e-4)               # (60 logged values: before the decorrelation sets in)
     if case == 'ref_traj_d20_headline_seed4':
         # 4096 paths per sample: the two runs stay together for the first 60 outer iterations (measured: 2e-6 at worst over the
