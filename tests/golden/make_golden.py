@@ -326,7 +326,7 @@ def trajectory(case, d, N_r, N_b, N_t, seed, outer_iters, gpu_loader_semantics, 
     print('wrote', path, 'steps', len(log), 'wall %.1fs' % wall, 'final rel-L2', log[-1])
 
 
-def sphere_groups(case, domain_name, d, N_r, N_b, N_t, seed, funcs_module='configs.Ex4_1_funcs'):
+def sphere_groups(case, domain_name, d, N_r, N_b, N_t, seed, funcs_module='configs.Ex4_1_funcs', radius=1.0):
     """Time-varying ball domains (src/dataset.py:48-229): the sampled groups themselves, then one generator
     sub-iteration, one more, and one discriminator sub-iteration with the reference's own modules over EXACTLY the
     (interior, v, boundary) triples its training loop visits -- `for (datau, datav, bdata) in points`
@@ -339,7 +339,7 @@ def sphere_groups(case, domain_name, d, N_r, N_b, N_t, seed, funcs_module='confi
     training, dataset, lossmod, F = load_reference(funcs_module, d)
     params = make_params(d, N_r, N_b, N_t, 'midpoint')
     params['domain'] = domain_name
-    params['shape_param'] = 1.0
+    params['shape_param'] = radius
     if not funcs_module.endswith('Ex4_1_funcs'):
         params['funcs'] = funcs_module.split('.')[-1]      # (read back by the tests to pick the callables)
     dev = torch.device('cpu')
@@ -690,6 +690,11 @@ if __name__ == '__main__':
         one_iteration('ref_interval_d3_rk4', 3, 40, 24, 5, 20, 'rk4', True, shape_param=[0.0, 2.0], net=dict(T0=-1.0, T=0.0))
         # and 15 outer iterations of the reference's own train() there (the compact cube sample, its weight kernel, the refill graph)
         trajectory('ref_traj_interval_d3_seed21', 3, 64, 40, 8, 21, 15, True, net=dict(T0=0.25, T=1.5, shape_param=[-0.5, 1.5]))
+        # the ball domains at radius 0.7 (10 outer iterations each)
+        # one sample at radius 0.7 whose last visited boundary group is ONE path on one time slice (seed 101), group by group
+        sphere_groups('ref_cone_r07_groups', 'NSphere_TCone', 3, 128, 64, 8, 101, 'configs.Ex4_3_funcs', radius=0.7)
+        sphere_trajectory('ref_traj_cone_r07_d3_seed22', 'NSphere_TCone', 3, 128, 64, 8, 22, 10, alpha=10000.0, net=dict(shape_param=0.7))
+        sphere_trajectory('ref_traj_hourglass_r07_d3_seed23', 'NSphere_THourglass', 3, 128, 64, 8, 23, 10, alpha=10000.0, net=dict(shape_param=0.7))
         sys.exit(0)
     if args.loops:
         # other sub-iteration counts than the YAML's n1 = 2, n2 = 1 (src/training.py:125,151): several discriminator sub-steps per outer

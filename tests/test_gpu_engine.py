@@ -366,7 +366,8 @@ def test_trained_error_trajectory_matches_reference(golden_dir, tmp_path, case, 
 
 @pytest.mark.parametrize('case,name', [('ref_cone_groups', 'NSphere_TCone'), ('ref_hourglass_groups', 'NSphere_THourglass'),
                                        ('ref_cone_ex43_d10_groups', 'NSphere_TCone'),
-                                       ('ref_hourglass_ex43_d10_groups', 'NSphere_THourglass')])
+                                       ('ref_hourglass_ex43_d10_groups', 'NSphere_THourglass'),
+                                       ('ref_cone_r07_groups', 'NSphere_TCone')])     # (round 5: radius 0.7, a one-path boundary group)
 def test_sphere_domain_groups_against_reference_vectors(golden_dir, case, name):
     """time-varying ball domains (BASELINE config 5 family): float64 groups of different lengths, late-entry groups that
     start on the moving boundary (g start values), time-dependent weight w, single-time boundary groups, and the
@@ -437,7 +438,9 @@ def test_sphere_domain_groups_against_reference_vectors(golden_dir, case, name):
                                         ('ref_traj_hourglass_ex43_d3_euler_seed7', 80), ('ref_traj_cone_ex43_d3_rk4_seed8', 80),
                                         # round 5: n1 = 3, n2 = 2 (12 outer iterations): several discriminator sub-iterations move phi
                                         # between them, three generator sub-iterations see the same phi
-                                        ('ref_traj_cone_n1_3_n2_2_d3_seed18', 36)])
+                                        ('ref_traj_cone_n1_3_n2_2_d3_seed18', 36),
+                                        # round 5: radius 0.7, 10 outer iterations each
+                                        ('ref_traj_cone_r07_d3_seed22', 20), ('ref_traj_hourglass_r07_d3_seed23', 20)])
 def test_ball_domain_training_trajectory_follows_reference(golden_dir, tmp_path, case, steps):
     """BASELINE configs[4] family, through train(): NSphere_TCone (seed 0, 100 outer iterations) and NSphere_THourglass (seed 1,
     60), Ex4_3, d = 3, N_r = 256, N_b = 128, N_t = 10 -- and, round 4, both domains AT THE CONFIG'S STATED SIZE (d = 10,
@@ -476,7 +479,11 @@ def test_ball_domain_training_trajectory_follows_reference(golden_dir, tmp_path,
     # runs do not decorrelate over these 100 outer iterations (~2400 optimiser steps over all groups): measured on the
     # MI355X 1.8e-9 relative at worst.  North-star criterion (trained error within 1e-2 absolute of the reference's on the
     # same seeds): holds at EVERY logged sub-iteration, not only at the end.
-    np.testing.assert_allclose(got, ref, rtol=1e-6)
+    # (radius 0.7, seed 22: this run is ill-conditioned from its fourth outer iteration on -- the engine against ITSELF with the narrow
+    #  tiles off, a change of summation order only, is 3e-15 / 2e-11 / 9e-6 apart at logged values 0 / 4 / 6 and 4e-5 later, exactly
+    #  the engine's distance from the reference there: tools/traj_r07_sensitivity.py -- so that fixture is followed to 2e-4)
+    np.testing.assert_allclose(got, ref, rtol=2e-4 if case == 'ref_traj_cone_r07_d3_seed22' else 1e-6)
+    np.testing.assert_allclose(got[:4], ref[:4], rtol=1e-7)
     assert np.abs(got - ref).max() < 1e-2
     late = min(20, steps // 2)
     assert got[late:].min() > 1.0 and ref[late:].min() > 1.0      # (the run the reference produces here does not converge)
