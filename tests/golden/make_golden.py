@@ -326,7 +326,7 @@ def trajectory(case, d, N_r, N_b, N_t, seed, outer_iters, gpu_loader_semantics, 
     print('wrote', path, 'steps', len(log), 'wall %.1fs' % wall, 'final rel-L2', log[-1])
 
 
-def sphere_groups(case, domain_name, d, N_r, N_b, N_t, seed, funcs_module='configs.Ex4_1_funcs', radius=1.0):
+def sphere_groups(case, domain_name, d, N_r, N_b, N_t, seed, funcs_module='configs.Ex4_1_funcs', radius=1.0, net=None):
     """Time-varying ball domains (src/dataset.py:48-229): the sampled groups themselves, then one generator
     sub-iteration, one more, and one discriminator sub-iteration with the reference's own modules over EXACTLY the
     (interior, v, boundary) triples its training loop visits -- `for (datau, datav, bdata) in points`
@@ -342,6 +342,8 @@ def sphere_groups(case, domain_name, d, N_r, N_b, N_t, seed, funcs_module='confi
     params['shape_param'] = radius
     if not funcs_module.endswith('Ex4_1_funcs'):
         params['funcs'] = funcs_module.split('.')[-1]      # (read back by the tests to pick the callables)
+    if net is not None:
+        params.update(net)
     dev = torch.device('cpu')
     torch.manual_seed(seed)
     np.random.seed(seed)
@@ -693,6 +695,8 @@ if __name__ == '__main__':
         # the ball domains at radius 0.7 (10 outer iterations each)
         # one sample at radius 0.7 whose last visited boundary group is ONE path on one time slice (seed 101), group by group
         sphere_groups('ref_cone_r07_groups', 'NSphere_TCone', 3, 128, 64, 8, 101, 'configs.Ex4_3_funcs', radius=0.7)
+        # (the ball domains on another time interval are not a configuration the reference survives: T = 1.4 asks its cone sampler for a
+        #  negative number of points, src/dataset.py:180,203-214, and T0 = 0.1 sends its single-slice groups into an IndexError, src/model.py:106)
         sphere_trajectory('ref_traj_cone_r07_d3_seed22', 'NSphere_TCone', 3, 128, 64, 8, 22, 10, alpha=10000.0, net=dict(shape_param=0.7))
         sphere_trajectory('ref_traj_hourglass_r07_d3_seed23', 'NSphere_THourglass', 3, 128, 64, 8, 23, 10, alpha=10000.0, net=dict(shape_param=0.7))
         sys.exit(0)
