@@ -509,8 +509,10 @@ def group_forward(theta, phi, config, setup, domain, funcs, X, XV, BX, need_boun
     d = setup['dim']
     h, f, g = funcs['h'](Xd[:, 0, :]), funcs['f'](Xd), funcs['g'](BXd)        # :25-27
     c_s = funcs['c'](Xd, u_s)                                                 # :29
-    a = torch.stack([torch.stack([funcs['a'](Xd, i, j) for j in range(d)], 0) for i in range(d)], 0)
-    b = torch.stack([funcs['b'](Xd, i) for i in range(d)], 0)
+    # (the tables are torch.Tensor(...) = FLOAT32 whatever the sample's dtype, src/training.py:32,37: on the float64 samples of the
+    #  ball domains a general a_ij / b_i is rounded to float32 there)
+    a = torch.stack([torch.stack([funcs['a'](Xd, i, j) for j in range(d)], 0) for i in range(d)], 0).to(torch.float32)
+    b = torch.stack([funcs['b'](Xd, i) for i in range(d)], 0).to(torch.float32)
     w = domain.func_w(XVl)
     th_keys = [k for k, p in theta.items() if p.requires_grad]
     ph_keys = [k for k, p in phi.items() if p.requires_grad]

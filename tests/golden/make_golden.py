@@ -326,7 +326,7 @@ def trajectory(case, d, N_r, N_b, N_t, seed, outer_iters, gpu_loader_semantics, 
     print('wrote', path, 'steps', len(log), 'wall %.1fs' % wall, 'final rel-L2', log[-1])
 
 
-def sphere_groups(case, domain_name, d, N_r, N_b, N_t, seed, funcs_module='configs.Ex4_1_funcs', radius=1.0, net=None):
+def sphere_groups(case, domain_name, d, N_r, N_b, N_t, seed, funcs_module='configs.Ex4_1_funcs', radius=1.0, net=None, general_ac=False):
     """Time-varying ball domains (src/dataset.py:48-229): the sampled groups themselves, then one generator
     sub-iteration, one more, and one discriminator sub-iteration with the reference's own modules over EXACTLY the
     (interior, v, boundary) triples its training loop visits -- `for (datau, datav, bdata) in points`
@@ -344,6 +344,16 @@ def sphere_groups(case, domain_name, d, N_r, N_b, N_t, seed, funcs_module='confi
         params['funcs'] = funcs_module.split('.')[-1]      # (read back by the tests to pick the callables)
     if net is not None:
         params.update(net)
+    if general_ac:
+        # round 5: a general diffusion tensor a_ij(t, x) and a non-linear reaction c(u, t, x) (tests/golden/general_funcs.py) on a list
+        # domain; b stays zero -- on the single-slice groups the reference sums the b-term with np.sum over a list of [N, N] tensors
+        # (src/loss.py:69), which does not mean the same thing on every numpy
+        import types
+        sys.path.insert(0, HERE)
+        import general_funcs as GF
+        F = types.SimpleNamespace(func_a=GF.func_a, func_b=F.func_b, func_c=GF.func_c, func_h=F.func_h, func_f=F.func_f,
+                                  func_g=F.func_g, func_u_sol=F.func_u_sol)
+        params['funcs'] = params.get('funcs', 'Ex4_1_funcs') + '+general_ac'
     dev = torch.device('cpu')
     torch.manual_seed(seed)
     np.random.seed(seed)
@@ -697,6 +707,9 @@ if __name__ == '__main__':
         sphere_groups('ref_cone_r07_groups', 'NSphere_TCone', 3, 128, 64, 8, 101, 'configs.Ex4_3_funcs', radius=0.7)
         # (the ball domains on another time interval are not a configuration the reference survives: T = 1.4 asks its cone sampler for a
         #  negative number of points, src/dataset.py:180,203-214, and T0 = 0.1 sends its single-slice groups into an IndexError, src/model.py:106)
+        # general a_ij, c(u, t, x) on both ball domains (one sample each, group by group)
+        sphere_groups('ref_cone_general_groups', 'NSphere_TCone', 3, 64, 40, 8, 26, 'configs.Ex4_3_funcs', general_ac=True)
+        sphere_groups('ref_hourglass_general_groups', 'NSphere_THourglass', 3, 64, 40, 8, 27, 'configs.Ex4_3_funcs', general_ac=True)
         sphere_trajectory('ref_traj_cone_r07_d3_seed22', 'NSphere_TCone', 3, 128, 64, 8, 22, 10, alpha=10000.0, net=dict(shape_param=0.7))
         sphere_trajectory('ref_traj_hourglass_r07_d3_seed23', 'NSphere_THourglass', 3, 128, 64, 8, 23, 10, alpha=10000.0, net=dict(shape_param=0.7))
         sys.exit(0)

@@ -367,7 +367,9 @@ def test_trained_error_trajectory_matches_reference(golden_dir, tmp_path, case, 
 @pytest.mark.parametrize('case,name', [('ref_cone_groups', 'NSphere_TCone'), ('ref_hourglass_groups', 'NSphere_THourglass'),
                                        ('ref_cone_ex43_d10_groups', 'NSphere_TCone'),
                                        ('ref_hourglass_ex43_d10_groups', 'NSphere_THourglass'),
-                                       ('ref_cone_r07_groups', 'NSphere_TCone')])     # (round 5: radius 0.7, a one-path boundary group)
+                                       ('ref_cone_r07_groups', 'NSphere_TCone'),      # (round 5: radius 0.7, a one-path boundary group)
+                                       # round 5: general a_ij(t, x), c(u, t, x) on the list domains
+                                       ('ref_cone_general_groups', 'NSphere_TCone'), ('ref_hourglass_general_groups', 'NSphere_THourglass')])
 def test_sphere_domain_groups_against_reference_vectors(golden_dir, case, name):
     """time-varying ball domains (BASELINE config 5 family): float64 groups of different lengths, late-entry groups that
     start on the moving boundary (g start values), time-dependent weight w, single-time boundary groups, and the
@@ -378,8 +380,17 @@ def test_sphere_domain_groups_against_reference_vectors(golden_dir, case, name):
     # the last two cases are BASELINE configs[4]: the Ex4_3 problem (configs/Ex4_3_funcs.py:6-49 of the reference: every
     # coordinate enters u_sol, c = -u) at d = 10, recorded from the reference with its own Ex4_3 callables
     F = P
-    if params.pop('funcs', 'Ex4_1_funcs') == 'Ex4_3_funcs':
+    fname = params.pop('funcs', 'Ex4_1_funcs')
+    if fname.startswith('Ex4_3_funcs'):
         import configs.Ex4_3_funcs as F
+    if fname.endswith('+general_ac'):        # (round 5: general a_ij(t, x) and c(u, t, x), b = 0 -- tests/golden/general_funcs.py)
+        import importlib.util
+        import types
+        spec = importlib.util.spec_from_file_location('general_funcs', os.path.join(golden_dir, 'general_funcs.py'))
+        GF = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(GF)
+        F = types.SimpleNamespace(func_a=GF.func_a, func_b=F.func_b, func_c=GF.func_c, func_h=F.func_h, func_f=F.func_f, func_g=F.func_g,
+                                  func_u_sol=F.func_u_sol)
     assert params['domain'] == name
     S = make_solver(params, int(z['seed']), F=F)
     s = S.setup

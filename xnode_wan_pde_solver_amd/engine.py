@@ -314,17 +314,17 @@ class Engine:
             jj = torch.arange(d, device=X1.device).view(1, d, 1, 1)
             out = fa(X1.unsqueeze(0).unsqueeze(0), ii, jj)
             if torch.is_tensor(out) and tuple(out.shape) == (d, d, N, 1):
-                A = out[..., 0].to(dev).to(F64)
+                A = out[..., 0].to(dev).to(F32).to(F64)       # (the reference's table is float32: src/training.py:32)
                 g = torch.Generator().manual_seed(d * 7919 + N)
                 for _ in range(3):
                     i, j = (int(k) for k in torch.randint(0, d, (2,), generator=g))
-                    if not torch.equal(A[i, j], fa(X1, i, j).to(dev).to(F64)[:, 0]):
+                    if not torch.equal(A[i, j], fa(X1, i, j).to(dev).to(F32).to(F64)[:, 0]):
                         A = None
                         break
         except Exception:               # the callable branches on (i, j) in Python, indexes with them, ...: scalar calls
             A = None
         if A is None:
-            A = torch.stack([torch.stack([fa(X1, i, j).to(dev).to(F64)[:, 0] for j in range(d)], 0) for i in range(d)], 0)
+            A = torch.stack([torch.stack([fa(X1, i, j).to(dev).to(F32).to(F64)[:, 0] for j in range(d)], 0) for i in range(d)], 0)
         off = A.clone()
         off.diagonal(dim1=0, dim2=1).zero_()
         if bool(torch.all(A == A[:, :, :1])):
@@ -339,12 +339,12 @@ class Engine:
         try:
             out = fb(X1.unsqueeze(0), torch.arange(d, device=X1.device).view(d, 1, 1))
             if torch.is_tensor(out) and tuple(out.shape) == (d, N, 1):
-                B = out[..., 0].to(dev).to(F64)
-                if all(torch.equal(B[i], fb(X1, i).to(dev).to(F64)[:, 0]) for i in (0, d // 2, d - 1)):
+                B = out[..., 0].to(dev).to(F32).to(F64)       # (float32 table: src/training.py:37)
+                if all(torch.equal(B[i], fb(X1, i).to(dev).to(F32).to(F64)[:, 0]) for i in (0, d // 2, d - 1)):
                     return B.contiguous()
         except Exception:
             pass
-        return torch.stack([fb(X1, i).to(dev).to(F64)[:, 0] for i in range(d)], 0).contiguous()
+        return torch.stack([fb(X1, i).to(dev).to(F32).to(F64)[:, 0] for i in range(d)], 0).contiguous()
 
     def _check_structure(self, X, version):
         """The fused fast paths (a = identity, b = 0, c = kappa u) were chosen from a probe on random points
@@ -968,7 +968,31 @@ class Engine:
     def _reaction(self, G):
         """c(u, t, x): linear fast path, or the user's callable differentiated by autograd (not graph-capturable)"""
         ck = self.structure.c_kappa
-        if ck is None:
+        if ck is None and G.pair_i:
+            # single-slice group at T0: the reference hands its callable u as [N, 1] there (src/model.py:89-91), not [N, 1, 1], and takes
+            # `c.squeeze() * u.squeeze() * phi.squeeze()` summed over ALL its entries (src/loss.py:70).  A callable that mixes u with a
+            # slice of X that kept its last axis ([N, 1, 1]) thereby returns the TABLE c[m, n] = c(u_n, x_m): per path n the term is
+            # sum_m c[m, n] u_n phi_n = N mean_m c[m, n] u_n phi_n -- the N is the one every term of such a group carries (s3_scale)
+            N = G.N
+            ul = G.u.t().detach().requires_grad_(True)                           # [N, 1]
+            with torch.enable_grad():
+                c = self.funcs['c'](G.X, ul)
+                c = c.reshape(N, N) if c.numel() == N * N and N > 1 else c.reshape(-1)
+                if c.dim() == 2:
+                    if getattr(G, 'sharded', False):
+                        raise XnwanError('func_c returns a table over all pairs of paths on a single-slice group (it mixes u [N, 1] with a slice of X that '
+                                         'kept its last axis): that needs every path of the group on one rank -- run such groups replicated '
+                                         '(XW_REPLICATE_BELOW >= their size) or on one GPU')
+                    c = c.mean(0)
+                elif c.numel() != N:
+                    raise XnwanError('func_c on a single-slice group returned %d values for %d paths' % (c.numel(), N))
+                cp = torch.autograd.grad(c.sum(), ul)[0] if c.requires_grad else torch.zeros_like(ul)
+            if G.c is None:
+                G.c, G.cp = torch.empty_like(G.u), torch.empty_like(G.u)
+            G.c.copy_(c.detach().reshape(1, N))
+            G.cp.copy_(cp.detach().reshape(1, N))
+            ck = 0.0
+        elif ck is None:
             ul = G.u.t().unsqueeze(2).detach().requires_grad_(True)
             with torch.enable_grad():
                 c = self.funcs['c'](G.X, ul)
