@@ -11,6 +11,7 @@ Round-4 fixtures, one option each (reference CPU time on this container's 8 core
         --general                 ref_general_d4_midpoint: general a_ij, b_i, c(u,t,x) (general_funcs.py)                               seconds
         --shapes                  ref_wide_d6_midpoint, ref_narrow_d3_euler, ref_m1_d4_rk4: other network shapes                        seconds
         --proj                    ref_proj: what the reference's proj() saves (three slices); ref_stop_taken_d3_seed15: a stop hook that fires                                           seconds
+        --alpha1                  ref_alpha1_*: alpha = 1 (cube midpoint / rk4 / general euler; cone, hourglass, hourglass general)                 seconds
         --intervals               ref_interval_d4_midpoint, ref_interval_d3_rk4: other time intervals and cubes                              seconds
         --loops                   ref_traj_n1_3_n2_2_d3_seed16, ref_traj_n1_1_n2_3_d3_seed17, ref_traj_cone_n1_3_n2_2_d3_seed18: other (n1, n2)         seconds
         --generic                 ref_generic_d5_midpoint, ref_generic_d3_rk4, ref_generic_mixed_d4_euler: widths of the generic path   seconds
@@ -679,6 +680,7 @@ if __name__ == '__main__':
     ap.add_argument('--shapes', action='store_true', help='round 4: one outer iteration of the reference at three other network shapes')
     ap.add_argument('--general', action='store_true', help='round 4: one outer iteration of the reference with general a_ij, b_i, c(u,t,x)')
     ap.add_argument('--loops', action='store_true', help='round 5: the reference\'s train() with other sub-iteration counts (n1, n2) = (3, 2), (1, 3)')
+    ap.add_argument('--alpha1', action='store_true', help='round 5: penalty weight alpha = 1 -- the interior loss term is not hidden behind alpha x penalties in the generator sub-steps')
     ap.add_argument('--intervals', action='store_true', help='round 5: one outer iteration of the reference on a time interval and a cube other than [0, 1] x [-1, 1]^d')
     ap.add_argument('--proj', action='store_true', help='round 5: the arrays the reference\'s proj() saves on a freshly initialised solver')
     ap.add_argument('--generic', action='store_true', help='round 5: one outer iteration of the reference at network widths beyond the '
@@ -695,6 +697,16 @@ if __name__ == '__main__':
     torch.set_num_threads(4)
     if args.general:
         one_iteration('ref_general_d4_midpoint', 4, 83, 45, 9, 5, 'midpoint', True, general=True, alpha=1000.0)
+        sys.exit(0)
+    if args.alpha1:
+        # every other fixture runs at alpha = 1e3 .. 1e8, where the generator's gradient is alpha x (penalty gradients) + a part in 1e3 .. 1e8
+        # of d log(I^2)/d theta: with alpha = 1 that part IS the gradient
+        one_iteration('ref_alpha1_d4_midpoint', 4, 48, 28, 6, 28, 'midpoint', True, alpha=1.0)
+        one_iteration('ref_alpha1_d3_rk4', 3, 40, 24, 5, 29, 'rk4', True, alpha=1.0)
+        one_iteration('ref_alpha1_general_d4_euler', 4, 48, 28, 6, 30, 'euler', True, general=True, alpha=1.0)
+        sphere_groups('ref_cone_alpha1_groups', 'NSphere_TCone', 3, 64, 40, 8, 31, 'configs.Ex4_3_funcs', net=dict(alpha=1.0))
+        sphere_groups('ref_hourglass_alpha1_groups', 'NSphere_THourglass', 3, 64, 40, 8, 32, 'configs.Ex4_3_funcs', net=dict(alpha=1.0))
+        sphere_groups('ref_hourglass_alpha1_general_groups', 'NSphere_THourglass', 3, 64, 40, 8, 33, 'configs.Ex4_3_funcs', net=dict(alpha=1.0), general_ac=True)
         sys.exit(0)
     if args.intervals:
         # T0 = 0.25, T = 1.5 and the asymmetric cube [-0.5, 1.5]^d (midpoint); T0 = -1, T = 0 on [0, 2]^d (rk4)

@@ -36,7 +36,9 @@ CASES = ['ref_tiny_midpoint', 'ref_tiny_euler', 'ref_tiny_rk4', 'ref_plumb_midpo
          # limits of csrc/xw_generic.hip) and the reference's own field next to a 70-wide test network (MFMA stepper + generic test net)
          'ref_generic_d5_midpoint', 'ref_generic_d3_rk4', 'ref_generic_mixed_d4_euler',
          # round 5: other time intervals and cubes -- [0.25, 1.5] x [-0.5, 1.5]^4 (midpoint), [-1, 0] x [0, 2]^3 (rk4)
-         'ref_interval_d4_midpoint', 'ref_interval_d3_rk4']
+         'ref_interval_d4_midpoint', 'ref_interval_d3_rk4',
+         # round 5: alpha = 1 -- the interior term's gradient is not hidden behind alpha x penalties in the generator sub-steps
+         'ref_alpha1_d4_midpoint', 'ref_alpha1_d3_rk4', 'ref_alpha1_general_d4_euler']
 FUNCS = dict(h=P.func_h, f=P.func_f, g=P.func_g, a=P.func_a, b=P.func_b, c=P.func_c)
 
 
@@ -369,7 +371,10 @@ def test_trained_error_trajectory_matches_reference(golden_dir, tmp_path, case, 
                                        ('ref_hourglass_ex43_d10_groups', 'NSphere_THourglass'),
                                        ('ref_cone_r07_groups', 'NSphere_TCone'),      # (round 5: radius 0.7, a one-path boundary group)
                                        # round 5: general a_ij(t, x), c(u, t, x) on the list domains
-                                       ('ref_cone_general_groups', 'NSphere_TCone'), ('ref_hourglass_general_groups', 'NSphere_THourglass')])
+                                       ('ref_cone_general_groups', 'NSphere_TCone'), ('ref_hourglass_general_groups', 'NSphere_THourglass'),
+                                       # round 5: alpha = 1
+                                       ('ref_cone_alpha1_groups', 'NSphere_TCone'), ('ref_hourglass_alpha1_groups', 'NSphere_THourglass'),
+                                       ('ref_hourglass_alpha1_general_groups', 'NSphere_THourglass')])
 def test_sphere_domain_groups_against_reference_vectors(golden_dir, case, name):
     """time-varying ball domains (BASELINE config 5 family): float64 groups of different lengths, late-entry groups that
     start on the moving boundary (g start values), time-dependent weight w, single-time boundary groups, and the
