@@ -704,6 +704,9 @@ if __name__ == '__main__':
         one_iteration('ref_alpha1_d4_midpoint', 4, 48, 28, 6, 28, 'midpoint', True, alpha=1.0)
         one_iteration('ref_alpha1_d3_rk4', 3, 40, 24, 5, 29, 'rk4', True, alpha=1.0)
         one_iteration('ref_alpha1_general_d4_euler', 4, 48, 28, 6, 30, 'euler', True, general=True, alpha=1.0)
+        # the smallest legal shapes: d = 2 (Ex4_1 needs x_1, x_2), two sample times (one step), seven paths; and N_t = 3 with rk4
+        one_iteration('ref_min_d2_nt2_midpoint', 2, 7, 5, 2, 34, 'midpoint', True, alpha=1.0)
+        one_iteration('ref_min_d2_nt3_rk4', 2, 17, 33, 3, 35, 'rk4', True, alpha=100.0)
         sphere_groups('ref_cone_alpha1_groups', 'NSphere_TCone', 3, 64, 40, 8, 31, 'configs.Ex4_3_funcs', net=dict(alpha=1.0))
         sphere_groups('ref_hourglass_alpha1_groups', 'NSphere_THourglass', 3, 64, 40, 8, 32, 'configs.Ex4_3_funcs', net=dict(alpha=1.0))
         sphere_groups('ref_hourglass_alpha1_general_groups', 'NSphere_THourglass', 3, 64, 40, 8, 33, 'configs.Ex4_3_funcs', net=dict(alpha=1.0), general_ac=True)

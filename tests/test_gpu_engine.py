@@ -38,7 +38,9 @@ CASES = ['ref_tiny_midpoint', 'ref_tiny_euler', 'ref_tiny_rk4', 'ref_plumb_midpo
          # round 5: other time intervals and cubes -- [0.25, 1.5] x [-0.5, 1.5]^4 (midpoint), [-1, 0] x [0, 2]^3 (rk4)
          'ref_interval_d4_midpoint', 'ref_interval_d3_rk4',
          # round 5: alpha = 1 -- the interior term's gradient is not hidden behind alpha x penalties in the generator sub-steps
-         'ref_alpha1_d4_midpoint', 'ref_alpha1_d3_rk4', 'ref_alpha1_general_d4_euler']
+         'ref_alpha1_d4_midpoint', 'ref_alpha1_d3_rk4', 'ref_alpha1_general_d4_euler',
+         # round 5: the smallest shapes -- d = 2, two sample times (ONE step), 7 interior / 5 boundary paths; N_t = 3 with rk4
+         'ref_min_d2_nt2_midpoint', 'ref_min_d2_nt3_rk4']
 FUNCS = dict(h=P.func_h, f=P.func_f, g=P.func_g, a=P.func_a, b=P.func_b, c=P.func_c)
 
 
