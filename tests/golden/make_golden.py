@@ -274,12 +274,19 @@ def one_iteration(case, d, N_r, N_b, N_t, seed, solver_name, full_tensors, shape
     print('wrote', path, '%.1f KB' % (os.path.getsize(path) / 1024))
 
 
-def trajectory(case, d, N_r, N_b, N_t, seed, outer_iters, gpu_loader_semantics, solver_name='midpoint', net=None):
+def trajectory(case, d, N_r, N_b, N_t, seed, outer_iters, gpu_loader_semantics, solver_name='midpoint', net=None, general=False):
     """rel-L2 at every generator sub-step through the reference's own train() loop (stop hook = logging point)."""
     training, dataset, lossmod, F = load_reference()
     params = make_params(d, N_r, N_b, N_t, solver_name, iterations=outer_iters)
     if net is not None:
         params.update(net)
+    if general:                                    # (round 5: tests/golden/general_funcs.py in place of Ex4_1's a, b, c)
+        import types
+        sys.path.insert(0, HERE)
+        import general_funcs as GF
+        F = types.SimpleNamespace(func_a=GF.func_a, func_b=GF.func_b, func_c=GF.func_c, func_h=F.func_h, func_f=F.func_f,
+                                  func_g=F.func_g, func_u_sol=F.func_u_sol)
+        params['funcs'] = 'general_v1'
     if gpu_loader_semantics:
         orig = dataset.Comb_loader.__getitem__
 
@@ -445,7 +452,7 @@ def sphere_sampling(case, domain_name, d, N_r, N_b, N_t, seed, radius):
 
 
 def sphere_trajectory(case, domain_name, d, N_r, N_b, N_t, seed, outer_iters, funcs_module='configs.Ex4_3_funcs', alpha=100000000,
-                      solver_name='midpoint', net=None):
+                      solver_name='midpoint', net=None, general_ac=False):
     """The reference's own train() on a time-varying ball domain (natural group loop incl. the single-slice groups),
     GPU loader semantics.  Its on-sample diagnostic is unusable on list domains (utils/auxillary_funcs.py:19 broadcasts
     [N,1] - [N] to [N,N] on single-slice groups), so the `stop` hook -- called once per generator sub-iteration,
@@ -459,6 +466,13 @@ def sphere_trajectory(case, domain_name, d, N_r, N_b, N_t, seed, outer_iters, fu
         params.update(net)
     if not funcs_module.endswith('Ex4_1_funcs'):
         params['funcs'] = funcs_module.split('.')[-1]
+    if general_ac:                                 # (as sphere_groups: general a_ij, c(u, t, x); b stays zero)
+        import types
+        sys.path.insert(0, HERE)
+        import general_funcs as GF
+        F = types.SimpleNamespace(func_a=GF.func_a, func_b=F.func_b, func_c=GF.func_c, func_h=F.func_h, func_f=F.func_f,
+                                  func_g=F.func_g, func_u_sol=F.func_u_sol)
+        params['funcs'] = params.get('funcs', 'Ex4_1_funcs') + '+general_ac'
     orig = dataset.Comb_loader.__getitem__
 
     def getitem(self, idx):
@@ -707,6 +721,11 @@ if __name__ == '__main__':
         # the smallest legal shapes: d = 2 (Ex4_1 needs x_1, x_2), two sample times (one step), seven paths; and N_t = 3 with rk4
         one_iteration('ref_min_d2_nt2_midpoint', 2, 7, 5, 2, 34, 'midpoint', True, alpha=1.0)
         one_iteration('ref_min_d2_nt3_rk4', 2, 17, 33, 3, 35, 'rk4', True, alpha=100.0)
+        # general coefficients through the reference's own train(): cube (a, b, c general; 20 outer iterations, alpha = 1e3), cone and hourglass
+        # (a, c general; 8 outer iterations, alpha = 1e2)
+        trajectory('ref_traj_general_d3_seed36', 3, 64, 40, 8, 36, 20, True, net=dict(alpha=1000.0), general=True)
+        sphere_trajectory('ref_traj_cone_general_d3_seed37', 'NSphere_TCone', 3, 128, 64, 8, 37, 8, alpha=100.0, general_ac=True)
+        sphere_trajectory('ref_traj_hourglass_general_d3_seed38', 'NSphere_THourglass', 3, 128, 64, 8, 38, 8, alpha=100.0, general_ac=True)
         sphere_groups('ref_cone_alpha1_groups', 'NSphere_TCone', 3, 64, 40, 8, 31, 'configs.Ex4_3_funcs', net=dict(alpha=1.0))
         sphere_groups('ref_hourglass_alpha1_groups', 'NSphere_THourglass', 3, 64, 40, 8, 32, 'configs.Ex4_3_funcs', net=dict(alpha=1.0))
         sphere_groups('ref_hourglass_alpha1_general_groups', 'NSphere_THourglass', 3, 64, 40, 8, 33, 'configs.Ex4_3_funcs', net=dict(alpha=1.0), general_ac=True)

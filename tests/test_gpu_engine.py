@@ -57,6 +57,17 @@ def make_solver(params, seed, F=P, **kw):
                            func_u_sol=F.func_u_sol, p=2, **kw)
 
 
+def _general_funcs(golden_dir, base, with_b):
+    """tests/golden/general_funcs.py (the callables the general-coefficient fixtures were recorded with) over `base`'s h, f, g"""
+    import importlib.util
+    import types
+    spec = importlib.util.spec_from_file_location('general_funcs', os.path.join(golden_dir, 'general_funcs.py'))
+    GF = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(GF)
+    return types.SimpleNamespace(func_a=GF.func_a, func_b=GF.func_b if with_b else base.func_b, func_c=GF.func_c, func_h=base.func_h,
+                                 func_f=base.func_f, func_g=base.func_g, func_u_sol=base.func_u_sol)
+
+
 def _np(x):
     return x.detach().cpu().double().numpy() if torch.is_tensor(x) else np.asarray(x, dtype=np.float64)
 
@@ -314,7 +325,9 @@ def test_engine_against_oracle_general_coefficients(m, q, adjoint):
     ('ref_traj_n1_3_n2_2_d3_seed16', 60, ((20, 40), (40, 60)), 0.08),
     ('ref_traj_n1_1_n2_3_d3_seed17', 30, ((10, 20), (20, 30)), 0.45),
     # round 5: [0.25, 1.5] x [-0.5, 1.5]^3, 15 outer iterations
-    ('ref_traj_interval_d3_seed21', 30, ((10, 20), (20, 30)), 0.2)])
+    ('ref_traj_interval_d3_seed21', 30, ((10, 20), (20, 30)), 0.2),
+    # round 5: general a_ij(t, x), b_i(t, x), c(u, t, x) through the reference's own train(), 20 outer iterations at alpha = 1e3
+    ('ref_traj_general_d3_seed36', 40, ((10, 25), (25, 40)), 1.0)])
 def test_trained_error_trajectory_matches_reference(golden_dir, tmp_path, case, steps, windows, reached):
     """BASELINE config 1 (d=5, N_r=256, N_b=64, N_t=16; seed 0, 400 outer iterations = 800 generator sub-steps), the
     headline dimension (d=20, N_r=128, N_b=96, N_t=12; seed 2, 150 outer iterations) and -- round 4 -- BASELINE configs[1] AT THE
@@ -325,11 +338,14 @@ def test_trained_error_trajectory_matches_reference(golden_dir, tmp_path, case, 
     z, params = load(golden_dir, case)
     ref = z['rel_l2']
     log = []
+    F = P
+    if params.pop('funcs', None) == 'general_v1':      # (round 5: general a_ij, b_i, c through train(): tests/golden/general_funcs.py)
+        F = _general_funcs(golden_dir, P, with_b=True)
 
     def hook(self, pts, domain):
         log.append(float(rel_err(pts, self.u_net, self.func_u_sol, self.p, domain.V(), self.params['N_r'])))
         return False
-    S = make_solver(params, int(z['seed']), stop=hook)
+    S = make_solver(params, int(z['seed']), F=F, stop=hook)
     S.tabulate_on_host = True          # tabulate h, f, g like the reference's CPU run (tight early-step comparison)
     cwd = os.getcwd()
     os.chdir(tmp_path)
@@ -345,7 +361,8 @@ def test_trained_error_trajectory_matches_reference(golden_dir, tmp_path, case, 
     # same seeds, same arithmetic: the runs track each other closely before chaotic decorrelation sets in
     np.testing.assert_allclose(got[:50], ref[:50], rtol=2e-3)
     if case in ('ref_traj_d20_headline_euler_seed5', 'ref_traj_d20_headline_rk4_seed6', 'ref_traj_generic_d3_seed14',
-                'ref_traj_n1_3_n2_2_d3_seed16', 'ref_traj_n1_1_n2_3_d3_seed17', 'ref_traj_interval_d3_seed21'):
+                'ref_traj_n1_3_n2_2_d3_seed16', 'ref_traj_n1_1_n2_3_d3_seed17', 'ref_traj_interval_d3_seed21',
+                'ref_traj_general_d3_seed36'):
         np.testing.assert_allclose(got, ref, rtol=1e-4)               # (60 logged values: before the decorrelation sets in)
     if case == 'ref_traj_d20_headline_seed4':
         # 4096 paths per sample: the two runs stay together for the first 60 outer iterations (measured: 2e-6 at worst over the
@@ -458,7 +475,9 @@ def test_sphere_domain_groups_against_reference_vectors(golden_dir, case, name):
                                         # between them, three generator sub-iterations see the same phi
                                         ('ref_traj_cone_n1_3_n2_2_d3_seed18', 36),
                                         # round 5: radius 0.7, 10 outer iterations each
-                                        ('ref_traj_cone_r07_d3_seed22', 20), ('ref_traj_hourglass_r07_d3_seed23', 20)])
+                                        ('ref_traj_cone_r07_d3_seed22', 20), ('ref_traj_hourglass_r07_d3_seed23', 20),
+                                        # round 5: general a_ij, c(u, t, x), 8 outer iterations each at alpha = 1e2
+                                        ('ref_traj_cone_general_d3_seed37', 16), ('ref_traj_hourglass_general_d3_seed38', 16)])
 def test_ball_domain_training_trajectory_follows_reference(golden_dir, tmp_path, case, steps):
     """BASELINE configs[4] family, through train(): NSphere_TCone (seed 0, 100 outer iterations) and NSphere_THourglass (seed 1,
     60), Ex4_3, d = 3, N_r = 256, N_b = 128, N_t = 10 -- and, round 4, both domains AT THE CONFIG'S STATED SIZE (d = 10,
@@ -470,7 +489,8 @@ def test_ball_domain_training_trajectory_follows_reference(golden_dir, tmp_path,
     and Ex4_3: DESIGN 8), what is pinned is that the engine FOLLOWS the reference's run, sub-iteration by sub-iteration."""
     import configs.Ex4_3_funcs as F
     z, params = load(golden_dir, case)
-    params.pop('funcs')
+    if params.pop('funcs').endswith('+general_ac'):
+        F = _general_funcs(golden_dir, F, with_b=False)
     ref = z['rel_l2']
     probe, sol = torch.from_numpy(z['probe']), torch.from_numpy(z['probe_sol'])
     log = []
