@@ -274,7 +274,8 @@ def one_iteration(case, d, N_r, N_b, N_t, seed, solver_name, full_tensors, shape
     print('wrote', path, '%.1f KB' % (os.path.getsize(path) / 1024))
 
 
-def trajectory(case, d, N_r, N_b, N_t, seed, outer_iters, gpu_loader_semantics, solver_name='midpoint', net=None, general=False):
+def trajectory(case, d, N_r, N_b, N_t, seed, outer_iters, gpu_loader_semantics, solver_name='midpoint', net=None, general=False,
+               hook_draws=False):
     """rel-L2 at every generator sub-step through the reference's own train() loop (stop hook = logging point)."""
     training, dataset, lossmod, F = load_reference()
     params = make_params(d, N_r, N_b, N_t, solver_name, iterations=outer_iters)
@@ -300,6 +301,9 @@ def trajectory(case, d, N_r, N_b, N_t, seed, outer_iters, gpu_loader_semantics, 
         with torch.no_grad():
             log.append(training.rel_err(pts, self.u_net, self.func_u_sol, self.p, domain.V(), self.params['N_r']).item())
         losses.append(self.av_l)
+        if hook_draws:                             # (round 5: a hook that consumes both global generators between the sub-iterations)
+            torch.rand(3)
+            np.random.rand(2)
         return False
     torch.manual_seed(seed)
     np.random.seed(seed)
@@ -452,7 +456,7 @@ def sphere_sampling(case, domain_name, d, N_r, N_b, N_t, seed, radius):
 
 
 def sphere_trajectory(case, domain_name, d, N_r, N_b, N_t, seed, outer_iters, funcs_module='configs.Ex4_3_funcs', alpha=100000000,
-                      solver_name='midpoint', net=None, general_ac=False):
+                      solver_name='midpoint', net=None, general_ac=False, hook_draws=False):
     """The reference's own train() on a time-varying ball domain (natural group loop incl. the single-slice groups),
     GPU loader semantics.  Its on-sample diagnostic is unusable on list domains (utils/auxillary_funcs.py:19 broadcasts
     [N,1] - [N] to [N,N] on single-slice groups), so the `stop` hook -- called once per generator sub-iteration,
@@ -493,6 +497,9 @@ def sphere_trajectory(case, domain_name, d, N_r, N_b, N_t, seed, outer_iters, fu
             up = self.u_net(probe).squeeze(2)
             log.append(float(torch.sqrt(torch.mean((up - sol) ** 2) / torch.mean(sol ** 2))))
         losses.append(self.av_l)
+        if hook_draws:
+            torch.rand(3)
+            np.random.rand(2)
         return False
     torch.manual_seed(seed)
     np.random.seed(seed)
@@ -726,6 +733,9 @@ if __name__ == '__main__':
         trajectory('ref_traj_general_d3_seed36', 3, 64, 40, 8, 36, 20, True, net=dict(alpha=1000.0), general=True)
         sphere_trajectory('ref_traj_cone_general_d3_seed37', 'NSphere_TCone', 3, 128, 64, 8, 37, 8, alpha=100.0, general_ac=True)
         sphere_trajectory('ref_traj_hourglass_general_d3_seed38', 'NSphere_THourglass', 3, 128, 64, 8, 38, 8, alpha=100.0, general_ac=True)
+        # a stop hook that draws from torch's and numpy's global generators at every call: every later sample of the run moves
+        trajectory('ref_traj_hook_draws_d3_seed39', 3, 64, 40, 8, 39, 12, True, hook_draws=True)
+        sphere_trajectory('ref_traj_cone_hook_draws_d3_seed40', 'NSphere_TCone', 3, 128, 64, 8, 40, 8, alpha=10000.0, hook_draws=True)
         sphere_groups('ref_cone_alpha1_groups', 'NSphere_TCone', 3, 64, 40, 8, 31, 'configs.Ex4_3_funcs', net=dict(alpha=1.0))
         sphere_groups('ref_hourglass_alpha1_groups', 'NSphere_THourglass', 3, 64, 40, 8, 32, 'configs.Ex4_3_funcs', net=dict(alpha=1.0))
         sphere_groups('ref_hourglass_alpha1_general_groups', 'NSphere_THourglass', 3, 64, 40, 8, 33, 'configs.Ex4_3_funcs', net=dict(alpha=1.0), general_ac=True)

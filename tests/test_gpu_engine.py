@@ -327,7 +327,9 @@ def test_engine_against_oracle_general_coefficients(m, q, adjoint):
     # round 5: [0.25, 1.5] x [-0.5, 1.5]^3, 15 outer iterations
     ('ref_traj_interval_d3_seed21', 30, ((10, 20), (20, 30)), 0.2),
     # round 5: general a_ij(t, x), b_i(t, x), c(u, t, x) through the reference's own train(), 20 outer iterations at alpha = 1e3
-    ('ref_traj_general_d3_seed36', 40, ((10, 25), (25, 40)), 1.0)])
+    ('ref_traj_general_d3_seed36', 40, ((10, 25), (25, 40)), 1.0),
+    # round 5: a hook that draws random numbers itself (12 outer iterations): the loop's own draws stay where the reference makes them
+    ('ref_traj_hook_draws_d3_seed39', 24, ((6, 15), (15, 24)), 1.0)])
 def test_trained_error_trajectory_matches_reference(golden_dir, tmp_path, case, steps, windows, reached):
     """BASELINE config 1 (d=5, N_r=256, N_b=64, N_t=16; seed 0, 400 outer iterations = 800 generator sub-steps), the
     headline dimension (d=20, N_r=128, N_b=96, N_t=12; seed 2, 150 outer iterations) and -- round 4 -- BASELINE configs[1] AT THE
@@ -344,6 +346,9 @@ def test_trained_error_trajectory_matches_reference(golden_dir, tmp_path, case, 
 
     def hook(self, pts, domain):
         log.append(float(rel_err(pts, self.u_net, self.func_u_sol, self.p, domain.V(), self.params['N_r'])))
+        if 'hook_draws' in case:                   # (the fixture's hook consumed both global generators at every call)
+            torch.rand(3)
+            np.random.rand(2)
         return False
     S = make_solver(params, int(z['seed']), F=F, stop=hook)
     S.tabulate_on_host = True          # tabulate h, f, g like the reference's CPU run (tight early-step comparison)
@@ -362,7 +367,7 @@ def test_trained_error_trajectory_matches_reference(golden_dir, tmp_path, case, 
     np.testing.assert_allclose(got[:50], ref[:50], rtol=2e-3)
     if case in ('ref_traj_d20_headline_euler_seed5', 'ref_traj_d20_headline_rk4_seed6', 'ref_traj_generic_d3_seed14',
                 'ref_traj_n1_3_n2_2_d3_seed16', 'ref_traj_n1_1_n2_3_d3_seed17', 'ref_traj_interval_d3_seed21',
-                'ref_traj_general_d3_seed36'):
+                'ref_traj_general_d3_seed36', 'ref_traj_hook_draws_d3_seed39'):
         np.testing.assert_allclose(got, ref, rtol=1e-4)               # (60 logged values: before the decorrelation sets in)
     if case == 'ref_traj_d20_headline_seed4':
         # 4096 paths per sample: the two runs stay together for the first 60 outer iterations (measured: 2e-6 at worst over the
@@ -477,7 +482,9 @@ def test_sphere_domain_groups_against_reference_vectors(golden_dir, case, name):
                                         # round 5: radius 0.7, 10 outer iterations each
                                         ('ref_traj_cone_r07_d3_seed22', 20), ('ref_traj_hourglass_r07_d3_seed23', 20),
                                         # round 5: general a_ij, c(u, t, x), 8 outer iterations each at alpha = 1e2
-                                        ('ref_traj_cone_general_d3_seed37', 16), ('ref_traj_hourglass_general_d3_seed38', 16)])
+                                        ('ref_traj_cone_general_d3_seed37', 16), ('ref_traj_hourglass_general_d3_seed38', 16),
+                                        # round 5: a hook that draws random numbers itself
+                                        ('ref_traj_cone_hook_draws_d3_seed40', 16)])
 def test_ball_domain_training_trajectory_follows_reference(golden_dir, tmp_path, case, steps):
     """BASELINE configs[4] family, through train(): NSphere_TCone (seed 0, 100 outer iterations) and NSphere_THourglass (seed 1,
     60), Ex4_3, d = 3, N_r = 256, N_b = 128, N_t = 10 -- and, round 4, both domains AT THE CONFIG'S STATED SIZE (d = 10,
@@ -499,6 +506,9 @@ def test_ball_domain_training_trajectory_follows_reference(golden_dir, tmp_path,
         with torch.no_grad():
             up = self.u_net(probe).squeeze(2).cpu()
         log.append(float(torch.sqrt(torch.mean((up - sol) ** 2) / torch.mean(sol ** 2))))
+        if 'hook_draws' in case:                   # (the fixture's hook consumed both global generators at every call)
+            torch.rand(3)
+            np.random.rand(2)
         return False
     S = make_solver(params, int(z['seed']), F=F, stop=hook)
     S.tabulate_on_host = True
