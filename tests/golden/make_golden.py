@@ -585,6 +585,40 @@ def bound_pad_hourglass_vectors():
     print('wrote ref_boundpad_hourglass.npz', k, 'cases', [tuple(out['%d/u' % i].shape) for i in range(k)])
 
 
+def bound_pad_cone_vectors():
+    """round 5: the evaluation path on the cone (NSphere_TCone.bound_pad, src/dataset.py:220-223), on the inputs the reference survives"""
+    training, dataset, lossmod, F = load_reference()
+    d = 3
+    params = make_params(d, 8, 12, 6, 'midpoint')
+    params.update({'domain': 'NSphere_TCone', 'shape_param': 1.0})
+    torch.manual_seed(7)
+    np.random.seed(7)
+    S = training.NODE_WAN_solver(params, F.func_a, F.func_b, F.func_c, F.func_h, F.func_f, F.func_g, torch.device('cpu'), './',
+                                 func_u_sol=F.func_u_sol, p=2)
+    g = torch.Generator().manual_seed(6)
+    out = {'params_json': np.array(json.dumps(params)), 'seed': np.array(7)}
+    k = 0
+    for times, scale in (([0.3, 0.5, 0.9], 0.2), ([0.25, 0.26, 0.8, 1.0], 0.1), ([0.6, 0.6, 0.6], 0.3), ([0.4], 0.3),
+                         ([0.1, 0.45], -0.5), ([0.2, 0.3, 0.35], -0.6), ([0.05, 0.1], -0.9)):
+        if scale > 0:
+            x = (torch.rand(7, 1, d, generator=g) - 0.5) * scale
+        else:       # radii spread up to |scale|
+            x = torch.randn(7, 1, d, generator=g)
+            x = x / torch.sqrt(torch.sum(x ** 2, 2, keepdim=True)) * torch.linspace(0.1, -scale, 7).view(7, 1, 1)
+        X = torch.cat((torch.tensor(times).view(1, -1, 1).repeat(7, 1, 1), x.repeat(1, len(times), 1)), 2)
+        try:
+            with torch.no_grad():
+                u = S.u_net(X)
+        except (IndexError, RuntimeError, ValueError) as exc:
+            print('   reference fails on', times, scale, '->', repr(exc)[:80])
+            continue
+        out['%d/X' % k], out['%d/u' % k] = npy(X), npy(u)
+        k += 1
+    out['n'] = np.array(k)
+    np.savez_compressed(os.path.join(HERE, 'ref_boundpad_cone.npz'), **out)
+    print('wrote ref_boundpad_cone.npz', k, 'cases', [tuple(out['%d/u' % i].shape) for i in range(k)])
+
+
 def stop_taken(case, d, N_r, N_b, N_t, seed, fire_at):
     """round 5: the reference's own train() with a `stop` hook that returns True at its `fire_at`-th call (src/training.py:142-146:
     save the generator's weights under <path>, print, exit()): the loss list it leaves, the weights it saved, the files that exist."""
@@ -766,6 +800,7 @@ if __name__ == '__main__':
         sys.exit(0)
     if args.proj:
         proj_vectors()
+        bound_pad_cone_vectors()
         stop_taken('ref_stop_taken_d3_seed15', 3, 64, 40, 8, 15, 5)
         sys.exit(0)
     if args.generic:

@@ -758,6 +758,20 @@ def test_evaluation_off_the_boundary_on_the_hourglass_matches_reference(golden_d
         close(u, z['%d/u' % k], F32TOL, F32TOL, 'case %d' % k)
 
 
+def test_evaluation_off_the_boundary_on_the_cone_matches_reference(golden_dir):
+    """NSphere_TCone.bound_pad (src/dataset.py:220-223: one padded grid for the whole batch, from its first path's times) -- on the
+    inputs the reference survives"""
+    z, params = load(golden_dir, 'ref_boundpad_cone')
+    S = make_solver(params, int(z['seed']))
+    assert int(z['n']) >= 4
+    for k in range(int(z['n'])):
+        X = torch.from_numpy(z['%d/X' % k])
+        with torch.no_grad():
+            u = S.u_net(X)
+        assert tuple(u.shape) == z['%d/u' % k].shape
+        close(u, z['%d/u' % k], F32TOL, F32TOL, 'case %d' % k)
+
+
 def test_checkpoint_resume_is_bit_exact(golden_dir, tmp_path):
     """train 2+2 outer iterations with a save/load in the middle == train 4 outer iterations in one go"""
     z, params = load(golden_dir, 'ref_tiny_midpoint')
