@@ -146,14 +146,15 @@ def one_iteration(case, d, N_r, N_b, N_t, seed, solver_name, full_tensors, shape
         import types
         sys.path.insert(0, HERE)
         import general_funcs as GF
-        F = types.SimpleNamespace(func_a=GF.func_a, func_b=GF.func_b, func_c=GF.func_c, func_h=F.func_h, func_f=F.func_f,
+        fa, fb, fc = GF.variant('v1' if general is True else general)        # (round 5: general may name another set, 'const' / 'diag')
+        F = types.SimpleNamespace(func_a=fa, func_b=fb, func_c=fc, func_h=F.func_h, func_f=F.func_f,
                                   func_g=F.func_g, func_u_sol=F.func_u_sol)
     sl = (lambda a: a[::slim].copy()) if slim else (lambda a: a)
     sl4 = (lambda a: a[::4 * slim].copy()) if slim else (lambda a: a)
     sha = lambda a: np.array(hashlib.sha1(np.ascontiguousarray(a).tobytes()).hexdigest())  # noqa: E731
     params = make_params(d, N_r, N_b, N_t, solver_name) if alpha is None else make_params(d, N_r, N_b, N_t, solver_name, alpha=alpha)
     if general:
-        params['funcs'] = 'general_v1'
+        params['funcs'] = 'general_' + ('v1' if general is True else general)
     if net is not None:           # network shapes other than the YAML's (src/model.py:30-43,62-85,130-138 accept any)
         params.update(net)
     if shape_param is not None:
@@ -770,6 +771,9 @@ if __name__ == '__main__':
         # a stop hook that draws from torch's and numpy's global generators at every call: every later sample of the run moves
         trajectory('ref_traj_hook_draws_d3_seed39', 3, 64, 40, 8, 39, 12, True, hook_draws=True)
         sphere_trajectory('ref_traj_cone_hook_draws_d3_seed40', 'NSphere_TCone', 3, 128, 64, 8, 40, 8, alpha=10000.0, hook_draws=True)
+        # the table forms of a: one constant matrix / a diagonal a(x), each with the linear reaction c = -0.7 u (fused path)
+        one_iteration('ref_const_a_d4_midpoint', 4, 48, 28, 6, 41, 'midpoint', True, general='const', alpha=10.0)
+        one_iteration('ref_diag_a_d5_rk4', 5, 40, 24, 5, 42, 'rk4', True, general='diag', alpha=10.0)
         sphere_groups('ref_cone_alpha1_groups', 'NSphere_TCone', 3, 64, 40, 8, 31, 'configs.Ex4_3_funcs', net=dict(alpha=1.0))
         sphere_groups('ref_hourglass_alpha1_groups', 'NSphere_THourglass', 3, 64, 40, 8, 32, 'configs.Ex4_3_funcs', net=dict(alpha=1.0))
         sphere_groups('ref_hourglass_alpha1_general_groups', 'NSphere_THourglass', 3, 64, 40, 8, 33, 'configs.Ex4_3_funcs', net=dict(alpha=1.0), general_ac=True)

@@ -40,7 +40,9 @@ CASES = ['ref_tiny_midpoint', 'ref_tiny_euler', 'ref_tiny_rk4', 'ref_plumb_midpo
          # round 5: alpha = 1 -- the interior term's gradient is not hidden behind alpha x penalties in the generator sub-steps
          'ref_alpha1_d4_midpoint', 'ref_alpha1_d3_rk4', 'ref_alpha1_general_d4_euler',
          # round 5: the smallest shapes -- d = 2, two sample times (ONE step), 7 interior / 5 boundary paths; N_t = 3 with rk4
-         'ref_min_d2_nt2_midpoint', 'ref_min_d2_nt3_rk4']
+         'ref_min_d2_nt2_midpoint', 'ref_min_d2_nt3_rk4',
+         # round 5: the table forms of a -- one constant matrix / a diagonal a(x) -- with the linear reaction c = -0.7 u
+         'ref_const_a_d4_midpoint', 'ref_diag_a_d5_rk4']
 FUNCS = dict(h=P.func_h, f=P.func_f, g=P.func_g, a=P.func_a, b=P.func_b, c=P.func_c)
 
 
@@ -121,7 +123,8 @@ def test_first_iteration_with_the_hoisted_x_projection_against_reference_vectors
 def _first_iteration(golden_dir, case):
     from utils.auxillary_funcs import L_norm, rel_err
     z, params = load(golden_dir, case)
-    general = params.pop('funcs', None) == 'general_v1'
+    fname = str(params.pop('funcs', ''))
+    general = fname[len('general_'):] if fname.startswith('general_') else ''
     F = P
     if general:       # the callables the fixture was recorded with (the reference's own classes ran them)
         import importlib.util
@@ -129,7 +132,8 @@ def _first_iteration(golden_dir, case):
         spec = importlib.util.spec_from_file_location('general_funcs', os.path.join(golden_dir, 'general_funcs.py'))
         GF = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(GF)
-        F = types.SimpleNamespace(func_a=GF.func_a, func_b=GF.func_b, func_c=GF.func_c, func_h=P.func_h, func_f=P.func_f, func_g=P.func_g,
+        fa, fb, fc = GF.variant(general)
+        F = types.SimpleNamespace(func_a=fa, func_b=fb, func_c=fc, func_h=P.func_h, func_f=P.func_f, func_g=P.func_g,
                                   func_u_sol=P.func_u_sol)
     S = make_solver(params, int(z['seed']), F=F)
     for tag, net in (('u', S.u_net), ('v', S.v_net)):
@@ -144,8 +148,12 @@ def _first_iteration(golden_dir, case):
     close(L_norm(pts.interioru, S.u_net, 2, P.func_u_sol, domain.V(), S.setup['N_r']), float(z['L2_start']), F32TOL)
     close(rel_err(pts.interioru, S.u_net, P.func_u_sol, 2, domain.V(), S.setup['N_r']), float(z['rel_start']), F32TOL)
     eng = S.engine
-    if general:       # every fused fast path is off: tabulated a_ij, b_i at t_0, c(u, t, x) through autograd, all inside the graphs
+    if general == 'v1':       # every fused fast path is off: tabulated a_ij, b_i at t_0, c(u, t, x) through autograd, all inside the graphs
         assert not eng.structure.a_identity and not eng.structure.b_zero and eng.structure.c_kappa is None
+    elif general == 'const':  # (round 5) one [d, d] matrix for all points, no b table, the linear reaction: the fused sub-step with A0
+        assert not eng.structure.a_identity and eng.structure.b_zero and eng.structure.c_kappa == -0.7
+    elif general == 'diag':   # (round 5) the diagonal [d, N] form of a, a b table, the linear reaction
+        assert not eng.structure.a_identity and not eng.structure.b_zero and eng.structure.c_kappa == -0.7
     else:
         assert eng.structure.a_identity and eng.structure.b_zero and eng.structure.c_kappa == -1.0
     G = eng.load_group(pts.interioru, pts.interiorv, pts.boundary, domain)   # host tensors: tabulated like the reference
