@@ -364,9 +364,14 @@ def sphere_groups(case, domain_name, d, N_r, N_b, N_t, seed, funcs_module='confi
         import types
         sys.path.insert(0, HERE)
         import general_funcs as GF
-        F = types.SimpleNamespace(func_a=GF.func_a, func_b=F.func_b, func_c=GF.func_c, func_h=F.func_h, func_f=F.func_f,
-                                  func_g=F.func_g, func_u_sol=F.func_u_sol)
-        params['funcs'] = params.get('funcs', 'Ex4_1_funcs') + '+general_ac'
+        if general_ac == 'const':                  # (one constant matrix a, the linear reaction c = -0.7 u: the group runner's fused path)
+            F = types.SimpleNamespace(func_a=GF.const_a, func_b=F.func_b, func_c=GF.lin_c, func_h=F.func_h, func_f=F.func_f,
+                                      func_g=F.func_g, func_u_sol=F.func_u_sol)
+            params['funcs'] = params.get('funcs', 'Ex4_1_funcs') + '+general_const'
+        else:
+            F = types.SimpleNamespace(func_a=GF.func_a, func_b=F.func_b, func_c=GF.func_c, func_h=F.func_h, func_f=F.func_f,
+                                      func_g=F.func_g, func_u_sol=F.func_u_sol)
+            params['funcs'] = params.get('funcs', 'Ex4_1_funcs') + '+general_ac'
     dev = torch.device('cpu')
     torch.manual_seed(seed)
     np.random.seed(seed)
@@ -774,6 +779,7 @@ if __name__ == '__main__':
         # the table forms of a: one constant matrix / a diagonal a(x), each with the linear reaction c = -0.7 u (fused path)
         one_iteration('ref_const_a_d4_midpoint', 4, 48, 28, 6, 41, 'midpoint', True, general='const', alpha=10.0)
         one_iteration('ref_diag_a_d5_rk4', 5, 40, 24, 5, 42, 'rk4', True, general='diag', alpha=10.0)
+        sphere_groups('ref_hourglass_const_a_groups', 'NSphere_THourglass', 3, 64, 40, 8, 43, 'configs.Ex4_3_funcs', net=dict(alpha=10.0), general_ac='const')
         sphere_groups('ref_cone_alpha1_groups', 'NSphere_TCone', 3, 64, 40, 8, 31, 'configs.Ex4_3_funcs', net=dict(alpha=1.0))
         sphere_groups('ref_hourglass_alpha1_groups', 'NSphere_THourglass', 3, 64, 40, 8, 32, 'configs.Ex4_3_funcs', net=dict(alpha=1.0))
         sphere_groups('ref_hourglass_alpha1_general_groups', 'NSphere_THourglass', 3, 64, 40, 8, 33, 'configs.Ex4_3_funcs', net=dict(alpha=1.0), general_ac=True)

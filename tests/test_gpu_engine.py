@@ -406,7 +406,9 @@ def test_trained_error_trajectory_matches_reference(golden_dir, tmp_path, case, 
                                        ('ref_cone_general_groups', 'NSphere_TCone'), ('ref_hourglass_general_groups', 'NSphere_THourglass'),
                                        # round 5: alpha = 1
                                        ('ref_cone_alpha1_groups', 'NSphere_TCone'), ('ref_hourglass_alpha1_groups', 'NSphere_THourglass'),
-                                       ('ref_hourglass_alpha1_general_groups', 'NSphere_THourglass')])
+                                       ('ref_hourglass_alpha1_general_groups', 'NSphere_THourglass'),
+                                       # round 5: one constant matrix a, c = -0.7 u -- the group runner's fused path with an A0 table
+                                       ('ref_hourglass_const_a_groups', 'NSphere_THourglass')])
 def test_sphere_domain_groups_against_reference_vectors(golden_dir, case, name):
     """time-varying ball domains (BASELINE config 5 family): float64 groups of different lengths, late-entry groups that
     start on the moving boundary (g start values), time-dependent weight w, single-time boundary groups, and the
@@ -427,6 +429,14 @@ def test_sphere_domain_groups_against_reference_vectors(golden_dir, case, name):
         GF = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(GF)
         F = types.SimpleNamespace(func_a=GF.func_a, func_b=F.func_b, func_c=GF.func_c, func_h=F.func_h, func_f=F.func_f, func_g=F.func_g,
+                                  func_u_sol=F.func_u_sol)
+    if fname.endswith('+general_const'):     # (one constant matrix a, c = -0.7 u: the fused path / the group runner with an A0 table)
+        import importlib.util
+        import types
+        spec = importlib.util.spec_from_file_location('general_funcs', os.path.join(golden_dir, 'general_funcs.py'))
+        GF = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(GF)
+        F = types.SimpleNamespace(func_a=GF.const_a, func_b=F.func_b, func_c=GF.lin_c, func_h=F.func_h, func_f=F.func_f, func_g=F.func_g,
                                   func_u_sol=F.func_u_sol)
     assert params['domain'] == name
     S = make_solver(params, int(z['seed']), F=F)
