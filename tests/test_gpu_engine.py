@@ -42,7 +42,9 @@ CASES = ['ref_tiny_midpoint', 'ref_tiny_euler', 'ref_tiny_rk4', 'ref_plumb_midpo
          # round 5: the smallest shapes -- d = 2, two sample times (ONE step), 7 interior / 5 boundary paths; N_t = 3 with rk4
          'ref_min_d2_nt2_midpoint', 'ref_min_d2_nt3_rk4',
          # round 5: the table forms of a -- one constant matrix / a diagonal a(x) -- with the linear reaction c = -0.7 u
-         'ref_const_a_d4_midpoint', 'ref_diag_a_d5_rk4']
+         'ref_const_a_d4_midpoint', 'ref_diag_a_d5_rk4',
+         # round 5: ONE boundary path; ONE interior path (where the reference's .squeeze() calls also drop the path axis)
+         'ref_nb1_d3_midpoint', 'ref_nr1_d3_midpoint']
 FUNCS = dict(h=P.func_h, f=P.func_f, g=P.func_g, a=P.func_a, b=P.func_b, c=P.func_c)
 
 
