@@ -520,3 +520,23 @@ def test_packed_list_sample_is_the_sample_and_its_hints_are_what_the_engine_woul
         assert any(not h['shared_times'] for h in hall)
     cube = sampling.Comb_loader(16, 16, sampling.Hypercube((-1.0, 1.0), 3, 0.0, 1.0, 4), 'cpu')
     assert cube.device_groups('cpu') is None and cube.device_interior('cpu') is None
+
+
+def test_rank_local_sampling_keeps_the_diagnostic_sample_rank_local():
+    """solver._loader: with several ranks and rank_local_sampling an interior_only request (the L^p diagnostic's sample in
+    draw_ahead / _iterate_body) is still this rank's share, a RankCubeLoader -- not the global sample on every rank."""
+    class W:
+        rank, size = 1, 4
+    sol = S.NODE_WAN_solver.__new__(S.NODE_WAN_solver)
+    sol.setup = {'N_r': 64, 'N_b': 32}
+    sol.device = torch.device('cpu')
+    sol.device_sampling, sol.tabulate_on_host = False, False
+    dom = sampling.Hypercube([-1, 1], 3, 0, 1, 5)
+    sol.world, sol.rank_local_sampling = W(), True
+    for interior_only in (False, True):
+        pts = sol._loader(dom, interior_only=interior_only)
+        assert isinstance(pts, sampling.RankCubeLoader) and pts.n_local == 16
+    sol.rank_local_sampling = False                       # shared seed: every rank draws the global sample and keeps a slice
+    assert isinstance(sol._loader(dom, interior_only=True), sampling.Comb_loader)
+    sol.world, sol.rank_local_sampling = None, True       # one GPU: the flag means nothing
+    assert isinstance(sol._loader(dom, interior_only=True), sampling.Comb_loader)

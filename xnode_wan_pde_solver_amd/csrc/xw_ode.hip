@@ -698,12 +698,19 @@ struct ActLane {       // (unsigned: uniform pointer + zero-extended 32-bit lane
                        //  global loads / stores -- with signed offsets every 4 KB of the record cost a 64-bit vector add)
   unsigned off;        // BYTES inside a full block of four rows: 8 (4 * column + g)
   unsigned off_part;   // inside the last, partially filled block of a K-row tile (p = K mod 4 rows): 8 (p * column + min(g, p - 1))
+  unsigned off_part_st;   // the same for STORES: lanes without a row of their own (g >= p) get an offset beyond every record --
+                          // the buffer's range check drops their store.  As a branch on the lane group (s_and_saveexec /
+                          // s_cbranch_execz / s_or exec around one store per layer) the partial block cost the lone forward wave
+                          // ~56 clocks per layer, 2.5 x the three stores themselves (tools/probe_store_cost.hip,
+                          // profiles/r06_probe_store_cost.txt), and cut the time loop into a basic block per layer.
   bool valid;
 };
+#define XW_ACT_OOB 0x7fffff00u
 __device__ __forceinline__ ActLane act_lane(int N, int col, bool valid, int krows) {
   const int g = xw_lane() >> 4, p = krows & 3;
   const int gp = p ? (g < p ? g : p - 1) : g;
-  return ActLane{8u * (unsigned)(4 * col + g), 8u * (unsigned)((p ? p : 4) * col + gp), valid};
+  const unsigned part = 8u * (unsigned)((p ? p : 4) * col + gp);
+  return ActLane{8u * (unsigned)(4 * col + g), part, (p == 0 || g < p) ? part : XW_ACT_OOB, valid};
 }
 // The forward pass writes the record through a BUFFER descriptor of the step's tile (base = the tile's 23 KB, built from
 // scalars once per step): a store is then  descriptor + scalar row offset + 32-bit lane offset  and costs no vector
@@ -717,7 +724,6 @@ __device__ __forceinline__ ActBuf act_buf(double* A, int bytes) {
   return ActBuf{__builtin_amdgcn_make_buffer_rsrc(A, 0, bytes, 0x00020000)};
 }
 __device__ __forceinline__ void act_store(const ActBuf& B, int row0, int nrows, int N, const ActLane& q, d4 v) {
-  const int g = xw_lane() >> 4;
 #pragma unroll
   for (int r = 0; r < 4; ++r)
     if (4 * r < nrows) {
@@ -725,8 +731,9 @@ __device__ __forceinline__ void act_store(const ActBuf& B, int row0, int nrows, 
       // (the element goes through a scalar first: __builtin_bit_cast applied to v[r] directly reads element 0 of the vector)
       const double x = v[r];
       const xw_u2v w2 = {(unsigned)__double2loint(x), (unsigned)__double2hiint(x)};
-      if (g + 4 * r < nrows && q.valid)                                     // (nt: streamed, read once, by a sweep)
-        __builtin_amdgcn_raw_buffer_store_b64(w2, B.rsrc, (int)(4 * r + 4 <= nrows ? q.off : q.off_part), so, 2);
+      // (nt: streamed, read once, by a sweep; no branch: the lanes past a partial block's rows carry an out-of-range offset.
+      //  Every caller's lanes are valid -- padding paths of the last tile hold finite copies and have slots of their own)
+      __builtin_amdgcn_raw_buffer_store_b64(w2, B.rsrc, (int)(4 * r + 4 <= nrows ? q.off : q.off_part_st), so, 2);
     }
 }
 __device__ __forceinline__ d4 act_load(const double* __restrict__ A, int row0, int nrows, int N, const ActLane& q) {
@@ -799,18 +806,49 @@ __global__ void __launch_bounds__(64, XW_ODE_FWD_WAVES) k_ode_fwd(const FwdJobs 
   const double flb = th[o.FLb];
   const ActLane aq = act_lane(16, n, true, K);           // every lane of the tile has a slot (padding paths: finite copies)
   const long ntile = (N + 15) >> 4, tile = base >> 4;
+  // The checkpoint y_l and u_l leave through buffer descriptors as well (one per time index: rows of [H][N] resp. one row of
+  // u): lanes that own nothing -- paths past N in the last tile, rows >= H of the last row tile, the lane groups g > 0 of u --
+  // carry an out-of-range offset, so the time loop has no branch but its own (see ActLane.off_part_st).
+  const bool big = (long)H * N * 8 >= (1L << 31);         // (a descriptor's 32-bit range: beyond it the plain guarded stores)
+  unsigned yoff[4 * D::HT];
+#pragma unroll
+  for (int ht = 0; ht < D::HT; ++ht)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * ht + g + 4 * r;
+      yoff[4 * ht + r] = (valid && row < H) ? 8u * (unsigned)(g * N + base + n) : XW_ACT_OOB;
+    }
+  const unsigned uoff = (g == 0 && valid) ? 8u * (unsigned)(base + n) : XW_ACT_OOB;
   for (int l = 0; l < L; ++l) {
     double part = 0.0;
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(Y != nullptr && !big ? Y + (long)l * H * N : nullptr, 0,
+                                                                         Y != nullptr && !big ? H * N * 8 : 0, 0x00020000);
 #pragma unroll
     for (int ht = 0; ht < D::HT; ++ht)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int row = 16 * ht + g + 4 * r;
         part += flw[ht][r] * y[ht][r];
-        if (Y != nullptr && valid && row < H) Y[((long)l * H + row) * N + base + n] = y[ht][r];
+        if (16 * ht + 4 * r < H) {                         // (compile time: the register holds live rows)
+          const double x = y[ht][r];
+          const xw_u2v w2 = {(unsigned)__double2loint(x), (unsigned)__double2hiint(x)};
+          __builtin_amdgcn_raw_buffer_store_b64(w2, yrs, (int)yoff[4 * ht + r], (16 * ht + 4 * r) * N * 8, 0);
+        }
       }
+    if (big && Y != nullptr) {                             // (uniform, never taken below 13 million paths)
+#pragma unroll
+      for (int ht = 0; ht < D::HT; ++ht)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * ht + g + 4 * r;
+          if (valid && row < H) Y[((long)l * H + row) * N + base + n] = y[ht][r];
+        }
+    }
     const double ul = xw_sum_over_g(part) + flb;           // final_linear, src/model.py:110
-    if (g == 0 && valid) u[(long)l * N + base + n] = ul;
+    {
+      const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(u + (long)l * N, 0, N * 8, 0x00020000);
+      const xw_u2v w2 = {(unsigned)__double2loint(ul), (unsigned)__double2hiint(ul)};
+      __builtin_amdgcn_raw_buffer_store_b64(w2, urs, (int)uoff, 0, 0);
+    }
     if (l == L - 1) break;
     const double t0 = tf[l], dt = tf[l + 1] - t0;
     d4 k[T::S][D::HT];

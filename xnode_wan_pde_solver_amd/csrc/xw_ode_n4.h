@@ -667,16 +667,29 @@ __global__ void __launch_bounds__(256, 2) k_ode_fwd_n4(const FwdJobs jobs, const
       for (int c = 0; c < 4; ++c) xp = XW_MFMA4(frag<false>(th + o.Win, o.ldin, K, d, 0, 16 * r, g, c), xr.v[c], xp);
     }
   }
-  // lane offsets into the activation store's tile (C layout), store predicates
-  const int cK = koff<K>(g.b, g.hi, 4 * g.q + g.lo);
-  const bool liveK = 4 * g.b + g.hi < K;
-  int cY[D::NY];
+  // lane offsets (bytes) into the activation store's tile (C layout).  Every store of the time loop goes through a buffer
+  // descriptor and lanes that own nothing carry an out-of-range offset (ActLane.off_part_st in xw_ode.hip: a branch on a lane
+  // predicate around one store per layer cost more than the layer's four matrix instructions)
+  const unsigned cK = 4 * g.b + g.hi < K ? 8u * (unsigned)koff<K>(g.b, g.hi, 4 * g.q + g.lo) : XW_ACT_OOB;
+  unsigned cY[D::NY], oY[D::NY];
+  const bool big = (long)H * N * 8 >= (1L << 31);         // (beyond a descriptor's 32-bit range: plain guarded stores)
 #pragma unroll
-  for (int q = 0; q < D::NY; ++q) cY[q] = 64 * (q == 0 ? g.b : (D::REP ? 4 : 4 + g.b)) + 4 * (4 * g.q + g.lo) + g.hi;
+  for (int q = 0; q < D::NY; ++q) {
+    cY[q] = liveC[q] ? 8u * (unsigned)(64 * (q == 0 ? g.b : (D::REP ? 4 : 4 + g.b)) + 4 * (4 * g.q + g.lo) + g.hi) : XW_ACT_OOB;
+    oY[q] = (valid && liveC[q]) ? 8u * (unsigned)(rowC[q] * N + col) : XW_ACT_OOB;
+  }
+  const unsigned oU = (g.b == 0 && g.hi == 0 && valid) ? 8u * (unsigned)col : XW_ACT_OOB;
+  const unsigned oW = g.b == 0 ? 4u * (unsigned)(16 * g.hi + 4 * g.q + g.lo) : XW_ACT_OOB;
   const long ntile = (N + 15) >> 4;
+#define st64(x, rs, voff, soff, aux)                                                                        \
+  {                                                                                                         \
+    const double x_ = (x);                                                                                  \
+    const xw_u2v w2_ = {(unsigned)__double2loint(x_), (unsigned)__double2hiint(x_)};                        \
+    __builtin_amdgcn_raw_buffer_store_b64(w2_, (rs), (int)(voff), (soff), (aux));                           \
+  }
 
   // one field evaluation: F([x, t, y]) of src/model.py:153-156; S: the stage's part of the activation record (or nullptr)
-  auto field = [&](double t, const double (&yi)[D::NY], double (&out)[D::NY], double* __restrict__ S, unsigned* __restrict__ mw) {
+  auto field = [&](double t, const double (&yi)[D::NY], double (&out)[D::NY], const __amdgpu_buffer_rsrc_t& rs, int i) {
     double z = fma(w.wt, t, xp);
     {
       const R4 r0 = rots(yi[0]);
@@ -697,14 +710,14 @@ __global__ void __launch_bounds__(256, 2) k_ode_fwd_n4(const FwdJobs jobs, const
       // (the bit is z > 0, not the sign: a dead layer feeds exact +0 to the next one and relu'(+0) = 0, xw_ode.hip SaveX)
       bits = (bits << D::KB) | (z > 0.0 ? 1u : 0u);
       const double r = xw_relu1(z);
-      if (ACT == 1 && liveK) xw_st_nt(r, S + j * K * 16 + cK);
+      if (ACT == 1) st64(r, rs, cK, (i * AL::STAGE + j * K) * 16 * 8, 2);      // (nt: streamed, read once, by a sweep)
       const R4 rr = rots(r);
       z = w.bh;
 #pragma unroll
       for (int c = 0; c < 4; ++c) z = XW_MFMA4(w.Wh[c], rr.v[c], z);
     }
     const double a = xw_tanh(z);
-    if (ACT && liveK) xw_st_nt(a, S + (M - 1) * K * 16 + cK);
+    if (ACT) st64(a, rs, cK, (i * AL::STAGE + (M - 1) * K) * 16 * 8, 2);
     if (ACT) {
       // this lane pushed (layer j) at bit KB (M - 2 - j); the record wants (layer j, block b) at bit KB (M - 1) - 1 - KB j - b,
       // all blocks of a lane row in ONE word: shift by the block, OR over the four blocks, block 0 stores
@@ -712,7 +725,7 @@ __global__ void __launch_bounds__(256, 2) k_ode_fwd_n4(const FwdJobs jobs, const
       wd = g.b < D::KB ? wd : 0u;
       wd |= (unsigned)rot_i<2>((int)wd);
       wd |= (unsigned)rot_i<1>((int)wd);
-      if (g.b == 0) __builtin_nontemporal_store(wd, (unsigned __attribute__((address_space(1)))*)(mw + 16 * g.hi + 4 * g.q + g.lo));
+      __builtin_amdgcn_raw_buffer_store_b32(wd, rs, (int)oW, (AL::MASK + 2 * i) * 16 * 8, 2);
     }
     const R4 ar = rots(a);
 #pragma unroll
@@ -726,16 +739,24 @@ __global__ void __launch_bounds__(256, 2) k_ode_fwd_n4(const FwdJobs jobs, const
 
   for (int l = 0; l < L; ++l) {
     double part = 0.0;
+    const bool ybuf = Y != nullptr && !big;
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(ybuf ? Y + (long)l * H * N : nullptr, 0, ybuf ? H * N * 8 : 0, 0x00020000);
 #pragma unroll
     for (int q = 0; q < D::NY; ++q) {
       part = fma(flw[q], y[q], part);
-      if (Y != nullptr && valid && liveC[q]) Y[((long)l * H + rowC[q]) * N + col] = y[q];
+      st64(y[q], yrs, oY[q], 0, 0);
+    }
+    if (big && Y != nullptr) {                            // (uniform, never taken below 13 million paths)
+#pragma unroll
+      for (int q = 0; q < D::NY; ++q)
+        if (valid && liveC[q]) Y[((long)l * H + rowC[q]) * N + col] = y[q];
     }
     const double ul = sum_rows(part) + flb;               // final_linear, src/model.py:110
-    if (g.b == 0 && g.hi == 0 && valid) u[(long)l * N + col] = ul;
+    st64(ul, __builtin_amdgcn_make_buffer_rsrc(u + (long)l * N, 0, N * 8, 0x00020000), oU, 0, 0);
     if (l == L - 1) break;
     const double t0 = tf[l], dt = tf[l + 1] - t0;
     double* __restrict__ A = ACT ? act + ((long)l * ntile + tile) * (AL::TOTAL * 16) : nullptr;
+    const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(A, 0, ACT ? AL::TOTAL * 16 * 8 : 0, 0x00020000);
     double k[T::S][D::NY];
 #pragma unroll
     for (int i = 0; i < T::S; ++i) {
@@ -746,10 +767,9 @@ __global__ void __launch_bounds__(256, 2) k_ode_fwd_n4(const FwdJobs jobs, const
 #pragma unroll
         for (int j = 0; j < i; ++j)
           if (T::a(i, j) != 0.0) yi[q] = fma(dt * T::a(i, j), k[j][q], yi[q]);
-        if (ACT == 1 && i > 0 && liveC[q]) xw_st_nt(yi[q], A + (long)(AL::YI + (i - 1) * H) * 16 + cY[q]);
+        if (ACT == 1 && i > 0) st64(yi[q], ars, cY[q], (AL::YI + (i - 1) * H) * 16 * 8, 2);
       }
-      field(t0 + T::c(i) * dt, yi, k[i], ACT ? A + (long)i * AL::STAGE * 16 : nullptr,
-            ACT ? reinterpret_cast<unsigned*>(A + (long)(AL::MASK + 2 * i) * 16) : nullptr);
+      field(t0 + T::c(i) * dt, yi, k[i], ars, i);
     }
 #pragma unroll
     for (int i = 0; i < T::S; ++i)
@@ -759,4 +779,5 @@ __global__ void __launch_bounds__(256, 2) k_ode_fwd_n4(const FwdJobs jobs, const
   }
 }
 
+#undef st64
 }  // namespace n4

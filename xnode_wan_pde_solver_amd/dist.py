@@ -104,6 +104,30 @@ class World:
         lo = self.rank * base + min(self.rank, rem)
         return lo, lo + base + (1 if self.rank < rem else 0)
 
+    def assert_in_step(self, *blobs):
+        """Raise on every rank if the ranks' copies of the given float64 parameter blobs are not bit-identical.  Parameters are
+        replicated and never broadcast (every rank applies the same fused Adam to the same all-reduced gradient; groups below
+        `replicate_below` are computed whole on every rank), so a divergence can only be noticed by looking: two position-
+        weighted checksums per blob, summed over the ranks and compared with size x the local value (an exact test: equal
+        addends sum to a multiple that rounds identically on every rank).  One small all-reduce and one read-back: called once
+        per train() / every `check_every` outer iterations, not per sub-step."""
+        sums = []
+        for b in blobs:
+            x = b.detach().reshape(-1).to(torch.float64)
+            w = torch.arange(1, x.numel() + 1, dtype=torch.float64, device=x.device)
+            sums += [x.sum(), (x * w).sum()]
+        mine = torch.stack(sums).contiguous()
+        tot = mine.clone()
+        self.all_reduce(tot)
+        # (size is a small integer: size * x is exact up to one rounding, and so is the sum of `size` equal addends in any order
+        #  only when they ARE equal -- compare with a tolerance of a few ulps to stay independent of the reduction tree)
+        bad = (tot - self.size * mine).abs() > 8 * torch.finfo(torch.float64).eps * self.size * mine.abs().clamp_min(1e-300)
+        flag = bad.any().to(torch.float64).reshape(1).contiguous()
+        self.all_reduce(flag)
+        if float(flag[0]) != 0.0:
+            raise RuntimeError('rank %d of %d: the replicated parameters have drifted apart across the ranks (checksums %r, sum over '
+                               'ranks %r)' % (self.rank, self.size, mine.tolist(), tot.tolist()))
+
     def close(self):
         if self.comm is not None:
             from ._lib import lib

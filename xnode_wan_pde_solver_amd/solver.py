@@ -219,6 +219,7 @@ class NODE_WAN_solver:
         self.reuse_test_net = True        # v, dv/dt, nabla_x v(t_0) are evaluated once per (phi, sample) and shared by the
                                           # sub-steps of an outer iteration -- bit-identical results (the reference
                                           # recomputes the same values); bench.py times the sub-steps WITHOUT it
+        self.check_replicas = True        # several GPUs: train() ends with a cross-rank checksum of theta and phi (dist.World.assert_in_step)
         self._group_cache = []
         self.config, self.setup, self.iterations = split_params(params)
         self.domain = sampling.resolve_domain(params['domain'])
@@ -251,10 +252,13 @@ class NODE_WAN_solver:
         return self.domain(s['shape_param'], s['dim'], s['T0'], s['T'], s['N_t'])
 
     def _loader(self, domain, interior_only=False):
-        if interior_only and not self.device_sampling and not self.tabulate_on_host:
-            return sampling.Comb_loader(self.setup['N_r'], self.setup['N_b'], domain, self.device, interior_only=True)
+        # (rank-local sampling first: an interior_only request -- the diagnostic's sample -- must not turn a rank-local run
+        #  into one where every rank draws and evaluates the GLOBAL sample; RankCubeLoader's share is what _l_norm_value's
+        #  8-byte exchange combines)
         if self.world is not None and self.rank_local_sampling and hasattr(domain, 'interior_x'):
             return sampling.RankCubeLoader(self.setup['N_r'], self.setup['N_b'], domain, self.device, self.world.rank, self.world.size)
+        if interior_only and not self.device_sampling and not self.tabulate_on_host:
+            return sampling.Comb_loader(self.setup['N_r'], self.setup['N_b'], domain, self.device, interior_only=True)
         if self.device_sampling and hasattr(domain, 'device_sample'):
             return sampling.DeviceCubeLoader(self.setup['N_r'], self.setup['N_b'], domain, self.device)
         return sampling.Comb_loader(self.setup['N_r'], self.setup['N_b'], domain, self.device)
@@ -307,7 +311,10 @@ class NODE_WAN_solver:
             return [(du, dv, bd, self.setup['N_r'], self.setup['N_b'], None) for (du, dv, bd) in points]
         out = []
         for du, dv, bd in points:
-            if len(points) > 1 and self.world.replicated(du.shape[0], bd.shape[0]):
+            # (replicas must compute bit-identical inputs: with tabulate_on_host the callables run on the concatenation of THIS
+            #  rank's shares, where a replicated group sits at another offset on every rank -- a vectorised body / scalar tail
+            #  may then differ in the last bit and nothing would ever resynchronise theta and phi.  Shard such runs instead.)
+            if len(points) > 1 and not self.tabulate_on_host and self.world.replicated(du.shape[0], bd.shape[0]):
                 out.append((du, dv, bd, None, None, None))
             else:
                 out.append(self.world.shard_group(du, dv, bd) + ((du[0, :, 0], bd[0, :, 0]),))
@@ -472,7 +479,11 @@ class NODE_WAN_solver:
             torch.set_num_threads(min(threads, int(self.host_threads)))
         self.engine.reuse_test_net = bool(self.reuse_test_net) or self.engine.reuse_test_net
         try:
-            return self._train(report, report_it, show_plt)
+            out = self._train(report, report_it, show_plt)
+            if self.world is not None and self.check_replicas:
+                # parameters are replicated, never broadcast: look once per call that the ranks still hold the same bits
+                self.world.assert_in_step(self.engine.theta.data, self.engine.phi.data)
+            return out
         finally:
             torch.set_num_threads(threads)
 
