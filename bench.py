@@ -315,6 +315,35 @@ def main():
              'frac_fp64_matrix_peak': round(step_flops * per_gpu_rate / 1e12 / PEAK_FP64_MATRIX_TFLOPS, 4),
              'ref_layout_mbytes_per_step': round(bytes_step / 1e6, 1),
              'frac_hbm_peak': round(bytes_step * per_gpu_rate / 8.0e12, 5)}
+    # ... and what the memory system actually moves: HBM bytes per sub-step from the committed counter passes (the activation
+    # store of the stepper and the test network's record are deliberate store-instead-of-recompute trades: ~30 x the reference
+    # layout's bytes).  Preferred source: the `cycle` section of the counter summary (all kernels of whole g,g,d cycles,
+    # tools/cycle_only.py under rocprofv3 --pmc); otherwise the per-kernel averages x this run's launches per sub-step.
+    if os.path.exists(pmc_path) and default_workload:
+        pmc_all = json.load(open(pmc_path))
+        counter_bytes, how = None, None
+        if isinstance(pmc_all.get('cycle'), dict) and pmc_all['cycle'].get('hbm_bytes_per_substep_corrected'):
+            counter_bytes = float(pmc_all['cycle']['hbm_bytes_per_substep_corrected'])
+            how = 'cycle section: every kernel of %s g,g,d cycles' % pmc_all['cycle'].get('cycles', '?')
+        else:
+            pk = pmc_all['kernels']
+            first = lambda pre: next((pk[k]['hbm_bytes_per_launch_corrected'] for k in sorted(pk) if k.startswith(pre)), None)  # noqa: E731
+            n_g, n_d = schedule.count('g'), schedule.count('d')
+            per_launch = {'disc_bwd': first('k_disc_rec<'), 'ode_fwd_2job': first('k_ode_fwd<20,10,8,1,1>'), 'ode_fwd_1job': first('k_ode_fwd<20,10,8,1,2>'),
+                          'ode_bwd_x_1job': first('k_ode_bwd<'), 'ode_bwd_params_1job': first('k_ode_bwd_duo<'), 'ode_bwd_params_2job': first('k_ode_bwd_duo<'),
+                          'ode_bwd_params_3job': first('k_ode_bwd_duo<'), 'weak_partials': first('k_weak_partials'), 'adam': first('k_adam'),
+                          'slab_sum': first('k_slab_sum'), 'disc_cotangent': first('k_disc_cot')}
+            fg, fd = first('k_disc_fwd<50,false'), first('k_disc_fwd<50,true')
+            if fg is not None and fd is not None:
+                per_launch['disc_fwd'] = (n_g * fg + n_d * fd) / (n_g + n_d)
+            if all(per_launch.get(k) is not None for k in kern if k in per_launch) and 'disc_fwd' in per_launch:
+                counter_bytes = sum(per_launch[k] * v['launches_per_step'] for k, v in kern.items() if k in per_launch)
+                how = 'per-kernel averages x launches per sub-step of this run'
+        if counter_bytes:
+            whole['counter_mbytes_per_step'] = round(counter_bytes / 1e6, 1)
+            whole['frac_hbm_peak_counter'] = round(counter_bytes * per_gpu_rate / 8.0e12, 4)
+            whole['counter_source'] = 'profiles/' + os.path.basename(pmc_path) + ' (' + how + '; counter passes of another run of this command)'
+            roofline['traffic_ratio'] = round(counter_bytes / bytes_step, 1)      # HBM bytes moved / algorithmic bytes of the reference layout, per sub-step
 
     # ---- opt-in exact optimisation, reported separately: reuse v, dv/dt, nabla_x v(t_0) while phi is unchanged ----------
     if world is None:
@@ -381,10 +410,29 @@ def main():
             torch.cuda.empty_cache()
             return out_
         try:
+            if world is not None and os.environ.get('XW_BENCH_FAIL_RANK') == str(rank):       # (test hook: a rank that dies mid-way)
+                raise RuntimeError('XW_BENCH_FAIL_RANK=%d' % rank)
             extras['strong'] = [strong_workload(20, 32, 4096, 'headline batch: Ex4_1 cube d=20, 4096 global paths, N_t=32 (configs[1] sharded)'),
                                 strong_workload(50, 64, 16384, 'configs[2]: Ex4_1 cube d=50, 16384 global paths, N_t=64')]
-        except Exception as e:        # (never at the expense of the headline line -- but every rank must get here or none: a collective)
-            extras['strong'] = {'error': repr(e)[:300]}
+        except Exception as e:
+            if world is None:         # one process: never at the expense of the headline line
+                extras['strong'] = {'error': repr(e)[:300]}
+            else:
+                # Several ranks: the others are inside (or on their way into) a collective of these workloads.  Catching the
+                # exception here and walking on would leave them waiting for ever -- a rank that fails ENDS THE JOB: the launcher
+                # (torch.distributed.run) sees the dead worker, stops the remaining ranks and returns non-zero.
+                import traceback
+                sys.stderr.write('bench.py: rank %d failed in the strong-scaling workloads, ending the job:\n' % rank)
+                traceback.print_exc()
+                sys.stderr.flush()
+                os._exit(3)
+        if world is not None:
+            # ... and a rank whose workloads ran but produced garbage says so to all of them (one MIN all-reduce: every rank
+            # prints / returns the same verdict)
+            ok = torch.tensor([1.0 if all(w_['finite'] for w_ in extras['strong']) else 0.0], dtype=torch.float64,
+                              device='cpu' if torch.distributed.get_backend() == 'gloo' else dev)
+            torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN)
+            extras['strong_finite_on_every_rank'] = bool(ok[0] == 1.0)
     if args.train_iters > 0 and world is None:
         # The reference's own acceptance rule is a stopping rule: train until the relative L2 error drops below 0.01
         # (configs/Ex4_1_funcs.py:36-37).  Same rule here, on the fixed held-out sample (16,384 paths, seed 12345), checked
@@ -532,6 +580,10 @@ def main():
                                        'sub-steps per second over the job; the global batch grows with the rank count; the same run '
                                        'times FIXED global batches too: extras.strong)' % (size, s['N_r'], s['N_r']))
                                       + '; 1 all-reduce per generator, 2 per discriminator sub-step'},
+            # the two FIXED global batches timed over the same ranks (extras.strong has the details): at --gpus 1, 2, 4, 8 these
+            # are the strong-scaling curves -- `value` above is the weak product (rate x ranks) and cannot answer that question
+            'strong_headline_steps_per_s': (extras['strong'][0]['steps_per_s'] if isinstance(extras.get('strong'), list) else None),
+            'strong_configs2_steps_per_s': (extras['strong'][1]['steps_per_s'] if isinstance(extras.get('strong'), list) else None),
             'roofline': roofline, 'cpu_baseline': cpu, 'whole_step': whole,
             'kernels': {k: {'ms': round(v['avg_ms'], 4), 'per_step': round(v['launches_per_step'], 2)} for k, v in sorted(kern.items())},
             'extras': extras,

@@ -225,6 +225,26 @@ def test_bench_launches_its_own_ranks():
     for w in strong:
         assert w['scaling'] == 'strong' and w['steps_per_s'] > 0 and w['finite'] and w['exchange'] and 0 < w['roofline_rank0']['frac'] < 1
     assert out['extras']['rccl'] == {'ranks_seen': 2, 'native_communicator': False, 'in_graph': False, 'backend': 'gloo'}
+    # ... promoted to the top level of the line, so that a scaling record cannot be misread as the weak product alone
+    assert out['strong_headline_steps_per_s'] == strong[0]['steps_per_s'] and out['strong_configs2_steps_per_s'] == strong[1]['steps_per_s']
+    assert out['extras']['strong_finite_on_every_rank'] is True
+
+
+@pytest.mark.timeout(600)
+def test_bench_rank_that_fails_ends_the_job():
+    """A rank that throws inside the strong-scaling workloads must not leave the others waiting in a collective: the job ends
+    with a non-zero code within the timeout (two gloo ranks on the test box's GPU, rank 1 forced to fail)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, XW_DIST_BACKEND='gloo', XW_BENCH_FAIL_RANK='1')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '3', '--repeats', '1',
+                        '--no-cpu-baseline', '--train-iters', '0', '--n_r', '256', '--n_b', '256'],
+                       env=env, capture_output=True, text=True, timeout=500)
+    assert r.returncode != 0
+    assert 'XW_BENCH_FAIL_RANK=1' in r.stderr and not [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
 
 
 # ---- list domains (time-varying balls) under a world: groups smaller than the rank count ------------------------------------

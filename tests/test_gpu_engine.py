@@ -117,12 +117,12 @@ def test_first_iteration_against_reference_vectors(golden_dir, case):
 def test_first_iteration_with_the_hoisted_x_projection_against_reference_vectors(golden_dir, case, monkeypatch):
     """the same comparison with the test network's input layer split into xw_disc_xproj (spatial columns, once per path) and
     xw_disc_fwd_xproj -- on by itself from d = 45 (engine.xproj_min_d), forced here for the smaller ones"""
-    monkeypatch.setenv('XW_XPROJ_MIN_D', '1')
-    G = _first_iteration(golden_dir, case)
+    from xnode_wan_pde_solver_amd.options import EngineOptions
+    G = _first_iteration(golden_dir, case, options=EngineOptions(xproj_min_d=1))
     assert G.ptr('xproj') != 0 and float(G.xproj.abs().sum()) > 0
 
 
-def _first_iteration(golden_dir, case):
+def _first_iteration(golden_dir, case, options=None):
     from utils.auxillary_funcs import L_norm, rel_err
     z, params = load(golden_dir, case)
     fname = str(params.pop('funcs', ''))
@@ -137,7 +137,7 @@ def _first_iteration(golden_dir, case):
         fa, fb, fc = GF.variant(general)
         F = types.SimpleNamespace(func_a=fa, func_b=fb, func_c=fc, func_h=P.func_h, func_f=P.func_f, func_g=P.func_g,
                                   func_u_sol=P.func_u_sol)
-    S = make_solver(params, int(z['seed']), F=F)
+    S = make_solver(params, int(z['seed']), F=F, options=options)
     for tag, net in (('u', S.u_net), ('v', S.v_net)):
         sd = net.state_dict()
         assert list(sd.keys()) == [str(k) for k in z[tag + '_sd_keys']]
@@ -593,8 +593,8 @@ def test_group_substep_runner_matches_the_launch_by_launch_path(tmp_path, name, 
     general: non-identity a_ij(t, x) and the linear reaction c = -0.7 u (the A0 table and xw_weak_contract_general inside the call;
     XW_ELEMENTWISE_SINGLE_SLICE semantics are not involved: b = 0 keeps the pairwise groups allowed)
     hoist: every path-mode group with the x-projection table in front of its test network (XwGroup.xproj), in both forms"""
-    if hoist:
-        monkeypatch.setenv('XW_XPROJ_MIN_D', '1')
+    from xnode_wan_pde_solver_amd.options import EngineOptions
+    opts = EngineOptions(xproj_min_d=1) if hoist else None
     F = P
     if general:
         class F:      # noqa: N801
@@ -615,7 +615,7 @@ def test_group_substep_runner_matches_the_launch_by_launch_path(tmp_path, name, 
     os.chdir(tmp_path)
     try:
         for runner in (True, False):
-            S = make_solver(params, 3, F=F)
+            S = make_solver(params, 3, F=F, options=opts)
             assert S.engine.structure.a_identity != general and S.engine.structure.c_kappa == (-0.7 if general else -1.0)
             S.engine.use_runner = runner
             losses = S.train(report=False)
@@ -1310,9 +1310,9 @@ def test_poisoned_work_buffers_change_nothing(golden_dir, monkeypatch):
     from the allocator is how such a read hides), and nothing may depend on timing -- the same three sub-steps, bit for bit"""
     z, params = load(golden_dir, 'ref_d20_small_midpoint')
     outs = []
+    from xnode_wan_pde_solver_amd.options import EngineOptions
     for poison in ('0', '1'):
-        monkeypatch.setenv('XW_POISON', poison)
-        S = make_solver(params, int(z['seed']))
+        S = make_solver(params, int(z['seed']), options=EngineOptions(poison=poison == '1'))
         domain, pts = first_sample(S)
         G = S.engine.load_group(pts.interioru, pts.interiorv, pts.boundary, domain)
         if poison == '1':

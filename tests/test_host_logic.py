@@ -540,3 +540,24 @@ def test_rank_local_sampling_keeps_the_diagnostic_sample_rank_local():
     assert isinstance(sol._loader(dom, interior_only=True), sampling.Comb_loader)
     sol.world, sol.rank_local_sampling = None, True       # one GPU: the flag means nothing
     assert isinstance(sol._loader(dom, interior_only=True), sampling.Comb_loader)
+
+
+def test_engine_options_are_read_from_the_environment_once_and_in_one_place(monkeypatch):
+    """options.EngineOptions: defaults, the XW_* mapping of from_env(), what plan() would print -- and that engine.py / solver.py
+    read no environment variable themselves"""
+    from xnode_wan_pde_solver_amd.options import EngineOptions
+    for k in list(os.environ):
+        if k.startswith('XW_'):
+            monkeypatch.delenv(k)
+    monkeypatch.delenv('GPU_MAX_HW_QUEUES', raising=False)
+    assert EngineOptions.from_env() == EngineOptions() and EngineOptions().non_default() == {}
+    monkeypatch.setenv('XW_GRAPHS', '0')
+    monkeypatch.setenv('XW_XPROJ_MIN_D', '7')
+    monkeypatch.setenv('XW_ELEMENTWISE_SINGLE_SLICE', '1')
+    monkeypatch.setenv('XW_PRIO_DROP_A', '2')
+    monkeypatch.setenv('XW_REPLICATE_BELOW', '0')
+    o = EngineOptions.from_env()
+    assert o.non_default() == {'use_graphs': False, 'xproj_min_d': 7, 'pairwise_single_slice': False, 'prio_drop_A': 2, 'replicate_below': 0}
+    pkg = os.path.join(ROOT, 'xnode_wan_pde_solver_amd')
+    for name in ('engine.py', 'solver.py'):
+        assert 'os.environ' not in open(os.path.join(pkg, name)).read(), name

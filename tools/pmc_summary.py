@@ -1,6 +1,10 @@
 """HBM traffic per launch from two rocprofv3 counter passes (FETCH_SIZE, WRITE_SIZE; unit KB) -> profiles/rNN_pmc_traffic.json
 
-    python tools/pmc_summary.py <fetch pass: csv or output dir> <write pass: csv or output dir> <out.json>
+    python tools/pmc_summary.py <fetch pass: csv or output dir> <write pass: csv or output dir> <out.json> [<cycle fetch pass> <cycle write pass>]
+
+The optional second pair are the same two passes over tools/cycle_only.py (whole g,g,d cycles, nothing else): their totals
+over the sub-step kernels, divided by the sub-steps they hold (3 x launches of k_disc_rec), are the `cycle` section --
+HBM bytes of an average sub-step, which bench.py prints as whole_step.counter_mbytes_per_step.
 
 FETCH_SIZE is doubled: gfx950 reports half the bytes of coalesced streaming reads (MI355X_MICROARCH.md, HBM section)."""
 import csv, glob, json, os, re, sys, collections
@@ -35,5 +39,18 @@ for k in sorted(set(fetch) | set(write)):
     out['kernels'][k] = {'FETCH_SIZE_KB_avg_per_launch': round(fa, 1), 'launches_FETCH_SIZE': len(f),
                          'WRITE_SIZE_KB_avg_per_launch': round(wa, 1), 'launches_WRITE_SIZE': len(w),
                          'hbm_bytes_per_launch_corrected': int(round((2 * fa + wa) * 1024))}
+if len(sys.argv) > 5:
+    cf, cw = collect(sys.argv[4], 'FETCH_SIZE'), collect(sys.argv[5], 'WRITE_SIZE')
+    # every launch of a sub-step kernel in that run belongs to a whole g,g,d cycle (the group load uses other kernels)
+    sub = lambda k: re.match(r'k_(disc_fwd|disc_rec|disc_cot|disc_xproj|ode_fwd|ode_bwd|weak|bdry|gen_cot|adam|slab_sum|losses)', k) is not None  # noqa: E731
+    ncyc = len(next((v for k, v in cf.items() if k.startswith('k_disc_rec')), []))
+    if ncyc:
+        fb = sum(sum(v) for k, v in cf.items() if sub(k)) * 1024
+        wb = sum(sum(v) for k, v in cw.items() if sub(k)) * 1024
+        out['cycle'] = {'command': 'rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE -- python3 tools/cycle_only.py (two passes)', 'cycles': ncyc,
+                        'substeps': 3 * ncyc, 'fetch_bytes_corrected_per_substep': int(2 * fb / (3 * ncyc)),
+                        'write_bytes_per_substep': int(wb / (3 * ncyc)),
+                        'hbm_bytes_per_substep_corrected': int((2 * fb + wb) / (3 * ncyc)),
+                        'launches_per_cycle': {k: round(len(v) / ncyc, 2) for k, v in sorted(cf.items()) if sub(k)}}
 json.dump(out, open(sys.argv[3], 'w'), indent=1)
 print(json.dumps({k: v['hbm_bytes_per_launch_corrected'] for k, v in out['kernels'].items()}, indent=1))

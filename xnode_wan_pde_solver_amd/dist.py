@@ -35,8 +35,11 @@ class World:
         self.rank = dist.get_rank(group)
         self.size = dist.get_world_size(group)
         self.comm = None
+        from .options import EngineOptions
+        self.replicate_below = int(EngineOptions.from_env().replicate_below)
         if native is None:
-            native = dist.get_backend(group) == 'nccl' and os.environ.get('XW_NATIVE_ALLREDUCE', '1') == '1'
+            from .options import EngineOptions
+            native = dist.get_backend(group) == 'nccl' and EngineOptions.from_env().native_allreduce
         if native:
             self._init_native()
 
@@ -145,7 +148,7 @@ class World:
         lim = self.replicate_below * self.size
         return n < lim and nb < lim
 
-    replicate_below = int(os.environ.get('XW_REPLICATE_BELOW', '16'))
+    replicate_below = 16          # (instance attribute, set in __init__ from options.EngineOptions.replicate_below)
 
     def shard_group(self, du, dv, bd):
         """this rank's slice of a group (every rank sampled the same global group from the same seed).  TOTAL: a group with

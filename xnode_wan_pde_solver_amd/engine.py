@@ -31,6 +31,7 @@ import torch
 
 from . import kernels as KN
 from ._lib import XnwanError
+from .options import EngineOptions
 from .sampling import HIP_HOST_LOCK, _PIN_POOL, Hypercube, _paths
 
 
@@ -156,8 +157,11 @@ class Group:
 
 
 class Engine:
-    def __init__(self, config, setup, u_mod, v_mod, funcs, device, world=None, structure=None):
+    def __init__(self, config, setup, u_mod, v_mod, funcs, device, world=None, structure=None, options=None):
         self.config, self.setup, self.u, self.v, self.funcs, self.dev, self.world = config, setup, u_mod, v_mod, funcs, device, world
+        # every switch comes from ONE object (options.EngineOptions; the XW_* environment is read once, in from_env()); the
+        # attributes below are the working copies -- tests and tools set them directly
+        opt = self.options = options if options is not None else EngineOptions.from_env()
         self.d = setup['dim']
         self.method = KN.method_id(config['solver'])
         # config['adjoint'] (src/model.py:103): the sweeps integrate torchdiffeq's continuous adjoint instead of reversing
@@ -165,8 +169,8 @@ class Engine:
         self.adjoint = bool(config.get('adjoint', False))
         self.alpha = float(config['alpha'])
         self.pollution = 1.0
-        self.verify_structure = os.environ.get('XW_VERIFY_STRUCTURE', '1') == '1'    # (_check_structure)
-        self.packed_load = os.environ.get('XW_PACKED_LOAD', '1') != '0'     # list domains: load_groups_packed
+        self.verify_structure = opt.verify_structure    # (_check_structure)
+        self.packed_load = opt.packed_load     # list domains: load_groups_packed
         self.refill_variants = 8        # captured variants of a group's refill / diagnostic graph before further ones run eagerly
         self.verify_every = 16          # ~3 d + 1 callable evaluations per check: ~1 ms at d = 20, a fifth of an outer iteration
         sp = setup.get('shape_param', [-1, 1])
@@ -191,7 +195,7 @@ class Engine:
         # XW_XPROJ_MIN_D: from which d on.  In the sub-step cycle the split form wins from d ~ 45 on and not below, at 131072 points as at
         # a million (profiles/r05_xproj.txt: headline d = 20 0.488 against 0.473 ms per sub-step -- the small launch is one more dependent
         # node on the critical chain --, d = 20 at 16384 x 64 3.41 against 3.38; d = 50 -1.3 %, BASELINE configs[2] -2.7 %, [3] -6.5 %).
-        self.xproj_min_d = 1 << 30 if self.generic[1] else int(os.environ.get('XW_XPROJ_MIN_D', '45'))
+        self.xproj_min_d = 1 << 30 if self.generic[1] else int(opt.xproj_min_d)
         if self.generic[0] and self.adjoint:
             raise XnwanError('adjoint=True (the continuous adjoint) exists for the MFMA stepper instantiations %s only; u_hidden_dim = %d, '
                              'u_hidden_hidden_dim = %d run on the generic path, which reverses the steps taken (adjoint=False)'
@@ -209,9 +213,9 @@ class Engine:
         #  * such a group never integrates the ODE, so the field's parameters get no gradient; after zero_grad() (None on
         #    torch >= 2.0) Adam SKIPS them -- no moment decay, no step count -- until a group of the sub-iteration has taken an
         #    ODE step: the field range of the blob keeps its own step count (xw_adam lag / skip).
-        self.pairwise_single_slice = os.environ.get('XW_ELEMENTWISE_SINGLE_SLICE', '0') != '1'
-        self.adam_skips_untouched = os.environ.get('XW_ADAM_NO_SKIP', '0') != '1'
-        self.eager_checked = 10 ** 12 if os.environ.get('XW_ALWAYS_CHECK', '0') == '1' else 256
+        self.pairwise_single_slice = opt.pairwise_single_slice
+        self.adam_skips_untouched = opt.adam_skips_untouched
+        self.eager_checked = 10 ** 12 if opt.always_check else 256
         self.field_range = (self.theta.slots[6][0], self.theta.slots[-2][0])      # Win .. Wo.b (nets._u_slots order)
         self._field_touched = False
         self.adam_v = dict(m=z(self.Pv), v=z(self.Pv), step=torch.zeros(1, dtype=torch.int64, device=device))
@@ -222,13 +226,13 @@ class Engine:
         # gradient carried from the previous groups of the same sub-iteration (list domains: the reference calls zero_grad()
         # once per sub-iteration but optimizer.step() after every group, src/training.py:127-138); None = off (one group)
         self.accum_u = self.accum_v = None
-        self.use_streams = os.environ.get('XW_STREAMS', '1') == '1'   # independent kernel chains on side streams
-        self.use_graphs = os.environ.get('XW_GRAPHS', '1') == '1'     # capture each sub-step into a HIP graph and replay it
+        self.use_streams = opt.use_streams   # independent kernel chains on side streams
+        self.use_graphs = opt.use_graphs     # capture each sub-step into a HIP graph and replay it
         # opt-in: v, dv/dt, nabla_x v(t_0) of a group are reused while phi and the sample are unchanged (exact: the
         # reference recomputes identical values in every sub-step of an outer iteration).  Off by default.
-        self.reuse_test_net = os.environ.get('XW_REUSE_V', '0') == '1'
+        self.reuse_test_net = opt.reuse_test_net
         # both forwards store their layer inputs for their backwards (include/xnwan.h: XwOdeFwdJob.act, xw_disc_fwd act)
-        self.keep_activations = os.environ.get('XW_KEEP_ACT', '1') == '1'
+        self.keep_activations = opt.keep_activations
         # The test network's launch is persistent (grid-stride over point tiles) and at 2 blocks per CU it owns every SIMD's
         # register file: the stepper's waves, launched next to it, then wait until it drains.  Capping it below the
         # resident slots leaves SIMDs to the stepper chains.  With the kernel's ticket queues (tiles go to whichever wave is
@@ -239,19 +243,19 @@ class Engine:
         # Round 4: with the generator's sweeps A + boundary at lowered wave priority (prio_drop below) the test network keeps more of
         # the chip: generator sub-step 0.492 / 0.484 / 0.480 / 0.475 ms at 9, 10, 11, 12 sixteenths of the slots -- and 0.545 at 13 (a
         # cliff: the stepper's forward pass no longer finds SIMDs); 12/16.
-        self.v_blocks = int(os.environ.get('XW_V_BLOCKS', '0')) or (12 * 2 * cus) // 16
+        self.v_blocks = int(opt.v_blocks) or (12 * 2 * cus) // 16
         # (discriminator sub-step: only the stepper forward and the x-only sweep run beside it, 33 us of SIMD time: 7/8 of the
         #  slots -- 0.615 ms against 0.638 at 3/4, 0.681 at 15/16, 0.735 at all of them; round 3: 13/16 and 14/16 equal
         #  (cycle 1.537 / 1.538 ms), 15/16 1.626; with the record stored through global instead of flat instructions the
         #  forward is 8 % shorter and the stepper's chain is what the sub-step waits for: 12/16 -- discriminator sub-step
         #  0.586 / 0.562 / 0.566 / 0.569 / 0.654 ms at 11..15 sixteenths, tools/sweep_caps.py)
         #  round 4: 0.583 / 0.566 / 0.563 / 0.566 ms at 11..14 sixteenths: 13/16)
-        self.v_blocks_disc = int(os.environ.get('XW_V_BLOCKS_DISC', '0')) or (13 * 2 * cus) // 16
+        self.v_blocks_disc = int(opt.v_blocks_disc) or (13 * 2 * cus) // 16
         # Narrow tiles (csrc/xw_ode_n4.h, xw_ode_bwd mode bit 4): a 16-path tile of a sweep as four waves of 4 paths instead of one
         # (+ a partner) -- four times the instruction streams, each a shorter chain, at ~1.8 x the matrix-pipe time per path.
         # Used where a sweep runs with SIMDs to spare: sweep B of the generator sub-step (alone on the chip behind the test
         # network), as long as its waves still find a SIMD each.  XW_NARROW: 0 off, 1 auto (default), 2 wherever possible.
-        self.narrow = os.environ.get('XW_NARROW', '1')
+        self.narrow = str(opt.narrow)
         # wave-priority drops of the stepper launches that are not on a sub-step's critical path (include/xnwan.h: xw_ode_bwd mode
         # bits 5..6, XwOdeFwdJob.prio_drop): A = the generator's sweeps A + boundary, X = the discriminator's x-only sweep,
         # F = the discriminator's forward pass, G = the generator's.  A = 3 puts sweeps A + boundary at the test network's own
@@ -263,36 +267,33 @@ class Engine:
         # at 2048 x 64, +0.8 % at 16384 x 64; d = 100: +1.2 % at 8192, +1.3 % at 65536.  Default: 3 up to d = 32, 2 above.
         # The sub-step graphs' four chains are laid out for the HIP runtime's default of FOUR hardware queues: with 5, 6 or 8
         # (GPU_MAX_HW_QUEUES) the headline sub-step takes 0.69 instead of 0.47 ms (tools/hwq.sh; 2 and 3 are as good as 4).
-        try:
-            if int(os.environ.get('GPU_MAX_HW_QUEUES', '4')) > 4:
-                import warnings
-                warnings.warn('GPU_MAX_HW_QUEUES=%s: the sub-step schedule is tuned for the runtime default of 4 hardware queues and '
-                              'measures ~45 %% slower with more' % os.environ['GPU_MAX_HW_QUEUES'], RuntimeWarning, stacklevel=2)
-        except ValueError:
-            pass
-        self.early_slab_sum = os.environ.get('XW_EARLY_SLAB_SUM', '1') == '1'
+        if opt.hw_queues > 4:
+            import warnings
+            warnings.warn('GPU_MAX_HW_QUEUES=%s: the sub-step schedule is tuned for the runtime default of 4 hardware queues and '
+                          'measures ~45 %% slower with more' % opt.hw_queues, RuntimeWarning, stacklevel=2)
+        self.early_slab_sum = opt.early_slab_sum
         # groups of at most this many 16-path tiles (interior + boundary) take the compact schedule of _gen_front_compact (0: never).
         # tools/shard_streams.sh, ms per sub-step wide / compact: 256 paths (+ 256 boundary paths) 0.2489 / 0.2183, 512 0.2609 / 0.2244,
         # 1024 0.2829 / 0.2487, 1536 0.3190 / 0.3108, 2048 0.3490 / 0.3432, 2560 0.3931 / 0.3791, 3072 0.4173 / 0.4272, 4096 0.4698 / 0.4919
-        self.compact_tiles = int(os.environ.get('XW_COMPACT_TILES', '320'))
-        self.prio_drop = {k: int(os.environ.get('XW_PRIO_DROP_' + k, dflt))
-                          for k, dflt in (('A', 3 if self.d <= 32 else 2), ('X', 0), ('F', 0), ('G', 0))}
-        self.use_runner = os.environ.get('XW_RUNNER', '1') == '1'      # one C call per eager group sub-step (xw_substep_*)
+        self.compact_tiles = int(opt.compact_tiles)
+        self.prio_drop = {'A': int(opt.prio_drop_A) if opt.prio_drop_A is not None else (3 if self.d <= 32 else 2),
+                          'X': int(opt.prio_drop_X), 'F': int(opt.prio_drop_F), 'G': int(opt.prio_drop_G)}
+        self.use_runner = opt.use_runner      # one C call per eager group sub-step (xw_substep_*)
         # Measured (profiles/r04_shard_sweep.md): forward and the sweep without weight gradients gain on shards up to ~2048
         # paths (0.302 -> 0.272 ms per sub-step at 512 paths, 0.332 -> 0.294 at 1024, 0.375 -> 0.367 at 2048); the narrow sweep
         # WITH weight gradients only ties the two-wave duo sweep (88 against 83 us alone) and is left to XW_NARROW_SET=fxp; at
         # the headline size everything narrow LOSES (0.502 -> 0.586 ms): those phases are bound by the sum of SIMD time.
-        self.narrow_set = os.environ.get('XW_NARROW_SET', 'fx')
+        self.narrow_set = str(opt.narrow_set)
         self.narrow_tiles = {'f': 192, 'x': 128, 'p': 64}    # largest launch (16-path tiles, all its jobs) that still gains
-        if os.environ.get('XW_NARROW_TILES'):                # (measurements: "f:x:p")
-            self.narrow_tiles = dict(zip('fxp', (int(v_) for v_ in os.environ['XW_NARROW_TILES'].split(':'))))
+        if opt.narrow_tiles:                                 # (measurements: "f:x:p")
+            self.narrow_tiles = dict(zip('fxp', (int(v_) for v_ in str(opt.narrow_tiles).split(':'))))
         self.simds = 4 * cus
         self._phi_version = 0
         self.streams, self._cap = _device_streams(device)
         # several GPUs on RCCL: the exchanges are device-side calls on the current stream (dist.World.capturable), so a
         # sub-step and its exchange(s) are captured into ONE HIP graph instead of graph / host call / graph
         self.capture_exchange = (world is not None and getattr(world, 'capturable', False)
-                                 and os.environ.get('XW_CAPTURE_EXCHANGE', '1') == '1')
+                                 and opt.capture_exchange)
         if self.capture_exchange:
             world.all_reduce(self.scal)           # (zeros) first use outside any capture: RCCL sets up its channels here
 
@@ -779,7 +780,7 @@ class Engine:
         """every buffer the sub-steps of G need, as regions of ONE allocation (Group._arena / _lazy), behind the regions `fields`
         = [(name, shape)] the caller fills itself (load_groups_packed: the sample fields)"""
         dev, d, N, L, Nb, Lb = self.dev, self.d, G.N, G.L, G.Nb, G.Lb
-        poison = os.environ.get('XW_POISON', '0') == '1'
+        poison = self.options.poison
         H = self.H
         # stage activations of every step, written by the forward, read back by the sweeps (183 MB at N = 4096, L = 32)
         ar = KN.ode_act_rows(self.method, H, self.K, self.m) if self.keep_activations and not self.adjoint else 0
@@ -1533,7 +1534,7 @@ class Engine:
                 # Capture refused (typically a user callable that syncs with the host or builds CPU tensors): THIS segment
                 # of THIS group runs eagerly from now on -- several times slower, so say it loudly, once per segment, and
                 # leave every other segment captured (XW_STRICT_GRAPHS=1 turns the cliff into an error)
-                if os.environ.get('XW_STRICT_GRAPHS', '0') == '1':
+                if self.options.strict_graphs:
                     raise
                 import warnings
                 warnings.warn('HIP graph capture of sub-step segment %r failed (%s: %s); this segment now runs as eager kernel launches '

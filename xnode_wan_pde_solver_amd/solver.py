@@ -25,6 +25,7 @@ from . import nets, sampling
 from .sampling import HIP_HOST_LOCK
 from ._lib import XnwanError
 from .engine import Engine
+from .options import EngineOptions
 from .kernels import adam as _adam_kernel
 
 CONFIG_KEYS = ['alpha', 'u_layers', 'u_hidden_dim', 'u_hidden_hidden_dim', 'v_layers', 'v_hidden_dim', 'n1', 'n2',
@@ -171,8 +172,11 @@ class FusedAdam:
 
 class NODE_WAN_solver:
     def __init__(self, params, func_a, func_b, func_c, func_h, func_f, func_g, device, path, stop=None,
-                 func_u_sol=None, p=1, world=None):
+                 func_u_sol=None, p=1, world=None, options=None):
         self.params = params
+        # every switch of the engine and of train()'s loops (options.EngineOptions): filled ONCE from the XW_* environment here
+        # unless the caller hands one in; passed down to the engine, printed by plan()
+        opt = self.options = options if options is not None else EngineOptions.from_env()
         self.func_a, self.func_b, self.func_c = func_a, func_b, func_c
         self.func_h, self.func_f, self.func_g = func_h, func_f, func_g
         self.device = torch.device(device) if not isinstance(device, torch.device) else device
@@ -201,17 +205,17 @@ class NODE_WAN_solver:
                                           # written to the side-effect files and compared while iteration k + 1 runs (same
                                           # values, same files, one iteration later; everything is flushed before train()
                                           # returns).  False: every sub-iteration is synchronised like the reference's loop
-        self.capture_refill = os.environ.get('XW_CAPTURE_REFILL', '1') != '0'
+        self.capture_refill = opt.capture_refill
                                           # the pipelined loop refills its group (path tensors, h, f, g, w, transposes: ~110 small
                                           # kernels) and evaluates the L^p diagnostic by replaying ONE captured graph each
                                           # (Engine.refill_compact, _l_norm_replayed); same arithmetic, same fallback rule as the
                                           # sub-step graphs.  False: eager launches
-        self.defer_list_readback = os.environ.get('XW_DEFER_LIST', '1') != '0'
+        self.defer_list_readback = opt.defer_list_readback
                                           # list domains (11-20 groups per sample) with the sampling thread: an outer iteration's
                                           # sub-steps are queued without a read-back and the NEXT sample's groups are loaded while
                                           # the GPU walks them; one read-back per outer iteration (_list_iteration_deferred).
                                           # False: every sub-iteration is synchronised like the reference's loop
-        self.sampler_process = os.environ.get('XW_SAMPLER_PROCESS', '1') != '0'
+        self.sampler_process = opt.sampler_process
                                           # the time-varying ball domains: the samples are drawn by a forked child process instead
                                           # of a helper thread (sampler_proc.py: the two sides of an outer iteration are ~2000 small
                                           # host operations each and two threads share the interpreter lock); same draws, the
@@ -231,7 +235,7 @@ class NODE_WAN_solver:
             self.u_net.module.bind(self.device)
             self.v_net.module.bind(self.device)
             funcs = dict(a=func_a, b=func_b, c=func_c, h=func_h, f=func_f, g=func_g)
-            self.engine = Engine(self.config, s, self.u_net.module, self.v_net.module, funcs, self.device, world=world)
+            self.engine = Engine(self.config, s, self.u_net.module, self.v_net.module, funcs, self.device, world=world, options=opt)
         self.optimizer_u = FusedAdam(self.u_net.module.blob, self.engine.adam_u, self.config['u_rate'])
         self.optimizer_v = FusedAdam(self.v_net.module.blob, self.engine.adam_v, self.config['v_rate'],
                                      on_step=self.engine.invalidate_test_net)
@@ -469,10 +473,11 @@ class NODE_WAN_solver:
                                                                        if self.world.replicate_below > 0 else 'sharded (empty shares)'),
             'test_net_reuse_inside_an_outer_iteration': bool(self.reuse_test_net),
             'coefficients': eng.structure.describe(),
+            'options_not_at_their_defaults': self.options.non_default(),
         }
 
     def train(self, report=False, report_it=10, show_plt=False):
-        if os.environ.get('XW_SHOW_PLAN', '0') == '1' and self._is_main():
+        if self.options.show_plan and self._is_main():
             print('train() plan: ' + json.dumps(self.plan(report)))
         threads = torch.get_num_threads()
         if self.host_threads:
