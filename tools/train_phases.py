@@ -10,6 +10,8 @@ torch.manual_seed(0)
 S = NODE_WAN_solver(dict(workload_params(20, 4096, 4096, 32), iterations=5), P.func_a, P.func_b, P.func_c, P.func_h, P.func_f, P.func_g,
                     torch.device('cuda'), './', func_u_sol=P.func_u_sol, p=2)
 os.makedirs('/tmp/tt', exist_ok=True); os.chdir('/tmp/tt')
+if 'nooverlap' in sys.argv:     # the diagnostic and the next sample's refill one after the other on the main stream (as up to round 5)
+    S.overlap_diagnostic = False
 S.train()
 n = S.iterations = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 if 'sync' in sys.argv:          # the synchronous loop (what a stop callback or report=True selects), with and without the captured refill

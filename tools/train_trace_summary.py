@@ -33,6 +33,6 @@ print('--- last iteration: start end dur (us), queue, kernel')
 last_e = 0
 for r in rows[j0 + 1:j1 + 1]:
     s, e = (int(r['Start_Timestamp']) - tt) / 1e3, (int(r['End_Timestamp']) - tt) / 1e3
-    if e - s > 6 or s - last_e > 15:
-        print('%8.1f %8.1f %7.1f  q%-2s gap %6.1f  %s' % (s, e, e - s, r['Queue_Id'], s - last_e, re.sub(r'\(.*', '', r['Kernel_Name'].replace('(anonymous namespace)::', ''))[:60]))
+    if e - s > 6 or s - last_e > 15 or 'all' in sys.argv:
+        print('%8.1f %8.1f %7.1f  q%-2s gap %6.1f  %s' % (s, e, e - s, r['Queue_Id'], s - last_e, re.sub(r'\(.*', '', r['Kernel_Name'].replace('(anonymous namespace)::', ''))[:60] if 'all' not in sys.argv else r['Kernel_Name'].replace('at::native::', '').replace('(anonymous namespace)::', '')[:150]))
     last_e = max(last_e, e)

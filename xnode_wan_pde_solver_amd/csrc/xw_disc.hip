@@ -171,6 +171,14 @@ __global__ void __launch_bounds__(256, XW_DISC_FWD_WAVES) k_disc_fwd(const doubl
       sT[idx] = k < W ? ph[o.Vh + (long)(16 * (D::MT - 1) + r) * W + k] : 0.0;
     }
   __syncthreads();
+#ifdef XW_DISC_STAGGER   // experiment: the two waves of a SIMD (different blocks, started together) out of phase by part of a layer
+  {
+    unsigned hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    if (hw & 1u)
+      for (int i_ = 0; i_ < XW_DISC_STAGGER; ++i_) __builtin_amdgcn_s_sleep(16);      // ~1024 clocks per iteration
+  }
+#endif
   const double vob = ph[o.Vob];
   // Static split: wave gw takes tiles gw, gw + G, ... (G waves in the grid), so ntiles mod G waves carry one tile more
   // than the others.  The tiles of the first time index also run the fused reverse chain (about one more tile's worth of
@@ -806,7 +814,14 @@ template <int W> __device__ __forceinline__ double rec_readT(const double* set, 
   return set[RecLds<W>::toff(mt) + row * XW_TSTRIDE + 4 * ks + (l >> 4)];
 }
 
-template <int W, int Q, int NG>
+// TSUM (path mode, N a multiple of 64: every 64-point unit is 64 consecutive paths at ONE time index): the input layer's
+//   gradient dVin = sum_p delta_0[p] (x) [t_p ; x_p ; 1] is not contracted unit by unit.  A block takes a CONTIGUOUS run of units in
+//   (path group, time index) order -- its waves stay on the same 16 paths while the time index advances -- and x does not move
+//   along a vertical path, so  dVin[:, 1..d] = (sum_l delta_0) (x) x,  dVin.b = rowsum(sum_l delta_0),  dVin[:, 0] = rowsum(sum_l
+//   t_l delta_0):  two running sums in registers per unit (26 multiply-adds) and ONE contraction per path group instead of one
+//   per unit (per unit it was 12 gathered loads, 12 LDS stores, two barriers, 32 matrix instructions and a read-modify-write of
+//   the slab: 11 % of a wave's time, profiles/r04_probe_rec_phases.txt).
+template <int W, int Q, int NG, bool TSUM>
 __global__ void __launch_bounds__(256, RecLds<W>::VT ? 2 : 1) k_disc_rec(const double* __restrict__ xT, const double* __restrict__ tf,
                                                      const double* __restrict__ tpp, const double* __restrict__ ph,
                                                      const double* __restrict__ vbar, int N, int L, int d,
@@ -881,7 +896,17 @@ __global__ void __launch_bounds__(256, RecLds<W>::VT ? 2 : 1) k_disc_rec(const d
 #ifdef XW_REC_PROBE
   unsigned long long phc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, phl = __builtin_amdgcn_s_memtime();
 #endif
-  for (long st = blockIdx.x; st < nsuper; st += gridDim.x) {
+  // TSUM: this block's units [u0, u1) in (path group, time index) order; unit u = (ng, l) is super-tile l (N / 64) + ng
+  const long ngs = N >> 6;
+  const long ub = nsuper / gridDim.x, ur = nsuper % gridDim.x;
+  const long u0 = (long)blockIdx.x * ub + ((long)blockIdx.x < ur ? (long)blockIdx.x : ur), u1 = u0 + ub + ((long)blockIdx.x < ur ? 1 : 0);
+  d4 sumS[D::MT], sumT[D::MT];                       // TSUM: sum_l delta_0, sum_l t_l delta_0 of the current path group
+#pragma unroll
+  for (int mt = 0; mt < D::MT; ++mt) sumS[mt] = sumT[mt] = xw_zero4();
+  bool slab_first = true;                            // (uniform) the block's slab has not been written yet
+  for (long it = TSUM ? u0 : (long)blockIdx.x; it < (TSUM ? u1 : nsuper); it += TSUM ? 1 : (long)gridDim.x) {
+    const long ung = TSUM ? it / L : 0;
+    const long st = TSUM ? (it - ung * L) * ngs + ung : it;
     const Pt pt = locate(st * 4 + wave, P, N, tf, tpp);
     // tile-major record (see k_disc_fwd): this wave's tile is one contiguous stretch, a layer 13 x 512 contiguous bytes
     const long ntile = (P + 15) >> 4;
@@ -1032,63 +1057,96 @@ __global__ void __launch_bounds__(256, RecLds<W>::VT ? 2 : 1) k_disc_rec(const d
         for (int r = 0; r < 4; ++r) dl[mt][r] = open[4 * mt + r] ? nd[mt][r] : 0.0;
     }
     // ---- dl = cotangent of a_0.  Input layer: dVin = dl (x) [t; x; 1], 48 input rows at a time
+    // contraction of a cotangent tile set Dm (chain layout) with the input rows of this wave's 16 points over the block's 64
+    // points; rows: 0 = all of [t; x; 1] (one unit), 1 = [0; x; 1] (a path group's sum over the time indices), 2 = [1; 0; 0]
+    // (the time column from the t-weighted sum).  acc0: what tile 0 of group 0 starts from; the result goes to the slab.
+    auto contract_input = [&](const d4 (&Dm)[D::MT], const int rows, const d4 acc0, d4* keep0) {
 #pragma unroll
-    for (int mt = 0; mt < D::MT; ++mt) {
-      if (mt < D::MT - 1 || !S::VT) xw_writeT(myD + S::toff(mt), dl[mt]);
-      else xw_writeT_n<1>(myD + S::toff(mt), dl[mt]);
-    }
-    const double* xl = xT;                    // laundered: the per-lane row addresses of x and of the slab are formed here,
-    double* sl = slab;                        // not hoisted out of the tile loop into (spilled) registers
-    int gl = g, nl = n;                       // (and copies of the lane coordinates the compiler cannot see through)
-    asm volatile("" : "+s"(xl), "+s"(sl), "+v"(gl), "+v"(nl));
-#pragma unroll
-    for (int grp = 0; grp < NG; ++grp) {
-      const int nct = d + 2 - 48 * grp >= 33 ? 3 : d + 2 - 48 * grp >= 17 ? 2 : 1;     // live 16-row tiles of this group
-#pragma unroll
-      for (int rr = 0; rr < 12; ++rr) {
-        if (rr >= 4 * nct) continue;
-        const int cl = gl + 4 * rr;           // local row 0..47 of this group
-        const int c = 48 * grp + cl;          // input row: 0 = t, 1..d = x, d+1 = ones
-        double val = 0.0;
-        if (pt.valid) {
-          if (c == 0) val = pt.t;
-          else if (c <= d) val = xw_ld_g(xl + (long)(c - 1) * N + pt.n);
-          else if (c == d + 1) val = 1.0;
-        }
-        myR[S::toff(cl >> 4) + (cl & 15) * XW_TSTRIDE + nl] = val;
+      for (int mt = 0; mt < D::MT; ++mt) {
+        if (mt < D::MT - 1 || !S::VT) xw_writeT(myD + S::toff(mt), Dm[mt]);
+        else xw_writeT_n<1>(myD + S::toff(mt), Dm[mt]);
       }
-      __syncthreads();
-      d4 accIn[3];
+      const double* xl = xT;                    // laundered: the per-lane row addresses of x and of the slab are formed here,
+      double* sl = slab;                        // not hoisted out of the tile loop into (spilled) registers
+      int gl = g, nl = n;                       // (and copies of the lane coordinates the compiler cannot see through)
+      asm volatile("" : "+s"(xl), "+s"(sl), "+v"(gl), "+v"(nl));
 #pragma unroll
-      for (int ct = 0; ct < 3; ++ct) accIn[ct] = xw_zero4();
+      for (int grp = 0; grp < NG; ++grp) {
+        if (rows == 2 && grp > 0) break;
+        const int nct = rows == 2 ? 1 : (d + 2 - 48 * grp >= 33 ? 3 : d + 2 - 48 * grp >= 17 ? 2 : 1);     // live 16-row tiles of this group
 #pragma unroll
-      for (int pw = 0; pw < 4; ++pw) {
-        const double* setD = lds + S::oD + pw * S::wset;
-        const double* setR = lds + S::oR + pw * S::wset;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          const double av = rec_readT<W>(setD, wave, ks);
-#pragma unroll
-          for (int ct = 0; ct < 3; ++ct)
-            if (ct < nct) accIn[ct] = XW_MFMA(av, rec_readT<W>(setR, ct, ks), accIn[ct]);
+        for (int rr = 0; rr < 12; ++rr) {
+          if (rr >= 4 * nct) continue;
+          const int cl = gl + 4 * rr;           // local row 0..47 of this group
+          const int c = 48 * grp + cl;          // input row: 0 = t, 1..d = x, d+1 = ones
+          double val = 0.0;
+          if (pt.valid) {
+            if (rows == 2) val = c == 0 ? 1.0 : 0.0;
+            else if (c == 0) val = rows == 0 ? pt.t : 0.0;
+            else if (c <= d) val = xw_ld_g(xl + (long)(c - 1) * N + pt.n);
+            else if (c == d + 1) val = 1.0;
+          }
+          myR[S::toff(cl >> 4) + (cl & 15) * XW_TSTRIDE + nl] = val;
         }
-      }
-      __syncthreads();
-      // dVin is touched once per 64 points: it is accumulated in the block's slab (L2), not in 24 registers per group that
-      // would be live through every layer above.  Wave `wave` owns rows [16 wave, 16 wave + 16).
-      const bool first = st == (long)blockIdx.x;
+        __syncthreads();
+        d4 accIn[3];
 #pragma unroll
-      for (int ct = 0; ct < 3; ++ct) {
-        if (ct >= nct) continue;
-        const int c = 48 * grp + 16 * ct + nl;
+        for (int ct = 0; ct < 3; ++ct) accIn[ct] = xw_zero4();
+        if (grp == 0) accIn[0] = acc0;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = 16 * wave + gl + 4 * r;
-          if (row < W && c <= d + 1) {
-            double* dst = c <= d ? sl + o.Vin + row * o.ldin + c : sl + o.Vinb + row;
-            xw_st_g(first ? accIn[ct][r] : xw_ld_g(dst) + accIn[ct][r], dst);
+        for (int pw = 0; pw < 4; ++pw) {
+          const double* setD = lds + S::oD + pw * S::wset;
+          const double* setR = lds + S::oR + pw * S::wset;
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) {
+            const double av = rec_readT<W>(setD, wave, ks);
+#pragma unroll
+            for (int ct = 0; ct < 3; ++ct)
+              if (ct < nct) accIn[ct] = XW_MFMA(av, rec_readT<W>(setR, ct, ks), accIn[ct]);
           }
         }
+        __syncthreads();
+        if (keep0 != nullptr) {                 // (the time-column pass: its tile is what the next pass starts from)
+          *keep0 = accIn[0];
+          break;
+        }
+        // dVin is touched once per contraction: it is accumulated in the block's slab (L2), not in 24 registers per group that
+        // would be live through every layer above.  Wave `wave` owns rows [16 wave, 16 wave + 16).
+#pragma unroll
+        for (int ct = 0; ct < 3; ++ct) {
+          if (ct >= nct) continue;
+          const int c = 48 * grp + 16 * ct + nl;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = 16 * wave + gl + 4 * r;
+            if (row < W && c <= d + 1) {
+              double* dst = c <= d ? sl + o.Vin + row * o.ldin + c : sl + o.Vinb + row;
+              xw_st_g(slab_first ? accIn[ct][r] : xw_ld_g(dst) + accIn[ct][r], dst);
+            }
+          }
+        }
+      }
+    };
+    if (!TSUM) {
+      contract_input(dl, 0, xw_zero4(), nullptr);
+      slab_first = false;
+    } else {
+      const double tl = pt.t;                   // (one time index per unit)
+#pragma unroll
+      for (int mt = 0; mt < D::MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (r < D::LR(mt)) {
+            sumS[mt][r] += dl[mt][r];
+            sumT[mt][r] = fma(tl, dl[mt][r], sumT[mt][r]);
+          }
+      if (it + 1 == u1 || (it + 1) / L != ung) {           // (uniform) the path group ends here: contract its sums
+        d4 tcol;
+        contract_input(sumT, 2, xw_zero4(), &tcol);
+        contract_input(sumS, 1, tcol, nullptr);
+        slab_first = false;
+#pragma unroll
+        for (int mt = 0; mt < D::MT; ++mt) sumS[mt] = sumT[mt] = xw_zero4();
       }
     }
     XW_PH(7)
@@ -1328,8 +1386,12 @@ extern "C" int xw_disc_bwd(const double* xT, const double* t, const double* tpp,
   double* gtv = nullptr;
   if (act != nullptr) {
     const int ng = d + 2 <= 48 ? 1 : d + 2 <= 96 ? 2 : 3;
+    // (vertical paths in whole 64-path groups: the input layer's gradient once per path group, see k_disc_rec)
+    static const bool tsum_on = [] { const char* e = getenv("XW_DISC_REC_TSUM"); return !(e && e[0] == '0'); }();
+    const bool tsum = tsum_on && tpp == nullptr && (N % 64) == 0;
 #define XW_DISC_REC(W_, Q, NG)                                                                                          \
-    hipLaunchKernelGGL((k_disc_rec<W_, Q, NG>), dim3(blocks), dim3(256), 0, s, xT, t, tpp, phi, vbar, N, L, d, gslab, act, q);
+    if (tsum) hipLaunchKernelGGL((k_disc_rec<W_, Q, NG, true>), dim3(blocks), dim3(256), 0, s, xT, t, tpp, phi, vbar, N, L, d, gslab, act, q); \
+    else hipLaunchKernelGGL((k_disc_rec<W_, Q, NG, false>), dim3(blocks), dim3(256), 0, s, xT, t, tpp, phi, vbar, N, L, d, gslab, act, q);
     if (W == 64) {
       if (ng == 1) { XW_DISC_REC(64, 0, 1) } else if (ng == 2) { XW_DISC_REC(64, 0, 2) } else { XW_DISC_REC(64, 0, 3) }
     } else {

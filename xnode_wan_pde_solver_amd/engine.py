@@ -72,10 +72,12 @@ def _device_streams(device):
     return _DEVICE_STREAMS[key]
 
 
-def _scratch_pool():
-    if not _SCRATCH_POOL:
+def _scratch_pool(which=0):
+    """which: graphs that may be replayed CONCURRENTLY (the diagnostic of one outer iteration beside the refill for the next one,
+    solver._iterate_pipelined) must not share scratch memory -- pool 0: refills, pool 1: diagnostics"""
+    while len(_SCRATCH_POOL) <= which:
         _SCRATCH_POOL.append(torch.cuda.graph_pool_handle())
-    return _SCRATCH_POOL[0]
+    return _SCRATCH_POOL[which]
 
 F32, F64 = torch.float32, torch.float64
 
@@ -287,6 +289,10 @@ class Engine:
         self.narrow_tiles = {'f': 192, 'x': 128, 'p': 64}    # largest launch (16-path tiles, all its jobs) that still gains
         if opt.narrow_tiles:                                 # (measurements: "f:x:p")
             self.narrow_tiles = dict(zip('fxp', (int(v_) for v_ in str(opt.narrow_tiles).split(':'))))
+        # ... and for a launch that has the chip to itself (tools/kernel_times.py at 256 / 512 tiles, profiles/r06_kernel_times.txt)
+        self.narrow_tiles_alone = dict(zip('fxp', (int(v_) for v_ in str(opt.narrow_tiles_alone).split(':'))))
+        for k_ in 'fxp':
+            self.narrow_tiles_alone[k_] = max(self.narrow_tiles_alone[k_], self.narrow_tiles[k_])
         self.simds = 4 * cus
         self._phi_version = 0
         self.streams, self._cap = _device_streams(device)
@@ -1119,7 +1125,9 @@ class Engine:
         if self.narrow == '2':
             return True
         tiles = sum((j['xT'].shape[1] + 15) // 16 for j in jobs)
-        return tiles <= self.narrow_tiles[kind]
+        # `alone`: nothing else runs beside this launch (the test network is reused / this is a lone evaluation) -- the narrow
+        # forms then gain up to larger launches (narrow_tiles_alone), they need SIMDs to spare, not a short chain only
+        return tiles <= (self.narrow_tiles_alone if alone else self.narrow_tiles)[kind]
 
     def _job(self, G, which, ubar=None, gslab=None, want_x=False):
         if which == 'i':
@@ -1243,7 +1251,13 @@ class Engine:
         """small groups (shards of a strong-scaling job, small problems): the sub-step is a chain of dependent launches whose
         every cross-queue dependency edge costs ~12 us -- the compact schedule below has one instead of three"""
         tiles = (G.N + 15) // 16 + ((G.Nb + 15) // 16 if G.Nb else 0)
-        return self.compact_tiles > 0 and tiles <= self.compact_tiles and self.use_streams and fused_x and joint
+        if not (self.compact_tiles > 0 and self.use_streams and fused_x and joint):
+            return False
+        # ... and ANY group whose test network is not evaluated in this sub-step (v, dv/dt, nabla_x v(t_0) reused while phi and the
+        # sample are unchanged: the second generator sub-iteration of train()): nothing holds sweep B back, the chip is empty, and
+        # the three sweep jobs in one launch take 146 us where sweeps A + boundary (139) and B (94) followed each other -- as branches
+        # of the wide graph they land on one hardware queue behind the reduction (profiles/r06_train_timeline.txt)
+        return tiles <= self.compact_tiles or bool(getattr(G, 'skip_v', False))
 
     def _gen_front_compact(self, G):
         """_gen_front for a group that leaves the chip mostly idle: test network (main) || forward pass (side 1), then ON THE MAIN
@@ -1257,7 +1271,8 @@ class Engine:
             self._launch_test_net_here(G)
         with self._side(1, e0):
             fwd = [self._job(G, 'i'), self._job(G, 'b')]
-            KN.ode_fwd_multi(fwd, G.t, th, *M, zero16=self.scal, narrow=self._narrow_ok(fwd, alone=False, forward=True),
+            lone = bool(getattr(G, 'skip_v', False))
+            KN.ode_fwd_multi(fwd, G.t, th, *M, zero16=self.scal, narrow=self._narrow_ok(fwd, alone=lone, forward=True),
                              prio_drop=self.prio_drop['G'])
             self._reaction(G)
             e_f = self._mark()
@@ -1270,7 +1285,7 @@ class Engine:
                   dict(self._job(G, 'b', None, G.slabA[G.ns_u:]), res=res_b),
                   dict(self._job(G, 'i', None, G.slabB), res=res_B)]
         KN.ode_bwd_multi(sweeps, G.t, th, *M, want_x=True, want_params=True, x_cot_ones=True, adjoint=self.adjoint,
-                         narrow=self._narrow_ok(sweeps, alone=False))
+                         narrow=self._narrow_ok(sweeps, alone=bool(getattr(G, 'skip_v', False))))
         G.sumA_ready = False
         self._contract(G, self.adam_u, with_bdry=True)
 
@@ -1407,12 +1422,13 @@ class Engine:
         with self._side(1, e0):
             # (the only sweep of this sub-step has no weight gradients: the forward stores a seventh of the record)
             fwd = [self._job(G, 'i')]
-            KN.ode_fwd_multi(fwd, G.t, th, *M, zero16=self.scal, act_x_only=True, narrow=self._narrow_ok(fwd, alone=False, forward=True),
+            lone = bool(getattr(G, 'skip_v', False))          # (the test network is reused: this chain has the chip to itself)
+            KN.ode_fwd_multi(fwd, G.t, th, *M, zero16=self.scal, act_x_only=True, narrow=self._narrow_ok(fwd, alone=lone, forward=True),
                              prio_drop=self.prio_drop['F'])
             self._reaction(G)
             sweep_x = [self._job(G, 'i', want_x=True)]
             KN.ode_bwd_multi(sweep_x, G.t, th, *M, want_x=True, want_params=False, adjoint=self.adjoint,
-                             narrow=self._narrow_ok(sweep_x, alone=False, params=False), prio_drop=self.prio_drop['X'])
+                             narrow=self._narrow_ok(sweep_x, alone=lone, params=False), prio_drop=self.prio_drop['X'])
             e_x = self._mark()
         self._join(e_x)
         self._contract(G, self.adam_v)
@@ -1495,7 +1511,7 @@ class Engine:
     # ------------------------------------------------------------------------------------------------------------
     def _run(self, G, key, fn, scratch=False):
         """execute fn(G) eagerly, or capture it once into a HIP graph (per group and segment) and replay it.
-        scratch: fn allocates while it runs and leaves nothing behind in what it allocated (_SCRATCH_POOL)"""
+        scratch: fn allocates while it runs and leaves nothing behind in what it allocated (True / 1: scratch pool 0, 2: pool 1)"""
         # (a pairwise group carries per-sample host constants -- the variance offsets -- into its launches: never captured)
         capturable = (self.use_graphs and self.accum_u is None and self.accum_v is None and getattr(G, 'persistent', True)
                       and not (G.pair_i or G.pair_b))
@@ -1527,7 +1543,7 @@ class Engine:
             try:
                 # thread_local: other threads (the RCCL watchdog polls events) must not invalidate the capture
                 # (HIP_HOST_LOCK: no page-locked allocation of the sampling helper thread during a capture or a launch)
-                with HIP_HOST_LOCK, torch.cuda.graph(g, pool=_scratch_pool() if scratch else None, stream=self._capture_stream(),
+                with HIP_HOST_LOCK, torch.cuda.graph(g, pool=_scratch_pool(int(scratch) - 1) if scratch else None, stream=self._capture_stream(),
                                                      capture_error_mode='thread_local'):
                     fn(G)
             except Exception as exc:

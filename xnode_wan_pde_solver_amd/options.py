@@ -36,6 +36,7 @@ class EngineOptions:
     narrow: str = '1'                   # XW_NARROW: narrow stepper tiles -- 0 off, 1 auto, 2 wherever possible
     narrow_set: str = 'fx'              # XW_NARROW_SET: which launches may go narrow (f forward, x x-only sweep, p sweep with weight gradients)
     narrow_tiles: Optional[str] = None  # XW_NARROW_TILES: "f:x:p" largest launches (16-path tiles) that still go narrow
+    narrow_tiles_alone: str = '256:256:64'   # XW_NARROW_TILES_ALONE: the same for a launch that has the chip to itself (test network reused)
     early_slab_sum: bool = True         # XW_EARLY_SLAB_SUM
     compact_tiles: int = 320            # XW_COMPACT_TILES: groups up to this many tiles take the compact generator schedule
     prio_drop_A: Optional[int] = None   # XW_PRIO_DROP_A: wave-priority drop of the generator's sweeps A + boundary (None: 3 up to d = 32, 2 above)
@@ -76,6 +77,7 @@ class EngineOptions:
         o.narrow = os.environ.get('XW_NARROW', o.narrow)
         o.narrow_set = os.environ.get('XW_NARROW_SET', o.narrow_set)
         o.narrow_tiles = os.environ.get('XW_NARROW_TILES') or None
+        o.narrow_tiles_alone = os.environ.get('XW_NARROW_TILES_ALONE') or o.narrow_tiles_alone
         o.early_slab_sum = _flag('XW_EARLY_SLAB_SUM', o.early_slab_sum)
         o.compact_tiles = _int('XW_COMPACT_TILES', o.compact_tiles)
         o.prio_drop_A = _int('XW_PRIO_DROP_A', None)
