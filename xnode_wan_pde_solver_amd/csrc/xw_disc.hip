@@ -171,14 +171,9 @@ __global__ void __launch_bounds__(256, XW_DISC_FWD_WAVES) k_disc_fwd(const doubl
       sT[idx] = k < W ? ph[o.Vh + (long)(16 * (D::MT - 1) + r) * W + k] : 0.0;
     }
   __syncthreads();
-#ifdef XW_DISC_STAGGER   // experiment: the two waves of a SIMD (different blocks, started together) out of phase by part of a layer
-  {
-    unsigned hw;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-    if (hw & 1u)
-      for (int i_ = 0; i_ < XW_DISC_STAGGER; ++i_) __builtin_amdgcn_s_sleep(16);      // ~1024 clocks per iteration
-  }
-#endif
+  // (starting the two waves of a SIMD -- different blocks, launched together -- out of phase by part of a layer changes nothing:
+  //  220.4 / 222.0 / 221.5 us at 0 / 2048 / 4096 clocks of offset, profiles/r06_disc_fwd_stagger.txt; a lone wave per SIMD already
+  //  reaches 91 % of the two-wave rate)
   const double vob = ph[o.Vob];
   // Static split: wave gw takes tiles gw, gw + G, ... (G waves in the grid), so ntiles mod G waves carry one tile more
   // than the others.  The tiles of the first time index also run the fused reverse chain (about one more tile's worth of

@@ -191,12 +191,14 @@ __device__ __forceinline__ void load_field_T(const double* __restrict__ th, cons
 // tanh, output layer.  y/out: HT chain tiles.
 // Where the layer inputs of an evaluation go: nowhere, into registers (Save), or straight to the activation store.
 struct SinkNone {
+  __device__ __forceinline__ void fence() const {}
   __device__ __forceinline__ double relu(int, int, double z) const { return xw_relu1(z); }
   __device__ __forceinline__ void z(int, d4) const {}
   __device__ __forceinline__ void a(d4) const {}
 };
 template <int M> struct SinkSave {
   Save<M>& sv;
+  __device__ __forceinline__ void fence() const {}
   __device__ __forceinline__ double relu(int, int, double z) const { return xw_relu1(z); }
   __device__ __forceinline__ void z(int j, d4 r) const { sv.z[j] = r; }
   __device__ __forceinline__ void a(d4 v) const { sv.a = v; }
@@ -218,6 +220,7 @@ __device__ __forceinline__ void field_fwd(const FieldW<H, K>& w, double t, d4 xp
     d4 r = xw_zero4();
 #pragma unroll
     for (int kb = 0; kb < D::KB; ++kb) r[kb] = sink.relu(j, kb, z[kb]);
+    sink.fence();
     sink.z(j, r);
     d4 nz = w.bh;
 #pragma unroll
@@ -760,15 +763,23 @@ template <int K, int M, bool FULL = true> struct SinkAct {
   // instructions per step); as inline assembly it would escape the hazard recogniser, which must keep a VALU read 6+ wait
   // states behind the MFMA that wrote z -- so the assembly takes the mask word as an (unused) operand: it then follows the
   // compare, a visible read of the same MFMA result for which the wait states have been inserted.
-  __device__ __forceinline__ double relu(int, int, double z) const {
+  __device__ __forceinline__ double relu(int, int kb, double z) const {
+    const bool kb_last = kb == (K + 3) / 4 - 1;
     // (the compare is compiler-visible -- it is the read of z the hazard recogniser sees --, its lane mask goes into the
     //  assembly as a scalar pair and becomes the carry-in of  word = word + word + carry;  written in C the compiler
     //  turns the add-with-carry back into compare + select + shift-or)
     const unsigned long long open = __builtin_amdgcn_ballot_w64(z > 0.0);
     double r;
-    asm("v_addc_co_u32_e64 %1, vcc, %1, %1, %3\n\tv_max_f64 %0, %2, 0\n\ts_nop 1" : "=v"(r), "+v"(bits) : "v"(z), "s"(open) : "vcc");
+    // (a matrix instruction may not read the maximum in the two issue slots behind it -- without any wait state the x-only form,
+    //  which stores nothing in between, fed stale registers to the next layer: round 6, test_ode_narrow_tile_sweeps -- and the
+    //  compiler does not look into the assembly.  A layer's registers are rectified back to back and fence() keeps the next layer's
+    //  matrix instructions behind all of them, so only the LAST register of a layer needs the two slots spelled out: the others
+    //  have the next register's two instructions behind them.  A lone wave pays ~5 clocks per s_nop: 14 per time step now, 42 before.)
+    if (kb_last) asm("v_addc_co_u32_e64 %1, vcc, %1, %1, %3\n\tv_max_f64 %0, %2, 0\n\ts_nop 1" : "=v"(r), "+v"(bits) : "v"(z), "s"(open) : "vcc");
+    else asm("v_addc_co_u32_e64 %1, vcc, %1, %1, %3\n\tv_max_f64 %0, %2, 0" : "=v"(r), "+v"(bits) : "v"(z), "s"(open) : "vcc");
     return r;
   }
+  __device__ __forceinline__ void fence() const { __builtin_amdgcn_sched_barrier(0); }
   __device__ __forceinline__ void z(int j, d4 r) const {
     if (FULL) act_store(A, row0 + j * K, K, N, q, r);
   }
