@@ -12,6 +12,7 @@
 //
 // Memory traffic per path: x (d floats) once, the checkpoint y[L,H] written once / read once, u[L] -- everything else
 // stays on chip.  At the headline size this kernel is bound by the FP64 matrix pipe, not by HBM.
+#include <cstdlib>
 #include <type_traits>
 #include "xw_common.h"
 #ifndef XW_ODE_FWD_WAVES
@@ -546,6 +547,7 @@ struct BwdJobs {
   int n;
   int x_ones;                  // gx, gs are those of the all-ones cotangent (ubar == 1 at every time index >= 1)
   int prio;                    // wave priority of this launch: XW_ODE_PRIO unless mode bits 5..6 lower it (XW_ODE_PRIO - bits)
+  int spread;                  // duo sweep: spacer rounds of this many blocks between the rounds of tiles (k_ode_bwd_duo), 0 = none
   // cotangent from a residual (XwOdeBwdJob.res_*): ubar[l][n] = base + coef (res_u[l][n] - ref)
   const double* res_u[XW_MAXJOBS];
   const double* res_ref[XW_MAXJOBS];
@@ -1736,8 +1738,20 @@ template <int H, int K, int M, int METHOD>
 __global__ void __launch_bounds__(XW_DUO_THREADS) k_ode_bwd_duo(const BwdJobs jobs, const double* __restrict__ tf,
                                                                 const double* __restrict__ th, int L, int d) {
   __shared__ double lds[2 * DuoPlan<H, K, M>::BUF];
-  if (threadIdx.x < 64) sweep_body<H, K, M, METHOD, true, true, false, true>(jobs, tf, th, L, d, nullptr, lds, (int)blockIdx.x);
-  else duo_outer<H, K, M, METHOD>(jobs, tf, th, L, d, lds, (int)blockIdx.x);
+  // jobs.spread (= the chip's CU count, 0: off): every second ROUND of blocks is a spacer that ends at once.  The dispatcher deals
+  // blocks round-robin over the CUs and starts a CU's next block one SIMD further than the last (profiles/r02_probe_place.txt):
+  // two of these two-wave blocks on a CU sit on SIMDs (0, 1) and (1, 2) -- one SIMD hosts a chain wave AND a partner wave, one
+  // stands idle, and a launch of 512 tiles takes 142 us where 256 take 92.  With a spacer round in between the second block
+  // starts on SIMD 2: (0, 1), (2, 3).
+  int vb = (int)blockIdx.x;
+  if (jobs.spread > 0) {
+    const int round = vb / jobs.spread;
+    if (round & 1) return;
+    vb -= (round >> 1) * jobs.spread;
+    if (vb >= jobs.tile0[jobs.n]) return;
+  }
+  if (threadIdx.x < 64) sweep_body<H, K, M, METHOD, true, true, false, true>(jobs, tf, th, L, d, nullptr, lds, vb);
+  else duo_outer<H, K, M, METHOD>(jobs, tf, th, L, d, lds, vb);
 }
 
 #include "xw_ode_n4.h"
@@ -1790,14 +1804,23 @@ int launch_bwd(int method, const BwdJobs& jobs, const double* t, const double* t
   for (int i = 0; i < jobs.n; ++i) act = act && jobs.act[i] != nullptr;
   if (adj || !act || method > 1)      // (the recomputing sweeps live in an object of their own: XW_ODE_PART_RECOMP below)
     return XW_ODE_FN(xw_ode_bwd_recomp_w)(&jobs, t, theta, method, L, d, M, PARAMS ? 1 : 0, adj ? 1 : 0, (void*)s);
-  const dim3 duo_grid(jobs.tile0[jobs.n]);
+  // two rounds of tiles over the CUs: a spacer round in between (k_ode_bwd_duo)
+  static const int spread_on = [] { const char* e = getenv("XW_DUO_SPREAD"); return e ? atoi(e) : 1; }();
+  static const int ncu = [] { int dev = 0, n = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0; return n; }();
+  const int tiles = jobs.tile0[jobs.n];
+  BwdJobs jd = jobs;
+  // (exactly two rounds: 103 against 142 us at 512 tiles; with three rounds the third block of a CU meets the first again either
+  //  way -- 149 against 145 us --, and from four rounds on every SIMD hosts two waves whatever the order)
+  jd.spread = (spread_on && ncu > 0 && tiles > ncu && tiles <= 2 * ncu) ? ncu : 0;
+  const int rounds = jd.spread ? (tiles + ncu - 1) / ncu : 0;
+  const dim3 duo_grid(jd.spread ? (2 * (rounds - 1)) * ncu + (tiles - (rounds - 1) * ncu) : tiles);
   switch (method) {
     case 0:
-      if (PARAMS) hipLaunchKernelGGL((k_ode_bwd_duo<H, K, M, 0>), duo_grid, dim3(XW_DUO_THREADS), 0, s, jobs, t, theta, L, d);
+      if (PARAMS) hipLaunchKernelGGL((k_ode_bwd_duo<H, K, M, 0>), duo_grid, dim3(XW_DUO_THREADS), 0, s, jd, t, theta, L, d);
       else hipLaunchKernelGGL((k_ode_bwd<H, K, M, 0, false, true>), grid, block, 0, s, jobs, t, theta, L, d);
       break;
     case 1:
-      if (PARAMS) hipLaunchKernelGGL((k_ode_bwd_duo<H, K, M, 1>), duo_grid, dim3(XW_DUO_THREADS), 0, s, jobs, t, theta, L, d);
+      if (PARAMS) hipLaunchKernelGGL((k_ode_bwd_duo<H, K, M, 1>), duo_grid, dim3(XW_DUO_THREADS), 0, s, jd, t, theta, L, d);
       else hipLaunchKernelGGL((k_ode_bwd<H, K, M, 1, false, true>), grid, block, 0, s, jobs, t, theta, L, d);
       break;
     default: return XW_E_ARG;
@@ -1844,6 +1867,7 @@ extern "C" int XW_ODE_FN(xw_ode_bwd_multi_w)(const XwOdeBwdJob* jobs, int njobs,
   BwdJobs J;
   J.n = njobs;
   J.x_ones = (mode & 4) ? 1 : 0;
+  J.spread = 0;
   J.prio = XW_ODE_PRIO - ((mode >> 5) & 3);
   J.tile0[0] = 0;
   for (int i = 0; i < XW_MAXJOBS; ++i) {
