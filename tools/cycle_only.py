@@ -7,7 +7,7 @@ kernels of the sub-steps (k_disc_*, k_ode_*, k_weak_*, k_bdry*, k_gen_cots, k_ad
 k_disc_rec (one per cycle)."""
 import os
 import sys
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch
 import bench as B
 import configs.Ex4_1_funcs as P
