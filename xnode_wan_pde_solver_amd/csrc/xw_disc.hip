@@ -39,7 +39,8 @@ template <int W> struct VDim {
   // W not a multiple of 16: a padding row of the last tile is set to one, so that column W of the dVh outer products
   // collects dVh.b for free; otherwise (W = 64) the bias gradient is summed on the vector ALU
   static constexpr bool BIASROW = (W % 16) != 0;
-  static_assert(MT == 4, "the backward kernels map the 4 row tiles of dVh onto the 4 waves of a block");
+  // (MT = 4: widths 50 and 64, every kernel of this file; MT = 8: the 128-wide container -- forward and reverse from the record)
+  static_assert(MT == 4 || MT == 8, "row tiles of the compiled widths");
 };
 
 // point -> (time, path) ; path mode: p = l*N + n ; point mode (tpp != null): p = n, L == 1
@@ -115,7 +116,7 @@ __device__ unsigned long long xw_clock_buf[2 * 4096];
 // layer do not move along a path -- L = 32..64 times the same d W multiply-adds per path, 12 % of the launch's matrix
 // instructions at d = 100 and 25 + 48 loads per tile)
 template <int W, bool ACT, bool DYN, int VKS>
-__global__ void __launch_bounds__(256, XW_DISC_FWD_WAVES) k_disc_fwd(const double* __restrict__ xT, const double* __restrict__ tf,
+__global__ void __launch_bounds__(256, (W > 64 ? 1 : XW_DISC_FWD_WAVES)) k_disc_fwd(const double* __restrict__ xT, const double* __restrict__ tf,
                                                      const double* __restrict__ tpp, const double* __restrict__ ph, int N,
                                                      int L, int d, int q, double* __restrict__ v, double* __restrict__ vt,
                                                      double* __restrict__ gxv, double* __restrict__ gtv, int ngrad,
@@ -128,7 +129,7 @@ __global__ void __launch_bounds__(256, XW_DISC_FWD_WAVES) k_disc_fwd(const doubl
   __shared__ double sVh[D::MTF * D::KS * 64];
   __shared__ double sB[2 * 16 * D::MT];
   __shared__ double sT[D::KS * 4 * (D::VTAIL ? D::TR : 1)];   // Vh[16 (MT-1) + r][4 ks + g]: the tail rows, per lane group
-  __shared__ unsigned short sMask[XW_QMAX][256];   // ReLU masks (16 rows per lane) of the layers, for the fused reverse chain
+  __shared__ unsigned int sMask[XW_QMAX][256];     // ReLU masks (4 MT rows per lane) of the layers, for the fused reverse chain
   // input layer: Vin[:, 1..d] as A-fragments, Vin[:, 0] and Vin.b as row vectors.  From global memory they were 52 loads per
   // tile (the fragment loads put the four lanes of a quad into four rows) and their address arithmetic, re-formed for
   // every tile to keep them out of the spilled loop-invariant set
@@ -278,7 +279,7 @@ __global__ void __launch_bounds__(256, XW_DISC_FWD_WAVES) k_disc_fwd(const doubl
         for (int mt = 0; mt < D::MT; ++mt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) mask |= (ai[mt][r] > 0.0 ? 1u : 0u) << (4 * mt + r);
-        sMask[j][threadIdx.x] = (unsigned short)mask;
+        sMask[j][threadIdx.x] = mask;
       }
       double tv[D::TR], td[D::TR];                          // partial dot products of the tail rows (this lane's k = 4 ks + g)
 #pragma unroll
@@ -508,6 +509,7 @@ __global__ void __launch_bounds__(256) k_disc_bwd(const double* __restrict__ xT,
                                                   double* __restrict__ gtv) {
   typedef VDim<W> D;
   typedef BwdLds<W> S;
+  static_assert(D::MT == 4, "the recomputing reverse kernel maps the 4 row tiles of dVh onto the 4 waves of a block");
   static_assert(D::BIASROW, "the recomputing reverse kernel takes dVh.b from the ones row");
   __shared__ double lds[S::total];
   double* sVh = lds + S::oVh;
@@ -791,13 +793,17 @@ template <int W> struct RecLds {
   static_assert(!VT || D::LR(D::MT - 1) == 1, "short last row tile: vector-ALU tail + one live 4-row group");
   static constexpr int T3 = VT ? 4 * XW_TSTRIDE : XW_TTILE;       // trimmed last tile
   static constexpr int wset = (D::MT - 1) * XW_TTILE + T3;        // one wave's set of transposed tiles
+  // W = 128: the 131 KB of Vh^T fragments do not fit beside the tile sets (139 KB) -- the reverse chain takes them from L2,
+  // one k-step ahead, like the fused input gradient of k_disc_fwd
+  static constexpr bool FRAG_LDS = D::MT == 4;
   static constexpr int oVhT = 0;                                  // [MTF][KS][64]
-  static constexpr int oTT = oVhT + D::MTF * D::KS * 64;          // [4 KS][TR]: Vh[k][16 (MT-1) + r]
+  static constexpr int oTT = oVhT + (FRAG_LDS ? D::MTF * D::KS * 64 : 0);   // [4 KS][TR]: Vh[k][16 (MT-1) + r]
   static constexpr int oVo = oTT + (VT ? 4 * D::KS * D::TR : 0);  // Vo, zero-padded to 16 MT rows
   static constexpr int oD = oVo + 16 * D::MT;
   static constexpr int oR = oD + 4 * wset;
-  static constexpr int oO = oR + 4 * wset;                        // [16 row slots + dVo.b][4 waves][4 g]
-  static constexpr int total = oO + 17 * 16;
+  static constexpr int oO = oR + 4 * wset;                        // [4 MT row slots + dVo.b][4 waves][4 g]
+  static constexpr int NO = 4 * D::MT;                            // row slots of dVo
+  static constexpr int total = oO + (NO + 1) * 16;
   static_assert(total * 8 <= (VT ? 80 : 160) * 1024, "two blocks per CU (short tail) / one");
   __device__ static constexpr int toff(int mt) { return mt * XW_TTILE; }
 };
@@ -840,26 +846,28 @@ __global__ void __launch_bounds__(256, RecLds<W>::VT ? 2 : 1) k_disc_rec(const d
   const long nsuper = (P + 63) / 64;
   const int nq = Q > 0 ? Q : qrt;
   constexpr int UNROLL = Q > 0 ? Q : 1;
-  static_assert(D::MT == 4, "2 x 2 waves x 2 x 2 tiles of dVh");
+  constexpr int TW = D::MT / 2;                      // 2 x 2 waves x TW x TW tiles of dVh
   const int wi = wave >> 1, wj = wave & 1;
 
-  for (int idx = wave; idx < D::MTF * D::KS; idx += 4) {
-    const int mt = idx / D::KS, ks = idx - mt * D::KS;
-    sVhT[idx * 64 + lane] = xw_fragAT(ph + o.Vh, W, W, W, 16 * mt, 4 * ks);
-  }
+  if (S::FRAG_LDS)
+    for (int idx = wave; idx < D::MTF * D::KS; idx += 4) {
+      const int mt = idx / D::KS, ks = idx - mt * D::KS;
+      sVhT[idx * 64 + lane] = xw_fragAT(ph + o.Vh, W, W, W, 16 * mt, 4 * ks);
+    }
   if (S::VT)
     for (int idx = threadIdx.x; idx < 4 * D::KS * D::TR; idx += blockDim.x) {
       const int r = idx % D::TR, k = idx / D::TR;                        // reverse chain: nd[48 + r] = sum_k Vh[k][48 + r] dl[k]
       sTT[idx] = k < W ? ph[o.Vh + (long)k * W + 16 * (D::MT - 1) + r] : 0.0;
     }
   if (threadIdx.x < 16 * D::MT) sVo[threadIdx.x] = (int)threadIdx.x < W ? ph[o.Vo + threadIdx.x] : 0.0;
-  sO[threadIdx.x] = 0.0;
-  if (threadIdx.x < 16) sO[256 + threadIdx.x] = 0.0;
+  for (int idx = threadIdx.x; idx < (S::NO + 1) * 16; idx += blockDim.x) sO[idx] = 0.0;
   __syncthreads();
 
-  d4 accH[D::MT], accB[D::MT];                       // accB: dVh.b without the ones row (W a multiple of 16)
+  d4 accH[TW * TW], accB[D::MT];                     // accB: dVh.b without the ones row (W a multiple of 16)
 #pragma unroll
-  for (int ct = 0; ct < D::MT; ++ct) accH[ct] = accB[ct] = xw_zero4();
+  for (int ct = 0; ct < TW * TW; ++ct) accH[ct] = xw_zero4();
+#pragma unroll
+  for (int ct = 0; ct < D::MT; ++ct) accB[ct] = xw_zero4();
   // ---- short last row tile (W = 50): dVh = 48 x 48 core on 16x16x4 tiles + the two edges on 4x4x4 blocks.
   // As 4 x 4 tiles of 16 x 16 the outer products ran 16 matrix instructions per k-step for 50 x 51 live entries of 64 x 64
   // (61 %): 7 of the 16 tiles existed for rows 48, 49 / columns 48..50.  Now, per 16 points,
@@ -943,7 +951,7 @@ __global__ void __launch_bounds__(256, RecLds<W>::VT ? 2 : 1) k_disc_rec(const d
       }
     {
       const double s_ = xw_sum_over_n(vb);
-      if (lane == 0) sO[16 * 16 + wave * 4] += s_;
+      if (lane == 0) sO[S::NO * 16 + wave * 4] += s_;
     }
     XW_PH(6)
     // ---- reverse chain, one layer at a time; the next layer's inputs are in flight meanwhile
@@ -980,15 +988,40 @@ __global__ void __launch_bounds__(256, RecLds<W>::VT ? 2 : 1) k_disc_rec(const d
       double tv[D::TR];
 #pragma unroll
       for (int r = 0; r < D::TR; ++r) tv[r] = 0.0;
+      if constexpr (S::FRAG_LDS) {
 #pragma unroll
-      for (int ks = 0; ks < D::KS; ++ks) {
-        const double b = dl[ks >> 2][ks & 3];
-        if ((ks & 1) == 0) asm volatile("" ::: "memory");   // bound the LDS loads in flight (else they are all hoisted -> spills)
+        for (int ks = 0; ks < D::KS; ++ks) {
+          const double b = dl[ks >> 2][ks & 3];
+          if ((ks & 1) == 0) asm volatile("" ::: "memory");   // bound the LDS loads in flight (else they are all hoisted -> spills)
 #pragma unroll
-        for (int mt = 0; mt < D::MTF; ++mt) nd[mt] = XW_MFMA(sVhT[(mt * D::KS + ks) * 64 + lane], b, nd[mt]);
-        if (S::VT) {
+          for (int mt = 0; mt < D::MTF; ++mt) nd[mt] = XW_MFMA(sVhT[(mt * D::KS + ks) * 64 + lane], b, nd[mt]);
+          if (S::VT) {
 #pragma unroll
-          for (int r = 0; r < D::TR; ++r) tv[r] = fma(sTT[(4 * ks + g) * D::TR + r], b, tv[r]);
+            for (int r = 0; r < D::TR; ++r) tv[r] = fma(sTT[(4 * ks + g) * D::TR + r], b, tv[r]);
+          }
+        }
+      } else {
+        // the wide container: Vh^T fragments from L2, requested one k-step ahead (laundered base and lane id: the per-lane
+        // fragment addresses are formed here, not hoisted out of the tile loop into spilled registers)
+        const double* phg = ph;
+        int ll = lane;
+        asm volatile("" : "+s"(phg), "+v"(ll));
+        double fn[D::MT];
+#pragma unroll
+        for (int mt = 0; mt < D::MT; ++mt) fn[mt] = xw_fragAT_l(phg + o.Vh, W, W, W, 16 * mt, 0, ll);
+#pragma unroll
+        for (int ks = 0; ks < D::KS; ++ks) {
+          const double b = dl[ks >> 2][ks & 3];
+          double fc[D::MT];
+#pragma unroll
+          for (int mt = 0; mt < D::MT; ++mt) fc[mt] = fn[mt];
+          if (ks + 1 < D::KS) {
+#pragma unroll
+            for (int mt = 0; mt < D::MT; ++mt) fn[mt] = xw_fragAT_l(phg + o.Vh, W, W, W, 16 * mt, 4 * (ks + 1), ll);
+          }
+          asm volatile("" ::: "memory");
+#pragma unroll
+          for (int mt = 0; mt < D::MT; ++mt) nd[mt] = XW_MFMA(fc[mt], b, nd[mt]);
         }
       }
       if (S::VT) {
@@ -1033,13 +1066,17 @@ __global__ void __launch_bounds__(256, RecLds<W>::VT ? 2 : 1) k_disc_rec(const d
 #pragma unroll
           for (int ks = 0; ks < 4; ++ks) {
             if ((ks & 1) == 0) asm volatile("" ::: "memory");
-            // 2 x 2 tiles of dVh per wave: four operand reads feed four MFMAs (a 1 x 4 strip needs five)
-            const double a0 = rec_readT<W>(setD, 2 * wi, ks), a1 = rec_readT<W>(setD, 2 * wi + 1, ks);
-            const double b0 = rec_readT<W>(setR, 2 * wj, ks), b1 = rec_readT<W>(setR, 2 * wj + 1, ks);
-            accH[0] = XW_MFMA(a0, b0, accH[0]);
-            accH[1] = XW_MFMA(a0, b1, accH[1]);
-            accH[2] = XW_MFMA(a1, b0, accH[2]);
-            accH[3] = XW_MFMA(a1, b1, accH[3]);
+            // TW x TW tiles of dVh per wave: 2 TW operand reads feed TW^2 MFMAs (2 x 2: four reads, four MFMAs; 4 x 4: eight, sixteen)
+            double aa[TW], bb[TW];
+#pragma unroll
+            for (int i_ = 0; i_ < TW; ++i_) {
+              aa[i_] = rec_readT<W>(setD, TW * wi + i_, ks);
+              bb[i_] = rec_readT<W>(setR, TW * wj + i_, ks);
+            }
+#pragma unroll
+            for (int i_ = 0; i_ < TW; ++i_)
+#pragma unroll
+              for (int j_ = 0; j_ < TW; ++j_) accH[i_ * TW + j_] = XW_MFMA(aa[i_], bb[j_], accH[i_ * TW + j_]);
           }
         }
       }
@@ -1055,7 +1092,9 @@ __global__ void __launch_bounds__(256, RecLds<W>::VT ? 2 : 1) k_disc_rec(const d
     // contraction of a cotangent tile set Dm (chain layout) with the input rows of this wave's 16 points over the block's 64
     // points; rows: 0 = all of [t; x; 1] (one unit), 1 = [0; x; 1] (a path group's sum over the time indices), 2 = [1; 0; 0]
     // (the time column from the t-weighted sum).  acc0: what tile 0 of group 0 starts from; the result goes to the slab.
-    auto contract_input = [&](const d4 (&Dm)[D::MT], const int rows, const d4 acc0, d4* keep0) {
+    constexpr int RH = D::MT / 4;             // row tiles of dVin a wave owns: wave, wave + 4, ...
+    struct InAcc { d4 v[RH]; };
+    auto contract_input = [&](const d4 (&Dm)[D::MT], const int rows, const InAcc& acc0, InAcc* keep0) {
 #pragma unroll
       for (int mt = 0; mt < D::MT; ++mt) {
         if (mt < D::MT - 1 || !S::VT) xw_writeT(myD + S::toff(mt), Dm[mt]);
@@ -1084,46 +1123,61 @@ __global__ void __launch_bounds__(256, RecLds<W>::VT ? 2 : 1) k_disc_rec(const d
           myR[S::toff(cl >> 4) + (cl & 15) * XW_TSTRIDE + nl] = val;
         }
         __syncthreads();
-        d4 accIn[3];
+        d4 accIn[RH][3];
 #pragma unroll
-        for (int ct = 0; ct < 3; ++ct) accIn[ct] = xw_zero4();
-        if (grp == 0) accIn[0] = acc0;
+        for (int rh = 0; rh < RH; ++rh) {
+#pragma unroll
+          for (int ct = 0; ct < 3; ++ct) accIn[rh][ct] = xw_zero4();
+          if (grp == 0) accIn[rh][0] = acc0.v[rh];
+        }
 #pragma unroll
         for (int pw = 0; pw < 4; ++pw) {
           const double* setD = lds + S::oD + pw * S::wset;
           const double* setR = lds + S::oR + pw * S::wset;
 #pragma unroll
           for (int ks = 0; ks < 4; ++ks) {
-            const double av = rec_readT<W>(setD, wave, ks);
+            double av[RH], bv[3];
 #pragma unroll
-            for (int ct = 0; ct < 3; ++ct)
-              if (ct < nct) accIn[ct] = XW_MFMA(av, rec_readT<W>(setR, ct, ks), accIn[ct]);
+            for (int rh = 0; rh < RH; ++rh) av[rh] = rec_readT<W>(setD, wave + 4 * rh, ks);
+#pragma unroll
+            for (int ct = 0; ct < 3; ++ct) bv[ct] = ct < nct ? rec_readT<W>(setR, ct, ks) : 0.0;
+#pragma unroll
+            for (int rh = 0; rh < RH; ++rh)
+#pragma unroll
+              for (int ct = 0; ct < 3; ++ct)
+                if (ct < nct) accIn[rh][ct] = XW_MFMA(av[rh], bv[ct], accIn[rh][ct]);
           }
         }
         __syncthreads();
-        if (keep0 != nullptr) {                 // (the time-column pass: its tile is what the next pass starts from)
-          *keep0 = accIn[0];
+        if (keep0 != nullptr) {                 // (the time-column pass: its tiles are what the next pass starts from)
+#pragma unroll
+          for (int rh = 0; rh < RH; ++rh) keep0->v[rh] = accIn[rh][0];
           break;
         }
         // dVin is touched once per contraction: it is accumulated in the block's slab (L2), not in 24 registers per group that
-        // would be live through every layer above.  Wave `wave` owns rows [16 wave, 16 wave + 16).
+        // would be live through every layer above.  Wave `wave` owns rows [16 wave, 16 wave + 16) (+ 64 in the wide container).
 #pragma unroll
-        for (int ct = 0; ct < 3; ++ct) {
-          if (ct >= nct) continue;
-          const int c = 48 * grp + 16 * ct + nl;
+        for (int rh = 0; rh < RH; ++rh)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int row = 16 * wave + gl + 4 * r;
-            if (row < W && c <= d + 1) {
-              double* dst = c <= d ? sl + o.Vin + row * o.ldin + c : sl + o.Vinb + row;
-              xw_st_g(slab_first ? accIn[ct][r] : xw_ld_g(dst) + accIn[ct][r], dst);
+          for (int ct = 0; ct < 3; ++ct) {
+            if (ct >= nct) continue;
+            const int c = 48 * grp + 16 * ct + nl;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int row = 16 * (wave + 4 * rh) + gl + 4 * r;
+              if (row < W && c <= d + 1) {
+                double* dst = c <= d ? sl + o.Vin + row * o.ldin + c : sl + o.Vinb + row;
+                xw_st_g(slab_first ? accIn[rh][ct][r] : xw_ld_g(dst) + accIn[rh][ct][r], dst);
+              }
             }
           }
-        }
       }
     };
+    InAcc zacc;
+#pragma unroll
+    for (int rh = 0; rh < RH; ++rh) zacc.v[rh] = xw_zero4();
     if (!TSUM) {
-      contract_input(dl, 0, xw_zero4(), nullptr);
+      contract_input(dl, 0, zacc, nullptr);
       slab_first = false;
     } else {
       const double tl = pt.t;                   // (one time index per unit)
@@ -1136,8 +1190,8 @@ __global__ void __launch_bounds__(256, RecLds<W>::VT ? 2 : 1) k_disc_rec(const d
             sumT[mt][r] = fma(tl, dl[mt][r], sumT[mt][r]);
           }
       if (it + 1 == u1 || (it + 1) / L != ung) {           // (uniform) the path group ends here: contract its sums
-        d4 tcol;
-        contract_input(sumT, 2, xw_zero4(), &tcol);
+        InAcc tcol;
+        contract_input(sumT, 2, zacc, &tcol);
         contract_input(sumS, 1, tcol, nullptr);
         slab_first = false;
 #pragma unroll
@@ -1186,13 +1240,13 @@ __global__ void __launch_bounds__(256, RecLds<W>::VT ? 2 : 1) k_disc_rec(const d
       }
     }
   } else {
-    // wave (wi, wj) owns row tiles 2 wi, 2 wi + 1 x column tiles 2 wj, 2 wj + 1 of dVh
+    // wave (wi, wj) owns row tiles TW wi .. x column tiles TW wj .. of dVh
 #pragma unroll
-    for (int t4 = 0; t4 < 4; ++t4) {
-      const int c = 16 * (2 * wj + (t4 & 1)) + n;
+    for (int t4 = 0; t4 < TW * TW; ++t4) {
+      const int c = 16 * (TW * wj + (t4 % TW)) + n;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int row = 16 * (2 * wi + (t4 >> 1)) + g + 4 * r;
+        const int row = 16 * (TW * wi + (t4 / TW)) + g + 4 * r;
         if (row < W) {
           if (c < W) slab[o.Vh + row * W + c] = accH[t4][r];
           else if (c == W) slab[o.Vhb + row] = accH[t4][r];
@@ -1221,7 +1275,7 @@ __global__ void __launch_bounds__(256, RecLds<W>::VT ? 2 : 1) k_disc_rec(const d
       for (int wv = 0; wv < 4; ++wv) s_ += sO[(mt * 4 + r) * 16 + wv * 4 + gg];
       slab[o.Vo + tid] = s_;
     } else {
-      for (int wv = 0; wv < 4; ++wv) s_ += sO[16 * 16 + wv * 4];
+      for (int wv = 0; wv < 4; ++wv) s_ += sO[S::NO * 16 + wv * 4];
       slab[o.Vob] = s_;
     }
   }
@@ -1247,7 +1301,7 @@ int bwd_blocks(long P) {
 
 // compiled widths: 50 (the reference's YAML; all kernels) and 64 (container of the widths above 50: forward with the
 // fused input gradient + reverse from the record, any depth; no recomputing reverse kernels)
-static bool disc_width_ok(int W) { return W == 50 || W == 64; }
+static bool disc_width_ok(int W) { return W == 50 || W == 64 || W == 128; }
 // (other widths up to 128: the generic path of xw_generic.hip, always from a record -- row-major there, [rows][columns])
 extern "C" int xw_disc_act_rows(int W, int q) { return ((disc_width_ok(W) && q >= 0) || xwg_disc_ok(1, W, q)) ? (q + 1) * W : XW_E_DIMS; }
 
@@ -1284,7 +1338,8 @@ __global__ void __launch_bounds__(256) k_disc_xproj(const double* __restrict__ x
 extern "C" int xw_disc_xproj(const double* xT, const double* phi, int N, int d, int W, double* xproj, void* stream) {
   if (!xT || !phi || !xproj || N <= 0 || d <= 0) return XW_E_ARG;
   if (!disc_width_ok(W)) return XW_E_DIMS;
-  hipLaunchKernelGGL(k_disc_xproj, dim3((N + 255) / 256, 16), dim3(256), 0, (hipStream_t)stream, xT, phi, N, d, W, xproj);
+  // (the table has 16 MT rows: 64 for the widths 50 and 64, 128 for the 128-wide container; four rows per thread)
+  hipLaunchKernelGGL(k_disc_xproj, dim3((N + 255) / 256, W > 64 ? 32 : 16), dim3(256), 0, (hipStream_t)stream, xT, phi, N, d, W, xproj);
   return xw_launch_status();
 }
 
@@ -1325,7 +1380,8 @@ extern "C" int xw_disc_fwd_xproj(const double* xT, const double* t, const double
     queue = qbase + (size_t)slot * ((XW_DISC_NQ + 1) * XW_DISC_QSTRIDE);
   }
   static const bool vin_on = [] { const char* e = getenv("XW_DISC_VIN_LDS"); return !(e && e[0] == '0'); }();
-  const int vks = xproj != nullptr ? -1 : !vin_on ? 0 : ((d + 3) / 4 <= XW_VIN_KS ? XW_VIN_KS : XW_VIN_KS_WIDE);
+  // (W = 128: the 131 KB of Vh fragments leave no LDS for input-layer fragments -- the x-projection table, or global loads)
+  const int vks = xproj != nullptr ? -1 : (!vin_on || W > 64) ? 0 : ((d + 3) / 4 <= XW_VIN_KS ? XW_VIN_KS : XW_VIN_KS_WIDE);
 #define XW_DISC_FWD2(W_, ACT_, DYN_, VIN_)                                                                                \
   hipLaunchKernelGGL((k_disc_fwd<W_, ACT_, DYN_, VIN_>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, xT, t,  \
                      tpp, phi, N, L, d, q, v, vt, gxv, gtv, ngrad, act, queue, xproj)
@@ -1336,7 +1392,17 @@ extern "C" int xw_disc_fwd_xproj(const double* xT, const double* t, const double
   } else {                                                                                                                \
     if (dyn) XW_DISC_FWD(W_, false, true); else XW_DISC_FWD(W_, false, false);                                            \
   }
-  if (W == 50) { XW_DISC_FWD_W(50) } else { XW_DISC_FWD_W(64) }
+  if (W == 50) { XW_DISC_FWD_W(50) } else if (W == 64) { XW_DISC_FWD_W(64) }
+  else {
+    // 128: one block per CU (the fragments of Vh are 131 KB of LDS, a wave holds up to 512 registers)
+    if (blocks > 256) blocks = 256;
+#define XW_DISC_FWD128(ACT_, DYN_) do { if (vks < 0) XW_DISC_FWD2(128, ACT_, DYN_, -1); else XW_DISC_FWD2(128, ACT_, DYN_, 0); } while (0)
+    const bool dyn128 = dyn && ntiles > 4 * blocks;
+    if (!dyn128) queue = nullptr;
+    if (act != nullptr) { if (dyn128) XW_DISC_FWD128(true, true); else XW_DISC_FWD128(true, false); }
+    else { if (dyn128) XW_DISC_FWD128(false, true); else XW_DISC_FWD128(false, false); }
+#undef XW_DISC_FWD128
+  }
 #undef XW_DISC_FWD_W
 #undef XW_DISC_FWD
 #undef XW_DISC_FWD2
@@ -1387,7 +1453,9 @@ extern "C" int xw_disc_bwd(const double* xT, const double* t, const double* tpp,
 #define XW_DISC_REC(W_, Q, NG)                                                                                          \
     if (tsum) hipLaunchKernelGGL((k_disc_rec<W_, Q, NG, true>), dim3(blocks), dim3(256), 0, s, xT, t, tpp, phi, vbar, N, L, d, gslab, act, q); \
     else hipLaunchKernelGGL((k_disc_rec<W_, Q, NG, false>), dim3(blocks), dim3(256), 0, s, xT, t, tpp, phi, vbar, N, L, d, gslab, act, q);
-    if (W == 64) {
+    if (W == 128) {
+      if (ng == 1) { XW_DISC_REC(128, 0, 1) } else if (ng == 2) { XW_DISC_REC(128, 0, 2) } else { XW_DISC_REC(128, 0, 3) }
+    } else if (W == 64) {
       if (ng == 1) { XW_DISC_REC(64, 0, 1) } else if (ng == 2) { XW_DISC_REC(64, 0, 2) } else { XW_DISC_REC(64, 0, 3) }
     } else {
       if (ng == 1) { XW_DISC_REC(50, 0, 1) } else if (ng == 2) { XW_DISC_REC(50, 0, 2) } else { XW_DISC_REC(50, 0, 3) }

@@ -198,6 +198,8 @@ class Engine:
         # a million (profiles/r05_xproj.txt: headline d = 20 0.488 against 0.473 ms per sub-step -- the small launch is one more dependent
         # node on the critical chain --, d = 20 at 16384 x 64 3.41 against 3.38; d = 50 -1.3 %, BASELINE configs[2] -2.7 %, [3] -6.5 %).
         self.xproj_min_d = 1 << 30 if self.generic[1] else int(opt.xproj_min_d)
+        if self.W > 64 and not self.generic[1]:
+            self.xproj_min_d = 0        # (the 128-wide container: 131 KB of Vh fragments leave no LDS for input-layer fragments -- always the table)
         if self.generic[0] and self.adjoint:
             raise XnwanError('adjoint=True (the continuous adjoint) exists for the MFMA stepper instantiations %s only; u_hidden_dim = %d, '
                              'u_hidden_hidden_dim = %d run on the generic path, which reverses the steps taken (adjoint=False)'
@@ -810,7 +812,7 @@ class Engine:
         if keep_v:
             plan.append(('vact', (KN.disc_act_rows(self.W, self.q), KN.disc_act_cols(L * N))))
         if N and d >= self.xproj_min_d:
-            plan.append(('xproj', (64, N)))                    # Vin[:, 1..d] x + Vin.b per path (_launch_test_net_here)
+            plan.append(('xproj', (KN.disc_xproj_rows(self.W), N)))   # Vin[:, 1..d] x + Vin.b per path (_launch_test_net_here)
         if Nb:
             plan += [('ub', (Lb, Nb)), ('Yb', (Lb, H, Nb))]
         lazy, off = {}, 0

@@ -66,7 +66,8 @@ def method_id(name):
 # Anything wider runs, at its own widths, on the GENERIC path (csrc/xw_generic.hip: per-path / per-point code on the vector ALU,
 # two to three orders of magnitude slower -- there so that every legal configuration of the reference trains).
 ODE_WIDTHS = [(20, 10), (32, 12)]          # (u_hidden_dim, u_hidden_hidden_dim) containers, smallest first
-DISC_WIDTHS = [50, 64]                     # v_hidden_dim containers (W = 50: 3 MFMA row tiles + a 2-row vector tail; 64: 4 tiles)
+DISC_WIDTHS = [50, 64, 128]                # v_hidden_dim containers (W = 50: 3 MFMA row tiles + a 2-row vector tail; 64: 4 tiles;
+                                           # 128 (round 6): 8 tiles, one block per CU, forward + reverse from the record)
 GENERIC_ODE_MAX = (64, 16)                 # csrc/xw_generic.h
 GENERIC_DISC_MAX = 128
 
@@ -285,13 +286,19 @@ def disc_act_cols(P):
     return (P + 15) // 16 * 16
 
 
+def disc_xproj_rows(W):
+    """rows of the x-projection table: the row tiles of the width's kernel (64 for the widths 50 and 64, 128 for 128)"""
+    return 128 if W > 64 else 64
+
+
 def disc_xproj(xT, phi, W, out=None):
-    """the input layer's x-projection per path, [64, N] (rows >= W zero): Vin[:, 1..d] x_n + Vin.b -- for disc_fwd(xproj=...)."""
+    """the input layer's x-projection per path, [disc_xproj_rows(W), N] (rows >= W zero): Vin[:, 1..d] x_n + Vin.b -- for disc_fwd(xproj=...)."""
     _need_gpu()
     d, N = xT.shape
     _chk(xT, F64, (d, N), 'xT'); _chk(phi, F64, (phi_size(d, W),), 'phi')
-    out = torch.empty(64, N, dtype=F64, device=xT.device) if out is None else out
-    _chk(out, F64, (64, N), 'xproj')
+    rows = disc_xproj_rows(W)
+    out = torch.empty(rows, N, dtype=F64, device=xT.device) if out is None else out
+    _chk(out, F64, (rows, N), 'xproj')
     check(lib.xw_disc_xproj(_p(xT), _p(phi), N, d, W, _p(out), _stream()), 'xw_disc_xproj')
     return out
 
@@ -301,7 +308,7 @@ def disc_fwd(xT, t, phi, W, q, tpp=None, want_vt=True, v=None, vt=None, gxv=None
     """v_phi and dv/dt.  Path mode: points (t[l], x_n) -> [L,N].  Point mode (tpp[N]): points (tpp[n], x_n) -> [1,N].
     gxv[d,ngrad] / gtv[ngrad]: also return the input gradient of v at the leading ngrad points (time-major order).
     act[disc_act_rows(W, q), disc_act_cols(L*N)]: also store the layer inputs, for disc_bwd(act=...).
-    xproj[64,N] (path mode, widths 50 / 64): disc_xproj's table -- the input layer then costs one load per row and point."""
+    xproj[disc_xproj_rows(W),N] (path mode, MFMA widths): disc_xproj's table -- the input layer then costs one load per row and point."""
     _need_gpu()
     d, N = xT.shape
     L = 1 if tpp is not None else t.shape[0]
@@ -316,7 +323,7 @@ def disc_fwd(xT, t, phi, W, q, tpp=None, want_vt=True, v=None, vt=None, gxv=None
     if act is not None:
         _chk(act, F64, (disc_act_rows(W, q), disc_act_cols(L * N)), 'act')
     if xproj is not None:
-        _chk(xproj, F64, (64, N), 'xproj')
+        _chk(xproj, F64, (disc_xproj_rows(W), N), 'xproj')
     check(lib.xw_disc_fwd_xproj(_p(xT), _p(t), _p(tpp), _p(phi), N, L, d, W, q, _p(v), _p(vt if want_vt else None), _p(gxv),
                                 _p(gtv), int(ngrad), int(max_blocks), _p(act), _p(xproj), _stream()), 'xw_disc_fwd')
     return v, (vt if want_vt else None)
