@@ -1379,6 +1379,10 @@ extern "C" int xw_disc_fwd_xproj(const double* xT, const double* t, const double
     const unsigned int slot = half * (XW_DISC_SLOTS / 2) + next_slot[half].fetch_add(1) % (XW_DISC_SLOTS / 2);
     queue = qbase + (size_t)slot * ((XW_DISC_NQ + 1) * XW_DISC_QSTRIDE);
   }
+  // (Two 16-point tiles per wave at one wave per SIMD -- every A-fragment read feeding four matrix instructions, 360-410 registers,
+  //  no scratch, results bit-identical -- was built and measured in round 6 and LOSES: 214.9 against 201.4 us without the gradient
+  //  tiles, 273.5 against 220.4 us with them (static split over pairs); profiles/r06_disc_fwd_two_tiles_per_wave.txt.  Two waves of
+  //  one tile each are the better way to fill a SIMD at this width; the kernel was removed again.)
   static const bool vin_on = [] { const char* e = getenv("XW_DISC_VIN_LDS"); return !(e && e[0] == '0'); }();
   // (W = 128: the 131 KB of Vh fragments leave no LDS for input-layer fragments -- the x-projection table, or global loads)
   const int vks = xproj != nullptr ? -1 : (!vin_on || W > 64) ? 0 : ((d + 3) / 4 <= XW_VIN_KS ? XW_VIN_KS : XW_VIN_KS_WIDE);
