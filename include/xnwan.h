@@ -131,9 +131,9 @@ int xw_disc_fwd(const double* xT, const double* t, const double* tpp, const doub
                 int max_blocks, double* act, void* stream);
 /* The same with the x-projection of the input layer HOISTED out of the points (path mode only, tpp == NULL): on vertical paths the d
  * spatial columns of the input layer do not move along a path, so Vin[:, 1..d] x_n + Vin.b is formed once per path by xw_disc_xproj
- * (xproj[16 MT][N]: 64 rows for the widths 50 and 64, 128 for the 128-wide container; rows >= W zero) and a point's input layer is one load and one multiply-add per row -- instead of ceil(d/4) x 4
+ * (xproj[16 MT][N]: 64 rows for the widths 50 and 64, 96 / 128 for the wide containers; rows >= W zero) and a point's input layer is one load and one multiply-add per row -- instead of ceil(d/4) x 4
  * matrix instructions and as many loads of x per 16-point tile, L times per path (12 % of the launch at d = 100).  xproj == NULL: as
- * xw_disc_fwd.  The widths of the MFMA kernels only (50, 64, 128). */
+ * xw_disc_fwd.  The widths of the MFMA kernels only (50, 64, 96, 128). */
 int xw_disc_xproj(const double* xT, const double* phi, int N, int d, int W, double* xproj, void* stream);
 int xw_disc_fwd_xproj(const double* xT, const double* t, const double* tpp, const double* phi,
                       int N, int L, int d, int W, int q, double* v, double* vt, double* gxv, double* gtv, int ngrad,
@@ -147,7 +147,7 @@ int xw_disc_act_rows(int W, int q);
 /* input gradient of <vbar, v> at a set of points (reverse mode, no parameter gradients): gxv[d,N] (nabla_x) and
  * gtv[N] (d/dt), for the N points (t_n, x_n) with t_n = tpp ? tpp[n] : t[0]; vbar[N] or NULL (= ones).
  * (XV.grad of src/loss.py:60-63; the fused step only needs it at the first time index)
- * Compiled for the reference's width and depth, W = 50, q = 9; other depths and W = 64, 128 (XW_E_DIMS here) take the same
+ * Compiled for the reference's width and depth, W = 50, q = 9; other depths and W = 64, 96, 128 (XW_E_DIMS here) take the same
  * gradient from xw_disc_fwd's gxv/gtv outputs, which run at any q <= 16, and scale it by vbar. */
 int xw_disc_gradx(const double* xT, const double* t, const double* tpp, const double* phi, const double* vbar,
                   int N, int d, int W, int q, double* gxv, double* gtv, void* stream);
@@ -155,7 +155,7 @@ int xw_disc_gradx(const double* xT, const double* t, const double* tpp, const do
 int xw_disc_bwd_slabs(int N, int L);
 /* parameter gradient of <vbar, v>: slabs gslab[xw_disc_bwd_slabs][P_v] (input gradient: xw_disc_gradx).
  * act: the record xw_disc_fwd stored for the same phi and points, or NULL (the forward is then recomputed per tile).
- * Any depth q >= 0 and all three widths (W = 50, 64, 128) run from the record; the recomputing form keeps its checkpoints in
+ * Any depth q >= 0 and all four widths (W = 50, 64, 96, 128) run from the record; the recomputing form keeps its checkpoints in
  * registers and is compiled for the reference's W = 50, q = 9 only (XW_E_DIMS otherwise). */
 int xw_disc_bwd(const double* xT, const double* t, const double* tpp, const double* phi, const double* vbar,
                 int N, int L, int d, int W, int q, const double* act, double* gslab, void* stream);
@@ -286,7 +286,7 @@ typedef struct {
   const double *xT, *xvT, *xbT, *t, *tb, *tpp, *xvT_pts;
   const double *start, *start_b, *h, *href, *f, *g, *w, *wt, *w0, *ghT, *gwx0T, *c, *cp, *A0, *B0;
   double *u, *ub, *Y, *Yb, *act, *act_b, *v, *vt, *gxv, *gtv, *gx, *gs, *vbar, *s3x, *vact, *slabA, *slabB, *slab_v, *work_i, *work_b;
-  double *xproj;                  /* [64][N] ([128][N] at W = 128) or NULL: table of xw_disc_xproj -- the test network then runs as xw_disc_fwd_xproj (path mode) */
+  double *xproj;                  /* [64][N] ([96][N] / [128][N] at W = 96 / 128) or NULL: table of xw_disc_xproj -- the test network then runs as xw_disc_fwd_xproj (path mode) */
 } XwGroup;
 /* in-place float64 sum of buf[count] over the ranks, enqueued on `stream`: xw_allreduce's own signature */
 typedef int (*XwExchangeFn)(double* buf, int count, void* ctx, void* stream);

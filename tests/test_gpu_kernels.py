@@ -485,7 +485,7 @@ def test_disc_time_tangent_at_an_exact_zero_preactivation():
     _close(vt.t(), dv, 1e-11, 'dv/dt')
 
 
-@pytest.mark.parametrize('Ww', [64, 100, 128, 51 + 64])          # (64, 128: MFMA containers; 100, 115 handed to the C ABI as they are: the generic path)
+@pytest.mark.parametrize('Ww', [64, 96, 100, 128, 51 + 64])      # (64, 96, 128: MFMA containers; 100, 115 handed to the C ABI as they are: the generic path)
 @pytest.mark.parametrize('N,L,d,q', [(37, 7, 5, 9), (64, 6, 20, 4), (100, 3, 70, 1), (16, 2, 3, 12), (700, 9, 6, 9),
                                      (1100, 32, 6, 2)])     # (the last one: more 64-point groups than blocks -- grid-stride)
 def test_disc_kernels_at_width_64(N, L, d, q, Ww):
@@ -494,7 +494,7 @@ def test_disc_kernels_at_width_64(N, L, d, q, Ww):
     row left for the ones-row trick) against the oracle at v_hidden_dim = 64.  No recomputing reverse kernels at this width."""
     from oracle import refspec as R
     from xnode_wan_pde_solver_amd import kernels as KN
-    if Ww not in (64, 128) and N * L > 1000:
+    if Ww not in (64, 96, 128) and N * L > 1000:
         pytest.skip('the generic path is slow: small cases only')
     cfg = dict(_cfg(), v_hidden_dim=Ww, v_layers=q)
     torch.manual_seed(61)
@@ -512,7 +512,8 @@ def test_disc_kernels_at_width_64(N, L, d, q, Ww):
     xT, tc, blob = x.double().t().contiguous().cuda(), t.double().cuda(), _blob(phi, V_ORDER)
     # (round 6: a 128-wide MFMA container serves v_hidden_dim 65..128; the kernels are called at Ww itself here)
     assert blob.numel() == KN.phi_size(d, Ww) and KN.disc_container(51) == 64 and KN.disc_container(64) == 64
-    assert KN.disc_container(65) == 128 and KN.disc_container(Ww) == (64 if Ww == 64 else 128) and not KN.disc_generic(128)
+    assert KN.disc_container(65) == 96 and KN.disc_container(97) == 128 and KN.disc_container(Ww) == (Ww if Ww in (64, 96) else 128)
+    assert not KN.disc_generic(96) and not KN.disc_generic(128)
     gxv, gtv = torch.empty(d, N, dtype=torch.float64).cuda(), torch.empty(N, dtype=torch.float64).cuda()
     rec = torch.empty(KN.disc_act_rows(Ww, q), KN.disc_act_cols(L * N), dtype=torch.float64).cuda()
     v, vt = KN.disc_fwd(xT, tc, blob, Ww, q, gxv=gxv, gtv=gtv, ngrad=N, act=rec, max_blocks=5)
@@ -539,7 +540,7 @@ def test_disc_kernels_at_width_64(N, L, d, q, Ww):
     _close(vp.view(L, N), v, 1e-13, 'point mode v'); _close(vtp.view(L, N), vt, 1e-13, 'point mode dv/dt')
 
 
-@pytest.mark.parametrize('Ww,q', [(50, 9), (64, 4), (128, 3)])
+@pytest.mark.parametrize('Ww,q', [(50, 9), (64, 4), (96, 2), (128, 3)])
 @pytest.mark.parametrize('N,L,d', [(37, 7, 5), (64, 6, 20), (100, 3, 70), (300, 5, 100), (1100, 32, 50)])
 def test_disc_forward_with_the_hoisted_x_projection(N, L, d, Ww, q):
     """xw_disc_xproj + xw_disc_fwd_xproj (the input layer's spatial columns applied once per path instead of once per point)

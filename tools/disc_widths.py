@@ -4,7 +4,7 @@ import torch
 from xnode_wan_pde_solver_amd import kernels as KN, _lib
 N, L, d, q = 4096, 32, 20, 9
 dev = torch.device('cuda'); g = torch.Generator().manual_seed(0)
-for W in (50, 64, 128):
+for W in (50, 64, 96, 128):
     ph = (0.2 * torch.randn(_lib.lib.xw_phi_size(d, W), generator=g, dtype=torch.float64)).to(dev)
     xT = torch.rand(d, N, generator=g, dtype=torch.float64).to(dev); t = torch.linspace(0, 1, L, dtype=torch.float64).to(dev)
     v = torch.empty(L, N, dtype=torch.float64, device=dev); vt = torch.empty_like(v)

@@ -12,7 +12,15 @@ import torch
 # reference's acceptance rule (configs/Ex4_1_funcs.py:36-37: rel_err after every generator sub-iteration) evaluates it FOUR times
 # per outer iteration on the same [N, L, d+1] tensor (error and norm, twice): one evaluation per sample here.  Keyed by the tensor
 # OBJECT and its version counter (an in-place change is a miss); the entries hold their tensors, so an id is never reused.
+# Scope: the entries are dropped when train() returns (NODE_WAN_solver.train -> clear_exact_cache), so nothing outlives a run; a
+# tensor whose MEMORY is rewritten without a version bump (raw kernels writing through data_ptr, graph replays into static buffers)
+# must not be handed to L_norm / rel_err twice -- the engine's own callers build a fresh tensor per sample.
 _EXACT = []
+
+
+def clear_exact_cache():
+    """forget the cached func_u_sol evaluations (and release the two samples and values they keep alive)"""
+    del _EXACT[:]
 
 
 def _exact(func_u_sol, x):

@@ -39,8 +39,8 @@ template <int W> struct VDim {
   // W not a multiple of 16: a padding row of the last tile is set to one, so that column W of the dVh outer products
   // collects dVh.b for free; otherwise (W = 64) the bias gradient is summed on the vector ALU
   static constexpr bool BIASROW = (W % 16) != 0;
-  // (MT = 4: widths 50 and 64, every kernel of this file; MT = 8: the 128-wide container -- forward and reverse from the record)
-  static_assert(MT == 4 || MT == 8, "row tiles of the compiled widths");
+  // (MT = 4: widths 50 and 64, every kernel of this file; MT = 6, 8: the 96- and 128-wide containers -- forward and reverse from the record)
+  static_assert(MT == 4 || MT == 6 || MT == 8, "row tiles of the compiled widths");
 };
 
 // point -> (time, path) ; path mode: p = l*N + n ; point mode (tpp != null): p = n, L == 1
@@ -1092,7 +1092,7 @@ __global__ void __launch_bounds__(256, RecLds<W>::VT ? 2 : 1) k_disc_rec(const d
     // contraction of a cotangent tile set Dm (chain layout) with the input rows of this wave's 16 points over the block's 64
     // points; rows: 0 = all of [t; x; 1] (one unit), 1 = [0; x; 1] (a path group's sum over the time indices), 2 = [1; 0; 0]
     // (the time column from the t-weighted sum).  acc0: what tile 0 of group 0 starts from; the result goes to the slab.
-    constexpr int RH = D::MT / 4;             // row tiles of dVin a wave owns: wave, wave + 4, ...
+    constexpr int RH = (D::MT + 3) / 4;       // row tiles of dVin a wave owns: wave, wave + 4, ... (below MT)
     struct InAcc { d4 v[RH]; };
     auto contract_input = [&](const d4 (&Dm)[D::MT], const int rows, const InAcc& acc0, InAcc* keep0) {
 #pragma unroll
@@ -1138,7 +1138,7 @@ __global__ void __launch_bounds__(256, RecLds<W>::VT ? 2 : 1) k_disc_rec(const d
           for (int ks = 0; ks < 4; ++ks) {
             double av[RH], bv[3];
 #pragma unroll
-            for (int rh = 0; rh < RH; ++rh) av[rh] = rec_readT<W>(setD, wave + 4 * rh, ks);
+            for (int rh = 0; rh < RH; ++rh) av[rh] = rec_readT<W>(setD, wave + 4 * rh < D::MT ? wave + 4 * rh : wave, ks);   // (a tile the wave does not own: a copy, never stored)
 #pragma unroll
             for (int ct = 0; ct < 3; ++ct) bv[ct] = ct < nct ? rec_readT<W>(setR, ct, ks) : 0.0;
 #pragma unroll
@@ -1165,7 +1165,7 @@ __global__ void __launch_bounds__(256, RecLds<W>::VT ? 2 : 1) k_disc_rec(const d
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const int row = 16 * (wave + 4 * rh) + gl + 4 * r;
-              if (row < W && c <= d + 1) {
+              if (wave + 4 * rh < D::MT && row < W && c <= d + 1) {
                 double* dst = c <= d ? sl + o.Vin + row * o.ldin + c : sl + o.Vinb + row;
                 xw_st_g(slab_first ? accIn[rh][ct][r] : xw_ld_g(dst) + accIn[rh][ct][r], dst);
               }
@@ -1301,7 +1301,7 @@ int bwd_blocks(long P) {
 
 // compiled widths: 50 (the reference's YAML; all kernels) and 64 (container of the widths above 50: forward with the
 // fused input gradient + reverse from the record, any depth; no recomputing reverse kernels)
-static bool disc_width_ok(int W) { return W == 50 || W == 64 || W == 128; }
+static bool disc_width_ok(int W) { return W == 50 || W == 64 || W == 96 || W == 128; }
 // (other widths up to 128: the generic path of xw_generic.hip, always from a record -- row-major there, [rows][columns])
 extern "C" int xw_disc_act_rows(int W, int q) { return ((disc_width_ok(W) && q >= 0) || xwg_disc_ok(1, W, q)) ? (q + 1) * W : XW_E_DIMS; }
 
@@ -1338,8 +1338,8 @@ __global__ void __launch_bounds__(256) k_disc_xproj(const double* __restrict__ x
 extern "C" int xw_disc_xproj(const double* xT, const double* phi, int N, int d, int W, double* xproj, void* stream) {
   if (!xT || !phi || !xproj || N <= 0 || d <= 0) return XW_E_ARG;
   if (!disc_width_ok(W)) return XW_E_DIMS;
-  // (the table has 16 MT rows: 64 for the widths 50 and 64, 128 for the 128-wide container; four rows per thread)
-  hipLaunchKernelGGL(k_disc_xproj, dim3((N + 255) / 256, W > 64 ? 32 : 16), dim3(256), 0, (hipStream_t)stream, xT, phi, N, d, W, xproj);
+  // (the table has 16 MT rows: 64 for the widths 50 and 64, 96 / 128 for the wide containers; four rows per thread)
+  hipLaunchKernelGGL(k_disc_xproj, dim3((N + 255) / 256, W > 96 ? 32 : W > 64 ? 24 : 16), dim3(256), 0, (hipStream_t)stream, xT, phi, N, d, W, xproj);
   return xw_launch_status();
 }
 
@@ -1398,14 +1398,16 @@ extern "C" int xw_disc_fwd_xproj(const double* xT, const double* t, const double
   }
   if (W == 50) { XW_DISC_FWD_W(50) } else if (W == 64) { XW_DISC_FWD_W(64) }
   else {
-    // 128: one block per CU (the fragments of Vh are 131 KB of LDS, a wave holds up to 512 registers)
+    // 96, 128: one block per CU (the fragments of Vh are 74 / 131 KB of LDS, a wave holds up to 512 registers)
     if (blocks > 256) blocks = 256;
-#define XW_DISC_FWD128(ACT_, DYN_) do { if (vks < 0) XW_DISC_FWD2(128, ACT_, DYN_, -1); else XW_DISC_FWD2(128, ACT_, DYN_, 0); } while (0)
+#define XW_DISC_FWDW(W_, ACT_, DYN_) do { if (vks < 0) XW_DISC_FWD2(W_, ACT_, DYN_, -1); else XW_DISC_FWD2(W_, ACT_, DYN_, 0); } while (0)
+#define XW_DISC_FWD128(ACT_, DYN_) do { if (W == 96) XW_DISC_FWDW(96, ACT_, DYN_); else XW_DISC_FWDW(128, ACT_, DYN_); } while (0)
     const bool dyn128 = dyn && ntiles > 4 * blocks;
     if (!dyn128) queue = nullptr;
     if (act != nullptr) { if (dyn128) XW_DISC_FWD128(true, true); else XW_DISC_FWD128(true, false); }
     else { if (dyn128) XW_DISC_FWD128(false, true); else XW_DISC_FWD128(false, false); }
 #undef XW_DISC_FWD128
+#undef XW_DISC_FWDW
   }
 #undef XW_DISC_FWD_W
 #undef XW_DISC_FWD
@@ -1459,6 +1461,8 @@ extern "C" int xw_disc_bwd(const double* xT, const double* t, const double* tpp,
     else hipLaunchKernelGGL((k_disc_rec<W_, Q, NG, false>), dim3(blocks), dim3(256), 0, s, xT, t, tpp, phi, vbar, N, L, d, gslab, act, q);
     if (W == 128) {
       if (ng == 1) { XW_DISC_REC(128, 0, 1) } else if (ng == 2) { XW_DISC_REC(128, 0, 2) } else { XW_DISC_REC(128, 0, 3) }
+    } else if (W == 96) {
+      if (ng == 1) { XW_DISC_REC(96, 0, 1) } else if (ng == 2) { XW_DISC_REC(96, 0, 2) } else { XW_DISC_REC(96, 0, 3) }
     } else if (W == 64) {
       if (ng == 1) { XW_DISC_REC(64, 0, 1) } else if (ng == 2) { XW_DISC_REC(64, 0, 2) } else { XW_DISC_REC(64, 0, 3) }
     } else {

@@ -303,12 +303,14 @@ __global__ void __launch_bounds__(256) k_disc_cot(const double* __restrict__ u, 
 // Block = 16 parameters x 64 slab groups; grid = P / 16.
 #define XW_ADAM_PARAMS 16
 #define XW_ADAM_GROUPS 64
+// (eA, eB and gsum_out carry no __restrict__: the group runner hands the SAME buffer in as the extra gradient and as the output
+//  of the summed gradient -- xw_substep.hip, a sharded discriminator update -- and every thread reads its entry before it writes it)
 __global__ void __launch_bounds__(1024) k_adam(double* __restrict__ param, const double* __restrict__ gA, int nA,
-                                               const double* __restrict__ eA, const double* __restrict__ gB, int nB,
-                                               const double* __restrict__ eB, const double* __restrict__ scal,
+                                               const double* eA, const double* __restrict__ gB, int nB,
+                                               const double* eB, const double* __restrict__ scal,
                                                double* __restrict__ m, double* __restrict__ v,
                                                const long long* __restrict__ step, int step_is_current, int P, double lr,
-                                               double beta1, double beta2, double eps, double* __restrict__ gsum_out,
+                                               double beta1, double beta2, double eps, double* gsum_out,
                                                int lag_lo, int lag_hi, int skip, const long long* __restrict__ lag) {
   // block = 16 parameters (one 128-byte line per slab row) x 64 slab groups: P / 16 blocks spread the 10 MB of slabs of
   // a generator sub-step over ~100 CUs (64 parameters per block used 26 of them and took 17 us)
@@ -588,7 +590,7 @@ extern "C" int xw_abi_version(void) { return 31; }
 extern "C" int xw_reduce_work_size(void) { return 6 * 1024 + 8; }
 
 extern "C" int xw_supported_dims(char* buf, int buflen) {
-  static const char s[] = "ode (H,K)=(20,10),(32,12), m=1..10 [MFMA]; any H<=64, K<=16 [generic path: vector ALU, slow]; disc_fwd W=50,64,128 any q; disc_bwd W=50 (q=9 unrolled, any q from the record), W=64,128 (from the record) [MFMA]; any other W<=128, q<=16 [generic path, from the record]; d<=126";
+  static const char s[] = "ode (H,K)=(20,10),(32,12), m=1..10 [MFMA]; any H<=64, K<=16 [generic path: vector ALU, slow]; disc_fwd W=50,64,96,128 any q; disc_bwd W=50 (q=9 unrolled, any q from the record), W=64,96,128 (from the record) [MFMA]; any other W<=128, q<=16 [generic path, from the record]; d<=126";
   int i = 0;
   for (; s[i] && i < buflen - 1; ++i) buf[i] = s[i];
   if (buflen > 0) buf[i] = 0;

@@ -66,8 +66,8 @@ def method_id(name):
 # Anything wider runs, at its own widths, on the GENERIC path (csrc/xw_generic.hip: per-path / per-point code on the vector ALU,
 # two to three orders of magnitude slower -- there so that every legal configuration of the reference trains).
 ODE_WIDTHS = [(20, 10), (32, 12)]          # (u_hidden_dim, u_hidden_hidden_dim) containers, smallest first
-DISC_WIDTHS = [50, 64, 128]                # v_hidden_dim containers (W = 50: 3 MFMA row tiles + a 2-row vector tail; 64: 4 tiles;
-                                           # 128 (round 6): 8 tiles, one block per CU, forward + reverse from the record)
+DISC_WIDTHS = [50, 64, 96, 128]            # v_hidden_dim containers (W = 50: 3 MFMA row tiles + a 2-row vector tail; 64: 4 tiles;
+                                           # 96, 128 (round 6): 6 / 8 tiles, one block per CU, forward + reverse from the record)
 GENERIC_ODE_MAX = (64, 16)                 # csrc/xw_generic.h
 GENERIC_DISC_MAX = 128
 
@@ -287,8 +287,8 @@ def disc_act_cols(P):
 
 
 def disc_xproj_rows(W):
-    """rows of the x-projection table: the row tiles of the width's kernel (64 for the widths 50 and 64, 128 for 128)"""
-    return 128 if W > 64 else 64
+    """rows of the x-projection table: the row tiles of the width's kernel (64 for the widths 50 and 64, 96 / 128 for the wide containers)"""
+    return 128 if W > 96 else 96 if W > 64 else 64
 
 
 def disc_xproj(xT, phi, W, out=None):

@@ -492,6 +492,11 @@ class NODE_WAN_solver:
             return out
         finally:
             torch.set_num_threads(threads)
+            try:                                   # (the diagnostics' per-sample cache of func_u_sol: nothing outlives a run)
+                from utils.auxillary_funcs import clear_exact_cache
+                clear_exact_cache()
+            except ImportError:
+                pass
 
     def _train(self, report, report_it, show_plt):
         past_losses = _JsonList()
