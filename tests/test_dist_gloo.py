@@ -493,3 +493,46 @@ def test_schedule_selection_on_a_node_of_eight():
     assert g.N == 2048 and eng._compact(g, True, True) and not eng._narrow_ok([job, job], alone=False, forward=True)
     g, job = shard(4099, 0)
     assert g.N == 513 and eng._compact(g, True, True)
+
+
+def _checksum_worker(rank, size, port, out_dir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(size), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from xnode_wan_pde_solver_amd import dist as xdist
+    world, _ = xdist.init_from_env('gloo')
+    g = torch.Generator().manual_seed(11)
+    theta, phi = torch.randn(1983, generator=g, dtype=torch.float64), torch.randn(5851, generator=g, dtype=torch.float64)
+    world.assert_in_step(theta, phi)                       # identical replicas: passes on every rank
+    res = {'same': True}
+    phi2 = phi.clone()
+    if rank == size - 1:
+        phi2[4097] = torch.nextafter(phi2[4097], torch.tensor(float('inf'), dtype=torch.float64))     # ONE ulp on ONE rank
+    try:
+        world.assert_in_step(theta, phi2)
+        res['caught'] = False
+    except RuntimeError as e:
+        res['caught'] = 'drifted apart' in str(e)
+    # swapped entries keep the plain sum: the position-weighted checksum still sees them
+    theta2 = theta.clone()
+    if rank == 0:
+        theta2[[3, 7]] = theta2[[7, 3]]
+    try:
+        world.assert_in_step(theta2, phi)
+        res['caught_swap'] = False
+    except RuntimeError:
+        res['caught_swap'] = True
+    torch.save(res, os.path.join(out_dir, 'rank%d.pt' % rank))
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize('size', [2, 4])
+def test_replica_checksum_catches_a_one_ulp_drift_on_one_rank(tmp_path, size):
+    """dist.World.assert_in_step (what train() ends with under a world): parameters are replicated and never broadcast, so a
+    divergence can only be noticed by looking -- identical blobs pass, one ulp in one entry on one rank raises ON EVERY RANK
+    (nobody is left waiting in the next collective), and so does a permutation that keeps the plain sum"""
+    port = _free_port()
+    mp.start_processes(_checksum_worker, args=(size, port, str(tmp_path)), nprocs=size, join=True, start_method='spawn')
+    for r in range(size):
+        res = torch.load(os.path.join(str(tmp_path), 'rank%d.pt' % r))
+        assert res == {'same': True, 'caught': True, 'caught_swap': True}, (r, res)

@@ -108,28 +108,28 @@ class World:
         return lo, lo + base + (1 if self.rank < rem else 0)
 
     def assert_in_step(self, *blobs):
-        """Raise on every rank if the ranks' copies of the given float64 parameter blobs are not bit-identical.  Parameters are
+        """Raise on every rank if the ranks' copies of the given float64 parameter blobs are not BIT-identical.  Parameters are
         replicated and never broadcast (every rank applies the same fused Adam to the same all-reduced gradient; groups below
-        `replicate_below` are computed whole on every rank), so a divergence can only be noticed by looking: two position-
-        weighted checksums per blob, summed over the ranks and compared with size x the local value (an exact test: equal
-        addends sum to a multiple that rounds identically on every rank).  One small all-reduce and one read-back: called once
-        per train() / every `check_every` outer iterations, not per sub-step."""
-        sums = []
+        `replicate_below` are computed whole on every rank), so a divergence can only be noticed by looking.  Per blob a 63-bit
+        position-weighted hash of the bit patterns (exact integer arithmetic, wrapping), cut into three 21-bit pieces p; the ranks
+        exchange sum(p) and sum(p^2) -- both exact in float64 -- and  size * sum(p^2) == sum(p)^2  holds iff every rank sent the
+        same p (Cauchy-Schwarz; exact up to 32 ranks: (32 x 2^21)^2 < 2^53).  One small all-reduce and one read-back: called once per
+        train(), not per sub-step."""
+        pieces = []
         for b in blobs:
-            x = b.detach().reshape(-1).to(torch.float64)
-            w = torch.arange(1, x.numel() + 1, dtype=torch.float64, device=x.device)
-            sums += [x.sum(), (x * w).sum()]
-        mine = torch.stack(sums).contiguous()
+            bits = b.detach().reshape(-1).to(torch.float64).contiguous().view(torch.int64)
+            w = torch.arange(1, 2 * bits.numel(), 2, dtype=torch.int64, device=bits.device)         # odd multipliers: a permutation changes the hash
+            h = int((bits * w).sum().item()) & ((1 << 63) - 1)                                      # (int64 products and sums wrap: exact mod 2^64)
+            pieces += [float(h & 0x1FFFFF), float((h >> 21) & 0x1FFFFF), float((h >> 42) & 0x1FFFFF)]
+        dev = blobs[0].device
+        mine = torch.tensor(pieces + [p_ * p_ for p_ in pieces], dtype=torch.float64, device=dev)
         tot = mine.clone()
         self.all_reduce(tot)
-        # (size is a small integer: size * x is exact up to one rounding, and so is the sum of `size` equal addends in any order
-        #  only when they ARE equal -- compare with a tolerance of a few ulps to stay independent of the reduction tree)
-        bad = (tot - self.size * mine).abs() > 8 * torch.finfo(torch.float64).eps * self.size * mine.abs().clamp_min(1e-300)
-        flag = bad.any().to(torch.float64).reshape(1).contiguous()
-        self.all_reduce(flag)
-        if float(flag[0]) != 0.0:
-            raise RuntimeError('rank %d of %d: the replicated parameters have drifted apart across the ranks (checksums %r, sum over '
-                               'ranks %r)' % (self.rank, self.size, mine.tolist(), tot.tolist()))
+        n = len(pieces)
+        bad = bool((self.size * tot[n:] != tot[:n] * tot[:n]).any().item())                         # (every rank sees the same verdict)
+        if bad:
+            raise RuntimeError('rank %d of %d: the replicated parameters have drifted apart across the ranks (hash pieces here %r)'
+                               % (self.rank, self.size, [int(p_) for p_ in pieces]))
 
     def close(self):
         if self.comm is not None:
