@@ -949,14 +949,17 @@ def test_structure_guard_catches_region_dependent_coefficients():
 @pytest.mark.parametrize('Hh,Kk,Ww,m,q', [(16, 8, 32, 8, 9), (24, 9, 40, 5, 4), (20, 12, 50, 8, 9), (32, 12, 50, 3, 9),
                                           (20, 10, 50, 1, 9), (7, 3, 11, 2, 2), (20, 10, 64, 8, 9), (16, 8, 57, 3, 5),
                                           (20, 10, 50, 10, 9), (30, 11, 50, 9, 9),          # (u_layers 9, 10: the deepest compiled fields)
-                                          (48, 16, 100, 8, 9), (64, 16, 128, 3, 4), (33, 10, 50, 8, 9), (20, 10, 70, 2, 9)])
+                                          (48, 16, 100, 8, 9), (64, 16, 128, 3, 4), (33, 10, 50, 8, 9), (20, 10, 70, 2, 9),
+                                          (40, 14, 96, 9, 3), (48, 16, 64, 10, 4)])
 def test_engine_at_other_network_widths(Hh, Kk, Ww, m, q):
     """src/model.py:30-43,62-85,130-138 accept any u_hidden_dim, u_hidden_hidden_dim, v_hidden_dim and u_layers >= 1.  A
     network narrower than a kernel instantiation runs EXACTLY inside the next larger one (zero-padded blob, nets.Blob):
     same initial draws as the reference's construction order, sub-steps against the oracle at the true widths, the
-    padding still identically zero after the updates, state_dict with the true shapes.  The last four cases are WIDER than the
-    MFMA containers in one or both networks: they run at their own widths on the generic path (csrc/xw_generic.hip), mixed with
-    the MFMA kernels of the other network where that one fits."""
+    padding still identically zero after the updates, state_dict with the true shapes.  From (48, 16, 100) on the cases are wider
+    than the round-5 containers: since round 6 they run inside the wide ones ((64, 16) for the stepper, 96 / 128 for the test
+    network); (20, 10, 70) mixes the narrow stepper with the 96-wide test network, and the last case -- u_layers = 10 beyond
+    (32, 12) -- is what still runs at its own widths on the generic path (csrc/xw_generic.hip), mixed with the MFMA kernels of the
+    test network."""
     from oracle import refspec as R
     from src.training import NODE_WAN_solver
     from xnode_wan_pde_solver_amd import kernels as KN
@@ -968,7 +971,8 @@ def test_engine_at_other_network_widths(Hh, Kk, Ww, m, q):
     torch.manual_seed(9)
     S = NODE_WAN_solver(params, P.func_a, P.func_b, P.func_c, P.func_h, P.func_f, P.func_g, torch.device('cuda'), './',
                         func_u_sol=P.func_u_sol, p=2)
-    assert (S.engine.H, S.engine.K) == KN.ode_container(Hh, Kk) and S.engine.W == KN.disc_container(Ww)
+    assert (S.engine.H, S.engine.K) == KN.ode_container(Hh, Kk, m) and S.engine.W == KN.disc_container(Ww)
+    assert S.engine.generic == ((Hh, Kk, m) == (48, 16, 10), False)
     torch.manual_seed(9)
     O = R.Solver(params, FUNCS, u_sol=P.func_u_sol, p=2)
     # (u_layers = 1: a field without the tied hidden layer, src/model.py:130 -- no such parameters in the module)

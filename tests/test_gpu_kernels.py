@@ -215,7 +215,10 @@ def test_ode_backward_from_stored_activations(solver):
     xT, tc, sc, blob = x.double().t().contiguous().cuda(), t.double().cuda(), start.cuda(), _blob(theta, U_ORDER)
     mid = KN.method_id(solver)
     rows = KN.ode_act_rows(mid, H, K, 8)
-    assert rows == {'euler': 80 + 2, 'midpoint': 180 + 4, 'rk4': 0}[solver]      # layer inputs + 2 rows of mask words per stage
+    if (H, K) == (20, 10):
+        assert rows == {'euler': 80 + 2, 'midpoint': 180 + 4, 'rk4': 0}[solver]      # layer inputs + 2 rows of mask words per stage
+    else:
+        assert (rows > 0) == (solver != 'rk4')
     u0, Y0 = KN.ode_fwd(xT, tc, sc, blob, mid, H, K, 8)
     gx0, gs0, slab0 = KN.ode_bwd(xT, tc, sc, blob, Y0, ub, mid, H, K, 8, want_x=True, want_params=True)
     u, Y = torch.empty_like(u0), torch.empty_like(Y0)
@@ -853,7 +856,8 @@ def test_empty_and_malformed_inputs_are_refused_by_the_c_abi():
 # ---- widths other than the YAML's (src/model.py:62-85,130-138 accept any u_hidden_dim / u_hidden_hidden_dim) ----------------
 @pytest.mark.parametrize('solver', ['euler', 'midpoint', 'rk4'])
 @pytest.mark.parametrize('Hh,Kk,m', [(32, 12, 8), (32, 12, 3), (32, 12, 1), (32, 12, 10), (20, 10, 10),
-                                     (48, 16, 8), (64, 16, 3), (33, 9, 1), (24, 13, 10)])       # (the last four: the generic path)
+                                     (48, 16, 8), (64, 16, 3), (33, 9, 1), (24, 13, 10),          # ((48, 16), (33, 9), (24, 13) as they are: the generic path)
+                                     (64, 16, 8), (64, 16, 9), (64, 16, 1)])                     # ((64, 16): the wide MFMA container, round 6)
 def test_ode_kernels_at_the_wide_instantiation(Hh, Kk, m, solver):
     """the (32, 12) stepper object: H a multiple of 16 (the time row of [y ; t] is a tile of its own), K = 12 (no padding
     row inside the 4-row blocks) -- forward 1e-12, sweep (x, start, every weight gradient) 1e-10 against the oracle,
@@ -902,6 +906,26 @@ def test_ode_kernels_at_the_wide_instantiation(Hh, Kk, m, solver):
             if k in theta:
                 _close(flat[off:off + n].view(theta[k].shape), grads[2 + order.index(k)], 1e-10, 'grad %s act=%s' % (k, with_act))
             off += n
+
+
+@pytest.mark.parametrize('solver', ['euler', 'midpoint', 'rk4'])
+@pytest.mark.parametrize('form', ['adjoint', 'ones', 'store', 'residual'])
+def test_ode_launch_forms_at_the_widest_container(monkeypatch, form, solver):
+    """the (64, 16) container (round 6: the field on 16x16x4 matrix instructions, one wave per tile) under every launch form the
+    engine uses -- the continuous adjoint, the all-ones x cotangent of two jobs in one launch, the activation store and its
+    x-only form, cotangents formed inside the sweep: the tests of the (20, 10) container above, run at these widths"""
+    import sys
+    mod = sys.modules[__name__]
+    monkeypatch.setattr(mod, 'H', 64)
+    monkeypatch.setattr(mod, 'K', 16)
+    if form == 'adjoint':
+        test_ode_backward_continuous_adjoint(37, 7, 5, solver)
+    elif form == 'ones':
+        test_ode_backward_pollution_and_x_sweep_in_one(solver)
+    elif form == 'store':
+        test_ode_backward_from_stored_activations(solver)
+    else:
+        test_ode_sweep_with_residual_cotangents(solver)
 
 
 @pytest.mark.parametrize('N,d', [(1, 1), (37, 2), (300, 5), (4096, 20), (1000, 100)])

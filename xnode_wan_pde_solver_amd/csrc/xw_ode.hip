@@ -35,6 +35,20 @@
     case XW_ODE_ONLY_M: { CALL(XW_ODE_H, XW_ODE_K, XW_ODE_ONLY_M) } \
     default: return XW_E_DIMS;                                   \
   }
+#elif defined(XW_ODE_WIDE16)     /* the ReLU-mask word of a stage holds 4 (m - 1) <= 32 bits: depths up to 9 */
+#define XW_ODE_DISPATCH(CALL)                                    \
+  switch (m) {                                                   \
+    case 1: { CALL(XW_ODE_H, XW_ODE_K, 1) }                      \
+    case 2: { CALL(XW_ODE_H, XW_ODE_K, 2) }                      \
+    case 3: { CALL(XW_ODE_H, XW_ODE_K, 3) }                      \
+    case 4: { CALL(XW_ODE_H, XW_ODE_K, 4) }                      \
+    case 5: { CALL(XW_ODE_H, XW_ODE_K, 5) }                      \
+    case 6: { CALL(XW_ODE_H, XW_ODE_K, 6) }                      \
+    case 7: { CALL(XW_ODE_H, XW_ODE_K, 7) }                      \
+    case 8: { CALL(XW_ODE_H, XW_ODE_K, 8) }                      \
+    case 9: { CALL(XW_ODE_H, XW_ODE_K, 9) }                      \
+    default: return XW_E_DIMS;                                   \
+  }
 #else
 #define XW_ODE_DISPATCH(CALL)                                    \
   switch (m) {                                                   \
@@ -100,10 +114,17 @@ template <int H, int K> struct Dim {
   __device__ static constexpr int HR(int ht) { return (H - 16 * ht) >= 16 ? 4 : (H - 16 * ht + 3) / 4; }        // rows of y
   __device__ static constexpr int HR1(int ct) { return (H + 1 - 16 * ct) >= 16 ? 4 : (H + 1 - 16 * ct + 3) / 4; }  // + time row
   static constexpr int CT = (H + 16) / 16;   // 16-row tiles of [y ; t]: the time row H is its own tile when H % 16 == 0
+#ifndef XW_ODE_WIDE16
   static_assert(K <= 15, "row K of the 16-row K-tile is the ones row that collects the bias gradients");
   static_assert(HT <= 2 && CT <= 3, "H <= 32");
+#else
+  // the wide container (round 6, -DXW_ODE_WIDE16): whole 16-row tiles on v_mfma_f64_16x16x4 (the wide field family below), bias
+  // gradients summed elementwise -- no ones row, no 4x4 blocks, no duo / narrow forms
+  static_assert(K == 16 && H % 16 == 0 && H <= 64, "the wide container: K = 16, H a multiple of 16 up to 64");
+#endif
 };
 
+#ifndef XW_ODE_WIDE16
 // The field's layers run on v_mfma_f64_4x4x4_4b_f64: one instruction = a 4x4 weight block times 4 rows x 16 paths of
 // the chain layout (its four "blocks" are the four groups of 4 paths; the weight block is replicated over them -- the
 // CBSZ/ABID broadcast does nothing on the f64 form, profiles/r02_probe_mfma4b.txt).  A [K x K] layer is KB x KB = 9
@@ -122,6 +143,24 @@ template <int H, int K> struct FieldWT {     // transposed operands for the vect
   double WhT[Dim<H, K>::KB][Dim<H, K>::KB];  // [K x K]
   double WoT[Dim<H, K>::KB][Dim<H, K>::HB];  // [K x H]
 };
+#else
+// ---- the wide container: the field on v_mfma_f64_16x16x4 -------------------------------------------------------------------
+// K = 16 and H = 16 HT are whole 16-row tiles, so the 16x16x4 form wastes nothing (at K = 10 it ran 10 of 16 rows): a [K x K]
+// layer is 4 chained instructions, Win's y-part H / 4, Wo HT x 4.  An A-fragment is ONE double per lane and (tile, k-step):
+// 16 + 4 + 4 HT doubles hold the whole field (as 4x4 blocks replicated over the lane blocks it would be 144 doubles at (64, 16)).
+template <int H, int K> struct FieldW {
+  double Wy[Dim<H, K>::KSH];                   // Win[:, d+1:]  [K x H], k-steps over H
+  double Wh[Dim<H, K>::KSK];                   // Wh            [K x K]
+  double Wo[Dim<H, K>::HT][Dim<H, K>::KSK];    // Wo            [H x K], row tiles x k-steps over K
+  d4 wt, bh;
+  d4 bo[Dim<H, K>::HT];
+};
+template <int H, int K> struct FieldWT {
+  double WoT[Dim<H, K>::KSH];                  // (Wo^T) [K x H]
+  double WhT[Dim<H, K>::KSK];                  // (Wh^T) [K x K]
+  double WyT[Dim<H, K>::HT][Dim<H, K>::KSK];   // (Wy^T) [H x K]
+};
+#endif
 template <int M> struct Save {               // what the VJP of one field evaluation needs
   d4 z[M > 1 ? M - 1 : 1];                   // relu(z_0) .. relu(z_{m-2}): layer inputs; their sign pattern is the ReLU mask
   d4 a;                                      // tanh(z_{m-1})
@@ -151,6 +190,7 @@ template <int M> struct SaveX {
   }
 };
 
+#ifndef XW_ODE_WIDE16
 template <int H, int K>
 __device__ __forceinline__ void load_field(const double* __restrict__ th, const UOff& o, int d, FieldW<H, K>& w) {
   typedef Dim<H, K> D;
@@ -188,6 +228,39 @@ __device__ __forceinline__ void load_field_T(const double* __restrict__ th, cons
   }
 }
 
+#else
+template <int H, int K>
+__device__ __forceinline__ void load_field(const double* __restrict__ th, const UOff& o, int d, FieldW<H, K>& w) {
+  typedef Dim<H, K> D;
+  const double* Wy = th + o.Win + d + 1;
+#pragma unroll
+  for (int ks = 0; ks < D::KSH; ++ks) w.Wy[ks] = xw_fragA(Wy, o.ldin, K, H, 0, 4 * ks);
+#pragma unroll
+  for (int ks = 0; ks < D::KSK; ++ks) w.Wh[ks] = xw_fragA(th + o.Wh, K, K, K, 0, 4 * ks);
+#pragma unroll
+  for (int ht = 0; ht < D::HT; ++ht) {
+#pragma unroll
+    for (int ks = 0; ks < D::KSK; ++ks) w.Wo[ht][ks] = xw_fragA(th + o.Wo, K, H, K, 16 * ht, 4 * ks);
+    w.bo[ht] = xw_vecD(th + o.Wob, H, 16 * ht);
+  }
+  w.wt = xw_vecD_strided(th + o.Win + d, o.ldin, K, 0);
+  w.bh = xw_vecD(th + o.Whb, K, 0);
+}
+template <int H, int K>
+__device__ __forceinline__ void load_field_T(const double* __restrict__ th, const UOff& o, int d, FieldWT<H, K>& w) {
+  typedef Dim<H, K> D;
+  const double* Wy = th + o.Win + d + 1;
+#pragma unroll
+  for (int ks = 0; ks < D::KSH; ++ks) w.WoT[ks] = xw_fragAT(th + o.Wo, K, H, K, 0, 4 * ks);          // (Wo^T)[i][4 ks + k] = Wo[4 ks + k][i]
+#pragma unroll
+  for (int ks = 0; ks < D::KSK; ++ks) w.WhT[ks] = xw_fragAT(th + o.Wh, K, K, K, 0, 4 * ks);
+#pragma unroll
+  for (int ht = 0; ht < D::HT; ++ht)
+#pragma unroll
+    for (int ks = 0; ks < D::KSK; ++ks) w.WyT[ht][ks] = xw_fragAT(Wy, o.ldin, K, H, 16 * ht, 4 * ks);   // (Wy^T)[16 ht + i][4 ks + k] = Wy[4 ks + k][16 ht + i]
+}
+
+#endif
 // F([x, t, y]) of src/model.py:153-156: z0 = Win [x;t;y] + b (x part pre-contracted into xp), (m-1) tied ReLU layers,
 // tanh, output layer.  y/out: HT chain tiles.
 // Where the layer inputs of an evaluation go: nowhere, into registers (Save), or straight to the activation store.
@@ -204,6 +277,7 @@ template <int M> struct SinkSave {
   __device__ __forceinline__ void z(int j, d4 r) const { sv.z[j] = r; }
   __device__ __forceinline__ void a(d4 v) const { sv.a = v; }
 };
+#ifndef XW_ODE_WIDE16
 template <int H, int K, int M, bool OUT = true, class Sink>
 __device__ __forceinline__ void field_fwd(const FieldW<H, K>& w, double t, d4 xp, const d4 (&y)[Dim<H, K>::HT],
                                           d4 (&out)[Dim<H, K>::HT], const Sink& sink) {
@@ -243,12 +317,58 @@ __device__ __forceinline__ void field_fwd(const FieldW<H, K>& w, double t, d4 xp
     for (int rb = 0; rb < D::HB; ++rb) out[rb >> 2][rb & 3] = XW_MFMA4(w.Wo[rb][kb], a[kb], out[rb >> 2][rb & 3]);
 }
 
+#else
+template <int H, int K, int M, bool OUT = true, class Sink>
+__device__ __forceinline__ void field_fwd(const FieldW<H, K>& w, double t, d4 xp, const d4 (&y)[Dim<H, K>::HT],
+                                          d4 (&out)[Dim<H, K>::HT], const Sink& sink) {
+  typedef Dim<H, K> D;
+  d4 z;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) z[r] = fma(w.wt[r], t, xp[r]);
+#pragma unroll
+  for (int ks = 0; ks < D::KSH; ++ks) z = XW_MFMA(w.Wy[ks], y[ks >> 2][ks & 3], z);
+#pragma unroll
+  for (int j = 0; j < M - 1; ++j) {
+    d4 r;
+#pragma unroll
+    for (int kb = 0; kb < D::KB; ++kb) r[kb] = sink.relu(j, kb, z[kb]);
+    sink.fence();
+    sink.z(j, r);
+    d4 nz = w.bh;
+#pragma unroll
+    for (int ks = 0; ks < D::KSK; ++ks) nz = XW_MFMA(w.Wh[ks], r[ks], nz);
+    z = nz;
+  }
+  d4 a;
+#pragma unroll
+  for (int kb = 0; kb < D::KB; ++kb) a[kb] = xw_tanh(z[kb]);
+  sink.a(a);
+  if (!OUT) return;
+#pragma unroll
+  for (int ht = 0; ht < D::HT; ++ht) {
+    out[ht] = w.bo[ht];
+#pragma unroll
+    for (int ks = 0; ks < D::KSK; ++ks) out[ht] = XW_MFMA(w.Wo[ht][ks], a[ks], out[ht]);
+  }
+}
+
+#endif
 // parameter-gradient accumulators of the field (chain-layout tiles of the gradient matrices)
+#ifndef XW_ODE_WIDE16
 template <int H, int K> struct FieldG {
   d4 Wh;                                          // rows K, cols K (+ column K = bias via a ones row)
   d4 Wy[Dim<H, K>::CT];                           // rows K, cols H (+ column H = time column)
   d4 Wo[Dim<H, K>::HT];                           // rows H, cols K (+ column K = bias)
 };
+#else
+template <int H, int K> struct FieldG {           // wide container: no ones row / time row -- their gradients are elementwise sums
+  d4 Wh;                                          // rows K, cols K
+  d4 Wy[Dim<H, K>::CT];                           // rows K, cols H (tiles 0 .. HT-1; the last entry is not used)
+  d4 Wo[Dim<H, K>::HT];                           // rows H, cols K
+  d4 bh, wt;                                      // sum over evaluations of cot(z_{j+1}) (Wh.b) and of t cot(z_0) (Win's time column), per path
+  d4 bo[Dim<H, K>::HT];                           // ... of cot(out) (Wo.b)
+};
+#endif
 
 // D[i][j] += sum over the 16 paths of Q[i][path] * R[j][path]
 // The block is exactly ONE wave and the LDS executes a wave's DS instructions in issue order, so the transposing
@@ -384,6 +504,7 @@ template <int H, int K, int M> struct DuoPlan {
   static constexpr int BUF = XW_TSTRIDE * (16 * (HT - 1) + HLAST + KROWS * M + 16);   // (+ 16 rows: reads past the last tile)
   static_assert(BUF >= 3 * XW_TTILE, "the chain wave's epilogue borrows a buffer for its three transpose tiles");
 };
+#ifndef XW_ODE_WIDE16
 template <int H, int K, int M, int OUTER, class SV>
 __device__ __forceinline__ void field_vjp(const FieldW<H, K>& w, const FieldWT<H, K>& wT, double t, const SV& sv,
                                           const d4 (&yin)[Dim<H, K>::HT], const d4 (&ob)[Dim<H, K>::HT],
@@ -477,6 +598,58 @@ __device__ __forceinline__ void field_vjp(const FieldW<H, K>& w, const FieldWT<H
   }
 }
 
+#else
+template <int H, int K, int M, int OUTER, class SV>
+__device__ __forceinline__ void field_vjp(const FieldW<H, K>& w, const FieldWT<H, K>& wT, double t, const SV& sv,
+                                          const d4 (&yin)[Dim<H, K>::HT], const d4 (&ob)[Dim<H, K>::HT],
+                                          d4 (&yb)[Dim<H, K>::HT], d4& xpb, FieldG<H, K>& G, double* lds) {
+  typedef Dim<H, K> D;
+  static_assert(OUTER == 0 || OUTER == 1, "the wide container has no duo sweep");
+  constexpr bool PARAMS = OUTER == 1;
+  // cotangent of tanh(z_{m-1}): Wo^T cot(out), one chained accumulator over H / 4 k-steps
+  d4 ab = xw_zero4();
+#pragma unroll
+  for (int ks = 0; ks < D::KSH; ++ks) ab = XW_MFMA(wT.WoT[ks], ob[ks >> 2][ks & 3], ab);
+  if (PARAMS) {
+    // dWo[16 ht ..][:] += cot(out)[ht] (x) tanh(z_{m-1}) over the 16 paths (LDS transposes, 4 k-steps each); dWo.b elementwise
+#pragma unroll
+    for (int ht = 0; ht < D::HT; ++ht) {
+      outer_acc(G.Wo[ht], ob[ht], sv.a, lds);
+      G.bo[ht] = G.bo[ht] + ob[ht];
+    }
+  }
+  d4 zb;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) zb[r] = ab[r] * (1.0 - sv.a[r] * sv.a[r]);
+#pragma unroll
+  for (int j = M - 2; j >= 0; --j) {
+    if constexpr (PARAMS) {
+      outer_acc(G.Wh, zb, sv.z[j], lds);
+      G.bh = G.bh + zb;
+    }
+    d4 tt = xw_zero4();
+#pragma unroll
+    for (int ks = 0; ks < D::KSK; ++ks) tt = XW_MFMA(wT.WhT[ks], zb[ks], tt);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) zb[r] = sv.gate(j, r, tt[r]);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) xpb[r] += zb[r];
+  if (PARAMS) {
+#pragma unroll
+    for (int ct = 0; ct < D::HT; ++ct) outer_acc(G.Wy[ct], zb, yin[ct], lds);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) G.wt[r] = fma(t, zb[r], G.wt[r]);
+  }
+#pragma unroll
+  for (int ht = 0; ht < D::HT; ++ht) {
+    yb[ht] = xw_zero4();
+#pragma unroll
+    for (int ks = 0; ks < D::KSK; ++ks) yb[ht] = XW_MFMA(wT.WyT[ht][ks], zb[ks], yb[ht]);
+  }
+}
+
+#endif
 // start scalar -> hidden state: initial_layers of src/model.py:78,97
 template <int H, int K>
 __device__ __forceinline__ void lift(const double* __restrict__ th, const UOff& o, double sv, d4 (&a0)[Dim<H, K>::HT],
@@ -928,6 +1101,7 @@ __device__ __forceinline__ void storeRowSums(double* dst, int rows, int r0, d4 q
   }
 }
 
+#ifndef XW_ODE_WIDE16
 // the field's weight-gradient accumulators -> one slab
 template <int H, int K, bool HID = true, bool IO = true>
 __device__ __forceinline__ void store_field_grads(double* slab, const UOff& o, int d, const FieldG<H, K>& G) {
@@ -949,6 +1123,33 @@ __device__ __forceinline__ void store_field_grads(double* slab, const UOff& o, i
   }
 }
 
+#else
+// the field's weight-gradient accumulators -> one slab (wide container: the biases and the time column are row sums over the 16 paths)
+template <int H, int K, bool HID = true, bool IO = true>
+__device__ __forceinline__ void store_field_grads(double* slab, const UOff& o, int d, const FieldG<H, K>& G) {
+  typedef Dim<H, K> D;
+  const int lane = xw_lane(), g = lane >> 4;
+  if (HID) {
+    storeD(slab + o.Wh, K, K, K, 0, 0, G.Wh);
+    storeRowSums(slab + o.Whb, K, 0, G.bh);
+  }
+  if (!IO) return;
+#pragma unroll
+  for (int ct = 0; ct < D::HT; ++ct) storeD(slab + o.Win + d + 1, o.ldin, K, H, 0, 16 * ct, G.Wy[ct]);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {                               // Win[:, d]: the time column
+    const double s_ = xw_sum_over_n(G.wt[r]);
+    const int row = g + 4 * r;
+    if ((lane & 15) == 0 && row < K) slab[o.Win + (long)row * o.ldin + d] = s_;
+  }
+#pragma unroll
+  for (int ht = 0; ht < D::HT; ++ht) {
+    storeD(slab + o.Wo, K, H, K, 16 * ht, 0, G.Wo[ht]);
+    storeRowSums(slab + o.Wob, H, 16 * ht, G.bo[ht]);
+  }
+}
+
+#endif
 // what the reverse of one step l -> l+1 needs from the forward pass: the stage inputs and the stage activations
 template <int H, int K, int M, int S> struct Rec {
   d4 yi[S][Dim<H, K>::HT];
@@ -1225,6 +1426,11 @@ __device__ __forceinline__ void sweep_body(const BwdJobs& jobs, const double* __
   for (int ct = 0; ct < (H + 1 + 15) / 16; ++ct) G.Wy[ct] = xw_zero4();
 #pragma unroll
   for (int ht = 0; ht < D::HT; ++ht) G.Wo[ht] = xw_zero4();
+#ifdef XW_ODE_WIDE16
+  G.bh = G.wt = xw_zero4();
+#pragma unroll
+  for (int ht = 0; ht < D::HT; ++ht) G.bo[ht] = xw_zero4();
+#endif
   d4 accFL[D::HT];
 #pragma unroll
   for (int ht = 0; ht < D::HT; ++ht) accFL[ht] = xw_zero4();
@@ -1502,6 +1708,7 @@ __device__ __forceinline__ void sweep_body(const BwdJobs& jobs, const double* __
                                 });
 }
 
+#ifndef XW_ODE_WIDE16
 // ---- the duo sweep's second wave: weight gradients of the field -------------------------------------------------------
 // For every field evaluation (same order as the chain wave, one evaluation behind it):
 //     dWo += cot(out) (x) [tanh(z_{m-1}) ; 1]     dWh += sum_j cot(z_{j+1}) (x) [relu(z_j) ; 1]     dWy += cot(z_0) (x) [y_in ; t]
@@ -1719,12 +1926,14 @@ __device__ __forceinline__ void duo_outer(const BwdJobs& jobs, const double* __r
     }
 }
 
+#endif   // !XW_ODE_WIDE16
 template <int H, int K, int M, int METHOD, bool PARAMS, bool SAVED, bool ADJ = false>
 __global__ void __launch_bounds__(64) k_ode_bwd(const BwdJobs jobs, const double* __restrict__ tf,
                                                 const double* __restrict__ th, int L, int d) {
   __shared__ double lds[XW_SWEEP_TILES * XW_TTILE];   // (plan: XW_SWEEP_TILES)
   sweep_body<H, K, M, METHOD, PARAMS, SAVED, ADJ, false>(jobs, tf, th, L, d, lds, nullptr, (int)blockIdx.x);
 }
+#ifndef XW_ODE_WIDE16
 // the duo sweep: wave 0 = adjoint chain, wave 1 = weight gradients of the field (see sweep_body / duo_outer).
 // Placement (tools/probe_place.hip, profiles/r02_probe_place.txt): the dispatcher puts a block's waves on consecutive
 // SIMDs and starts the next block of the same CU ONE SIMD further, so two of these blocks on a CU land on SIMDs (0,1),
@@ -1756,11 +1965,14 @@ __global__ void __launch_bounds__(XW_DUO_THREADS) k_ode_bwd_duo(const BwdJobs jo
 
 #include "xw_ode_n4.h"
 
+#endif   // !XW_ODE_WIDE16 (no duo sweep, no narrow tiles in the wide container)
+
 template <int H, int K, int M>
 int launch_fwd(int method, const FwdJobs& jobs, const double* t, const double* theta, int L, int d, hipStream_t s) {
   const dim3 grid(jobs.tile0[jobs.n]), block(64);
   bool act = true;                                     // all jobs or none, all in the same mode (checked by the caller)
   for (int i = 0; i < jobs.n; ++i) act = act && jobs.act[i] != nullptr;
+#ifndef XW_ODE_WIDE16
   if (jobs.narrow) {
     // narrow tiles (xw_ode_n4.h): the same grid of 16-path tiles, four waves of 4 paths each
     switch (method * 3 + (act ? (jobs.x_only ? 2 : 1) : 0)) {
@@ -1775,6 +1987,7 @@ int launch_fwd(int method, const FwdJobs& jobs, const double* t, const double* t
     }
     return xw_launch_status();
   }
+#endif
   switch (method * 3 + (act ? (jobs.x_only ? 2 : 1) : 0)) {
     case 0: hipLaunchKernelGGL((k_ode_fwd<H, K, M, 0, 0>), grid, block, 0, s, jobs, t, theta, L, d); break;
     case 1: hipLaunchKernelGGL((k_ode_fwd<H, K, M, 0, 1>), grid, block, 0, s, jobs, t, theta, L, d); break;
@@ -1791,6 +2004,18 @@ template <int H, int K, int M, bool PARAMS>
 int launch_bwd(int method, const BwdJobs& jobs, const double* t, const double* theta, int L, int d, bool adj, bool narrow,
                hipStream_t s) {
   const dim3 grid(jobs.tile0[jobs.n]), block(64);
+#ifdef XW_ODE_WIDE16
+  // the wide container: one wave per tile in every form; the sweep with weight gradients forms them itself (OUTER = 1)
+  {
+    bool act_ = true;
+    for (int i = 0; i < jobs.n; ++i) act_ = act_ && jobs.act[i] != nullptr;
+    if (adj || !act_ || method > 1)
+      return XW_ODE_FN(xw_ode_bwd_recomp_w)(&jobs, t, theta, method, L, d, M, PARAMS ? 1 : 0, adj ? 1 : 0, (void*)s);
+    if (method == 0) hipLaunchKernelGGL((k_ode_bwd<H, K, M, 0, PARAMS, true>), grid, block, 0, s, jobs, t, theta, L, d);
+    else hipLaunchKernelGGL((k_ode_bwd<H, K, M, 1, PARAMS, true>), grid, block, 0, s, jobs, t, theta, L, d);
+    return xw_launch_status();
+  }
+#else
   if (narrow) {
     // narrow tiles (xw_ode_n4.h): the same grid of 16-path tiles, four waves of 4 paths each; from the activation store only
     if (adj || method > 1) return XW_E_ARG;
@@ -1826,6 +2051,7 @@ int launch_bwd(int method, const BwdJobs& jobs, const double* t, const double* t
     default: return XW_E_ARG;
   }
   return xw_launch_status();
+#endif
 }
 
 }  // namespace

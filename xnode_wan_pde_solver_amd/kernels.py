@@ -65,15 +65,23 @@ def method_id(name):
 # relu / tanh, contribute exact zeros to every sum, and receive exactly zero gradients (Adam leaves them at zero).
 # Anything wider runs, at its own widths, on the GENERIC path (csrc/xw_generic.hip: per-path / per-point code on the vector ALU,
 # two to three orders of magnitude slower -- there so that every legal configuration of the reference trains).
-ODE_WIDTHS = [(20, 10), (32, 12)]          # (u_hidden_dim, u_hidden_hidden_dim) containers, smallest first
+ODE_WIDTHS = [(20, 10), (32, 12), (64, 16)]   # (u_hidden_dim, u_hidden_hidden_dim) containers, smallest first.  (64, 16) (round 6) is the
+                                           # WIDE container: the field on 16x16x4 matrix instructions, one wave per tile, depths 1..9
+                                           # (depth 10 there: the C ABI falls through to the generic path at the same widths)
 DISC_WIDTHS = [50, 64, 96, 128]            # v_hidden_dim containers (W = 50: 3 MFMA row tiles + a 2-row vector tail; 64: 4 tiles;
                                            # 96, 128 (round 6): 6 / 8 tiles, one block per CU, forward + reverse from the record)
 GENERIC_ODE_MAX = (64, 16)                 # csrc/xw_generic.h
 GENERIC_DISC_MAX = 128
 
 
-def ode_container(H, K):
+ODE_WIDE_MAX_DEPTH = 9                     # (64, 16): one 32-bit ReLU-mask word per stage holds 4 (u_layers - 1) bits
+
+
+def ode_container(H, K, m=1):
+    """the widths the stepper kernels run a (u_hidden_dim H, u_hidden_hidden_dim K) network of u_layers = m at"""
     for Hc, Kc in ODE_WIDTHS:
+        if (Hc, Kc) == ODE_WIDTHS[-1] and m > ODE_WIDE_MAX_DEPTH:
+            continue                       # (u_layers 10 beyond (32, 12): the generic path, at the network's own widths)
         if H <= Hc and K <= Kc and lib.xw_theta_size(1, Hc, Kc) > 0 and lib.xw_ode_act_rows(0, Hc, Kc, 1) >= 0:
             return Hc, Kc
     if H <= GENERIC_ODE_MAX[0] and K <= GENERIC_ODE_MAX[1] and lib.xw_ode_act_rows(0, H, K, 1) >= 0:
@@ -82,9 +90,9 @@ def ode_container(H, K):
                      % (H, K, ODE_WIDTHS[-1], GENERIC_ODE_MAX))
 
 
-def ode_generic(H, K):
-    """True when (H, K) is served by the generic (slow) path rather than by an MFMA instantiation"""
-    return (H, K) not in ODE_WIDTHS
+def ode_generic(H, K, m=1):
+    """True when (H, K) at u_layers = m is served by the generic (slow) path rather than by an MFMA instantiation"""
+    return (H, K) not in ODE_WIDTHS or ((H, K) == ODE_WIDTHS[-1] and m > ODE_WIDE_MAX_DEPTH)
 
 
 def disc_container(W):

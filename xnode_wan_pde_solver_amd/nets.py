@@ -221,7 +221,7 @@ class XNODE(nn.Module):
         instantiation that holds this network (kernels.ode_container; equal widths: plain concatenation)"""
         self.to(device)
         H, K, d = self.hidden_dim, self.hidden_hidden_dim, self.setup['dim']
-        self.kdims = KN.ode_container(H, K)
+        self.kdims = KN.ode_container(H, K, self.num_layers)
         slots, total = _u_slots(d, H, K, self.kdims[0], self.kdims[1], self.num_layers > 1)
         assert total == KN.theta_size(d, *self.kdims)
         self.blob = Blob(self, device, slots, total)
