@@ -23,7 +23,7 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 #define XW_MFMA4(a, b, c) __builtin_amdgcn_mfma_f64_4x4x4f64((a), (b), (c), 0, 0, 0)
 
 #define XW_E_DIMS (-1)
-#define XW_ODE_MAX_LAYERS 10   /* u_layers: the depths xw_ode.hip instantiates (XW_ODE_DISPATCH); the ReLU-mask word of a stage holds 3 (m - 1) + 3 <= 32 bits */
+#define XW_ODE_MAX_LAYERS 10   /* u_layers: the depths xw_ode.hip instantiates (XW_ODE_DISPATCH); the ReLU-mask word of a stage holds 3 (m - 1) + 3 <= 32 bits.  Deeper fields (up to XWG_MAX_M): the generic path */
 #define XW_E_ARG (-2)
 #define XW_E_WORKSPACE (-3)
 #define XW_E_COMM (-4)

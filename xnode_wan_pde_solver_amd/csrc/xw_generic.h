@@ -6,6 +6,7 @@
 #define XWG_MAX_K 16     /* u_hidden_hidden_dim */
 #define XWG_MAX_W 128    /* v_hidden_dim */
 #define XWG_MAX_Q 16     /* v_layers */
+#define XWG_MAX_M 32     /* u_layers (the MFMA containers stop at XW_ODE_MAX_LAYERS = 10; deeper fields run here, at their own widths) */
 #define XWG_HIDDEN __attribute__((visibility("hidden")))
 XWG_HIDDEN int xwg_ode_ok(int d, int H, int K, int m);
 XWG_HIDDEN int xwg_disc_ok(int d, int W, int q);

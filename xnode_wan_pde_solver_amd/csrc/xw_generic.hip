@@ -20,7 +20,7 @@
 #include "xw_generic.h"
 
 namespace {
-constexpr int GH = XWG_MAX_H, GK = XWG_MAX_K, GW = XWG_MAX_W, GM = XW_ODE_MAX_LAYERS, GQ = XWG_MAX_Q;
+constexpr int GH = XWG_MAX_H, GK = XWG_MAX_K, GW = XWG_MAX_W, GM = XWG_MAX_M, GQ = XWG_MAX_Q;
 
 __device__ __forceinline__ double gsum16(double x) {       // sum over the 16 lanes (paths) that share a slab
   x += __shfl_xor(x, 1);

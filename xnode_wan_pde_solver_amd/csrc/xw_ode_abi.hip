@@ -30,10 +30,10 @@ static bool width_compiled(int H, int K) {
 extern "C" int xw_ode_act_rows(int method, int H, int K, int m) {
   if (H == XW_WIDE_H && K == XW_WIDE_K) {                             // the wide container: a store up to depth 9, else the generic path
     const int S_ = method == 0 ? 1 : method == 1 ? 2 : 0;
-    if (m < 1 || m > XW_ODE_MAX_LAYERS) return XW_E_DIMS;
+    if (!xwg_ode_ok(1, H, K, m)) return XW_E_DIMS;
     return (S_ == 0 || m > 9) ? 0 : S_ * m * K + (S_ - 1) * H + 2 * S_;
   }
-  if (!width_compiled(H, K) && xwg_ode_ok(1, H, K, m)) return 0;      // generic widths (xw_generic.hip): the sweeps recompute
+  if ((!width_compiled(H, K) || m > XW_ODE_MAX_LAYERS) && xwg_ode_ok(1, H, K, m)) return 0;   // generic widths / depths (xw_generic.hip): the sweeps recompute
   if (!width_compiled(H, K) || m < 1 || m > XW_ODE_MAX_LAYERS) return XW_E_DIMS;
   const int S = method == 0 ? 1 : method == 1 ? 2 : 0;           // rk4: the sweeps recompute
   return S == 0 ? 0 : S * m * K + (S - 1) * H + 2 * S;             // (+ the ReLU-mask words of every stage)
@@ -41,7 +41,7 @@ extern "C" int xw_ode_act_rows(int method, int H, int K, int m) {
 
 extern "C" int xw_ode_fwd_multi(const XwOdeFwdJob* jobs, int njobs, const double* t, const double* theta, int method, int L,
                                 int d, int H, int K, int m, double* zero16, void* stream) {
-#define CALL(HH, KK) if (H == HH && K == KK) return xw_ode_fwd_multi_w##HH##_##KK(jobs, njobs, t, theta, method, L, d, m, zero16, stream);
+#define CALL(HH, KK) if (H == HH && K == KK && m <= XW_ODE_MAX_LAYERS) return xw_ode_fwd_multi_w##HH##_##KK(jobs, njobs, t, theta, method, L, d, m, zero16, stream);
   XW_ODE_WIDTHS(CALL)
 #undef CALL
   if (H == XW_WIDE_H && K == XW_WIDE_K && m <= 9) return xw_ode_fwd_multi_w64_16(jobs, njobs, t, theta, method, L, d, m, zero16, stream);
@@ -56,7 +56,7 @@ extern "C" int xw_ode_fwd(const double* xT, const double* t, const double* start
 
 extern "C" int xw_ode_bwd_multi(const XwOdeBwdJob* jobs, int njobs, const double* t, const double* theta, int method, int L,
                                 int d, int H, int K, int m, int mode, void* stream) {
-#define CALL(HH, KK) if (H == HH && K == KK) return xw_ode_bwd_multi_w##HH##_##KK(jobs, njobs, t, theta, method, L, d, m, mode, stream);
+#define CALL(HH, KK) if (H == HH && K == KK && m <= XW_ODE_MAX_LAYERS) return xw_ode_bwd_multi_w##HH##_##KK(jobs, njobs, t, theta, method, L, d, m, mode, stream);
   XW_ODE_WIDTHS(CALL)
 #undef CALL
   if (H == XW_WIDE_H && K == XW_WIDE_K && m <= 9) return xw_ode_bwd_multi_w64_16(jobs, njobs, t, theta, method, L, d, m, mode, stream);

@@ -75,24 +75,26 @@ GENERIC_DISC_MAX = 128
 
 
 ODE_WIDE_MAX_DEPTH = 9                     # (64, 16): one 32-bit ReLU-mask word per stage holds 4 (u_layers - 1) bits
+ODE_MAX_DEPTH = 10                         # the other containers (csrc/xw_common.h XW_ODE_MAX_LAYERS); deeper fields, up to
+GENERIC_ODE_MAX_DEPTH = 32                 # this (csrc/xw_generic.h XWG_MAX_M), run on the generic path at their own widths
 
 
 def ode_container(H, K, m=1):
     """the widths the stepper kernels run a (u_hidden_dim H, u_hidden_hidden_dim K) network of u_layers = m at"""
     for Hc, Kc in ODE_WIDTHS:
-        if (Hc, Kc) == ODE_WIDTHS[-1] and m > ODE_WIDE_MAX_DEPTH:
-            continue                       # (u_layers 10 beyond (32, 12): the generic path, at the network's own widths)
+        if m > (ODE_WIDE_MAX_DEPTH if (Hc, Kc) == ODE_WIDTHS[-1] else ODE_MAX_DEPTH):
+            continue                       # (u_layers 10 beyond (32, 12), u_layers > 10 anywhere: the generic path, at the network's own widths)
         if H <= Hc and K <= Kc and lib.xw_theta_size(1, Hc, Kc) > 0 and lib.xw_ode_act_rows(0, Hc, Kc, 1) >= 0:
             return Hc, Kc
-    if H <= GENERIC_ODE_MAX[0] and K <= GENERIC_ODE_MAX[1] and lib.xw_ode_act_rows(0, H, K, 1) >= 0:
+    if H <= GENERIC_ODE_MAX[0] and K <= GENERIC_ODE_MAX[1] and m <= GENERIC_ODE_MAX_DEPTH and lib.xw_ode_act_rows(0, H, K, m) >= 0:
         return H, K                        # the generic path, at the network's own widths
-    raise XnwanError('u_hidden_dim = %d, u_hidden_hidden_dim = %d: the stepper kernels serve widths up to %s (MFMA) / %s (generic path)'
-                     % (H, K, ODE_WIDTHS[-1], GENERIC_ODE_MAX))
+    raise XnwanError('u_hidden_dim = %d, u_hidden_hidden_dim = %d, u_layers = %d: the stepper kernels serve widths up to %s (MFMA) / %s (generic '
+                     'path), depths up to %d / %d' % (H, K, m, ODE_WIDTHS[-1], GENERIC_ODE_MAX, ODE_MAX_DEPTH, GENERIC_ODE_MAX_DEPTH))
 
 
 def ode_generic(H, K, m=1):
     """True when (H, K) at u_layers = m is served by the generic (slow) path rather than by an MFMA instantiation"""
-    return (H, K) not in ODE_WIDTHS or ((H, K) == ODE_WIDTHS[-1] and m > ODE_WIDE_MAX_DEPTH)
+    return (H, K) not in ODE_WIDTHS or m > (ODE_WIDE_MAX_DEPTH if (H, K) == ODE_WIDTHS[-1] else ODE_MAX_DEPTH)
 
 
 def disc_container(W):
