@@ -910,7 +910,7 @@ def test_ode_kernels_at_the_wide_instantiation(Hh, Kk, m, solver):
 
 
 @pytest.mark.parametrize('solver', ['euler', 'midpoint', 'rk4'])
-@pytest.mark.parametrize('form', ['adjoint', 'ones', 'store', 'residual'])
+@pytest.mark.parametrize('form', ['adjoint', 'ones', 'store', 'residual', 'smallest'])
 def test_ode_launch_forms_at_the_widest_container(monkeypatch, form, solver):
     """the (64, 16) container (round 6: the field on 16x16x4 matrix instructions, one wave per tile) under every launch form the
     engine uses -- the continuous adjoint, the all-ones x cotangent of two jobs in one launch, the activation store and its
@@ -925,6 +925,10 @@ def test_ode_launch_forms_at_the_widest_container(monkeypatch, form, solver):
         test_ode_backward_pollution_and_x_sweep_in_one(solver)
     elif form == 'store':
         test_ode_backward_from_stored_activations(solver)
+    elif form == 'smallest':
+        if solver == 'midpoint':              # (one path and two time points; 19 paths at the widest input, d = 126)
+            test_smallest_and_widest_inputs(1, 2, 1)
+            test_smallest_and_widest_inputs(19, 3, 126)
     else:
         test_ode_sweep_with_residual_cotangents(solver)
 
