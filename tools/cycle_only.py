@@ -17,6 +17,10 @@ from src.dataset import Comb_loader
 cycles = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 dev = torch.device('cuda', 0)
 params = B.workload_params(20, 4096, 4096, 32)
+# (other network widths, e.g. the wide containers:  XW_CYCLE_WIDTHS=64,16,128 python3 tools/cycle_only.py 10)
+if os.environ.get('XW_CYCLE_WIDTHS'):
+    h_, k_, w_ = (int(x) for x in os.environ['XW_CYCLE_WIDTHS'].split(','))
+    params.update(u_hidden_dim=h_, u_hidden_hidden_dim=k_, v_hidden_dim=w_)
 torch.manual_seed(0)
 S = NODE_WAN_solver(params, P.func_a, P.func_b, P.func_c, P.func_h, P.func_f, P.func_g, dev, './', func_u_sol=P.func_u_sol, p=2)
 eng, s = S.engine, S.setup
