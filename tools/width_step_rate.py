@@ -13,7 +13,7 @@ from src.training import NODE_WAN_solver
 from src.dataset import Comb_loader
 
 dev = torch.device('cuda', 0)
-cases = [(20, 10, 50, 8), (32, 12, 64, 8), (48, 16, 100, 8), (64, 16, 128, 8), (64, 16, 128, 9), (20, 10, 128, 8), (64, 16, 50, 8)]
+cases = [(20, 10, 50, 8), (32, 12, 64, 8), (48, 16, 100, 8), (64, 16, 128, 8), (64, 16, 128, 9), (20, 10, 128, 8), (20, 10, 96, 8), (64, 16, 50, 8)]
 if len(sys.argv) > 1 and sys.argv[1] == 'generic':
     cases = [(48, 16, 50, 10)]          # u_layers = 10 beyond (32, 12): the one shape left on the generic stepper
 for (H, K, W, m) in cases:

@@ -247,6 +247,8 @@ class Engine:
         # Round 4: with the generator's sweeps A + boundary at lowered wave priority (prio_drop below) the test network keeps more of
         # the chip: generator sub-step 0.492 / 0.484 / 0.480 / 0.475 ms at 9, 10, 11, 12 sixteenths of the slots -- and 0.545 at 13 (a
         # cliff: the stepper's forward pass no longer finds SIMDs); 12/16.
+        # (the 96- / 128-wide containers run one block per CU, the cap is clipped to all of them: 3/4 of the CUs measured the same with
+        #  the wide stepper beside it and 6 % slower with the narrow one -- profiles/r06_width_step_rate.txt)
         self.v_blocks = int(opt.v_blocks) or (12 * 2 * cus) // 16
         # (discriminator sub-step: only the stepper forward and the x-only sweep run beside it, 33 us of SIMD time: 7/8 of the
         #  slots -- 0.615 ms against 0.638 at 3/4, 0.681 at 15/16, 0.735 at all of them; round 3: 13/16 and 14/16 equal
