@@ -119,7 +119,7 @@ template <int H, int K> struct Dim {
   static_assert(HT <= 2 && CT <= 3, "H <= 32");
 #else
   // the wide container (round 6, -DXW_ODE_WIDE16): whole 16-row tiles on v_mfma_f64_16x16x4 (the wide field family below), bias
-  // gradients summed elementwise -- no ones row, no 4x4 blocks, no duo / narrow forms
+  // gradients as row sums -- no ones row, no 4x4 blocks, no narrow tiles; a duo sweep of its own (duo_outer below)
   static_assert(K == 16 && H % 16 == 0 && H <= 64, "the wide container: K = 16, H a multiple of 16 up to 64");
 #endif
 };
@@ -490,6 +490,16 @@ __device__ __forceinline__ void outer_fire(d4& acc, const double (&a)[4], const 
 // OUTER: 0 = no weight gradients, 1 = this wave forms them itself (outer products through its own LDS tiles),
 //        2 = "duo" sweep: this wave only posts the cotangent tiles (transposed) into `lds` = the evaluation's Q buffer
 //            (DuoPlan), a partner wave of the block contracts them with the activations it loads itself.
+#ifdef XW_ODE_WIDE16
+// (wide container: every Q tile is a full 16-row tile of the 16x16x4 form -- cot(out) x HT, cot(z_{j+1}) for j = M-2 .. 0, cot(z_0))
+template <int H, int K, int M> struct DuoPlan {
+  static constexpr int HT = Dim<H, K>::HT;
+  static constexpr int NQ = HT + M;
+  __device__ static constexpr int off(int t) { return t * XW_TTILE; }
+  static constexpr int BUF = NQ * XW_TTILE;
+  static_assert(BUF >= 3 * XW_TTILE, "the chain wave's epilogue borrows a buffer for its three transpose tiles");
+};
+#else
 template <int H, int K, int M> struct DuoPlan {
   static constexpr int HT = Dim<H, K>::HT;
   static constexpr int NQ = HT + (M - 1) + 1;     // Q tiles of one field evaluation: cot(out) x HT, cot(z_{j+1}) for j = M-2 .. 0, cot(z_0)
@@ -504,6 +514,7 @@ template <int H, int K, int M> struct DuoPlan {
   static constexpr int BUF = XW_TSTRIDE * (16 * (HT - 1) + HLAST + KROWS * M + 16);   // (+ 16 rows: reads past the last tile)
   static_assert(BUF >= 3 * XW_TTILE, "the chain wave's epilogue borrows a buffer for its three transpose tiles");
 };
+#endif
 #ifndef XW_ODE_WIDE16
 template <int H, int K, int M, int OUTER, class SV>
 __device__ __forceinline__ void field_vjp(const FieldW<H, K>& w, const FieldWT<H, K>& wT, double t, const SV& sv,
@@ -604,8 +615,16 @@ __device__ __forceinline__ void field_vjp(const FieldW<H, K>& w, const FieldWT<H
                                           const d4 (&yin)[Dim<H, K>::HT], const d4 (&ob)[Dim<H, K>::HT],
                                           d4 (&yb)[Dim<H, K>::HT], d4& xpb, FieldG<H, K>& G, double* lds) {
   typedef Dim<H, K> D;
-  static_assert(OUTER == 0 || OUTER == 1, "the wide container has no duo sweep");
+  // OUTER: 0 = no weight gradients, 1 = this wave forms them itself (one LDS round trip per product, in the middle of the chain: the
+  // recomputing sweeps), 2 = duo sweep: this wave only posts its cotangent tiles (transposed) into `lds` = the evaluation's Q buffer
+  // (DuoPlan), the partner wave of the block (duo_outer) contracts them with the layer inputs it loads from the activation store
   constexpr bool PARAMS = OUTER == 1;
+  constexpr bool POST = OUTER == 2;
+  typedef DuoPlan<H, K, M> P;
+  if (POST) {
+#pragma unroll
+    for (int ht = 0; ht < D::HT; ++ht) xw_writeT_n<4>(lds + P::off(ht), ob[ht]);
+  }
   // cotangent of tanh(z_{m-1}): Wo^T cot(out), one chained accumulator over H / 4 k-steps
   d4 ab = xw_zero4();
 #pragma unroll
@@ -627,6 +646,7 @@ __device__ __forceinline__ void field_vjp(const FieldW<H, K>& w, const FieldWT<H
       outer_acc(G.Wh, zb, sv.z[j], lds);
       G.bh = G.bh + zb;
     }
+    if (POST) xw_writeT_n<4>(lds + P::off(D::HT + (M - 2 - j)), zb);      // cot(z_{j+1})
     d4 tt = xw_zero4();
 #pragma unroll
     for (int ks = 0; ks < D::KSK; ++ks) tt = XW_MFMA(wT.WhT[ks], zb[ks], tt);
@@ -635,6 +655,7 @@ __device__ __forceinline__ void field_vjp(const FieldW<H, K>& w, const FieldWT<H
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r) xpb[r] += zb[r];
+  if (POST) xw_writeT_n<4>(lds + P::off(D::HT + M - 1), zb);              // cot(z_0)
   if (PARAMS) {
 #pragma unroll
     for (int ct = 0; ct < D::HT; ++ct) outer_acc(G.Wy[ct], zb, yin[ct], lds);
@@ -1926,14 +1947,151 @@ __device__ __forceinline__ void duo_outer(const BwdJobs& jobs, const double* __r
     }
 }
 
-#endif   // !XW_ODE_WIDE16
+#else    // XW_ODE_WIDE16
+// ---- the duo sweep's second wave in the wide container: weight gradients of the field on v_mfma_f64_16x16x4 --------------------
+// One wave that runs the adjoint chain AND its 15 outer products per evaluation paid an LDS round trip per product in the middle
+// of the chain and spilled 330 registers (641 us per sweep at the headline sample against 161 us without weight gradients).  As in
+// the narrow containers the chain wave only POSTS its cotangent tiles (field_vjp OUTER = 2: cot(out) x HT, cot(z_{j+1}) of every
+// tied layer, cot(z_0); two alternating buffers, one s_barrier per evaluation) and this wave, one evaluation behind, contracts
+// them over the 16 paths with the layer inputs it loads from the activation store / the checkpoints itself, a whole evaluation
+// ahead: 4 (HT + M - 1 + HT) matrix instructions per evaluation.  A operand = xw_readT of a posted tile (row i, path 4 ks + kk);
+// B operand = (row j, path 4 ks + kk) of a 16-row block of the record, whose 4-row blocks are path-major (act_store): double
+// 64 (j >> 2) + 4 (4 ks + kk) + (j & 3) of the block.  The bias gradients and the time column are row sums of the posted tiles: a
+// lane adds the A operands it reads anyway, the four lane groups are folded once at the end.
+template <int H, int K, int M, int METHOD>
+__device__ __forceinline__ void duo_outer(const BwdJobs& jobs, const double* __restrict__ tf, const double* __restrict__ th,
+                                          int L, int d, const double* qbuf, int vb) {
+  typedef Dim<H, K> D;
+  typedef RK<METHOD> T;
+  typedef DuoPlan<H, K, M> P;
+  typedef ActLayout<H, K, M, T::S> AL;
+  constexpr int NH = M > 1 ? M - 1 : 1;
+  xw_setprio(jobs.prio);
+  const int job = find_job(jobs, vb);
+  const double* __restrict__ Y = jobs.Y[job];
+  const double* __restrict__ act = jobs.act[job];
+  const int N = jobs.N[job];
+  const int tile = vb - jobs.tile0[job];
+  const int lane = xw_lane(), j = lane & 15, kk = lane >> 4;
+  const UOff o = u_offsets(d, H, K);
+  const int lo = 64 * (j >> 2) + 4 * kk + (j & 3);
+  const long ntile = (N + 15) >> 4;
+  long ycol[4];                                          // columns of the checkpoint this lane reads (clamped: the last tile's padding paths)
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const long c = (long)tile * 16 + 4 * ks + kk;
+    ycol[ks] = c < N ? c : N - 1;
+  }
+  d4 gWo[D::HT], gWy[D::HT], gWh = xw_zero4();
+  double sbo[D::HT], sbh = 0.0, swt = 0.0;
+#pragma unroll
+  for (int ht = 0; ht < D::HT; ++ht) {
+    gWo[ht] = xw_zero4();
+    gWy[ht] = xw_zero4();
+    sbo[ht] = 0.0;
+  }
+  double Ra[4], Rr[NH][4], Ry[D::HT][4];                 // B operands of the evaluation in flight
+  const int E = (L - 1) * T::S;                          // field evaluations of the sweep (chain-wave order: steps L-2 .. 0, stages S-1 .. 0)
+  // operands of evaluation e: the record of its step, its stage, its time
+  auto load_eval = [&](int e, double& ti) {
+    const int l = L - 2 - e / T::S, i = T::S - 1 - e % T::S;
+    const double* __restrict__ A = act + ((long)l * ntile + tile) * (AL::TOTAL * 16) + lo;
+    const double t0 = tf[l];
+    ti = t0 + T::c(i) * (tf[l + 1] - t0);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) Ra[ks] = __builtin_nontemporal_load(A + (i * AL::STAGE + (M - 1) * K) * 16 + 16 * ks);
+#pragma unroll
+    for (int jj = 0; jj < M - 1; ++jj)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) Rr[jj][ks] = __builtin_nontemporal_load(A + (i * AL::STAGE + jj * K) * 16 + 16 * ks);
+    // the field's input: the checkpoint y_l [H][N] (stage 0) or the stage input kept in the record
+    const bool first = i == 0;                           // (wave-uniform)
+#pragma unroll
+    for (int ct = 0; ct < D::HT; ++ct)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const double* __restrict__ sy = Y + ((long)l * H + 16 * ct + j) * N + ycol[ks];
+        const double* __restrict__ sa = A + (long)(AL::YI + (i > 0 ? i - 1 : 0) * H + 16 * ct) * 16 + 16 * ks;
+        Ry[ct][ks] = __builtin_nontemporal_load(first ? sy : sa);
+      }
+  };
+  double ti_cur = 0.0;
+  if (E > 0) load_eval(0, ti_cur);
+  for (int e = 0; e < E; ++e) {
+    // the chain wave has posted evaluation e (and is free to start e + 1).  No fence: an acquire would drain vmcnt and with it the
+    // operand loads issued a whole evaluation ahead; LDS reads behind the barrier see the posted tiles.
+    asm volatile("s_barrier" ::: "memory");
+    const double* q = qbuf + (e & 1) * P::BUF;
+    double Ao[D::HT][4], Az[M][4];
+#pragma unroll
+    for (int ht = 0; ht < D::HT; ++ht)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) Ao[ht][ks] = xw_readT(q + P::off(ht), ks);
+#pragma unroll
+    for (int tq = 0; tq < M; ++tq)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) Az[tq][ks] = xw_readT(q + P::off(D::HT + tq), ks);
+    __builtin_amdgcn_sched_barrier(0);
+    // cot(out) against tanh(z_{m-1})
+#pragma unroll
+    for (int ht = 0; ht < D::HT; ++ht) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) gWo[ht] = XW_MFMA(Ao[ht][ks], Ra[ks], gWo[ht]);
+      sbo[ht] += (Ao[ht][0] + Ao[ht][1]) + (Ao[ht][2] + Ao[ht][3]);
+    }
+    // cot(z_{j+1}) against relu(z_j), j = M-2 .. 0 (tile order of the chain wave); the record keeps the layer INPUT z_j
+#pragma unroll
+    for (int jj = M - 2; jj >= 0; --jj) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const double r = Rr[jj][ks];
+        gWh = XW_MFMA(Az[M - 2 - jj][ks], r, gWh);
+      }
+      sbh += (Az[M - 2 - jj][0] + Az[M - 2 - jj][1]) + (Az[M - 2 - jj][2] + Az[M - 2 - jj][3]);
+    }
+    // cot(z_0) against the field's input; its row sums times t are the time column
+#pragma unroll
+    for (int ct = 0; ct < D::HT; ++ct)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) gWy[ct] = XW_MFMA(Az[M - 1][ks], Ry[ct][ks], gWy[ct]);
+    swt = fma(ti_cur, (Az[M - 1][0] + Az[M - 1][1]) + (Az[M - 1][2] + Az[M - 1][3]), swt);
+    __builtin_amdgcn_sched_barrier(0);
+    load_eval(e + 1 < E ? e + 1 : e, ti_cur);            // (the last evaluation reloads its own operands: no branch)
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // ---- this tile's slab pieces: accumulator register r of lane (g, n) = element (row g + 4 r, column n)
+  double* slab = jobs.gslab[job] + (long)tile * o.total;
+  storeD(slab + o.Wh, K, K, K, 0, 0, gWh);                  // (u_layers = 1: zeros -- the slot of the missing tied layer)
+#pragma unroll
+  for (int ct = 0; ct < D::HT; ++ct) storeD(slab + o.Win + d + 1, o.ldin, K, H, 0, 16 * ct, gWy[ct]);
+#pragma unroll
+  for (int ht = 0; ht < D::HT; ++ht) storeD(slab + o.Wo, K, H, K, 16 * ht, 0, gWo[ht]);
+  // row sums: lane (row j, group kk) holds its group's share
+  auto fold = [](double x) {
+    x += __shfl_xor(x, 16);
+    x += __shfl_xor(x, 32);
+    return x;
+  };
+  sbh = fold(sbh);
+  swt = fold(swt);
+#pragma unroll
+  for (int ht = 0; ht < D::HT; ++ht) sbo[ht] = fold(sbo[ht]);
+  if (kk == 0) {
+    if (j < K) slab[o.Whb + j] = sbh;
+    if (j < K) slab[o.Win + (long)j * o.ldin + d] = swt;
+#pragma unroll
+    for (int ht = 0; ht < D::HT; ++ht)
+      if (16 * ht + j < H) slab[o.Wob + 16 * ht + j] = sbo[ht];
+  }
+}
+
+#endif   // XW_ODE_WIDE16
 template <int H, int K, int M, int METHOD, bool PARAMS, bool SAVED, bool ADJ = false>
 __global__ void __launch_bounds__(64) k_ode_bwd(const BwdJobs jobs, const double* __restrict__ tf,
                                                 const double* __restrict__ th, int L, int d) {
   __shared__ double lds[XW_SWEEP_TILES * XW_TTILE];   // (plan: XW_SWEEP_TILES)
   sweep_body<H, K, M, METHOD, PARAMS, SAVED, ADJ, false>(jobs, tf, th, L, d, lds, nullptr, (int)blockIdx.x);
 }
-#ifndef XW_ODE_WIDE16
 // the duo sweep: wave 0 = adjoint chain, wave 1 = weight gradients of the field (see sweep_body / duo_outer).
 // Placement (tools/probe_place.hip, profiles/r02_probe_place.txt): the dispatcher puts a block's waves on consecutive
 // SIMDs and starts the next block of the same CU ONE SIMD further, so two of these blocks on a CU land on SIMDs (0,1),
@@ -1963,9 +2121,9 @@ __global__ void __launch_bounds__(XW_DUO_THREADS) k_ode_bwd_duo(const BwdJobs jo
   else duo_outer<H, K, M, METHOD>(jobs, tf, th, L, d, lds, vb);
 }
 
+#ifndef XW_ODE_WIDE16
 #include "xw_ode_n4.h"
-
-#endif   // !XW_ODE_WIDE16 (no duo sweep, no narrow tiles in the wide container)
+#endif   // (no narrow tiles in the wide container)
 
 template <int H, int K, int M>
 int launch_fwd(int method, const FwdJobs& jobs, const double* t, const double* theta, int L, int d, hipStream_t s) {
@@ -2005,14 +2163,22 @@ int launch_bwd(int method, const BwdJobs& jobs, const double* t, const double* t
                hipStream_t s) {
   const dim3 grid(jobs.tile0[jobs.n]), block(64);
 #ifdef XW_ODE_WIDE16
-  // the wide container: one wave per tile in every form; the sweep with weight gradients forms them itself (OUTER = 1)
+  // the wide container: no narrow tiles; the recomputing sweeps form their weight gradients themselves (OUTER = 1)
   {
     bool act_ = true;
     for (int i = 0; i < jobs.n; ++i) act_ = act_ && jobs.act[i] != nullptr;
     if (adj || !act_ || method > 1)
       return XW_ODE_FN(xw_ode_bwd_recomp_w)(&jobs, t, theta, method, L, d, M, PARAMS ? 1 : 0, adj ? 1 : 0, (void*)s);
-    if (method == 0) hipLaunchKernelGGL((k_ode_bwd<H, K, M, 0, PARAMS, true>), grid, block, 0, s, jobs, t, theta, L, d);
-    else hipLaunchKernelGGL((k_ode_bwd<H, K, M, 1, PARAMS, true>), grid, block, 0, s, jobs, t, theta, L, d);
+    // from the activation store: without weight gradients one wave per tile, with them the duo sweep (chain wave + partner wave)
+    if (PARAMS) {
+      BwdJobs jd = jobs;
+      jd.spread = 0;
+      if (method == 0) hipLaunchKernelGGL((k_ode_bwd_duo<H, K, M, 0>), grid, dim3(XW_DUO_THREADS), 0, s, jd, t, theta, L, d);
+      else hipLaunchKernelGGL((k_ode_bwd_duo<H, K, M, 1>), grid, dim3(XW_DUO_THREADS), 0, s, jd, t, theta, L, d);
+    } else {
+      if (method == 0) hipLaunchKernelGGL((k_ode_bwd<H, K, M, 0, false, true>), grid, block, 0, s, jobs, t, theta, L, d);
+      else hipLaunchKernelGGL((k_ode_bwd<H, K, M, 1, false, true>), grid, block, 0, s, jobs, t, theta, L, d);
+    }
     return xw_launch_status();
   }
 #else

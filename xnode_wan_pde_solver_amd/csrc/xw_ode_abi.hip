@@ -5,8 +5,8 @@
 #include "xw_generic.h"
 
 #define XW_ODE_WIDTHS(X) X(20, 10) X(32, 12)      /* keep in step with the Makefile and kernels.ODE_WIDTHS */
-/* ... and the WIDE container (64, 16) (round 6; xw_ode.hip -DXW_ODE_WIDE16: the field on v_mfma_f64_16x16x4, one wave per tile in
- * every form, depths 1..9): same entry points; what it does not have (depth 10) falls through to the generic path at these widths */
+/* ... and the WIDE container (64, 16) (round 6; xw_ode.hip -DXW_ODE_WIDE16: the field on v_mfma_f64_16x16x4, one wave per tile --
+ * the sweep with weight gradients from the store: chain wave + partner wave --, no narrow tiles, depths 1..9): same entry points; what it does not have (depth 10) falls through to the generic path at these widths */
 #define XW_WIDE_H 64
 #define XW_WIDE_K 16
 extern "C" int xw_ode_fwd_multi_w64_16(const XwOdeFwdJob*, int, const double*, const double*, int, int, int, int, double*, void*);

@@ -66,7 +66,7 @@ def method_id(name):
 # Anything wider runs, at its own widths, on the GENERIC path (csrc/xw_generic.hip: per-path / per-point code on the vector ALU,
 # two to three orders of magnitude slower -- there so that every legal configuration of the reference trains).
 ODE_WIDTHS = [(20, 10), (32, 12), (64, 16)]   # (u_hidden_dim, u_hidden_hidden_dim) containers, smallest first.  (64, 16) (round 6) is the
-                                           # WIDE container: the field on 16x16x4 matrix instructions, one wave per tile, depths 1..9
+                                           # WIDE container: the field on 16x16x4 matrix instructions, one wave per tile (+ a partner in the sweep with weight gradients), depths 1..9
                                            # (depth 10 there: the C ABI falls through to the generic path at the same widths)
 DISC_WIDTHS = [50, 64, 96, 128]            # v_hidden_dim containers (W = 50: 3 MFMA row tiles + a 2-row vector tail; 64: 4 tiles;
                                            # 96, 128 (round 6): 6 / 8 tiles, one block per CU, forward + reverse from the record)
