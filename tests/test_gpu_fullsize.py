@@ -98,6 +98,17 @@ def test_stepper_sweeps_at_full_size(d, N, L, narrow):
     assert _rel(KN.slab_sum(slabp), a[2]) < 1e-11
 
 
+@pytest.mark.parametrize('d,N,L', SIZES[:3])
+def test_widest_stepper_container_at_full_size(d, N, L, monkeypatch):
+    """the (64, 16) container (round 6: the field on 16x16x4 matrix instructions; the sweep with weight gradients from the
+    store is a duo sweep -- chain wave + partner wave --, the recomputing one a single wave): the same properties"""
+    import sys
+    mod = sys.modules[__name__]
+    monkeypatch.setattr(mod, 'H', 64)
+    monkeypatch.setattr(mod, 'K', 16)
+    test_stepper_sweeps_at_full_size(d, N, L, False)
+
+
 @pytest.mark.parametrize('d,N,L', SIZES)
 def test_test_network_at_full_size(d, N, L):
     KN, g, dev, th, ph, xT, t, start = _setup(d, N, L, 2)

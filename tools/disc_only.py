@@ -3,7 +3,7 @@ import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch
 from xnode_wan_pde_solver_amd import kernels as KN, _lib
-N, L, d, W, q = 4096, 32, 20, 50, 9
+N, L, d, W, q = 4096, 32, 20, int(os.environ.get('XW_W', '50')), 9     # (XW_W=128: the wide container)
 dev = torch.device('cuda'); g = torch.Generator().manual_seed(0)
 ph = (0.2 * torch.randn(_lib.lib.xw_phi_size(d, W), generator=g, dtype=torch.float64)).to(dev)
 xT = torch.rand(d, N, generator=g, dtype=torch.float64).to(dev); t = torch.linspace(0, 1, L, dtype=torch.float64).to(dev)
