@@ -9,7 +9,11 @@ from src.training import NODE_WAN_solver
 from src.dataset import Comb_loader
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 torch.manual_seed(0)
-S = NODE_WAN_solver(workload_params(20, 4096, 4096, 32), P.func_a, P.func_b, P.func_c, P.func_h, P.func_f, P.func_g,
+params = workload_params(20, 4096, 4096, 32)
+if os.environ.get('XW_CYCLE_WIDTHS'):        # other network widths, e.g. the wide containers: XW_CYCLE_WIDTHS=64,16,128
+    h_, k_, w_ = (int(x) for x in os.environ['XW_CYCLE_WIDTHS'].split(','))
+    params.update(u_hidden_dim=h_, u_hidden_hidden_dim=k_, v_hidden_dim=w_)
+S = NODE_WAN_solver(params, P.func_a, P.func_b, P.func_c, P.func_h, P.func_f, P.func_g,
                     torch.device('cuda'), './', func_u_sol=P.func_u_sol, p=2)
 eng, s = S.engine, S.setup
 domain = S.domain(s['shape_param'], s['dim'], s['T0'], s['T'], s['N_t'])
