@@ -857,8 +857,8 @@ def test_empty_and_malformed_inputs_are_refused_by_the_c_abi():
 @pytest.mark.parametrize('solver', ['euler', 'midpoint', 'rk4'])
 @pytest.mark.parametrize('Hh,Kk,m', [(32, 12, 8), (32, 12, 3), (32, 12, 1), (32, 12, 10), (20, 10, 10),
                                      (48, 16, 8), (64, 16, 3), (33, 9, 1), (24, 13, 10),          # ((48, 16), (33, 9), (24, 13) as they are: the generic path)
-                                     (64, 16, 8), (64, 16, 9), (64, 16, 1),                      # ((64, 16): the wide MFMA container, round 6)
-                                     (64, 16, 10), (20, 10, 12), (24, 13, 17)])                  # (deeper than the containers: the generic path, u_layers <= 32)
+                                     (64, 16, 8), (64, 16, 9), (64, 16, 1), (64, 16, 10),        # ((64, 16): the wide MFMA container, round 6; depth 10: two mask words)
+                                     (64, 16, 11), (20, 10, 12), (24, 13, 17)])                  # (deeper than the containers: the generic path, u_layers <= 32)
 def test_ode_kernels_at_the_wide_instantiation(Hh, Kk, m, solver):
     """the (32, 12) stepper object: H a multiple of 16 (the time row of [y ; t] is a tile of its own), K = 12 (no padding
     row inside the 4-row blocks) -- forward 1e-12, sweep (x, start, every weight gradient) 1e-10 against the oracle,

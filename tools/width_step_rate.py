@@ -13,9 +13,9 @@ from src.training import NODE_WAN_solver
 from src.dataset import Comb_loader
 
 dev = torch.device('cuda', 0)
-cases = [(20, 10, 50, 8), (32, 12, 64, 8), (48, 16, 100, 8), (64, 16, 128, 8), (64, 16, 128, 9), (20, 10, 128, 8), (20, 10, 96, 8), (64, 16, 50, 8)]
+cases = [(20, 10, 50, 8), (32, 12, 64, 8), (48, 16, 100, 8), (64, 16, 128, 8), (64, 16, 128, 10), (20, 10, 128, 8), (20, 10, 96, 8), (64, 16, 50, 8)]
 if len(sys.argv) > 1 and sys.argv[1] == 'generic':
-    cases = [(48, 16, 50, 10)]          # u_layers = 10 beyond (32, 12): the one shape left on the generic stepper
+    cases = [(20, 10, 50, 12)]          # u_layers > 10: what is left on the generic stepper
 for (H, K, W, m) in cases:
     params = B.workload_params(20, 4096, 4096, 32)
     params.update(u_hidden_dim=H, u_hidden_hidden_dim=K, v_hidden_dim=W, u_layers=m)

@@ -35,7 +35,7 @@
     case XW_ODE_ONLY_M: { CALL(XW_ODE_H, XW_ODE_K, XW_ODE_ONLY_M) } \
     default: return XW_E_DIMS;                                   \
   }
-#elif defined(XW_ODE_WIDE16)     /* the ReLU-mask word of a stage holds 4 (m - 1) <= 32 bits: depths up to 9 */
+#elif defined(XW_ODE_WIDE16)     /* (4 (m - 1) ReLU-mask bits per stage: one 32-bit word up to depth 9, two at depth 10 -- SaveX) */
 #define XW_ODE_DISPATCH(CALL)                                    \
   switch (m) {                                                   \
     case 1: { CALL(XW_ODE_H, XW_ODE_K, 1) }                      \
@@ -47,6 +47,7 @@
     case 7: { CALL(XW_ODE_H, XW_ODE_K, 7) }                      \
     case 8: { CALL(XW_ODE_H, XW_ODE_K, 8) }                      \
     case 9: { CALL(XW_ODE_H, XW_ODE_K, 9) }                      \
+    case 10: { CALL(XW_ODE_H, XW_ODE_K, 10) }                    \
     default: return XW_E_DIMS;                                   \
   }
 #else
@@ -175,17 +176,19 @@ template <int M> struct Save {               // what the VJP of one field evalua
 // feeds EXACT zeros (+0, the biases start at zero) to the next one, and relu'(+0) = 0 in the reference (torch) -- with sign
 // bits the boundary sweep of the d = 20 fixture was off by 5e-5.
 #define XW_KB ((XW_ODE_K + 3) / 4)
+// (more than 32 bits -- the wide container at depth 10: 36 -- take a second word, bits_hi = bits 32 and up; XW_MASK_WORDS)
+#define XW_MASK_WORDS(M) ((XW_KB * ((M) - 1) > 32) ? 2 : 1)
 template <int M> struct SaveX {
-  static_assert(XW_KB * (M - 1) <= 32, "mask word");
+  static_assert(XW_KB * (M - 1) <= 64, "mask words");
   d4 a;
-  unsigned bits;
+  unsigned bits, bits_hi;
   __device__ static constexpr int bit(int j, int r) { return XW_KB * (M - 1) - 1 - (XW_KB * j + r); }
-  __device__ __forceinline__ bool pos(int j, int r) const { return (bits >> bit(j, r)) & 1u; }
+  __device__ __forceinline__ bool pos(int j, int r) const { return ((bit(j, r) < 32 ? bits >> bit(j, r) : bits_hi >> (bit(j, r) - 32)) & 1u) != 0; }
   // relu'(z_j) * x as two 32-bit ANDs with the mask bit spread to 0 / ~0 (one v_bfe_i32 that does not depend on x):
   // a v_cndmask_b32 costs ~6 clocks of the SIMD, a v_and_b32 2.3 (profiles/r02_probe_coexec.txt), and the gate sits on the
   // adjoint chain's critical path once per layer and register
   __device__ __forceinline__ double gate(int j, int r, double x) const {
-    const int m = __builtin_amdgcn_sbfe((int)bits, bit(j, r), 1);
+    const int m = bit(j, r) < 32 ? __builtin_amdgcn_sbfe((int)bits, bit(j, r), 1) : __builtin_amdgcn_sbfe((int)bits_hi, bit(j, r) - 32, 1);
     return __hiloint2double(__double2hiint(x) & m, __double2loint(x) & m);
   }
 };
@@ -888,8 +891,9 @@ template <int H, int K, int M, int S> struct ActLayout {
   static constexpr int STAGE = M * K;
   static constexpr int YI = S * STAGE;
   static constexpr int ROWS = S * STAGE + (S - 1) * H;
-  static constexpr int MASK = ROWS;                      // + 2 rows (64 words) per stage: the ReLU masks of SaveX
-  static constexpr int TOTAL = ROWS + 2 * S;
+  static constexpr int MASK = ROWS;                      // + 2 rows (64 words) per stage and mask word: the ReLU masks of SaveX
+  static constexpr int MR = 2 * XW_MASK_WORDS(M);
+  static constexpr int TOTAL = ROWS + MR * S;
 };
 // rows [row0, row0 + nrows) of the record <-> the first registers of a chain tile (row g + 4 r).  Addresses are
 // formed as  (uniform row pointer) + (32-bit lane offset)  so that they cost SGPRs, not a VGPR pair per stored row.
@@ -954,6 +958,7 @@ template <int K, int M, bool FULL = true> struct SinkAct {
   int row0, N;
   const ActLane& q;
   unsigned& bits;              // (z > 0) of the stage's pre-activations, pushed in (layer, register) order (SaveX)
+  unsigned& bits_hi;           // (the second word: only where XW_MASK_WORDS(M) == 2)
   // relu of one pre-activation register: its bit (z > 0) goes into the mask word (v_cmp_gt_f64 + v_addc_co_u32), then
   // ONE v_max_f64 (3 vector instructions per register where compare, select, shift-or and two v_max_f64 were 4.5).  As a builtin the maximum comes with a canonicalising v_max_f64 z, z in front of it (45 extra vector
   // instructions per step); as inline assembly it would escape the hazard recogniser, which must keep a VALU read 6+ wait
@@ -971,6 +976,11 @@ template <int K, int M, bool FULL = true> struct SinkAct {
     //  compiler does not look into the assembly.  A layer's registers are rectified back to back and fence() keeps the next layer's
     //  matrix instructions behind all of them, so only the LAST register of a layer needs the two slots spelled out: the others
     //  have the next register's two instructions behind them.  A lone wave pays ~5 clocks per s_nop: 14 per time step now, 42 before.)
+    if constexpr (XW_MASK_WORDS(M) == 2) {      // (the carry out of the low word shifts into the high one)
+      if (kb_last) asm("v_addc_co_u32_e64 %1, vcc, %1, %1, %4\n\tv_addc_co_u32_e64 %2, vcc, %2, %2, vcc\n\tv_max_f64 %0, %3, 0\n\ts_nop 1" : "=v"(r), "+v"(bits), "+v"(bits_hi) : "v"(z), "s"(open) : "vcc");
+      else asm("v_addc_co_u32_e64 %1, vcc, %1, %1, %4\n\tv_addc_co_u32_e64 %2, vcc, %2, %2, vcc\n\tv_max_f64 %0, %3, 0" : "=v"(r), "+v"(bits), "+v"(bits_hi) : "v"(z), "s"(open) : "vcc");
+      return r;
+    }
     if (kb_last) asm("v_addc_co_u32_e64 %1, vcc, %1, %1, %3\n\tv_max_f64 %0, %2, 0\n\ts_nop 1" : "=v"(r), "+v"(bits) : "v"(z), "s"(open) : "vcc");
     else asm("v_addc_co_u32_e64 %1, vcc, %1, %1, %3\n\tv_max_f64 %0, %2, 0" : "=v"(r), "+v"(bits) : "v"(z), "s"(open) : "vcc");
     return r;
@@ -1079,9 +1089,10 @@ __global__ void __launch_bounds__(64, XW_ODE_FWD_WAVES) k_ode_fwd(const FwdJobs 
           for (int ht = 0; ht < D::HT; ++ht)
             act_store(AB, AL::YI + (i - 1) * H + 16 * ht, H - 16 * ht < 16 ? H - 16 * ht : 16, 16, aq, yi[ht]);
         }
-        unsigned bits = 0;
-        field_fwd<H, K, M, true>(w, t0 + T::c(i) * dt, xp, yi, k[i], SinkAct<K, M, ACT == 1>{AB, i * AL::STAGE, 16, aq, bits});
-        __builtin_amdgcn_raw_buffer_store_b32(bits, AB.rsrc, lane * 4, (AL::MASK + 2 * i) * 16 * 8, 0);   // 1 = open (SaveX)
+        unsigned bits = 0, bits_hi = 0;
+        field_fwd<H, K, M, true>(w, t0 + T::c(i) * dt, xp, yi, k[i], SinkAct<K, M, ACT == 1>{AB, i * AL::STAGE, 16, aq, bits, bits_hi});
+        __builtin_amdgcn_raw_buffer_store_b32(bits, AB.rsrc, lane * 4, (AL::MASK + AL::MR * i) * 16 * 8, 0);   // 1 = open (SaveX)
+        if (XW_MASK_WORDS(M) == 2) __builtin_amdgcn_raw_buffer_store_b32(bits_hi, AB.rsrc, lane * 4, (AL::MASK + AL::MR * i + 2) * 16 * 8, 0);
       }
     }
 #pragma unroll
@@ -1231,7 +1242,8 @@ __device__ __forceinline__ void load_stage(const double* __restrict__ Y, const d
   const double* __restrict__ A = act + ((long)l * ntile + tile) * (AL::TOTAL * 16);
   const ActLane q = act_lane(16, xw_lane() & 15, true, K);
   if constexpr (std::is_same<SV, SaveX<M>>::value) {
-    R.sv.bits = reinterpret_cast<const unsigned*>(A + (AL::MASK + 2 * i) * 16)[xw_lane()];
+    R.sv.bits = reinterpret_cast<const unsigned*>(A + (AL::MASK + AL::MR * i) * 16)[xw_lane()];
+    R.sv.bits_hi = XW_MASK_WORDS(M) == 2 ? reinterpret_cast<const unsigned*>(A + (AL::MASK + AL::MR * i + 2) * 16)[xw_lane()] : 0u;
     R.sv.a = act_load(A, i * AL::STAGE + (M - 1) * K, K, 16, q);
     return;
   }

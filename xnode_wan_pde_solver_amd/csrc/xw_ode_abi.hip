@@ -6,7 +6,7 @@
 
 #define XW_ODE_WIDTHS(X) X(20, 10) X(32, 12)      /* keep in step with the Makefile and kernels.ODE_WIDTHS */
 /* ... and the WIDE container (64, 16) (round 6; xw_ode.hip -DXW_ODE_WIDE16: the field on v_mfma_f64_16x16x4, one wave per tile --
- * the sweep with weight gradients from the store: chain wave + partner wave --, no narrow tiles, depths 1..9): same entry points; what it does not have (depth 10) falls through to the generic path at these widths */
+ * the sweep with weight gradients from the store: chain wave + partner wave --, no narrow tiles, depths 1..10): same entry points */
 #define XW_WIDE_H 64
 #define XW_WIDE_K 16
 extern "C" int xw_ode_fwd_multi_w64_16(const XwOdeFwdJob*, int, const double*, const double*, int, int, int, int, double*, void*);
@@ -28,10 +28,11 @@ static bool width_compiled(int H, int K) {
 }
 
 extern "C" int xw_ode_act_rows(int method, int H, int K, int m) {
-  if (H == XW_WIDE_H && K == XW_WIDE_K) {                             // the wide container: a store up to depth 9, else the generic path
+  if (H == XW_WIDE_H && K == XW_WIDE_K) {                             // the wide container
     const int S_ = method == 0 ? 1 : method == 1 ? 2 : 0;
     if (!xwg_ode_ok(1, H, K, m)) return XW_E_DIMS;
-    return (S_ == 0 || m > 9) ? 0 : S_ * m * K + (S_ - 1) * H + 2 * S_;
+    // (layer inputs + the stage inputs + the ReLU-mask words of every stage: 4 (m - 1) bits per lane, two words at depth 10)
+    return (S_ == 0 || m > XW_ODE_MAX_LAYERS) ? 0 : S_ * m * K + (S_ - 1) * H + (4 * (m - 1) > 32 ? 4 : 2) * S_;
   }
   if ((!width_compiled(H, K) || m > XW_ODE_MAX_LAYERS) && xwg_ode_ok(1, H, K, m)) return 0;   // generic widths / depths (xw_generic.hip): the sweeps recompute
   if (!width_compiled(H, K) || m < 1 || m > XW_ODE_MAX_LAYERS) return XW_E_DIMS;
@@ -44,7 +45,7 @@ extern "C" int xw_ode_fwd_multi(const XwOdeFwdJob* jobs, int njobs, const double
 #define CALL(HH, KK) if (H == HH && K == KK && m <= XW_ODE_MAX_LAYERS) return xw_ode_fwd_multi_w##HH##_##KK(jobs, njobs, t, theta, method, L, d, m, zero16, stream);
   XW_ODE_WIDTHS(CALL)
 #undef CALL
-  if (H == XW_WIDE_H && K == XW_WIDE_K && m <= 9) return xw_ode_fwd_multi_w64_16(jobs, njobs, t, theta, method, L, d, m, zero16, stream);
+  if (H == XW_WIDE_H && K == XW_WIDE_K && m <= XW_ODE_MAX_LAYERS) return xw_ode_fwd_multi_w64_16(jobs, njobs, t, theta, method, L, d, m, zero16, stream);
   return xwg_ode_fwd_multi(jobs, njobs, t, theta, method, L, d, H, K, m, zero16, stream);    // any other width: the generic path
 }
 
@@ -59,7 +60,7 @@ extern "C" int xw_ode_bwd_multi(const XwOdeBwdJob* jobs, int njobs, const double
 #define CALL(HH, KK) if (H == HH && K == KK && m <= XW_ODE_MAX_LAYERS) return xw_ode_bwd_multi_w##HH##_##KK(jobs, njobs, t, theta, method, L, d, m, mode, stream);
   XW_ODE_WIDTHS(CALL)
 #undef CALL
-  if (H == XW_WIDE_H && K == XW_WIDE_K && m <= 9) return xw_ode_bwd_multi_w64_16(jobs, njobs, t, theta, method, L, d, m, mode, stream);
+  if (H == XW_WIDE_H && K == XW_WIDE_K && m <= XW_ODE_MAX_LAYERS) return xw_ode_bwd_multi_w64_16(jobs, njobs, t, theta, method, L, d, m, mode, stream);
   return xwg_ode_bwd_multi(jobs, njobs, t, theta, method, L, d, H, K, m, mode, stream);
 }
 

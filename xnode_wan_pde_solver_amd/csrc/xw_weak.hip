@@ -590,7 +590,7 @@ extern "C" int xw_abi_version(void) { return 31; }
 extern "C" int xw_reduce_work_size(void) { return 6 * 1024 + 8; }
 
 extern "C" int xw_supported_dims(char* buf, int buflen) {
-  static const char s[] = "ode (H,K)=(20,10),(32,12), m=1..10, (64,16), m=1..9 [MFMA]; any other H<=64, K<=16, m<=32 [generic path: vector ALU, slow]; disc_fwd W=50,64,96,128 any q; disc_bwd W=50 (q=9 unrolled, any q from the record), W=64,96,128 (from the record) [MFMA]; any other W<=128, q<=16 [generic path, from the record]; d<=126";
+  static const char s[] = "ode (H,K)=(20,10),(32,12),(64,16), m=1..10 [MFMA]; any other H<=64, K<=16, m<=32 [generic path: vector ALU, slow]; disc_fwd W=50,64,96,128 any q; disc_bwd W=50 (q=9 unrolled, any q from the record), W=64,96,128 (from the record) [MFMA]; any other W<=128, q<=16 [generic path, from the record]; d<=126";
   int i = 0;
   for (; s[i] && i < buflen - 1; ++i) buf[i] = s[i];
   if (buflen > 0) buf[i] = 0;

@@ -191,7 +191,7 @@ class Engine:
             import warnings
             which = ' and '.join(n_ for n_, g_ in zip(('u_theta (u_hidden_dim %d, u_hidden_hidden_dim %d, u_layers %d)' % (self.H, self.K, self.m),
                                                        'v_phi (v_hidden_dim %d)' % self.W), self.generic) if g_)
-            warnings.warn('%s is outside the MFMA kernel instantiations %s (u_layers <= 10, <= 9 at the widest) / %s: running on the generic vector-ALU path, expect a step '
+            warnings.warn('%s is outside the MFMA kernel instantiations %s (u_layers <= 10) / %s: running on the generic vector-ALU path, expect a step '
                           'rate lower by two to three orders of magnitude' % (which, KN.ODE_WIDTHS, KN.DISC_WIDTHS), RuntimeWarning, stacklevel=3)
         # the test network's input layer: spatial columns once per path (xw_disc_xproj) -- the MFMA widths, paths over a shared grid
         # XW_XPROJ_MIN_D: from which d on.  In the sub-step cycle the split form wins from d ~ 45 on and not below, at 131072 points as at

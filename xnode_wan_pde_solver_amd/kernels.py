@@ -66,15 +66,15 @@ def method_id(name):
 # Anything wider runs, at its own widths, on the GENERIC path (csrc/xw_generic.hip: per-path / per-point code on the vector ALU,
 # two to three orders of magnitude slower -- there so that every legal configuration of the reference trains).
 ODE_WIDTHS = [(20, 10), (32, 12), (64, 16)]   # (u_hidden_dim, u_hidden_hidden_dim) containers, smallest first.  (64, 16) (round 6) is the
-                                           # WIDE container: the field on 16x16x4 matrix instructions, one wave per tile (+ a partner in the sweep with weight gradients), depths 1..9
-                                           # (depth 10 there: the C ABI falls through to the generic path at the same widths)
+                                           # WIDE container: the field on 16x16x4 matrix instructions, one wave per tile (+ a partner in the sweep with weight gradients), depths 1..10
+                                           # (deeper fields: the generic path, at the network's own widths)
 DISC_WIDTHS = [50, 64, 96, 128]            # v_hidden_dim containers (W = 50: 3 MFMA row tiles + a 2-row vector tail; 64: 4 tiles;
                                            # 96, 128 (round 6): 6 / 8 tiles, one block per CU, forward + reverse from the record)
 GENERIC_ODE_MAX = (64, 16)                 # csrc/xw_generic.h
 GENERIC_DISC_MAX = 128
 
 
-ODE_WIDE_MAX_DEPTH = 9                     # (64, 16): one 32-bit ReLU-mask word per stage holds 4 (u_layers - 1) bits
+ODE_WIDE_MAX_DEPTH = 10                    # (64, 16): 4 (u_layers - 1) ReLU-mask bits per stage, two words at depth 10
 ODE_MAX_DEPTH = 10                         # the other containers (csrc/xw_common.h XW_ODE_MAX_LAYERS); deeper fields, up to
 GENERIC_ODE_MAX_DEPTH = 32                 # this (csrc/xw_generic.h XWG_MAX_M), run on the generic path at their own widths
 
@@ -83,7 +83,7 @@ def ode_container(H, K, m=1):
     """the widths the stepper kernels run a (u_hidden_dim H, u_hidden_hidden_dim K) network of u_layers = m at"""
     for Hc, Kc in ODE_WIDTHS:
         if m > (ODE_WIDE_MAX_DEPTH if (Hc, Kc) == ODE_WIDTHS[-1] else ODE_MAX_DEPTH):
-            continue                       # (u_layers 10 beyond (32, 12), u_layers > 10 anywhere: the generic path, at the network's own widths)
+            continue                       # (u_layers > 10: the generic path, at the network's own widths)
         if H <= Hc and K <= Kc and lib.xw_theta_size(1, Hc, Kc) > 0 and lib.xw_ode_act_rows(0, Hc, Kc, 1) >= 0:
             return Hc, Kc
     if H <= GENERIC_ODE_MAX[0] and K <= GENERIC_ODE_MAX[1] and m <= GENERIC_ODE_MAX_DEPTH and lib.xw_ode_act_rows(0, H, K, m) >= 0:
