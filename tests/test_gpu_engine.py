@@ -583,16 +583,20 @@ def test_pipelined_loop_flushes_its_last_iteration_when_interrupted(golden_dir, 
         os.chdir(cwd)
 
 
-@pytest.mark.parametrize('name,general,hoist', [('NSphere_TCone', False, False), ('NSphere_THourglass', False, False),
-                                                ('NSphere_TCone', True, False), ('NSphere_THourglass', True, False),
-                                                ('NSphere_THourglass', False, True)])
-def test_group_substep_runner_matches_the_launch_by_launch_path(tmp_path, name, general, hoist, monkeypatch):
+@pytest.mark.parametrize('name,general,hoist,widths', [('NSphere_TCone', False, False, None), ('NSphere_THourglass', False, False, None),
+                                                       ('NSphere_TCone', True, False, None), ('NSphere_THourglass', True, False, None),
+                                                       ('NSphere_THourglass', False, True, None),
+                                                       ('NSphere_THourglass', False, False, (48, 16, 100)),     # (the wide containers)
+                                                       ('NSphere_TCone', True, False, (64, 16, 70))])
+def test_group_substep_runner_matches_the_launch_by_launch_path(tmp_path, name, general, hoist, widths, monkeypatch):
     """xw_substep_gen / xw_substep_disc (one C-ABI call per group sub-step, csrc/xw_substep.hip) against the same chain issued
     launch by launch from engine.py: bit-identical parameters after three outer iterations over all groups of a ball domain
     (single-slice pairwise groups, boundary groups on their own grids, point-mode test network, carried gradients).
     general: non-identity a_ij(t, x) and the linear reaction c = -0.7 u (the A0 table and xw_weak_contract_general inside the call;
     XW_ELEMENTWISE_SINGLE_SLICE semantics are not involved: b = 0 keeps the pairwise groups allowed)
-    hoist: every path-mode group with the x-projection table in front of its test network (XwGroup.xproj), in both forms"""
+    hoist: every path-mode group with the x-projection table in front of its test network (XwGroup.xproj), in both forms
+    widths: other network widths -- the wide containers of round 6 (the stepper's duo sweep on 16x16x4 tiles, the 96- / 128-wide
+    test network) under the group runner"""
     from xnode_wan_pde_solver_amd.options import EngineOptions
     opts = EngineOptions(xproj_min_d=1) if hoist else None
     F = P
@@ -610,6 +614,8 @@ def test_group_substep_runner_matches_the_launch_by_launch_path(tmp_path, name, 
     params = {'alpha': 1e4, 'u_layers': 8, 'u_hidden_dim': 20, 'u_hidden_hidden_dim': 10, 'v_layers': 9, 'v_hidden_dim': 50,
               'n1': 2, 'n2': 1, 'u_rate': 0.015, 'v_rate': 0.04, 'min_steps': 5, 'adjoint': False, 'solver': 'midpoint',
               'dim': 4, 'N_t': 8, 'N_r': 300, 'N_b': 200, 'T0': 0, 'T': 1, 'shape_param': 1.0, 'iterations': 3, 'domain': name}
+    if widths is not None:
+        params.update(u_hidden_dim=widths[0], u_hidden_hidden_dim=widths[1], v_hidden_dim=widths[2])
     out = []
     cwd = os.getcwd()
     os.chdir(tmp_path)
