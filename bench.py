@@ -111,6 +111,24 @@ def main():
     world, local = xdist.init_from_env()
     size = world.size if world is not None else 1
     rank = world.rank if world is not None else 0
+    if size > 1:
+        # N > 1: a rank stuck in a collective (an exchange inside a captured sub-step that never completes, a peer that died without
+        # its exception reaching the launcher) would hang the job until the driver's own clock ends it without a word.  A watchdog
+        # thread ends THIS process loudly instead; the launcher then stops the others and returns non-zero.  (A healthy run of every
+        # workload of this file takes 1 - 2 minutes per rank.)  XW_BENCH_WATCHDOG_S: seconds, 0 disables.
+        import threading
+        limit = float(os.environ.get('XW_BENCH_WATCHDOG_S', '900'))
+
+        def _stuck():
+            sys.stderr.write('bench.py: rank %d of %d made no end within %.0f s -- a collective that never completed? '
+                             '(XW_CAPTURE_EXCHANGE=0 keeps the exchanges out of the captured sub-steps, XW_NATIVE_ALLREDUCE=0 '
+                             'routes them through torch.distributed)\n' % (rank, size, limit))
+            sys.stderr.flush()
+            os._exit(4)
+        if limit > 0:
+            wd = threading.Timer(limit, _stuck)
+            wd.daemon = True
+            wd.start()
     if size != args.gpus:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d' % (args.gpus, size, args.gpus))
     torch.cuda.set_device(local)

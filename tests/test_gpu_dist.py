@@ -247,6 +247,22 @@ def test_bench_rank_that_fails_ends_the_job():
     assert 'XW_BENCH_FAIL_RANK=1' in r.stderr and not [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
 
 
+def test_bench_watchdog_ends_a_job_that_makes_no_progress():
+    """N > 1: a rank that is still running after XW_BENCH_WATCHDOG_S seconds (stuck in a collective) ends its process with a message
+    and code 4; the launcher stops the other rank and returns non-zero (two gloo ranks, a limit of one second)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, XW_DIST_BACKEND='gloo', XW_BENCH_WATCHDOG_S='1')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '3', '--repeats', '1',
+                        '--no-cpu-baseline', '--train-iters', '0', '--n_r', '256', '--n_b', '256'],
+                       env=env, capture_output=True, text=True, timeout=500)
+    assert r.returncode != 0
+    assert 'made no end within 1 s' in r.stderr and not [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+
+
 # ---- list domains (time-varying balls) under a world: groups smaller than the rank count ------------------------------------
 LIST_PARAMS = {'alpha': 1e4, 'u_layers': 8, 'u_hidden_dim': 20, 'u_hidden_hidden_dim': 10, 'v_layers': 9, 'v_hidden_dim': 50,
                'n1': 2, 'n2': 1, 'u_rate': 0.015, 'v_rate': 0.04, 'min_steps': 5, 'adjoint': False, 'solver': 'midpoint',
